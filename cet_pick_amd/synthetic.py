@@ -1,0 +1,83 @@
+"""Synthetic tomograms and seeded weights shared by tests, bench and the golden-vector generator.
+
+SURVEY.md §8(d) defines the synthetic tomogram: fp32 N(0,1) noise plus Gaussian blobs whose
+centres keep a minimum pairwise distance so greedy-NMS results are tie-free.  Stored (Z, H, W),
+i.e. the in-memory order the reference holds after ``load_rec`` (utils/loader.py:27-88).
+"""
+import numpy as np
+
+
+def make_tomo(shape, seed=317, blob_spacing=16, margin_xy=40, margin_z=12, dtype=np.float32):
+    """Return (volume (Z,H,W), centres (n,3) as x,y,z)."""
+    z, h, w = shape
+    rng = np.random.default_rng(seed)
+    vol = rng.standard_normal(shape, dtype=np.float32)
+    n_target = max(1, int(z * h * w / 64 ** 3))
+    mz = min(margin_z, max(0, z // 2 - 1))
+    my = min(margin_xy, max(0, h // 2 - 1))
+    mx = min(margin_xy, max(0, w // 2 - 1))
+    centres = []
+    # jittered grid keeps the pairwise distance >= blob_spacing by construction
+    cell = max(blob_spacing * 2, 32)
+    gz = np.arange(mz, max(mz + 1, z - mz), cell)
+    gy = np.arange(my, max(my + 1, h - my), cell)
+    gx = np.arange(mx, max(mx + 1, w - mx), cell)
+    grid = np.stack(np.meshgrid(gz, gy, gx, indexing="ij"), -1).reshape(-1, 3)
+    rng.shuffle(grid)
+    jit = cell - blob_spacing
+    for cz, cy, cx in grid[:n_target]:
+        dz, dy, dx = rng.integers(0, max(1, jit), size=3)
+        pz = int(min(cz + dz, z - mz - 1)) if z - mz - 1 >= mz else int(cz)
+        py = int(min(cy + dy, h - my - 1)) if h - my - 1 >= my else int(cy)
+        px = int(min(cx + dx, w - mx - 1)) if w - mx - 1 >= mx else int(cx)
+        sigma = float(rng.choice([2.0, 3.0, 4.0]))
+        amp = float(rng.uniform(2.0, 4.0))
+        r = int(4 * sigma)
+        z0, z1 = max(0, pz - r), min(z, pz + r + 1)
+        y0, y1 = max(0, py - r), min(h, py + r + 1)
+        x0, x1 = max(0, px - r), min(w, px + r + 1)
+        zz, yy, xx = np.ogrid[z0:z1, y0:y1, x0:x1]
+        g = np.exp(-((zz - pz) ** 2 + (yy - py) ** 2 + (xx - px) ** 2) / (2 * sigma * sigma))
+        vol[z0:z1, y0:y1, x0:x1] += (amp * g).astype(np.float32)
+        centres.append((px, py, pz))
+    return vol.astype(dtype, copy=False), np.asarray(centres, dtype=np.int32).reshape(-1, 3)
+
+
+def make_logits(shape, seed=317, n_peaks=None):
+    """Synthetic detector logit volume (D,H,W): background ~N(-4,1) with sparse positive peaks."""
+    rng = np.random.default_rng(seed)
+    d, h, w = shape
+    vol = (rng.standard_normal(shape, dtype=np.float32) - 4.0).astype(np.float32)
+    if n_peaks is None:
+        n_peaks = max(4, d * h * w // 4096)
+    flat = rng.choice(d * h * w, size=n_peaks, replace=False)
+    vol.reshape(-1)[flat] = rng.uniform(0.0, 6.0, size=n_peaks).astype(np.float32)
+    return vol
+
+
+def seeded_state_dict(model, seed=317, gain=1.0):
+    """Deterministic O(1)-activation weights for any nn.Module (fan-in scaled normal).
+
+    The reference's default init draws feature_3d/fc/proj weights with std 1e-3
+    (moco_encoder_3d.py:137-154), which leaves BatchNorm dividing by sqrt(eps); parity fixtures use
+    this well-conditioned init instead, regenerated identically in the tests from the seed alone.
+    """
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in model.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            out[k] = torch.zeros_like(v)
+        elif k.endswith("running_mean"):
+            out[k] = torch.randn(v.shape, generator=g) * 0.1
+        elif k.endswith("running_var"):
+            out[k] = torch.rand(v.shape, generator=g) * 0.5 + 0.75
+        elif v.dim() == 1:
+            if k.endswith("bias"):
+                out[k] = torch.randn(v.shape, generator=g) * 0.1
+            else:
+                out[k] = torch.rand(v.shape, generator=g) * 0.5 + 0.75
+        else:
+            fan_in = v[0].numel()
+            out[k] = torch.randn(v.shape, generator=g) * (gain * (2.0 / fan_in) ** 0.5)
+    return out

@@ -1,0 +1,228 @@
+"""Generate golden vectors by IMPORTING the reference (read-only at /root/reference) in the build
+container.  Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+The reference never travels; only the small .npz / .json outputs written next to this script do.
+Inputs are regenerated from seeds by the tests (cet_pick_amd.synthetic), so fixtures hold outputs
+(plus small inputs where they are tiny).
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+# inert stubs for packages the hot functions never touch
+_stub("cv2")
+tv = _stub("torchvision")
+tvt = _stub("torchvision.transforms")
+tvf = _stub("torchvision.transforms.functional", InterpolationMode=type("InterpolationMode", (), {}))
+tv.transforms = tvt
+tvt.functional = tvf
+_stub("skimage")
+_stub("skimage.transform", rescale=None)
+
+from cet_pick.models import decode as R_decode            # noqa: E402
+from cet_pick.models.utils import _sigmoid as R_sigmoid   # noqa: E402
+from cet_pick.utils import image as R_image               # noqa: E402
+from cet_pick.models.networks import moco_encoder_3d as R_enc3d  # noqa: E402
+from cet_pick.models import moco as R_moco                # noqa: E402
+from cet_pick.utils import utils as R_utils               # noqa: E402
+
+from cet_pick_amd.synthetic import make_tomo, make_logits, seeded_state_dict  # noqa: E402
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote", name, os.path.getsize(path) // 1024, "KiB")
+
+
+def gen_decode():
+    logits = make_logits((12, 28, 24), seed=11)
+    x = torch.from_numpy(logits.copy())[None, None]
+    hm = R_sigmoid(x)  # in place
+    out = {"logits": logits, "sigmoid": hm[0, 0].numpy().copy()}
+    for k in (3, 5):
+        out[f"nms_3kk_{k}"] = R_decode._nms(hm, kernel=k)[0, 0].numpy()
+        out[f"nms_xy_{k}"] = R_decode._nms_xy(hm, kernel=k)[0, 0].numpy()
+        out[f"nms_z_{k}"] = R_decode._nms_z(hm, kernel=k)[0, 0].numpy()
+        out[f"nms_kkk_{k}"] = R_image._nms(hm, kernel=k)[0, 0].numpy()
+        out[f"decode_{k}"] = R_decode.tomo_decode(hm, kernel=k, K=50)[0].numpy()
+        out[f"decode_fiber_{k}"] = R_decode.tomo_decode(hm, kernel=k, K=50, if_fiber=True)[0].numpy()
+    s, z, y, xx, inds = R_decode._topk(R_decode._nms(hm, 3), K=40)
+    out.update(topk_scores=s[0, 0].numpy(), topk_z=z[0].numpy(), topk_y=y[0].numpy(),
+               topk_x=xx[0].numpy(), topk_inds=inds[0].numpy())
+    # image.py variant (x = t % h) on H != W
+    s2, z2, y2, x2, i2 = R_image._topk(R_image._nms(hm, 3), K=40)
+    out.update(img_topk_z=z2[0].numpy(), img_topk_y=y2[0].numpy(), img_topk_x=x2[0].numpy())
+    save("decode_small.npz", **out)
+
+
+def gen_greedy():
+    rng = np.random.default_rng(5)
+    vol = rng.standard_normal((14, 20, 22)).astype(np.float32)
+    out = {"vol": vol}
+    for d, thr in ((6, 0.5), (14, 1.0), (4, -np.inf)):
+        s, c = R_image.non_maximum_suppression_3d(vol, d, threshold=thr)
+        out[f"scores_d{d}"] = s
+        out[f"coords_d{d}"] = c
+    s, c = R_decode.non_maximum_suppression_3d(vol.astype(np.float64), 6, scale=1.5, threshold=0.2)
+    out["scores_d6_s15"] = s
+    out["coords_d6_s15"] = c
+    save("greedy_small.npz", **out)
+
+
+def gen_dog():
+    from scipy.ndimage import gaussian_filter
+    shape = (36, 112, 104)
+    vol, centres = make_tomo(shape, seed=317, margin_xy=40, margin_z=12)
+    rec = vol.astype(np.float64)
+    out = {"centres": centres, "shape": np.asarray(shape)}
+    for sig in (2, 3, 5):
+        g = gaussian_filter(rec, sig)
+        out[f"gauss{sig}_z18"] = g[18, ::3].astype(np.float64)
+        out[f"gauss{sig}_z0"] = g[0, ::3].astype(np.float64)
+    for sigmas in ((2, 4), (3, 5), (2, 4, 6)):
+        tag = "_".join(map(str, sigmas))
+        s, c = R_image.get_potential_coords_pyramid(rec.copy(), sigmas=list(sigmas))
+        out[f"scores_{tag}"] = s
+        out[f"coords_{tag}"] = c
+    # float32 input variant (what the GPU path consumes)
+    s, c = R_image.get_potential_coords_pyramid(vol.copy(), sigmas=[3, 5])
+    out["scores_3_5_f32in"] = s
+    out["coords_3_5_f32in"] = c
+    tz, ty, tx = R_image.get_potential_coords(rec.copy(), sigma1=2, sigma2=4, kernel=3, K=64)
+    out.update(gpc_z=tz[0].numpy(), gpc_y=ty[0].numpy(), gpc_x=tx[0].numpy())
+    save("dog_small.npz", **out)
+
+
+HEADS = {"proj": 256, "pred": 256}
+
+
+def _enc():
+    enc = R_enc3d.TomoResClassifier3D(R_enc3d.BasicBlock, [2, 2, 2, 2], HEADS, 0)
+    enc.load_state_dict(seeded_state_dict(enc, seed=317))
+    return enc
+
+
+def gen_enc3d():
+    import contextlib
+    import io
+    enc = _enc()
+    keys = {k: list(v.shape) for k, v in enc.state_dict().items()}
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(4, 1, 32, 32, 32, generator=g)
+    acts = {}
+    hooks = []
+    for name in ("conv1", "bn1", "maxpool", "layer1", "layer2", "layer3", "feature_3d", "fc"):
+        mod = getattr(enc, name)
+        hooks.append(mod.register_forward_hook(
+            lambda m, i, o, name=name: acts.__setitem__(name, o.detach().clone())))
+    enc.train()
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = enc(x)[0]["proj"]
+    loss = (out * torch.linspace(-1, 1, 128)[None]).sum() + (out ** 2).sum() * 0.1
+    loss.backward()
+    res = {"proj_train": out.detach().numpy()}
+    idx = np.random.default_rng(3).integers(0, 2 ** 31, size=256)
+    for k, v in acts.items():
+        f = v.reshape(-1).numpy()
+        res[f"act_{k}_sample"] = f[idx % f.size]
+        res[f"act_{k}_absmean"] = np.asarray(np.abs(f).mean())
+    for k, p in enc.named_parameters():
+        if p.grad is None:
+            continue
+        gf = p.grad.reshape(-1).numpy()
+        res[f"grad_{k}_sample"] = gf[idx % gf.size]
+        res[f"grad_{k}_norm"] = np.asarray(np.linalg.norm(gf.astype(np.float64)))
+    res["bn1_running_mean"] = enc.bn1.running_mean.numpy().copy()
+    res["bn1_running_var"] = enc.bn1.running_var.numpy().copy()
+    res["proj7_running_var"] = enc.proj[7].running_var.numpy().copy()
+    for h in hooks:
+        h.remove()
+    enc2 = _enc()
+    enc2.eval()
+    res["proj_eval"] = enc2.forward_test(x)["proj"].numpy()
+    res["sample_idx"] = idx
+    save("enc3d.npz", **res)
+    with open(os.path.join(HERE, "ckpt_keys.json"), "w") as f:
+        json.dump({"moco3d_encoder": keys,
+                   "proj_is_pred": bool(enc.proj is enc.pred)}, f, indent=1)
+
+
+def gen_moco():
+    """3 MoCo steps, SGD lr 0.05 (moco.py:101-146 restated around the hard-coded .cuda() at :141
+    exactly as SURVEY.md §8c prescribes: the pieces are the reference's own methods)."""
+    import contextlib
+    import io
+    torch.manual_seed(7)
+    q, k = _enc(), _enc()
+    moco = R_moco.MoCo(q, k, dim=128, r=64, m=0.99, T=0.1)
+    g = torch.Generator().manual_seed(123)
+    moco.queue.copy_(torch.nn.functional.normalize(torch.randn(128, 64, generator=g), dim=0))
+    opt = torch.optim.SGD(moco.parameters(), lr=0.05)
+    crit = torch.nn.CrossEntropyLoss()
+    res = {"queue0": moco.queue.numpy().copy()}
+    B = 8
+    for step in range(3):
+        im_q = torch.randn(B, 1, 32, 32, 32, generator=g)
+        im_k = im_q.flip(4) + 0.1 * torch.randn(B, 1, 32, 32, 32, generator=g)
+        with contextlib.redirect_stdout(io.StringIO()):
+            qf = torch.nn.functional.normalize(moco.encoder_q(im_q)[0]["proj"], dim=1)
+            with torch.no_grad():
+                moco._momentum_update_key_encoder()
+                kf = torch.nn.functional.normalize(moco.encoder_k(im_k)[0]["proj"], dim=1)
+        l_pos = torch.einsum("nc,nc->n", [qf, kf]).unsqueeze(-1)
+        l_neg = torch.einsum("nc,ck->nk", [qf, moco.queue.clone().detach()])
+        logits = torch.cat([l_pos, l_neg], dim=1) / moco.T
+        labels = torch.zeros(B, dtype=torch.long)
+        moco._dequeue_and_enqueue(kf)
+        loss = crit(logits, labels)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        res[f"logits_{step}"] = logits.detach().numpy()
+        res[f"loss_{step}"] = np.asarray(loss.item())
+        res[f"ptr_{step}"] = np.asarray(int(moco.queue_ptr))
+    res["queue_final"] = moco.queue.numpy().copy()
+    res["q_fc_weight"] = moco.encoder_q.fc.weight.detach().numpy().copy()
+    res["k_fc_weight"] = moco.encoder_k.fc.weight.detach().numpy().copy()
+    res["q_l1c1_sample"] = moco.encoder_q.layer1[0].conv1.weight.detach().reshape(-1)[::997].numpy().copy()
+    res["k_l1c1_sample"] = moco.encoder_k.layer1[0].conv1.weight.detach().reshape(-1)[::997].numpy().copy()
+    res["state_keys"] = np.asarray(list(moco.state_dict().keys()))
+    save("moco_3steps.npz", **res)
+
+
+def gen_lr():
+    class A:
+        pass
+    rows = []
+    for cosine in (False, True):
+        a = A()
+        a.lr, a.cosine, a.lr_decay_rate, a.num_epochs, a.lr_step = 0.02, cosine, 0.1, 140, [90, 120]
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=a.lr)
+        for ep in (1, 50, 90, 91, 120, 121, 140):
+            R_utils.adjust_learning_rate(a, opt, ep)
+            rows.append((float(cosine), ep, opt.param_groups[0]["lr"]))
+    save("lr_sched.npz", rows=np.asarray(rows, dtype=np.float64))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr"]
+    for w in which:
+        globals()["gen_" + w]()
