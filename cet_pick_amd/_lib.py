@@ -1,0 +1,87 @@
+"""ctypes binding of the C-ABI in include/cetpick_hip.h.
+
+The product path has no CPU fallback: if libcetpick_hip.so is missing or a call fails this module
+raises.  PyTorch is only the owner of device memory and streams here.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcetpick_hip.so")
+
+_c = ctypes
+_P, _I, _F, _Z, _D = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_double
+
+# name -> (restype, argtypes); kept in step with include/cetpick_hip.h (tests/test_abi.py checks)
+SIGNATURES = {
+    "mi_abi_version": (_I, []),
+    "mi_build_arch": (_c.c_char_p, []),
+    "mi_sigmoid_clamp": (_I, [_P, _P, _Z, _P]),
+    "mi_nms3d": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "mi_decode_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "mi_sigmoid_nms_topk": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "mi_gauss3d_sep": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
+    "mi_dog_pick_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "mi_dog_pick": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
+    "mi_greedy_nms3d_workspace_bytes": (_Z, [_I, _I, _I]),
+    "mi_greedy_nms3d": (_I, [_P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _I, _P, _Z, _P]),
+}
+
+_lib = None
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library (loads on first use; raises if it is not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionError(
+                "%s is missing: run `python -m cet_pick_amd.build` (there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "workspace too small", -3: "unsupported"}.get(rc, "hipError %d" % rc)
+        raise HipExtensionError("%s failed: %s" % (what, kind))
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t, name="tensor", dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HipExtensionError("%s must be a tensor on the MI355X (cuda) device; there is no CPU path" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise HipExtensionError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """A cached device scratch buffer of at least nbytes (grown geometrically, never shrunk)."""
+    key = (str(device), tag)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

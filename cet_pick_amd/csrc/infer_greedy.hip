@@ -1,0 +1,548 @@
+// Greedy 3-D ball NMS with the reference's sequential semantics, run in parallel, and the DoG
+// particle-picker pipeline built on it.
+//
+// Replaces (reference, cet_pick/...): models/decode.py:42-79 == utils/image.py:42-79
+// `non_maximum_suppression_3d`, utils/image.py:138-183 `get_potential_coords_pyramid`.
+//
+// The reference visits ALL voxels in descending value order; a voxel is a pick iff no earlier pick
+// has it in its ball (flat-offset ball: i_pick + delta == i, no bounds check).  Only voxels above
+// the threshold can be picks, and a voxel can only be suppressed by a PICK, so the sequential
+// result equals the unique fixed point of
+//      pick(i)  <=>  no higher-priority candidate j with (i - j) in ball is a pick
+// over the candidate set {value > threshold}.  We resolve it in rounds: a candidate is decided as
+// soon as all its higher-priority ball-neighbours are decided.  Priority = (value, flat index),
+// both descending - what a stable ascending argsort reversed yields.
+#include "common.h"
+#include "infer_common.h"
+
+int mi_launch_gauss_axis(const float* in, float* out, int D, int H, int W, int axis, float sigma,
+                         hipStream_t s);
+
+namespace {
+
+constexpr int CAPN = 32;          // stored higher-priority neighbours per candidate
+constexpr int MAX_DELTAS = 36000; // (2*16+1)^3
+
+struct GreedyHeader {
+    unsigned cand_count;     // positive NMS survivors (march kernel)
+    unsigned n;              // candidates above the cutoff
+    unsigned n_kept;
+    unsigned n_deltas;
+    unsigned overflow;       // bit0: candidate buffer overflow, bit1: too many picks for max_out
+    float cutoff;
+    unsigned pad[2];
+};
+
+__device__ __forceinline__ unsigned order_bits(float v) {
+    unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float unorder_bits(unsigned u) {
+    unsigned b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(b);
+}
+
+// ---- cutoff = mean(pos) + 0.5 * std_unbiased(pos)   (utils/image.py:177-179) -------------------
+__global__ void stats_finalize_kernel(const double* partials, int n_part, GreedyHeader* hdr,
+                                      float* cutoff_out) {
+    __shared__ double r[3][256];
+    int tid = threadIdx.x;
+    double a = 0, s = 0, ss = 0;
+    for (int i = tid; i < n_part; i += 256) {   // fixed order -> deterministic
+        a += partials[3 * i]; s += partials[3 * i + 1]; ss += partials[3 * i + 2];
+    }
+    r[0][tid] = a; r[1][tid] = s; r[2][tid] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { r[0][tid] += r[0][tid + o]; r[1][tid] += r[1][tid + o]; r[2][tid] += r[2][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double n = r[0][0], mean = n > 0 ? r[1][0] / n : 0.0;
+        double var = n > 1 ? (r[2][0] - n * mean * mean) / (n - 1.0) : 0.0;
+        if (var < 0) var = 0;
+        float c = (float)(mean + 0.5 * sqrt(var));
+        if (!(n > 0)) c = INFINITY;     // no positive voxel: the reference would raise on mean() of empty
+        hdr->cutoff = c;
+        if (cutoff_out) *cutoff_out = c;
+    }
+}
+
+__global__ void set_cutoff_kernel(GreedyHeader* hdr, float v) { hdr->cutoff = v; }
+
+// ---- ball offsets (decode.py:43-54) ------------------------------------------------------------
+__global__ void build_deltas_kernel(GreedyHeader* hdr, long* deltas, double r, int width, long zs,
+                                    long ys) {
+    __shared__ unsigned cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int side = 2 * width + 1;
+    int total = side * side * side;
+    double r2 = r * r;
+    for (int t = threadIdx.x; t < total; t += blockDim.x) {
+        int a = t / (side * side) - width, b = (t / side) % side - width, c = t % side - width;
+        if ((double)(a * a + b * b + c * c) <= r2) {
+            unsigned slot = atomicAdd(&cnt, 1u);
+            if (slot < MAX_DELTAS) deltas[slot] = (long)a * zs + (long)b * ys + (long)c;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) hdr->n_deltas = min(cnt, (unsigned)MAX_DELTAS);
+}
+
+// ---- dense volume -> candidate list (values > cutoff) ------------------------------------------
+__global__ __launch_bounds__(256) void dense_filter_kernel(const float* vol, size_t n_vox,
+                                                          GreedyHeader* hdr,
+                                                          unsigned long long* G, int* map,
+                                                          unsigned cap) {
+    const float cut = hdr->cutoff;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n_vox; i += stride) {
+        float v = vol[i];
+        if (v > cut) {
+            unsigned slot = atomicAdd(&hdr->n, 1u);
+            if (slot < cap) {
+                G[slot] = ((unsigned long long)order_bits(v) << 32) | (unsigned long long)i;
+                map[i] = (int)slot;
+            } else {
+                atomicOr(&hdr->overflow, 1u);
+            }
+        }
+    }
+}
+
+// ---- sparse candidates (score bits, idx) -> candidate list (values > cutoff) -------------------
+__global__ __launch_bounds__(256) void cand_filter_kernel(const uint2* cands, unsigned cand_cap,
+                                                         GreedyHeader* hdr, unsigned long long* G,
+                                                         int* map, unsigned cap) {
+    const float cut = hdr->cutoff;
+    unsigned total = hdr->cand_count;
+    if (total > cand_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&hdr->overflow, 1u); total = cand_cap; }
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        uint2 c = cands[i];
+        float v = __uint_as_float(c.x);
+        if (v > cut) {
+            unsigned slot = atomicAdd(&hdr->n, 1u);
+            if (slot < cap) {
+                G[slot] = ((unsigned long long)order_bits(v) << 32) | (unsigned long long)c.y;
+                map[c.y] = (int)slot;
+            } else {
+                atomicOr(&hdr->overflow, 1u);
+            }
+        }
+    }
+}
+
+// ---- higher-priority ball neighbours of every candidate (one wave per candidate) ---------------
+__global__ __launch_bounds__(256) void neighbors_kernel(const GreedyHeader* hdr,
+                                                       const unsigned long long* G, const int* map,
+                                                       const long* deltas, long n_vox, unsigned cap,
+                                                       int* nbr, int* nbr_count) {
+    const unsigned n = min(hdr->n, cap);
+    const int nd = (int)hdr->n_deltas;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const unsigned n_waves = (gridDim.x * 256) >> 6;
+    for (unsigned i = wave; i < n; i += n_waves) {
+        const unsigned long long ki = G[i];
+        const long idx = (long)(ki & 0xffffffffull);
+        int count = 0;
+        for (int q0 = 0; q0 < nd; q0 += 64) {
+            int q = q0 + lane;
+            int m = -1;
+            if (q < nd) {
+                long j = idx + deltas[q];
+                if (j >= 0 && j < n_vox) {
+                    int mm = map[j];
+                    if (mm >= 0 && (unsigned)mm != i && G[mm] > ki) m = mm;
+                }
+            }
+            unsigned long long ball = __ballot(m >= 0);
+            if (m >= 0) {
+                int pos = count + __popcll(ball & ((1ull << lane) - 1ull));
+                if (pos < CAPN) nbr[(size_t)i * CAPN + pos] = m;
+            }
+            count += __popcll(ball);
+        }
+        if (lane == 0) nbr_count[i] = count;   // > CAPN -> overflow: re-probe in the rounds
+    }
+}
+
+// ---- rounds: single workgroup, all candidates --------------------------------------------------
+// state: 0 undecided, 1 pick, 2 suppressed
+__device__ __forceinline__ int decide(unsigned i, const unsigned long long* G, const int* map,
+                                      const long* deltas, int nd, long n_vox, const int* nbr,
+                                      const int* nbr_count, const unsigned char* state) {
+    int cnt = nbr_count[i];
+    bool all_decided = true;
+    if (cnt <= CAPN) {
+        for (int q = 0; q < cnt; ++q) {
+            unsigned char st = state[nbr[(size_t)i * CAPN + q]];
+            if (st == 1) return 2;
+            if (st == 0) all_decided = false;
+        }
+    } else {
+        const unsigned long long ki = G[i];
+        const long idx = (long)(ki & 0xffffffffull);
+        for (int q = 0; q < nd; ++q) {
+            long j = idx + deltas[q];
+            if (j < 0 || j >= n_vox) continue;
+            int mm = map[j];
+            if (mm < 0 || (unsigned)mm == i || !(G[mm] > ki)) continue;
+            unsigned char st = state[mm];
+            if (st == 1) return 2;
+            if (st == 0) all_decided = false;
+        }
+    }
+    return all_decided ? 1 : 0;
+}
+
+__global__ __launch_bounds__(1024) void rounds_kernel(GreedyHeader* hdr, const unsigned long long* G,
+                                                      const int* map, const long* deltas, long n_vox,
+                                                      unsigned cap, const int* nbr,
+                                                      const int* nbr_count,
+                                                      volatile unsigned char* state,
+                                                      unsigned* act_a, unsigned* act_b,
+                                                      unsigned long long* kept, unsigned kept_cap) {
+    __shared__ unsigned s_next, s_kept;
+    const int tid = threadIdx.x;
+    const unsigned n = min(hdr->n, cap);
+    const int nd = (int)hdr->n_deltas;
+    if (tid == 0) { s_next = 0; s_kept = 0; }
+    for (unsigned i = tid; i < n; i += 1024) state[i] = 0;
+    __syncthreads();
+    unsigned n_act = n;
+    unsigned* cur = act_a;
+    unsigned* nxt = act_b;
+    bool first = true;
+    while (n_act > 0) {
+        for (unsigned t = tid; t < n_act; t += 1024) {
+            unsigned i = first ? t : cur[t];
+            int d = decide(i, G, map, deltas, nd, n_vox, nbr, nbr_count,
+                           const_cast<const unsigned char*>(state));
+            if (d == 0) {
+                nxt[atomicAdd(&s_next, 1u)] = i;
+            } else {
+                state[i] = (unsigned char)d;
+                if (d == 1) {
+                    unsigned slot = atomicAdd(&s_kept, 1u);
+                    if (slot < kept_cap) kept[slot] = G[i];
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        n_act = s_next;
+        __syncthreads();
+        if (tid == 0) s_next = 0;
+        unsigned* tmp = cur; cur = nxt; nxt = tmp;
+        first = false;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        unsigned k = s_kept;
+        if (k > kept_cap) { atomicOr(&hdr->overflow, 2u); k = kept_cap; }
+        hdr->n_kept = k;
+    }
+}
+
+// ---- sort picks (descending priority) and write outputs ----------------------------------------
+constexpr int SORT_TILE = 8192;   // keys per workgroup in LDS (64 KiB)
+
+// pads kept[n_kept, P) with zero keys, P = pow2 >= max(n_kept, SORT_TILE)
+__global__ void sort_pad_kernel(const GreedyHeader* hdr, unsigned long long* kept, unsigned kept_pow2_cap) {
+    unsigned n = hdr->n_kept;
+    unsigned P = SORT_TILE;
+    while (P < n) P <<= 1;
+    if (P > kept_pow2_cap) P = kept_pow2_cap;
+    for (unsigned i = n + blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) kept[i] = 0ull;
+}
+
+__device__ __forceinline__ unsigned sort_P(const GreedyHeader* hdr, unsigned cap) {
+    unsigned n = hdr->n_kept, P = SORT_TILE;
+    while (P < n) P <<= 1;
+    return min(P, cap);
+}
+
+// all stages with j < SORT_TILE for the given k (k_log2 == 0: full local sort up to SORT_TILE)
+__global__ __launch_bounds__(1024) void sort_local_kernel(const GreedyHeader* hdr,
+                                                          unsigned long long* kept, unsigned cap,
+                                                          unsigned k_global) {
+    __shared__ unsigned long long keys[SORT_TILE];
+    const unsigned P = sort_P(hdr, cap);
+    const unsigned tile0 = blockIdx.x * SORT_TILE;
+    if (tile0 >= P) return;
+    if (k_global != 0 && k_global > P) return;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SORT_TILE; i += 1024) keys[i] = kept[tile0 + i];
+    __syncthreads();
+    if (k_global == 0) {
+        for (unsigned k = 2; k <= SORT_TILE; k <<= 1)
+            for (unsigned j = k >> 1; j > 0; j >>= 1) {
+                for (unsigned t = tid; t < SORT_TILE / 2; t += 1024) {
+                    unsigned i = ((t / j) * (j << 1)) + (t % j), l = i + j;
+                    bool desc = (((tile0 + i) & k) == 0);
+                    unsigned long long a = keys[i], b = keys[l];
+                    if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[l] = a; }
+                }
+                __syncthreads();
+            }
+    } else {
+        const unsigned k = k_global;
+        for (unsigned j = SORT_TILE >> 1; j > 0; j >>= 1) {
+            for (unsigned t = tid; t < SORT_TILE / 2; t += 1024) {
+                unsigned i = ((t / j) * (j << 1)) + (t % j), l = i + j;
+                bool desc = (((tile0 + i) & k) == 0);
+                unsigned long long a = keys[i], b = keys[l];
+                if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < SORT_TILE; i += 1024) kept[tile0 + i] = keys[i];
+}
+
+__global__ void sort_global_step_kernel(const GreedyHeader* hdr, unsigned long long* kept,
+                                        unsigned cap, unsigned k, unsigned j) {
+    const unsigned P = sort_P(hdr, cap);
+    if (k > P) return;
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < P / 2; t += gridDim.x * blockDim.x) {
+        unsigned i = ((t / j) * (j << 1)) + (t % j), l = i + j;
+        bool desc = ((i & k) == 0);
+        unsigned long long a = kept[i], b = kept[l];
+        if (desc ? (a < b) : (a > b)) { kept[i] = b; kept[l] = a; }
+    }
+}
+
+__global__ void emit_picks_kernel(GreedyHeader* hdr, const unsigned long long* kept, int H,
+                                  int W, float* scores, int32_t* coords, int32_t* n_out,
+                                  int max_out, unsigned sorted_pow2) {
+    unsigned n = hdr->n_kept;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n > sorted_pow2) atomicOr(&hdr->overflow, 2u);
+    if (n > (unsigned)max_out) n = (unsigned)max_out;
+    const long hw = (long)H * W;
+    for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        unsigned long long key = kept[r];
+        long idx = (long)(key & 0xffffffffull);
+        scores[r] = unorder_bits((unsigned)(key >> 32));
+        long z = idx / hw, t = idx - z * hw;
+        coords[3 * r + 0] = (int)(t % W);
+        coords[3 * r + 1] = (int)(t / W);
+        coords[3 * r + 2] = (int)z;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int v = (int)n;
+        unsigned ov = hdr->overflow | ((hdr->n_kept > sorted_pow2) ? 2u : 0u);
+        if (ov) v = -(int)ov;   // -1: candidate overflow, -2: pick overflow
+        *n_out = v;
+    }
+}
+
+struct GreedyWs {
+    GreedyHeader* hdr;
+    long* deltas;
+    unsigned long long* G;
+    unsigned long long* kept;
+    int* nbr;
+    int* nbr_count;
+    unsigned char* state;
+    unsigned* act_a;
+    unsigned* act_b;
+    int* map;          // dense, n_vox ints
+    unsigned cap, kept_cap;
+};
+
+// candidate capacity.  DoG picker: every 4th voxel (xy-NMS survivors are at most 1 per 2x2 patch
+// without plateaus).  Dense API: all voxels for small volumes, every 4th above 4 Mi voxels.
+size_t greedy_default_cap(size_t n_vox, bool dense_api) {
+    if (dense_api && n_vox <= (1u << 22)) return n_vox;
+    return n_vox / 4 + 1024;
+}
+
+size_t greedy_ws_layout(size_t n_vox, size_t cap, GreedyWs* w, char* base, bool with_map) {
+    size_t kept_cap = SORT_TILE;
+    while (kept_cap < cap) kept_cap <<= 1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += mi_align_up(bytes, 256); return base ? base + o : nullptr; };
+    char* p;
+    p = take(sizeof(GreedyHeader)); if (w) w->hdr = (GreedyHeader*)p;
+    p = take(sizeof(long) * MAX_DELTAS); if (w) w->deltas = (long*)p;
+    p = take(sizeof(unsigned long long) * cap); if (w) w->G = (unsigned long long*)p;
+    p = take(sizeof(unsigned long long) * kept_cap); if (w) w->kept = (unsigned long long*)p;
+    p = take(sizeof(int) * cap * CAPN); if (w) w->nbr = (int*)p;
+    p = take(sizeof(int) * cap); if (w) w->nbr_count = (int*)p;
+    p = take(cap); if (w) w->state = (unsigned char*)p;
+    p = take(sizeof(unsigned) * cap); if (w) w->act_a = (unsigned*)p;
+    p = take(sizeof(unsigned) * cap); if (w) w->act_b = (unsigned*)p;
+    if (with_map) { p = take(sizeof(int) * n_vox); if (w) w->map = (int*)p; }
+    if (w) { w->cap = (unsigned)cap; w->kept_cap = (unsigned)kept_cap; }
+    return off;
+}
+
+// everything after the candidate list G (and map) is filled: neighbours, rounds, sort, emit
+int greedy_tail(const GreedyWs& w, int D, int H, int W, float d, float scale, float* scores,
+                int32_t* coords, int32_t* n_out, int max_out, hipStream_t s) {
+    const long n_vox = (long)D * H * W;
+    double r = (double)scale * (double)d / 2.0;
+    int width = (int)ceil(r);
+    if (width > 16 || width < 0) return MI_E_UNSUPPORTED;
+    hipLaunchKernelGGL(build_deltas_kernel, dim3(1), dim3(1024), 0, s, w.hdr, w.deltas, r, width,
+                       (long)H * W, (long)W);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(neighbors_kernel, dim3(2048), dim3(256), 0, s, w.hdr, w.G, w.map, w.deltas,
+                       n_vox, w.cap, w.nbr, w.nbr_count);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(rounds_kernel, dim3(1), dim3(1024), 0, s, w.hdr, w.G, w.map, w.deltas, n_vox,
+                       w.cap, w.nbr, w.nbr_count, w.state, w.act_a, w.act_b, w.kept, w.kept_cap);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    // sort: bitonic network over P = pow2 >= n_kept; stages above the picks' P exit at once
+    hipLaunchKernelGGL(sort_pad_kernel, dim3(64), dim3(256), 0, s, w.hdr, w.kept, w.kept_cap);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    // launch only as many stages as max_out can need
+    unsigned Pmax = SORT_TILE;
+    while (Pmax < (unsigned)max_out && Pmax < w.kept_cap) Pmax <<= 1;
+    unsigned tiles = Pmax / SORT_TILE;
+    hipLaunchKernelGGL(sort_local_kernel, dim3(tiles), dim3(1024), 0, s, w.hdr, w.kept, w.kept_cap, 0u);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    for (unsigned k = 2 * SORT_TILE; k <= Pmax; k <<= 1) {
+        for (unsigned j = k >> 1; j >= SORT_TILE; j >>= 1) {
+            hipLaunchKernelGGL(sort_global_step_kernel, dim3(256), dim3(256), 0, s, w.hdr, w.kept,
+                               w.kept_cap, k, j);
+            MI_RETURN_IF_LAUNCH_FAILED();
+        }
+        hipLaunchKernelGGL(sort_local_kernel, dim3(tiles), dim3(1024), 0, s, w.hdr, w.kept, w.kept_cap, k);
+        MI_RETURN_IF_LAUNCH_FAILED();
+    }
+    hipLaunchKernelGGL(emit_picks_kernel, dim3(64), dim3(256), 0, s, w.hdr, w.kept, H, W, scores,
+                       coords, n_out, max_out, Pmax);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mi_greedy_nms3d_workspace_bytes(int D, int H, int W) {
+    size_t n = (size_t)D * H * W;
+    return greedy_ws_layout(n, greedy_default_cap(n, true), nullptr, nullptr, true);
+}
+
+extern "C" int mi_greedy_nms3d(const float* vol, int D, int H, int W, float d, float scale,
+                               float threshold, float* scores, int32_t* coords, int32_t* n_out,
+                               int max_out, void* workspace, size_t workspace_bytes,
+                               mi_stream_t stream) {
+    if (!vol || !scores || !coords || !n_out || !workspace || max_out <= 0) return MI_E_ARG;
+    if (D <= 0 || H <= 0 || W <= 0) return MI_E_ARG;
+    size_t n_vox = (size_t)D * H * W;
+    if (n_vox >= (1ull << 31)) return MI_E_UNSUPPORTED;
+    if (workspace_bytes < mi_greedy_nms3d_workspace_bytes(D, H, W)) return MI_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    GreedyWs w;
+    greedy_ws_layout(n_vox, greedy_default_cap(n_vox, true), &w, (char*)workspace, true);
+    MI_HIP(hipMemsetAsync(w.hdr, 0, sizeof(GreedyHeader), s));
+    MI_HIP(hipMemsetAsync(w.map, 0xff, sizeof(int) * n_vox, s));
+    hipLaunchKernelGGL(set_cutoff_kernel, dim3(1), dim3(1), 0, s, w.hdr, threshold);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    int blocks = (int)std::min<size_t>((n_vox + 255) / 256, 4096);
+    hipLaunchKernelGGL(dense_filter_kernel, dim3(blocks), dim3(256), 0, s, vol, n_vox, w.hdr, w.G,
+                       w.map, w.cap);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return greedy_tail(w, D, H, W, d, scale, scores, coords, n_out, max_out, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// DoG particle picker
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct DogWs {
+    float* g[2];
+    float* tmp;
+    float* heat;
+    uint2* cands;
+    double* stats;
+    unsigned cand_cap;
+    size_t n_stats;
+    GreedyWs gw;
+};
+
+size_t dog_ws_layout(int D, int H, int W, DogWs* w, char* base) {
+    size_t n_vox = (size_t)D * H * W;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += mi_align_up(bytes, 256); return base ? base + o : nullptr; };
+    char* p;
+    p = take(sizeof(float) * n_vox); if (w) w->g[0] = (float*)p;
+    p = take(sizeof(float) * n_vox); if (w) w->g[1] = (float*)p;
+    p = take(sizeof(float) * n_vox); if (w) w->tmp = (float*)p;
+    p = take(sizeof(float) * n_vox); if (w) w->heat = (float*)p;
+    size_t cand_cap = n_vox / 4 + 1024;
+    p = take(sizeof(uint2) * cand_cap); if (w) { w->cands = (uint2*)p; w->cand_cap = (unsigned)cand_cap; }
+    int zc;
+    dim3 grid = mi_march_grid(D, H, W, &zc);
+    size_t n_stats = (size_t)grid.x * grid.y * grid.z;
+    p = take(sizeof(double) * 3 * n_stats); if (w) { w->stats = (double*)p; w->n_stats = n_stats; }
+    // the dense candidate map reuses a Gaussian buffer (free once the last DoG level is consumed)
+    off += greedy_ws_layout(n_vox, greedy_default_cap(n_vox, false), w ? &w->gw : nullptr, base ? base + off : nullptr, false);
+    return off;
+}
+}  // namespace
+
+extern "C" size_t mi_dog_pick_workspace_bytes(int D, int H, int W, int n_sigmas) {
+    (void)n_sigmas;
+    return dog_ws_layout(D, H, W, nullptr, nullptr);
+}
+
+extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* sigmas_host,
+                           int n_sigmas, int k, int border_z, int nms_d, float* heat_out,
+                           float* scores, int32_t* coords, int32_t* n_out, int max_out,
+                           float* cutoff_out, void* workspace, size_t workspace_bytes,
+                           mi_stream_t stream) {
+    if (!rec || !sigmas_host || n_sigmas < 2 || !scores || !coords || !n_out || !workspace) return MI_E_ARG;
+    if (D <= 0 || H <= 0 || W <= 0 || max_out <= 0 || border_z < 0) return MI_E_ARG;
+    size_t n_vox = (size_t)D * H * W;
+    if (n_vox >= (1ull << 31)) return MI_E_UNSUPPORTED;
+    if (workspace_bytes < mi_dog_pick_workspace_bytes(D, H, W, n_sigmas)) return MI_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    DogWs w;
+    dog_ws_layout(D, H, W, &w, (char*)workspace);
+    GreedyWs& gw = w.gw;
+    MI_HIP(hipMemsetAsync(gw.hdr, 0, sizeof(GreedyHeader), s));
+
+    // utils/image.py:141-143: 30-voxel xy border, doubled when both H and W exceed 512
+    int bxy = (H > 512 && W > 512) ? 60 : 30;
+    auto gauss = [&](float sigma, float* dst) -> int {
+        int rc;
+        if ((rc = mi_launch_gauss_axis(rec, dst, D, H, W, 0, sigma, s))) return rc;
+        if ((rc = mi_launch_gauss_axis(dst, w.tmp, D, H, W, 1, sigma, s))) return rc;
+        return mi_launch_gauss_axis(w.tmp, dst, D, H, W, 2, sigma, s);
+    };
+    int rc;
+    int cur = 0;
+    if ((rc = gauss(sigmas_host[0], w.g[cur]))) return rc;
+    float* dense = heat_out ? heat_out : ((n_sigmas > 2) ? w.heat : nullptr);
+    for (int i = 1; i < n_sigmas; ++i) {
+        int nxt = cur ^ 1;
+        if ((rc = gauss(sigmas_host[i], w.g[nxt]))) return rc;
+        const bool last = (i == n_sigmas - 1);
+        MarchParams p = {};
+        p.in = w.g[cur]; p.in2 = w.g[nxt]; p.mode = MI_LOAD_DOG;
+        p.nms_out = dense; p.accumulate = (i > 1);
+        p.D = D; p.H = H; p.W = W;
+        p.bz = border_z; p.by = bxy; p.bx = bxy;
+        if (last) {
+            p.cands = w.cands; p.cand_count = &gw.hdr->cand_count; p.cand_cap = w.cand_cap;
+            p.stats = w.stats;
+        }
+        if ((rc = mi_launch_march(p, 1, k, s))) return rc;
+        cur = nxt;
+    }
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(256), 0, s, w.stats, (int)w.n_stats,
+                       gw.hdr, cutoff_out);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    // dense candidate-id map in the Gaussian buffer that is no longer needed
+    gw.map = reinterpret_cast<int*>(w.g[cur ^ 1]);
+    MI_HIP(hipMemsetAsync(gw.map, 0xff, sizeof(int) * n_vox, s));
+    hipLaunchKernelGGL(cand_filter_kernel, dim3(512), dim3(256), 0, s, w.cands, w.cand_cap, gw.hdr,
+                       gw.G, gw.map, gw.cap);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return greedy_tail(gw, D, H, W, (float)nms_d, 1.0f, scores, coords, n_out, max_out, s);
+}

@@ -1,0 +1,541 @@
+// Pooled 3-D NMS as a z-marching stencil, fused with the value producer (plain / sigmoid+clamp /
+// DoG+border) and with candidate compaction + score histogram; top-K selection kernels.
+//
+// Replaces (reference, cet_pick/...): models/utils.py:167-169 `_sigmoid`, models/decode.py:11-33
+// `_nms_xy/_nms_z/_nms`, utils/image.py:81-105 (same + k*k*k `_nms`), models/decode.py:82-92 `_topk`,
+// models/decode.py:123-155 `tomo_decode`.
+//
+// HBM-bound: one read of the input plane tile (+halo from L2) and at most one write per voxel.
+// Layout: a 256-thread workgroup owns a 16(y) x 64(x) column of the volume and marches over a
+// z-chunk; the current plane (with xy halo) sits in LDS (double buffered, one barrier per plane),
+// the z-window lives in registers.  Each thread owns 4 consecutive x (16-B loads/stores).
+#include "common.h"
+#include "infer_common.h"
+
+namespace {
+
+constexpr int TY = 16, TX = 64, NT = 256;
+constexpr int LW = TX + 8;          // LDS row stride: tile centre starts at col 4 (16-B aligned)
+constexpr int CAND_LDS = 2048;      // per-block candidate staging (flushed above 1024)
+
+template <int KXY>
+struct PlaneBuf {
+    static constexpr int PXY = KXY / 2;
+    static constexpr int LH = TY + 2 * PXY;
+    float v[2][LH][LW];
+};
+
+__device__ __forceinline__ float produce(const MarchParams& p, long idx, int z, int y, int x) {
+    if (p.mode == MI_LOAD_SIGMOID) {
+        float v = p.in[idx];
+        float s = 1.0f / (1.0f + expf(-v));
+        return fminf(fmaxf(s, 1e-4f), 1.0f - 1e-4f);
+    } else if (p.mode == MI_LOAD_DOG) {
+        bool border = (z < p.bz) | (z >= p.D - p.bz) | (y < p.by) | (y >= p.H - p.by) |
+                      (x < p.bx) | (x >= p.W - p.bx);
+        return border ? 0.0f : (p.in2[idx] - p.in[idx]);
+    }
+    return p.in[idx];
+}
+
+template <int KZ, int KXY>
+__global__ __launch_bounds__(NT) void nms_march_kernel(MarchParams p) {
+    constexpr int PZ = KZ / 2, PXY = KXY / 2;
+    constexpr int LH = TY + 2 * PXY;
+    constexpr int HW_ = TX + 2 * PXY;                       // halo-inclusive tile width
+    constexpr int N_TOPBOT = 2 * PXY * HW_;
+    constexpr int N_HALO = N_TOPBOT + TY * 2 * PXY;
+    constexpr int NCOL = 4 + 2 * PXY;
+
+    __shared__ __attribute__((aligned(16))) float plane[2][LH][LW];
+    __shared__ uint2 cbuf[CAND_LDS];
+    __shared__ unsigned lhist[MI_HIST_BINS];
+    __shared__ unsigned s_ccount, s_cbase;
+    __shared__ double s_red[3][NT / 64];
+
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int xt0 = blockIdx.x * TX, yt0 = blockIdx.y * TY;
+    const int z0 = blockIdx.z * p.zchunk;
+    const int zend = min(z0 + p.zchunk, p.D);
+    const int x0 = xt0 + 4 * tx, y = yt0 + ty;
+    const long HW = (long)p.H * p.W;
+    const bool row_ok = y < p.H;
+    const bool vec_ok = p.vec_ok && (x0 + 3 < p.W);
+    const bool emit = p.cands != nullptr;
+
+    if (tid == 0) s_ccount = 0;
+    if (p.hist) for (int i = tid; i < MI_HIST_BINS; i += NT) lhist[i] = 0;
+
+    const float NEG = -INFINITY;
+    float ringM[KZ][4];       // xy-pooled planes (fiber: xy-NMS'd values)
+    float ringC[PZ + 1][4];   // plane centres (newest last)
+#pragma unroll
+    for (int k = 0; k < KZ; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ringM[k][i] = NEG;
+#pragma unroll
+    for (int k = 0; k <= PZ; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ringC[k][i] = 0.f;
+
+    double st_n = 0, st_s = 0, st_ss = 0;
+    __syncthreads();
+
+    int it = 0;
+    for (int zz = z0 - PZ; zz < zend + PZ; ++zz, ++it) {
+        const int b = it & 1;
+        const bool plane_in = (zz >= 0) && (zz < p.D);
+        float c[4] = {NEG, NEG, NEG, NEG};
+        if (plane_in) {
+            // ---- stage the plane tile (+halo) into LDS
+            const long base = (long)zz * HW + (long)y * p.W + x0;
+            if (row_ok) {
+                if (vec_ok) {
+                    if (p.mode == MI_LOAD_PLAIN) {
+                        float4 v = *reinterpret_cast<const float4*>(p.in + base);
+                        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+                    } else if (p.mode == MI_LOAD_SIGMOID) {
+                        float4 v = *reinterpret_cast<const float4*>(p.in + base);
+                        float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float s = 1.0f / (1.0f + expf(-t[i]));
+                            c[i] = fminf(fmaxf(s, 1e-4f), 1.0f - 1e-4f);
+                        }
+                    } else {
+                        float4 a = *reinterpret_cast<const float4*>(p.in + base);
+                        float4 g = *reinterpret_cast<const float4*>(p.in2 + base);
+                        float t[4] = {g.x - a.x, g.y - a.y, g.z - a.z, g.w - a.w};
+                        bool zb = (zz < p.bz) | (zz >= p.D - p.bz) | (y < p.by) | (y >= p.H - p.by);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            int x = x0 + i;
+                            c[i] = (zb | (x < p.bx) | (x >= p.W - p.bx)) ? 0.f : t[i];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (x0 + i < p.W) c[i] = produce(p, base + i, zz, y, x0 + i);
+                }
+            }
+            *reinterpret_cast<float4*>(&plane[b][ty + PXY][4 + 4 * tx]) = make_float4(c[0], c[1], c[2], c[3]);
+            if (PXY > 0) {
+                for (int h = tid; h < N_HALO; h += NT) {
+                    int row, col;
+                    if (h < N_TOPBOT) {
+                        int r = h / HW_;
+                        col = h - r * HW_;
+                        row = (r < PXY) ? r : (TY + r);
+                    } else {
+                        int hh = h - N_TOPBOT;
+                        int r = hh / (2 * PXY);
+                        int cc = hh - r * (2 * PXY);
+                        row = PXY + r;
+                        col = (cc < PXY) ? cc : (TX + cc);
+                    }
+                    int gy = yt0 - PXY + row, gx = xt0 - PXY + col;
+                    float v = NEG;
+                    if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                        v = produce(p, (long)zz * HW + (long)gy * p.W + gx, zz, gy, gx);
+                    plane[b][row][col + 4 - PXY] = v;
+                }
+            }
+            // pre-NMS value (sigmoid heat-map) is an output of the fused decode
+            if (p.val_out && zz >= z0 && zz < zend && row_ok) {
+                if (vec_ok) {
+                    *reinterpret_cast<float4*>(p.val_out + base) = make_float4(c[0], c[1], c[2], c[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (x0 + i < p.W) p.val_out[base + i] = c[i];
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- flush the candidate staging buffer when it could overflow during this plane
+        if (emit && s_ccount >= 1024) {
+            unsigned cnt = s_ccount;
+            if (tid == 0) s_cbase = atomicAdd(p.cand_count, cnt);
+            __syncthreads();
+            unsigned cb = s_cbase;
+            for (unsigned i = tid; i < cnt; i += NT)
+                if (cb + i < p.cand_cap) p.cands[cb + i] = cbuf[i];
+            __syncthreads();
+            if (tid == 0) s_ccount = 0;
+            __syncthreads();
+        }
+
+        // ---- xy pooling of this plane from LDS
+        float m[4] = {NEG, NEG, NEG, NEG};
+        if (plane_in) {
+            float colmax[NCOL];
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) colmax[j] = NEG;
+#pragma unroll
+            for (int dy = 0; dy < KXY; ++dy) {
+                const float* row = &plane[b][ty + dy][0];
+                float4 cv = *reinterpret_cast<const float4*>(row + 4 + 4 * tx);
+                colmax[PXY + 0] = fmaxf(colmax[PXY + 0], cv.x);
+                colmax[PXY + 1] = fmaxf(colmax[PXY + 1], cv.y);
+                colmax[PXY + 2] = fmaxf(colmax[PXY + 2], cv.z);
+                colmax[PXY + 3] = fmaxf(colmax[PXY + 3], cv.w);
+#pragma unroll
+                for (int j = 0; j < PXY; ++j) {
+                    colmax[j] = fmaxf(colmax[j], row[4 + 4 * tx - PXY + j]);
+                    colmax[PXY + 4 + j] = fmaxf(colmax[PXY + 4 + j], row[4 + 4 * tx + 4 + j]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int dx = 0; dx < KXY; ++dx) m[i] = fmaxf(m[i], colmax[i + dx]);
+            if (p.fiber) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m[i] = (m[i] == c[i]) ? c[i] : 0.f;
+            }
+        }
+        // ---- shift the z window
+#pragma unroll
+        for (int k = 0; k + 1 < KZ; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ringM[k][i] = ringM[k + 1][i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ringM[KZ - 1][i] = m[i];
+#pragma unroll
+        for (int k = 0; k < PZ; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ringC[k][i] = ringC[k + 1][i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ringC[PZ][i] = c[i];
+
+        // ---- emit plane zo = zz - PZ
+        const int zo = zz - PZ;
+        if (zo >= z0 && zo < zend && row_ok) {
+            const long obase = (long)zo * HW + (long)y * p.W + x0;
+            float out[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float hm = ringM[0][i];
+#pragma unroll
+                for (int k = 1; k < KZ; ++k) hm = fmaxf(hm, ringM[k][i]);
+                float cc = p.fiber ? ringM[PZ][i] : ringC[0][i];
+                out[i] = (hm == cc) ? cc : 0.f;
+            }
+            if (p.accumulate && p.nms_out) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (x0 + i < p.W) out[i] = fmaxf(out[i], p.nms_out[obase + i]);
+            }
+            if (p.nms_out) {
+                if (vec_ok) {
+                    *reinterpret_cast<float4*>(p.nms_out + obase) = make_float4(out[0], out[1], out[2], out[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (x0 + i < p.W) p.nms_out[obase + i] = out[i];
+                }
+            }
+            if (emit || p.stats) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (x0 + i < p.W && out[i] > 0.f) {
+                        if (emit) {
+                            unsigned bits = __float_as_uint(out[i]);
+                            unsigned slot = atomicAdd(&s_ccount, 1u);
+                            cbuf[slot] = make_uint2(bits, (unsigned)(obase + i));
+                            if (p.hist) atomicAdd(&lhist[bits >> MI_HIST_SHIFT], 1u);
+                        }
+                        double dv = (double)out[i];
+                        st_n += 1.0; st_s += dv; st_ss += dv * dv;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (emit) {
+        unsigned cnt = s_ccount;
+        if (cnt > 0) {
+            if (tid == 0) s_cbase = atomicAdd(p.cand_count, cnt);
+            __syncthreads();
+            unsigned cb = s_cbase;
+            for (unsigned i = tid; i < cnt; i += NT)
+                if (cb + i < p.cand_cap) p.cands[cb + i] = cbuf[i];
+        }
+        if (p.hist)
+            for (int i = tid; i < MI_HIST_BINS; i += NT) {
+                unsigned hcount = lhist[i];
+                if (hcount) atomicAdd(&p.hist[i], hcount);
+            }
+    }
+    if (p.stats) {
+        double a = wave_sum(st_n), s = wave_sum(st_s), ss = wave_sum(st_ss);
+        if ((tid & 63) == 0) { s_red[0][tid >> 6] = a; s_red[1][tid >> 6] = s; s_red[2][tid >> 6] = ss; }
+        __syncthreads();
+        if (tid == 0) {
+            double A = 0, S = 0, SS = 0;
+            for (int w = 0; w < NT / 64; ++w) { A += s_red[0][w]; S += s_red[1][w]; SS += s_red[2][w]; }
+            long bid = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            p.stats[3 * bid + 0] = A; p.stats[3 * bid + 1] = S; p.stats[3 * bid + 2] = SS;
+        }
+    }
+}
+
+template <int KZ>
+int launch_kxy(const MarchParams& p, int kxy, dim3 grid, hipStream_t s) {
+    switch (kxy) {
+        case 1: hipLaunchKernelGGL((nms_march_kernel<KZ, 1>), grid, dim3(NT), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((nms_march_kernel<KZ, 3>), grid, dim3(NT), 0, s, p); break;
+        case 5: hipLaunchKernelGGL((nms_march_kernel<KZ, 5>), grid, dim3(NT), 0, s, p); break;
+        case 7: hipLaunchKernelGGL((nms_march_kernel<KZ, 7>), grid, dim3(NT), 0, s, p); break;
+        default: return MI_E_ARG;
+    }
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+__global__ void sigmoid_clamp_kernel(float* x, float* y, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float s = 1.0f / (1.0f + expf(-x[i]));
+        x[i] = s;
+        y[i] = fminf(fmaxf(s, 1e-4f), 1.0f - 1e-4f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// top-K: histogram threshold -> filter -> single-block sort + emit
+// ---------------------------------------------------------------------------------------------
+__device__ int hist_threshold_bin(const unsigned* hist, int K, unsigned* s_scan /*256*/, int tid) {
+    // 256 threads, 8 bins each; returns the highest bin T with count(bins >= T) >= K (0 if none)
+    constexpr int PER = MI_HIST_BINS / 256;
+    unsigned mine = 0;
+    for (int b = 0; b < PER; ++b) mine += hist[tid * PER + b];
+    s_scan[tid] = mine;
+    __syncthreads();
+    // suffix sum (inclusive) by Hillis-Steele
+    for (int off = 1; off < 256; off <<= 1) {
+        unsigned v = (tid + off < 256) ? s_scan[tid + off] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    __shared__ int s_T;
+    if (tid == 0) s_T = 0;
+    __syncthreads();
+    unsigned incl = s_scan[tid];
+    unsigned above = (tid + 1 < 256) ? s_scan[tid + 1] : 0u;
+    if (incl >= (unsigned)K && above < (unsigned)K) {
+        unsigned acc = above;
+        int T = tid * PER;
+        for (int b = PER - 1; b >= 0; --b) {
+            acc += hist[tid * PER + b];
+            if (acc >= (unsigned)K) { T = tid * PER + b; break; }
+        }
+        s_T = T;
+    }
+    __syncthreads();
+    return s_T;
+}
+
+__global__ __launch_bounds__(256) void topk_filter_kernel(const uint2* cands, DecodeHeader* hdr,
+                                                         unsigned cand_cap, uint2* sel,
+                                                         unsigned sel_cap, int K) {
+    __shared__ unsigned s_scan[256];
+    const int tid = threadIdx.x;
+    int T = hist_threshold_bin(hdr->hist, K, s_scan, tid);
+    unsigned n = min(hdr->cand_count, cand_cap);
+    for (unsigned i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+        uint2 c = cands[i];
+        if ((int)(c.x >> MI_HIST_SHIFT) >= T) {
+            unsigned slot = atomicAdd(&hdr->sel_count, 1u);
+            if (slot < sel_cap) sel[slot] = c;
+        }
+    }
+}
+
+__device__ __forceinline__ void emit_det(float* dets, int r, unsigned long long key, int H, int W,
+                                         bool valid) {
+    float* o = dets + 5 * (long)r;
+    if (!valid) { o[0] = 0.25f; o[1] = 0.25f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f; return; }
+    float score = __uint_as_float((unsigned)(key >> 32));
+    unsigned idx = ~(unsigned)(key & 0xffffffffu);
+    // `_convert_1d_to_3d` (decode.py:35-41): float32 division, then integer remainder
+    int hw = H * W;
+    int z = (int)floorf(__fdiv_rn((float)idx, (float)hw));
+    int t = (int)idx - z * hw;
+    float yf = floorf(__fdiv_rn((float)t, (float)W));
+    int x = t % W;
+    if (x < 0) x += W;
+    o[0] = (float)x + 0.25f; o[1] = yf + 0.25f; o[2] = (float)z; o[3] = score; o[4] = score;
+}
+
+// Single block.  Fast path: the filtered set fits LDS -> bitonic sort.  Slow path (degenerate
+// plateaus): exact 64-bit radix select over the whole candidate list, then sort the survivors.
+__global__ __launch_bounds__(1024) void topk_final_kernel(const uint2* cands, DecodeHeader* hdr,
+                                                          unsigned cand_cap, const uint2* sel,
+                                                          int K, int H, int W, float* dets,
+                                                          int* n_valid_out) {
+    extern __shared__ unsigned long long keys[];   // MI_SEL_CAP entries
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned s_remaining, s_n;
+    const int tid = threadIdx.x;
+    unsigned n_sel = hdr->sel_count;
+    unsigned n_cand = min(hdr->cand_count, cand_cap);
+    int n = 0;
+    if (n_sel <= MI_SEL_CAP) {
+        n = (int)n_sel;
+        for (int i = tid; i < n; i += 1024) {
+            uint2 c = sel[i];
+            keys[i] = ((unsigned long long)c.x << 32) | (unsigned long long)(~c.y);
+        }
+    } else {
+        // exact select of the K-th largest key among cands (keys are unique: idx is unique)
+        if (tid == 0) { s_prefix = 0ull; s_remaining = (unsigned)K; }
+        __syncthreads();
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            if (tid < 256) s_hist[tid] = 0;
+            __syncthreads();
+            unsigned long long prefix = s_prefix;
+            unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
+            for (unsigned i = tid; i < n_cand; i += 1024) {
+                uint2 c = cands[i];
+                unsigned long long k = ((unsigned long long)c.x << 32) | (unsigned long long)(~c.y);
+                if ((k & himask) == prefix) atomicAdd(&s_hist[(unsigned)(k >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned rem = s_remaining, acc = 0;
+                int d = 255;
+                for (; d > 0; --d) {
+                    if (acc + s_hist[d] >= rem) break;
+                    acc += s_hist[d];
+                }
+                s_remaining = rem - acc;
+                s_prefix = prefix | ((unsigned long long)d << shift);
+            }
+            __syncthreads();
+        }
+        unsigned long long thr = s_prefix;   // K-th largest key (or smallest key if fewer than K)
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        for (unsigned i = tid; i < n_cand; i += 1024) {
+            uint2 c = cands[i];
+            unsigned long long k = ((unsigned long long)c.x << 32) | (unsigned long long)(~c.y);
+            if (k >= thr) {
+                unsigned slot = atomicAdd(&s_n, 1u);
+                if (slot < MI_SEL_CAP) keys[slot] = k;
+            }
+        }
+        __syncthreads();
+        n = (int)min(s_n, (unsigned)MI_SEL_CAP);
+    }
+    int P = 1024;
+    while (P < n) P <<= 1;
+    for (int i = n + tid; i < P; i += 1024) keys[i] = 0ull;
+    block_bitonic_sort_desc(keys, P, tid, 1024);
+    int n_valid = min(n, K);
+    for (int r = tid; r < K; r += 1024) emit_det(dets, r, r < n_valid ? keys[r] : 0ull, H, W, r < n_valid);
+    if (tid == 0 && n_valid_out) *n_valid_out = n_valid;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+int mi_launch_march(MarchParams p, int kz, int kxy, hipStream_t s) {
+    if (p.D <= 0 || p.H <= 0 || p.W <= 0) return MI_E_ARG;
+    if (!(kz == 1 || kz == 3 || kz == 5 || kz == 7)) return MI_E_ARG;
+    p.vec_ok = ((p.W & 3) == 0) && (((uintptr_t)p.in & 15) == 0) &&
+               (p.in2 == nullptr || ((uintptr_t)p.in2 & 15) == 0) &&
+               (p.val_out == nullptr || ((uintptr_t)p.val_out & 15) == 0) &&
+               (p.nms_out == nullptr || ((uintptr_t)p.nms_out & 15) == 0);
+    dim3 grid = mi_march_grid(p.D, p.H, p.W, &p.zchunk);
+    switch (kz) {
+        case 1: return launch_kxy<1>(p, kxy, grid, s);
+        case 3: return launch_kxy<3>(p, kxy, grid, s);
+        case 5: return launch_kxy<5>(p, kxy, grid, s);
+        default: return launch_kxy<7>(p, kxy, grid, s);
+    }
+}
+
+dim3 mi_march_grid(int D, int H, int W, int* zchunk_out) {
+    int gx = mi_cdiv(W, TX), gy = mi_cdiv(H, TY);
+    // enough z-chunks to put >= ~2048 workgroups on the chip, but chunks of >= 8 planes
+    int zc = D;
+    long tiles = (long)gx * gy;
+    while (zc > 8 && tiles * mi_cdiv(D, zc) < 2048) zc = (zc + 1) / 2;
+    if (zc < 1) zc = 1;
+    *zchunk_out = zc;
+    return dim3(gx, gy, mi_cdiv(D, zc));
+}
+
+extern "C" int mi_sigmoid_clamp(float* x, float* y, size_t n, mi_stream_t stream) {
+    if (!x || !y) return MI_E_ARG;
+    if (n == 0) return MI_OK;
+    int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(sigmoid_clamp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_nms3d(const float* heat, float* out, int D, int H, int W, int kd, int kh,
+                        mi_stream_t stream) {
+    if (!heat || !out || heat == out) return MI_E_ARG;
+    MarchParams p = {};
+    p.in = heat; p.nms_out = out; p.mode = MI_LOAD_PLAIN;
+    p.D = D; p.H = H; p.W = W;
+    return mi_launch_march(p, kd, kh, (hipStream_t)stream);
+}
+
+extern "C" size_t mi_decode_workspace_bytes(int D, int H, int W, int K) {
+    (void)K;
+    size_t n = (size_t)D * H * W;
+    return mi_align_up(sizeof(DecodeHeader), 256) + mi_align_up(n * sizeof(uint2), 256) +
+           mi_align_up((size_t)MI_SEL_CAP * sizeof(uint2), 256);
+}
+
+extern "C" int mi_sigmoid_nms_topk(const float* logits, float* heat_out, int D, int H, int W,
+                                   int k, int fiber, int apply_sigmoid, int K, float* dets,
+                                   int32_t* n_valid_out, void* workspace, size_t workspace_bytes,
+                                   mi_stream_t stream) {
+    if (!logits || !dets || !workspace || K <= 0 || K > MI_SEL_CAP) return MI_E_ARG;
+    if (heat_out == logits) return MI_E_ARG;
+    if ((size_t)D * H * W >= (1ull << 32)) return MI_E_UNSUPPORTED;
+    if (workspace_bytes < mi_decode_workspace_bytes(D, H, W, K)) return MI_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    size_t n = (size_t)D * H * W;
+    char* w = (char*)workspace;
+    DecodeHeader* hdr = (DecodeHeader*)w;
+    w += mi_align_up(sizeof(DecodeHeader), 256);
+    uint2* cands = (uint2*)w;
+    w += mi_align_up(n * sizeof(uint2), 256);
+    uint2* sel = (uint2*)w;
+    MI_HIP(hipMemsetAsync(hdr, 0, sizeof(DecodeHeader), s));
+
+    MarchParams p = {};
+    p.in = logits; p.val_out = apply_sigmoid ? heat_out : nullptr;
+    p.mode = apply_sigmoid ? MI_LOAD_SIGMOID : MI_LOAD_PLAIN;
+    p.D = D; p.H = H; p.W = W; p.fiber = fiber ? 1 : 0;
+    p.cands = cands; p.cand_count = &hdr->cand_count; p.cand_cap = (unsigned)n; p.hist = hdr->hist;
+    int rc = mi_launch_march(p, fiber ? k : 3, k, s);
+    if (rc) return rc;
+    int fblocks = (int)std::min<size_t>((n / 64 + 255) / 256 + 1, 512);
+    hipLaunchKernelGGL(topk_filter_kernel, dim3(fblocks), dim3(256), 0, s, cands, hdr, (unsigned)n,
+                       sel, (unsigned)MI_SEL_CAP, K);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    // 128 KiB of dynamic LDS for the single-workgroup sorter (above the 64 KiB default limit)
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_final_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(MI_SEL_CAP * sizeof(unsigned long long))));
+    hipLaunchKernelGGL(topk_final_kernel, dim3(1), dim3(1024), MI_SEL_CAP * sizeof(unsigned long long),
+                       s, cands, hdr, (unsigned)n, sel, K, H, W, dets, (int*)n_valid_out);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}

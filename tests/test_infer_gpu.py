@@ -1,0 +1,198 @@
+"""GPU parity of the inference path (through the C-ABI) against the CPU oracle and the golden
+vectors generated from the reference.  Integer/index results must be exact; fp32 scores 1e-5
+relative (sigmoid/Gaussian arithmetic differs in the last ulps between libm and the GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from cet_pick_amd.synthetic import make_tomo, make_logits
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x)).cuda()
+
+
+def test_sigmoid_inplace_semantics(golden):
+    from cet_pick_amd.models.utils import _sigmoid
+    g = golden("decode_small.npz")
+    x = dev(g["logits"])[None, None].clone()
+    y = _sigmoid(x)
+    np.testing.assert_allclose(y[0, 0].cpu().numpy(), g["sigmoid"], rtol=2e-6, atol=1e-7)
+    # input is overwritten with the un-clamped sigmoid (reference mutates x)
+    ref = 1.0 / (1.0 + np.exp(-g["logits"].astype(np.float64)))
+    np.testing.assert_allclose(x[0, 0].cpu().numpy(), ref, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("k", [3, 5, 7])
+def test_nms_windows_exact(golden, k):
+    from oracle import infer_ref as O
+    from cet_pick_amd.models import decode as Dm
+    from cet_pick_amd.utils import image as Im
+    g = golden("decode_small.npz")
+    hm = g["sigmoid"]
+    t = dev(hm)[None, None]
+    for fn, win in ((Dm._nms, (3, k, k)), (Dm._nms_xy, (1, k, k)), (Dm._nms_z, (k, 1, 1)), (Im._nms, (k, k, k))):
+        got = fn(t, kernel=k)[0, 0].cpu().numpy()
+        np.testing.assert_array_equal(got, O.nms_window(hm, win))
+    if k in (3, 5):
+        np.testing.assert_array_equal(Dm._nms(t, kernel=k)[0, 0].cpu().numpy(), g[f"nms_3kk_{k}"])
+        np.testing.assert_array_equal(Im._nms(t, kernel=k)[0, 0].cpu().numpy(), g[f"nms_kkk_{k}"])
+
+
+@pytest.mark.parametrize("shape", [(5, 17, 23), (9, 64, 64), (20, 33, 130), (3, 16, 260)])
+def test_nms_ragged_shapes(shape):
+    from oracle import infer_ref as O
+    from cet_pick_amd.models import decode as Dm
+    rng = np.random.default_rng(1)
+    # coarse quantisation -> many exact ties / plateaus
+    vol = np.round(rng.standard_normal(shape) * 2).astype(np.float32) / 2
+    t = dev(vol)[None, None]
+    for k in (3, 5):
+        np.testing.assert_array_equal(Dm._nms(t, k)[0, 0].cpu().numpy(), O.nms_window(vol, (3, k, k)))
+        np.testing.assert_array_equal(Dm._nms_xy(t, k)[0, 0].cpu().numpy(), O.nms_window(vol, (1, k, k)))
+        np.testing.assert_array_equal(Dm._nms_z(t, k)[0, 0].cpu().numpy(), O.nms_window(vol, (k, 1, 1)))
+
+
+def _cmp_dets(got, want, floor=1.5e-4):
+    got = got[got[:, 3] > floor]
+    want = want[want[:, 3] > floor]
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got[:, :3], want[:, :3])
+    np.testing.assert_allclose(got[:, 3:], want[:, 3:], rtol=1e-5)
+
+
+def test_tomo_decode_golden(golden):
+    from cet_pick_amd.models import decode as Dm
+    g = golden("decode_small.npz")
+    hm = dev(g["sigmoid"])[None, None]
+    for k in (3, 5):
+        _cmp_dets(Dm.tomo_decode(hm, kernel=k, K=50)[0].cpu().numpy(), g[f"decode_{k}"])
+        _cmp_dets(Dm.tomo_decode(hm, kernel=k, K=50, if_fiber=True)[0].cpu().numpy(), g[f"decode_fiber_{k}"])
+    # fused sigmoid + decode from the raw logits
+    heat, dets = Dm.sigmoid_tomo_decode(dev(g["logits"])[None, None], kernel=3, K=50)
+    np.testing.assert_allclose(heat[0, 0].cpu().numpy(), g["sigmoid"], rtol=2e-6, atol=1e-7)
+    _cmp_dets(dets[0].cpu().numpy(), g["decode_3"])
+
+
+def test_topk_matches_reference_indices(golden):
+    from cet_pick_amd.models import decode as Dm
+    g = golden("decode_small.npz")
+    nms = dev(g["nms_3kk_3"])[None, None]
+    s, z, y, x, inds = Dm._topk(nms, K=40)
+    m = g["topk_scores"] > 1.5e-4
+    np.testing.assert_array_equal(s[0, 0].cpu().numpy()[m], g["topk_scores"][m])
+    np.testing.assert_array_equal(inds[0].cpu().numpy()[m], g["topk_inds"][m])
+    np.testing.assert_array_equal(z[0].cpu().numpy()[m], g["topk_z"][m])
+    np.testing.assert_array_equal(y[0].cpu().numpy()[m], g["topk_y"][m])
+    np.testing.assert_array_equal(x[0].cpu().numpy()[m], g["topk_x"][m])
+
+
+def test_decode_vs_oracle_medium():
+    from oracle import infer_ref as O
+    from cet_pick_amd.models import decode as Dm
+    logits = make_logits((32, 96, 128), seed=3)
+    heat, dets = Dm.sigmoid_tomo_decode(dev(logits)[None, None], kernel=3, K=300)
+    hm = heat[0, 0].cpu().numpy()
+    np.testing.assert_allclose(hm, O.sigmoid_clamp(logits), rtol=2e-6, atol=1e-7)
+    want = O.tomo_decode(hm, kernel=3, K=300)      # oracle continues from the GPU's heat bits
+    _cmp_dets(dets[0].cpu().numpy(), want)
+
+
+def test_topk_degenerate_plateau():
+    """All-equal heat: every voxel survives NMS; ties resolve to the lowest flat indices."""
+    from cet_pick_amd.models import decode as Dm
+    hm = torch.full((1, 1, 6, 40, 72), 0.5, device="cuda")
+    dets = Dm.tomo_decode(hm, kernel=3, K=100)[0].cpu().numpy()
+    idx = (dets[:, 2] * 40 + (dets[:, 1] - 0.25)) * 72 + (dets[:, 0] - 0.25)
+    np.testing.assert_array_equal(idx, np.arange(100))
+    assert np.all(dets[:, 3] == 0.5)
+
+
+def test_topk_fewer_than_k():
+    from cet_pick_amd.models import decode as Dm
+    hm = torch.zeros((1, 1, 4, 16, 64), device="cuda")
+    hm[0, 0, 2, 5, 7] = 0.9
+    hm[0, 0, 1, 9, 60] = 0.7
+    dets = Dm.tomo_decode(hm, kernel=3, K=10)[0].cpu().numpy()
+    np.testing.assert_allclose(dets[0], [7.25, 5.25, 2, 0.9, 0.9], rtol=1e-6)
+    np.testing.assert_allclose(dets[1], [60.25, 9.25, 1, 0.7, 0.7], rtol=1e-6)
+    assert np.all(dets[2:, 3] == 0)
+
+
+@pytest.mark.parametrize("sigma", [1.0, 2, 3, 5])
+def test_gaussian_vs_oracle(golden, sigma):
+    from oracle import infer_ref as O
+    from cet_pick_amd.utils import image as Im
+    g = golden("dog_small.npz")
+    shape = tuple(int(v) for v in g["shape"])
+    vol, _ = make_tomo(shape, seed=317)
+    got = Im.gaussian_filter(vol, sigma).cpu().numpy()
+    want = O.gaussian_filter(vol.astype(np.float64), sigma)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+    if sigma in (2, 3, 5):
+        np.testing.assert_allclose(got[18, ::3], g[f"gauss{int(sigma)}_z18"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(got[0, ::3], g[f"gauss{int(sigma)}_z0"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(7, 9, 11), (24, 50, 300), (40, 70, 65)])
+def test_gaussian_small_and_ragged(shape):
+    from oracle import infer_ref as O
+    from cet_pick_amd.utils import image as Im
+    rng = np.random.default_rng(2)
+    vol = rng.standard_normal(shape).astype(np.float32)
+    got = Im.gaussian_filter(vol, 2.5).cpu().numpy()    # radius 10 > some dims: multi-reflection
+    want = O.gaussian_filter(vol.astype(np.float64), 2.5)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+
+
+def test_greedy_nms_golden(golden):
+    from cet_pick_amd.utils import image as Im
+    g = golden("greedy_small.npz")
+    vol = g["vol"]
+    for d, thr in ((6, 0.5), (14, 1.0), (4, -np.inf)):
+        s, c = Im.non_maximum_suppression_3d(vol, d, threshold=thr)
+        np.testing.assert_array_equal(c, g[f"coords_d{d}"])
+        np.testing.assert_array_equal(s, g[f"scores_d{d}"])
+    s, c = Im.non_maximum_suppression_3d(vol, 6, scale=1.5, threshold=0.2)
+    np.testing.assert_array_equal(c, g["coords_d6_s15"])
+
+
+def test_dog_pick_golden(golden):
+    from cet_pick_amd.utils import image as Im
+    g = golden("dog_small.npz")
+    shape = tuple(int(v) for v in g["shape"])
+    vol, _ = make_tomo(shape, seed=317)
+    for sigmas in ((2, 4), (3, 5), (2, 4, 6)):
+        tag = "_".join(map(str, sigmas))
+        s, c = Im.get_potential_coords_pyramid(vol, sigmas=list(sigmas))
+        np.testing.assert_array_equal(c, g[f"coords_{tag}"])
+        np.testing.assert_allclose(s, g[f"scores_{tag}"], rtol=1e-3)
+
+
+def test_dog_pick_vs_oracle_larger():
+    from oracle import infer_ref as O
+    from cet_pick_amd.utils import image as Im
+    vol, _ = make_tomo((48, 200, 264), seed=318)
+    s, c = Im.get_potential_coords_pyramid(vol, sigmas=[3, 5])
+    so, co = O.get_potential_coords_pyramid(vol.astype(np.float64), sigmas=(3, 5))
+    assert len(s) > 20
+    # picks whose score clears the cutoff by a margin must agree exactly (fp32 vs fp64 DoG)
+    heat = O.dog_nms_heat(vol.astype(np.float64), (3, 5))
+    cut = O.pos_threshold(heat)
+    strong_o = {tuple(r) for r, sc in zip(co, so) if sc > cut * 1.01}
+    strong_g = {tuple(r) for r, sc in zip(c, s) if sc > cut * 1.01}
+    assert strong_o == strong_g
+    assert abs(len(s) - len(so)) <= max(2, len(so) // 100)
+
+
+def test_get_potential_coords(golden):
+    from cet_pick_amd.utils import image as Im
+    g = golden("dog_small.npz")
+    shape = tuple(int(v) for v in g["shape"])
+    vol, _ = make_tomo(shape, seed=317)
+    z, y, x = Im.get_potential_coords(vol, sigma1=2, sigma2=4, kernel=3, K=64)
+    got = set(zip(z[0].cpu().numpy().tolist(), y[0].cpu().numpy().tolist(), x[0].cpu().numpy().tolist()))
+    want = set(zip(g["gpc_z"].tolist(), g["gpc_y"].tolist(), g["gpc_x"].tolist()))
+    assert len(got & want) >= 62    # fp32 vs fp64 DoG may reorder the last near-ties
