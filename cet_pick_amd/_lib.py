@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcetpick_hip.so")
 
 _c = ctypes
-_P, _I, _F, _Z, _D = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_double
+_P, _I, _F, _Z, _D, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_double, _c.c_long
 
 # name -> (restype, argtypes); kept in step with include/cetpick_hip.h (tests/test_abi.py checks)
 SIGNATURES = {
@@ -27,6 +27,32 @@ SIGNATURES = {
     "mi_dog_pick": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
     "mi_greedy_nms3d_workspace_bytes": (_Z, [_I, _I, _I]),
     "mi_greedy_nms3d": (_I, [_P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _I, _P, _Z, _P]),
+    # training path
+    "mi_conv3d_workspace_bytes": (_Z, [_I] * 9),
+    "mi_conv3d_fwd_f32": (_I, [_P, _P, _P, _P, _I] + [_I] * 9 + [_P, _Z, _P]),
+    "mi_conv3d_dgrad_f32": (_I, [_P, _P, _P, _P, _P] + [_I] * 9 + [_P, _Z, _P]),
+    "mi_conv3d_wgrad_f32": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _Z, _P]),
+    "mi_colreduce_workspace_bytes": (_Z, [_L, _I]),
+    "mi_bn_stats": (_I, [_P, _L, _I, _P, _P, _Z, _P]),
+    "mi_bn_apply_fwd": (_I, [_P, _P, _L, _I, _P, _D, _P, _P, _F, _F, _P, _P, _P, _I, _P]),
+    "mi_bn_eval_fwd": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _F, _P, _I, _P]),
+    "mi_bn_bwd_reduce": (_I, [_P, _P, _P, _L, _I, _P, _I, _P, _P, _Z, _P]),
+    "mi_bn_bwd_apply": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _D, _I, _P, _P, _P]),
+    "mi_colsum": (_I, [_P, _L, _I, _P, _P, _P, _Z, _P]),
+    "mi_maxpool3d_fwd": (_I, [_P, _P, _P] + [_I] * 8 + [_P]),
+    "mi_maxpool3d_bwd": (_I, [_P, _P, _P] + [_I] * 8 + [_P]),
+    "mi_avgpool_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mi_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mi_bias_add": (_I, [_P, _P, _L, _I, _P]),
+    "mi_relu_mask": (_I, [_P, _P, _P, _P, _L, _P]),
+    "mi_l2norm_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "mi_l2norm_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "mi_moco_logits_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "mi_moco_logits_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "mi_ce_label0": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "mi_ema_update": (_I, [_P, _P, _F, _L, _P]),
+    "mi_sgd_step": (_I, [_P, _P, _P, _F, _F, _L, _P]),
+    "mi_queue_enqueue": (_I, [_P, _P, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

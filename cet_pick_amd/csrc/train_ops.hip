@@ -1,0 +1,683 @@
+// Non-GEMM kernels of the contrastive training step (channels-last fp32):
+// BatchNorm (train/eval, fwd/bwd, split so SyncBN can all-reduce the per-channel sums),
+// MaxPool3d, global average pool, bias, L2-normalise, MoCo logits, cross-entropy(label 0),
+// momentum (EMA) update, SGD, queue enqueue.
+//
+// Replaces (reference, cet_pick/...): nn.BatchNorm3d/1d, nn.MaxPool3d, nn.AdaptiveAvgPool3d at
+// models/networks/moco_encoder_3d.py:170-205; models/moco.py:31-52,111-141 (EMA, enqueue, logits);
+// trains/tomo_moco_trainer.py:52,73 (CrossEntropyLoss); torch.optim.SGD at moco_main.py:79.
+// All are HBM-bound elementwise / column-reduction passes.
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ---------------------------------------------------------------------------------------------
+// column reductions over [M][C] (C % 4 == 0, 256 % (C/4) == 0)
+// ---------------------------------------------------------------------------------------------
+enum { CR_STATS = 0, CR_BNBWD = 1, CR_SUM = 2 };
+
+struct ColReduceParams {
+    const float* a;      // STATS: x ; BNBWD: dy ; SUM: dy
+    const float* x;      // BNBWD: x
+    const float* y;      // BNBWD: y (post-ReLU output) when relu != 0
+    const float* save;   // BNBWD: mean[C], invstd[C]
+    long M;
+    int C, relu;
+    double* partials;    // [gridDim.x][2][C]
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(ColReduceParams p) {
+    const int CV = p.C >> 2;
+    const int tcol = threadIdx.x % CV, trow = threadIdx.x / CV;
+    const int RS = 256 / CV;
+    float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    float mean[4] = {0, 0, 0, 0}, inv[4] = {1, 1, 1, 1};
+    if (MODE == CR_BNBWD) {
+        float4 m = ld4(p.save + 4 * tcol), iv = ld4(p.save + p.C + 4 * tcol);
+        mean[0] = m.x; mean[1] = m.y; mean[2] = m.z; mean[3] = m.w;
+        inv[0] = iv.x; inv[1] = iv.y; inv[2] = iv.z; inv[3] = iv.w;
+    }
+    for (long r = (long)blockIdx.x * RS + trow; r < p.M; r += (long)gridDim.x * RS) {
+        const long o = r * p.C + 4 * tcol;
+        float4 a4 = ld4(p.a + o);
+        float a[4] = {a4.x, a4.y, a4.z, a4.w};
+        if (MODE == CR_STATS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s0[i] += a[i]; s1[i] = fmaf(a[i], a[i], s1[i]); }
+        } else if (MODE == CR_BNBWD) {
+            float4 x4 = ld4(p.x + o);
+            float x[4] = {x4.x, x4.y, x4.z, x4.w};
+            if (p.relu) {
+                float4 y4 = ld4(p.y + o);
+                float y[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = y[i] > 0.f ? a[i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s0[i] += a[i]; s1[i] = fmaf(a[i], (x[i] - mean[i]) * inv[i], s1[i]); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s0[i] += a[i];
+        }
+    }
+    __shared__ double red[2][256][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[0][threadIdx.x][i] = (double)s0[i]; red[1][threadIdx.x][i] = (double)s1[i]; }
+    __syncthreads();
+    if (trow == 0) {
+        double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+        for (int rr = 0; rr < RS; ++rr)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a0[i] += red[0][rr * CV + tcol][i]; a1[i] += red[1][rr * CV + tcol][i]; }
+        double* dst = p.partials + (long)blockIdx.x * 2 * p.C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dst[4 * tcol + i] = a0[i]; dst[p.C + 4 * tcol + i] = a1[i]; }
+    }
+}
+
+__global__ void colreduce_finalize_kernel(const double* partials, int n_part, int C, double* sums) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * C) return;
+    double s = 0;
+    for (int b = 0; b < n_part; ++b) s += partials[(long)b * 2 * C + c];   // fixed order
+    sums[c] = s;
+}
+
+int colreduce_blocks(long M, int C) {
+    int RS = 256 / (C / 4);
+    long b = (M + (long)RS * 8 - 1) / ((long)RS * 8);
+    return (int)std::max<long>(1, std::min<long>(b, 512));
+}
+bool colreduce_ok(int C) { return C >= 4 && (C % 4) == 0 && (C / 4) <= 256 && (256 % (C / 4)) == 0; }
+
+template <int MODE>
+int run_colreduce(ColReduceParams p, double* sums, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!colreduce_ok(p.C) || p.M <= 0) return MI_E_ARG;
+    int blocks = colreduce_blocks(p.M, p.C);
+    if (!ws || ws_bytes < sizeof(double) * 2 * p.C * (size_t)blocks) return MI_E_WORKSPACE;
+    p.partials = (double*)ws;
+    hipLaunchKernelGGL((colreduce_kernel<MODE>), dim3(blocks), dim3(256), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((2 * p.C + 255) / 256), dim3(256), 0, s,
+                       (const double*)ws, blocks, p.C, sums);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm apply kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* sums, double count, int C, float eps,
+                                   float momentum, float* running_mean, float* running_var,
+                                   float* save) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean = sums[c] / count;
+    double var = sums[C + c] / count - mean * mean;
+    if (var < 0) var = 0;
+    save[c] = (float)mean;
+    save[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        double unbiased = count > 1 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// y = relu?((x - mean) * invstd * gamma + beta)   (save = mean[C], invstd[C])
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, float* y, long n4, int C,
+                                                      const float* save, const float* gamma,
+                                                      const float* beta, int relu) {
+    const int CV = C >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % CV) * 4;
+        float4 v = ld4(x + 4 * i);
+        float4 m = ld4(save + c), iv = ld4(save + C + c);
+        float4 g = gamma ? ld4(gamma + c) : make_float4(1, 1, 1, 1);
+        float4 b = beta ? ld4(beta + c) : make_float4(0, 0, 0, 0);
+        float4 o;
+        o.x = fmaf((v.x - m.x) * iv.x, g.x, b.x); o.y = fmaf((v.y - m.y) * iv.y, g.y, b.y);
+        o.z = fmaf((v.z - m.z) * iv.z, g.z, b.z); o.w = fmaf((v.w - m.w) * iv.w, g.w, b.w);
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        st4(y + 4 * i, o);
+    }
+}
+
+__global__ void bn_eval_prepare_kernel(const float* running_mean, const float* running_var, int C,
+                                       float eps, float* save) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    save[c] = running_mean[c];
+    save[C + c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+// dx = gamma * invstd * (dy' - sum_dy/count - xhat * sum_dyxhat/count)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, const float* x,
+                                                          const float* y, float* dx, long n4, int C,
+                                                          const float* save, const float* gamma,
+                                                          const double* sums, double count,
+                                                          int relu) {
+    const int CV = C >> 2;
+    const float rc = (float)(1.0 / count);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % CV) * 4;
+        float4 d4 = ld4(dy + 4 * i), x4 = ld4(x + 4 * i);
+        float d[4] = {d4.x, d4.y, d4.z, d4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+        if (relu) {
+            float4 y4 = ld4(y + 4 * i);
+            float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = yv[k] > 0.f ? d[k] : 0.f;
+        }
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float mean = save[c + k], inv = save[C + c + k];
+            float g = gamma ? gamma[c + k] : 1.f;
+            float xhat = (xv[k] - mean) * inv;
+            float sdy = (float)sums[c + k], sdx = (float)sums[C + c + k];
+            o[k] = g * inv * (d[k] - sdy * rc - xhat * sdx * rc);
+        }
+        st4(dx + 4 * i, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+__global__ void bn_param_grad_kernel(const double* sums, int C, float* dgamma, float* dbeta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dbeta) dbeta[c] = (float)sums[c];
+    if (dgamma) dgamma[c] = (float)sums[C + c];
+}
+
+__global__ void cast_sums_kernel(const double* sums, int n, float* out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) out[c] = (float)sums[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool3d (cubic window k, stride s, pad p), channels-last, argmax tap saved per element
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, float* y, uint8_t* arg,
+                                                         int N, int Di, int Hi, int Wi, int C,
+                                                         int Do, int Ho, int Wo, int k, int s, int pad) {
+    const int CV = C >> 2;
+    const long total = (long)N * Do * Ho * Wo * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int cv = (int)(i % CV);
+        long v = i / CV;
+        int xo = (int)(v % Wo); v /= Wo;
+        int yo = (int)(v % Ho); v /= Ho;
+        int zo = (int)(v % Do);
+        int n = (int)(v / Do);
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        bool first = true;
+        for (int a = 0; a < k; ++a) {
+            int zi = zo * s - pad + a;
+            if ((unsigned)zi >= (unsigned)Di) continue;
+            for (int b = 0; b < k; ++b) {
+                int yi = yo * s - pad + b;
+                if ((unsigned)yi >= (unsigned)Hi) continue;
+                for (int c = 0; c < k; ++c) {
+                    int xi = xo * s - pad + c;
+                    if ((unsigned)xi >= (unsigned)Wi) continue;
+                    float4 t = ld4(x + ((((long)n * Di + zi) * Hi + yi) * Wi + xi) * C + 4 * cv);
+                    float tv[4] = {t.x, t.y, t.z, t.w};
+                    int tap = (a * k + b) * k + c;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (first || tv[q] > best[q] || tv[q] != tv[q]) { best[q] = tv[q]; bi[q] = tap; }
+                    first = false;
+                }
+            }
+        }
+        st4(y + 4 * i, make_float4(best[0], best[1], best[2], best[3]));
+        if (arg) *reinterpret_cast<uchar4*>(arg + 4 * i) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, const uint8_t* arg,
+                                                         float* dx, int N, int Di, int Hi, int Wi,
+                                                         int C, int Do, int Ho, int Wo, int k, int s,
+                                                         int pad) {
+    const int CV = C >> 2;
+    const long total = (long)N * Di * Hi * Wi * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int cv = (int)(i % CV);
+        long v = i / CV;
+        int xi = (int)(v % Wi); v /= Wi;
+        int yi = (int)(v % Hi); v /= Hi;
+        int zi = (int)(v % Di);
+        int n = (int)(v / Di);
+        float acc[4] = {0, 0, 0, 0};
+        for (int a = 0; a < k; ++a) {
+            int tz = zi + pad - a;
+            if (tz < 0 || tz % s) continue;
+            int zo = tz / s;
+            if (zo >= Do) continue;
+            for (int b = 0; b < k; ++b) {
+                int ty = yi + pad - b;
+                if (ty < 0 || ty % s) continue;
+                int yo = ty / s;
+                if (yo >= Ho) continue;
+                for (int c = 0; c < k; ++c) {
+                    int tx = xi + pad - c;
+                    if (tx < 0 || tx % s) continue;
+                    int xo = tx / s;
+                    if (xo >= Wo) continue;
+                    long o = ((((long)n * Do + zo) * Ho + yo) * Wo + xo) * C + 4 * cv;
+                    uchar4 am = *reinterpret_cast<const uchar4*>(arg + o);
+                    float4 d = ld4(dy + o);
+                    int tap = (a * k + b) * k + c;
+                    if (am.x == tap) acc[0] += d.x;
+                    if (am.y == tap) acc[1] += d.y;
+                    if (am.z == tap) acc[2] += d.z;
+                    if (am.w == tap) acc[3] += d.w;
+                }
+            }
+        }
+        st4(dx + 4 * i, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// global average pool over S spatial positions: x [B][S][C] -> y [B][C]
+// ---------------------------------------------------------------------------------------------
+__global__ void avgpool_fwd_kernel(const float* x, float* y, int B, int S, int C) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * C) return;
+    int c = (int)(i % C);
+    long b = i / C;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += x[(b * S + k) * C + c];
+    y[i] = s / (float)S;
+}
+__global__ void avgpool_bwd_kernel(const float* dy, float* dx, int B, int S, int C) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * S * C) return;
+    int c = (int)(i % C);
+    long b = i / ((long)S * C);
+    dx[i] = dy[b * C + c] / (float)S;
+}
+
+__global__ void bias_add_kernel(float* y, const float* bias, long n, int C) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] += bias[i % C];
+}
+
+// out = dy * (y > 0)  (+ add)
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float* dy, const float* y,
+                                                       const float* add, float* out, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 d = ld4(dy + 4 * i), v = ld4(y + 4 * i);
+        if (add) { float4 a = ld4(add + 4 * i); d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w; }
+        d.x = v.x > 0.f ? d.x : 0.f; d.y = v.y > 0.f ? d.y : 0.f;
+        d.z = v.z > 0.f ? d.z : 0.f; d.w = v.w > 0.f ? d.w : 0.f;
+        st4(out + 4 * i, d);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// L2 normalise rows (F.normalize, eps 1e-12), MoCo logits, CE(label 0)
+// one wave per row
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* x, float* y, float* inv_norm,
+                                                        int B, int C) {
+    int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { float v = x[(long)row * C + c]; s = fmaf(v, v, s); }
+    s = wave_sum(s);
+    float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    for (int c = lane; c < C; c += 64) y[(long)row * C + c] = x[(long)row * C + c] * inv;
+    if (lane == 0 && inv_norm) inv_norm[row] = inv;
+}
+// dx = (dy - y * (y . dy)) * inv_norm
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* dy, const float* y,
+                                                        const float* inv_norm, float* dx, int B,
+                                                        int C) {
+    int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(dy[(long)row * C + c], y[(long)row * C + c], s);
+    s = wave_sum(s);
+    float inv = inv_norm[row];
+    for (int c = lane; c < C; c += 64) {
+        long o = (long)row * C + c;
+        dx[o] = (dy[o] - y[o] * s) * inv;
+    }
+}
+
+// logits[b][0] = (q_b . k_b)/T ; logits[b][1+j] = (q_b . queue[:,j])/T     queue is [C][R]
+// one workgroup per row b; q_b staged in LDS
+__global__ __launch_bounds__(256) void moco_logits_fwd_kernel(const float* q, const float* k,
+                                                             const float* queue, float* logits,
+                                                             int C, int R, float invT) {
+    extern __shared__ float qs[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) qs[c] = q[(long)b * C + c];
+    __syncthreads();
+    float* out = logits + (long)b * (R + 1);
+    for (int j = tid; j < R; j += 256) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s = fmaf(qs[c], queue[(long)c * R + j], s);
+        out[1 + j] = s * invT;
+    }
+    if (tid < 64) {
+        float s = 0.f;
+        for (int c = tid; c < C; c += 64) s = fmaf(qs[c], k[(long)b * C + c], s);
+        s = wave_sum(s);
+        if (tid == 0) out[0] = s * invT;
+    }
+}
+// dq[b][c] = (dl[b][0]*k[b][c] + sum_j dl[b][1+j]*queue[c][j]) / T
+__global__ __launch_bounds__(256) void moco_logits_bwd_kernel(const float* dlogits, const float* k,
+                                                             const float* queue, float* dq, int C,
+                                                             int R, float invT) {
+    extern __shared__ float dl[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int j = tid; j < R + 1; j += 256) dl[j] = dlogits[(long)b * (R + 1) + j];
+    __syncthreads();
+    for (int c = wave; c < C; c += 4) {
+        float s = 0.f;
+        for (int j = lane; j < R; j += 64) s = fmaf(dl[1 + j], queue[(long)c * R + j], s);
+        s = wave_sum(s);
+        if (lane == 0) dq[(long)b * C + c] = (s + dl[0] * k[(long)b * C + c]) * invT;
+    }
+}
+
+// mean cross-entropy against label 0 and its gradient: dlogits = scale * (softmax - onehot0) / B
+// one workgroup per row; row_loss[b] written, loss reduced by a second tiny kernel (fixed order)
+__global__ __launch_bounds__(256) void ce0_kernel(const float* logits, float* row_loss,
+                                                 float* dlogits, int B, int n, float scale) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* l = logits + (long)b * n;
+    float m = -INFINITY;
+    for (int j = tid; j < n; j += 256) m = fmaxf(m, l[j]);
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int j = tid; j < n; j += 256) s += expf(l[j] - m);
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    s = red[0] + red[1] + red[2] + red[3];
+    const float lse = m + logf(s);
+    if (tid == 0) row_loss[b] = lse - l[0];
+    if (dlogits) {
+        const float g = scale / (float)B;
+        for (int j = tid; j < n; j += 256) {
+            float pj = expf(l[j] - lse);
+            dlogits[(long)b * n + j] = g * (pj - (j == 0 ? 1.f : 0.f));
+        }
+    }
+}
+__global__ void mean_kernel(const float* v, int n, float* out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += v[i];
+        *out = s / (float)n;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimiser-side passes over flat parameter arenas
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ema_kernel(float* k, const float* q, float m, long n) {
+    const float om = 1.0f - m;
+    long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 a = ld4(k + 4 * i), b = ld4(q + 4 * i);
+        a.x = a.x * m + b.x * om; a.y = a.y * m + b.y * om;
+        a.z = a.z * m + b.z * om; a.w = a.w * m + b.w * om;
+        st4(k + 4 * i, a);
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) k[i] = k[i] * m + q[i] * om;
+}
+// p <- p - lr * (g + wd * p)   (torch.optim.SGD without momentum)
+__global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, const float* lr_dev,
+                                                 float lr_host, float wd, long n) {
+    const float lr = lr_dev ? *lr_dev : lr_host;
+    long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 a = ld4(p + 4 * i), b = ld4(g + 4 * i);
+        a.x -= lr * (b.x + wd * a.x); a.y -= lr * (b.y + wd * a.y);
+        a.z -= lr * (b.z + wd * a.z); a.w -= lr * (b.w + wd * a.w);
+        st4(p + 4 * i, a);
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) p[i] -= lr * (g[i] + wd * p[i]);
+}
+
+// queue[:, ptr:ptr+B] = keys.T ; ptr = (ptr + B) % R      (queue is [C][R], ptr is int64 on device)
+__global__ void enqueue_kernel(float* queue, long long* ptr, const float* keys, int B, int C, int R) {
+    const long long p0 = *ptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * C; i += gridDim.x * blockDim.x) {
+        int b = i % B, c = i / B;
+        long long col = p0 + b;
+        if (col < R) queue[(long)c * R + col] = keys[(long)b * C + c];
+    }
+}
+__global__ void advance_ptr_kernel(long long* ptr, int B, int R) { *ptr = (*ptr + B) % R; }
+
+int ew_blocks(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 2048)); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t mi_colreduce_workspace_bytes(long M, int C) {
+    if (!colreduce_ok(C)) return 0;
+    return sizeof(double) * 2 * C * (size_t)colreduce_blocks(M, C);
+}
+
+extern "C" int mi_bn_stats(const float* x, long M, int C, double* sums, void* ws, size_t ws_bytes,
+                           mi_stream_t stream) {
+    if (!x || !sums) return MI_E_ARG;
+    ColReduceParams p = {};
+    p.a = x; p.M = M; p.C = C;
+    return run_colreduce<CR_STATS>(p, sums, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mi_bn_apply_fwd(const float* x, float* y, long M, int C, const double* sums,
+                               double count, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var,
+                               float* save_mean_invstd, int relu, mi_stream_t stream) {
+    if (!x || !y || !sums || !save_mean_invstd || !colreduce_ok(C) || M <= 0 || !(count > 0)) return MI_E_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return MI_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, count, C, eps,
+                       momentum, running_mean, running_var, save_mean_invstd);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    long n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, y, n4, C,
+                       (const float*)save_mean_invstd, gamma, beta, relu);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_bn_eval_fwd(const float* x, float* y, long M, int C, const float* running_mean,
+                              const float* running_var, const float* gamma, const float* beta,
+                              float eps, float* scratch_2c, int relu, mi_stream_t stream) {
+    if (!x || !y || !running_mean || !running_var || !scratch_2c || !colreduce_ok(C) || M <= 0) return MI_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean,
+                       running_var, C, eps, scratch_2c);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    long n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, y, n4, C,
+                       (const float*)scratch_2c, gamma, beta, relu);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_bn_bwd_reduce(const float* dy, const float* x, const float* y, long M, int C,
+                                const float* save_mean_invstd, int relu, double* sums, void* ws,
+                                size_t ws_bytes, mi_stream_t stream) {
+    if (!dy || !x || !save_mean_invstd || !sums || (relu && !y)) return MI_E_ARG;
+    ColReduceParams p = {};
+    p.a = dy; p.x = x; p.y = y; p.save = save_mean_invstd; p.M = M; p.C = C; p.relu = relu;
+    return run_colreduce<CR_BNBWD>(p, sums, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mi_bn_bwd_apply(const float* dy, const float* x, const float* y, float* dx, long M,
+                               int C, const float* save_mean_invstd, const float* gamma,
+                               const double* sums, double count, int relu, float* dgamma,
+                               float* dbeta, mi_stream_t stream) {
+    if (!dy || !x || !dx || !save_mean_invstd || !sums || (relu && !y) || !colreduce_ok(C) || !(count > 0)) return MI_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    long n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, y, dx, n4, C,
+                       save_mean_invstd, gamma, sums, count, relu);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    if (dgamma || dbeta) {
+        hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, dgamma, dbeta);
+        MI_RETURN_IF_LAUNCH_FAILED();
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_colsum(const float* dy, long M, int C, float* out, double* sums_scratch, void* ws,
+                         size_t ws_bytes, mi_stream_t stream) {
+    if (!dy || !out || !sums_scratch) return MI_E_ARG;
+    ColReduceParams p = {};
+    p.a = dy; p.M = M; p.C = C;
+    int rc = run_colreduce<CR_SUM>(p, sums_scratch, ws, ws_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cast_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)sums_scratch, C, out);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_maxpool3d_fwd(const float* x, float* y, uint8_t* argmax, int N, int Di, int Hi,
+                                int Wi, int C, int k, int stride, int pad, mi_stream_t stream) {
+    if (!x || !y || C % 4 || k <= 0 || k > 6 || stride <= 0 || pad < 0) return MI_E_ARG;
+    int Do = (Di + 2 * pad - k) / stride + 1, Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
+    if (Do <= 0 || Ho <= 0 || Wo <= 0) return MI_E_ARG;
+    long total = (long)N * Do * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       argmax, N, Di, Hi, Wi, C, Do, Ho, Wo, k, stride, pad);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_maxpool3d_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, int Di,
+                                int Hi, int Wi, int C, int k, int stride, int pad, mi_stream_t stream) {
+    if (!dy || !argmax || !dx || C % 4 || k <= 0 || k > 6 || stride <= 0 || pad < 0) return MI_E_ARG;
+    int Do = (Di + 2 * pad - k) / stride + 1, Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
+    long total = (long)N * Di * Hi * Wi * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy,
+                       argmax, dx, N, Di, Hi, Wi, C, Do, Ho, Wo, k, stride, pad);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_avgpool_fwd(const float* x, float* y, int B, int S, int C, mi_stream_t stream) {
+    if (!x || !y || B <= 0 || S <= 0 || C <= 0) return MI_E_ARG;
+    long n = (long)B * C;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, B, S, C);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+extern "C" int mi_avgpool_bwd(const float* dy, float* dx, int B, int S, int C, mi_stream_t stream) {
+    if (!dy || !dx || B <= 0 || S <= 0 || C <= 0) return MI_E_ARG;
+    long n = (long)B * S * C;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, S, C);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_bias_add(float* y, const float* bias, long M, int C, mi_stream_t stream) {
+    if (!y || !bias || M <= 0 || C <= 0) return MI_E_ARG;
+    hipLaunchKernelGGL(bias_add_kernel, dim3(ew_blocks(M * C)), dim3(256), 0, (hipStream_t)stream, y, bias, M * C, C);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_relu_mask(const float* dy, const float* y, const float* add, float* out, long n,
+                            mi_stream_t stream) {
+    if (!dy || !y || !out || n <= 0 || (n & 3)) return MI_E_ARG;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, add, out, n / 4);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_l2norm_fwd(const float* x, float* y, float* inv_norm, int B, int C, mi_stream_t stream) {
+    if (!x || !y || B <= 0 || C <= 0) return MI_E_ARG;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, inv_norm, B, C);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+extern "C" int mi_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int B,
+                             int C, mi_stream_t stream) {
+    if (!dy || !y || !inv_norm || !dx || B <= 0 || C <= 0) return MI_E_ARG;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, inv_norm, dx, B, C);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_moco_logits_fwd(const float* q, const float* k, const float* queue, float* logits,
+                                  int B, int C, int R, float T, mi_stream_t stream) {
+    if (!q || !k || !queue || !logits || B <= 0 || C <= 0 || R <= 0 || !(T > 0.f) || C > 8192) return MI_E_ARG;
+    hipLaunchKernelGGL(moco_logits_fwd_kernel, dim3(B), dim3(256), sizeof(float) * C, (hipStream_t)stream,
+                       q, k, queue, logits, C, R, 1.0f / T);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+extern "C" int mi_moco_logits_bwd(const float* dlogits, const float* k, const float* queue, float* dq,
+                                  int B, int C, int R, float T, mi_stream_t stream) {
+    if (!dlogits || !k || !queue || !dq || B <= 0 || C <= 0 || R <= 0 || !(T > 0.f) || R > 12000) return MI_E_ARG;
+    hipLaunchKernelGGL(moco_logits_bwd_kernel, dim3(B), dim3(256), sizeof(float) * (R + 1), (hipStream_t)stream,
+                       dlogits, k, queue, dq, C, R, 1.0f / T);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_ce_label0(const float* logits, float* loss, float* row_loss, float* dlogits, int B,
+                            int n, float grad_scale, mi_stream_t stream) {
+    if (!logits || !loss || !row_loss || B <= 0 || n <= 0) return MI_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce0_kernel, dim3(B), dim3(256), 0, s, logits, row_loss, dlogits, B, n, grad_scale);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, s, (const float*)row_loss, B, loss);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_ema_update(float* k, const float* q, float m, long n, mi_stream_t stream) {
+    if (!k || !q || n <= 0 || ((uintptr_t)k & 15) || ((uintptr_t)q & 15)) return MI_E_ARG;
+    hipLaunchKernelGGL(ema_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, k, q, m, n);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_sgd_step(float* p, const float* g, const float* lr_dev, float lr, float weight_decay,
+                           long n, mi_stream_t stream) {
+    if (!p || !g || n <= 0 || ((uintptr_t)p & 15) || ((uintptr_t)g & 15)) return MI_E_ARG;
+    hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, lr_dev, lr, weight_decay, n);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_queue_enqueue(float* queue, int64_t* queue_ptr, const float* keys, int B, int C, int R,
+                                mi_stream_t stream) {
+    if (!queue || !queue_ptr || !keys || B <= 0 || C <= 0 || R <= 0 || (R % B)) return MI_E_ARG;  // moco.py:47
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(enqueue_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, queue, (long long*)queue_ptr, keys, B, C, R);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(advance_ptr_kernel, dim3(1), dim3(1), 0, s, (long long*)queue_ptr, B, R);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}

@@ -1,0 +1,595 @@
+"""torch.autograd glue over the training-path C-ABI (include/cetpick_hip.h).
+
+Activations are channels-last fp32: 5-D (N, D, H, W, C) for volumes, 2-D (M, C) for vectors.
+Weights are stored [tap][Cin][Cout]; modules expose them to state_dict() as permuted views with
+the reference's logical shapes (Cout, Cin, kd, kh, kw) / (out, in).
+
+Weight gradients are written straight into ``param.grad`` (a view of a flat gradient arena when
+the model was flattened by :class:`ParamArena`): a parameter whose ``.grad`` is None gets the
+gradient assigned, otherwise it is accumulated - the same contract as torch's AccumulateGrad.
+PyTorch is the allocator / stream owner; all arithmetic happens in the HIP kernels.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+def _ws(nbytes, device, tag):
+    return L.workspace(max(int(nbytes), 256), device, tag)
+
+
+def _f32c(t, name):
+    L.require_cuda(t, name)
+    if not t.is_contiguous():
+        raise L.HipExtensionError(name + " must be contiguous (channels-last storage)")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter plumbing
+# ------------------------------------------------------------------------------------------------
+def conv_weight_param(co, ci, k, device=None):
+    """Parameter with logical shape (co, ci, k, k, k) over physical storage [k,k,k,ci,co]."""
+    phys = torch.empty(k, k, k, ci, co, device=device)
+    return nn.Parameter(phys.permute(4, 3, 0, 1, 2))
+
+
+def linear_weight_param(out_f, in_f, device=None):
+    """Parameter with logical shape (out, in) over physical storage [in][out]."""
+    phys = torch.empty(in_f, out_f, device=device)
+    return nn.Parameter(phys.t())
+
+
+def _phys_ok(p):
+    """True when the parameter's strides are the kernel layout (co fastest, then ci, then taps)."""
+    if p.dim() == 5:
+        co, ci, kd, kh, kw = p.shape
+        return p.stride() == (1, co, kh * kw * ci * co, kw * ci * co, ci * co)
+    if p.dim() == 2:
+        out_f, in_f = p.shape
+        return p.stride() == (1, out_f)
+    return p.is_contiguous()
+
+
+def _grad_target(param):
+    """(tensor to write into, accumulate?) for a parameter's gradient."""
+    g = param.grad
+    if g is None:
+        view = getattr(param, "_mi_grad_view", None)
+        if view is None:
+            view = torch.empty_like(param)        # preserve_format keeps the kernel layout
+        param.grad = view
+        return view, False
+    if g.stride() != param.stride():
+        raise L.HipExtensionError("param.grad layout differs from the parameter's kernel layout")
+    return g, True
+
+
+class ParamArena:
+    """Flatten a module's parameters (and their gradients) into two contiguous fp32 arenas so the
+    momentum update (models/moco.py:31-39), SGD (moco_main.py:79) and the gradient all-reduce are
+    single passes.  Parameters keep their identity, logical shapes and kernel strides."""
+
+    def __init__(self, module):
+        params = [p for p in module.parameters()]
+        if not params:
+            raise ValueError("module has no parameters")
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4          # keep every view 16-B aligned
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.params, self.offsets = params, offs
+        for p, o in zip(params, offs):
+            if not (_phys_ok(p) or p.is_contiguous()):
+                raise L.HipExtensionError("unexpected parameter layout")
+            view = torch.as_strided(self.flat, p.shape, p.stride(), o)
+            view.copy_(p.data)
+            p.data = view
+            p._mi_grad_view = torch.as_strided(self.flat_grad, p.shape, p.stride(), o)
+            p.grad = None
+        self.numel = total
+
+    def attach_grads(self):
+        for p in self.params:
+            p.grad = p._mi_grad_view
+
+    def zero_grad(self):
+        """set_to_none semantics: the next backward overwrites the arena views."""
+        for p in self.params:
+            p.grad = None
+
+
+# ------------------------------------------------------------------------------------------------
+# conv / linear
+# ------------------------------------------------------------------------------------------------
+def _conv_geom(x, w, k, stride, pad):
+    n, d, h, wd, ci = x.shape
+    co = w.shape[0]
+    do = (d + 2 * pad - k) // stride + 1
+    ho = (h + 2 * pad - k) // stride + 1
+    wo = (wd + 2 * pad - k) // stride + 1
+    return n, d, h, wd, ci, co, do, ho, wo
+
+
+def conv_fwd(x, w, k, stride, pad, res=None, relu=False):
+    _f32c(x, "x")
+    if not _phys_ok(w):
+        raise L.HipExtensionError("conv weight is not in kernel layout [tap][Cin][Cout]")
+    n, d, h, wd, ci, co, do, ho, wo = _conv_geom(x, w, k, stride, pad)
+    y = torch.empty((n, do, ho, wo, co), dtype=torch.float32, device=x.device)
+    lib = L.lib()
+    ws = _ws(lib.mi_conv3d_workspace_bytes(n, d, h, wd, ci, co, k, stride, pad), x.device, "conv")
+    L.check(lib.mi_conv3d_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(res), int(relu), n, d, h, wd, ci,
+                                  co, k, stride, pad, L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_fwd_f32")
+    return y
+
+
+def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None):
+    _f32c(dy, "dy")
+    n, d, h, wd, ci = in_shape
+    co = w.shape[0]
+    dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
+    lib = L.lib()
+    ws = _ws(lib.mi_conv3d_workspace_bytes(n, d, h, wd, ci, co, k, stride, pad), dy.device, "conv")
+    L.check(lib.mi_conv3d_dgrad_f32(L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(res), L.ptr(mask), n, d, h, wd,
+                                    ci, co, k, stride, pad, L.ptr(ws), ws.numel(), L.stream()),
+            "mi_conv3d_dgrad_f32")
+    return dx
+
+
+def conv_wgrad_into(x, dy, param, k, stride, pad):
+    """dW for `param`, written (or accumulated) into param.grad."""
+    n, d, h, wd, ci = x.shape
+    co = dy.shape[-1]
+    lib = L.lib()
+    ws = _ws(lib.mi_conv3d_workspace_bytes(n, d, h, wd, ci, co, k, stride, pad), x.device, "conv")
+    g, acc = _grad_target(param)
+    if acc:
+        tmp = torch.empty_like(g)
+        L.check(lib.mi_conv3d_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tmp), n, d, h, wd, ci, co, k, stride, pad,
+                                        L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_wgrad_f32")
+        g.add_(tmp)
+    else:
+        L.check(lib.mi_conv3d_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(g), n, d, h, wd, ci, co, k, stride, pad,
+                                        L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_wgrad_f32")
+
+
+def relu_mask(dy, y, add=None):
+    out = torch.empty_like(dy)
+    L.check(L.lib().mi_relu_mask(L.ptr(dy), L.ptr(y), L.ptr(add), L.ptr(out), dy.numel(), L.stream()),
+            "mi_relu_mask")
+    return out
+
+
+class _ConvFn(torch.autograd.Function):
+    """y = act(conv(x, W)); W's gradient goes to mod.weight.grad directly."""
+
+    @staticmethod
+    def forward(ctx, x, w, mod, relu):
+        ctx.mod, ctx.relu = mod, relu
+        y = conv_fwd(x, w, mod.k, mod.stride, mod.pad, None, relu)
+        ctx.save_for_backward(x, y if relu else None)
+        ctx.x_needs_grad = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        mod = ctx.mod
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = relu_mask(dy, y)
+        if mod.weight.requires_grad:
+            conv_wgrad_into(x, dy, mod.weight, mod.k, mod.stride, mod.pad)
+        dx = None
+        if ctx.x_needs_grad:
+            dx = conv_dgrad(dy, mod.weight, x.shape, mod.k, mod.stride, mod.pad)
+        return dx, None, None, None
+
+
+class HipConv3d(nn.Module):
+    """nn.Conv3d(ci, co, k, stride, padding, bias=False) on channels-last activations."""
+
+    def __init__(self, ci, co, k, stride=1, pad=0):
+        super().__init__()
+        self.ci, self.co, self.k, self.stride, self.pad = ci, co, k, stride, pad
+        self.weight = conv_weight_param(co, ci, k)
+        with torch.no_grad():
+            # nn.Conv3d default init: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+            bound = 1.0 / (ci * k ** 3) ** 0.5
+            self.weight.uniform_(-bound, bound)
+
+    def forward(self, x, relu=False):
+        return _ConvFn.apply(x, self.weight, self, relu)
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, mod):
+        m, ci = x.shape
+        y = conv_fwd(x.view(m, 1, 1, 1, ci), w.view(w.shape[0], ci, 1, 1, 1) if w.dim() == 5 else _as5(w),
+                     1, 1, 0).view(m, -1)
+        if b is not None:
+            L.check(L.lib().mi_bias_add(L.ptr(y), L.ptr(b), m, y.shape[1], L.stream()), "mi_bias_add")
+        ctx.mod = mod
+        ctx.save_for_backward(x)
+        ctx.x_needs_grad = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        mod = ctx.mod
+        dy = dy.contiguous()
+        m, ci = x.shape
+        co = dy.shape[1]
+        lib = L.lib()
+        if mod.weight.requires_grad:
+            g, acc = _grad_target(mod.weight)
+            tgt = torch.empty_like(g) if acc else g
+            ws = _ws(lib.mi_conv3d_workspace_bytes(m, 1, 1, 1, ci, co, 1, 1, 0), x.device, "conv")
+            L.check(lib.mi_conv3d_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), m, 1, 1, 1, ci, co, 1, 1, 0,
+                                            L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_wgrad_f32")
+            if acc:
+                g.add_(tgt)
+        if mod.bias is not None and mod.bias.requires_grad:
+            g, acc = _grad_target(mod.bias)
+            tgt = torch.empty_like(g) if acc else g
+            ws = _ws(lib.mi_colreduce_workspace_bytes(m, co), x.device, "colreduce")
+            sums = torch.empty(2 * co, dtype=torch.float64, device=x.device)
+            L.check(lib.mi_colsum(L.ptr(dy), m, co, L.ptr(tgt), L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()),
+                    "mi_colsum")
+            if acc:
+                g.add_(tgt)
+        dx = None
+        if ctx.x_needs_grad:
+            dx = conv_dgrad(dy.view(m, 1, 1, 1, co), _as5(mod.weight), (m, 1, 1, 1, ci), 1, 1, 0).view(m, ci)
+        return dx, None, None, None
+
+
+def _as5(w2):
+    """(out, in) weight with strides (1, out) viewed as (out, in, 1, 1, 1) in kernel layout."""
+    out_f, in_f = w2.shape
+    return torch.as_strided(w2, (out_f, in_f, 1, 1, 1), (1, out_f, in_f * out_f, in_f * out_f, in_f * out_f))
+
+
+class HipLinear(nn.Module):
+    def __init__(self, in_f, out_f, bias=True):
+        super().__init__()
+        self.in_f, self.out_f = in_f, out_f
+        self.weight = linear_weight_param(out_f, in_f)
+        self.bias = nn.Parameter(torch.empty(out_f)) if bias else None
+        with torch.no_grad():
+            bound = 1.0 / in_f ** 0.5
+            self.weight.uniform_(-bound, bound)
+            if bias:
+                self.bias.uniform_(-bound, bound)
+
+    def forward(self, x):
+        if not _phys_ok(self.weight):
+            raise L.HipExtensionError("linear weight is not in kernel layout [in][out]")
+        return _LinearFn.apply(_f32c(x, "x"), self.weight, self.bias, self)
+
+
+# ------------------------------------------------------------------------------------------------
+# batch norm (+ReLU), SyncBN-capable
+# ------------------------------------------------------------------------------------------------
+def _dist_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
+class _BNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mod, relu):
+        shape = x.shape
+        c = shape[-1]
+        m = x.numel() // c
+        lib = L.lib()
+        dev = x.device
+        y = torch.empty_like(x)
+        save = torch.empty(2 * c, dtype=torch.float32, device=dev)
+        if mod.training or not mod.track_running_stats:
+            ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
+            sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+            L.check(lib.mi_bn_stats(L.ptr(x), m, c, L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()), "mi_bn_stats")
+            count = float(m)
+            if mod.sync and _dist_world() > 1:
+                import torch.distributed as dist
+                dist.all_reduce(sums)                     # RCCL: 2*C doubles
+                count = float(m) * _dist_world()
+            track = mod.track_running_stats and mod.training
+            L.check(lib.mi_bn_apply_fwd(L.ptr(x), L.ptr(y), m, c, L.ptr(sums), count, L.ptr(gamma), L.ptr(beta),
+                                        mod.eps, mod.momentum,
+                                        L.ptr(mod.running_mean if track else None),
+                                        L.ptr(mod.running_var if track else None),
+                                        L.ptr(save), int(relu), L.stream()), "mi_bn_apply_fwd")
+            if track:
+                mod.num_batches_tracked += 1
+            ctx.count = count
+            ctx.train_stats = True
+        else:
+            L.check(lib.mi_bn_eval_fwd(L.ptr(x), L.ptr(y), m, c, L.ptr(mod.running_mean), L.ptr(mod.running_var),
+                                       L.ptr(gamma), L.ptr(beta), mod.eps, L.ptr(save), int(relu), L.stream()),
+                    "mi_bn_eval_fwd")
+            ctx.train_stats = False
+        ctx.mod, ctx.relu, ctx.m, ctx.c = mod, relu, m, c
+        ctx.save_for_backward(x, y if relu else None, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, save = ctx.saved_tensors
+        mod, relu, m, c = ctx.mod, ctx.relu, ctx.m, ctx.c
+        dy = dy.contiguous()
+        lib = L.lib()
+        dev = x.device
+        if not ctx.train_stats:
+            raise L.HipExtensionError("BatchNorm backward in eval mode is not on the hot path")
+        ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
+        sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+        L.check(lib.mi_bn_bwd_reduce(L.ptr(dy), L.ptr(x), L.ptr(y), m, c, L.ptr(save), int(relu), L.ptr(sums),
+                                     L.ptr(ws), ws.numel(), L.stream()), "mi_bn_bwd_reduce")
+        if mod.sync and _dist_world() > 1:
+            import torch.distributed as dist
+            dist.all_reduce(sums)
+        dx = torch.empty_like(x)
+        gamma = mod.weight
+        dg = db = None
+        acc_g = acc_b = False
+        if gamma is not None and gamma.requires_grad:
+            gt, acc_g = _grad_target(gamma)
+            dg = torch.empty_like(gt) if acc_g else gt
+            bt, acc_b = _grad_target(mod.bias)
+            db = torch.empty_like(bt) if acc_b else bt
+        L.check(lib.mi_bn_bwd_apply(L.ptr(dy), L.ptr(x), L.ptr(y), L.ptr(dx), m, c, L.ptr(save), L.ptr(gamma),
+                                    L.ptr(sums), ctx.count, int(relu), L.ptr(dg), L.ptr(db), L.stream()),
+                "mi_bn_bwd_apply")
+        if acc_g:
+            gamma.grad.add_(dg)
+        if acc_b:
+            mod.bias.grad.add_(db)
+        # under SyncBN the local dgamma/dbeta already hold the global sums (sums were all-reduced);
+        # the data-parallel gradient averaging divides them like every other gradient.
+        return dx, None, None, None, None
+
+
+class HipBatchNorm(nn.Module):
+    """nn.BatchNorm3d / nn.BatchNorm1d over the last (channel) axis, optional fused ReLU."""
+
+    def __init__(self, c, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.affine, self.track_running_stats = affine, track_running_stats
+        self.sync = False
+        if affine:
+            self.weight = nn.Parameter(torch.ones(c))
+            self.bias = nn.Parameter(torch.zeros(c))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, relu=False):
+        return _BNFn.apply(_f32c(x, "x"), self.weight, self.bias, self, relu)
+
+
+def convert_sync_batchnorm(module):
+    """Counterpart of nn.SyncBatchNorm.convert_sync_batchnorm (moco_main.py:65-66): the same
+    modules, with their per-channel sums all-reduced over RCCL."""
+    for m in module.modules():
+        if isinstance(m, HipBatchNorm):
+            m.sync = True
+    return module
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling
+# ------------------------------------------------------------------------------------------------
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        n, d, h, w, c = x.shape
+        do, ho, wo = [(v + 2 * pad - k) // stride + 1 for v in (d, h, w)]
+        y = torch.empty((n, do, ho, wo, c), dtype=torch.float32, device=x.device)
+        arg = torch.empty((n, do, ho, wo, c), dtype=torch.uint8, device=x.device)
+        L.check(L.lib().mi_maxpool3d_fwd(L.ptr(x), L.ptr(y), L.ptr(arg), n, d, h, w, c, k, stride, pad, L.stream()),
+                "mi_maxpool3d_fwd")
+        ctx.save_for_backward(arg)
+        ctx.geom = (x.shape, k, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        shape, k, stride, pad = ctx.geom
+        n, d, h, w, c = shape
+        dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
+        L.check(L.lib().mi_maxpool3d_bwd(L.ptr(dy.contiguous()), L.ptr(arg), L.ptr(dx), n, d, h, w, c, k, stride,
+                                         pad, L.stream()), "mi_maxpool3d_bwd")
+        return dx, None, None, None
+
+
+def maxpool3d(x, k, stride, pad):
+    return _MaxPoolFn.apply(_f32c(x, "x"), k, stride, pad)
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        n = x.shape[0]
+        c = x.shape[-1]
+        s = x.numel() // (n * c)
+        y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        L.check(L.lib().mi_avgpool_fwd(L.ptr(x), L.ptr(y), n, s, c, L.stream()), "mi_avgpool_fwd")
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape = ctx.shape
+        n, c = shape[0], shape[-1]
+        s = 1
+        for v in shape[1:-1]:
+            s *= v
+        dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
+        L.check(L.lib().mi_avgpool_bwd(L.ptr(dy.contiguous()), L.ptr(dx), n, s, c, L.stream()), "mi_avgpool_bwd")
+        return dx
+
+
+def global_avgpool(x):
+    return _AvgPoolFn.apply(_f32c(x, "x"))
+
+
+# ------------------------------------------------------------------------------------------------
+# BasicBlock (moco_encoder_3d.py:55-84): conv-ReLU-conv (+residual) -ReLU, no BN, with the ReLU
+# derivatives fused into the data-gradient epilogues
+# ------------------------------------------------------------------------------------------------
+class _BasicBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, w2, wds, blk):
+        s = blk.stride
+        hmid = conv_fwd(x, w1, 3, s, 1, None, True)
+        r = conv_fwd(x, wds, 1, s, 0) if wds is not None else x
+        out = conv_fwd(hmid, w2, 3, 1, 1, r, True)
+        ctx.blk = blk
+        ctx.save_for_backward(x, hmid, out)
+        ctx.x_needs_grad = x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, hmid, out = ctx.saved_tensors
+        blk = ctx.blk
+        s = blk.stride
+        d2 = relu_mask(dout.contiguous(), out)                       # through the block's last ReLU
+        if blk.conv2.weight.requires_grad:
+            conv_wgrad_into(hmid, d2, blk.conv2.weight, 3, 1, 1)
+        dh = conv_dgrad(d2, blk.conv2.weight, hmid.shape, 3, 1, 1, None, hmid)   # * (hmid > 0) fused
+        if blk.conv1.weight.requires_grad:
+            conv_wgrad_into(x, dh, blk.conv1.weight, 3, s, 1)
+        dx = None
+        ds = blk.downsample
+        if ds is not None:
+            if ds[0].weight.requires_grad:
+                conv_wgrad_into(x, d2, ds[0].weight, 1, s, 0)
+            if ctx.x_needs_grad:
+                dres = conv_dgrad(d2, ds[0].weight, x.shape, 1, s, 0)
+                dx = conv_dgrad(dh, blk.conv1.weight, x.shape, 3, s, 1, dres, None)
+        elif ctx.x_needs_grad:
+            dx = conv_dgrad(dh, blk.conv1.weight, x.shape, 3, s, 1, d2, None)   # + identity branch fused
+        return dx, None, None, None, None
+
+
+def basic_block(x, blk):
+    wds = blk.downsample[0].weight if blk.downsample is not None else None
+    return _BasicBlockFn.apply(_f32c(x, "x"), blk.conv1.weight, blk.conv2.weight, wds, blk)
+
+
+# ------------------------------------------------------------------------------------------------
+# contrastive head: normalise, logits, cross-entropy
+# ------------------------------------------------------------------------------------------------
+class _L2NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        b, c = x.shape
+        y = torch.empty_like(x)
+        inv = torch.empty(b, dtype=torch.float32, device=x.device)
+        L.check(L.lib().mi_l2norm_fwd(L.ptr(x), L.ptr(y), L.ptr(inv), b, c, L.stream()), "mi_l2norm_fwd")
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        b, c = y.shape
+        dx = torch.empty_like(y)
+        L.check(L.lib().mi_l2norm_bwd(L.ptr(dy.contiguous()), L.ptr(y), L.ptr(inv), L.ptr(dx), b, c, L.stream()),
+                "mi_l2norm_bwd")
+        return dx
+
+
+def l2_normalize(x):
+    return _L2NormFn.apply(_f32c(x, "x"))
+
+
+class _MocoLogitsFn(torch.autograd.Function):
+    """logits = cat([q.k, q @ queue], 1) / T   (models/moco.py:130-138); gradient w.r.t. q only."""
+
+    @staticmethod
+    def forward(ctx, q, k, queue, T):
+        b, c = q.shape
+        r = queue.shape[1]
+        logits = torch.empty((b, r + 1), dtype=torch.float32, device=q.device)
+        L.check(L.lib().mi_moco_logits_fwd(L.ptr(q), L.ptr(k), L.ptr(queue), L.ptr(logits), b, c, r, float(T),
+                                           L.stream()), "mi_moco_logits_fwd")
+        ctx.save_for_backward(k, queue.clone())      # the queue is overwritten by the enqueue below
+        ctx.T = float(T)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        k, queue = ctx.saved_tensors
+        b, c = k.shape
+        r = queue.shape[1]
+        dq = torch.empty_like(k)
+        L.check(L.lib().mi_moco_logits_bwd(L.ptr(dl.contiguous()), L.ptr(k), L.ptr(queue), L.ptr(dq), b, c, r,
+                                           ctx.T, L.stream()), "mi_moco_logits_bwd")
+        return dq, None, None, None
+
+
+def moco_logits(q, k, queue, T):
+    return _MocoLogitsFn.apply(_f32c(q, "q"), _f32c(k, "k"), _f32c(queue, "queue"), T)
+
+
+class _CELabel0Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits):
+        b, n = logits.shape
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        row = torch.empty(b, dtype=torch.float32, device=logits.device)
+        dl = torch.empty_like(logits)
+        L.check(L.lib().mi_ce_label0(L.ptr(logits), L.ptr(loss), L.ptr(row), L.ptr(dl), b, n, 1.0, L.stream()),
+                "mi_ce_label0")
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g
+
+
+def cross_entropy_label0(logits):
+    """nn.CrossEntropyLoss()(logits, zeros) (trains/tomo_moco_trainer.py:52,73)."""
+    return _CELabel0Fn.apply(_f32c(logits, "logits"))
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser-side passes
+# ------------------------------------------------------------------------------------------------
+def ema_update_(k_flat, q_flat, m):
+    L.check(L.lib().mi_ema_update(L.ptr(k_flat), L.ptr(q_flat), float(m), k_flat.numel(), L.stream()),
+            "mi_ema_update")
+
+
+def sgd_step_(p_flat, g_flat, lr, weight_decay=0.0, lr_dev=None):
+    L.check(L.lib().mi_sgd_step(L.ptr(p_flat), L.ptr(g_flat), L.ptr(lr_dev), float(lr), float(weight_decay),
+                                p_flat.numel(), L.stream()), "mi_sgd_step")
+
+
+def queue_enqueue_(queue, queue_ptr, keys):
+    c, r = queue.shape
+    b = keys.shape[0]
+    if r % b != 0:
+        raise AssertionError("queue size must be a multiple of the batch (models/moco.py:47)")
+    L.check(L.lib().mi_queue_enqueue(L.ptr(queue), L.ptr(queue_ptr), L.ptr(keys), b, c, r, L.stream()),
+            "mi_queue_enqueue")

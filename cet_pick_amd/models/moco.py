@@ -1,0 +1,85 @@
+"""Mirror of cet_pick/models/moco.py (reference models/moco.py:12-162) on the MI355X kernels.
+
+Same constructor, buffers (`queue`, `queue_ptr`) and `forward(im_q, im_k) -> (logits, labels)`.
+Differences (reference defects): labels are created on the logits' device (the
+reference hard-codes .cuda()), nothing is printed per step, the queue pointer never leaves the
+device, and under torch.distributed the keys are all-gathered before the enqueue so every rank
+holds the same queue (canonical MoCo; the reference leaves that to DDP's buffer broadcast).
+"""
+import torch
+import torch.nn as nn
+
+from .. import hipops as H
+
+
+class MoCo(nn.Module):
+    def __init__(self, encoder_q, encoder_k, dim=32, r=1024, m=0.999, T=0.1):
+        super().__init__()
+        self.r, self.m, self.T = r, m, T
+        self.encoder_q = encoder_q
+        self.encoder_k = encoder_k
+        for param_q, param_k in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+            param_k.data.copy_(param_q.data)
+            param_k.requires_grad = False
+        self.register_buffer("queue", torch.randn(dim, r))
+        self.queue = nn.functional.normalize(self.queue, dim=0)
+        self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+        self._arena_q = self._arena_k = None
+
+    # ---- flat arenas (built once the model sits on the GPU) ------------------------------------
+    def flatten_parameters(self):
+        """Re-home both encoders' parameters in flat fp32 arenas: EMA, SGD and the gradient
+        all-reduce then run as single passes.  Call after .cuda()/.to(device)."""
+        if self._arena_q is None or self._arena_q.flat.device != next(self.encoder_q.parameters()).device:
+            self._arena_q = H.ParamArena(self.encoder_q)
+            self._arena_k = H.ParamArena(self.encoder_k)
+            assert self._arena_q.numel == self._arena_k.numel
+        return self._arena_q, self._arena_k
+
+    @torch.no_grad()
+    def _momentum_update_key_encoder(self):
+        """models/moco.py:31-39: k <- m*k + (1-m)*q over parameters (buffers untouched)."""
+        if self._arena_q is not None:
+            H.ema_update_(self._arena_k.flat, self._arena_q.flat, self.m)
+            return
+        for param_q, param_k in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+            # un-flattened model: one launch per tensor over its (dense) storage
+            n = param_q.numel()
+            q = torch.as_strided(param_q.data, (n,), (1,))
+            k = torch.as_strided(param_k.data, (n,), (1,))
+            if n % 4 == 0 and k.data_ptr() % 16 == 0 and q.data_ptr() % 16 == 0:
+                H.ema_update_(k, q, self.m)
+            else:
+                k.mul_(self.m).add_(q, alpha=1.0 - self.m)
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys):
+        """models/moco.py:41-52, on the device (ptr is read and advanced by the kernel)."""
+        H.queue_enqueue_(self.queue, self.queue_ptr, keys.contiguous())
+
+    def forward(self, im_q, im_k):
+        q = self.encoder_q(im_q)[0]["proj"]
+        q = H.l2_normalize(q)
+        with torch.no_grad():
+            self._momentum_update_key_encoder()
+            k = self.encoder_k(im_k)[0]["proj"]
+            k = H.l2_normalize(k)
+        logits = H.moco_logits(q, k, self.queue, self.T)
+        labels = torch.zeros(logits.shape[0], dtype=torch.long, device=logits.device)
+        keys = concat_all_gather(k) if _world_size() > 1 else k
+        self._dequeue_and_enqueue(keys)
+        return logits, labels
+
+
+def _world_size():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+@torch.no_grad()
+def concat_all_gather(tensor):
+    """models/moco.py:149-162: all_gather (RCCL) + cat along the batch; no gradient."""
+    import torch.distributed as dist
+    tensors_gather = [torch.empty_like(tensor) for _ in range(dist.get_world_size())]
+    dist.all_gather(tensors_gather, tensor.contiguous(), async_op=False)
+    return torch.cat(tensors_gather, dim=0)

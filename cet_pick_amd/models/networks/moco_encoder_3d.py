@@ -1,0 +1,158 @@
+"""Mirror of cet_pick/models/networks/moco_encoder_3d.py on the MI355X kernels.
+
+Same class / factory names, constructor arguments, forward / forward_test outputs and state_dict
+keys + logical shapes as the reference (moco_encoder_3d.py:156-236, 326-404, 470-478), so a
+reference checkpoint loads into this module and vice versa.  Internally activations are
+channels-last and every layer runs a hand-written HIP kernel (see cet_pick_amd/hipops.py).
+
+Deliberate differences from the reference file (its defects listed in SURVEY.md §3.1 are not
+reproduced): no per-step print(), `init_weights` does not read a hard-coded lab path, and the
+factory accepts (and ignores) the `last_k` / `local_path` kwargs `create_model` passes.
+"""
+import torch
+import torch.nn as nn
+
+from ... import hipops as H
+
+BN_MOMENTUM = 0.1
+
+
+def fill_fc_weights(layers):
+    """moco_encoder_3d.py:137-154: N(0, 1e-3) weights, conv/linear bias 0 / 0.001."""
+    for m in layers.modules():
+        if isinstance(m, H.HipConv3d):
+            nn.init.normal_(m.weight, std=0.001)
+        elif isinstance(m, H.HipLinear):
+            nn.init.normal_(m.weight, std=0.001)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0.001)
+
+
+class BasicBlock(nn.Module):
+    """moco_encoder_3d.py:55-84 (the BatchNorms are commented out in the reference)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
+        super().__init__()
+        if dilation != 1:
+            raise NotImplementedError("dilation != 1 is not used by the moco3d encoder")
+        self.conv1 = H.HipConv3d(inplanes, planes, 3, stride=stride, pad=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = H.HipConv3d(planes, planes, 3, stride=1, pad=1)
+        self.downsample = downsample
+        self.stride = stride
+        self.dilation = dilation
+
+    def forward(self, x):
+        return H.basic_block(x, self)
+
+
+class TomoResClassifier3D(nn.Module):
+    def __init__(self, block, layers, heads, head_conv):
+        self.inplanes = 64
+        self.heads = heads
+        self.deconv_with_bias = False
+        super().__init__()
+        self.conv1 = H.HipConv3d(1, 64, 7, stride=2, pad=3)
+        self.bn1 = H.HipBatchNorm(64, momentum=BN_MOMENTUM)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.Identity()            # placeholder: pooling runs as a kernel (k3, s2, p1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.feature_3d = nn.Sequential(
+            H.HipConv3d(256 * block.expansion, 256 * block.expansion, 3, stride=1, pad=1),
+            H.HipBatchNorm(256 * block.expansion, momentum=BN_MOMENTUM),
+            nn.ReLU(inplace=True))
+        fill_fc_weights(self.feature_3d)
+        self.avgpool = nn.Identity()
+        self.fc = H.HipLinear(256 * block.expansion, 128)
+        fill_fc_weights(self.fc)
+        for head in self.heads:
+            if "proj" in head:
+                fc = nn.Sequential(H.HipLinear(128, 128, bias=False), H.HipBatchNorm(128), nn.ReLU(inplace=True),
+                                   H.HipLinear(128, 128, bias=False), H.HipBatchNorm(128), nn.ReLU(inplace=True),
+                                   H.HipLinear(128, 128, bias=False), H.HipBatchNorm(128, affine=False))
+            # 'pred' re-registers the module built for 'proj' (moco_encoder_3d.py:195-236: the pred
+            # branch is commented out, so `fc` from the previous iteration is set again)
+            fill_fc_weights(fc)
+            self.__setattr__(head, fc)
+
+    def _make_layer(self, block, planes, blocks, stride=1, dilation=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(H.HipConv3d(self.inplanes, planes * block.expansion, 1, stride=stride, pad=0))
+        layers = [block(self.inplanes, planes, stride, dilation=dilation, downsample=downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, dilation=dilation))
+        return nn.Sequential(*layers)
+
+    # ---- the trunk, channels-last -------------------------------------------------------------
+    def _trunk(self, x1):
+        b, c, d, h, w = x1.shape
+        if c != 1:
+            raise ValueError("the moco3d encoder takes single-channel sub-tomograms (B,1,D,H,W)")
+        x = x1.contiguous().float().view(b, d, h, w, 1)      # C == 1: NCDHW is already channels-last
+        x = self.conv1(x)
+        x = self.bn1(x, relu=True)
+        x = H.maxpool3d(x, 3, 2, 1)
+        for blk in self.layer1:
+            x = blk(x)
+        for blk in self.layer2:
+            x = blk(x)
+        for blk in self.layer3:
+            x = blk(x)
+        x = self.feature_3d[0](x)
+        x = self.feature_3d[1](x, relu=True)
+        x = H.global_avgpool(x)
+        return self.fc(x)
+
+    def _head(self, head, x):
+        seq = self.__getattr__(head)
+        x = seq[1](seq[0](x), relu=True)
+        x = seq[4](seq[3](x), relu=True)
+        return seq[7](seq[6](x))
+
+    def forward_test(self, x1):
+        """moco_encoder_3d.py:326-351: {'proj': z.detach()}."""
+        x = self._trunk(x1)
+        ret1 = {}
+        for head in self.heads:
+            if "proj" in head:
+                ret1[head] = self._head(head, x).detach()
+        return ret1
+
+    def forward(self, x1):
+        """moco_encoder_3d.py:353-404: [{'proj': z}]."""
+        x = self._trunk(x1)
+        ret1 = {}
+        for head in self.heads:
+            if "proj" in head:
+                ret1[head] = self._head(head, x)
+        return [ret1]
+
+    def init_weights(self, num_layers, local_path=None):
+        """moco_encoder_3d.py:441-459 loads a ResNet-18 checkpoint from a fixed path; here the path
+        is a parameter and a missing file leaves the random init (the reference would raise)."""
+        if local_path is None:
+            return
+        ckpt = torch.load(local_path, map_location="cpu")
+        sd = ckpt.get("state_dict", ckpt)
+        sd = {(k[7:] if k.startswith("module") and not k.startswith("module_list") else k): v for k, v in sd.items()}
+        if "conv1.weight" in sd and sd["conv1.weight"].shape[1] == 3:
+            sd["conv1.weight"] = sd["conv1.weight"].sum(dim=1, keepdim=True)
+        own = self.state_dict()
+        sd = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
+        self.load_state_dict(sd, strict=False)
+
+
+resnet_spec = {18: (BasicBlock, [2, 2, 2, 2]),
+               34: (BasicBlock, [3, 4, 6, 3])}
+
+
+def get_moco_net_small_3d(num_layers, heads, head_conv=32, last_k=0, local_path=None):
+    block_class, layers = resnet_spec[num_layers]
+    model = TomoResClassifier3D(block_class, layers, heads, head_conv=0)
+    model.init_weights(num_layers, local_path)
+    return model

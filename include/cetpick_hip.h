@@ -94,6 +94,98 @@ int mi_greedy_nms3d(const float* vol, int D, int H, int W, float d, float scale,
                     float* scores, int32_t* coords, int32_t* n_out, int max_out, void* workspace,
                     size_t workspace_bytes, mi_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Training path: channels-last fp32 activations (N,D,H,W,C),
+ * weights [tap][Cin][Cout] with tap = (kd*k + kh)*k + kw.
+ * ------------------------------------------------------------------------------------------ */
+
+/* nn.Conv3d (cubic kernel k, stride, pad, no bias) / nn.Linear (k=1, D=H=W=1) as implicit GEMM
+ * on v_mfma_f32_32x32x2_f32.  Replaces models/networks/moco_encoder_3d.py:40-84 (conv3x3x3,
+ * BasicBlock), :163-169 (7x7x7 stem, Ci == 1), :183, :189, :198-205 (feature conv, fc, proj).
+ * Ci % 16 == 0 (or Ci == 1), Co % 16 == 0.
+ *   fwd:   y  = act(conv(x, w) + res)                 res may be NULL, relu 0/1
+ *   dgrad: dx = (conv_transpose(dy, w) + res) * (mask > 0)     res, mask may be NULL
+ *   wgrad: dw = sum over output voxels
+ * `ws` holds split-K slabs (mi_conv3d_workspace_bytes covers all three); a NULL / short ws
+ * silently selects the unsplit schedule (same values up to fp32 summation order). */
+size_t mi_conv3d_workspace_bytes(int N, int Di, int Hi, int Wi, int Ci, int Co, int k, int stride,
+                                 int pad);
+int mi_conv3d_fwd_f32(const float* x, const float* w, float* y, const float* res, int relu, int N,
+                      int Di, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad, void* ws,
+                      size_t ws_bytes, mi_stream_t stream);
+int mi_conv3d_dgrad_f32(const float* dy, const float* w, float* dx, const float* res,
+                        const float* mask, int N, int Di, int Hi, int Wi, int Ci, int Co, int k,
+                        int stride, int pad, void* ws, size_t ws_bytes, mi_stream_t stream);
+int mi_conv3d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int Di, int Hi, int Wi,
+                        int Ci, int Co, int k, int stride, int pad, void* ws, size_t ws_bytes,
+                        mi_stream_t stream);
+
+/* nn.BatchNorm3d / BatchNorm1d over rows [M][C] (moco_encoder_3d.py:170,184,199-205), split so a
+ * SyncBN all-reduce of `sums` (2*C doubles: sum x, sum x^2) fits between stats and apply.
+ * count = rows behind `sums` (global M under SyncBN).  save = mean[C], invstd[C].
+ * gamma/beta NULL = affine=False.  running stats NULL = not tracked.  C % 4 == 0, 256 % (C/4) == 0. */
+size_t mi_colreduce_workspace_bytes(long M, int C);
+int mi_bn_stats(const float* x, long M, int C, double* sums, void* ws, size_t ws_bytes,
+                mi_stream_t stream);
+int mi_bn_apply_fwd(const float* x, float* y, long M, int C, const double* sums, double count,
+                    const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, float* save_mean_invstd, int relu,
+                    mi_stream_t stream);
+int mi_bn_eval_fwd(const float* x, float* y, long M, int C, const float* running_mean,
+                   const float* running_var, const float* gamma, const float* beta, float eps,
+                   float* scratch_2c, int relu, mi_stream_t stream);
+/* backward: sums = {sum dy', sum dy'*xhat} with dy' = dy*(y>0) when relu; then
+ * dx = gamma*invstd*(dy' - sums[0]/count - xhat*sums[1]/count), dgamma = sums[1], dbeta = sums[0]. */
+int mi_bn_bwd_reduce(const float* dy, const float* x, const float* y, long M, int C,
+                     const float* save_mean_invstd, int relu, double* sums, void* ws,
+                     size_t ws_bytes, mi_stream_t stream);
+int mi_bn_bwd_apply(const float* dy, const float* x, const float* y, float* dx, long M, int C,
+                    const float* save_mean_invstd, const float* gamma, const double* sums,
+                    double count, int relu, float* dgamma, float* dbeta, mi_stream_t stream);
+/* column sum (bias gradient of nn.Linear, moco_encoder_3d.py:189): out[c] = sum_m dy[m][c] */
+int mi_colsum(const float* dy, long M, int C, float* out, double* sums_scratch, void* ws,
+              size_t ws_bytes, mi_stream_t stream);
+
+/* nn.MaxPool3d(k, stride, pad) (moco_encoder_3d.py:172), argmax tap kept per element (uint8,
+ * first maximum in (kd,kh,kw) scan order, as torch); backward routes dy to that element. */
+int mi_maxpool3d_fwd(const float* x, float* y, uint8_t* argmax, int N, int Di, int Hi, int Wi,
+                     int C, int k, int stride, int pad, mi_stream_t stream);
+int mi_maxpool3d_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, int Di, int Hi,
+                     int Wi, int C, int k, int stride, int pad, mi_stream_t stream);
+/* nn.AdaptiveAvgPool3d(1) (moco_encoder_3d.py:188): x [B][S][C] -> y [B][C] */
+int mi_avgpool_fwd(const float* x, float* y, int B, int S, int C, mi_stream_t stream);
+int mi_avgpool_bwd(const float* dy, float* dx, int B, int S, int C, mi_stream_t stream);
+int mi_bias_add(float* y, const float* bias, long M, int C, mi_stream_t stream);
+/* out = (dy + add) * (y > 0)   (ReLU backward; add may be NULL; n % 4 == 0) */
+int mi_relu_mask(const float* dy, const float* y, const float* add, float* out, long n,
+                 mi_stream_t stream);
+
+/* F.normalize(x, dim=1) and the MoCo logits (models/moco.py:111-138):
+ * logits[b] = [q_b.k_b, q_b.queue] / T, queue is [C][R]. */
+int mi_l2norm_fwd(const float* x, float* y, float* inv_norm, int B, int C, mi_stream_t stream);
+int mi_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int B, int C,
+                  mi_stream_t stream);
+int mi_moco_logits_fwd(const float* q, const float* k, const float* queue, float* logits, int B,
+                       int C, int R, float T, mi_stream_t stream);
+int mi_moco_logits_bwd(const float* dlogits, const float* k, const float* queue, float* dq, int B,
+                       int C, int R, float T, mi_stream_t stream);
+/* nn.CrossEntropyLoss against label 0 (trains/tomo_moco_trainer.py:52,73; models/moco.py:141):
+ * loss = mean_b(logsumexp(l_b) - l_b[0]); dlogits = grad_scale*(softmax - onehot0)/B (may be NULL). */
+int mi_ce_label0(const float* logits, float* loss, float* row_loss, float* dlogits, int B, int n,
+                 float grad_scale, mi_stream_t stream);
+
+/* models/moco.py:31-39: k <- m*k + (1-m)*q over a flat parameter arena (16-B aligned). */
+int mi_ema_update(float* k, const float* q, float m, long n, mi_stream_t stream);
+/* torch.optim.SGD (moco_main.py:79, no momentum): p <- p - lr*(g + wd*p).  lr_dev (device float,
+ * may be NULL -> lr) lets a captured graph follow the schedule. */
+int mi_sgd_step(float* p, const float* g, const float* lr_dev, float lr, float weight_decay, long n,
+                mi_stream_t stream);
+/* models/moco.py:41-52: queue[:, ptr:ptr+B] = keys.T; ptr = (ptr+B) % R, ptr read and advanced on
+ * the device (no host sync).  R % B == 0 as the reference asserts. */
+int mi_queue_enqueue(float* queue, int64_t* queue_ptr, const float* keys, int B, int C, int R,
+                     mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,117 @@
+"""Oracle for the training path: plain torch fp32 on the CPU.
+
+TEST INFRASTRUCTURE ONLY - see oracle/__init__.py.  A functional restatement (state_dict in,
+tensors out) of the reference encoder / MoCo step, pinned by tests/golden/enc3d.npz and
+tests/golden/moco_3steps.npz which were produced by the reference's own modules.
+"""
+import copy
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_MOMENTUM = 0.1
+
+
+def _bn(sd, prefix, x, train, momentum, affine=True):
+    """nn.BatchNorm (train: batch stats + running-stat update in place in `sd`)."""
+    w = sd.get(prefix + ".weight") if affine else None
+    b = sd.get(prefix + ".bias") if affine else None
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], w, b,
+                        training=train, momentum=momentum, eps=1e-5)
+
+
+def _block(sd, prefix, x, stride):
+    """moco_encoder_3d.py:55-84 BasicBlock (no BN)."""
+    out = F.relu(F.conv3d(x, sd[prefix + ".conv1.weight"], stride=stride, padding=1))
+    out = F.conv3d(out, sd[prefix + ".conv2.weight"], padding=1)
+    res = x
+    if prefix + ".downsample.0.weight" in sd:
+        res = F.conv3d(x, sd[prefix + ".downsample.0.weight"], stride=stride)
+    return F.relu(out + res)
+
+
+def encoder_forward(sd, x, train=True, acts=None):
+    """moco_encoder_3d.py:353-404 (`forward`) / :326-351 (`forward_test` when train=False).
+    sd: dict name -> tensor with the reference's logical shapes; running stats are updated in
+    place when train.  Returns proj (B,128)."""
+    def rec(name, t):
+        if acts is not None:
+            acts[name] = t
+        return t
+    x = rec("conv1", F.conv3d(x, sd["conv1.weight"], stride=2, padding=3))
+    x = rec("bn1", _bn(sd, "bn1", x, train, BN_MOMENTUM))
+    x = F.relu(x)
+    x = rec("maxpool", F.max_pool3d(x, 3, stride=2, padding=1))
+    for li, stride in ((1, 1), (2, 2), (3, 2)):
+        for bi in range(2):
+            x = _block(sd, "layer%d.%d" % (li, bi), x, stride if bi == 0 else 1)
+        rec("layer%d" % li, x)
+    x = F.conv3d(x, sd["feature_3d.0.weight"], padding=1)
+    x = rec("feature_3d", F.relu(_bn(sd, "feature_3d.1", x, train, BN_MOMENTUM)))
+    x = F.adaptive_avg_pool3d(x, 1).reshape(x.shape[0], -1)
+    x = rec("fc", F.linear(x, sd["fc.weight"], sd["fc.bias"]))
+    x = F.relu(_bn(sd, "proj.1", F.linear(x, sd["proj.0.weight"]), train, 0.1))
+    x = F.relu(_bn(sd, "proj.4", F.linear(x, sd["proj.3.weight"]), train, 0.1))
+    x = _bn(sd, "proj.7", F.linear(x, sd["proj.6.weight"]), train, 0.1, affine=False)
+    return x
+
+
+PARAM_SUFFIX = (".weight", ".bias")
+
+
+def param_names(sd):
+    """Parameter (not buffer) names in module order, 'pred.*' aliases of 'proj.*' dropped."""
+    return [k for k in sd if k.endswith(PARAM_SUFFIX) and not k.startswith("pred.")]
+
+
+def moco_logits(q, k, queue, T):
+    """models/moco.py:111-138."""
+    l_pos = torch.einsum("nc,nc->n", [q, k]).unsqueeze(-1)
+    l_neg = torch.einsum("nc,ck->nk", [q, queue.clone().detach()])
+    return torch.cat([l_pos, l_neg], dim=1) / T
+
+
+class MocoRef:
+    """models/moco.py:12-146 + trains/tomo_moco_trainer.py:52,73 + SGD (moco_main.py:79) as one
+    functional step over two state_dicts."""
+
+    def __init__(self, sd_q, queue, m=0.999, T=0.1, lr=0.05):
+        self.q = {k: v.clone() for k, v in sd_q.items()}
+        self.k = {k: v.clone() for k, v in sd_q.items()}
+        self.queue = queue.clone()
+        self.ptr = 0
+        self.m, self.T, self.lr = m, T, lr
+        self.names = param_names(self.q)
+
+    def step(self, im_q, im_k):
+        for n in self.names:
+            self.q[n] = self.q[n].detach().requires_grad_(True)
+        self.q.update({("pred" + n[4:]): self.q[n] for n in self.names if n.startswith("proj.")})
+        qf = F.normalize(encoder_forward(self.q, im_q, True), dim=1)
+        with torch.no_grad():
+            for n in self.names:                                    # moco.py:31-39
+                self.k[n] = self.k[n] * self.m + self.q[n].detach() * (1.0 - self.m)
+            kf = F.normalize(encoder_forward(self.k, im_k, True), dim=1)
+        logits = moco_logits(qf, kf, self.queue, self.T)
+        labels = torch.zeros(logits.shape[0], dtype=torch.long)
+        b = kf.shape[0]
+        assert self.queue.shape[1] % b == 0                          # moco.py:47
+        self.queue[:, self.ptr:self.ptr + b] = kf.T                  # moco.py:49
+        self.ptr = (self.ptr + b) % self.queue.shape[1]
+        loss = F.cross_entropy(logits, labels)
+        grads = torch.autograd.grad(loss, [self.q[n] for n in self.names])
+        with torch.no_grad():
+            for n, g in zip(self.names, grads):
+                self.q[n] = (self.q[n] - self.lr * g).detach()
+        return logits.detach(), float(loss.detach()), {n: g for n, g in zip(self.names, grads)}
+
+
+def adjust_learning_rate(lr, epoch, lr_step, lr_decay_rate, cosine=False, num_epochs=None):
+    """utils/utils.py:58-70."""
+    if cosine:
+        eta_min = lr * (lr_decay_rate ** 3)
+        return eta_min + (lr - eta_min) * (1 + math.cos(math.pi * epoch / num_epochs)) / 2
+    steps = int(np.sum(epoch > np.asarray(lr_step)))
+    return lr * (lr_decay_rate ** steps) if steps > 0 else lr

@@ -1,0 +1,273 @@
+"""GPU parity of the training path (through the C-ABI) against the torch-CPU oracle and the
+golden vectors generated from the reference.  fp32 tolerance 1e-3 (north_star), usually far
+tighter because the f32 MFMA is an exact fmaf chain."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def cl(x):  # NCDHW -> channels-last contiguous on the GPU
+    return x.permute(0, 2, 3, 4, 1).contiguous().cuda()
+
+
+def ncdhw(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+
+def make_w(co, ci, k, g):
+    from cet_pick_amd import hipops as H
+    p = H.conv_weight_param(co, ci, k)
+    w = torch.randn(co, ci, k, k, k, generator=g) * (2.0 / (ci * k ** 3)) ** 0.5
+    with torch.no_grad():
+        p.copy_(w)
+    p.data = p.data.cuda()
+    return p, w
+
+
+CASES = [
+    # N, D, H, W, Ci, Co, k, stride, pad
+    (2, 8, 8, 8, 64, 64, 3, 1, 1),
+    (2, 8, 8, 8, 64, 128, 3, 2, 1),
+    (3, 4, 4, 4, 128, 128, 3, 1, 1),
+    (2, 8, 8, 8, 64, 128, 1, 2, 0),
+    (4, 2, 2, 2, 256, 256, 3, 1, 1),
+    (1, 5, 6, 7, 16, 32, 3, 1, 1),       # non power-of-two grid
+    (2, 7, 5, 6, 32, 16, 3, 2, 1),
+    (2, 16, 16, 16, 1, 64, 7, 2, 3),     # stem
+    (64, 1, 1, 1, 256, 128, 1, 1, 0),    # linear
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+    from cet_pick_amd import hipops as H
+    n, d, h, w_, ci, co, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, ci, d, h, w_, generator=g)
+    param, w = make_w(co, ci, k, g)
+    assert H._phys_ok(param)
+    y = H.conv_fwd(cl(x), param, k, s, p)
+    y_ref = F.conv3d(x, w, stride=s, padding=p)
+    np.testing.assert_allclose(ncdhw(y).numpy(), y_ref.numpy(), rtol=1e-4, atol=1e-4)
+    # fused epilogue: residual + relu
+    res = torch.randn(y_ref.shape, generator=g)
+    y2 = H.conv_fwd(cl(x), param, k, s, p, cl(res), True)
+    np.testing.assert_allclose(ncdhw(y2).numpy(), F.relu(y_ref + res).numpy(), rtol=1e-4, atol=1e-4)
+    dy = torch.randn(y_ref.shape, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv3d(xr, wr, stride=s, padding=p).backward(dy)
+    if ci != 1:
+        dx = H.conv_dgrad(cl(dy), param, (n, d, h, w_, ci), k, s, p)
+        np.testing.assert_allclose(ncdhw(dx).numpy(), xr.grad.numpy(), rtol=1e-4, atol=2e-4)
+        mask = torch.randn(x.shape, generator=g)
+        r2 = torch.randn(x.shape, generator=g)
+        dx2 = H.conv_dgrad(cl(dy), param, (n, d, h, w_, ci), k, s, p, cl(r2), cl(mask))
+        np.testing.assert_allclose(ncdhw(dx2).numpy(), ((xr.grad + r2) * (mask > 0)).numpy(), rtol=1e-4, atol=2e-4)
+    param.grad = None
+    H.conv_wgrad_into(cl(x), cl(dy), param, k, s, p)
+    scale = float(wr.grad.abs().max())
+    np.testing.assert_allclose(param.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol=2e-5 * max(scale, 1.0))
+    # second call accumulates (AccumulateGrad contract)
+    H.conv_wgrad_into(cl(x), cl(dy), param, k, s, p)
+    np.testing.assert_allclose(param.grad.cpu().numpy(), 2 * wr.grad.numpy(), rtol=1e-4, atol=4e-5 * max(scale, 1.0))
+
+
+@pytest.mark.parametrize("shape", [(4, 16, 16, 16, 64), (8, 2, 2, 2, 256), (64, 128), (6, 3, 5, 7, 32)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_batchnorm_train_fwd_bwd(shape, relu):
+    from cet_pick_amd import hipops as H
+    g = torch.Generator().manual_seed(len(shape) + int(relu))
+    c = shape[-1]
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    bn = H.HipBatchNorm(c).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, generator=g) * 0.1)
+    ref = torch.nn.BatchNorm1d(c)
+    with torch.no_grad():
+        ref.weight.copy_(bn.weight.cpu()); ref.bias.copy_(bn.bias.cpu())
+    xg = x.cuda().requires_grad_(True)
+    y = bn(xg, relu=relu)
+    xr = x.reshape(-1, c).clone().requires_grad_(True)
+    yr = ref(xr)
+    if relu:
+        yr = F.relu(yr)
+    np.testing.assert_allclose(y.detach().cpu().reshape(-1, c).numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-5)
+    dy = torch.randn(shape, generator=g)
+    y.backward(dy.cuda())
+    yr.backward(dy.reshape(-1, c))
+    np.testing.assert_allclose(xg.grad.cpu().reshape(-1, c).numpy(), xr.grad.numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+    bn.eval(); ref.eval()
+    ye = bn(x.cuda(), relu=relu)
+    yre = F.relu(ref(x.reshape(-1, c))) if relu else ref(x.reshape(-1, c))
+    np.testing.assert_allclose(ye.cpu().reshape(-1, c).numpy(), yre.detach().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_maxpool_avgpool():
+    from cet_pick_amd import hipops as H
+    g = torch.Generator().manual_seed(4)
+    x = F.relu(torch.randn(3, 64, 16, 12, 10, generator=g))     # ReLU'd input: many exact-zero ties
+    xg = cl(x).requires_grad_(True)
+    y = H.maxpool3d(xg, 3, 2, 1)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool3d(xr, 3, stride=2, padding=1)
+    np.testing.assert_array_equal(ncdhw(y.detach()).numpy(), yr.detach().numpy())
+    dy = torch.randn(yr.shape, generator=g)
+    y.backward(cl(dy))
+    yr.backward(dy)
+    np.testing.assert_allclose(ncdhw(xg.grad).numpy(), xr.grad.numpy(), rtol=1e-6, atol=1e-6)
+    a = cl(x).requires_grad_(True)
+    p = H.global_avgpool(a)
+    np.testing.assert_allclose(p.detach().cpu().numpy(), x.mean(dim=(2, 3, 4)).numpy(), rtol=1e-5, atol=1e-6)
+    p.backward(torch.ones_like(p))
+    np.testing.assert_allclose(a.grad.cpu().numpy(), np.full(a.shape, 1.0 / (16 * 12 * 10), np.float32), rtol=1e-6)
+
+
+def test_head_kernels():
+    from cet_pick_amd import hipops as H
+    g = torch.Generator().manual_seed(8)
+    B, C, R, T = 16, 128, 256, 0.1
+    q0 = torch.randn(B, C, generator=g); k0 = torch.randn(B, C, generator=g)
+    queue = F.normalize(torch.randn(C, R, generator=g), dim=0)
+    qg = q0.cuda().requires_grad_(True)
+    qn = H.l2_normalize(qg)
+    kn = H.l2_normalize(k0.cuda())
+    logits = H.moco_logits(qn, kn, queue.cuda(), T)
+    loss = H.cross_entropy_label0(logits)
+    loss.backward()
+    qr = q0.clone().requires_grad_(True)
+    qrn = F.normalize(qr, dim=1); krn = F.normalize(k0, dim=1)
+    lr = torch.cat([(qrn * krn).sum(1, keepdim=True), qrn @ queue], 1) / T
+    lossr = F.cross_entropy(lr, torch.zeros(B, dtype=torch.long))
+    lossr.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), lr.detach().numpy(), rtol=1e-4, atol=1e-4)
+    assert abs(float(loss) - float(lossr)) < 1e-5
+    np.testing.assert_allclose(qg.grad.cpu().numpy(), qr.grad.numpy(), rtol=1e-3, atol=1e-6)
+
+
+def test_ema_sgd_enqueue():
+    from cet_pick_amd import hipops as H
+    g = torch.Generator().manual_seed(9)
+    n = 1000 * 4 + 3
+    q = torch.randn(n + 1, generator=g)[:n].clone(); k = torch.randn(n, generator=g); gr = torch.randn(n, generator=g)
+    qd, kd, gd = q.cuda(), k.cuda(), gr.cuda()
+    H.ema_update_(kd, qd, 0.99)
+    np.testing.assert_allclose(kd.cpu().numpy(), (k * 0.99 + q * (1.0 - 0.99)).numpy(), rtol=1e-6, atol=1e-7)
+    H.sgd_step_(qd, gd, 0.05)
+    np.testing.assert_allclose(qd.cpu().numpy(), (q - 0.05 * gr).numpy(), rtol=1e-6, atol=1e-7)
+    queue = torch.zeros(8, 12).cuda(); ptr = torch.zeros(1, dtype=torch.long).cuda()
+    ref = torch.zeros(8, 12); p = 0
+    for it in range(5):
+        keys = torch.randn(4, 8, generator=g)
+        H.queue_enqueue_(queue, ptr, keys.cuda())
+        ref[:, p:p + 4] = keys.T; p = (p + 4) % 12
+        np.testing.assert_array_equal(queue.cpu().numpy(), ref.numpy())
+        assert int(ptr) == p
+    with pytest.raises(AssertionError):
+        H.queue_enqueue_(queue, ptr, torch.randn(5, 8).cuda())
+
+
+def _seeded_encoder():
+    from cet_pick_amd.models.networks.moco_encoder_3d import TomoResClassifier3D, BasicBlock
+    from cet_pick_amd.synthetic import seeded_state_dict
+    enc = TomoResClassifier3D(BasicBlock, [2, 2, 2, 2], {"proj": 256, "pred": 256}, 0)
+    enc.load_state_dict(seeded_state_dict(enc, seed=317))
+    return enc.cuda()
+
+
+def test_encoder_matches_reference_golden(golden):
+    g = golden("enc3d.npz")
+    enc = _seeded_encoder()
+    x = torch.randn(4, 1, 32, 32, 32, generator=torch.Generator().manual_seed(99))
+    enc.train()
+    out = enc(x.cuda())[0]["proj"]
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["proj_train"], rtol=1e-3, atol=1e-3)
+    loss = (out * torch.linspace(-1, 1, 128).cuda()[None]).sum() + (out ** 2).sum() * 0.1
+    loss.backward()
+    idx = g["sample_idx"]
+    for n, p in enc.named_parameters():
+        if f"grad_{n}_norm" not in g.files:
+            continue
+        assert p.grad is not None, n
+        # logical (reference) element order
+        gf = p.grad.detach().cpu().contiguous().reshape(-1).numpy()
+        ref_norm = float(g[f"grad_{n}_norm"])
+        assert abs(np.linalg.norm(gf.astype(np.float64)) - ref_norm) <= 2e-3 * ref_norm + 1e-6, n
+        ref_s = g[f"grad_{n}_sample"]
+        np.testing.assert_allclose(gf[idx % gf.size], ref_s, rtol=2e-3, atol=2e-3 * float(np.abs(ref_s).max()) + 1e-7,
+                                   err_msg=n)
+    np.testing.assert_allclose(enc.bn1.running_mean.cpu().numpy(), g["bn1_running_mean"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(enc.bn1.running_var.cpu().numpy(), g["bn1_running_var"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(enc.proj[7].running_var.cpu().numpy(), g["proj7_running_var"], rtol=1e-3, atol=1e-5)
+    enc2 = _seeded_encoder()
+    enc2.eval()
+    ev = enc2.forward_test(x.cuda())["proj"]
+    np.testing.assert_allclose(ev.cpu().numpy(), g["proj_eval"], rtol=1e-3, atol=1e-3)
+
+
+def test_state_dict_roundtrip_with_reference_layout(tmp_path):
+    """Checkpoints keep the reference's keys and logical shapes; values survive save -> load."""
+    enc = _seeded_encoder()
+    keys = json.load(open(os.path.join(HERE, "golden", "ckpt_keys.json")))["moco3d_encoder"]
+    sd = enc.state_dict()
+    assert list(sd.keys()) == list(keys.keys())
+    path = str(tmp_path / "m.pth")
+    torch.save({"epoch": 1, "state_dict": {k: v.detach().cpu().contiguous().clone() for k, v in sd.items()}}, path)
+    enc2 = _seeded_encoder()
+    with torch.no_grad():
+        for p in enc2.parameters():
+            p.zero_()
+    enc2.load_state_dict(torch.load(path)["state_dict"])
+    for (k, a), (_, b) in zip(enc.state_dict().items(), enc2.state_dict().items()):
+        assert torch.equal(a.cpu(), b.cpu()), k
+        assert list(a.shape) == keys[k]
+
+
+def test_moco_three_steps_match_reference(golden):
+    """MoCo.forward + CE + SGD for 3 steps against the reference run (moco_3steps.npz)."""
+    from cet_pick_amd.models.moco import MoCo
+    from cet_pick_amd import hipops as H
+    g = golden("moco_3steps.npz")
+    torch.manual_seed(7)
+    q, k = _seeded_encoder(), _seeded_encoder()
+    moco = MoCo(q, k, dim=128, r=64, m=0.99, T=0.1).cuda()
+    assert list(moco.state_dict().keys()) == [str(s) for s in g["state_keys"]]
+    moco.queue.copy_(torch.from_numpy(g["queue0"]).cuda())
+    aq, ak = moco.flatten_parameters()
+    gen = torch.Generator().manual_seed(123)
+    torch.randn(128, 64, generator=gen)
+    B = 8
+    moco.train()
+    for step in range(3):
+        im_q = torch.randn(B, 1, 32, 32, 32, generator=gen)
+        im_k = im_q.flip(4) + 0.1 * torch.randn(B, 1, 32, 32, 32, generator=gen)
+        aq.zero_grad()
+        logits, labels = moco(im_q.cuda(), im_k.cuda())
+        loss = H.cross_entropy_label0(logits)
+        loss.backward()
+        H.sgd_step_(aq.flat, aq.flat_grad, 0.05)
+        tol = 1e-3 if step == 0 else 1e-2
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), g[f"logits_{step}"], rtol=tol, atol=tol)
+        assert abs(float(loss) - float(g[f"loss_{step}"])) < tol
+        assert int(moco.queue_ptr) == int(g[f"ptr_{step}"])
+        assert labels.dtype == torch.long and int(labels.sum()) == 0
+    np.testing.assert_allclose(moco.queue.cpu().numpy(), g["queue_final"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(moco.encoder_q.fc.weight.detach().cpu().numpy(), g["q_fc_weight"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(moco.encoder_k.fc.weight.detach().cpu().numpy(), g["k_fc_weight"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(moco.encoder_q.layer1[0].conv1.weight.detach().cpu().contiguous().reshape(-1)[::997].numpy(),
+                               g["q_l1c1_sample"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(moco.encoder_k.layer1[0].conv1.weight.detach().cpu().contiguous().reshape(-1)[::997].numpy(),
+                               g["k_l1c1_sample"], rtol=0, atol=1e-3)
