@@ -1,0 +1,253 @@
+"""Driver benchmark.  `python bench.py --gpus N --steps K --warmup W` (N>1: one rank per GPU under
+torch.distributed.run, RCCL).  Prints ONE JSON line on rank 0.
+
+step      = one MoCo-3D training step (BASELINE.json configs[1]): q forward + EMA + k forward +
+            InfoNCE + backward + SGD on a batch of 64 pairs of 32^3 sub-tomogram views cut from a
+            synthetic 128x512x512 tomogram; inputs are resident in HBM before the timed region.
+value     = sub-tomograms/s over all ranks (one PAIR of views counts as one sub-tomogram).
+roofline  = conv_igemm_kernel (every conv / linear fwd, dgrad, wgrad launch): algorithmic FLOPs
+            2*M*N*K per launch / HIP-event duration per launch, vs the gfx950 fp32 matrix peak.
+secondary = the inference half of the metric (voxels/s of sigmoid+NMS+top-K decode and of the DoG
+            particle picker) with its own HBM roofline.
+cpu_baseline = the CPU oracle (oracle/train_ref.py, torch fp32 on the host cores) on the same step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
+FLOP_PER_SUBTOMO = 3.66e9        # q fwd+bwd 2.70 + k fwd 0.96 GFLOP
+
+
+def build_views(tomo_dev, n_crops, crop, seed):
+    """Two views per crop centre: the z-normalised crop, and the crop shifted by <=1 voxel and
+    flipped along x.  Returns (pool_q, pool_k) of shape (n,1,c,c,c) on device."""
+    g = np.random.default_rng(seed)
+    Z, H, W = tomo_dev.shape
+    h = crop // 2
+    cz = g.integers(h + 1, Z - h - 1, n_crops)
+    cy = g.integers(h + 1, H - h - 1, n_crops)
+    cx = g.integers(h + 1, W - h - 1, n_crops)
+    sh = g.integers(-1, 2, (n_crops, 3))
+    pq = torch.empty((n_crops, 1, crop, crop, crop), dtype=torch.float32, device=tomo_dev.device)
+    pk = torch.empty_like(pq)
+    for i in range(n_crops):
+        z, y, x = int(cz[i]), int(cy[i]), int(cx[i])
+        a = tomo_dev[z - h:z + h, y - h:y + h, x - h:x + h]
+        z2, y2, x2 = z + int(sh[i, 0]), y + int(sh[i, 1]), x + int(sh[i, 2])
+        b = tomo_dev[z2 - h:z2 + h, y2 - h:y2 + h, x2 - h:x2 + h].flip(2)
+        pq[i, 0] = a
+        pk[i, 0] = b
+    for p in (pq, pk):
+        m = p.mean(dim=(2, 3, 4), keepdim=True)
+        s = p.std(dim=(2, 3, 4), keepdim=True)
+        p.sub_(m).div_(s)
+    return pq, pk
+
+
+def conv_profile(engine, pq, pk, batch, steps):
+    """Eager steps with a HIP-event pair around every conv_igemm launch (events are recorded on the
+    stream the kernels are launched on)."""
+    from cet_pick_amd import hipops as H
+    H.PROFILE = []
+    saved = engine.use_graph
+    engine.use_graph = False
+    for i in range(steps):
+        o = (i * batch) % (pq.shape[0] - batch + 1)
+        engine.step(pq[o:o + batch], pk[o:o + batch])
+    torch.cuda.synchronize()
+    recs = H.PROFILE
+    H.PROFILE = None
+    engine.use_graph = saved
+    tot_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in recs)
+    tot_flop = sum(f for _, f, _, _ in recs)
+    by = {}
+    for tag, f, e0, e1 in recs:
+        d = by.setdefault(tag, [0, 0.0, 0.0])
+        d[0] += 1; d[1] += f; d[2] += e0.elapsed_time(e1)
+    return tot_flop, tot_ms, len(recs), by
+
+
+def cpu_baseline(batch, steps, seed):
+    from oracle import train_ref as T
+    from cet_pick_amd.synthetic import seeded_state_dict
+    from cet_pick_amd.models.networks.moco_encoder_3d import TomoResClassifier3D, BasicBlock
+    torch.set_num_threads(os.cpu_count() or 1)
+    enc = TomoResClassifier3D(BasicBlock, [2, 2, 2, 2], {"proj": 256, "pred": 256}, 0)
+    sd = {k: v.detach().clone().contiguous() for k, v in seeded_state_dict(enc, seed=seed).items()}
+    for k in list(sd):
+        if k.startswith("pred."):
+            sd["proj." + k[5:]] = sd[k]
+    g = torch.Generator().manual_seed(seed)
+    queue = torch.nn.functional.normalize(torch.randn(128, 1024, generator=g), dim=0)
+    ref = T.MocoRef(sd, queue, m=0.999, T=0.1, lr=1e-3)
+    xq = torch.randn(batch, 1, 32, 32, 32, generator=g)
+    xk = xq.flip(4)
+    ref.step(xq, xk)                    # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ref.step(xq, xk)
+    dt = time.perf_counter() - t0
+    return batch * steps / dt, torch.get_num_threads()
+
+
+def inference_secondary(dev):
+    """voxels/s of the inference half on BASELINE configs[2] sizes (one rank, after the timed region)."""
+    from cet_pick_amd.synthetic import make_tomo, make_logits
+    from cet_pick_amd.models import decode as Dm
+    from cet_pick_amd.utils import image as Im
+
+    def timeit(fn, n, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    logits = torch.as_tensor(make_logits((128, 256, 256), seed=317)).to(dev)[None, None]
+    ms_dec = timeit(lambda: Dm.sigmoid_tomo_decode(logits, kernel=3, K=900), 20)
+    vol, _ = make_tomo((256, 512, 512), seed=317)
+    v = torch.as_tensor(vol).to(dev)
+    ms_dog = timeit(lambda: Im.dog_pick(v, [3, 5]), 5)
+    n_dec, n_dog = logits.numel(), v.numel()
+    return {
+        "metric": "voxels/sec (heatmap+NMS)",
+        "decode_sigmoid_nms_topk": {"workload": "logits 1x1x128x256x256, k=3, K=900", "ms": round(ms_dec, 4),
+                                    "voxels_per_sec": n_dec / ms_dec * 1e3,
+                                    "hbm_frac_8B_per_voxel": n_dec * 8 / ms_dec * 1e3 / 1e9 / PEAK_HBM_GBS},
+        "dog_pick": {"workload": "tomogram 256x512x512, sigma=(3,5), nms_xy k=3, greedy d=14", "ms": round(ms_dog, 4),
+                     "voxels_per_sec": n_dog / ms_dog * 1e3,
+                     "hbm_frac_8B_per_voxel": n_dog * 8 / ms_dog * 1e3 / 1e9 / PEAK_HBM_GBS},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--crops", type=int, default=2048)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from cet_pick_amd import hipops as H
+    from cet_pick_amd.synthetic import make_tomo
+    from cet_pick_amd.models.networks.moco_encoder_3d import get_moco_net_small_3d
+    from cet_pick_amd.models.moco import MoCo
+    from cet_pick_amd.trains.moco_engine import MocoStepEngine
+
+    torch.manual_seed(317)
+    heads = {"proj": 256, "pred": 256}
+    enc_q = get_moco_net_small_3d(18, heads, 0)
+    enc_k = get_moco_net_small_3d(18, heads, 0)
+    moco = MoCo(enc_q, enc_k, dim=128, r=1024, m=0.999, T=0.1).to(dev)
+    if world > 1:
+        H.convert_sync_batchnorm(moco)
+        for p in moco.parameters():                 # identical replicas
+            dist.broadcast(p.data, 0)
+        dist.broadcast(moco.queue, 0)
+    moco.train()
+    engine = MocoStepEngine(moco, lr=1e-3, use_graph=not args.no_graph)
+
+    # synthetic tomogram for this rank (seed 317 + rank), crops resident in HBM
+    vol, _ = make_tomo((128, 512, 512), seed=317 + rank)
+    tomo = torch.as_tensor(vol).to(dev)
+    pq, pk = build_views(tomo, args.crops, 32, seed=317 + rank)
+    B = args.batch
+    nb = pq.shape[0] // B
+
+    def run(i):
+        o = (i % nb) * B
+        return engine.step(pq[o:o + B], pk[o:o + B])
+
+    for i in range(args.warmup):
+        run(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = run(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+
+    out = None
+    if rank == 0:
+        value = B * world * args.steps / dt
+        flop, ms, n_launch, by = conv_profile(engine, pq, pk, B, 3)
+        achieved = flop / (ms * 1e-3) / 1e12
+        out = {
+            "metric": "subtomograms/sec (MoCo-3D train) + voxels/sec (heatmap+NMS) at 1/2/4/8 GPU",
+            "value": value, "unit": "subtomograms/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "moco_main.py moco3d_18: 3D encoder, synthetic 512x512x128 tomogram, 32^3 subtomo "
+                                   "crops, batch 64 per GPU, r=1024, dim=128, m=0.999, T=0.1, SGD lr 1e-3",
+                       "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "hipgraph": bool(engine.use_graph), "final_loss": final_loss},
+            "step_mfma_frac_of_peak": value / world * FLOP_PER_SUBTOMO / 1e12 / PEAK_F32_MATRIX_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd/dgrad/wgrad, all layers)",
+                         "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                         "launches_per_step": n_launch // 3, "kernel_ms_per_step": ms / 3,
+                         "algorithmic_gflop_per_step": flop / 3 / 1e9,
+                         "measured": "HIP events around every launch, 3 eager steps after the timed region"},
+        }
+        if not args.no_secondary:
+            out["secondary"] = inference_secondary(dev)
+        if not args.no_cpu_baseline and world == 1:
+            v, cores = cpu_baseline(B, 4, 317)
+            out["cpu_baseline"] = {"value": v, "unit": "subtomograms/sec", "cores": cores, "kind": "port",
+                                   "sample": "4 MoCo steps of batch 64 (after 1 warm-up) of the same workload "
+                                             "with oracle/train_ref.py (torch fp32, all host cores)"}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,27 @@ import torch.nn as nn
 from . import _lib as L
 
 
+PROFILE = None   # bench.py: list collecting (tag, flops, start_event, end_event) per conv launch
+
+
+class _Prof:
+    def __init__(self, tag, flops):
+        self.on = PROFILE is not None
+        if self.on:
+            self.tag, self.flops = tag, flops
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e1.record()
+            PROFILE.append((self.tag, self.flops, self.e0, self.e1))
+
+
 def _ws(nbytes, device, tag):
     return L.workspace(max(int(nbytes), 256), device, tag)
 
@@ -123,8 +144,9 @@ def conv_fwd(x, w, k, stride, pad, res=None, relu=False):
     y = torch.empty((n, do, ho, wo, co), dtype=torch.float32, device=x.device)
     lib = L.lib()
     ws = _ws(lib.mi_conv3d_workspace_bytes(n, d, h, wd, ci, co, k, stride, pad), x.device, "conv")
-    L.check(lib.mi_conv3d_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(res), int(relu), n, d, h, wd, ci,
-                                  co, k, stride, pad, L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_fwd_f32")
+    with _Prof("fwd", 2.0 * n * do * ho * wo * co * ci * k ** 3):
+        L.check(lib.mi_conv3d_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(res), int(relu), n, d, h, wd, ci,
+                                      co, k, stride, pad, L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_fwd_f32")
     return y
 
 
@@ -135,9 +157,10 @@ def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None):
     dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
     lib = L.lib()
     ws = _ws(lib.mi_conv3d_workspace_bytes(n, d, h, wd, ci, co, k, stride, pad), dy.device, "conv")
-    L.check(lib.mi_conv3d_dgrad_f32(L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(res), L.ptr(mask), n, d, h, wd,
-                                    ci, co, k, stride, pad, L.ptr(ws), ws.numel(), L.stream()),
-            "mi_conv3d_dgrad_f32")
+    with _Prof("dgrad", 2.0 * dy.numel() * ci * k ** 3):
+        L.check(lib.mi_conv3d_dgrad_f32(L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(res), L.ptr(mask), n, d, h, wd,
+                                        ci, co, k, stride, pad, L.ptr(ws), ws.numel(), L.stream()),
+                "mi_conv3d_dgrad_f32")
     return dx
 
 
@@ -148,14 +171,12 @@ def conv_wgrad_into(x, dy, param, k, stride, pad):
     lib = L.lib()
     ws = _ws(lib.mi_conv3d_workspace_bytes(n, d, h, wd, ci, co, k, stride, pad), x.device, "conv")
     g, acc = _grad_target(param)
+    tgt = torch.empty_like(g) if acc else g
+    with _Prof("wgrad", 2.0 * dy.numel() * ci * k ** 3):
+        L.check(lib.mi_conv3d_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, k, stride, pad,
+                                        L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_wgrad_f32")
     if acc:
-        tmp = torch.empty_like(g)
-        L.check(lib.mi_conv3d_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tmp), n, d, h, wd, ci, co, k, stride, pad,
-                                        L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_wgrad_f32")
-        g.add_(tmp)
-    else:
-        L.check(lib.mi_conv3d_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(g), n, d, h, wd, ci, co, k, stride, pad,
-                                        L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_wgrad_f32")
+        g.add_(tgt)
 
 
 def relu_mask(dy, y, add=None):

@@ -1,0 +1,73 @@
+"""One MoCo training step as the reference's hot loop performs it
+(trains/base_trainer.py:486-508 -> models/moco.py:101-146 -> trains/tomo_moco_trainer.py:73 ->
+optimizer.step), driven without per-iteration host syncs and, on one GPU, replayed from a hipGraph.
+
+Data-parallel ranks (one process per GPU, torch.distributed backend "nccl" = RCCL) exchange per step:
+gradient arena all-reduce (40.4 MB fp32), MoCo key all-gather (B x 128), SyncBN per-channel sums.
+"""
+import torch
+
+from .. import hipops as H
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+class MocoStepEngine:
+    def __init__(self, moco, lr, weight_decay=0.0, use_graph=False):
+        self.moco = moco
+        self.lr = float(lr)
+        self.weight_decay = float(weight_decay)
+        self.arena_q, self.arena_k = moco.flatten_parameters()
+        dev = self.arena_q.flat.device
+        self.lr_dev = torch.full((1,), self.lr, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        d = _dist()
+        self.world = d.get_world_size() if d else 1
+        self.use_graph = bool(use_graph) and self.world == 1
+        self._graph = None
+        self._static_q = self._static_k = None
+
+    def set_lr(self, lr):
+        """utils/utils.py:58-70 `adjust_learning_rate` target: the schedule reaches a captured graph
+        through a device scalar."""
+        self.lr = float(lr)
+        self.lr_dev.fill_(self.lr)
+
+    def _step_eager(self, im_q, im_k):
+        moco = self.moco
+        self.arena_q.zero_grad()
+        logits, labels = moco(im_q, im_k)
+        loss = H.cross_entropy_label0(logits)
+        loss.backward()
+        if self.world > 1:
+            d = _dist()
+            d.all_reduce(self.arena_q.flat_grad)            # RCCL ring / direct over xGMI
+            self.arena_q.flat_grad.mul_(1.0 / self.world)
+        H.sgd_step_(self.arena_q.flat, self.arena_q.flat_grad, self.lr, self.weight_decay, self.lr_dev)
+        self.loss.copy_(loss.detach())
+        return self.loss
+
+    def step(self, im_q, im_k):
+        """Returns the loss as a 0-d device tensor (no host sync).
+
+        Graph mode: the first two calls run eagerly (they size every workspace), the third call
+        captures the step into a hipGraph and from then on each call is one graph replay."""
+        if not self.use_graph:
+            return self._step_eager(im_q, im_k)
+        if self._graph is None:
+            self._calls = getattr(self, "_calls", 0) + 1
+            if self._calls <= 2:
+                return self._step_eager(im_q, im_k)
+            self._static_q = im_q.clone()
+            self._static_k = im_k.clone()
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):       # records, does not execute
+                self._step_eager(self._static_q, self._static_k)
+        self._static_q.copy_(im_q)
+        self._static_k.copy_(im_k)
+        self._graph.replay()
+        return self.loss
