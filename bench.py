@@ -81,7 +81,11 @@ def cpu_baseline(batch, steps, seed):
     from oracle import train_ref as T
     from cet_pick_amd.synthetic import seeded_state_dict
     from cet_pick_amd.models.networks.moco_encoder_3d import TomoResClassifier3D, BasicBlock
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        ncpu = len(os.sched_getaffinity(0))      # the cores this process may actually use
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 16)))   # the GPU box shares its host: 16 cores per GPU
     enc = TomoResClassifier3D(BasicBlock, [2, 2, 2, 2], {"proj": 256, "pred": 256}, 0)
     sd = {k: v.detach().clone().contiguous() for k, v in seeded_state_dict(enc, seed=seed).items()}
     for k in list(sd):
@@ -135,6 +139,13 @@ def inference_secondary(dev):
     }
 
 
+T_START = time.perf_counter()
+
+
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +180,7 @@ def main():
     from cet_pick_amd.models.moco import MoCo
     from cet_pick_amd.trains.moco_engine import MocoStepEngine
 
+    log("extension built/loaded")
     torch.manual_seed(317)
     heads = {"proj": 256, "pred": 256}
     enc_q = get_moco_net_small_3d(18, heads, 0)
@@ -188,6 +200,7 @@ def main():
     pq, pk = build_views(tomo, args.crops, 32, seed=317 + rank)
     B = args.batch
     nb = pq.shape[0] // B
+    log("model + %d crop pairs resident on %s" % (pq.shape[0], dev))
 
     def run(i):
         o = (i % nb) * B
@@ -195,6 +208,9 @@ def main():
 
     for i in range(args.warmup):
         run(i)
+        if i < 3:
+            torch.cuda.synchronize()
+            log("warm-up step %d done" % i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -212,6 +228,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    log("timed region: %d steps in %.3f s" % (args.steps, dt))
 
     out = None
     if rank == 0:
@@ -235,8 +252,10 @@ def main():
                          "algorithmic_gflop_per_step": flop / 3 / 1e9,
                          "measured": "HIP events around every launch, 3 eager steps after the timed region"},
         }
+        log("conv roofline pass done")
         if not args.no_secondary:
             out["secondary"] = inference_secondary(dev)
+            log("inference secondary done")
         if not args.no_cpu_baseline and world == 1:
             v, cores = cpu_baseline(B, 4, 317)
             out["cpu_baseline"] = {"value": v, "unit": "subtomograms/sec", "cores": cores, "kind": "port",
