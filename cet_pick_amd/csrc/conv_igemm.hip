@@ -11,27 +11,37 @@
 //   DGRAD dX[m,ci] = sum_{tap,co} dY[srcT(m,tap),co] * W[tap][ci][co]        m = input voxel
 //   WGRAD dW[tap][ci][co] = sum_m X[src(m,tap),ci] * dY[m,co]                m = output voxel
 //
-// One 256-thread workgroup (4 waves, WM x WN) owns a BM x BN tile of the GEMM output and walks the
-// reduction in 16-deep slices, double-buffered in LDS with register-staged prefetch (one barrier
-// per slice).  Each operand is kept in LDS in the orientation its global layout is contiguous in:
-//   "RowK" [row][k] (+4 pad): fragments by 2 x ds_read_b128 per 32 rows   (im2col rows, W in DGRAD)
-//   "KRow" [k][row]:          fragments by 8 x ds_read_b32  per 32 rows   (W in FWD, dY/X in WGRAD)
-// Within a slice lane-half h of the wave owns k = 8h..8h+7 for BOTH operands, which turns the
+// One 256-thread workgroup (4 waves, 2 x 2) owns a BM x 64 tile of the GEMM output and walks the
+// reduction in BK-deep slices (16 or 32), double-buffered in LDS with register-staged prefetch
+// (one barrier per slice).  Each operand is kept in LDS in the orientation its global layout is
+// contiguous in:
+//   "RowK" [row][k] (+4 pad): fragments by ds_read_b128            (im2col rows, W in DGRAD)
+//   "KRow" [k][row]:          fragments by ds_read_b32             (W in FWD, dY/X in WGRAD)
+// Within a slice lane-half h of the wave owns k = h*BK/2 .. for BOTH operands, which turns the
 // 32x32x2 MFMA's (k = lane>>5) operand map into contiguous LDS reads; the reduction order inside a
 // slice is therefore permuted (irrelevant beyond fp32 rounding).
+//
+// Gather cost is kept off the matrix pipe's critical path: every im2col row keeps ONE base pointer
+// and a packed per-axis validity mask, a tap adds a wave-uniform offset, loads are branchless
+// (invalid lanes read a safe address and select 0), and the (tap, channel) cursor advances
+// incrementally.  A strided DGRAD is decomposed by output-coordinate parity class so that only the
+// taps that can reach a row are multiplied (k=3, s=2: 27 tap-rows instead of 216).
 // Small-M layers are split along the reduction (grid.z) into fp32 slabs, summed by a second
 // kernel that also applies the epilogue (deterministic, no atomics).
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
-constexpr int BK = 16;
-constexpr int LDK = BK + 4;   // RowK row stride in floats (conflict-free ds_read_b128)
 constexpr int NTHREADS = 256;
+constexpr int BN = 64;
+constexpr int MAX_CLASSES = 8;     // stride <= 2 per axis
+constexpr int LUT_TAPS = 352;      // 7^3 = 343 rounded up to a multiple of 32
+constexpr int LUT_INVALID = 0x070707;   // bit 7 of a per-axis mask byte is never set (k <= 7)
 
 struct ConvParams {
     const float* a_src;   // gathered tensor: X (FWD, WGRAD) or dY (DGRAD)
@@ -40,227 +50,328 @@ struct ConvParams {
     const float* res;     // epilogue: out = act(acc + res)         (may be null)
     const float* mask;    // epilogue: out *= (mask > 0)            (may be null)
     int relu;
-    // gathered tensor grid / channels, row grid (see header comment)
-    int N, Dg, Hg, Wg, Cg;
-    int Dr, Hr, Wr;
-    int lDr, lHr, lWr;    // log2 of the row grid dims, or -1 when not powers of two
-    int kd, kh, kw, stride, pad;
-    int Ci, Co;           // conv channels (weights are [tap][Ci][Co])
-    long M;               // GEMM rows
-    int Ncols;            // GEMM cols
-    int nk;               // 16-deep reduction slices in total
-    int nk_per_split;
-    long slab_stride;     // elements between split-K slabs (0: direct epilogue)
+    int N, Dg, Hg, Wg, Cg;         // gathered tensor grid / channels
+    int Dr, Hr, Wr;                // row grid: FWD/WGRAD output voxels, DGRAD input voxels
+    int k, stride, pad;
+    int Ci, Co;                    // conv channels (weights are [tap][Ci][Co])
+    long M;                        // GEMM rows (all classes)
+    int Ncols;                     // GEMM cols
+    int splits;
+    long slab_stride;              // elements between split-K slabs (0: direct epilogue)
+    long n_red_vox;                // WGRAD: reduction length in voxels
+    int n_classes;                 // DGRAD: stride^3 parity classes (1 otherwise)
+    int cls_tile_start[MAX_CLASSES + 1];
 };
 
-__device__ __forceinline__ void decode_row(const ConvParams& p, long m, int& n, int& z, int& y, int& x) {
-    if (p.lWr >= 0) {
-        x = (int)(m & (p.Wr - 1)); m >>= p.lWr;
-        y = (int)(m & (p.Hr - 1)); m >>= p.lHr;
-        z = (int)(m & (p.Dr - 1)); n = (int)(m >> p.lDr);
-    } else {
-        x = (int)(m % p.Wr); m /= p.Wr;
-        y = (int)(m % p.Hr); m /= p.Hr;
-        z = (int)(m % p.Dr); n = (int)(m / p.Dr);
-    }
-}
-
-// forward gather: source voxel of (row voxel, tap) in the gathered (input) grid, or -1
-__device__ __forceinline__ long src_fwd(const ConvParams& p, int n, int z, int y, int x, int a, int b, int c) {
-    int zi = z * p.stride - p.pad + a, yi = y * p.stride - p.pad + b, xi = x * p.stride - p.pad + c;
-    bool ok = (unsigned)zi < (unsigned)p.Dg && (unsigned)yi < (unsigned)p.Hg && (unsigned)xi < (unsigned)p.Wg;
-    return ok ? ((((long)n * p.Dg + zi) * p.Hg + yi) * p.Wg + xi) : -1;
-}
-// transposed gather (DGRAD): output voxel that input voxel (z,y,x) feeds through tap (a,b,c)
-__device__ __forceinline__ long src_bwd(const ConvParams& p, int n, int z, int y, int x, int a, int b, int c) {
-    int tz = z + p.pad - a, ty = y + p.pad - b, tx = x + p.pad - c;
-    if ((tz | ty | tx) < 0) return -1;
-    int s = p.stride;
-    if (s == 2) {
-        if ((tz | ty | tx) & 1) return -1;
-        tz >>= 1; ty >>= 1; tx >>= 1;
-    } else if (s != 1) {
-        if (tz % s || ty % s || tx % s) return -1;
-        tz /= s; ty /= s; tx /= s;
-    }
-    bool ok = tz < p.Dg && ty < p.Hg && tx < p.Wg;
-    return ok ? ((((long)n * p.Dg + tz) * p.Hg + ty) * p.Wg + tx) : -1;
-}
-
 __device__ __forceinline__ float4 ld4(const float* ptr) { return *reinterpret_cast<const float4*>(ptr); }
-__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// Zero padding without a select: an out-of-range im2col element is LOADED from this block of
+// zeros, so nothing between the global loads and the LDS stores depends on the loaded data.
+// (a mutable __device__ variable so that it lives in the global address space like the tensors:
+// selecting between two global pointers keeps the loads global_load, not flat_load)
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// bit t of the result: 0 <= base + step*t < n, for t in [0, count)
+__device__ __forceinline__ unsigned axis_mask(int base, int step, int count, int n) {
+    unsigned m = 0;
+    for (int t = 0; t < count; ++t)
+        if ((unsigned)(base + step * t) < (unsigned)n) m |= 1u << t;
+    return m;
+}
+
+// flat voxel index -> (n, z, y, x) of a (N, D, H, W) grid; 32-bit, shifts when all dims are 2^k
+struct GridDec {
+    int D, H, W, lD, lH, lW;     // l*: log2 or -1
+    __device__ __forceinline__ void operator()(unsigned m, int& n, int& z, int& y, int& x) const {
+        if (lW >= 0) {
+            x = (int)(m & (unsigned)(W - 1)); m >>= lW;
+            y = (int)(m & (unsigned)(H - 1)); m >>= lH;
+            z = (int)(m & (unsigned)(D - 1)); n = (int)(m >> lD);
+        } else {
+            unsigned q = m / (unsigned)W; x = (int)(m - q * (unsigned)W); m = q;
+            q = m / (unsigned)H; y = (int)(m - q * (unsigned)H); m = q;
+            q = m / (unsigned)D; z = (int)(m - q * (unsigned)D); n = (int)q;
+        }
+    }
+};
+__device__ __forceinline__ int ilog2_dev(int v) { return (v > 0 && (v & (v - 1)) == 0) ? (31 - __clz(v)) : -1; }
+__device__ __forceinline__ GridDec make_dec(int D, int H, int W) {
+    GridDec g{D, H, W, ilog2_dev(D), ilog2_dev(H), ilog2_dev(W)};
+    if (g.lD < 0 || g.lH < 0 || g.lW < 0) g.lD = g.lH = g.lW = -1;
+    return g;
+}
+
+// (tap, channel-offset) cursor of the reduction, advanced one slice at a time without divisions
+struct Cursor {
+    int c0, ia, ib, ic;     // channel offset inside the tap, tap coordinates inside the class list
+};
 
 // STEM: Cin == 1 (the 7x7x7 stride-2 stem, moco_encoder_3d.py:163-169): the reduction index is
-// the tap itself and each of a chunk's 4 taps is gathered separately.
-template <int MODE, int BM, int BN, int WM, int WN, bool STEM>
+// the tap itself and each of a chunk's 4 taps is gathered separately through a tap LUT in LDS.
+template <int MODE, int BM, int BK, bool STEM>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
-    static_assert(WM * WN == 4, "4 waves");
-    constexpr int WTM = BM / WM, WTN = BN / WN;     // wave tile
+    static_assert(BK == 16 || BK == 32, "slice depth");
+    constexpr int WM = 2, WN = 2;
+    constexpr int LDK = BK + 4;
+    constexpr int KH = BK / 2;                       // k's owned by one lane-half per slice
+    constexpr int KC = BK / 4;                       // 16-B chunks along k per RowK row
+    constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
     constexpr int MT = WTM / 32, NT = WTN / 32;
-    static_assert(MT >= 1 && NT >= 1, "wave tile >= 32x32");
+    static_assert(MT >= 1 && NT == 1, "wave tile");
     constexpr bool A_ROWK = (MODE != MODE_WGRAD);
     constexpr bool B_ROWK = (MODE == MODE_DGRAD);
     constexpr int A_ELEMS = A_ROWK ? BM * LDK : BK * BM;
     constexpr int B_ELEMS = B_ROWK ? BN * LDK : BK * BN;
-    constexpr int A_CH = BM * 4 / NTHREADS;          // 16-B chunks per thread per slice
-    constexpr int B_CH = BN * 4 / NTHREADS;
+    constexpr int STAGE = A_ELEMS + B_ELEMS;
+    constexpr int A_CH = BM * KC / NTHREADS;         // 16-B chunks per thread per slice
+    constexpr int B_CH = BN * KC / NTHREADS;
+    constexpr int TPV = NTHREADS / BK;               // WGRAD: threads sharing one reduction voxel
     static_assert(A_CH >= 1 && B_CH >= 1, "tile too small for 256 threads");
 
-    __shared__ __attribute__((aligned(16))) float lds[2 * (A_ELEMS + B_ELEMS)];
-    constexpr int STAGE = A_ELEMS + B_ELEMS;         // buffer b: A at lds + b*STAGE, B right after
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    __shared__ long rowmap[BM];                       // DGRAD classes: tile row -> output row
+    __shared__ int2 taplut[STEM ? LUT_TAPS : 1];      // STEM: tap -> (voxel delta, a | b<<8 | c<<16)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, l32 = lane & 31;
-    const long m0 = (long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const int kt0 = blockIdx.z * p.nk_per_split;
-    const int kt1 = min(kt0 + p.nk_per_split, p.nk);
-    const int taps_hw = p.kh * p.kw;
-    const int taps = p.kd * taps_hw;
+    const int K = p.k, S = p.stride, P = p.pad;
+    const int taps = K * K * K;
 
-    // ---- per-thread staging state ------------------------------------------------------------
-    // A operand
-    int a_n[A_CH], a_z[A_CH], a_y[A_CH], a_x[A_CH];   // RowK: row voxel ; KRow (WGRAD): tap a,b,c + ci
-    bool a_ok[A_CH];
+    // ---- which rows does this workgroup own? ---------------------------------------------------
+    int cls = 0;
+    if (MODE == MODE_DGRAD && p.n_classes > 1) {
+        while (cls + 1 < p.n_classes && (int)blockIdx.x >= p.cls_tile_start[cls + 1]) ++cls;
+    }
+    const long tile_in_cls = (long)blockIdx.x - ((MODE == MODE_DGRAD) ? p.cls_tile_start[cls] : 0);
+    const long m0 = tile_in_cls * BM;                 // first row (within the class for DGRAD)
+    // DGRAD class geometry (stride 1: a single class with cz = cy = cx = 0)
+    int cz = 0, cy = 0, cx = 0, zf = 0, yf = 0, xf = 0, Dz = p.Dr, Dy = p.Hr, Dx = p.Wr;
+    int nz = K, ny = K, nx = K;                       // taps of the class per axis
+    if (MODE == MODE_DGRAD) {
+        cz = cls / (S * S); cy = (cls / S) % S; cx = cls % S;
+        zf = ((cz - P) % S + S) % S; yf = ((cy - P) % S + S) % S; xf = ((cx - P) % S + S) % S;
+        Dz = zf < p.Dr ? (p.Dr - zf + S - 1) / S : 0;
+        Dy = yf < p.Hr ? (p.Hr - yf + S - 1) / S : 0;
+        Dx = xf < p.Wr ? (p.Wr - xf + S - 1) / S : 0;
+        nz = cz < K ? (K - cz + S - 1) / S : 0;
+        ny = cy < K ? (K - cy + S - 1) / S : 0;
+        nx = cx < K ? (K - cx + S - 1) / S : 0;
+    }
+    const long M_here = (MODE == MODE_DGRAD) ? (long)p.N * Dz * Dy * Dx : p.M;
+
+    // ---- reduction extent of this workgroup ----------------------------------------------------
+    int nk;
+    if (MODE == MODE_WGRAD) nk = (int)((p.n_red_vox + BK - 1) / BK);
+    else if (STEM) nk = (taps + BK - 1) / BK;
+    else nk = nz * ny * nx * (((MODE == MODE_FWD) ? p.Ci : p.Co) / BK);
+    const int nk_per_split = (nk + p.splits - 1) / p.splits;
+    const int kt0 = min((int)blockIdx.z * nk_per_split, nk);
+    const int kt1 = min(kt0 + nk_per_split, nk);
+
+    if (STEM) {
+        for (int t = tid; t < LUT_TAPS; t += NTHREADS) {
+            int a = t / (K * K), b = (t / K) % K, c = t % K;
+            taplut[t] = (t < taps) ? make_int2((a * p.Hg + b) * p.Wg + c, a | (b << 8) | (c << 16))
+                                   : make_int2(0, LUT_INVALID);
+        }
+    }
+
+    const GridDec rdec = make_dec(p.Dr, p.Hr, p.Wr);     // row grid (rows < 2^31, checked on the host)
+    const GridDec cdec = make_dec(Dz, Dy, Dx);           // DGRAD class grid
+
+    // ---- per-thread staging state --------------------------------------------------------------
+    const float* a_ptr[A_CH];        // row base pointer (+ chunk offset); WGRAD: tap + ci offset
+    unsigned a_msk[A_CH];            // RowK: per-axis validity bits (z | y<<8 | x<<16), 0 = row off
+                                     // WGRAD: the chunk's tap coordinates a | b<<8 | c<<16
+    bool w_ok[A_CH];
     int a_lds[A_CH];
+    const int w_kk = tid / TPV;
+
     if (A_ROWK) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
-            int q = tid + i * NTHREADS;
-            int row = q >> 2, c = q & 3;
-            long m = m0 + row;
-            a_ok[i] = m < p.M;
-            decode_row(p, a_ok[i] ? m : 0, a_n[i], a_z[i], a_y[i], a_x[i]);
+            const int q = tid + i * NTHREADS;
+            const int row = q / KC, c = q % KC;
+            const long m = m0 + row;
             a_lds[i] = row * LDK + 4 * c;
+            a_msk[i] = 0;
+            a_ptr[i] = p.a_src;
+            w_ok[i] = false;
+            if (m < M_here) {
+                if (MODE == MODE_FWD) {
+                    int n, z, y, x;
+                    rdec((unsigned)m, n, z, y, x);
+                    const int zb = z * S - P, yb = y * S - P, xb = x * S - P;
+                    a_msk[i] = axis_mask(zb, 1, K, p.Dg) | (axis_mask(yb, 1, K, p.Hg) << 8) |
+                               (axis_mask(xb, 1, K, p.Wg) << 16);
+                    a_ptr[i] = p.a_src + ((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg + (STEM ? 0 : 4 * c);
+                } else {
+                    int n, jz, jy, jx;
+                    cdec((unsigned)m, n, jz, jy, jx);
+                    const int z = zf + S * jz, y = yf + S * jy, x = xf + S * jx;
+                    const int zb = (z + P - cz) / S, yb = (y + P - cy) / S, xb = (x + P - cx) / S;
+                    a_msk[i] = axis_mask(zb, -1, nz, p.Dg) | (axis_mask(yb, -1, ny, p.Hg) << 8) |
+                               (axis_mask(xb, -1, nx, p.Wg) << 16);
+                    a_ptr[i] = p.a_src + ((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg + 4 * c;
+                    if (c == 0 && p.n_classes > 1) rowmap[row] = (((long)n * p.Dr + z) * p.Hr + y) * p.Wr + x;
+                }
+            } else if (MODE == MODE_DGRAD && c == 0 && p.n_classes > 1) {
+                rowmap[row] = -1;
+            }
         }
     } else {
-        // WGRAD: GEMM rows are (tap, ci); this thread's 4 rows share one tap
+        // WGRAD: GEMM rows are (tap, ci).  TPV threads share one reduction voxel kk (one voxel
+        // decode per thread and slice); chunk i of a thread covers rows 4*(tid%TPV + TPV*i) ..+3,
+        // which share a tap because Ci % 4 == 0.
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
-            int q = tid + i * NTHREADS;
-            int kk = q / (BM / 4), j = q % (BM / 4);
-            long row = m0 + 4 * j;
-            a_ok[i] = row < p.M;
-            int tap = STEM ? (int)row : (int)(row / p.Ci);   // STEM: rows ARE taps (4 consecutive)
-            a_n[i] = STEM ? 0 : (int)(row % p.Ci);           // ci of the first of the 4 rows
-            a_z[i] = tap / taps_hw; a_y[i] = (tap / p.kw) % p.kh; a_x[i] = tap % p.kw;
-            a_lds[i] = kk * BM + 4 * j;
+            const int j = (tid % TPV) + TPV * i;
+            a_lds[i] = w_kk * BM + 4 * j;
+            const long row = m0 + 4 * j;
+            w_ok[i] = row < p.M;
+            a_msk[i] = 0;
+            a_ptr[i] = p.a_src;
+            if (w_ok[i] && !STEM) {
+                const int tap = (int)(row / p.Ci);
+                const int ci = (int)(row % p.Ci);
+                const int a = tap / (K * K), b = (tap / K) % K, c = tap % K;
+                a_ptr[i] = p.a_src + ((long)(a * p.Hg + b) * p.Wg + c) * p.Cg + ci;
+                a_msk[i] = (unsigned)(a | (b << 8) | (c << 16));
+            }
         }
     }
-    // B operand
-    int b_lds[B_CH];
-    int b_row[B_CH], b_col[B_CH];
+    // B operand: per-thread base pointer (the zero block when the column is out of range) plus a
+    // wave-uniform offset per slice
+    const float* const zsrc = g_zero16;
+    int b_lds[B_CH], b_row[B_CH], b_col[B_CH];
+    const float* b_ptr[B_CH];
+    long b_live[B_CH];           // 1 when the base is a real row/column, 0 when it is the zero block
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-        int q = tid + i * NTHREADS;
+        const int q = tid + i * NTHREADS;
         if (B_ROWK) {            // DGRAD: LDS [n][k]; global W[tap][ci = n][co = k]
-            b_row[i] = q >> 2; b_col[i] = (q & 3) * 4;
+            b_row[i] = q / KC; b_col[i] = (q % KC) * 4;
             b_lds[i] = b_row[i] * LDK + b_col[i];
+            const bool ok = n0 + b_row[i] < p.Ncols;
+            b_ptr[i] = ok ? p.b_src + (long)(n0 + b_row[i]) * p.Co + b_col[i] : zsrc;
+            b_live[i] = ok ? 1 : 0;
         } else {                 // LDS [k][n]; global rows k, cols n contiguous
             b_row[i] = q / (BN / 4); b_col[i] = (q % (BN / 4)) * 4;
             b_lds[i] = b_row[i] * BN + b_col[i];
+            const bool ok = n0 + b_col[i] < p.Ncols;
+            b_ptr[i] = ok ? p.b_src + (long)b_row[i] * p.Co + n0 + b_col[i] : zsrc;
+            b_live[i] = ok ? 1 : 0;
         }
     }
 
+    // reduction cursor at kt0 (divisions here, none in the loop)
+    Cursor cur = {0, 0, 0, 0};
+    if (MODE != MODE_WGRAD && !STEM && nk > 0) {
+        const int per_tap = ((MODE == MODE_FWD) ? p.Ci : p.Co) / BK;
+        int t = kt0 / per_tap;
+        cur.c0 = (kt0 - t * per_tap) * BK;
+        cur.ic = t % nx; t /= nx; cur.ib = t % ny; cur.ia = t / ny;
+    }
+    if (STEM) __syncthreads();          // tap LUT visible
+
     float4 a_reg[A_CH], b_reg[B_CH];
 
-    auto load_tile = [&](int kt) {
+    // live == false (wave-uniform): the prefetch of the iteration after the last; every load then
+    // reads the zero block (the cursor may already point past the reduction)
+    auto load_tile = [&](int kt, bool live) {
         if (MODE == MODE_WGRAD) {
-            // reduction index = output voxel m = kt*16 + kk
+            // reduction index = output voxel mv = kt*BK + kk (one decode per thread)
+            const long mv = (long)kt * BK + w_kk;
+            const bool vok = live && mv < p.n_red_vox;
+            int n, z, y, x;
+            rdec(vok ? (unsigned)mv : 0u, n, z, y, x);
+            const int zb = z * S - P, yb = y * S - P, xb = x * S - P;
+            const long voff = ((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg;
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
-                int q = tid + i * NTHREADS;
-                int kk = q / (BM / 4);
-                long mv = (long)kt * BK + kk;
-                float4 v = zero4();
-                if (a_ok[i] && mv < (long)p.N * p.Dr * p.Hr * p.Wr) {
-                    int n, z, y, x;
-                    decode_row(p, mv, n, z, y, x);
-                    if (STEM) {
-                        int j = q % (BM / 4);
-                        float e[4];
+                if (STEM) {
+                    float e[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            int tap = (int)m0 + 4 * j + u;
-                            e[u] = 0.f;
-                            if (tap < taps) {
-                                long s = src_fwd(p, n, z, y, x, tap / taps_hw, (tap / p.kw) % p.kh, tap % p.kw);
-                                if (s >= 0) e[u] = p.a_src[s];
-                            }
-                        }
-                        v = make_float4(e[0], e[1], e[2], e[3]);
-                    } else {
-                        long s = src_fwd(p, n, z, y, x, a_z[i], a_y[i], a_x[i]);
-                        if (s >= 0) v = ld4(p.a_src + s * p.Cg + a_n[i]);
+                    for (int u = 0; u < 4; ++u) {
+                        const int tap = (int)m0 + 4 * ((tid % TPV) + TPV * i) + u;
+                        const int2 tl = taplut[min(tap, LUT_TAPS - 1)];
+                        const int a = tl.y & 0xff, b = (tl.y >> 8) & 0xff, c = (tl.y >> 16) & 0xff;
+                        const bool ok = vok && tap < taps && (unsigned)(zb + a) < (unsigned)p.Dg &&
+                                        (unsigned)(yb + b) < (unsigned)p.Hg && (unsigned)(xb + c) < (unsigned)p.Wg;
+                        e[u] = *(ok ? (p.a_src + voff + tl.x) : zsrc);
                     }
+                    a_reg[i] = make_float4(e[0], e[1], e[2], e[3]);
+                } else {
+                    const int a = a_msk[i] & 0xff, b = (a_msk[i] >> 8) & 0xff, c = (a_msk[i] >> 16) & 0xff;
+                    const bool ok = vok && w_ok[i] && (unsigned)(zb + a) < (unsigned)p.Dg &&
+                                    (unsigned)(yb + b) < (unsigned)p.Hg && (unsigned)(xb + c) < (unsigned)p.Wg;
+                    a_reg[i] = ld4(ok ? (a_ptr[i] + voff) : zsrc);
                 }
-                a_reg[i] = v;
             }
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) {
-                long mv = (long)kt * BK + b_row[i];
-                int col = n0 + b_col[i];
-                float4 v = zero4();
-                if (mv < (long)p.N * p.Dr * p.Hr * p.Wr && col < p.Ncols) v = ld4(p.b_src + mv * p.Co + col);
-                b_reg[i] = v;
+                const bool ok = live && (long)kt * BK + b_row[i] < p.n_red_vox;
+                b_reg[i] = ld4(ok ? (b_ptr[i] + b_live[i] * ((long)kt * BK * p.Co)) : zsrc);
             }
         } else if (STEM) {
-            // FWD stem: slice kt covers taps kt*16 .. kt*16+15
+            // FWD stem: slice kt covers taps kt*BK .. kt*BK+BK-1
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
-                int q = tid + i * NTHREADS;
-                float e[4] = {0.f, 0.f, 0.f, 0.f};
-                if (a_ok[i]) {
+                const int q = tid + i * NTHREADS;
+                const unsigned m = a_msk[i];
+                float e[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        int tap = kt * BK + 4 * (q & 3) + u;
-                        if (tap < taps) {
-                            long s = src_fwd(p, a_n[i], a_z[i], a_y[i], a_x[i], tap / taps_hw,
-                                             (tap / p.kw) % p.kh, tap % p.kw);
-                            if (s >= 0) e[u] = p.a_src[s];
-                        }
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const int tap = kt * BK + 4 * (q % KC) + u;
+                    const int2 tl = taplut[min(tap, LUT_TAPS - 1)];
+                    const bool ok = live && ((m >> (tl.y & 0xff)) & (m >> (8 + ((tl.y >> 8) & 0xff))) &
+                                             (m >> (16 + ((tl.y >> 16) & 0xff))) & 1u) != 0;
+                    e[u] = *(ok ? (a_ptr[i] + tl.x) : zsrc);
                 }
                 a_reg[i] = make_float4(e[0], e[1], e[2], e[3]);
             }
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) {
-                int tap = kt * BK + b_row[i];
-                int col = n0 + b_col[i];
-                float4 v = zero4();
-                if (tap < taps && col < p.Ncols) v = ld4(p.b_src + (long)tap * p.Co + col);
-                b_reg[i] = v;
+                const bool ok = live && kt * BK + b_row[i] < taps;
+                b_reg[i] = ld4(ok ? (b_ptr[i] + b_live[i] * ((long)kt * BK * p.Co)) : zsrc);
             }
         } else {
-            const int cred = (MODE == MODE_FWD) ? p.Ci : p.Co;    // reduction channels
-            const int per_tap = cred / BK;
-            const int tap = kt / per_tap;
-            const int c0 = (kt - tap * per_tap) * BK;
-            const int ta = tap / taps_hw, tb = (tap / p.kw) % p.kh, tc = tap % p.kw;
+            // wave-uniform tap state from the cursor
+            const int ia = cur.ia, ib = cur.ib, ic = cur.ic, c0 = cur.c0;
+            long a_off;            // element offset added to every row's base pointer
+            int wtap;              // weight tap index
+            if (MODE == MODE_FWD) {
+                a_off = ((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0;
+                wtap = (ia * K + ib) * K + ic;
+            } else {
+                a_off = -((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0;
+                wtap = ((cz + S * ia) * K + (cy + S * ib)) * K + (cx + S * ic);
+            }
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
-                float4 v = zero4();
-                if (a_ok[i]) {
-                    long s = (MODE == MODE_FWD) ? src_fwd(p, a_n[i], a_z[i], a_y[i], a_x[i], ta, tb, tc)
-                                                : src_bwd(p, a_n[i], a_z[i], a_y[i], a_x[i], ta, tb, tc);
-                    int q = tid + i * NTHREADS;
-                    if (s >= 0) v = ld4(p.a_src + s * p.Cg + c0 + 4 * (q & 3));
-                }
-                a_reg[i] = v;
+                const unsigned m = a_msk[i];
+                const bool ok = live && ((m >> ia) & (m >> (8 + ib)) & (m >> (16 + ic)) & 1u) != 0;
+                a_reg[i] = ld4(ok ? (a_ptr[i] + a_off) : zsrc);
             }
+            // weights: FWD rows (wtap*Ci + c0 + k) of [.][Co]; DGRAD row (wtap*Ci + ci), cols c0 + k
+            const long b_off = (MODE == MODE_FWD) ? ((long)wtap * p.Ci + c0) * p.Co
+                                                   : (long)wtap * p.Ci * p.Co + c0;
 #pragma unroll
-            for (int i = 0; i < B_CH; ++i) {
-                float4 v = zero4();
-                if (MODE == MODE_FWD) {
-                    int col = n0 + b_col[i];
-                    if (col < p.Ncols) v = ld4(p.b_src + ((long)tap * p.Ci + c0 + b_row[i]) * p.Co + col);
-                } else {
-                    int ci = n0 + b_row[i];
-                    if (ci < p.Ncols) v = ld4(p.b_src + ((long)tap * p.Ci + ci) * p.Co + c0 + b_col[i]);
-                }
-                b_reg[i] = v;
-            }
+            for (int i = 0; i < B_CH; ++i) b_reg[i] = ld4(live ? (b_ptr[i] + b_live[i] * b_off) : zsrc);
+            // advance the cursor
+            const int cred = (MODE == MODE_FWD) ? p.Ci : p.Co;
+            // (branch-free: the loop body must stay one basic block for the MFMA interleave)
+            const int c0n = cur.c0 + BK;
+            const int w0 = c0n >= cred ? 1 : 0;
+            cur.c0 = w0 ? 0 : c0n;
+            const int icn = cur.ic + w0;
+            const int w1 = icn >= nx ? 1 : 0;
+            cur.ic = w1 ? 0 : icn;
+            const int ibn = cur.ib + w1;
+            const int w2 = ibn >= ny ? 1 : 0;
+            cur.ib = w2 ? 0 : ibn;
+            cur.ia += w2;
         }
     };
     auto store_tile = [&](int buf) {
@@ -270,16 +381,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
         for (int i = 0; i < B_CH; ++i) *reinterpret_cast<float4*>(lds + buf * STAGE + A_ELEMS + b_lds[i]) = b_reg[i];
     };
 
-    f32x16 acc[MT][NT];
+    f32x16 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     if (kt0 < kt1) {
-        load_tile(kt0);
+        load_tile(kt0, true);
         store_tile(0);
     }
     __syncthreads();
@@ -287,46 +396,51 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     int buf = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
         const bool more = (kt + 1 < kt1);
-        if (more) load_tile(kt + 1);
-
-        float af[MT][8], bf[NT][8];
+        // Phase 1: gather addresses + global loads of the NEXT slice (unconditional: the last
+        // iteration fetches zeros into the idle buffer, so the body has no branch).
+        // Out-of-range elements are loaded from a block of zeros, so nothing until the LDS stores
+        // of phase 3 depends on the loaded data and the loads stay in flight across the MFMAs.
+        load_tile(kt + 1, more);
+        __builtin_amdgcn_sched_barrier(0);
+        // Phase 2: fragments of the current slice from LDS, then the MFMAs
         const float* Ab = lds + buf * STAGE;
         const float* Bb = Ab + A_ELEMS;
+        float af[MT][KH], bf[KH];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int r = wm * WTM + i * 32 + l32;
             if (A_ROWK) {
-                float4 v0 = *reinterpret_cast<const float4*>(Ab + r * LDK + h * 8);
-                float4 v1 = *reinterpret_cast<const float4*>(Ab + r * LDK + h * 8 + 4);
-                af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
-                af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+#pragma unroll
+                for (int u = 0; u < KH / 4; ++u) {
+                    const float4 v = *reinterpret_cast<const float4*>(Ab + r * LDK + h * KH + 4 * u);
+                    af[i][4 * u] = v.x; af[i][4 * u + 1] = v.y; af[i][4 * u + 2] = v.z; af[i][4 * u + 3] = v.w;
+                }
             } else {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) af[i][t] = Ab[(h * 8 + t) * BM + r];
+                for (int t = 0; t < KH; ++t) af[i][t] = Ab[(h * KH + t) * BM + r];
             }
         }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int c = wn * WTN + j * 32 + l32;
+        {
+            const int c = wn * WTN + l32;
             if (B_ROWK) {
-                float4 v0 = *reinterpret_cast<const float4*>(Bb + c * LDK + h * 8);
-                float4 v1 = *reinterpret_cast<const float4*>(Bb + c * LDK + h * 8 + 4);
-                bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
-                bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
+#pragma unroll
+                for (int u = 0; u < KH / 4; ++u) {
+                    const float4 v = *reinterpret_cast<const float4*>(Bb + c * LDK + h * KH + 4 * u);
+                    bf[4 * u] = v.x; bf[4 * u + 1] = v.y; bf[4 * u + 2] = v.z; bf[4 * u + 3] = v.w;
+                }
             } else {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) bf[j][t] = Bb[(h * 8 + t) * BN + c];
+                for (int t = 0; t < KH; ++t) bf[t] = Bb[(h * KH + t) * BN + c];
             }
         }
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < KH; ++t)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
-
-        if (more) store_tile(buf ^ 1);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[t], acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // Phase 3: the prefetched slice goes to the other LDS buffer
+        store_tile(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
@@ -334,26 +448,28 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* outp = p.out + (long)blockIdx.z * p.slab_stride;
     const bool direct = (p.slab_stride == 0);
+    const bool mapped = (MODE == MODE_DGRAD) && p.n_classes > 1;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+        const int col = n0 + wn * WTN + l32;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = n0 + wn * WTN + j * 32 + l32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < p.M && col < p.Ncols) {
-                    const long o = row * p.Ncols + col;
-                    float v = acc[i][j][r];
-                    if (direct) {
-                        if (p.res) v += p.res[o];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        if (p.mask) v = (p.mask[o] > 0.f) ? v : 0.f;
-                    }
-                    outp[o] = v;
+        for (int r = 0; r < 16; ++r) {
+            const int trow = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            long row = m0 + trow;
+            bool ok = row < M_here && col < p.Ncols;
+            if (mapped) { row = rowmap[trow]; ok = ok && row >= 0; }
+            if (ok) {
+                const long o = row * p.Ncols + col;
+                float v = acc[i][r];
+                if (direct) {
+                    if (p.res) v += p.res[o];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.mask) v = (p.mask[o] > 0.f) ? v : 0.f;
                 }
+                outp[o] = v;
             }
         }
+    }
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int n_slabs,
@@ -377,42 +493,52 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
     }
 }
 
-int ilog2_exact(int v) {
-    if (v <= 0 || (v & (v - 1))) return -1;
-    int l = 0;
-    while ((1 << l) < v) ++l;
-    return l;
+struct Plan { int bm, bk, splits; long tiles_x; };
+
+int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
 }
 
-struct Plan { int bm, bn, splits, nk_per_split; };
-
-Plan make_plan(long M, int Ncols, int nk, int force_splits) {
+// red_ch: reduction channels (FWD: Ci, DGRAD: Co; 0 for WGRAD / stem where any depth works)
+// red_len: longest reduction in elements; tiles_x_of(bm): row tiles for a given BM
+// mode-specific tile choice measured on MI355X (tools/bench_conv.py, profiles/r01_conv_tuning.txt):
+// FWD/DGRAD take 128-row tiles only when there are >= 16 Ki rows; WGRAD (few rows, long reduction)
+// prefers 128-row tiles while that still leaves <= 64 tiles, except for the scalar-gather stem.
+template <class F>
+Plan make_plan(int mode, bool stem, long M, int Ncols, long red_len, int red_ch, F tiles_x_of) {
     Plan pl;
-    pl.bn = 64;
-    pl.bm = (M >= 16384) ? 128 : 64;
-    long tiles = ((M + pl.bm - 1) / pl.bm) * ((Ncols + pl.bn - 1) / pl.bn);
+    if (mode == MODE_WGRAD) pl.bm = (!stem && ((M + 127) / 128) * ((Ncols + BN - 1) / BN) <= 64) ? 128 : 64;
+    else pl.bm = (M >= 16384) ? 128 : 64;
+    pl.bk = (red_ch == 0 || red_ch % 32 == 0) ? 32 : 16;
+    if (int v = env_int("MI_CONV_BM")) pl.bm = (v == 128) ? 128 : 64;            // tuning overrides
+    if (int v = env_int("MI_CONV_BK")) if ((v == 16 || v == 32) && (red_ch == 0 || red_ch % v == 0)) pl.bk = v;
+    pl.tiles_x = tiles_x_of(pl.bm);
+    const long tiles = pl.tiles_x * ((Ncols + BN - 1) / BN);
+    const long nk = (red_len + pl.bk - 1) / pl.bk;
     int splits = 1;
-    if (force_splits > 0) {
-        splits = force_splits;
-    } else if (tiles < 384) {
+    if (tiles < 384) {
         splits = (int)((512 + tiles - 1) / tiles);
-        int max_splits = nk / 8 > 0 ? nk / 8 : 1;     // at least 8 slices per split
-        if (splits > max_splits) splits = max_splits;
-        if (splits > 64) splits = 64;
+        const long min_slices = 128 / pl.bk;             // at least 128 reduction elements per split
+        const long max_splits = nk / min_slices > 0 ? nk / min_slices : 1;
+        if (splits > max_splits) splits = (int)max_splits;
+        if (splits > 128) splits = 128;
     }
-    if (splits < 1) splits = 1;
-    pl.nk_per_split = (nk + splits - 1) / splits;
-    pl.splits = (nk + pl.nk_per_split - 1) / pl.nk_per_split;
+    if (int v = env_int("MI_CONV_SPLITS")) splits = v;
+    pl.splits = splits < 1 ? 1 : splits;
     return pl;
 }
 
 template <int MODE, bool STEM>
-int launch_mode(ConvParams p, const Plan& pl, hipStream_t s) {
-    dim3 grid((unsigned)((p.M + pl.bm - 1) / pl.bm), (unsigned)((p.Ncols + pl.bn - 1) / pl.bn), pl.splits);
-    if (pl.bm == 128)
-        hipLaunchKernelGGL((conv_igemm_kernel<MODE, 128, 64, 2, 2, STEM>), grid, dim3(NTHREADS), 0, s, p);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<MODE, 64, 64, 2, 2, STEM>), grid, dim3(NTHREADS), 0, s, p);
+int launch_mode(const ConvParams& p, const Plan& pl, hipStream_t s) {
+    dim3 grid((unsigned)pl.tiles_x, (unsigned)((p.Ncols + BN - 1) / BN), pl.splits);
+#define MI_LAUNCH(BM_, BK_) \
+    hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM_, BK_, STEM>), grid, dim3(NTHREADS), 0, s, p)
+    if (pl.bm == 128 && pl.bk == 32) MI_LAUNCH(128, 32);
+    else if (pl.bm == 128) MI_LAUNCH(128, 16);
+    else if (pl.bk == 32) MI_LAUNCH(64, 32);
+    else MI_LAUNCH(64, 16);
+#undef MI_LAUNCH
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -423,8 +549,9 @@ struct Geom {
 
 bool geom_ok(const Geom& g) {
     if (g.N <= 0 || g.Di <= 0 || g.Hi <= 0 || g.Wi <= 0 || g.Ci <= 0 || g.Co <= 0) return false;
-    if (g.k <= 0 || g.stride <= 0 || g.pad < 0) return false;
-    if ((g.Ci % BK && g.Ci != 1) || g.Co % BK) return false;
+    if (g.k <= 0 || g.k > 7 || g.stride <= 0 || g.stride > 2 || g.pad < 0) return false;
+    if ((g.Ci % 16 && g.Ci != 1) || g.Co % 16) return false;
+    if ((long)g.N * g.Di * g.Hi * g.Wi >= (1l << 31)) return false;     // 32-bit voxel indices
     return true;
 }
 Geom make_geom(int N, int Di, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
@@ -435,47 +562,79 @@ Geom make_geom(int N, int Di, int Hi, int Wi, int Ci, int Co, int k, int stride,
     return g;
 }
 
-int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, float* out,
-             const float* res, const float* mask, int relu, void* ws, size_t ws_bytes,
-             int force_splits, hipStream_t s) {
-    ConvParams p = {};
-    p.a_src = a_src; p.b_src = b_src; p.res = res; p.mask = mask; p.relu = relu;
-    p.N = g.N; p.kd = p.kh = p.kw = g.k; p.stride = g.stride; p.pad = g.pad; p.Ci = g.Ci; p.Co = g.Co;
+// rows of DGRAD parity class c and its reduction length in taps
+void dgrad_class(const Geom& g, int c, long* rows, int* ntaps) {
+    const int S = g.stride, P = g.pad, K = g.k;
+    const int cc[3] = {c / (S * S), (c / S) % S, c % S};
+    const int dims[3] = {g.Di, g.Hi, g.Wi};
+    long r = g.N;
+    int t = 1;
+    for (int a = 0; a < 3; ++a) {
+        const int f = ((cc[a] - P) % S + S) % S;
+        r *= f < dims[a] ? (dims[a] - f + S - 1) / S : 0;
+        t *= cc[a] < K ? (K - cc[a] + S - 1) / S : 0;
+    }
+    *rows = r; *ntaps = t;
+}
+
+struct Setup { ConvParams p; Plan pl; };
+
+int setup_conv(int mode, const Geom& g, Setup* st) {
+    ConvParams& p = st->p;
+    p = ConvParams{};
+    p.N = g.N; p.k = g.k; p.stride = g.stride; p.pad = g.pad; p.Ci = g.Ci; p.Co = g.Co;
     const int taps = g.k * g.k * g.k;
     const bool stem = (g.Ci == 1);
     const long Mout = (long)g.N * g.Do * g.Ho * g.Wo, Min = (long)g.N * g.Di * g.Hi * g.Wi;
+    p.n_classes = 1;
     if (mode == MODE_FWD) {
         p.Dg = g.Di; p.Hg = g.Hi; p.Wg = g.Wi; p.Cg = g.Ci;
         p.Dr = g.Do; p.Hr = g.Ho; p.Wr = g.Wo;
-        p.M = Mout; p.Ncols = g.Co; p.nk = stem ? (taps + BK - 1) / BK : taps * g.Ci / BK;
+        p.M = Mout; p.Ncols = g.Co;
+        const long M = p.M;
+        st->pl = make_plan(mode, stem, p.M, p.Ncols, (long)taps * g.Ci, stem ? 0 : g.Ci, [M](int bm) { return (M + bm - 1) / bm; });
     } else if (mode == MODE_DGRAD) {
         if (stem) return MI_E_UNSUPPORTED;    // the stem's input is the image: no data gradient
         p.Dg = g.Do; p.Hg = g.Ho; p.Wg = g.Wo; p.Cg = g.Co;
         p.Dr = g.Di; p.Hr = g.Hi; p.Wr = g.Wi;
-        p.M = Min; p.Ncols = g.Ci; p.nk = taps * g.Co / BK;
+        p.M = Min; p.Ncols = g.Ci;
+        const int nc = g.stride * g.stride * g.stride;
+        p.n_classes = nc;
+        long rows[MAX_CLASSES]; int nt[MAX_CLASSES]; int max_t = 0;
+        for (int c = 0; c < nc; ++c) { dgrad_class(g, c, &rows[c], &nt[c]); max_t = std::max(max_t, nt[c]); }
+        auto tiles_of = [&](int bm) { long t = 0; for (int c = 0; c < nc; ++c) t += (rows[c] + bm - 1) / bm; return t; };
+        st->pl = make_plan(mode, stem, p.M, p.Ncols, (long)std::max(max_t, 1) * g.Co, g.Co, tiles_of);
+        long acc = 0;
+        for (int c = 0; c < nc; ++c) { p.cls_tile_start[c] = (int)acc; acc += (rows[c] + st->pl.bm - 1) / st->pl.bm; }
+        p.cls_tile_start[nc] = (int)acc;
     } else {
         p.Dg = g.Di; p.Hg = g.Hi; p.Wg = g.Wi; p.Cg = g.Ci;
         p.Dr = g.Do; p.Hr = g.Ho; p.Wr = g.Wo;
-        p.M = (long)taps * g.Ci; p.Ncols = g.Co; p.nk = (int)((Mout + BK - 1) / BK);
+        p.M = (long)taps * g.Ci; p.Ncols = g.Co; p.n_red_vox = Mout;
+        const long M = p.M;
+        st->pl = make_plan(mode, stem, p.M, p.Ncols, Mout, 0, [M](int bm) { return (M + bm - 1) / bm; });
     }
-    p.lDr = ilog2_exact(p.Dr); p.lHr = ilog2_exact(p.Hr); p.lWr = ilog2_exact(p.Wr);
-    if (p.lDr < 0 || p.lHr < 0 || p.lWr < 0) p.lDr = p.lHr = p.lWr = -1;
-    Plan pl = make_plan(p.M, p.Ncols, p.nk, force_splits);
-    p.nk_per_split = pl.nk_per_split;
+    p.splits = st->pl.splits;
+    return MI_OK;
+}
+
+int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, float* out,
+             const float* res, const float* mask, int relu, void* ws, size_t ws_bytes, hipStream_t s) {
+    Setup st;
+    int rc = setup_conv(mode, g, &st);
+    if (rc) return rc;
+    ConvParams& p = st.p;
+    Plan& pl = st.pl;
+    p.a_src = a_src; p.b_src = b_src; p.res = res; p.mask = mask; p.relu = relu;
+    const bool stem = (g.Ci == 1);
     const long out_elems = p.M * p.Ncols;
     if (pl.splits > 1) {
         size_t need = sizeof(float) * (size_t)out_elems * pl.splits;
-        if (!ws || ws_bytes < need) {
-            // not enough scratch for slabs: fall back to the unsplit schedule (same result)
-            pl.splits = 1; pl.nk_per_split = p.nk; p.nk_per_split = p.nk;
-        }
+        if (!ws || ws_bytes < need) pl.splits = 1;     // unsplit schedule: same values up to summation order
     }
-    if (pl.splits > 1) {
-        p.out = (float*)ws; p.slab_stride = out_elems;
-    } else {
-        p.out = out; p.slab_stride = 0;
-    }
-    int rc;
+    p.splits = pl.splits;
+    if (pl.splits > 1) { p.out = (float*)ws; p.slab_stride = out_elems; }
+    else { p.out = out; p.slab_stride = 0; }
     if (mode == MODE_FWD) rc = stem ? launch_mode<MODE_FWD, true>(p, pl, s) : launch_mode<MODE_FWD, false>(p, pl, s);
     else if (mode == MODE_DGRAD) rc = launch_mode<MODE_DGRAD, false>(p, pl, s);
     else rc = stem ? launch_mode<MODE_WGRAD, true>(p, pl, s) : launch_mode<MODE_WGRAD, false>(p, pl, s);
@@ -495,17 +654,12 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
 extern "C" size_t mi_conv3d_workspace_bytes(int N, int Di, int Hi, int Wi, int Ci, int Co, int k,
                                             int stride, int pad) {
     Geom g = make_geom(N, Di, Hi, Wi, Ci, Co, k, stride, pad);
-    if (!geom_ok(g)) return 0;
-    const int taps = k * k * k;
-    const long Mout = (long)N * g.Do * g.Ho * g.Wo, Min = (long)N * Di * Hi * Wi;
+    if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
     size_t best = 0;
-    struct { long M; int Nc; int nk; } cases[3] = {
-        {Mout, Co, Ci == 1 ? (taps + BK - 1) / BK : taps * Ci / BK}, {Min, Ci, taps * Co / BK},
-        {(long)taps * Ci, Co, (int)((Mout + BK - 1) / BK)}};
-    for (auto& c : cases) {
-        Plan pl = make_plan(c.M, c.Nc, c.nk, 0);
-        size_t b = pl.splits > 1 ? sizeof(float) * (size_t)c.M * c.Nc * pl.splits : 0;
-        best = std::max(best, b);
+    for (int mode = 0; mode < 3; ++mode) {
+        Setup st;
+        if (setup_conv(mode, g, &st)) continue;
+        if (st.pl.splits > 1) best = std::max(best, sizeof(float) * (size_t)st.p.M * st.p.Ncols * st.pl.splits);
     }
     return best + 256;
 }
@@ -515,7 +669,7 @@ extern "C" int mi_conv3d_fwd_f32(const float* x, const float* w, float* y, const
                                  int stride, int pad, void* ws, size_t ws_bytes, mi_stream_t stream) {
     Geom g = make_geom(N, Di, Hi, Wi, Ci, Co, k, stride, pad);
     if (!x || !w || !y || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
-    return run_conv(MODE_FWD, g, x, w, y, res, nullptr, relu, ws, ws_bytes, 0, (hipStream_t)stream);
+    return run_conv(MODE_FWD, g, x, w, y, res, nullptr, relu, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int mi_conv3d_dgrad_f32(const float* dy, const float* w, float* dx, const float* res,
@@ -524,7 +678,7 @@ extern "C" int mi_conv3d_dgrad_f32(const float* dy, const float* w, float* dx, c
                                    mi_stream_t stream) {
     Geom g = make_geom(N, Di, Hi, Wi, Ci, Co, k, stride, pad);
     if (!dy || !w || !dx || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
-    return run_conv(MODE_DGRAD, g, dy, w, dx, res, mask, 0, ws, ws_bytes, 0, (hipStream_t)stream);
+    return run_conv(MODE_DGRAD, g, dy, w, dx, res, mask, 0, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int mi_conv3d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int Di,
@@ -532,5 +686,5 @@ extern "C" int mi_conv3d_wgrad_f32(const float* x, const float* dy, float* dw, i
                                    void* ws, size_t ws_bytes, mi_stream_t stream) {
     Geom g = make_geom(N, Di, Hi, Wi, Ci, Co, k, stride, pad);
     if (!x || !dy || !dw || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
-    return run_conv(MODE_WGRAD, g, x, dy, dw, nullptr, nullptr, 0, ws, ws_bytes, 0, (hipStream_t)stream);
+    return run_conv(MODE_WGRAD, g, x, dy, dw, nullptr, nullptr, 0, ws, ws_bytes, (hipStream_t)stream);
 }
