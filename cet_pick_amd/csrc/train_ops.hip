@@ -80,12 +80,16 @@ __global__ __launch_bounds__(256) void colreduce_kernel(ColReduceParams p) {
     }
 }
 
-__global__ void colreduce_finalize_kernel(const double* partials, int n_part, int C, double* sums) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * C) return;
+// 8 columns per workgroup, 32 lanes per column: fixed-shape tree -> deterministic
+__global__ __launch_bounds__(256) void colreduce_finalize_kernel(const double* partials, int n_part,
+                                                                int C, double* sums) {
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
     double s = 0;
-    for (int b = 0; b < n_part; ++b) s += partials[(long)b * 2 * C + c];   // fixed order
-    sums[c] = s;
+    if (c < 2 * C)
+        for (int b = l; b < n_part; b += 32) s += partials[(long)b * 2 * C + c];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+    if (l == 0 && c < 2 * C) sums[c] = s;
 }
 
 int colreduce_blocks(long M, int C) {
@@ -103,7 +107,7 @@ int run_colreduce(ColReduceParams p, double* sums, void* ws, size_t ws_bytes, hi
     p.partials = (double*)ws;
     hipLaunchKernelGGL((colreduce_kernel<MODE>), dim3(blocks), dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((2 * p.C + 255) / 256), dim3(256), 0, s,
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((2 * p.C + 7) / 8), dim3(256), 0, s,
                        (const double*)ws, blocks, p.C, sums);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* dy, const 
 }
 
 // logits[b][0] = (q_b . k_b)/T ; logits[b][1+j] = (q_b . queue[:,j])/T     queue is [C][R]
-// one workgroup per row b; q_b staged in LDS
+// grid (B, ceil(R/256)): one queue column per thread, q_b staged in LDS
 __global__ __launch_bounds__(256) void moco_logits_fwd_kernel(const float* q, const float* k,
                                                              const float* queue, float* logits,
                                                              int C, int R, float invT) {
@@ -363,12 +367,14 @@ __global__ __launch_bounds__(256) void moco_logits_fwd_kernel(const float* q, co
     for (int c = tid; c < C; c += 256) qs[c] = q[(long)b * C + c];
     __syncthreads();
     float* out = logits + (long)b * (R + 1);
-    for (int j = tid; j < R; j += 256) {
+    const int j = blockIdx.y * 256 + tid;
+    if (j < R) {
         float s = 0.f;
+#pragma unroll 8
         for (int c = 0; c < C; ++c) s = fmaf(qs[c], queue[(long)c * R + j], s);
         out[1 + j] = s * invT;
     }
-    if (tid < 64) {
+    if (blockIdx.y == 0 && tid < 64) {
         float s = 0.f;
         for (int c = tid; c < C; c += 64) s = fmaf(qs[c], k[(long)b * C + c], s);
         s = wave_sum(s);
@@ -376,19 +382,19 @@ __global__ __launch_bounds__(256) void moco_logits_fwd_kernel(const float* q, co
     }
 }
 // dq[b][c] = (dl[b][0]*k[b][c] + sum_j dl[b][1+j]*queue[c][j]) / T
+// grid (B, ceil(C/4)): one wave per (b, c), the row of queue is read contiguously
 __global__ __launch_bounds__(256) void moco_logits_bwd_kernel(const float* dlogits, const float* k,
                                                              const float* queue, float* dq, int C,
                                                              int R, float invT) {
-    extern __shared__ float dl[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int j = tid; j < R + 1; j += 256) dl[j] = dlogits[(long)b * (R + 1) + j];
-    __syncthreads();
-    for (int c = wave; c < C; c += 4) {
-        float s = 0.f;
-        for (int j = lane; j < R; j += 64) s = fmaf(dl[1 + j], queue[(long)c * R + j], s);
-        s = wave_sum(s);
-        if (lane == 0) dq[(long)b * C + c] = (s + dl[0] * k[(long)b * C + c]) * invT;
-    }
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int c = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const float* dl = dlogits + (long)b * (R + 1);
+    const float* qr = queue + (long)c * R;
+    float s = 0.f;
+    for (int j = lane; j < R; j += 64) s = fmaf(dl[1 + j], qr[j], s);
+    s = wave_sum(s);
+    if (lane == 0) dq[(long)b * C + c] = (s + dl[0] * k[(long)b * C + c]) * invT;
 }
 
 // mean cross-entropy against label 0 and its gradient: dlogits = scale * (softmax - onehot0) / B
@@ -631,15 +637,15 @@ extern "C" int mi_l2norm_bwd(const float* dy, const float* y, const float* inv_n
 extern "C" int mi_moco_logits_fwd(const float* q, const float* k, const float* queue, float* logits,
                                   int B, int C, int R, float T, mi_stream_t stream) {
     if (!q || !k || !queue || !logits || B <= 0 || C <= 0 || R <= 0 || !(T > 0.f) || C > 8192) return MI_E_ARG;
-    hipLaunchKernelGGL(moco_logits_fwd_kernel, dim3(B), dim3(256), sizeof(float) * C, (hipStream_t)stream,
-                       q, k, queue, logits, C, R, 1.0f / T);
+    hipLaunchKernelGGL(moco_logits_fwd_kernel, dim3(B, (R + 255) / 256), dim3(256), sizeof(float) * C,
+                       (hipStream_t)stream, q, k, queue, logits, C, R, 1.0f / T);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
 extern "C" int mi_moco_logits_bwd(const float* dlogits, const float* k, const float* queue, float* dq,
                                   int B, int C, int R, float T, mi_stream_t stream) {
-    if (!dlogits || !k || !queue || !dq || B <= 0 || C <= 0 || R <= 0 || !(T > 0.f) || R > 12000) return MI_E_ARG;
-    hipLaunchKernelGGL(moco_logits_bwd_kernel, dim3(B), dim3(256), sizeof(float) * (R + 1), (hipStream_t)stream,
+    if (!dlogits || !k || !queue || !dq || B <= 0 || C <= 0 || R <= 0 || !(T > 0.f)) return MI_E_ARG;
+    hipLaunchKernelGGL(moco_logits_bwd_kernel, dim3(B, (C + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        dlogits, k, queue, dq, C, R, 1.0f / T);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
