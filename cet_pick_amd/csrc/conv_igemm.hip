@@ -38,7 +38,6 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
 constexpr int NTHREADS = 256;
-constexpr int BN = 64;
 constexpr int MAX_CLASSES = 8;     // stride <= 2 per axis
 constexpr int LUT_TAPS = 352;      // 7^3 = 343 rounded up to a multiple of 32
 constexpr int LUT_INVALID = 0x070707;   // bit 7 of a per-axis mask byte is never set (k <= 7)
@@ -107,16 +106,17 @@ struct Cursor {
 
 // STEM: Cin == 1 (the 7x7x7 stride-2 stem, moco_encoder_3d.py:163-169): the reduction index is
 // the tap itself and each of a chunk's 4 taps is gathered separately through a tap LUT in LDS.
-template <int MODE, int BM, int BK, bool STEM>
+template <int MODE, int BM, int BN, int BK, bool STEM>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     static_assert(BK == 16 || BK == 32, "slice depth");
+    static_assert(BN == 64 || BN == 128, "tile width");
     constexpr int WM = 2, WN = 2;
     constexpr int LDK = BK + 4;
     constexpr int KH = BK / 2;                       // k's owned by one lane-half per slice
     constexpr int KC = BK / 4;                       // 16-B chunks along k per RowK row
     constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
     constexpr int MT = WTM / 32, NT = WTN / 32;
-    static_assert(MT >= 1 && NT == 1, "wave tile");
+    static_assert(MT >= 1 && NT >= 1, "wave tile");
     constexpr bool A_ROWK = (MODE != MODE_WGRAD);
     constexpr bool B_ROWK = (MODE == MODE_DGRAD);
     constexpr int A_ELEMS = A_ROWK ? BM * LDK : BK * BM;
@@ -381,11 +381,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
         for (int i = 0; i < B_CH; ++i) *reinterpret_cast<float4*>(lds + buf * STAGE + A_ELEMS + b_lds[i]) = b_reg[i];
     };
 
-    f32x16 acc[MT];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (kt0 < kt1) {
         load_tile(kt0, true);
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
         // Phase 2: fragments of the current slice from LDS, then the MFMAs
         const float* Ab = lds + buf * STAGE;
         const float* Bb = Ab + A_ELEMS;
-        float af[MT][KH], bf[KH];
+        float af[MT][KH], bf[NT][KH];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int r = wm * WTM + i * 32 + l32;
@@ -420,24 +422,27 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                 for (int t = 0; t < KH; ++t) af[i][t] = Ab[(h * KH + t) * BM + r];
             }
         }
-        {
-            const int c = wn * WTN + l32;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int c = wn * WTN + j * 32 + l32;
             if (B_ROWK) {
 #pragma unroll
                 for (int u = 0; u < KH / 4; ++u) {
                     const float4 v = *reinterpret_cast<const float4*>(Bb + c * LDK + h * KH + 4 * u);
-                    bf[4 * u] = v.x; bf[4 * u + 1] = v.y; bf[4 * u + 2] = v.z; bf[4 * u + 3] = v.w;
+                    bf[j][4 * u] = v.x; bf[j][4 * u + 1] = v.y; bf[j][4 * u + 2] = v.z; bf[j][4 * u + 3] = v.w;
                 }
             } else {
 #pragma unroll
-                for (int t = 0; t < KH; ++t) bf[t] = Bb[(h * KH + t) * BN + c];
+                for (int t = 0; t < KH; ++t) bf[j][t] = Bb[(h * KH + t) * BN + c];
             }
         }
 #pragma unroll
         for (int t = 0; t < KH; ++t)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[t], acc[i], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         // Phase 3: the prefetched slice goes to the other LDS buffer
         store_tile(buf ^ 1);
@@ -450,8 +455,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     const bool direct = (p.slab_stride == 0);
     const bool mapped = (MODE == MODE_DGRAD) && p.n_classes > 1;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int col = n0 + wn * WTN + l32;
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * WTN + j * 32 + l32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int trow = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
             if (mapped) { row = rowmap[trow]; ok = ok && row >= 0; }
             if (ok) {
                 const long o = row * p.Ncols + col;
-                float v = acc[i][r];
+                float v = acc[i][j][r];
                 if (direct) {
                     if (p.res) v += p.res[o];
                     if (p.relu) v = fmaxf(v, 0.f);
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
     }
 }
 
-struct Plan { int bm, bk, splits; long tiles_x; };
+struct Plan { int bm, bn, bk, splits; long tiles_x; };
 
 int env_int(const char* name) {
     const char* v = getenv(name);
@@ -508,13 +515,16 @@ int env_int(const char* name) {
 template <class F>
 Plan make_plan(int mode, bool stem, long M, int Ncols, long red_len, int red_ch, F tiles_x_of) {
     Plan pl;
-    if (mode == MODE_WGRAD) pl.bm = (!stem && ((M + 127) / 128) * ((Ncols + BN - 1) / BN) <= 64) ? 128 : 64;
+    if (mode == MODE_WGRAD) pl.bm = (!stem && ((M + 127) / 128) * ((Ncols + 63) / 64) <= 64) ? 128 : 64;
     else pl.bm = (M >= 16384) ? 128 : 64;
     pl.bk = (red_ch == 0 || red_ch % 32 == 0) ? 32 : 16;
+    pl.bn = 64;                     // 128-wide tiles measured no faster on any layer (profiles/r01_conv_tuning.txt)
     if (int v = env_int("MI_CONV_BM")) pl.bm = (v == 128) ? 128 : 64;            // tuning overrides
+    if (int v = env_int("MI_CONV_BN")) pl.bn = (v == 128 && Ncols % 128 == 0) ? 128 : 64;
     if (int v = env_int("MI_CONV_BK")) if ((v == 16 || v == 32) && (red_ch == 0 || red_ch % v == 0)) pl.bk = v;
+    if (pl.bk != 32 || stem) pl.bn = 64;
     pl.tiles_x = tiles_x_of(pl.bm);
-    const long tiles = pl.tiles_x * ((Ncols + BN - 1) / BN);
+    const long tiles = pl.tiles_x * ((Ncols + pl.bn - 1) / pl.bn);
     const long nk = (red_len + pl.bk - 1) / pl.bk;
     int splits = 1;
     if (tiles < 384) {
@@ -531,13 +541,15 @@ Plan make_plan(int mode, bool stem, long M, int Ncols, long red_len, int red_ch,
 
 template <int MODE, bool STEM>
 int launch_mode(const ConvParams& p, const Plan& pl, hipStream_t s) {
-    dim3 grid((unsigned)pl.tiles_x, (unsigned)((p.Ncols + BN - 1) / BN), pl.splits);
-#define MI_LAUNCH(BM_, BK_) \
-    hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM_, BK_, STEM>), grid, dim3(NTHREADS), 0, s, p)
-    if (pl.bm == 128 && pl.bk == 32) MI_LAUNCH(128, 32);
-    else if (pl.bm == 128) MI_LAUNCH(128, 16);
-    else if (pl.bk == 32) MI_LAUNCH(64, 32);
-    else MI_LAUNCH(64, 16);
+    dim3 grid((unsigned)pl.tiles_x, (unsigned)((p.Ncols + pl.bn - 1) / pl.bn), pl.splits);
+#define MI_LAUNCH(BM_, BN_, BK_) \
+    hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM_, BN_, BK_, STEM>), grid, dim3(NTHREADS), 0, s, p)
+    if (pl.bn == 128 && !STEM) {           // 128-wide tiles only with 32-deep slices
+        if (pl.bm == 128) MI_LAUNCH(128, 128, 32); else MI_LAUNCH(64, 128, 32);
+    } else if (pl.bm == 128 && pl.bk == 32) MI_LAUNCH(128, 64, 32);
+    else if (pl.bm == 128) MI_LAUNCH(128, 64, 16);
+    else if (pl.bk == 32) MI_LAUNCH(64, 64, 32);
+    else MI_LAUNCH(64, 64, 16);
 #undef MI_LAUNCH
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;

@@ -288,8 +288,9 @@ def test_moco_three_steps_match_reference(golden):
         assert labels.dtype == torch.long and int(labels.sum()) == 0
         H.sgd_step_(aq.flat, aq.flat_grad, 0.05)
         np.testing.assert_allclose(moco.queue.cpu().numpy(), ref.queue.numpy(), rtol=0, atol=1e-4)
-        for n, p in moco.encoder_q.named_parameters():
-            np.testing.assert_allclose(p.detach().cpu().contiguous().numpy(), ref.q[n].numpy(), rtol=5e-3, atol=2e-3, err_msg=n)
+        for n, p in moco.encoder_q.named_parameters():     # after SGD: compared in norm (see gtol above)
+            a, b = p.detach().cpu().contiguous(), ref.q[n]
+            assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-5, (step, n)
         for n, p in moco.encoder_k.named_parameters():
             np.testing.assert_allclose(p.detach().cpu().contiguous().numpy(), ref.k[n].numpy(), rtol=0, atol=1e-4, err_msg=n)
         # restart the oracle from the GPU's state
