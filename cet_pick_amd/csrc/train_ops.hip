@@ -554,6 +554,13 @@ extern "C" int mi_bn_bwd_apply(const float* dy, const float* x, const float* y, 
     return MI_OK;
 }
 
+extern "C" int mi_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta, mi_stream_t stream) {
+    if (!sums || C <= 0) return MI_E_ARG;
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, dgamma, dbeta);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
 extern "C" int mi_colsum(const float* dy, long M, int C, float* out, double* sums_scratch, void* ws,
                          size_t ws_bytes, mi_stream_t stream) {
     if (!dy || !out || !sums_scratch) return MI_E_ARG;

@@ -357,10 +357,6 @@ class _BNFn(torch.autograd.Function):
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         L.check(lib.mi_bn_bwd_reduce(L.ptr(dy), L.ptr(x), L.ptr(y), m, c, L.ptr(save), int(relu), L.ptr(sums),
                                      L.ptr(ws), ws.numel(), L.stream()), "mi_bn_bwd_reduce")
-        if mod.sync and _dist_world() > 1:
-            import torch.distributed as dist
-            dist.all_reduce(sums)
-        dx = torch.empty_like(x)
         gamma = mod.weight
         dg = db = None
         acc_g = acc_b = False
@@ -369,15 +365,20 @@ class _BNFn(torch.autograd.Function):
             dg = torch.empty_like(gt) if acc_g else gt
             bt, acc_b = _grad_target(mod.bias)
             db = torch.empty_like(bt) if acc_b else bt
+            # affine gradients come from the LOCAL sums (torch.nn.SyncBatchNorm does the same); the
+            # data-parallel gradient averaging then treats them like every other parameter
+            L.check(lib.mi_bn_param_grads(L.ptr(sums), c, L.ptr(dg), L.ptr(db), L.stream()), "mi_bn_param_grads")
+        if mod.sync and _dist_world() > 1:
+            import torch.distributed as dist
+            dist.all_reduce(sums)                      # dx needs the global sums
+        dx = torch.empty_like(x)
         L.check(lib.mi_bn_bwd_apply(L.ptr(dy), L.ptr(x), L.ptr(y), L.ptr(dx), m, c, L.ptr(save), L.ptr(gamma),
-                                    L.ptr(sums), ctx.count, int(relu), L.ptr(dg), L.ptr(db), L.stream()),
+                                    L.ptr(sums), ctx.count, int(relu), None, None, L.stream()),
                 "mi_bn_bwd_apply")
         if acc_g:
             gamma.grad.add_(dg)
         if acc_b:
             mod.bias.grad.add_(db)
-        # under SyncBN the local dgamma/dbeta already hold the global sums (sums were all-reduced);
-        # the data-parallel gradient averaging divides them like every other gradient.
         return dx, None, None, None, None
 
 

@@ -143,6 +143,10 @@ int mi_bn_bwd_reduce(const float* dy, const float* x, const float* y, long M, in
 int mi_bn_bwd_apply(const float* dy, const float* x, const float* y, float* dx, long M, int C,
                     const float* save_mean_invstd, const float* gamma, const double* sums,
                     double count, int relu, float* dgamma, float* dbeta, mi_stream_t stream);
+/* dgamma = sums[C..2C), dbeta = sums[0..C) from the LOCAL (pre all-reduce) backward sums: under
+ * SyncBN the affine gradients stay per-rank and are averaged with the other gradients, exactly as
+ * torch.nn.SyncBatchNorm does. */
+int mi_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta, mi_stream_t stream);
 /* column sum (bias gradient of nn.Linear, moco_encoder_3d.py:189): out[c] = sum_m dy[m][c] */
 int mi_colsum(const float* dy, long M, int C, float* out, double* sums_scratch, void* ws,
               size_t ws_bytes, mi_stream_t stream);
