@@ -27,6 +27,7 @@ SIGNATURES = {
     "mi_dog_pick": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
     "mi_greedy_nms3d_workspace_bytes": (_Z, [_I, _I, _I]),
     "mi_greedy_nms3d": (_I, [_P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _I, _P, _Z, _P]),
+    "mi_crop_normalize": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     # training path
     "mi_conv3d_workspace_bytes": (_Z, [_I] * 9),
     "mi_conv3d_fwd_f32": (_I, [_P, _P, _P, _P, _I] + [_I] * 9 + [_P, _Z, _P]),

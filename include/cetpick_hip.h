@@ -95,6 +95,15 @@ int mi_greedy_nms3d(const float* vol, int D, int H, int W, float d, float scale,
                     size_t workspace_bytes, mi_stream_t stream);
 
 
+/* Sub-tomogram crops, one per centre (x,y,z int32); window along an axis is
+ * [c - s/2, c - s/2 + s) as the reference slices it; out-of-volume voxels repeat the edge.
+ *   mode 0: raw crop (n, cz, cy, cx)         datasets/tomo_pre_proj_angle_select_new3d_vol.py:130-138
+ *   mode 1: sum over z, min-max -> (n, cy, cx)                                          ...:117-128
+ *   mode 2: z-normalised 3-D crop (mean 0, unbiased std 1) -> (n, cz, cy, cx)   (MoCo-3D input, §8d C2)
+ * flip_x mirrors the crop along x (second contrastive view). */
+int mi_crop_normalize(const float* vol, int D, int H, int W, const int32_t* centres_xyz, int n,
+                      int cz, int cy, int cx, int mode, int flip_x, float* out, mi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training path: channels-last fp32 activations (N,D,H,W,C),
  * weights [tap][Cin][Cout] with tap = (kd*k + kh)*k + kw.

@@ -209,3 +209,23 @@ def get_potential_coords_pyramid(rec, sigmas=(2, 4), kernel=3, border_z=10, nms_
     heat = dog_nms_heat(rec, sigmas, kernel, border_z, dtype)
     cutoff = pos_threshold(heat)
     return non_maximum_suppression_3d(heat, nms_d, threshold=cutoff)
+
+
+# --------------------------------------------------------------------------- a13
+def extract_subvols(v, coord, size):
+    """datasets/tomo_pre_proj_angle_select_new3d_vol.py:117-128 (one pick, numpy like the reference).
+    Parity unpinned: that module is not importable here (mrcfile, cwd-relative imports); restated
+    from its source."""
+    sz, sy, sx = size
+    x, y, z = coord
+    sub = v[z - sz // 2:z + sz // 2 + 1, y - sy // 2:y + sy // 2, x - sx // 2:x + sx // 2].copy()
+    sub = np.sum(sub, axis=0)
+    sub = (sub - np.min(sub)) / (np.max(sub) - np.min(sub))
+    return sub.astype(np.float32)[None]
+
+
+def extract_subvols_3d(v, coord, size):
+    """...:130-138."""
+    sz, sy, sx = size
+    x, y, z = coord
+    return v[z - sz // 2:z + sz // 2 + 1, y - sy // 2:y + sy // 2, x - sx // 2:x + sx // 2].copy()
