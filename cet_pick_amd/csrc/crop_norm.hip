@@ -73,9 +73,9 @@ __global__ __launch_bounds__(256) void crop_kernel(const float* __restrict__ vol
 extern "C" int mi_crop_normalize(const float* vol, int D, int H, int W, const int32_t* centres_xyz,
                                  int n, int cz, int cy, int cx, int mode, int flip_x, float* out,
                                  mi_stream_t stream) {
+    if (n == 0) return MI_OK;
     if (!vol || !centres_xyz || !out || D <= 0 || H <= 0 || W <= 0 || n < 0) return MI_E_ARG;
     if (cz <= 0 || cy <= 0 || cx <= 0 || mode < 0 || mode > 2) return MI_E_ARG;
-    if (n == 0) return MI_OK;
     size_t lds = (mode == CROP_SUMZ_MINMAX) ? sizeof(float) * (size_t)cy * cx : 0;
     if (lds > 64 * 1024) return MI_E_UNSUPPORTED;
     hipLaunchKernelGGL(crop_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, vol, D, H, W,

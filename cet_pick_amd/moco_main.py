@@ -78,7 +78,13 @@ def main(opt):
             print(line)
             log.write(line + "\n")
             log.flush()
-            save_model(os.path.join(opt.save_dir, "model_last_contrastive.pth"), epoch, model, optimizer)
+            # moco_main.py:157,175-188: every val_intervals epochs 'model_{last|epoch}.pth' (the file
+            # --resume picks up), otherwise 'model_last_contrastive.pth'
+            mark = epoch if opt.save_all else "last"
+            if opt.val_intervals > 0 and epoch % opt.val_intervals == 0:
+                save_model(os.path.join(opt.save_dir, "model_{}.pth".format(mark)), epoch, model, optimizer)
+            else:
+                save_model(os.path.join(opt.save_dir, "model_last_contrastive.pth"), epoch, model, optimizer)
             if epoch in opt.lr_step:
                 save_model(os.path.join(opt.save_dir, "model_{}.pth".format(epoch)), epoch, model, optimizer)
     if log:

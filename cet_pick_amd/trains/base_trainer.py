@@ -126,7 +126,7 @@ class BaseTrainer(object):
             end = time.time()
             if opt.print_iter > 0 and iter_id % opt.print_iter == 0:
                 flush()
-                msg = "{}/{}| {phase}: [{0}][{1}/{2}]".format(opt.task, opt.exp_id, epoch, iter_id, num_iters, phase=phase)
+                msg = "{}/{}| {}: [{}][{}/{}]".format(opt.task, opt.exp_id, phase, epoch, iter_id, num_iters)
                 for l in avg_loss_stats:
                     msg += "|{} {:.4f} ".format(l, avg_loss_stats[l].avg)
                 if not opt.hide_data_time:
