@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 
 enum { MI_LOAD_PLAIN = 0, MI_LOAD_SIGMOID = 1, MI_LOAD_DOG = 2 };
 

@@ -21,6 +21,7 @@ int mi_launch_gauss_axis(const float* in, float* out, int D, int H, int W, int a
 namespace {
 
 constexpr int CAPN = 32;          // stored higher-priority neighbours per candidate
+constexpr int GREEDY_WIDE_ROUNDS = 24;   // chip-wide rounds before the single-workgroup finisher
 constexpr int MAX_DELTAS = 36000; // (2*16+1)^3
 
 struct GreedyHeader {
@@ -198,6 +199,44 @@ __device__ __forceinline__ int decide(unsigned i, const unsigned long long* G, c
     return all_decided ? 1 : 0;
 }
 
+// Chip-wide rounds: every launch decides whatever can be decided from the states left by the
+// previous launches (reads of states written in the same launch may be stale: that only defers a
+// decision).  `undecided` counts candidates still open; a launch that finds 0 returns at once.
+__global__ __launch_bounds__(256) void rounds_init_kernel(GreedyHeader* hdr, unsigned cap,
+                                                         unsigned char* state, unsigned* undecided) {
+    const unsigned n = min(hdr->n, cap);
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) state[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *undecided = n; hdr->n_kept = 0; }
+}
+
+__global__ __launch_bounds__(256) void round_step_kernel(GreedyHeader* hdr, const unsigned long long* G,
+                                                        const int* map, const long* deltas, long n_vox,
+                                                        unsigned cap, const int* nbr, const int* nbr_count,
+                                                        unsigned char* state, unsigned* undecided,
+                                                        unsigned long long* kept, unsigned kept_cap) {
+    if (*reinterpret_cast<volatile unsigned*>(undecided) == 0) return;
+    const unsigned n = min(hdr->n, cap);
+    const int nd = (int)hdr->n_deltas;
+    unsigned decided_here = 0;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (state[i] != 0) continue;
+        int d = decide(i, G, map, deltas, nd, n_vox, nbr, nbr_count, state);
+        if (d != 0) {
+            state[i] = (unsigned char)d;
+            ++decided_here;
+            if (d == 1) {
+                unsigned slot = atomicAdd(&hdr->n_kept, 1u);
+                if (slot < kept_cap) kept[slot] = G[i];
+            }
+        }
+    }
+    // one atomic per wave
+    unsigned tot = decided_here;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    if ((threadIdx.x & 63) == 0 && tot) atomicSub(undecided, tot);
+}
+
 __global__ __launch_bounds__(1024) void rounds_kernel(GreedyHeader* hdr, const unsigned long long* G,
                                                       const int* map, const long* deltas, long n_vox,
                                                       unsigned cap, const int* nbr,
@@ -209,13 +248,19 @@ __global__ __launch_bounds__(1024) void rounds_kernel(GreedyHeader* hdr, const u
     const int tid = threadIdx.x;
     const unsigned n = min(hdr->n, cap);
     const int nd = (int)hdr->n_deltas;
-    if (tid == 0) { s_next = 0; s_kept = 0; }
-    for (unsigned i = tid; i < n; i += 1024) state[i] = 0;
+    // finisher: picks up whatever the chip-wide rounds left undecided (usually nothing)
+    if (tid == 0) { s_next = 0; s_kept = hdr->n_kept; }
     __syncthreads();
-    unsigned n_act = n;
+    for (unsigned i = tid; i < n; i += 1024)
+        if (state[i] == 0) act_a[atomicAdd(&s_next, 1u)] = i;
+    __syncthreads();
+    unsigned n_act = s_next;
+    __syncthreads();
+    if (tid == 0) s_next = 0;
+    __syncthreads();
     unsigned* cur = act_a;
     unsigned* nxt = act_b;
-    bool first = true;
+    bool first = false;
     while (n_act > 0) {
         for (unsigned t = tid; t < n_act; t += 1024) {
             unsigned i = first ? t : cur[t];
@@ -349,6 +394,7 @@ struct GreedyWs {
     unsigned char* state;
     unsigned* act_a;
     unsigned* act_b;
+    unsigned* undecided;
     int* map;          // dense, n_vox ints
     unsigned cap, kept_cap;
 };
@@ -375,6 +421,7 @@ size_t greedy_ws_layout(size_t n_vox, size_t cap, GreedyWs* w, char* base, bool 
     p = take(cap); if (w) w->state = (unsigned char*)p;
     p = take(sizeof(unsigned) * cap); if (w) w->act_a = (unsigned*)p;
     p = take(sizeof(unsigned) * cap); if (w) w->act_b = (unsigned*)p;
+    p = take(256); if (w) w->undecided = (unsigned*)p;
     if (with_map) { p = take(sizeof(int) * n_vox); if (w) w->map = (int*)p; }
     if (w) { w->cap = (unsigned)cap; w->kept_cap = (unsigned)kept_cap; }
     return off;
@@ -393,6 +440,13 @@ int greedy_tail(const GreedyWs& w, int D, int H, int W, float d, float scale, fl
     hipLaunchKernelGGL(neighbors_kernel, dim3(2048), dim3(256), 0, s, w.hdr, w.G, w.map, w.deltas,
                        n_vox, w.cap, w.nbr, w.nbr_count);
     MI_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(rounds_init_kernel, dim3(256), dim3(256), 0, s, w.hdr, w.cap, w.state, w.undecided);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    for (int r = 0; r < GREEDY_WIDE_ROUNDS; ++r) {
+        hipLaunchKernelGGL(round_step_kernel, dim3(1024), dim3(256), 0, s, w.hdr, w.G, w.map, w.deltas, n_vox,
+                           w.cap, w.nbr, w.nbr_count, w.state, w.undecided, w.kept, w.kept_cap);
+        MI_RETURN_IF_LAUNCH_FAILED();
+    }
     hipLaunchKernelGGL(rounds_kernel, dim3(1), dim3(1024), 0, s, w.hdr, w.G, w.map, w.deltas, n_vox,
                        w.cap, w.nbr, w.nbr_count, w.state, w.act_a, w.act_b, w.kept, w.kept_cap);
     MI_RETURN_IF_LAUNCH_FAILED();

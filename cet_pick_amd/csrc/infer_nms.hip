@@ -82,64 +82,98 @@ __global__ __launch_bounds__(NT) void nms_march_kernel(MarchParams p) {
     double st_n = 0, st_s = 0, st_ss = 0;
     __syncthreads();
 
+    // ---- software pipeline: the raw values of plane zz+1 are in flight while plane zz is pooled
+    constexpr int HALO_PT = (N_HALO + NT - 1) / NT;    // halo elements per thread
+    float raw_c[4], raw_c2[4];                          // centre values (in, in2)
+    float raw_h[HALO_PT > 0 ? HALO_PT : 1], raw_h2[HALO_PT > 0 ? HALO_PT : 1];
+    // static halo geometry of this thread
+    int h_row[HALO_PT > 0 ? HALO_PT : 1], h_col[HALO_PT > 0 ? HALO_PT : 1];
+    bool h_ok[HALO_PT > 0 ? HALO_PT : 1];
+#pragma unroll
+    for (int k = 0; k < HALO_PT; ++k) {
+        const int hidx = tid + k * NT;
+        int row = 0, col = 0;
+        if (hidx < N_HALO) {
+            if (hidx < N_TOPBOT) {
+                int r = hidx / HW_;
+                col = hidx - r * HW_;
+                row = (r < PXY) ? r : (TY + r);
+            } else {
+                int hh = hidx - N_TOPBOT;
+                int r = hh / (2 * PXY > 0 ? 2 * PXY : 1);
+                int cc = hh - r * (2 * PXY);
+                row = PXY + r;
+                col = (cc < PXY) ? cc : (TX + cc);
+            }
+        }
+        h_row[k] = row; h_col[k] = col;
+        const int gy = yt0 - PXY + row, gx = xt0 - PXY + col;
+        h_ok[k] = hidx < N_HALO && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    }
+    auto fetch = [&](int zz) {
+        if (zz < 0 || zz >= p.D) return;
+        const long zb = (long)zz * HW;
+        const long base = zb + (long)y * p.W + x0;
+        if (row_ok) {
+            if (vec_ok) {
+                float4 v = *reinterpret_cast<const float4*>(p.in + base);
+                raw_c[0] = v.x; raw_c[1] = v.y; raw_c[2] = v.z; raw_c[3] = v.w;
+                if (p.mode == MI_LOAD_DOG) {
+                    float4 g = *reinterpret_cast<const float4*>(p.in2 + base);
+                    raw_c2[0] = g.x; raw_c2[1] = g.y; raw_c2[2] = g.z; raw_c2[3] = g.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (x0 + i < p.W) {
+                        raw_c[i] = p.in[base + i];
+                        if (p.mode == MI_LOAD_DOG) raw_c2[i] = p.in2[base + i];
+                    }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < HALO_PT; ++k)
+            if (h_ok[k]) {
+                const long o = zb + (long)(yt0 - PXY + h_row[k]) * p.W + (xt0 - PXY + h_col[k]);
+                raw_h[k] = p.in[o];
+                if (p.mode == MI_LOAD_DOG) raw_h2[k] = p.in2[o];
+            }
+    };
+    auto transform = [&](float v, float v2, int z, int yy, int xx) -> float {
+        if (p.mode == MI_LOAD_SIGMOID) {
+            // v_exp_f32 + v_rcp_f32 (about 1e-6 relative on the clamped range, monotone): the exact
+            // expf + IEEE divide made this HBM-bound pass VALU-bound
+            float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+            return fminf(fmaxf(sg, 1e-4f), 1.0f - 1e-4f);
+        } else if (p.mode == MI_LOAD_DOG) {
+            bool border = (z < p.bz) | (z >= p.D - p.bz) | (yy < p.by) | (yy >= p.H - p.by) |
+                          (xx < p.bx) | (xx >= p.W - p.bx);
+            return border ? 0.0f : (v2 - v);
+        }
+        return v;
+    };
+
+    fetch(z0 - PZ);
     int it = 0;
     for (int zz = z0 - PZ; zz < zend + PZ; ++zz, ++it) {
         const int b = it & 1;
         const bool plane_in = (zz >= 0) && (zz < p.D);
         float c[4] = {NEG, NEG, NEG, NEG};
         if (plane_in) {
-            // ---- stage the plane tile (+halo) into LDS
+            // ---- commit the fetched plane (+halo) to LDS
             const long base = (long)zz * HW + (long)y * p.W + x0;
             if (row_ok) {
-                if (vec_ok) {
-                    if (p.mode == MI_LOAD_PLAIN) {
-                        float4 v = *reinterpret_cast<const float4*>(p.in + base);
-                        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
-                    } else if (p.mode == MI_LOAD_SIGMOID) {
-                        float4 v = *reinterpret_cast<const float4*>(p.in + base);
-                        float t[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            float s = 1.0f / (1.0f + expf(-t[i]));
-                            c[i] = fminf(fmaxf(s, 1e-4f), 1.0f - 1e-4f);
-                        }
-                    } else {
-                        float4 a = *reinterpret_cast<const float4*>(p.in + base);
-                        float4 g = *reinterpret_cast<const float4*>(p.in2 + base);
-                        float t[4] = {g.x - a.x, g.y - a.y, g.z - a.z, g.w - a.w};
-                        bool zb = (zz < p.bz) | (zz >= p.D - p.bz) | (y < p.by) | (y >= p.H - p.by);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            int x = x0 + i;
-                            c[i] = (zb | (x < p.bx) | (x >= p.W - p.bx)) ? 0.f : t[i];
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (x0 + i < p.W) c[i] = produce(p, base + i, zz, y, x0 + i);
-                }
+                for (int i = 0; i < 4; ++i)
+                    if (x0 + i < p.W) c[i] = transform(raw_c[i], raw_c2[i], zz, y, x0 + i);
             }
             *reinterpret_cast<float4*>(&plane[b][ty + PXY][4 + 4 * tx]) = make_float4(c[0], c[1], c[2], c[3]);
-            if (PXY > 0) {
-                for (int h = tid; h < N_HALO; h += NT) {
-                    int row, col;
-                    if (h < N_TOPBOT) {
-                        int r = h / HW_;
-                        col = h - r * HW_;
-                        row = (r < PXY) ? r : (TY + r);
-                    } else {
-                        int hh = h - N_TOPBOT;
-                        int r = hh / (2 * PXY);
-                        int cc = hh - r * (2 * PXY);
-                        row = PXY + r;
-                        col = (cc < PXY) ? cc : (TX + cc);
-                    }
-                    int gy = yt0 - PXY + row, gx = xt0 - PXY + col;
+#pragma unroll
+            for (int k = 0; k < HALO_PT; ++k) {
+                if (tid + k * NT < N_HALO) {
                     float v = NEG;
-                    if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                        v = produce(p, (long)zz * HW + (long)gy * p.W + gx, zz, gy, gx);
-                    plane[b][row][col + 4 - PXY] = v;
+                    if (h_ok[k]) v = transform(raw_h[k], raw_h2[k], zz, yt0 - PXY + h_row[k], xt0 - PXY + h_col[k]);
+                    plane[b][h_row[k]][h_col[k] + 4 - PXY] = v;
                 }
             }
             // pre-NMS value (sigmoid heat-map) is an output of the fused decode
@@ -153,6 +187,7 @@ __global__ __launch_bounds__(NT) void nms_march_kernel(MarchParams p) {
                 }
             }
         }
+        if (zz + 1 < zend + PZ) fetch(zz + 1);      // in flight across the barrier and the pooling below
         __syncthreads();
 
         // ---- flush the candidate staging buffer when it could overflow during this plane
@@ -467,10 +502,13 @@ int mi_launch_march(MarchParams p, int kz, int kxy, hipStream_t s) {
 
 dim3 mi_march_grid(int D, int H, int W, int* zchunk_out) {
     int gx = mi_cdiv(W, TX), gy = mi_cdiv(H, TY);
-    // enough z-chunks to put >= ~2048 workgroups on the chip, but chunks of >= 8 planes
+    // z-chunks: >= ~768 workgroups (3 per CU) but chunks of >= 16 planes - every workgroup pays
+    // (2*PZ halo planes + one histogram flush of global atomics), so fewer, longer marches win
     int zc = D;
     long tiles = (long)gx * gy;
-    while (zc > 8 && tiles * mi_cdiv(D, zc) < 2048) zc = (zc + 1) / 2;
+    int target = 768;   // (MI_MARCH_TARGET overrides; 256..2048 measured within 5 % of each other)
+    if (const char* e = getenv("MI_MARCH_TARGET")) target = atoi(e);
+    while (zc > 16 && tiles * mi_cdiv(D, zc) < target) zc = (zc + 1) / 2;
     if (zc < 1) zc = 1;
     *zchunk_out = zc;
     return dim3(gx, gy, mi_cdiv(D, zc));

@@ -45,7 +45,7 @@ def non_maximum_suppression_3d(x, d, scale=1.0, threshold=-np.inf, max_out=None)
     lib = L.lib()
     ws = L.workspace(lib.mi_greedy_nms3d_workspace_bytes(D, H, W), v.device, "greedy")
     if max_out is None:
-        max_out = min(D * H * W, 1 << 20)
+        max_out = min(D * H * W, 1 << 17)
     scores = torch.empty((max_out,), dtype=torch.float32, device=v.device)
     coords = torch.empty((max_out, 3), dtype=torch.int32, device=v.device)
     n = torch.zeros((1,), dtype=torch.int32, device=v.device)
@@ -96,7 +96,7 @@ def dog_pick(rec, sigmas, kernel=3, border_z=10, nms_d=14, max_out=None, return_
     lib = L.lib()
     ws = L.workspace(lib.mi_dog_pick_workspace_bytes(D, H, W, len(sigmas)), v.device, "dog")
     if max_out is None:
-        max_out = min(D * H * W // 4 + 1024, 1 << 20)
+        max_out = min(D * H * W // 4 + 1024, 1 << 17)   # picks are >= d apart: 128 Ki covers a 512x512x512 volume at d=14
     scores = torch.empty((max_out,), dtype=torch.float32, device=v.device)
     coords = torch.empty((max_out, 3), dtype=torch.int32, device=v.device)
     n = torch.zeros((1,), dtype=torch.int32, device=v.device)

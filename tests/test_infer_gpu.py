@@ -72,7 +72,7 @@ def test_tomo_decode_golden(golden):
         _cmp_dets(Dm.tomo_decode(hm, kernel=k, K=50, if_fiber=True)[0].cpu().numpy(), g[f"decode_fiber_{k}"])
     # fused sigmoid + decode from the raw logits
     heat, dets = Dm.sigmoid_tomo_decode(dev(g["logits"])[None, None], kernel=3, K=50)
-    np.testing.assert_allclose(heat[0, 0].cpu().numpy(), g["sigmoid"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(heat[0, 0].cpu().numpy(), g["sigmoid"], rtol=4e-6, atol=1e-7)   # fused pass: v_exp/v_rcp
     _cmp_dets(dets[0].cpu().numpy(), g["decode_3"])
 
 
@@ -95,7 +95,7 @@ def test_decode_vs_oracle_medium():
     logits = make_logits((32, 96, 128), seed=3)
     heat, dets = Dm.sigmoid_tomo_decode(dev(logits)[None, None], kernel=3, K=300)
     hm = heat[0, 0].cpu().numpy()
-    np.testing.assert_allclose(hm, O.sigmoid_clamp(logits), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(hm, O.sigmoid_clamp(logits), rtol=4e-6, atol=1e-7)
     want = O.tomo_decode(hm, kernel=3, K=300)      # oracle continues from the GPU's heat bits
     _cmp_dets(dets[0].cpu().numpy(), want)
 
