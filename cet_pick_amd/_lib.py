@@ -33,10 +33,14 @@ SIGNATURES = {
     "mi_conv3d_fwd_f32": (_I, [_P, _P, _P, _P, _I] + [_I] * 9 + [_P, _Z, _P]),
     "mi_conv3d_dgrad_f32": (_I, [_P, _P, _P, _P, _P] + [_I] * 9 + [_P, _Z, _P]),
     "mi_conv3d_wgrad_f32": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _Z, _P]),
+    "mi_convnd_workspace_bytes": (_Z, [_I] * 13),
+    "mi_convnd_fwd_f32": (_I, [_P, _P, _P, _P, _I] + [_I] * 13 + [_P, _Z, _P]),
+    "mi_convnd_dgrad_f32": (_I, [_P, _P, _P, _P, _P] + [_I] * 13 + [_P, _Z, _P]),
+    "mi_convnd_wgrad_f32": (_I, [_P, _P, _P] + [_I] * 13 + [_P, _Z, _P]),
     "mi_colreduce_workspace_bytes": (_Z, [_L, _I]),
     "mi_bn_stats": (_I, [_P, _L, _I, _P, _P, _Z, _P]),
-    "mi_bn_apply_fwd": (_I, [_P, _P, _L, _I, _P, _D, _P, _P, _F, _F, _P, _P, _P, _I, _P]),
-    "mi_bn_eval_fwd": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _F, _P, _I, _P]),
+    "mi_bn_apply_fwd": (_I, [_P, _P, _L, _I, _P, _D, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P]),
+    "mi_bn_eval_fwd": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "mi_bn_bwd_reduce": (_I, [_P, _P, _P, _L, _I, _P, _I, _P, _P, _Z, _P]),
     "mi_bn_bwd_apply": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _D, _I, _P, _P, _P]),
     "mi_bn_param_grads": (_I, [_P, _I, _P, _P, _P]),
@@ -51,6 +55,9 @@ SIGNATURES = {
     "mi_l2norm_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "mi_moco_logits_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "mi_moco_logits_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "mi_rowdot_mean_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "mi_rowdot_mean_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "mi_column_std_mean": (_I, [_P, _P, _I, _I, _P]),
     "mi_ce_label0": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "mi_ema_update": (_I, [_P, _P, _F, _L, _P]),
     "mi_sgd_step": (_I, [_P, _P, _P, _F, _F, _L, _P]),

@@ -51,7 +51,7 @@ struct ConvParams {
     int relu;
     int N, Dg, Hg, Wg, Cg;         // gathered tensor grid / channels
     int Dr, Hr, Wr;                // row grid: FWD/WGRAD output voxels, DGRAD input voxels
-    int k, stride, pad;
+    int kd, kh, kw, stride, pd, ph, pw;   // window / zero padding per axis (2-D convs: kd = 1, pd = 0, D = 1)
     int Ci, Co;                    // conv channels (weights are [tap][Ci][Co])
     long M;                        // GEMM rows (all classes)
     int Ncols;                     // GEMM cols
@@ -135,8 +135,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, l32 = lane & 31;
     const int n0 = blockIdx.y * BN;
-    const int K = p.k, S = p.stride, P = p.pad;
-    const int taps = K * K * K;
+    const int Kz = p.kd, Ky = p.kh, Kx = p.kw, S = p.stride, Pz = p.pd, Py = p.ph, Px = p.pw;
+    const int taps = Kz * Ky * Kx;
 
     // ---- which rows does this workgroup own? ---------------------------------------------------
     int cls = 0;
@@ -147,16 +147,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     const long m0 = tile_in_cls * BM;                 // first row (within the class for DGRAD)
     // DGRAD class geometry (stride 1: a single class with cz = cy = cx = 0)
     int cz = 0, cy = 0, cx = 0, zf = 0, yf = 0, xf = 0, Dz = p.Dr, Dy = p.Hr, Dx = p.Wr;
-    int nz = K, ny = K, nx = K;                       // taps of the class per axis
+    int nz = Kz, ny = Ky, nx = Kx;                    // taps of the class per axis
     if (MODE == MODE_DGRAD) {
         cz = cls / (S * S); cy = (cls / S) % S; cx = cls % S;
-        zf = ((cz - P) % S + S) % S; yf = ((cy - P) % S + S) % S; xf = ((cx - P) % S + S) % S;
+        zf = ((cz - Pz) % S + S) % S; yf = ((cy - Py) % S + S) % S; xf = ((cx - Px) % S + S) % S;
         Dz = zf < p.Dr ? (p.Dr - zf + S - 1) / S : 0;
         Dy = yf < p.Hr ? (p.Hr - yf + S - 1) / S : 0;
         Dx = xf < p.Wr ? (p.Wr - xf + S - 1) / S : 0;
-        nz = cz < K ? (K - cz + S - 1) / S : 0;
-        ny = cy < K ? (K - cy + S - 1) / S : 0;
-        nx = cx < K ? (K - cx + S - 1) / S : 0;
+        nz = cz < Kz ? (Kz - cz + S - 1) / S : 0;
+        ny = cy < Ky ? (Ky - cy + S - 1) / S : 0;
+        nx = cx < Kx ? (Kx - cx + S - 1) / S : 0;
     }
     const long M_here = (MODE == MODE_DGRAD) ? (long)p.N * Dz * Dy * Dx : p.M;
 
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
 
     if (STEM) {
         for (int t = tid; t < LUT_TAPS; t += NTHREADS) {
-            int a = t / (K * K), b = (t / K) % K, c = t % K;
+            int a = t / (Ky * Kx), b = (t / Kx) % Ky, c = t % Kx;
             taplut[t] = (t < taps) ? make_int2((a * p.Hg + b) * p.Wg + c, a | (b << 8) | (c << 16))
                                    : make_int2(0, LUT_INVALID);
         }
@@ -202,15 +202,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                 if (MODE == MODE_FWD) {
                     int n, z, y, x;
                     rdec((unsigned)m, n, z, y, x);
-                    const int zb = z * S - P, yb = y * S - P, xb = x * S - P;
-                    a_msk[i] = axis_mask(zb, 1, K, p.Dg) | (axis_mask(yb, 1, K, p.Hg) << 8) |
-                               (axis_mask(xb, 1, K, p.Wg) << 16);
+                    const int zb = z * S - Pz, yb = y * S - Py, xb = x * S - Px;
+                    a_msk[i] = axis_mask(zb, 1, Kz, p.Dg) | (axis_mask(yb, 1, Ky, p.Hg) << 8) |
+                               (axis_mask(xb, 1, Kx, p.Wg) << 16);
                     a_ptr[i] = p.a_src + ((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg + (STEM ? 0 : 4 * c);
                 } else {
                     int n, jz, jy, jx;
                     cdec((unsigned)m, n, jz, jy, jx);
                     const int z = zf + S * jz, y = yf + S * jy, x = xf + S * jx;
-                    const int zb = (z + P - cz) / S, yb = (y + P - cy) / S, xb = (x + P - cx) / S;
+                    const int zb = (z + Pz - cz) / S, yb = (y + Py - cy) / S, xb = (x + Px - cx) / S;
                     a_msk[i] = axis_mask(zb, -1, nz, p.Dg) | (axis_mask(yb, -1, ny, p.Hg) << 8) |
                                (axis_mask(xb, -1, nx, p.Wg) << 16);
                     a_ptr[i] = p.a_src + ((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg + 4 * c;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
             if (w_ok[i] && !STEM) {
                 const int tap = (int)(row / p.Ci);
                 const int ci = (int)(row % p.Ci);
-                const int a = tap / (K * K), b = (tap / K) % K, c = tap % K;
+                const int a = tap / (Ky * Kx), b = (tap / Kx) % Ky, c = tap % Kx;
                 a_ptr[i] = p.a_src + ((long)(a * p.Hg + b) * p.Wg + c) * p.Cg + ci;
                 a_msk[i] = (unsigned)(a | (b << 8) | (c << 16));
             }
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
             const bool vok = live && mv < p.n_red_vox;
             int n, z, y, x;
             rdec(vok ? (unsigned)mv : 0u, n, z, y, x);
-            const int zb = z * S - P, yb = y * S - P, xb = x * S - P;
+            const int zb = z * S - Pz, yb = y * S - Py, xb = x * S - Px;
             const long voff = ((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg;
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
@@ -343,10 +343,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
             int wtap;              // weight tap index
             if (MODE == MODE_FWD) {
                 a_off = ((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0;
-                wtap = (ia * K + ib) * K + ic;
+                wtap = (ia * Ky + ib) * Kx + ic;
             } else {
                 a_off = -((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0;
-                wtap = ((cz + S * ia) * K + (cy + S * ib)) * K + (cx + S * ic);
+                wtap = ((cz + S * ia) * Ky + (cy + S * ib)) * Kx + (cx + S * ic);
             }
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
@@ -556,35 +556,41 @@ int launch_mode(const ConvParams& p, const Plan& pl, hipStream_t s) {
 }
 
 struct Geom {
-    int N, Di, Hi, Wi, Ci, Do, Ho, Wo, Co, k, stride, pad;
+    int N, Di, Hi, Wi, Ci, Do, Ho, Wo, Co, kd, kh, kw, stride, pd, ph, pw;
 };
 
 bool geom_ok(const Geom& g) {
     if (g.N <= 0 || g.Di <= 0 || g.Hi <= 0 || g.Wi <= 0 || g.Ci <= 0 || g.Co <= 0) return false;
-    if (g.k <= 0 || g.k > 7 || g.stride <= 0 || g.stride > 2 || g.pad < 0) return false;
+    if (g.kd <= 0 || g.kd > 7 || g.kh <= 0 || g.kh > 7 || g.kw <= 0 || g.kw > 7) return false;
+    if (g.stride <= 0 || g.stride > 2 || g.pd < 0 || g.ph < 0 || g.pw < 0) return false;
     if ((g.Ci % 16 && g.Ci != 1) || g.Co % 16) return false;
     if ((long)g.N * g.Di * g.Hi * g.Wi >= (1l << 31)) return false;     // 32-bit voxel indices
     return true;
 }
-Geom make_geom(int N, int Di, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
-    Geom g{N, Di, Hi, Wi, Ci, 0, 0, 0, Co, k, stride, pad};
-    g.Do = (Di + 2 * pad - k) / stride + 1;
-    g.Ho = (Hi + 2 * pad - k) / stride + 1;
-    g.Wo = (Wi + 2 * pad - k) / stride + 1;
+Geom make_geom_nd(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride,
+                  int pd, int ph, int pw) {
+    Geom g{N, Di, Hi, Wi, Ci, 0, 0, 0, Co, kd, kh, kw, stride, pd, ph, pw};
+    g.Do = (Di + 2 * pd - kd) / stride + 1;
+    g.Ho = (Hi + 2 * ph - kh) / stride + 1;
+    g.Wo = (Wi + 2 * pw - kw) / stride + 1;
     return g;
+}
+Geom make_geom(int N, int Di, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
+    return make_geom_nd(N, Di, Hi, Wi, Ci, Co, k, k, k, stride, pad, pad, pad);
 }
 
 // rows of DGRAD parity class c and its reduction length in taps
 void dgrad_class(const Geom& g, int c, long* rows, int* ntaps) {
-    const int S = g.stride, P = g.pad, K = g.k;
+    const int S = g.stride;
+    const int Ps[3] = {g.pd, g.ph, g.pw}, Ks[3] = {g.kd, g.kh, g.kw};
     const int cc[3] = {c / (S * S), (c / S) % S, c % S};
     const int dims[3] = {g.Di, g.Hi, g.Wi};
     long r = g.N;
     int t = 1;
     for (int a = 0; a < 3; ++a) {
-        const int f = ((cc[a] - P) % S + S) % S;
+        const int f = ((cc[a] - Ps[a]) % S + S) % S;
         r *= f < dims[a] ? (dims[a] - f + S - 1) / S : 0;
-        t *= cc[a] < K ? (K - cc[a] + S - 1) / S : 0;
+        t *= cc[a] < Ks[a] ? (Ks[a] - cc[a] + S - 1) / S : 0;
     }
     *rows = r; *ntaps = t;
 }
@@ -594,8 +600,9 @@ struct Setup { ConvParams p; Plan pl; };
 int setup_conv(int mode, const Geom& g, Setup* st) {
     ConvParams& p = st->p;
     p = ConvParams{};
-    p.N = g.N; p.k = g.k; p.stride = g.stride; p.pad = g.pad; p.Ci = g.Ci; p.Co = g.Co;
-    const int taps = g.k * g.k * g.k;
+    p.N = g.N; p.kd = g.kd; p.kh = g.kh; p.kw = g.kw; p.stride = g.stride;
+    p.pd = g.pd; p.ph = g.ph; p.pw = g.pw; p.Ci = g.Ci; p.Co = g.Co;
+    const int taps = g.kd * g.kh * g.kw;
     const bool stem = (g.Ci == 1);
     const long Mout = (long)g.N * g.Do * g.Ho * g.Wo, Min = (long)g.N * g.Di * g.Hi * g.Wi;
     p.n_classes = 1;
@@ -697,6 +704,46 @@ extern "C" int mi_conv3d_wgrad_f32(const float* x, const float* dy, float* dw, i
                                    int Hi, int Wi, int Ci, int Co, int k, int stride, int pad,
                                    void* ws, size_t ws_bytes, mi_stream_t stream) {
     Geom g = make_geom(N, Di, Hi, Wi, Ci, Co, k, stride, pad);
+    if (!x || !dy || !dw || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
+    return run_conv(MODE_WGRAD, g, x, dy, dw, nullptr, nullptr, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---- per-axis window / padding (2-D convolutions of the SimSiam 2-D encoder: kd = 1, pd = 0, D = 1)
+extern "C" size_t mi_convnd_workspace_bytes(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh,
+                                            int kw, int stride, int pd, int ph, int pw) {
+    Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
+    if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
+    size_t best = 0;
+    for (int mode = 0; mode < 3; ++mode) {
+        Setup st;
+        if (setup_conv(mode, g, &st)) continue;
+        if (st.pl.splits > 1) best = std::max(best, sizeof(float) * (size_t)st.p.M * st.p.Ncols * st.pl.splits);
+    }
+    return best + 256;
+}
+
+extern "C" int mi_convnd_fwd_f32(const float* x, const float* w, float* y, const float* res, int relu,
+                                 int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw,
+                                 int stride, int pd, int ph, int pw, void* ws, size_t ws_bytes,
+                                 mi_stream_t stream) {
+    Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
+    if (!x || !w || !y || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
+    return run_conv(MODE_FWD, g, x, w, y, res, nullptr, relu, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mi_convnd_dgrad_f32(const float* dy, const float* w, float* dx, const float* res,
+                                   const float* mask, int N, int Di, int Hi, int Wi, int Ci, int Co,
+                                   int kd, int kh, int kw, int stride, int pd, int ph, int pw, void* ws,
+                                   size_t ws_bytes, mi_stream_t stream) {
+    Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
+    if (!dy || !w || !dx || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
+    return run_conv(MODE_DGRAD, g, dy, w, dx, res, mask, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mi_convnd_wgrad_f32(const float* x, const float* dy, float* dw, int N, int Di, int Hi,
+                                   int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd,
+                                   int ph, int pw, void* ws, size_t ws_bytes, mi_stream_t stream) {
+    Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
     if (!x || !dy || !dw || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
     return run_conv(MODE_WGRAD, g, x, dy, dw, nullptr, nullptr, 0, ws, ws_bytes, (hipStream_t)stream);
 }

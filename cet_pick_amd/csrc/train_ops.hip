@@ -136,7 +136,7 @@ __global__ void bn_finalize_kernel(const double* sums, double count, int C, floa
 // y = relu?((x - mean) * invstd * gamma + beta)   (save = mean[C], invstd[C])
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, float* y, long n4, int C,
                                                       const float* save, const float* gamma,
-                                                      const float* beta, int relu) {
+                                                      const float* beta, const float* res, int relu) {
     const int CV = C >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const int c = (int)(i % CV) * 4;
@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, float* y,
         float4 o;
         o.x = fmaf((v.x - m.x) * iv.x, g.x, b.x); o.y = fmaf((v.y - m.y) * iv.y, g.y, b.y);
         o.z = fmaf((v.z - m.z) * iv.z, g.z, b.z); o.w = fmaf((v.w - m.w) * iv.w, g.w, b.w);
+        if (res) { float4 r = ld4(res + 4 * i); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         st4(y + 4 * i, o);
     }
@@ -357,6 +358,38 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* dy, const 
     }
 }
 
+// out = mean_b (a_b . b_b)   (SimSiam cosine term on normalised rows); one workgroup, fixed order
+__global__ __launch_bounds__(256) void rowdot_mean_kernel(const float* a, const float* b, float* out,
+                                                         int B, int C) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < (long)B * C; i += 256) s = fmaf(a[i], b[i], s);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+}
+// da = (g / B) * b
+__global__ void scale_by_scalar_kernel(const float* b, const float* g, float mul, float* da, long n) {
+    const float s = (*g) * mul;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) da[i] = s * b[i];
+}
+// mean over columns of the unbiased std over rows: torch.std(x, 0).mean()
+__global__ __launch_bounds__(256) void column_std_mean_kernel(const float* x, float* out, int B, int C) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s = 0, ss = 0;
+        for (int r = 0; r < B; ++r) { double v = x[(long)r * C + c]; s += v; ss += v * v; }
+        double mean = s / B, var = B > 1 ? (ss - B * mean * mean) / (B - 1) : 0.0;
+        acc += (float)sqrt(var > 0 ? var : 0.0);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+}
+
 // logits[b][0] = (q_b . k_b)/T ; logits[b][1+j] = (q_b . queue[:,j])/T     queue is [C][R]
 // grid (B, ceil(R/256)): one queue column per thread, q_b staged in LDS
 __global__ __launch_bounds__(256) void moco_logits_fwd_kernel(const float* q, const float* k,
@@ -499,7 +532,7 @@ extern "C" int mi_bn_stats(const float* x, long M, int C, double* sums, void* ws
 extern "C" int mi_bn_apply_fwd(const float* x, float* y, long M, int C, const double* sums,
                                double count, const float* gamma, const float* beta, float eps,
                                float momentum, float* running_mean, float* running_var,
-                               float* save_mean_invstd, int relu, mi_stream_t stream) {
+                               float* save_mean_invstd, const float* res, int relu, mi_stream_t stream) {
     if (!x || !y || !sums || !save_mean_invstd || !colreduce_ok(C) || M <= 0 || !(count > 0)) return MI_E_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MI_E_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -508,14 +541,14 @@ extern "C" int mi_bn_apply_fwd(const float* x, float* y, long M, int C, const do
     MI_RETURN_IF_LAUNCH_FAILED();
     long n4 = M * C / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, y, n4, C,
-                       (const float*)save_mean_invstd, gamma, beta, relu);
+                       (const float*)save_mean_invstd, gamma, beta, res, relu);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
 
 extern "C" int mi_bn_eval_fwd(const float* x, float* y, long M, int C, const float* running_mean,
                               const float* running_var, const float* gamma, const float* beta,
-                              float eps, float* scratch_2c, int relu, mi_stream_t stream) {
+                              float eps, float* scratch_2c, const float* res, int relu, mi_stream_t stream) {
     if (!x || !y || !running_mean || !running_var || !scratch_2c || !colreduce_ok(C) || M <= 0) return MI_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean,
@@ -523,7 +556,7 @@ extern "C" int mi_bn_eval_fwd(const float* x, float* y, long M, int C, const flo
     MI_RETURN_IF_LAUNCH_FAILED();
     long n4 = M * C / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, y, n4, C,
-                       (const float*)scratch_2c, gamma, beta, relu);
+                       (const float*)scratch_2c, gamma, beta, res, relu);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -637,6 +670,27 @@ extern "C" int mi_l2norm_bwd(const float* dy, const float* y, const float* inv_n
                              int C, mi_stream_t stream) {
     if (!dy || !y || !inv_norm || !dx || B <= 0 || C <= 0) return MI_E_ARG;
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, inv_norm, dx, B, C);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_rowdot_mean_fwd(const float* a, const float* b, float* out, int B, int C, mi_stream_t stream) {
+    if (!a || !b || !out || B <= 0 || C <= 0) return MI_E_ARG;
+    hipLaunchKernelGGL(rowdot_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, b, out, B, C);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+extern "C" int mi_rowdot_mean_bwd(const float* b, const float* grad_out, float* da, int B, int C, mi_stream_t stream) {
+    if (!b || !grad_out || !da || B <= 0 || C <= 0) return MI_E_ARG;
+    long n = (long)B * C;
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, b, grad_out,
+                       1.0f / (float)B, da, n);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+extern "C" int mi_column_std_mean(const float* x, float* out, int B, int C, mi_stream_t stream) {
+    if (!x || !out || B <= 0 || C <= 0) return MI_E_ARG;
+    hipLaunchKernelGGL(column_std_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, out, B, C);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

@@ -67,6 +67,9 @@ def _phys_ok(p):
     if p.dim() == 5:
         co, ci, kd, kh, kw = p.shape
         return p.stride() == (1, co, kh * kw * ci * co, kw * ci * co, ci * co)
+    if p.dim() == 4:
+        co, ci, kh, kw = p.shape
+        return p.stride() == (1, co, kw * ci * co, ci * co)
     if p.dim() == 2:
         out_f, in_f = p.shape
         return p.stride() == (1, out_f)
@@ -127,54 +130,84 @@ class ParamArena:
 # ------------------------------------------------------------------------------------------------
 # conv / linear
 # ------------------------------------------------------------------------------------------------
-def _conv_geom(x, w, k, stride, pad):
-    n, d, h, wd, ci = x.shape
-    co = w.shape[0]
-    do = (d + 2 * pad - k) // stride + 1
-    ho = (h + 2 * pad - k) // stride + 1
-    wo = (wd + 2 * pad - k) // stride + 1
-    return n, d, h, wd, ci, co, do, ho, wo
+def conv2d_weight_param(co, ci, k, device=None):
+    """Parameter with logical shape (co, ci, k, k) over physical storage [k,k,ci,co]."""
+    phys = torch.empty(k, k, ci, co, device=device)
+    return nn.Parameter(phys.permute(3, 2, 0, 1))
+
+
+def _k3(k, nd5):
+    """int or tuple -> (kd, kh, kw); 2-D activations (N,H,W,C) use kd = 1."""
+    if isinstance(k, (tuple, list)):
+        return tuple(int(v) for v in k) if len(k) == 3 else (1, int(k[0]), int(k[1]))
+    return (int(k),) * 3 if nd5 else (1, int(k), int(k))
+
+
+def _p3(p, nd5):
+    if isinstance(p, (tuple, list)):
+        return tuple(int(v) for v in p) if len(p) == 3 else (0, int(p[0]), int(p[1]))
+    return (int(p),) * 3 if nd5 else (0, int(p), int(p))
+
+
+def _as5d(x):
+    """(N,H,W,C) -> (N,1,H,W,C) view; 5-D passes through."""
+    return x if x.dim() == 5 else x.unsqueeze(1)
+
+
+def _out_dims(shape5, k3, stride, p3):
+    n, d, h, w, _ = shape5
+    return tuple((v + 2 * p - k) // stride + 1 for v, k, p in zip((d, h, w), k3, p3))
 
 
 def conv_fwd(x, w, k, stride, pad, res=None, relu=False):
+    """y = act(conv(x, w) + res).  x: (N,D,H,W,Ci) or (N,H,W,Ci) channels-last; w in kernel layout."""
     _f32c(x, "x")
     if not _phys_ok(w):
         raise L.HipExtensionError("conv weight is not in kernel layout [tap][Cin][Cout]")
-    n, d, h, wd, ci, co, do, ho, wo = _conv_geom(x, w, k, stride, pad)
-    y = torch.empty((n, do, ho, wo, co), dtype=torch.float32, device=x.device)
+    nd5 = x.dim() == 5
+    k3, p3 = _k3(k, nd5), _p3(pad, nd5)
+    x5 = _as5d(x)
+    n, d, h, wd, ci = x5.shape
+    co = w.shape[0]
+    do, ho, wo = _out_dims(x5.shape, k3, stride, p3)
+    y = torch.empty((n, do, ho, wo, co) if nd5 else (n, ho, wo, co), dtype=torch.float32, device=x.device)
     lib = L.lib()
-    ws = _ws(lib.mi_conv3d_workspace_bytes(n, d, h, wd, ci, co, k, stride, pad), x.device, "conv")
-    with _Prof("fwd", 2.0 * n * do * ho * wo * co * ci * k ** 3):
-        L.check(lib.mi_conv3d_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(res), int(relu), n, d, h, wd, ci,
-                                      co, k, stride, pad, L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_fwd_f32")
+    ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), x.device, "conv")
+    with _Prof("fwd", 2.0 * n * do * ho * wo * co * ci * k3[0] * k3[1] * k3[2]):
+        L.check(lib.mi_convnd_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(res), int(relu), n, d, h, wd, ci, co,
+                                      *k3, stride, *p3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_fwd_f32")
     return y
 
 
 def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None):
     _f32c(dy, "dy")
-    n, d, h, wd, ci = in_shape
+    nd5 = len(in_shape) == 5
+    k3, p3 = _k3(k, nd5), _p3(pad, nd5)
+    shape5 = tuple(in_shape) if nd5 else (in_shape[0], 1) + tuple(in_shape[1:])
+    n, d, h, wd, ci = shape5
     co = w.shape[0]
-    dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
+    dx = torch.empty(tuple(in_shape), dtype=torch.float32, device=dy.device)
     lib = L.lib()
-    ws = _ws(lib.mi_conv3d_workspace_bytes(n, d, h, wd, ci, co, k, stride, pad), dy.device, "conv")
-    with _Prof("dgrad", 2.0 * dy.numel() * ci * k ** 3):
-        L.check(lib.mi_conv3d_dgrad_f32(L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(res), L.ptr(mask), n, d, h, wd,
-                                        ci, co, k, stride, pad, L.ptr(ws), ws.numel(), L.stream()),
-                "mi_conv3d_dgrad_f32")
+    ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), dy.device, "conv")
+    with _Prof("dgrad", 2.0 * dy.numel() * ci * k3[0] * k3[1] * k3[2]):
+        L.check(lib.mi_convnd_dgrad_f32(L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(res), L.ptr(mask), n, d, h, wd, ci, co,
+                                        *k3, stride, *p3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_dgrad_f32")
     return dx
 
 
 def conv_wgrad_into(x, dy, param, k, stride, pad):
     """dW for `param`, written (or accumulated) into param.grad."""
-    n, d, h, wd, ci = x.shape
+    nd5 = x.dim() == 5
+    k3, p3 = _k3(k, nd5), _p3(pad, nd5)
+    n, d, h, wd, ci = _as5d(x).shape
     co = dy.shape[-1]
     lib = L.lib()
-    ws = _ws(lib.mi_conv3d_workspace_bytes(n, d, h, wd, ci, co, k, stride, pad), x.device, "conv")
+    ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), x.device, "conv")
     g, acc = _grad_target(param)
     tgt = torch.empty_like(g) if acc else g
-    with _Prof("wgrad", 2.0 * dy.numel() * ci * k ** 3):
-        L.check(lib.mi_conv3d_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, k, stride, pad,
-                                        L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_wgrad_f32")
+    with _Prof("wgrad", 2.0 * dy.numel() * ci * k3[0] * k3[1] * k3[2]):
+        L.check(lib.mi_convnd_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, *k3, stride, *p3,
+                                        L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_wgrad_f32")
     if acc:
         g.add_(tgt)
 
@@ -222,6 +255,21 @@ class HipConv3d(nn.Module):
         with torch.no_grad():
             # nn.Conv3d default init: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
             bound = 1.0 / (ci * k ** 3) ** 0.5
+            self.weight.uniform_(-bound, bound)
+
+    def forward(self, x, relu=False):
+        return _ConvFn.apply(x, self.weight, self, relu)
+
+
+class HipConv2d(nn.Module):
+    """nn.Conv2d(ci, co, k, stride, padding, bias=False) on channels-last (N,H,W,C) activations."""
+
+    def __init__(self, ci, co, k, stride=1, pad=0):
+        super().__init__()
+        self.ci, self.co, self.k, self.stride, self.pad = ci, co, k, stride, pad
+        self.weight = conv2d_weight_param(co, ci, k)
+        with torch.no_grad():
+            bound = 1.0 / (ci * k * k) ** 0.5
             self.weight.uniform_(-bound, bound)
 
     def forward(self, x, relu=False):
@@ -307,8 +355,10 @@ def _dist_world():
 
 
 class _BNFn(torch.autograd.Function):
+    """y = act(bn(x) + res); res (optional) is a residual branch added before the activation."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, mod, relu):
+    def forward(ctx, x, gamma, beta, mod, relu, res=None):
         shape = x.shape
         c = shape[-1]
         m = x.numel() // c
@@ -330,17 +380,18 @@ class _BNFn(torch.autograd.Function):
                                         mod.eps, mod.momentum,
                                         L.ptr(mod.running_mean if track else None),
                                         L.ptr(mod.running_var if track else None),
-                                        L.ptr(save), int(relu), L.stream()), "mi_bn_apply_fwd")
+                                        L.ptr(save), L.ptr(res), int(relu), L.stream()), "mi_bn_apply_fwd")
             if track:
                 mod.num_batches_tracked += 1
             ctx.count = count
             ctx.train_stats = True
         else:
             L.check(lib.mi_bn_eval_fwd(L.ptr(x), L.ptr(y), m, c, L.ptr(mod.running_mean), L.ptr(mod.running_var),
-                                       L.ptr(gamma), L.ptr(beta), mod.eps, L.ptr(save), int(relu), L.stream()),
-                    "mi_bn_eval_fwd")
+                                       L.ptr(gamma), L.ptr(beta), mod.eps, L.ptr(save), L.ptr(res), int(relu),
+                                       L.stream()), "mi_bn_eval_fwd")
             ctx.train_stats = False
         ctx.mod, ctx.relu, ctx.m, ctx.c = mod, relu, m, c
+        ctx.has_res = res is not None
         ctx.save_for_backward(x, y if relu else None, save)
         return y
 
@@ -353,6 +404,13 @@ class _BNFn(torch.autograd.Function):
         dev = x.device
         if not ctx.train_stats:
             raise L.HipExtensionError("BatchNorm backward in eval mode is not on the hot path")
+        dres = None
+        if ctx.has_res:
+            # the residual branch receives the gradient behind the activation; BN continues from it
+            if relu:
+                dy = relu_mask(dy, y)
+                relu = False
+            dres = dy
         ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         L.check(lib.mi_bn_bwd_reduce(L.ptr(dy), L.ptr(x), L.ptr(y), m, c, L.ptr(save), int(relu), L.ptr(sums),
@@ -379,7 +437,7 @@ class _BNFn(torch.autograd.Function):
             gamma.grad.add_(dg)
         if acc_b:
             mod.bias.grad.add_(db)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, dres
 
 
 class HipBatchNorm(nn.Module):
@@ -400,8 +458,8 @@ class HipBatchNorm(nn.Module):
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, relu=False):
-        return _BNFn.apply(_f32c(x, "x"), self.weight, self.bias, self, relu)
+    def forward(self, x, relu=False, res=None):
+        return _BNFn.apply(_f32c(x, "x"), self.weight, self.bias, self, relu, res)
 
 
 def convert_sync_batchnorm(module):
@@ -593,6 +651,38 @@ class _CELabel0Fn(torch.autograd.Function):
 def cross_entropy_label0(logits):
     """nn.CrossEntropyLoss()(logits, zeros) (trains/tomo_moco_trainer.py:52,73)."""
     return _CELabel0Fn.apply(_f32c(logits, "logits"))
+
+
+class _RowDotMeanFn(torch.autograd.Function):
+    """mean_b(a_b . b_b); gradient w.r.t. a only (b is the detached target)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        bsz, c = a.shape
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        L.check(L.lib().mi_rowdot_mean_fwd(L.ptr(a), L.ptr(b), L.ptr(out), bsz, c, L.stream()), "mi_rowdot_mean_fwd")
+        ctx.save_for_backward(b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (b,) = ctx.saved_tensors
+        da = torch.empty_like(b)
+        L.check(L.lib().mi_rowdot_mean_bwd(L.ptr(b), L.ptr(g.contiguous()), L.ptr(da), b.shape[0], b.shape[1],
+                                           L.stream()), "mi_rowdot_mean_bwd")
+        return da, None
+
+
+def rowdot_mean(a, b):
+    return _RowDotMeanFn.apply(_f32c(a, "a"), _f32c(b, "b"))
+
+
+def column_std_mean(x):
+    """torch.std(x, 0).mean() (the SimSiam `output_std` monitor)."""
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    L.check(L.lib().mi_column_std_mean(L.ptr(_f32c(x, "x")), L.ptr(out), x.shape[0], x.shape[1], L.stream()),
+            "mi_column_std_mean")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

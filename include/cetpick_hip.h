@@ -130,20 +130,38 @@ int mi_conv3d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int D
                         int Ci, int Co, int k, int stride, int pad, void* ws, size_t ws_bytes,
                         mi_stream_t stream);
 
+/* Same kernels with a per-axis window (kd,kh,kw) and zero padding (pd,ph,pw); weights
+ * [kd][kh][kw][Cin][Cout].  nn.Conv2d of the 2-D encoder (models/networks/simsiam_model_2d.py:25-28,
+ * 473-502, 617-661) is the D = 1, kd = 1, pd = 0 case on (N,1,H,W,C) activations. */
+size_t mi_convnd_workspace_bytes(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw,
+                                 int stride, int pd, int ph, int pw);
+int mi_convnd_fwd_f32(const float* x, const float* w, float* y, const float* res, int relu, int N,
+                      int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd,
+                      int ph, int pw, void* ws, size_t ws_bytes, mi_stream_t stream);
+int mi_convnd_dgrad_f32(const float* dy, const float* w, float* dx, const float* res,
+                        const float* mask, int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh,
+                        int kw, int stride, int pd, int ph, int pw, void* ws, size_t ws_bytes,
+                        mi_stream_t stream);
+int mi_convnd_wgrad_f32(const float* x, const float* dy, float* dw, int N, int Di, int Hi, int Wi,
+                        int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw,
+                        void* ws, size_t ws_bytes, mi_stream_t stream);
+
 /* nn.BatchNorm3d / BatchNorm1d over rows [M][C] (moco_encoder_3d.py:170,184,199-205), split so a
  * SyncBN all-reduce of `sums` (2*C doubles: sum x, sum x^2) fits between stats and apply.
  * count = rows behind `sums` (global M under SyncBN).  save = mean[C], invstd[C].
- * gamma/beta NULL = affine=False.  running stats NULL = not tracked.  C % 4 == 0, 256 % (C/4) == 0. */
+ * gamma/beta NULL = affine=False.  running stats NULL = not tracked.  C % 4 == 0, 256 % (C/4) == 0.
+ * y = act(bn(x) + res): res (may be NULL) is the residual branch of the 2-D BasicBlock
+ * (simsiam_model_2d.py:485-502). */
 size_t mi_colreduce_workspace_bytes(long M, int C);
 int mi_bn_stats(const float* x, long M, int C, double* sums, void* ws, size_t ws_bytes,
                 mi_stream_t stream);
 int mi_bn_apply_fwd(const float* x, float* y, long M, int C, const double* sums, double count,
                     const float* gamma, const float* beta, float eps, float momentum,
-                    float* running_mean, float* running_var, float* save_mean_invstd, int relu,
-                    mi_stream_t stream);
+                    float* running_mean, float* running_var, float* save_mean_invstd,
+                    const float* res, int relu, mi_stream_t stream);
 int mi_bn_eval_fwd(const float* x, float* y, long M, int C, const float* running_mean,
                    const float* running_var, const float* gamma, const float* beta, float eps,
-                   float* scratch_2c, int relu, mi_stream_t stream);
+                   float* scratch_2c, const float* res, int relu, mi_stream_t stream);
 /* backward: sums = {sum dy', sum dy'*xhat} with dy' = dy*(y>0) when relu; then
  * dx = gamma*invstd*(dy' - sums[0]/count - xhat*sums[1]/count), dgamma = sums[1], dbeta = sums[0]. */
 int mi_bn_bwd_reduce(const float* dy, const float* x, const float* y, long M, int C,
@@ -183,6 +201,12 @@ int mi_moco_logits_fwd(const float* q, const float* k, const float* queue, float
                        int C, int R, float T, mi_stream_t stream);
 int mi_moco_logits_bwd(const float* dlogits, const float* k, const float* queue, float* dq, int B,
                        int C, int R, float T, mi_stream_t stream);
+/* SimSiam loss pieces (trains/tomo_simsiam_trainer.py:28-40) on L2-normalised rows:
+ * out = mean_b(a_b . b_b) (nn.CosineSimilarity(dim=1)(p, z).mean() once p, z are normalised), its
+ * gradient da = grad_out/B * b, and output_std = torch.std(x, 0).mean(). */
+int mi_rowdot_mean_fwd(const float* a, const float* b, float* out, int B, int C, mi_stream_t stream);
+int mi_rowdot_mean_bwd(const float* b, const float* grad_out, float* da, int B, int C, mi_stream_t stream);
+int mi_column_std_mean(const float* x, float* out, int B, int C, mi_stream_t stream);
 /* nn.CrossEntropyLoss against label 0 (trains/tomo_moco_trainer.py:52,73; models/moco.py:141):
  * loss = mean_b(logsumexp(l_b) - l_b[0]); dlogits = grad_scale*(softmax - onehot0)/B (may be NULL). */
 int mi_ce_label0(const float* logits, float* loss, float* row_loss, float* dlogits, int B, int n,

@@ -115,3 +115,65 @@ def adjust_learning_rate(lr, epoch, lr_step, lr_decay_rate, cosine=False, num_ep
         return eta_min + (lr - eta_min) * (1 + math.cos(math.pi * epoch / num_epochs)) / 2
     steps = int(np.sum(epoch > np.asarray(lr_step)))
     return lr * (lr_decay_rate ** steps) if steps > 0 else lr
+
+
+# ------------------------------------------------------------------------------------------------
+# a2 / a9: SimSiam 2-D encoder and loss
+# ------------------------------------------------------------------------------------------------
+def _block2d(sd, prefix, x, stride, train):
+    """simsiam_model_2d.py:473-502 BasicBlock (BatchNorm2d inside, 1x1 strided downsample without BN)."""
+    out = F.conv2d(x, sd[prefix + ".conv1.weight"], stride=stride, padding=1)
+    out = F.relu(_bn(sd, prefix + ".bn1", out, train, BN_MOMENTUM))
+    out = F.conv2d(out, sd[prefix + ".conv2.weight"], padding=1)
+    out = _bn(sd, prefix + ".bn2", out, train, BN_MOMENTUM)
+    res = x
+    if prefix + ".downsample.0.weight" in sd:
+        res = F.conv2d(x, sd[prefix + ".downsample.0.weight"], stride=stride)
+    return F.relu(out + res)
+
+
+def encoder2d_trunk(sd, x, train=True):
+    """simsiam_model_2d.py:776-800 (one view): conv1-bn-relu, layer1-3, avgpool, fc."""
+    x = F.relu(_bn(sd, "bn1", F.conv2d(x, sd["conv1.weight"], padding=1), train, BN_MOMENTUM))
+    for li, stride in ((1, 1), (2, 2), (3, 2)):
+        for bi in range(2):
+            x = _block2d(sd, "layer%d.%d" % (li, bi), x, stride if bi == 0 else 1, train)
+    x = F.adaptive_avg_pool2d(x, 1).reshape(x.shape[0], -1)
+    return F.linear(x, sd["fc.weight"], sd["fc.bias"])
+
+
+def simsiam_heads(sd, f, train=True):
+    """proj (3 x Linear+BN, last affine=False) and pred (Linear-BN-ReLU-Linear) MLPs, :643-660."""
+    z = F.relu(_bn(sd, "proj.1", F.linear(f, sd["proj.0.weight"]), train, 0.1))
+    z = F.relu(_bn(sd, "proj.4", F.linear(z, sd["proj.3.weight"]), train, 0.1))
+    z = _bn(sd, "proj.7", F.linear(z, sd["proj.6.weight"]), train, 0.1, affine=False)
+    p = F.relu(_bn(sd, "pred.1", F.linear(z, sd["pred.0.weight"]), train, 0.1))
+    p = F.linear(p, sd["pred.3.weight"], sd["pred.3.bias"])
+    return z, p
+
+
+def simsiam_forward(sd, x1, x2, train=True):
+    """:776-819: views share weights; BN layers see view 1's trunk, then view 2's trunk, then the
+    heads in the order z1, z2, p1, p2 (running statistics are updated in that order)."""
+    f1 = encoder2d_trunk(sd, x1, train)
+    f2 = encoder2d_trunk(sd, x2, train)
+    # heads: proj(view1), proj(view2), pred(view1), pred(view2) - the reference's call order
+    def proj(f):
+        z = F.relu(_bn(sd, "proj.1", F.linear(f, sd["proj.0.weight"]), train, 0.1))
+        z = F.relu(_bn(sd, "proj.4", F.linear(z, sd["proj.3.weight"]), train, 0.1))
+        return _bn(sd, "proj.7", F.linear(z, sd["proj.6.weight"]), train, 0.1, affine=False)
+
+    def pred(z):
+        p = F.relu(_bn(sd, "pred.1", F.linear(z, sd["pred.0.weight"]), train, 0.1))
+        return F.linear(p, sd["pred.3.weight"], sd["pred.3.bias"])
+    z1, z2 = proj(f1), proj(f2)
+    p1, p2 = pred(z1), pred(z2)
+    return p1, z1, p2, z2
+
+
+def simsiam_loss(p1, z1, p2, z2):
+    """trains/tomo_simsiam_trainer.py:28-40."""
+    cos = torch.nn.CosineSimilarity(dim=1)
+    loss = -(cos(p1, z2.detach()).mean() + cos(p2, z1.detach()).mean()) * 0.5
+    output_std = torch.std(F.normalize(p1.detach(), dim=1), 0).mean()
+    return loss, output_std

@@ -160,9 +160,11 @@ def gen_enc3d():
     res["proj_eval"] = enc2.forward_test(x)["proj"].numpy()
     res["sample_idx"] = idx
     save("enc3d.npz", **res)
-    with open(os.path.join(HERE, "ckpt_keys.json"), "w") as f:
-        json.dump({"moco3d_encoder": keys,
-                   "proj_is_pred": bool(enc.proj is enc.pred)}, f, indent=1)
+    path = os.path.join(HERE, "ckpt_keys.json")
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    d.update({"moco3d_encoder": keys, "proj_is_pred": bool(enc.proj is enc.pred)})
+    with open(path, "w") as f:
+        json.dump(d, f, indent=1)
 
 
 def gen_moco():
@@ -208,6 +210,52 @@ def gen_moco():
     save("moco_3steps.npz", **res)
 
 
+def gen_simsiam2d():
+    """a2 + a9: TomoResClassifier2D (simsiam_model_2d.py:617-819) two-view forward/backward under
+    TomoSimSiamLoss's arithmetic (trains/tomo_simsiam_trainer.py:28-40; that module itself imports
+    `progress`, so its six lines are evaluated here on the reference model's outputs)."""
+    tvm = _stub("torchvision.models")
+    _stub("torchvision.models.resnet", BasicBlock=object, Bottleneck=object, ResNet=object)
+    sys.modules["torchvision"].models = tvm
+    from cet_pick.models.networks import simsiam_model_2d as R2
+    heads = {"proj": 128, "pred": 128}
+    net = R2.TomoResClassifier2D(R2.BasicBlock, [2, 2, 2, 2], heads, 128)
+    net.load_state_dict(seeded_state_dict(net, seed=318))
+    keys = {k: list(v.shape) for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x1 = torch.randn(8, 1, 36, 36, generator=g)
+    x2 = x1.flip(3) + 0.1 * torch.randn(8, 1, 36, 36, generator=g)
+    net.train()
+    out = net(x1, x2)
+    p1, z1, p2, z2 = out[0]["pred"], out[0]["proj"], out[1]["pred"], out[1]["proj"]
+    cos = torch.nn.CosineSimilarity(dim=1)
+    loss = -(cos(p1, z2).mean() + cos(p2, z1).mean()) * 0.5
+    ostd = torch.std(torch.nn.functional.normalize(p1.detach(), dim=1), 0).mean()
+    loss.backward()
+    res = {"p1": p1.detach().numpy(), "z1": z1.numpy(), "p2": p2.detach().numpy(), "z2": z2.numpy(),
+           "loss": np.asarray(loss.item()), "output_std": np.asarray(ostd.item()),
+           "z_requires_grad": np.asarray(int(z1.requires_grad))}
+    idx = np.random.default_rng(4).integers(0, 2 ** 31, size=128)
+    for k, prm in net.named_parameters():
+        gf = prm.grad.reshape(-1).numpy()
+        res[f"grad_{k}_norm"] = np.asarray(np.linalg.norm(gf.astype(np.float64)))
+        res[f"grad_{k}_sample"] = gf[idx % gf.size]
+    res["sample_idx"] = idx
+    res["bn1_running_var"] = net.bn1.running_var.numpy().copy()
+    res["nbt"] = np.asarray(int(net.bn1.num_batches_tracked))
+    net2 = R2.TomoResClassifier2D(R2.BasicBlock, [2, 2, 2, 2], heads, 128)
+    net2.load_state_dict(seeded_state_dict(net2, seed=318))
+    net2.eval()
+    ft = net2.forward_test(x1)
+    res["test_proj"] = ft["proj"].numpy()
+    res["test_pred"] = ft["pred"].detach().numpy()
+    save("simsiam2d.npz", **res)
+    path = os.path.join(HERE, "ckpt_keys.json")
+    d = json.load(open(path))
+    d["simsiam2d_encoder"] = keys
+    json.dump(d, open(path, "w"), indent=1)
+
+
 def gen_lr():
     class A:
         pass
@@ -223,6 +271,6 @@ def gen_lr():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr"]
+    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d"]
     for w in which:
         globals()["gen_" + w]()

@@ -90,3 +90,39 @@ def test_lr_schedule(golden):
     for cosine, ep, lr in rows:
         got = T.adjust_learning_rate(0.02, int(ep), [90, 120], 0.1, bool(cosine), 140)
         assert abs(got - lr) < 1e-12
+
+
+def _seeded_sd_2d(seed=318):
+    import json, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    shapes = json.load(open(os.path.join(here, "golden", "ckpt_keys.json")))["simsiam2d_encoder"]
+    return seeded_state_dict(_Shape(shapes), seed=seed)
+
+
+def test_simsiam2d_forward_backward_matches_reference(golden):
+    g = golden("simsiam2d.npz")
+    sd = _seeded_sd_2d()
+    names = [k for k in sd if k.endswith((".weight", ".bias"))]
+    for n in names:
+        sd[n].requires_grad_(True)
+    gen = torch.Generator().manual_seed(5)
+    x1 = torch.randn(8, 1, 36, 36, generator=gen)
+    x2 = x1.flip(3) + 0.1 * torch.randn(8, 1, 36, 36, generator=gen)
+    p1, z1, p2, z2 = T.simsiam_forward(sd, x1, x2, True)
+    loss, ostd = T.simsiam_loss(p1, z1, p2, z2)
+    np.testing.assert_allclose(p1.detach().numpy(), g["p1"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(z2.detach().numpy(), g["z2"], rtol=1e-4, atol=1e-5)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-6
+    assert abs(float(ostd) - float(g["output_std"])) < 1e-6
+    grads = torch.autograd.grad(loss, [sd[n] for n in names])
+    for n, gr in zip(names, grads):
+        ref = float(g[f"grad_{n}_norm"])
+        got = float(np.linalg.norm(gr.reshape(-1).numpy().astype(np.float64)))
+        assert abs(got - ref) <= 1e-3 * ref + 1e-7, n
+    np.testing.assert_allclose(sd["bn1.running_var"].numpy(), g["bn1_running_var"], rtol=1e-5, atol=1e-6)
+    sd2 = _seeded_sd_2d()
+    with torch.no_grad():
+        f = T.encoder2d_trunk(sd2, x1, False)
+        z, p = T.simsiam_heads(sd2, f, False)
+    np.testing.assert_allclose(z.numpy(), g["test_proj"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(p.numpy(), g["test_pred"], rtol=1e-4, atol=1e-5)

@@ -1,0 +1,116 @@
+"""a2 + a9 on the GPU: 2-D convolutions through the implicit-GEMM kernel, the SimSiam 2-D encoder
+two-view forward/backward and loss against the reference's golden vectors, and the simsiam trainer
+entry points on BASELINE configs[0]-sized inputs (36x36 crops, batch 8)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("case", [(4, 36, 36, 64, 64, 3, 1, 1), (4, 36, 36, 64, 128, 3, 2, 1), (3, 18, 18, 64, 128, 1, 2, 0),
+                                  (8, 36, 36, 1, 64, 3, 1, 1), (2, 9, 9, 256, 256, 3, 1, 1), (2, 13, 11, 32, 16, 3, 2, 1)])
+def test_conv2d_fwd_dgrad_wgrad(case):
+    from cet_pick_amd import hipops as H
+    n, h, w, ci, co, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5
+    param = H.conv2d_weight_param(co, ci, k)
+    with torch.no_grad():
+        param.copy_(wt)
+    param.data = param.data.cuda()
+    assert H._phys_ok(param)
+    xc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y = H.conv_fwd(xc, param, k, s, p)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, stride=s, padding=p)
+    np.testing.assert_allclose(y.permute(0, 3, 1, 2).cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-4)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    dyc = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    if ci != 1:
+        dx = H.conv_dgrad(dyc, param, tuple(xc.shape), k, s, p)
+        np.testing.assert_allclose(dx.permute(0, 3, 1, 2).cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=2e-4)
+    param.grad = None
+    H.conv_wgrad_into(xc, dyc, param, k, s, p)
+    sc = max(1.0, float(wr.grad.abs().max()))
+    np.testing.assert_allclose(param.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol=2e-5 * sc)
+
+
+def _seeded_net():
+    from cet_pick_amd.models.model import create_model
+    from cet_pick_amd.synthetic import seeded_state_dict
+    net = create_model("simsiam2d_18", {"proj": 128, "pred": 128}, 128)
+    net.load_state_dict(seeded_state_dict(net, seed=318))
+    return net.cuda()
+
+
+def test_simsiam2d_matches_reference_golden(golden):
+    from cet_pick_amd.trains.tomo_simsiam_trainer import TomoSimSiamLoss
+    g = golden("simsiam2d.npz")
+    net = _seeded_net()
+    keys = json.load(open(os.path.join(HERE, "golden", "ckpt_keys.json")))["simsiam2d_encoder"]
+    sd = net.state_dict()
+    assert list(sd) == list(keys) and all(list(sd[k].shape) == keys[k] for k in keys)
+    gen = torch.Generator().manual_seed(5)
+    x1 = torch.randn(8, 1, 36, 36, generator=gen)
+    x2 = x1.flip(3) + 0.1 * torch.randn(8, 1, 36, 36, generator=gen)
+    net.train()
+    out = net(x1.cuda(), x2.cuda())
+    assert not out[0]["proj"].requires_grad and out[0]["pred"].requires_grad        # SimSiam stop-gradient
+    for name, ref in (("p1", out[0]["pred"]), ("z1", out[0]["proj"]), ("p2", out[1]["pred"]), ("z2", out[1]["proj"])):
+        np.testing.assert_allclose(ref.detach().cpu().numpy(), g[name], rtol=1e-3, atol=1e-3, err_msg=name)
+    loss, stats = TomoSimSiamLoss(None)(out, None, 0)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4
+    assert abs(float(stats["output_std"]) - float(g["output_std"])) < 1e-5
+    loss.backward()
+    idx = g["sample_idx"]
+    for n, p in net.named_parameters():
+        gf = p.grad.detach().cpu().contiguous().reshape(-1).numpy()
+        ref = float(g[f"grad_{n}_norm"])
+        assert abs(np.linalg.norm(gf.astype(np.float64)) - ref) <= 3e-3 * ref + 2e-6, n
+        rs = g[f"grad_{n}_sample"]
+        np.testing.assert_allclose(gf[idx % gf.size], rs, rtol=3e-3, atol=3e-3 * float(np.abs(rs).max()) + 2e-6, err_msg=n)
+    np.testing.assert_allclose(net.bn1.running_var.cpu().numpy(), g["bn1_running_var"], rtol=1e-4, atol=1e-5)
+    assert int(net.bn1.num_batches_tracked) == int(g["nbt"])          # two views -> two updates
+    net2 = _seeded_net()
+    net2.eval()
+    ft = net2.forward_test(x1.cuda())
+    np.testing.assert_allclose(ft["proj"].cpu().numpy(), g["test_proj"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(ft["pred"].detach().cpu().numpy(), g["test_pred"], rtol=1e-3, atol=1e-3)
+
+
+def test_simsiam_trainer_entry_points(tmp_path, monkeypatch):
+    """configs[0]-style plumbing on the GPU: opts -> create_model -> train_factory['simsiam3d'] ->
+    trainer.train with an SGD optimizer over the strided kernel-layout parameters."""
+    from cet_pick_amd.opts import opts
+    from cet_pick_amd.models.model import create_model, save_model, load_model
+    from cet_pick_amd.trains.train_factory import train_factory
+    monkeypatch.chdir(tmp_path)
+    opt = opts().parse(["simsiam3d", "--arch", "simsiam2d_18", "--batch_size", "8", "--lr", "0.05", "--debug", "0",
+                        "--bbox", "36"])
+    opt.heads = {"proj": opt.head_conv, "pred": opt.head_conv}
+    assert opt.head_conv == 128
+    model = create_model(opt.arch, opt.heads, opt.head_conv, local_path=opt.pretrained_model)
+    optimizer = torch.optim.SGD(filter(lambda p: p.requires_grad, model.parameters()), opt.lr)
+    trainer = train_factory[opt.task](opt, model, optimizer)
+    trainer.set_device(opt.gpus, opt.chunk_sizes, torch.device("cuda"))
+    gen = torch.Generator().manual_seed(1)
+    base = torch.randn(32, 1, 36, 36, generator=gen)
+    loader = [{"input": base[i:i + 8], "input_aug": base[i:i + 8].flip(3) + 0.05 * torch.randn(8, 1, 36, 36, generator=gen)}
+              for i in range(0, 32, 8)]
+    first, _ = trainer.train(1, loader)
+    for ep in range(2, 5):
+        last, _ = trainer.train(ep, loader)
+    assert set(first) == {"loss", "cosine_loss", "output_std", "time"}
+    assert np.isfinite(last["loss"]) and last["loss"] < first["loss"]        # cosine loss decreases
+    path = str(tmp_path / "m.pth")
+    save_model(path, 4, model, optimizer)
+    m2 = load_model(create_model(opt.arch, opt.heads, opt.head_conv), path)
+    assert torch.equal(m2.fc.weight.cpu(), model.fc.weight.detach().cpu())
