@@ -29,28 +29,18 @@ FLOP_PER_SUBTOMO = 3.66e9        # q fwd+bwd 2.70 + k fwd 0.96 G
 
 
 def build_views(tomo_dev, n_crops, crop, seed):
-    """Two views per crop centre: the z-normalised crop, and the crop shifted by <=1 voxel and
-    flipped along x.  Returns (pool_q, pool_k) of shape (n,1,c,c,c) on device."""
+    """Two views per crop centre, cut and z-normalised on the GPU by mi_crop_normalize: the crop, and
+    the crop shifted by <=1 voxel and mirrored along x.
+    Returns (pool_q, pool_k) of shape (n,1,c,c,c), resident in HBM."""
+    from cet_pick_amd.datasets import subvols as S
     g = np.random.default_rng(seed)
     Z, H, W = tomo_dev.shape
     h = crop // 2
-    cz = g.integers(h + 1, Z - h - 1, n_crops)
-    cy = g.integers(h + 1, H - h - 1, n_crops)
-    cx = g.integers(h + 1, W - h - 1, n_crops)
-    sh = g.integers(-1, 2, (n_crops, 3))
-    pq = torch.empty((n_crops, 1, crop, crop, crop), dtype=torch.float32, device=tomo_dev.device)
-    pk = torch.empty_like(pq)
-    for i in range(n_crops):
-        z, y, x = int(cz[i]), int(cy[i]), int(cx[i])
-        a = tomo_dev[z - h:z + h, y - h:y + h, x - h:x + h]
-        z2, y2, x2 = z + int(sh[i, 0]), y + int(sh[i, 1]), x + int(sh[i, 2])
-        b = tomo_dev[z2 - h:z2 + h, y2 - h:y2 + h, x2 - h:x2 + h].flip(2)
-        pq[i, 0] = a
-        pk[i, 0] = b
-    for p in (pq, pk):
-        m = p.mean(dim=(2, 3, 4), keepdim=True)
-        s = p.std(dim=(2, 3, 4), keepdim=True)
-        p.sub_(m).div_(s)
+    centres = np.stack([g.integers(h + 1, W - h - 1, n_crops), g.integers(h + 1, H - h - 1, n_crops),
+                        g.integers(h + 1, Z - h - 1, n_crops)], 1).astype(np.int32)
+    shift = g.integers(-1, 2, (n_crops, 3)).astype(np.int32)
+    pq = S.crop_znorm(tomo_dev, centres, (crop,) * 3)
+    pk = S.crop_znorm(tomo_dev, centres + shift, (crop,) * 3, flip_x=True)
     return pq, pk
 
 

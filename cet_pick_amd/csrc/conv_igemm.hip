@@ -108,7 +108,7 @@ struct Cursor {
 // the tap itself and each of a chunk's 4 taps is gathered separately through a tap LUT in LDS.
 template <int MODE, int BM, int BN, int BK, bool STEM>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
-    static_assert(BK == 16 || BK == 32, "slice depth");
+    static_assert(BK == 16 || BK == 32 || BK == 64, "slice depth");
     static_assert(BN == 64 || BN == 128, "tile width");
     constexpr int WM = 2, WN = 2;
     constexpr int LDK = BK + 4;
@@ -521,8 +521,9 @@ Plan make_plan(int mode, bool stem, long M, int Ncols, long red_len, int red_ch,
     pl.bn = 64;                     // 128-wide tiles measured no faster on any layer (profiles/r01_conv_tuning.txt)
     if (int v = env_int("MI_CONV_BM")) pl.bm = (v == 128) ? 128 : 64;            // tuning overrides
     if (int v = env_int("MI_CONV_BN")) pl.bn = (v == 128 && Ncols % 128 == 0) ? 128 : 64;
-    if (int v = env_int("MI_CONV_BK")) if ((v == 16 || v == 32) && (red_ch == 0 || red_ch % v == 0)) pl.bk = v;
+    if (int v = env_int("MI_CONV_BK")) if ((v == 16 || v == 32 || v == 64) && (red_ch == 0 || red_ch % v == 0)) pl.bk = v;
     if (pl.bk != 32 || stem) pl.bn = 64;
+    if (pl.bk == 64 && (stem || pl.bm != 128)) pl.bk = 32;     // 64-deep slices: 128x64 tiles only
     pl.tiles_x = tiles_x_of(pl.bm);
     const long tiles = pl.tiles_x * ((Ncols + pl.bn - 1) / pl.bn);
     const long nk = (red_len + pl.bk - 1) / pl.bk;
@@ -546,7 +547,8 @@ int launch_mode(const ConvParams& p, const Plan& pl, hipStream_t s) {
     hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM_, BN_, BK_, STEM>), grid, dim3(NTHREADS), 0, s, p)
     if (pl.bn == 128 && !STEM) {           // 128-wide tiles only with 32-deep slices
         if (pl.bm == 128) MI_LAUNCH(128, 128, 32); else MI_LAUNCH(64, 128, 32);
-    } else if (pl.bm == 128 && pl.bk == 32) MI_LAUNCH(128, 64, 32);
+    } else if (pl.bm == 128 && pl.bk == 64 && !STEM) MI_LAUNCH(128, 64, 64);
+    else if (pl.bm == 128 && pl.bk == 32) MI_LAUNCH(128, 64, 32);
     else if (pl.bm == 128) MI_LAUNCH(128, 64, 16);
     else if (pl.bk == 32) MI_LAUNCH(64, 64, 32);
     else MI_LAUNCH(64, 64, 16);
