@@ -31,6 +31,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -275,21 +276,48 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     }
     if (STEM) __syncthreads();          // tap LUT visible
 
-    float4 a_reg[A_CH], b_reg[B_CH];
+    // two staging register sets (statically indexed): while set P is being filled with slice s+2,
+    // set 1-P (slice s+1, loaded one whole iteration earlier) goes to LDS - a prefetch distance of
+    // two slices, enough to cover the loaded global-memory latency (a distance of one was not)
+    float4 a_reg[2][A_CH], b_reg[2][B_CH];
 
-    // live == false (wave-uniform): the prefetch of the iteration after the last; every load then
-    // reads the zero block (the cursor may already point past the reduction)
-    auto load_tile = [&](int kt, bool live) {
-        if (MODE == MODE_WGRAD) {
-            // reduction index = output voxel mv = kt*BK + kk (one decode per thread)
-            const long mv = (long)kt * BK + w_kk;
-            const bool vok = live && mv < p.n_red_vox;
-            int n, z, y, x;
-            rdec(vok ? (unsigned)mv : 0u, n, z, y, x);
-            const int zb = z * S - Pz, yb = y * S - Py, xb = x * S - Px;
-            const long voff = ((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg;
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) {
+    // ---- gather of one slice, cut into NPARTS pieces so that the main loop can issue one piece in
+    // the shadow of each MFMA (64 cycles): part 0 = wave-uniform preparation, parts 1..A_CH = the A
+    // chunks, then the B chunks, last = cursor advance.  live == false (wave-uniform): the prefetch
+    // behind the last slice - every load then reads the zero block.
+    constexpr int NPARTS = 2 + A_CH + B_CH;
+    long pt_aoff = 0, pt_boff = 0, pt_voff = 0;
+    int pt_zb = 0, pt_yb = 0, pt_xb = 0;
+    bool pt_vok = false;
+    // (SETc / CURc are std::integral_constant: the staging sets must be indexed by compile-time
+    // constants or the register arrays spill to scratch)
+    auto load_part = [&](int kt, bool live, int part, auto SETc) {
+        constexpr int SET = decltype(SETc)::value;
+        if (part == 0) {
+            if (MODE == MODE_WGRAD) {
+                // reduction index = output voxel mv = kt*BK + kk (one decode per thread)
+                const long mv = (long)kt * BK + w_kk;
+                pt_vok = live & (mv < p.n_red_vox);
+                int n, z, y, x;
+                rdec(pt_vok ? (unsigned)mv : 0u, n, z, y, x);
+                pt_zb = z * S - Pz; pt_yb = y * S - Py; pt_xb = x * S - Px;
+                pt_voff = ((((long)n * p.Dg + pt_zb) * p.Hg + pt_yb) * p.Wg + pt_xb) * p.Cg;
+            } else if (!STEM) {
+                const int ia = cur.ia, ib = cur.ib, ic = cur.ic, c0 = cur.c0;
+                int wtap;
+                if (MODE == MODE_FWD) {
+                    pt_aoff = ((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0;
+                    wtap = (ia * Ky + ib) * Kx + ic;
+                } else {
+                    pt_aoff = -((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0;
+                    wtap = ((cz + S * ia) * Ky + (cy + S * ib)) * Kx + (cx + S * ic);
+                }
+                // weights: FWD rows (wtap*Ci + c0 + k) of [.][Co]; DGRAD row (wtap*Ci + ci), cols c0 + k
+                pt_boff = (MODE == MODE_FWD) ? ((long)wtap * p.Ci + c0) * p.Co : (long)wtap * p.Ci * p.Co + c0;
+            }
+        } else if (part <= A_CH) {
+            const int i = part - 1;
+            if (MODE == MODE_WGRAD) {
                 if (STEM) {
                     float e[4];
 #pragma unroll
@@ -297,27 +325,19 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                         const int tap = (int)m0 + 4 * ((tid % TPV) + TPV * i) + u;
                         const int2 tl = taplut[min(tap, LUT_TAPS - 1)];
                         const int a = tl.y & 0xff, b = (tl.y >> 8) & 0xff, c = (tl.y >> 16) & 0xff;
-                        const bool ok = vok && tap < taps && (unsigned)(zb + a) < (unsigned)p.Dg &&
-                                        (unsigned)(yb + b) < (unsigned)p.Hg && (unsigned)(xb + c) < (unsigned)p.Wg;
-                        e[u] = *(ok ? (p.a_src + voff + tl.x) : zsrc);
+                        const bool ok = pt_vok & (tap < taps) & ((unsigned)(pt_zb + a) < (unsigned)p.Dg) &
+                                        ((unsigned)(pt_yb + b) < (unsigned)p.Hg) & ((unsigned)(pt_xb + c) < (unsigned)p.Wg);
+                        e[u] = *(ok ? (p.a_src + pt_voff + tl.x) : zsrc);
                     }
-                    a_reg[i] = make_float4(e[0], e[1], e[2], e[3]);
+                    a_reg[SET][i] = make_float4(e[0], e[1], e[2], e[3]);
                 } else {
                     const int a = a_msk[i] & 0xff, b = (a_msk[i] >> 8) & 0xff, c = (a_msk[i] >> 16) & 0xff;
-                    const bool ok = vok && w_ok[i] && (unsigned)(zb + a) < (unsigned)p.Dg &&
-                                    (unsigned)(yb + b) < (unsigned)p.Hg && (unsigned)(xb + c) < (unsigned)p.Wg;
-                    a_reg[i] = ld4(ok ? (a_ptr[i] + voff) : zsrc);
+                    const bool ok = pt_vok & w_ok[i] & ((unsigned)(pt_zb + a) < (unsigned)p.Dg) &
+                                    ((unsigned)(pt_yb + b) < (unsigned)p.Hg) & ((unsigned)(pt_xb + c) < (unsigned)p.Wg);
+                    a_reg[SET][i] = ld4(ok ? (a_ptr[i] + pt_voff) : zsrc);
                 }
-            }
-#pragma unroll
-            for (int i = 0; i < B_CH; ++i) {
-                const bool ok = live && (long)kt * BK + b_row[i] < p.n_red_vox;
-                b_reg[i] = ld4(ok ? (b_ptr[i] + b_live[i] * ((long)kt * BK * p.Co)) : zsrc);
-            }
-        } else if (STEM) {
-            // FWD stem: slice kt covers taps kt*BK .. kt*BK+BK-1
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) {
+            } else if (STEM) {
+                // FWD stem: slice kt covers taps kt*BK .. kt*BK+BK-1
                 const int q = tid + i * NTHREADS;
                 const unsigned m = a_msk[i];
                 float e[4];
@@ -325,43 +345,30 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                 for (int u = 0; u < 4; ++u) {
                     const int tap = kt * BK + 4 * (q % KC) + u;
                     const int2 tl = taplut[min(tap, LUT_TAPS - 1)];
-                    const bool ok = live && ((m >> (tl.y & 0xff)) & (m >> (8 + ((tl.y >> 8) & 0xff))) &
-                                             (m >> (16 + ((tl.y >> 16) & 0xff))) & 1u) != 0;
+                    const bool ok = live & (((m >> (tl.y & 0xff)) & (m >> (8 + ((tl.y >> 8) & 0xff))) &
+                                             (m >> (16 + ((tl.y >> 16) & 0xff))) & 1u) != 0);
                     e[u] = *(ok ? (a_ptr[i] + tl.x) : zsrc);
                 }
-                a_reg[i] = make_float4(e[0], e[1], e[2], e[3]);
-            }
-#pragma unroll
-            for (int i = 0; i < B_CH; ++i) {
-                const bool ok = live && kt * BK + b_row[i] < taps;
-                b_reg[i] = ld4(ok ? (b_ptr[i] + b_live[i] * ((long)kt * BK * p.Co)) : zsrc);
-            }
-        } else {
-            // wave-uniform tap state from the cursor
-            const int ia = cur.ia, ib = cur.ib, ic = cur.ic, c0 = cur.c0;
-            long a_off;            // element offset added to every row's base pointer
-            int wtap;              // weight tap index
-            if (MODE == MODE_FWD) {
-                a_off = ((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0;
-                wtap = (ia * Ky + ib) * Kx + ic;
+                a_reg[SET][i] = make_float4(e[0], e[1], e[2], e[3]);
             } else {
-                a_off = -((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0;
-                wtap = ((cz + S * ia) * Ky + (cy + S * ib)) * Kx + (cx + S * ic);
-            }
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) {
                 const unsigned m = a_msk[i];
-                const bool ok = live && ((m >> ia) & (m >> (8 + ib)) & (m >> (16 + ic)) & 1u) != 0;
-                a_reg[i] = ld4(ok ? (a_ptr[i] + a_off) : zsrc);
+                const bool ok = live & (((m >> cur.ia) & (m >> (8 + cur.ib)) & (m >> (16 + cur.ic)) & 1u) != 0);
+                a_reg[SET][i] = ld4(ok ? (a_ptr[i] + pt_aoff) : zsrc);
             }
-            // weights: FWD rows (wtap*Ci + c0 + k) of [.][Co]; DGRAD row (wtap*Ci + ci), cols c0 + k
-            const long b_off = (MODE == MODE_FWD) ? ((long)wtap * p.Ci + c0) * p.Co
-                                                   : (long)wtap * p.Ci * p.Co + c0;
-#pragma unroll
-            for (int i = 0; i < B_CH; ++i) b_reg[i] = ld4(live ? (b_ptr[i] + b_live[i] * b_off) : zsrc);
-            // advance the cursor
+        } else if (part <= A_CH + B_CH) {
+            const int i = part - 1 - A_CH;
+            if (MODE == MODE_WGRAD) {
+                const bool ok = live & ((long)kt * BK + b_row[i] < p.n_red_vox);
+                b_reg[SET][i] = ld4(ok ? (b_ptr[i] + b_live[i] * ((long)kt * BK * p.Co)) : zsrc);
+            } else if (STEM) {
+                const bool ok = live & (kt * BK + b_row[i] < taps);
+                b_reg[SET][i] = ld4(ok ? (b_ptr[i] + b_live[i] * ((long)kt * BK * p.Co)) : zsrc);
+            } else {
+                b_reg[SET][i] = ld4(live ? (b_ptr[i] + b_live[i] * pt_boff) : zsrc);
+            }
+        } else if (MODE != MODE_WGRAD && !STEM) {
+            // advance the (tap, channel) cursor, branch-free
             const int cred = (MODE == MODE_FWD) ? p.Ci : p.Co;
-            // (branch-free: the loop body must stay one basic block for the MFMA interleave)
             const int c0n = cur.c0 + BK;
             const int w0 = c0n >= cred ? 1 : 0;
             cur.c0 = w0 ? 0 : c0n;
@@ -374,11 +381,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
             cur.ia += w2;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto load_tile = [&](int kt, bool live, auto SETc) {
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<float4*>(lds + buf * STAGE + a_lds[i]) = a_reg[i];
+        for (int part = 0; part < NPARTS; ++part) load_part(kt, live, part, SETc);
+    };
+    auto store_tile = [&](int buf, auto SETc) {
+        constexpr int SET = decltype(SETc)::value;
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<float4*>(lds + buf * STAGE + A_ELEMS + b_lds[i]) = b_reg[i];
+        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<float4*>(lds + buf * STAGE + a_lds[i]) = a_reg[SET][i];
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<float4*>(lds + buf * STAGE + A_ELEMS + b_lds[i]) = b_reg[SET][i];
     };
 
     f32x16 acc[MT][NT];
@@ -389,22 +401,19 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kt0 < kt1) {
-        load_tile(kt0, true);
-        store_tile(0);
-    }
-    __syncthreads();
-
-    int buf = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const bool more = (kt + 1 < kt1);
-        // Phase 1: gather addresses + global loads of the NEXT slice (unconditional: the last
-        // iteration fetches zeros into the idle buffer, so the body has no branch).
-        // Out-of-range elements are loaded from a block of zeros, so nothing until the LDS stores
-        // of phase 3 depends on the loaded data and the loads stay in flight across the MFMAs.
-        load_tile(kt + 1, more);
-        __builtin_amdgcn_sched_barrier(0);
-        // Phase 2: fragments of the current slice from LDS, then the MFMAs
+    // ---- software pipeline over the reduction slices (prefetch distance 2) ----------------------
+    //   LDS buffer (s & 1)      : slice s, read into fragment registers at the top of iteration s
+    //   staging set (s+1) & 1   : slice s+1, loaded during iteration s-1, stored to LDS at the end of s
+    //   staging set s & 1       : slice s+2, its global loads are issued during iteration s
+    // One iteration, parametrised by the (compile-time) parity of the staging sets:
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    auto iteration = [&](int kt, int buf, auto CURc) {
+        constexpr int CUR = decltype(CURc)::value;
+        using SetCur = std::integral_constant<int, CUR>;
+        using SetOther = std::integral_constant<int, CUR ^ 1>;
+        const bool more2 = (kt + 2 < kt1);
+        // Phase 1: fragments of the current slice from LDS
         const float* Ab = lds + buf * STAGE;
         const float* Bb = Ab + A_ELEMS;
         float af[MT][KH], bf[NT][KH];
@@ -436,18 +445,44 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                 for (int t = 0; t < KH; ++t) bf[j][t] = Bb[(h * KH + t) * BN + c];
             }
         }
-#pragma unroll
-        for (int t = 0; t < KH; ++t)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        // Phase 3: the prefetched slice goes to the other LDS buffer
-        store_tile(buf ^ 1);
+        // Phase 2: the MFMAs of slice kt; behind each of the first NPARTS of them one piece of the
+        // gather of slice kt+2 (address arithmetic + one global load into set CUR^1... see above) is
+        // pinned, so it issues while that MFMA occupies the matrix pipe (64 cycles).  The gather is
+        // unconditional (zeros behind the last slice): the body has no branch, and out-of-range
+        // elements are LOADED from a zero block, so nothing depends on the loaded data until the
+        // LDS stores of the NEXT iteration.
+        constexpr int NMF = KH * MT * NT;
+        static_assert(NPARTS <= NMF, "more gather pieces than MFMAs");
+#pragma unroll
+        for (int g = 0; g < NMF; ++g) {
+            const int t = g / (MT * NT), i = (g / NT) % MT, j = g % NT;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+            if (g < NPARTS) {
+                load_part(kt + 2, more2, g, SetCur{});
+                // compiler-level fence (no instruction): keeps this piece's global load from being
+                // sunk towards its use; the sched_barrier pins the machine schedule
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // Phase 3: slice kt+1 (set CUR^1, in flight since the previous iteration) goes to the other
+        // LDS buffer; the wait only covers those older loads (counted vmcnt)
+        store_tile(buf ^ 1, SetOther{});
         __syncthreads();
-        buf ^= 1;
+    };
+
+    if (kt0 < kt1) {
+        load_tile(kt0, true, Set0{});
+        store_tile(0, Set0{});
+        load_tile(kt0 + 1, kt0 + 1 < kt1, Set1{});       // slice kt0+1 -> set 1, stored at the end of iteration kt0
+    }
+    __syncthreads();
+
+    for (int kt = kt0; kt < kt1; kt += 2) {
+        iteration(kt, 0, Set0{});                          // loads slice kt+2 into set 0, stores set 1
+        if (kt + 1 < kt1) iteration(kt + 1, 1, Set1{});    // loads slice kt+3 into set 1, stores set 0
     }
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -509,14 +544,14 @@ int env_int(const char* name) {
 
 // red_ch: reduction channels (FWD: Ci, DGRAD: Co; 0 for WGRAD / stem where any depth works)
 // red_len: longest reduction in elements; tiles_x_of(bm): row tiles for a given BM
-// mode-specific tile choice measured on MI355X (tools/bench_conv.py, profiles/r01_conv_tuning.txt):
-// FWD/DGRAD take 128-row tiles only when there are >= 16 Ki rows; WGRAD (few rows, long reduction)
-// prefers 128-row tiles while that still leaves <= 64 tiles, except for the scalar-gather stem.
+// Tile choice measured on MI355X (tools/bench_conv.py, profiles/r01_conv_tuning.txt): with the
+// prefetch-distance-2 pipeline 64-row tiles (two workgroups per CU) win or tie on every layer and
+// mode; 128-row tiles stay available through MI_CONV_BM for tuning.
 template <class F>
 Plan make_plan(int mode, bool stem, long M, int Ncols, long red_len, int red_ch, F tiles_x_of) {
     Plan pl;
-    if (mode == MODE_WGRAD) pl.bm = (!stem && ((M + 127) / 128) * ((Ncols + 63) / 64) <= 64) ? 128 : 64;
-    else pl.bm = (M >= 16384) ? 128 : 64;
+    (void)mode; (void)stem;
+    pl.bm = 64;
     pl.bk = (red_ch == 0 || red_ch % 32 == 0) ? 32 : 16;
     pl.bn = 64;                     // 128-wide tiles measured no faster on any layer (profiles/r01_conv_tuning.txt)
     if (int v = env_int("MI_CONV_BM")) pl.bm = (v == 128) ? 128 : 64;            // tuning overrides
