@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcetpick_hip.so")
+LIB_PATH = os.environ.get("CETPICK_HIP_LIB") or os.path.join(_HERE, "libcetpick_hip.so")   # env: tuning builds
 
 _c = ctypes
 _P, _I, _F, _Z, _D, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_double, _c.c_long

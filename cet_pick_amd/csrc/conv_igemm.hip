@@ -52,10 +52,13 @@ struct ConvParams {
     int relu;
     int N, Dg, Hg, Wg, Cg;         // gathered tensor grid / channels
     int Dr, Hr, Wr;                // row grid: FWD/WGRAD output voxels, DGRAD input voxels
+    unsigned mgW, mgH, mgD;        // branch-free division of a row index (< 2^31) by Wr, Hr, Dr:
+    int shW, shH, shD;             //   q = (uint64(n) * mg) >> sh   (Granlund-Montgomery, N = 31)
     int kd, kh, kw, stride, pd, ph, pw;   // window / zero padding per axis (2-D convs: kd = 1, pd = 0, D = 1)
     int Ci, Co;                    // conv channels (weights are [tap][Ci][Co])
     long M;                        // GEMM rows (all classes)
     int Ncols;                     // GEMM cols
+    unsigned a_bytes, b_bytes;     // extents of a_src / b_src (< 2 GiB each): buffer-load range check
     int splits;
     long slab_stride;              // elements between split-K slabs (0: direct epilogue)
     long n_red_vox;                // WGRAD: reduction length in voxels
@@ -63,12 +66,23 @@ struct ConvParams {
     int cls_tile_start[MAX_CLASSES + 1];
 };
 
+// All gathers are raw buffer loads: 32-bit byte offset against a descriptor of the whole tensor.  An offset
+// outside [0, bytes) returns zeros without touching memory, so zero padding, ragged tiles and the prefetch
+// behind the last slice need no select on loaded data and no branch: an invalid element just gets the
+// offset OOR (tensors are < 2 GiB, checked on the host, so OOR plus any in-tensor displacement stays outside).
+constexpr unsigned OOR = 0x80000000u;
 __device__ __forceinline__ float4 ld4(const float* ptr) { return *reinterpret_cast<const float4*>(ptr); }
-// Zero padding without a select: an out-of-range im2col element is LOADED from this block of
-// zeros, so nothing between the global loads and the LDS stores depends on the loaded data.
-// (a mutable __device__ variable so that it lives in the global address space like the tensors:
-// selecting between two global pointers keeps the loads global_load, not flat_load)
-__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float bld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
 
 // bit t of the result: 0 <= base + step*t < n, for t in [0, count)
 __device__ __forceinline__ unsigned axis_mask(int base, int step, int count, int n) {
@@ -78,25 +92,32 @@ __device__ __forceinline__ unsigned axis_mask(int base, int step, int count, int
     return m;
 }
 
-// flat voxel index -> (n, z, y, x) of a (N, D, H, W) grid; 32-bit, shifts when all dims are 2^k
+// flat voxel index -> (n, z, y, x) of a (N, D, H, W) grid, 32-bit and branch-free: division by the
+// (run-time) extents through precomputed multiply-shift constants, exact for every index < 2^31
 struct GridDec {
-    int D, H, W, lD, lH, lW;     // l*: log2 or -1
+    int D, H, W;
+    unsigned mD, mH, mW;
+    int sD, sH, sW;
+    __device__ __forceinline__ static unsigned divm(unsigned n, unsigned m, int s) {
+        return (unsigned)(((unsigned long long)n * m) >> s);
+    }
     __device__ __forceinline__ void operator()(unsigned m, int& n, int& z, int& y, int& x) const {
-        if (lW >= 0) {
-            x = (int)(m & (unsigned)(W - 1)); m >>= lW;
-            y = (int)(m & (unsigned)(H - 1)); m >>= lH;
-            z = (int)(m & (unsigned)(D - 1)); n = (int)(m >> lD);
-        } else {
-            unsigned q = m / (unsigned)W; x = (int)(m - q * (unsigned)W); m = q;
-            q = m / (unsigned)H; y = (int)(m - q * (unsigned)H); m = q;
-            q = m / (unsigned)D; z = (int)(m - q * (unsigned)D); n = (int)q;
-        }
+        unsigned q = divm(m, mW, sW); x = (int)(m - q * (unsigned)W); m = q;
+        q = divm(m, mH, sH); y = (int)(m - q * (unsigned)H); m = q;
+        q = divm(m, mD, sD); z = (int)(m - q * (unsigned)D); n = (int)q;
     }
 };
-__device__ __forceinline__ int ilog2_dev(int v) { return (v > 0 && (v & (v - 1)) == 0) ? (31 - __clz(v)) : -1; }
-__device__ __forceinline__ GridDec make_dec(int D, int H, int W) {
-    GridDec g{D, H, W, ilog2_dev(D), ilog2_dev(H), ilog2_dev(W)};
-    if (g.lD < 0 || g.lH < 0 || g.lW < 0) g.lD = g.lH = g.lW = -1;
+__host__ __device__ inline void magic31(int d, unsigned* m, int* s) {
+    // M = floor(2^(31+L)/d) + 1 with L = ceil(log2 d): floor(n*M / 2^(31+L)) == n/d for 0 <= n < 2^31
+    int L = 0;
+    while ((1ll << L) < (long long)d) ++L;
+    *s = 31 + L;
+    *m = (unsigned)(((1ull << (31 + L)) / (unsigned long long)d) + 1ull);
+}
+__device__ __forceinline__ GridDec make_dec(int D, int H, int W) {      // prologue-only (DGRAD class grid)
+    GridDec g;
+    g.D = D > 0 ? D : 1; g.H = H > 0 ? H : 1; g.W = W > 0 ? W : 1;
+    magic31(g.D, &g.mD, &g.sD); magic31(g.H, &g.mH, &g.sH); magic31(g.W, &g.mW, &g.sW);
     return g;
 }
 
@@ -178,11 +199,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
         }
     }
 
-    const GridDec rdec = make_dec(p.Dr, p.Hr, p.Wr);     // row grid (rows < 2^31, checked on the host)
+    const GridDec rdec = {p.Dr, p.Hr, p.Wr, p.mgD, p.mgH, p.mgW, p.shD, p.shH, p.shW};   // row grid
     const GridDec cdec = make_dec(Dz, Dy, Dx);           // DGRAD class grid
 
     // ---- per-thread staging state --------------------------------------------------------------
-    const float* a_ptr[A_CH];        // row base pointer (+ chunk offset); WGRAD: tap + ci offset
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(p.a_src, p.a_bytes), b_rs = make_rsrc(p.b_src, p.b_bytes);
+    unsigned a_off[A_CH];            // byte offset of the row base (+ chunk) in a_src, mod 2^32 (padding rows
+                                     // start "before" the tensor); WGRAD: tap + ci offset
     unsigned a_msk[A_CH];            // RowK: per-axis validity bits (z | y<<8 | x<<16), 0 = row off
                                      // WGRAD: the chunk's tap coordinates a | b<<8 | c<<16
     bool w_ok[A_CH];
@@ -197,7 +220,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
             const long m = m0 + row;
             a_lds[i] = row * LDK + 4 * c;
             a_msk[i] = 0;
-            a_ptr[i] = p.a_src;
+            a_off[i] = 0;
             w_ok[i] = false;
             if (m < M_here) {
                 if (MODE == MODE_FWD) {
@@ -206,7 +229,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                     const int zb = z * S - Pz, yb = y * S - Py, xb = x * S - Px;
                     a_msk[i] = axis_mask(zb, 1, Kz, p.Dg) | (axis_mask(yb, 1, Ky, p.Hg) << 8) |
                                (axis_mask(xb, 1, Kx, p.Wg) << 16);
-                    a_ptr[i] = p.a_src + ((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg + (STEM ? 0 : 4 * c);
+                    a_off[i] = 4u * (unsigned)(((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg + (STEM ? 0 : 4 * c));
                 } else {
                     int n, jz, jy, jx;
                     cdec((unsigned)m, n, jz, jy, jx);
@@ -214,7 +237,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                     const int zb = (z + Pz - cz) / S, yb = (y + Py - cy) / S, xb = (x + Px - cx) / S;
                     a_msk[i] = axis_mask(zb, -1, nz, p.Dg) | (axis_mask(yb, -1, ny, p.Hg) << 8) |
                                (axis_mask(xb, -1, nx, p.Wg) << 16);
-                    a_ptr[i] = p.a_src + ((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg + 4 * c;
+                    a_off[i] = 4u * (unsigned)(((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg + 4 * c);
                     if (c == 0 && p.n_classes > 1) rowmap[row] = (((long)n * p.Dr + z) * p.Hr + y) * p.Wr + x;
                 }
             } else if (MODE == MODE_DGRAD && c == 0 && p.n_classes > 1) {
@@ -232,22 +255,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
             const long row = m0 + 4 * j;
             w_ok[i] = row < p.M;
             a_msk[i] = 0;
-            a_ptr[i] = p.a_src;
+            a_off[i] = 0;
             if (w_ok[i] && !STEM) {
                 const int tap = (int)(row / p.Ci);
                 const int ci = (int)(row % p.Ci);
                 const int a = tap / (Ky * Kx), b = (tap / Kx) % Ky, c = tap % Kx;
-                a_ptr[i] = p.a_src + ((long)(a * p.Hg + b) * p.Wg + c) * p.Cg + ci;
+                a_off[i] = 4u * (unsigned)(((long)(a * p.Hg + b) * p.Wg + c) * p.Cg + ci);
                 a_msk[i] = (unsigned)(a | (b << 8) | (c << 16));
             }
         }
     }
-    // B operand: per-thread base pointer (the zero block when the column is out of range) plus a
-    // wave-uniform offset per slice
-    const float* const zsrc = g_zero16;
+    // B operand: per-thread byte offset (OOR when the column is out of range) plus a wave-uniform
+    // offset per slice
     int b_lds[B_CH], b_row[B_CH], b_col[B_CH];
-    const float* b_ptr[B_CH];
-    long b_live[B_CH];           // 1 when the base is a real row/column, 0 when it is the zero block
+    unsigned b_off[B_CH];
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
         const int q = tid + i * NTHREADS;
@@ -255,14 +276,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
             b_row[i] = q / KC; b_col[i] = (q % KC) * 4;
             b_lds[i] = b_row[i] * LDK + b_col[i];
             const bool ok = n0 + b_row[i] < p.Ncols;
-            b_ptr[i] = ok ? p.b_src + (long)(n0 + b_row[i]) * p.Co + b_col[i] : zsrc;
-            b_live[i] = ok ? 1 : 0;
+            b_off[i] = ok ? 4u * (unsigned)((long)(n0 + b_row[i]) * p.Co + b_col[i]) : OOR;
         } else {                 // LDS [k][n]; global rows k, cols n contiguous
             b_row[i] = q / (BN / 4); b_col[i] = (q % (BN / 4)) * 4;
             b_lds[i] = b_row[i] * BN + b_col[i];
             const bool ok = n0 + b_col[i] < p.Ncols;
-            b_ptr[i] = ok ? p.b_src + (long)b_row[i] * p.Co + n0 + b_col[i] : zsrc;
-            b_live[i] = ok ? 1 : 0;
+            b_off[i] = ok ? 4u * (unsigned)((long)b_row[i] * p.Co + n0 + b_col[i]) : OOR;
         }
     }
 
@@ -286,34 +305,39 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     // chunks, then the B chunks, last = cursor advance.  live == false (wave-uniform): the prefetch
     // behind the last slice - every load then reads the zero block.
     constexpr int NPARTS = 2 + A_CH + B_CH;
-    long pt_aoff = 0, pt_boff = 0, pt_voff = 0;
+    unsigned pt_aoff = 0, pt_boff = 0, pt_voff = 0;       // byte offsets (mod 2^32)
     int pt_zb = 0, pt_yb = 0, pt_xb = 0;
     bool pt_vok = false;
     // (SETc / CURc are std::integral_constant: the staging sets must be indexed by compile-time
     // constants or the register arrays spill to scratch)
     auto load_part = [&](int kt, bool live, int part, auto SETc) {
         constexpr int SET = decltype(SETc)::value;
+#ifdef MI_DBG_NOGLOAD      // timing experiment: no gathers in the loop (results are garbage)
+        if (kt >= kt0 + 2) return;
+#endif
         if (part == 0) {
             if (MODE == MODE_WGRAD) {
-                // reduction index = output voxel mv = kt*BK + kk (one decode per thread)
+                // reduction index = output voxel mv = kt*BK + kk (one decode per thread); a voxel behind
+                // the last one decodes to n >= N: its offsets fall behind the tensors (zeros)
                 const long mv = (long)kt * BK + w_kk;
                 pt_vok = live & (mv < p.n_red_vox);
                 int n, z, y, x;
                 rdec(pt_vok ? (unsigned)mv : 0u, n, z, y, x);
                 pt_zb = z * S - Pz; pt_yb = y * S - Py; pt_xb = x * S - Px;
-                pt_voff = ((((long)n * p.Dg + pt_zb) * p.Hg + pt_yb) * p.Wg + pt_xb) * p.Cg;
+                pt_voff = 4u * (unsigned)(((((long)n * p.Dg + pt_zb) * p.Hg + pt_yb) * p.Wg + pt_xb) * p.Cg);
             } else if (!STEM) {
                 const int ia = cur.ia, ib = cur.ib, ic = cur.ic, c0 = cur.c0;
                 int wtap;
                 if (MODE == MODE_FWD) {
-                    pt_aoff = ((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0;
+                    pt_aoff = 4u * (unsigned)(((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0);
                     wtap = (ia * Ky + ib) * Kx + ic;
                 } else {
-                    pt_aoff = -((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0;
+                    pt_aoff = 4u * (unsigned)(-((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0);
                     wtap = ((cz + S * ia) * Ky + (cy + S * ib)) * Kx + (cx + S * ic);
                 }
                 // weights: FWD rows (wtap*Ci + c0 + k) of [.][Co]; DGRAD row (wtap*Ci + ci), cols c0 + k
-                pt_boff = (MODE == MODE_FWD) ? ((long)wtap * p.Ci + c0) * p.Co : (long)wtap * p.Ci * p.Co + c0;
+                const long bo = (MODE == MODE_FWD) ? ((long)wtap * p.Ci + c0) * p.Co : (long)wtap * p.Ci * p.Co + c0;
+                pt_boff = live ? 4u * (unsigned)bo : OOR;
             }
         } else if (part <= A_CH) {
             const int i = part - 1;
@@ -327,14 +351,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                         const int a = tl.y & 0xff, b = (tl.y >> 8) & 0xff, c = (tl.y >> 16) & 0xff;
                         const bool ok = pt_vok & (tap < taps) & ((unsigned)(pt_zb + a) < (unsigned)p.Dg) &
                                         ((unsigned)(pt_yb + b) < (unsigned)p.Hg) & ((unsigned)(pt_xb + c) < (unsigned)p.Wg);
-                        e[u] = *(ok ? (p.a_src + pt_voff + tl.x) : zsrc);
+                        e[u] = bld1(a_rs, ok ? pt_voff + 4u * (unsigned)tl.x : OOR);
                     }
                     a_reg[SET][i] = make_float4(e[0], e[1], e[2], e[3]);
                 } else {
                     const int a = a_msk[i] & 0xff, b = (a_msk[i] >> 8) & 0xff, c = (a_msk[i] >> 16) & 0xff;
                     const bool ok = pt_vok & w_ok[i] & ((unsigned)(pt_zb + a) < (unsigned)p.Dg) &
                                     ((unsigned)(pt_yb + b) < (unsigned)p.Hg) & ((unsigned)(pt_xb + c) < (unsigned)p.Wg);
-                    a_reg[SET][i] = ld4(ok ? (a_ptr[i] + pt_voff) : zsrc);
+                    a_reg[SET][i] = bld4(a_rs, ok ? a_off[i] + pt_voff : OOR);
                 }
             } else if (STEM) {
                 // FWD stem: slice kt covers taps kt*BK .. kt*BK+BK-1
@@ -347,24 +371,25 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                     const int2 tl = taplut[min(tap, LUT_TAPS - 1)];
                     const bool ok = live & (((m >> (tl.y & 0xff)) & (m >> (8 + ((tl.y >> 8) & 0xff))) &
                                              (m >> (16 + ((tl.y >> 16) & 0xff))) & 1u) != 0);
-                    e[u] = *(ok ? (a_ptr[i] + tl.x) : zsrc);
+                    e[u] = bld1(a_rs, ok ? a_off[i] + 4u * (unsigned)tl.x : OOR);
                 }
                 a_reg[SET][i] = make_float4(e[0], e[1], e[2], e[3]);
             } else {
                 const unsigned m = a_msk[i];
                 const bool ok = live & (((m >> cur.ia) & (m >> (8 + cur.ib)) & (m >> (16 + cur.ic)) & 1u) != 0);
-                a_reg[SET][i] = ld4(ok ? (a_ptr[i] + pt_aoff) : zsrc);
+                a_reg[SET][i] = bld4(a_rs, ok ? a_off[i] + pt_aoff : OOR);
             }
         } else if (part <= A_CH + B_CH) {
             const int i = part - 1 - A_CH;
-            if (MODE == MODE_WGRAD) {
-                const bool ok = live & ((long)kt * BK + b_row[i] < p.n_red_vox);
-                b_reg[SET][i] = ld4(ok ? (b_ptr[i] + b_live[i] * ((long)kt * BK * p.Co)) : zsrc);
-            } else if (STEM) {
-                const bool ok = live & (kt * BK + b_row[i] < taps);
-                b_reg[SET][i] = ld4(ok ? (b_ptr[i] + b_live[i] * ((long)kt * BK * p.Co)) : zsrc);
+            if (MODE == MODE_WGRAD || STEM) {
+                // rows kt*BK + b_row of dY (WGRAD) / of the stem weights: a row behind the last one is
+                // behind the tensor (zeros)
+                const unsigned so = live ? 4u * (unsigned)((long)kt * BK * p.Co) : OOR;
+                b_reg[SET][i] = bld4(b_rs, b_off[i] + so);
             } else {
-                b_reg[SET][i] = ld4(live ? (b_ptr[i] + b_live[i] * pt_boff) : zsrc);
+                // (an out-of-range column has b_off == OOR: the sum stays out of range; both OOR only
+                // happens behind the last slice, whose tile is never consumed)
+                b_reg[SET][i] = bld4(b_rs, b_off[i] + pt_boff);
             }
         } else if (MODE != MODE_WGRAD && !STEM) {
             // advance the (tap, channel) cursor, branch-free
@@ -387,6 +412,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     };
     auto store_tile = [&](int buf, auto SETc) {
         constexpr int SET = decltype(SETc)::value;
+#ifdef MI_DBG_NOSTORE      // timing experiment: no LDS stores in the loop (results are garbage)
+        if (buf >= 0 && kt1 - kt0 > 2) return;
+#endif
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) *reinterpret_cast<float4*>(lds + buf * STAGE + a_lds[i]) = a_reg[SET][i];
 #pragma unroll
@@ -470,7 +498,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
         // Phase 3: slice kt+1 (set CUR^1, in flight since the previous iteration) goes to the other
         // LDS buffer; the wait only covers those older loads (counted vmcnt)
         store_tile(buf ^ 1, SetOther{});
+#ifndef MI_DBG_NOBARRIER
         __syncthreads();
+#endif
     };
 
     if (kt0 < kt1) {
@@ -480,10 +510,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     }
     __syncthreads();
 
-    for (int kt = kt0; kt < kt1; kt += 2) {
+    // pairs in the loop, the odd slice after it: a skip of the second half inside the loop would make the
+    // compiler wait at the loop head for gathers that are only in flight on that (exiting) path
+    int kt = kt0;
+    for (; kt + 1 < kt1; kt += 2) {
         iteration(kt, 0, Set0{});                          // loads slice kt+2 into set 0, stores set 1
-        if (kt + 1 < kt1) iteration(kt + 1, 1, Set1{});    // loads slice kt+3 into set 1, stores set 0
+        iteration(kt + 1, 1, Set1{});                      // loads slice kt+3 into set 1, stores set 0
     }
+    if (kt < kt1) iteration(kt, 0, Set0{});
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* outp = p.out + (long)blockIdx.z * p.slab_stride;
@@ -562,13 +596,26 @@ Plan make_plan(int mode, bool stem, long M, int Ncols, long red_len, int red_ch,
     pl.tiles_x = tiles_x_of(pl.bm);
     const long tiles = pl.tiles_x * ((Ncols + pl.bn - 1) / pl.bn);
     const long nk = (red_len + pl.bk - 1) / pl.bk;
+    // Split count from a load model of the 256 CUs. Workgroups of one launch are all co-resident (<= 5 per CU
+    // by LDS), so the launch ends with the most loaded CU: time ~ ceil(blocks/256) * (slices per block +
+    // prologue/epilogue), a lone workgroup per CU running at ~0.7 of the paired rate. 513 blocks cost 3/2 of 512
+    // (measured: l1 wgrad with 19 splits 122 us, see profiles/r01_conv_tuning.txt).
     int splits = 1;
-    if (tiles < 384) {
-        splits = (int)((512 + tiles - 1) / tiles);
+    {
         const long min_slices = 128 / pl.bk;             // at least 128 reduction elements per split
-        const long max_splits = nk / min_slices > 0 ? nk / min_slices : 1;
-        if (splits > max_splits) splits = (int)max_splits;
-        if (splits > 128) splits = 128;
+        long max_splits = nk / min_slices > 0 ? nk / min_slices : 1;
+        if (max_splits > 128) max_splits = 128;
+        double best = 1e30;
+        for (long sp = 1; sp <= max_splits; ++sp) {
+            const long per = (nk + sp - 1) / sp;
+            if ((sp - 1) * per >= nk) continue;           // an empty last split: same schedule as a smaller sp
+            const long blocks = tiles * sp;
+            const long per_cu = (blocks + 255) / 256;
+            const double rate = per_cu == 1 ? 1.4 : (double)per_cu;
+            double cost = rate * (double)(per + 6);
+            if (sp > 1) cost += 2.0 + 0.05 * (double)sp;  // slab write + reduce pass
+            if (cost < best - 1e-9) { best = cost; splits = (int)sp; }
+        }
     }
     if (int v = env_int("MI_CONV_SPLITS")) splits = v;
     pl.splits = splits < 1 ? 1 : splits;
@@ -670,6 +717,12 @@ int setup_conv(int mode, const Geom& g, Setup* st) {
         const long M = p.M;
         st->pl = make_plan(mode, stem, p.M, p.Ncols, Mout, 0, [M](int bm) { return (M + bm - 1) / bm; });
     }
+    magic31(p.Dr, &p.mgD, &p.shD); magic31(p.Hr, &p.mgH, &p.shH); magic31(p.Wr, &p.mgW, &p.shW);
+    // operand extents for the buffer descriptors; 32-bit byte offsets with the top bit as "out of range"
+    const long x_bytes = 4 * Min * g.Ci, y_bytes = 4 * Mout * g.Co, w_bytes = 4l * taps * g.Ci * g.Co;
+    const long ab = (mode == MODE_DGRAD) ? y_bytes : x_bytes, bb = (mode == MODE_WGRAD) ? y_bytes : w_bytes;
+    if (ab >= 0x7fff0000l || bb >= 0x7fff0000l) return MI_E_UNSUPPORTED;   // split the batch on the host side
+    p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.splits = st->pl.splits;
     return MI_OK;
 }
