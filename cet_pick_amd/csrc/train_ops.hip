@@ -116,61 +116,100 @@ int run_colreduce(ColReduceParams p, double* sums, void* ws, size_t ws_bytes, hi
 // ---------------------------------------------------------------------------------------------
 // BatchNorm apply kernels
 // ---------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const double* sums, double count, int C, float eps,
-                                   float momentum, float* running_mean, float* running_var,
-                                   float* save) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double mean = sums[c] / count;
-    double var = sums[C + c] / count - mean * mean;
-    if (var < 0) var = 0;
-    save[c] = (float)mean;
-    save[C + c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        double unbiased = count > 1 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+// Training statistics -> (mean, invstd) for 4 channels, from the fp64 column sums
+struct BnStat4 { float mean[4], inv[4]; double var[4]; };
+__device__ __forceinline__ BnStat4 bn_stat4(const double* sums, double count, int C, int c, float eps) {
+    BnStat4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double mean = sums[c + k] / count;
+        double var = sums[C + c + k] / count - mean * mean;
+        if (var < 0) var = 0;
+        r.mean[k] = (float)mean;
+        r.inv[k] = (float)(1.0 / sqrt(var + (double)eps));
+        r.var[k] = var;
     }
+    return r;
 }
 
-// y = relu?((x - mean) * invstd * gamma + beta)   (save = mean[C], invstd[C])
+// y = relu?((x - mean) * invstd * gamma + beta + res).  One launch does the whole forward BatchNorm:
+//   sums != NULL (training): mean / invstd from the column sums (every thread recomputes its 4 channels: the
+//     channel of a thread is loop-invariant because 256 % (C/4) == 0); workgroup 0 also writes
+//     save = mean[C], invstd[C], the running statistics (momentum update, unbiased variance) and increments
+//     num_batches_tracked.
+//   sums == NULL (eval): mean / invstd from the running statistics.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, float* y, long n4, int C,
-                                                      const float* save, const float* gamma,
+                                                      const double* sums, double count, float eps,
+                                                      float momentum, float* running_mean,
+                                                      float* running_var, long long* num_batches_tracked,
+                                                      float* save, const float* gamma,
                                                       const float* beta, const float* res, int relu) {
     const int CV = C >> 2;
+    const int c = (int)(threadIdx.x % CV) * 4;
+    float m[4], iv[4];
+    if (sums) {
+        const BnStat4 st = bn_stat4(sums, count, C, c, eps);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { m[k] = st.mean[k]; iv[k] = st.inv[k]; }
+        if (blockIdx.x == 0 && threadIdx.x < CV) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (save) { save[c + k] = m[k]; save[C + c + k] = iv[k]; }
+                if (running_mean) {
+                    const double unbiased = count > 1 ? st.var[k] * count / (count - 1.0) : st.var[k];
+                    running_mean[c + k] = (1.f - momentum) * running_mean[c + k] + momentum * m[k];
+                    running_var[c + k] = (1.f - momentum) * running_var[c + k] + momentum * (float)unbiased;
+                }
+            }
+            if (threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { m[k] = running_mean[c + k]; iv[k] = 1.0f / sqrtf(running_var[c + k] + eps); }
+        if (save && blockIdx.x == 0 && threadIdx.x < CV) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { save[c + k] = m[k]; save[C + c + k] = iv[k]; }
+        }
+    }
+    const float4 g = gamma ? ld4(gamma + c) : make_float4(1, 1, 1, 1);
+    const float4 b = beta ? ld4(beta + c) : make_float4(0, 0, 0, 0);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % CV) * 4;
         float4 v = ld4(x + 4 * i);
-        float4 m = ld4(save + c), iv = ld4(save + C + c);
-        float4 g = gamma ? ld4(gamma + c) : make_float4(1, 1, 1, 1);
-        float4 b = beta ? ld4(beta + c) : make_float4(0, 0, 0, 0);
         float4 o;
-        o.x = fmaf((v.x - m.x) * iv.x, g.x, b.x); o.y = fmaf((v.y - m.y) * iv.y, g.y, b.y);
-        o.z = fmaf((v.z - m.z) * iv.z, g.z, b.z); o.w = fmaf((v.w - m.w) * iv.w, g.w, b.w);
+        o.x = fmaf((v.x - m[0]) * iv[0], g.x, b.x); o.y = fmaf((v.y - m[1]) * iv[1], g.y, b.y);
+        o.z = fmaf((v.z - m[2]) * iv[2], g.z, b.z); o.w = fmaf((v.w - m[3]) * iv[3], g.w, b.w);
         if (res) { float4 r = ld4(res + 4 * i); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         st4(y + 4 * i, o);
     }
 }
 
-__global__ void bn_eval_prepare_kernel(const float* running_mean, const float* running_var, int C,
-                                       float eps, float* save) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    save[c] = running_mean[c];
-    save[C + c] = 1.0f / sqrtf(running_var[c] + eps);
-}
-
-// dx = gamma * invstd * (dy' - sum_dy/count - xhat * sum_dyxhat/count)
+// dx = gamma * invstd * (dy' - sum_dy/count - xhat * sum_dyxhat/count); workgroup 0 also writes the affine
+// gradients dbeta = sum_dy, dgamma = sum_dy*xhat when asked to (from `sums`, i.e. the sums of THIS rank's rows
+// only when the caller has not all-reduced them)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, const float* x,
                                                           const float* y, float* dx, long n4, int C,
                                                           const float* save, const float* gamma,
                                                           const double* sums, double count,
-                                                          int relu) {
+                                                          int relu, float* dgamma, float* dbeta) {
     const int CV = C >> 2;
+    const int c = (int)(threadIdx.x % CV) * 4;
     const float rc = (float)(1.0 / count);
+    float mean[4], inv[4], gi[4], sdy[4], sdx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mean[k] = save[c + k]; inv[k] = save[C + c + k];
+        gi[k] = (gamma ? gamma[c + k] : 1.f) * inv[k];
+        sdy[k] = (float)sums[c + k] * rc; sdx[k] = (float)sums[C + c + k] * rc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < CV) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (dbeta) dbeta[c + k] = (float)sums[c + k];
+            if (dgamma) dgamma[c + k] = (float)sums[C + c + k];
+        }
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % CV) * 4;
         float4 d4 = ld4(dy + 4 * i), x4 = ld4(x + 4 * i);
         float d[4] = {d4.x, d4.y, d4.z, d4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
         if (relu) {
@@ -182,11 +221,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, cons
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float mean = save[c + k], inv = save[C + c + k];
-            float g = gamma ? gamma[c + k] : 1.f;
-            float xhat = (xv[k] - mean) * inv;
-            float sdy = (float)sums[c + k], sdx = (float)sums[C + c + k];
-            o[k] = g * inv * (d[k] - sdy * rc - xhat * sdx * rc);
+            const float xhat = (xv[k] - mean[k]) * inv[k];
+            o[k] = gi[k] * (d[k] - sdy[k] - xhat * sdx[k]);
         }
         st4(dx + 4 * i, make_float4(o[0], o[1], o[2], o[3]));
     }
@@ -260,32 +296,22 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, const
         int zi = (int)(v % Di);
         int n = (int)(v / Di);
         float acc[4] = {0, 0, 0, 0};
-        for (int a = 0; a < k; ++a) {
-            int tz = zi + pad - a;
-            if (tz < 0 || tz % s) continue;
-            int zo = tz / s;
-            if (zo >= Do) continue;
-            for (int b = 0; b < k; ++b) {
-                int ty = yi + pad - b;
-                if (ty < 0 || ty % s) continue;
-                int yo = ty / s;
-                if (yo >= Ho) continue;
-                for (int c = 0; c < k; ++c) {
-                    int tx = xi + pad - c;
-                    if (tx < 0 || tx % s) continue;
-                    int xo = tx / s;
-                    if (xo >= Wo) continue;
-                    long o = ((((long)n * Do + zo) * Ho + yo) * Wo + xo) * C + 4 * cv;
-                    uchar4 am = *reinterpret_cast<const uchar4*>(arg + o);
-                    float4 d = ld4(dy + o);
-                    int tap = (a * k + b) * k + c;
+        // the pooled windows that contain this voxel: o in [ceil((i + pad - k + 1)/s), floor((i + pad)/s)]
+        const int zl = max(0, (zi + pad - k + s) / s), zh = min(Do - 1, (zi + pad) / s);
+        const int yl = max(0, (yi + pad - k + s) / s), yh = min(Ho - 1, (yi + pad) / s);
+        const int xl = max(0, (xi + pad - k + s) / s), xh = min(Wo - 1, (xi + pad) / s);
+        for (int zo = zl; zo <= zh; ++zo)
+            for (int yo = yl; yo <= yh; ++yo)
+                for (int xo = xl; xo <= xh; ++xo) {
+                    const long o = ((((long)n * Do + zo) * Ho + yo) * Wo + xo) * C + 4 * cv;
+                    const uchar4 am = *reinterpret_cast<const uchar4*>(arg + o);
+                    const float4 d = ld4(dy + o);
+                    const int tap = ((zi + pad - zo * s) * k + (yi + pad - yo * s)) * k + (xi + pad - xo * s);
                     if (am.x == tap) acc[0] += d.x;
                     if (am.y == tap) acc[1] += d.y;
                     if (am.z == tap) acc[2] += d.z;
                     if (am.w == tap) acc[3] += d.w;
                 }
-            }
-        }
         st4(dx + 4 * i, make_float4(acc[0], acc[1], acc[2], acc[3]));
     }
 }
@@ -532,31 +558,29 @@ extern "C" int mi_bn_stats(const float* x, long M, int C, double* sums, void* ws
 extern "C" int mi_bn_apply_fwd(const float* x, float* y, long M, int C, const double* sums,
                                double count, const float* gamma, const float* beta, float eps,
                                float momentum, float* running_mean, float* running_var,
-                               float* save_mean_invstd, const float* res, int relu, mi_stream_t stream) {
+                               long long* num_batches_tracked, float* save_mean_invstd, const float* res,
+                               int relu, mi_stream_t stream) {
     if (!x || !y || !sums || !save_mean_invstd || !colreduce_ok(C) || M <= 0 || !(count > 0)) return MI_E_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MI_E_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, count, C, eps,
-                       momentum, running_mean, running_var, save_mean_invstd);
-    MI_RETURN_IF_LAUNCH_FAILED();
     long n4 = M * C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, y, n4, C,
-                       (const float*)save_mean_invstd, gamma, beta, res, relu);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, y, n4, C, sums, count, eps,
+                       momentum, running_mean, running_var, num_batches_tracked, save_mean_invstd, gamma,
+                       beta, res, relu);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
 
 extern "C" int mi_bn_eval_fwd(const float* x, float* y, long M, int C, const float* running_mean,
                               const float* running_var, const float* gamma, const float* beta,
-                              float eps, float* scratch_2c, const float* res, int relu, mi_stream_t stream) {
-    if (!x || !y || !running_mean || !running_var || !scratch_2c || !colreduce_ok(C) || M <= 0) return MI_E_ARG;
+                              float eps, float* save_mean_invstd, const float* res, int relu,
+                              mi_stream_t stream) {
+    if (!x || !y || !running_mean || !running_var || !colreduce_ok(C) || M <= 0) return MI_E_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean,
-                       running_var, C, eps, scratch_2c);
-    MI_RETURN_IF_LAUNCH_FAILED();
     long n4 = M * C / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, y, n4, C,
-                       (const float*)scratch_2c, gamma, beta, res, relu);
+                       (const double*)nullptr, 1.0, eps, 0.f, (float*)running_mean, (float*)running_var,
+                       (long long*)nullptr, save_mean_invstd, gamma, beta, res, relu);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -578,12 +602,8 @@ extern "C" int mi_bn_bwd_apply(const float* dy, const float* x, const float* y, 
     hipStream_t s = (hipStream_t)stream;
     long n4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, y, dx, n4, C,
-                       save_mean_invstd, gamma, sums, count, relu);
+                       save_mean_invstd, gamma, sums, count, relu, dgamma, dbeta);
     MI_RETURN_IF_LAUNCH_FAILED();
-    if (dgamma || dbeta) {
-        hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, dgamma, dbeta);
-        MI_RETURN_IF_LAUNCH_FAILED();
-    }
     return MI_OK;
 }
 

@@ -380,9 +380,8 @@ class _BNFn(torch.autograd.Function):
                                         mod.eps, mod.momentum,
                                         L.ptr(mod.running_mean if track else None),
                                         L.ptr(mod.running_var if track else None),
+                                        L.ptr(mod.num_batches_tracked if track else None),
                                         L.ptr(save), L.ptr(res), int(relu), L.stream()), "mi_bn_apply_fwd")
-            if track:
-                mod.num_batches_tracked += 1
             ctx.count = count
             ctx.train_stats = True
         else:

@@ -149,7 +149,8 @@ int mi_convnd_wgrad_f32(const float* x, const float* dy, float* dw, int N, int D
 /* nn.BatchNorm3d / BatchNorm1d over rows [M][C] (moco_encoder_3d.py:170,184,199-205), split so a
  * SyncBN all-reduce of `sums` (2*C doubles: sum x, sum x^2) fits between stats and apply.
  * count = rows behind `sums` (global M under SyncBN).  save = mean[C], invstd[C].
- * gamma/beta NULL = affine=False.  running stats NULL = not tracked.  C % 4 == 0, 256 % (C/4) == 0.
+ * gamma/beta NULL = affine=False.  running stats NULL = not tracked; num_batches_tracked (int64, may be
+ * NULL) is incremented on the device by the same launch.  C % 4 == 0, 256 % (C/4) == 0.
  * y = act(bn(x) + res): res (may be NULL) is the residual branch of the 2-D BasicBlock
  * (simsiam_model_2d.py:485-502). */
 size_t mi_colreduce_workspace_bytes(long M, int C);
@@ -157,11 +158,11 @@ int mi_bn_stats(const float* x, long M, int C, double* sums, void* ws, size_t ws
                 mi_stream_t stream);
 int mi_bn_apply_fwd(const float* x, float* y, long M, int C, const double* sums, double count,
                     const float* gamma, const float* beta, float eps, float momentum,
-                    float* running_mean, float* running_var, float* save_mean_invstd,
-                    const float* res, int relu, mi_stream_t stream);
+                    float* running_mean, float* running_var, long long* num_batches_tracked,
+                    float* save_mean_invstd, const float* res, int relu, mi_stream_t stream);
 int mi_bn_eval_fwd(const float* x, float* y, long M, int C, const float* running_mean,
                    const float* running_var, const float* gamma, const float* beta, float eps,
-                   float* scratch_2c, const float* res, int relu, mi_stream_t stream);
+                   float* save_mean_invstd, const float* res, int relu, mi_stream_t stream);
 /* backward: sums = {sum dy', sum dy'*xhat} with dy' = dy*(y>0) when relu; then
  * dx = gamma*invstd*(dy' - sums[0]/count - xhat*sums[1]/count), dgamma = sums[1], dbeta = sums[0]. */
 int mi_bn_bwd_reduce(const float* dy, const float* x, const float* y, long M, int C,
