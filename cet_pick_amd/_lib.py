@@ -29,6 +29,12 @@ SIGNATURES = {
     "mi_greedy_nms3d": (_I, [_P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _I, _P, _Z, _P]),
     "mi_crop_normalize": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     # training path
+    "mi_gauss2d_slices": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
+    "mi_rec_reorder": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "mi_vol_stats_workspace_bytes": (_Z, [_L, _L]),
+    "mi_vol_stats": (_I, [_P, _L, _L, _P, _P, _Z, _P]),
+    "mi_zscore": (_I, [_P, _P, _L, _L, _P, _P]),
+    "mi_zscore_quantize_minmax": (_I, [_P, _P, _L, _L, _P, _D, _D, _I, _P]),
     "mi_conv3d_workspace_bytes": (_Z, [_I] * 9),
     "mi_conv3d_fwd_f32": (_I, [_P, _P, _P, _P, _I] + [_I] * 9 + [_P, _Z, _P]),
     "mi_conv3d_dgrad_f32": (_I, [_P, _P, _P, _P, _P] + [_I] * 9 + [_P, _Z, _P]),

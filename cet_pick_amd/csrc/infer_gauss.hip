@@ -199,3 +199,14 @@ extern "C" int mi_gauss3d_sep(const float* in, float* out, float* tmp, int D, in
     }
     return MI_OK;
 }
+
+extern "C" int mi_gauss2d_slices(const float* in, float* out, float* tmp, int D, int H, int W, float sigma,
+                                 mi_stream_t stream) {
+    if (!in || !out || !tmp || D <= 0 || H <= 0 || W <= 0 || !(sigma > 0.f)) return MI_E_ARG;
+    if (tmp == in || tmp == out) return MI_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = mi_launch_gauss_axis(in, tmp, D, H, W, 1, sigma, s))) return rc;     // y: in -> tmp
+    if ((rc = mi_launch_gauss_axis(tmp, out, D, H, W, 2, sigma, s))) return rc;    // x: tmp -> out
+    return MI_OK;
+}

@@ -73,6 +73,37 @@ int mi_sigmoid_nms_topk(const float* logits, float* heat_out, int D, int H, int 
 int mi_gauss3d_sep(const float* in, float* out, float* tmp, int D, int H, int W, float sigma,
                    mi_stream_t stream);
 
+/* Per-slice 2-D variant (axes 1 and 2 only): `gaussian_filter(sli, sigma)` in the tilt-series branch of
+ * utils/loader.py:94-96. */
+int mi_gauss2d_slices(const float* in, float* out, float* tmp, int D, int H, int W, float sigma,
+                      mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Tomogram loading: utils/loader.py `load_rec` :27-88, `quantize` :16-25,
+ * `preprocess` :90-121.  Values are evaluated in fp64 registers and stored as fp32.
+ * ------------------------------------------------------------------------------------------ */
+enum { MI_ORDER_XYZ = 0, MI_ORDER_XZY = 1, MI_ORDER_YXZ = 2, MI_ORDER_ZXY = 3 };   /* `--order` */
+
+/* Axis reorder of an MRC data block `src` of shape (d0,d1,d2) (= mrcfile's .data.shape), element type by
+ * MRC mode (0 int8, 1 int16, 2 float32, 6 uint16), into dst (Z',X,Y) fp32 as load_rec does
+ * (loader.py:32-36,:62), with `compress`: Z' = ceil(Z/2), slice j = max(slice 2j, slice 2j+1)
+ * (loader.py:45-47,:70-71; zxy + compress + odd Z is the reference's IndexError -> MI_E_ARG). */
+int mi_rec_reorder(const void* src, int mrc_mode, int d0, int d1, int d2, int order, int compress,
+                   float* dst, mi_stream_t stream);
+/* stats[s] = {mean, std (ddof 0), min, max} of slice s of x [n_slices][slice_elems] (n_slices = 1: the whole
+ * volume, loader.py:59,:87; per slice: the is_tilt branches :48-49,:97). */
+size_t mi_vol_stats_workspace_bytes(long n_slices, long slice_elems);
+int mi_vol_stats(const float* x, long n_slices, long slice_elems, double* stats, void* ws, size_t ws_bytes,
+                 mi_stream_t stream);
+/* y = (x - mean) / std per slice (y may alias x). */
+int mi_zscore(const float* x, float* y, long n_slices, long slice_elems, const double* stats,
+              mi_stream_t stream);
+/* preprocess (loader.py:103-106,:118-120): z-score -> q = round(clip(255 (z - mi)/(ma - mi), 0, 255)) ->
+ * (q - min q)/(max q - min q).  flat_zero != 0: a constant slice gives 0 (cv2.normalize, :98,:114) instead
+ * of NaN.  y may alias x. */
+int mi_zscore_quantize_minmax(const float* x, float* y, long n_slices, long slice_elems, const double* stats,
+                              double mi, double ma, int flat_zero, mi_stream_t stream);
+
 /* utils/image.py:138-183 `get_potential_coords_pyramid`: DoG pyramid -> border zero (z: border_z
  * slices each end, x/y: 30, or 60 when H>512 and W>512) -> `_nms_xy`(k) -> max over levels ->
  * cutoff = mean(pos)+0.5*std(pos) -> greedy 3-D NMS (`non_maximum_suppression_3d`, distance d).

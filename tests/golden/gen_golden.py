@@ -36,6 +36,22 @@ tvt.functional = tvf
 _stub("skimage")
 _stub("skimage.transform", rescale=None)
 
+
+class _MrcHandle:
+    """stand-in for mrcfile.open(path, permissive=True): context manager exposing .data (the array)"""
+    def __init__(self, path, **kw):
+        from cet_pick_amd.utils.mrc import open_data
+        self.data = open_data(path)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_stub("mrcfile", open=_MrcHandle)
+
 from cet_pick.models import decode as R_decode            # noqa: E402
 from cet_pick.models.utils import _sigmoid as R_sigmoid   # noqa: E402
 from cet_pick.utils import image as R_image               # noqa: E402
@@ -44,6 +60,45 @@ from cet_pick.models import moco as R_moco                # noqa: E402
 from cet_pick.utils import utils as R_utils               # noqa: E402
 
 from cet_pick_amd.synthetic import make_tomo, make_logits, seeded_state_dict  # noqa: E402
+
+
+def gen_loader():
+    """utils/loader.py load_rec / preprocess / quantize and utils/mrc.py write -> loader_small.npz, ref_written.mrc"""
+    import tempfile
+    from cet_pick.utils import loader as R_loader
+    from cet_pick.utils import mrc as R_mrc
+    from cet_pick_amd.utils import mrc as my_mrc
+    rng = np.random.default_rng(23)
+    vol = (rng.standard_normal((10, 12, 9)) * 3.0 + 40.0).astype(np.float32)
+    vol[2:5, 3:8, 2:6] += 9.0
+    out = {"vol": vol}
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "v.mrc")
+        my_mrc.write(path, vol)
+        for order in ("xyz", "xzy", "yxz", "zxy"):
+            for comp in (False, True):
+                out[f"load_{order}_{int(comp)}"] = R_loader.load_rec(path, order=order, compress=comp)
+            out[f"load_tilt_{order}"] = R_loader.load_rec(path, order=order, compress=True, is_tilt=True)
+        v16 = np.round(vol * 10).astype(np.int16)
+        my_mrc.write(path, v16)
+        out["vol_i16"] = v16
+        out["load_i16_xzy_1"] = R_loader.load_rec(path, order="xzy", compress=True)
+        # the reference's own writer / reader: a file fixture + what its parser returns
+        ref_path = os.path.join(HERE, "ref_written.mrc")
+        R_mrc.write(ref_path, vol[:4, :5, :6].copy())
+        arr, hdr = R_mrc.parse_mrc(ref_path)
+        out["ref_written_data"] = arr
+        out["ref_written_fields"] = np.array([hdr.fields[k] for k in ("nx", "ny", "nz", "mode", "mapc", "mapr", "maps", "ispg", "next")])
+        my_mrc.write(path, vol)
+        arr2, hdr2 = R_mrc.parse_mrc(path)      # the reference reads what this build writes
+        assert np.array_equal(arr2, vol) and hdr2.fields["nx"] == 9
+    z = R_loader.load_rec.__globals__["np"].asarray(out["load_xzy_0"])
+    out["pre_0"] = R_loader.preprocess(z, denoise=0)
+    out["pre_dn"] = R_loader.preprocess(z, denoise=1.0)
+    out["quant"] = R_loader.quantize(z)
+    out["quant_33"] = R_loader.quantize(z, mi=-3, ma=3)
+    out["quant_auto"] = R_loader.quantize(z, mi=None, ma=None)
+    save("loader_small.npz", **out)
 
 
 def save(name, **arrs):
@@ -271,6 +326,6 @@ def gen_lr():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d"]
+    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader"]
     for w in which:
         globals()["gen_" + w]()
