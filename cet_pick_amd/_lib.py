@@ -43,6 +43,17 @@ SIGNATURES = {
     "mi_convnd_fwd_f32": (_I, [_P, _P, _P, _P, _I] + [_I] * 13 + [_P, _Z, _P]),
     "mi_convnd_dgrad_f32": (_I, [_P, _P, _P, _P, _P] + [_I] * 13 + [_P, _Z, _P]),
     "mi_convnd_wgrad_f32": (_I, [_P, _P, _P] + [_I] * 13 + [_P, _Z, _P]),
+    "mi_convnd_dil_workspace_bytes": (_Z, [_I] * 15),
+    "mi_convnd_dil_fwd_f32": (_I, [_P, _P, _P, _P, _I] + [_I] * 15 + [_P, _Z, _P]),
+    "mi_convnd_dil_dgrad_f32": (_I, [_P, _P, _P, _P, _P] + [_I] * 15 + [_P, _Z, _P]),
+    "mi_convnd_dil_wgrad_f32": (_I, [_P, _P, _P] + [_I] * 15 + [_P, _Z, _P]),
+    "mi_maxpool2d_ceil_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mi_maxpool2d_ceil_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mi_shuffle2x2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mi_shuffle2x2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mi_concat_channels": (_I, [_P, _I, _P, _I, _P, _L, _P]),
+    "mi_split_channels": (_I, [_P, _P, _I, _P, _I, _L, _P]),
+    "mi_zhead_fwd": (_I, [_P, _P, _P, _I, _I, _L, _I, _I, _P]),
     "mi_colreduce_workspace_bytes": (_Z, [_L, _I]),
     "mi_bn_stats": (_I, [_P, _L, _I, _P, _P, _Z, _P]),
     "mi_bn_apply_fwd": (_I, [_P, _P, _L, _I, _P, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P]),

@@ -55,6 +55,7 @@ struct ConvParams {
     unsigned mgW, mgH, mgD;        // branch-free division of a row index (< 2^31) by Wr, Hr, Dr:
     int shW, shH, shD;             //   q = (uint64(n) * mg) >> sh   (Granlund-Montgomery, N = 31)
     int kd, kh, kw, stride, pd, ph, pw;   // window / zero padding per axis (2-D convs: kd = 1, pd = 0, D = 1)
+    int dd, dh, dw;                // dilation per axis (1 unless stride == 1 and Ci > 1)
     int Ci, Co;                    // conv channels (weights are [tap][Ci][Co])
     long M;                        // GEMM rows (all classes)
     int Ncols;                     // GEMM cols
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     const int n0 = blockIdx.y * BN;
     const int Kz = p.kd, Ky = p.kh, Kx = p.kw, S = p.stride, Pz = p.pd, Py = p.ph, Px = p.pw;
     const int taps = Kz * Ky * Kx;
+    const int Lz = p.dd, Ly = p.dh, Lx = p.dw;        // dilation
 
     // ---- which rows does this workgroup own? ---------------------------------------------------
     int cls = 0;
@@ -227,16 +229,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                     int n, z, y, x;
                     rdec((unsigned)m, n, z, y, x);
                     const int zb = z * S - Pz, yb = y * S - Py, xb = x * S - Px;
-                    a_msk[i] = axis_mask(zb, 1, Kz, p.Dg) | (axis_mask(yb, 1, Ky, p.Hg) << 8) |
-                               (axis_mask(xb, 1, Kx, p.Wg) << 16);
+                    a_msk[i] = axis_mask(zb, Lz, Kz, p.Dg) | (axis_mask(yb, Ly, Ky, p.Hg) << 8) |
+                               (axis_mask(xb, Lx, Kx, p.Wg) << 16);
                     a_off[i] = 4u * (unsigned)(((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg + (STEM ? 0 : 4 * c));
                 } else {
                     int n, jz, jy, jx;
                     cdec((unsigned)m, n, jz, jy, jx);
                     const int z = zf + S * jz, y = yf + S * jy, x = xf + S * jx;
                     const int zb = (z + Pz - cz) / S, yb = (y + Py - cy) / S, xb = (x + Px - cx) / S;
-                    a_msk[i] = axis_mask(zb, -1, nz, p.Dg) | (axis_mask(yb, -1, ny, p.Hg) << 8) |
-                               (axis_mask(xb, -1, nx, p.Wg) << 16);
+                    a_msk[i] = axis_mask(zb, -Lz, nz, p.Dg) | (axis_mask(yb, -Ly, ny, p.Hg) << 8) |
+                               (axis_mask(xb, -Lx, nx, p.Wg) << 16);
                     a_off[i] = 4u * (unsigned)(((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg + 4 * c);
                     if (c == 0 && p.n_classes > 1) rowmap[row] = (((long)n * p.Dr + z) * p.Hr + y) * p.Wr + x;
                 }
@@ -260,8 +262,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                 const int tap = (int)(row / p.Ci);
                 const int ci = (int)(row % p.Ci);
                 const int a = tap / (Ky * Kx), b = (tap / Kx) % Ky, c = tap % Kx;
-                a_off[i] = 4u * (unsigned)(((long)(a * p.Hg + b) * p.Wg + c) * p.Cg + ci);
-                a_msk[i] = (unsigned)(a | (b << 8) | (c << 16));
+                a_off[i] = 4u * (unsigned)(((long)(a * Lz * p.Hg + b * Ly) * p.Wg + c * Lx) * p.Cg + ci);
+                a_msk[i] = (unsigned)((a * Lz) | ((b * Ly) << 8) | ((c * Lx) << 16));   // dilated tap coordinates
             }
         }
     }
@@ -329,10 +331,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                 const int ia = cur.ia, ib = cur.ib, ic = cur.ic, c0 = cur.c0;
                 int wtap;
                 if (MODE == MODE_FWD) {
-                    pt_aoff = 4u * (unsigned)(((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0);
+                    pt_aoff = 4u * (unsigned)(((long)(ia * Lz * p.Hg + ib * Ly) * p.Wg + ic * Lx) * p.Cg + c0);
                     wtap = (ia * Ky + ib) * Kx + ic;
                 } else {
-                    pt_aoff = 4u * (unsigned)(-((long)(ia * p.Hg + ib) * p.Wg + ic) * p.Cg + c0);
+                    pt_aoff = 4u * (unsigned)(-((long)(ia * Lz * p.Hg + ib * Ly) * p.Wg + ic * Lx) * p.Cg + c0);
                     wtap = ((cz + S * ia) * Ky + (cy + S * ib)) * Kx + (cx + S * ic);
                 }
                 // weights: FWD rows (wtap*Ci + c0 + k) of [.][Co]; DGRAD row (wtap*Ci + ci), cols c0 + k
@@ -641,6 +643,7 @@ int launch_mode(const ConvParams& p, const Plan& pl, hipStream_t s) {
 
 struct Geom {
     int N, Di, Hi, Wi, Ci, Do, Ho, Wo, Co, kd, kh, kw, stride, pd, ph, pw;
+    int dd = 1, dh = 1, dw = 1;
 };
 
 bool geom_ok(const Geom& g) {
@@ -649,14 +652,16 @@ bool geom_ok(const Geom& g) {
     if (g.stride <= 0 || g.stride > 2 || g.pd < 0 || g.ph < 0 || g.pw < 0) return false;
     if ((g.Ci % 16 && g.Ci != 1) || g.Co % 16) return false;
     if ((long)g.N * g.Di * g.Hi * g.Wi >= (1l << 31)) return false;     // 32-bit voxel indices
+    if (g.dd < 1 || g.dh < 1 || g.dw < 1 || g.dd > 36 || g.dh > 36 || g.dw > 36) return false;
+    if ((g.dd > 1 || g.dh > 1 || g.dw > 1) && (g.stride != 1 || g.Ci == 1)) return false;   // dilation: stride 1, no stem
     return true;
 }
 Geom make_geom_nd(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride,
-                  int pd, int ph, int pw) {
-    Geom g{N, Di, Hi, Wi, Ci, 0, 0, 0, Co, kd, kh, kw, stride, pd, ph, pw};
-    g.Do = (Di + 2 * pd - kd) / stride + 1;
-    g.Ho = (Hi + 2 * ph - kh) / stride + 1;
-    g.Wo = (Wi + 2 * pw - kw) / stride + 1;
+                  int pd, int ph, int pw, int dd = 1, int dh = 1, int dw = 1) {
+    Geom g{N, Di, Hi, Wi, Ci, 0, 0, 0, Co, kd, kh, kw, stride, pd, ph, pw, dd, dh, dw};
+    g.Do = (Di + 2 * pd - dd * (kd - 1) - 1) / stride + 1;
+    g.Ho = (Hi + 2 * ph - dh * (kh - 1) - 1) / stride + 1;
+    g.Wo = (Wi + 2 * pw - dw * (kw - 1) - 1) / stride + 1;
     return g;
 }
 Geom make_geom(int N, int Di, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
@@ -685,6 +690,7 @@ int setup_conv(int mode, const Geom& g, Setup* st) {
     ConvParams& p = st->p;
     p = ConvParams{};
     p.N = g.N; p.kd = g.kd; p.kh = g.kh; p.kw = g.kw; p.stride = g.stride;
+    p.dd = g.dd; p.dh = g.dh; p.dw = g.dw;
     p.pd = g.pd; p.ph = g.ph; p.pw = g.pw; p.Ci = g.Ci; p.Co = g.Co;
     const int taps = g.kd * g.kh * g.kw;
     const bool stem = (g.Ci == 1);
@@ -836,4 +842,46 @@ extern "C" int mi_convnd_wgrad_f32(const float* x, const float* dy, float* dw, i
     Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
     if (!x || !dy || !dw || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
     return run_conv(MODE_WGRAD, g, x, dy, dw, nullptr, nullptr, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---- dilated windows (stride 1): the 3-D head of the detector, unet_small.py:38-41 (kernel 3x3x3,
+// dilation (1,4,4), padding (1,4,4))
+extern "C" size_t mi_convnd_dil_workspace_bytes(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh,
+                                                int kw, int pd, int ph, int pw, int dd, int dh, int dw) {
+    Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, 1, pd, ph, pw, dd, dh, dw);
+    if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
+    size_t best = 0;
+    for (int mode = 0; mode < 3; ++mode) {
+        Setup st;
+        if (setup_conv(mode, g, &st)) continue;
+        if (st.pl.splits > 1) best = std::max(best, sizeof(float) * (size_t)st.p.M * st.p.Ncols * st.pl.splits);
+    }
+    return best + 256;
+}
+
+extern "C" int mi_convnd_dil_fwd_f32(const float* x, const float* w, float* y, const float* res, int relu,
+                                     int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw,
+                                     int pd, int ph, int pw, int dd, int dh, int dw, void* ws,
+                                     size_t ws_bytes, mi_stream_t stream) {
+    Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, 1, pd, ph, pw, dd, dh, dw);
+    if (!x || !w || !y || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
+    return run_conv(MODE_FWD, g, x, w, y, res, nullptr, relu, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mi_convnd_dil_dgrad_f32(const float* dy, const float* w, float* dx, const float* res,
+                                       const float* mask, int N, int Di, int Hi, int Wi, int Ci, int Co,
+                                       int kd, int kh, int kw, int pd, int ph, int pw, int dd, int dh,
+                                       int dw, void* ws, size_t ws_bytes, mi_stream_t stream) {
+    Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, 1, pd, ph, pw, dd, dh, dw);
+    if (!dy || !w || !dx || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
+    return run_conv(MODE_DGRAD, g, dy, w, dx, res, mask, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mi_convnd_dil_wgrad_f32(const float* x, const float* dy, float* dwt, int N, int Di, int Hi,
+                                       int Wi, int Ci, int Co, int kd, int kh, int kw, int pd, int ph,
+                                       int pw, int dd, int dh, int dw, void* ws, size_t ws_bytes,
+                                       mi_stream_t stream) {
+    Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, 1, pd, ph, pw, dd, dh, dw);
+    if (!x || !dy || !dwt || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
+    return run_conv(MODE_WGRAD, g, x, dy, dwt, nullptr, nullptr, 0, ws, ws_bytes, (hipStream_t)stream);
 }

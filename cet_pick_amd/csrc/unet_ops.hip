@@ -1,0 +1,238 @@
+// Memory-bound glue of the detector network (models/networks/unet.py, unet_small.py)
+// around the implicit-GEMM convolutions: 2-D max pooling with ceil_mode, the 2x2 stride-2 transposed
+// convolution's pixel shuffle, the skip concatenation and the (3,1,1) heads with a handful of outputs.
+// Channels-last fp32 everywhere; every kernel moves float4s and is bound by HBM bandwidth.
+#include "common.h"
+#include "../../include/cetpick_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+int ew_blocks(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 4096)); }
+
+// nn.MaxPool2d(k, stride=k, ceil_mode=True) per image (unet.py:231-233): windows may hang over the far edge
+__global__ __launch_bounds__(256) void maxpool2d_kernel(const float* x, float* y, uint8_t* arg, int N, int Hi,
+                                                       int Wi, int C, int Ho, int Wo, int k) {
+    const int CV = C >> 2;
+    const long total = (long)N * Ho * Wo * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        long v = i / CV;
+        const int xo = (int)(v % Wo); v /= Wo;
+        const int yo = (int)(v % Ho);
+        const int n = (int)(v / Ho);
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        bool first = true;
+        for (int b = 0; b < k; ++b) {
+            const int yi = yo * k + b;
+            if (yi >= Hi) break;
+            for (int c = 0; c < k; ++c) {
+                const int xi = xo * k + c;
+                if (xi >= Wi) break;
+                const float4 t = ld4(x + (((long)n * Hi + yi) * Wi + xi) * C + 4 * cv);
+                const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (first || tv[q] > best[q] || tv[q] != tv[q]) { best[q] = tv[q]; bi[q] = b * k + c; }
+                first = false;
+            }
+        }
+        st4(y + 4 * i, make_float4(best[0], best[1], best[2], best[3]));
+        if (arg) *reinterpret_cast<uchar4*>(arg + 4 * i) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+    }
+}
+
+// dx[n][yi][xi][c] = dy of the window that holds (yi, xi) when this element was its arg-max (windows are
+// disjoint: stride == k)
+__global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const float* dy, const uint8_t* arg, float* dx, int N,
+                                                           int Hi, int Wi, int C, int Ho, int Wo, int k) {
+    const int CV = C >> 2;
+    const long total = (long)N * Hi * Wi * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        long v = i / CV;
+        const int xi = (int)(v % Wi); v /= Wi;
+        const int yi = (int)(v % Hi);
+        const int n = (int)(v / Hi);
+        const int yo = yi / k, xo = xi / k, tap = (yi - yo * k) * k + (xi - xo * k);
+        const long o = (((long)n * Ho + yo) * Wo + xo) * C + 4 * cv;
+        const uchar4 am = *reinterpret_cast<const uchar4*>(arg + o);
+        const float4 d = ld4(dy + o);
+        st4(dx + 4 * i, make_float4(am.x == tap ? d.x : 0.f, am.y == tap ? d.y : 0.f, am.z == tap ? d.z : 0.f,
+                                    am.w == tap ? d.w : 0.f));
+    }
+}
+
+// nn.ConvTranspose2d(Ci, Co, kernel_size=2, stride=2) (unet.py:155-160) = a 1x1 convolution to 4*Co columns
+// (column (a*2 + b)*Co + co, done by the implicit-GEMM kernel) followed by this shuffle:
+//   y[n][2h + a][2w + b][co] = t[n][h][w][(a*2 + b)*Co + co] + bias[co],   cropped to (Ho, Wo) (autocrop, :253-266)
+__global__ __launch_bounds__(256) void shuffle2x2_kernel(const float* t, const float* bias, float* y, int N, int H,
+                                                        int W, int Co, int Ho, int Wo) {
+    const int CV = Co >> 2;
+    const long total = (long)N * Ho * Wo * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        long v = i / CV;
+        const int xo = (int)(v % Wo); v /= Wo;
+        const int yo = (int)(v % Ho);
+        const int n = (int)(v / Ho);
+        const int h = yo >> 1, a = yo & 1, w = xo >> 1, b = xo & 1;
+        float4 r = ld4(t + ((((long)n * H + h) * W + w) * 4 + (a * 2 + b)) * Co + 4 * cv);
+        if (bias) { const float4 bb = ld4(bias + 4 * cv); r.x += bb.x; r.y += bb.y; r.z += bb.z; r.w += bb.w; }
+        st4(y + 4 * i, r);
+    }
+}
+// backward of the shuffle: dt[n][h][w][(a*2+b)*Co + co] = dy[n][2h+a][2w+b][co] (0 in the cropped rim)
+__global__ __launch_bounds__(256) void unshuffle2x2_kernel(const float* dy, float* dt, int N, int H, int W, int Co,
+                                                          int Ho, int Wo) {
+    const int CV = Co >> 2;
+    const long total = (long)N * H * W * 4 * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        long v = i / CV;
+        const int ab = (int)(v % 4); v /= 4;
+        const int w = (int)(v % W); v /= W;
+        const int h = (int)(v % H);
+        const int n = (int)(v / H);
+        const int yo = 2 * h + (ab >> 1), xo = 2 * w + (ab & 1);
+        float4 r = make_float4(0, 0, 0, 0);
+        if (yo < Ho && xo < Wo) r = ld4(dy + (((long)n * Ho + yo) * Wo + xo) * Co + 4 * cv);
+        st4(dt + 4 * i, r);
+    }
+}
+
+// torch.cat((a, b), 1) in channels-last: out[m][0:Ca] = a[m], out[m][Ca:Ca+Cb] = b[m]; b may be a crop
+// (autocrop's centre crop is the identity for 'same' convolutions, so rows coincide)
+__global__ __launch_bounds__(256) void concat_kernel(const float* a, int Ca, const float* b, int Cb, float* out,
+                                                    long M) {
+    const int CV = (Ca + Cb) >> 2, CA = Ca >> 2;
+    const long total = M * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        const long m = i / CV;
+        st4(out + 4 * i, cv < CA ? ld4(a + m * Ca + 4 * cv) : ld4(b + m * Cb + 4 * (cv - CA)));
+    }
+}
+// backward: split d(out) into da, db
+__global__ __launch_bounds__(256) void split_kernel(const float* dout, float* da, int Ca, float* db, int Cb, long M) {
+    const int CV = (Ca + Cb) >> 2, CA = Ca >> 2;
+    const long total = M * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        const long m = i / CV;
+        const float4 v = ld4(dout + 4 * i);
+        if (cv < CA) st4(da + m * Ca + 4 * cv, v); else st4(db + m * Cb + 4 * (cv - CA), v);
+    }
+}
+
+// nn.Conv3d(C, K, kernel_size=(3,1,1), padding=(1,0,0), bias=False) with K <= 4 outputs (the `hm` head,
+// unet_small.py:55-62): y[n][z][p][k] = sum_{dz, c} x[n][z+dz-1][p][c] * w[dz][c][k].  One thread per voxel,
+// the 3*C*K weights in LDS; reads 3*C floats per voxel (2 of the 3 planes hit L2).
+template <int K>
+__global__ __launch_bounds__(256) void zhead_kernel(const float* x, const float* w, float* y, int N, int D, long P,
+                                                   int C) {
+    extern __shared__ float ws[];                      // [3][C][K]
+    for (int i = threadIdx.x; i < 3 * C * K; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const long total = (long)N * D * P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long pz = i / P;
+        const int z = (int)(pz % D);
+        float acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = 0.f;
+        for (int dz = 0; dz < 3; ++dz) {
+            const int zz = z + dz - 1;
+            if ((unsigned)zz >= (unsigned)D) continue;
+            const float* xr = x + (i + (long)(dz - 1) * P) * C;
+            const float* wr = ws + dz * C * K;
+            for (int c = 0; c < C; c += 4) {
+                const float4 v = ld4(xr + c);
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    acc[k] = fmaf(v.x, wr[c * K + k], fmaf(v.y, wr[(c + 1) * K + k],
+                             fmaf(v.z, wr[(c + 2) * K + k], fmaf(v.w, wr[(c + 3) * K + k], acc[k]))));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) y[i * K + k] = acc[k];
+    }
+}
+
+}  // namespace
+
+extern "C" int mi_maxpool2d_ceil_fwd(const float* x, float* y, uint8_t* argmax, int N, int Hi, int Wi, int C, int k,
+                                     mi_stream_t stream) {
+    if (!x || !y || C % 4 || k <= 0 || k > 15 || N <= 0 || Hi <= 0 || Wi <= 0) return MI_E_ARG;
+    const int Ho = (Hi + k - 1) / k, Wo = (Wi + k - 1) / k;
+    const long total = (long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool2d_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, N,
+                       Hi, Wi, C, Ho, Wo, k);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+extern "C" int mi_maxpool2d_ceil_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, int Hi, int Wi, int C,
+                                     int k, mi_stream_t stream) {
+    if (!dy || !argmax || !dx || C % 4 || k <= 0 || k > 15 || N <= 0 || Hi <= 0 || Wi <= 0) return MI_E_ARG;
+    const int Ho = (Hi + k - 1) / k, Wo = (Wi + k - 1) / k;
+    const long total = (long)N * Hi * Wi * (C / 4);
+    hipLaunchKernelGGL(maxpool2d_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx,
+                       N, Hi, Wi, C, Ho, Wo, k);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_shuffle2x2_fwd(const float* t, const float* bias, float* y, int N, int H, int W, int Co, int Ho,
+                                 int Wo, mi_stream_t stream) {
+    if (!t || !y || Co % 4 || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Ho > 2 * H || Wo > 2 * W) return MI_E_ARG;
+    const long total = (long)N * Ho * Wo * (Co / 4);
+    hipLaunchKernelGGL(shuffle2x2_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, t, bias, y, N, H, W,
+                       Co, Ho, Wo);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+extern "C" int mi_shuffle2x2_bwd(const float* dy, float* dt, int N, int H, int W, int Co, int Ho, int Wo,
+                                 mi_stream_t stream) {
+    if (!dy || !dt || Co % 4 || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Ho > 2 * H || Wo > 2 * W) return MI_E_ARG;
+    const long total = (long)N * H * W * Co;
+    hipLaunchKernelGGL(unshuffle2x2_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, dt, N, H, W,
+                       Co, Ho, Wo);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, long M,
+                                  mi_stream_t stream) {
+    if (!a || !b || !out || Ca <= 0 || Cb <= 0 || Ca % 4 || Cb % 4 || M <= 0) return MI_E_ARG;
+    const long total = M * ((Ca + Cb) / 4);
+    hipLaunchKernelGGL(concat_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a, Ca, b, Cb, out, M);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+extern "C" int mi_split_channels(const float* dout, float* da, int Ca, float* db, int Cb, long M, mi_stream_t stream) {
+    if (!dout || !da || !db || Ca <= 0 || Cb <= 0 || Ca % 4 || Cb % 4 || M <= 0) return MI_E_ARG;
+    const long total = M * ((Ca + Cb) / 4);
+    hipLaunchKernelGGL(split_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dout, da, Ca, db, Cb, M);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_zhead_fwd(const float* x, const float* w, float* y, int N, int D, long P, int C, int K,
+                            mi_stream_t stream) {
+    if (!x || !w || !y || N <= 0 || D <= 0 || P <= 0 || C <= 0 || C % 4 || K < 1 || K > 4) return MI_E_ARG;
+    const long total = (long)N * D * P;
+    const size_t lds = sizeof(float) * 3 * (size_t)C * K;
+    if (lds > 48 * 1024) return MI_E_UNSUPPORTED;
+    const dim3 grid(ew_blocks(total)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (K) {
+        case 1: hipLaunchKernelGGL((zhead_kernel<1>), grid, block, lds, s, x, w, y, N, D, P, C); break;
+        case 2: hipLaunchKernelGGL((zhead_kernel<2>), grid, block, lds, s, x, w, y, N, D, P, C); break;
+        case 3: hipLaunchKernelGGL((zhead_kernel<3>), grid, block, lds, s, x, w, y, N, D, P, C); break;
+        default: hipLaunchKernelGGL((zhead_kernel<4>), grid, block, lds, s, x, w, y, N, D, P, C); break;
+    }
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}

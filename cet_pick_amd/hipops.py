@@ -159,8 +159,9 @@ def _out_dims(shape5, k3, stride, p3):
     return tuple((v + 2 * p - k) // stride + 1 for v, k, p in zip((d, h, w), k3, p3))
 
 
-def conv_fwd(x, w, k, stride, pad, res=None, relu=False):
-    """y = act(conv(x, w) + res).  x: (N,D,H,W,Ci) or (N,H,W,Ci) channels-last; w in kernel layout."""
+def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None):
+    """y = act(conv(x, w) + res).  x: (N,D,H,W,Ci) or (N,H,W,Ci) channels-last; w in kernel layout.
+    dil: per-axis dilation (stride 1 only)."""
     _f32c(x, "x")
     if not _phys_ok(w):
         raise L.HipExtensionError("conv weight is not in kernel layout [tap][Cin][Cout]")
@@ -169,9 +170,20 @@ def conv_fwd(x, w, k, stride, pad, res=None, relu=False):
     x5 = _as5d(x)
     n, d, h, wd, ci = x5.shape
     co = w.shape[0]
+    lib = L.lib()
+    if dil is not None and tuple(dil) != (1, 1, 1):
+        d3 = _k3(dil, nd5)
+        if stride != 1:
+            raise L.HipExtensionError("dilated convolution needs stride 1")
+        do, ho, wo = (v + 2 * p - dl * (kk - 1) for v, kk, p, dl in zip((d, h, wd), k3, p3, d3))
+        y = torch.empty((n, do, ho, wo, co) if nd5 else (n, ho, wo, co), dtype=torch.float32, device=x.device)
+        ws = _ws(lib.mi_convnd_dil_workspace_bytes(n, d, h, wd, ci, co, *k3, *p3, *d3), x.device, "conv")
+        with _Prof("fwd", 2.0 * n * do * ho * wo * co * ci * k3[0] * k3[1] * k3[2]):
+            L.check(lib.mi_convnd_dil_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(res), int(relu), n, d, h, wd, ci, co,
+                                              *k3, *p3, *d3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_dil_fwd_f32")
+        return y
     do, ho, wo = _out_dims(x5.shape, k3, stride, p3)
     y = torch.empty((n, do, ho, wo, co) if nd5 else (n, ho, wo, co), dtype=torch.float32, device=x.device)
-    lib = L.lib()
     ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), x.device, "conv")
     with _Prof("fwd", 2.0 * n * do * ho * wo * co * ci * k3[0] * k3[1] * k3[2]):
         L.check(lib.mi_convnd_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(res), int(relu), n, d, h, wd, ci, co,

@@ -177,6 +177,46 @@ int mi_convnd_wgrad_f32(const float* x, const float* dy, float* dw, int N, int D
                         int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw,
                         void* ws, size_t ws_bytes, mi_stream_t stream);
 
+/* Dilated windows, stride 1 (kernel (3,3,3), dilation (1,4,4), padding (1,4,4): the 3-D head of the detector
+ * network, models/networks/unet_small.py:38-41).  Same contract as mi_convnd_*; output extent per axis
+ * = in + 2*pad - dil*(k-1). */
+size_t mi_convnd_dil_workspace_bytes(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw,
+                                     int pd, int ph, int pw, int dd, int dh, int dw);
+int mi_convnd_dil_fwd_f32(const float* x, const float* w, float* y, const float* res, int relu, int N, int Di,
+                          int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int pd, int ph, int pw,
+                          int dd, int dh, int dw, void* ws, size_t ws_bytes, mi_stream_t stream);
+int mi_convnd_dil_dgrad_f32(const float* dy, const float* w, float* dx, const float* res, const float* mask,
+                            int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int pd,
+                            int ph, int pw, int dd, int dh, int dw, void* ws, size_t ws_bytes,
+                            mi_stream_t stream);
+int mi_convnd_dil_wgrad_f32(const float* x, const float* dy, float* dw_out, int N, int Di, int Hi, int Wi,
+                            int Ci, int Co, int kd, int kh, int kw, int pd, int ph, int pw, int dd, int dh,
+                            int dw, void* ws, size_t ws_bytes, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Detector network glue (models/networks/unet.py, unet_small.py), channels-last.
+ * ------------------------------------------------------------------------------------------ */
+/* nn.MaxPool2d(k, ceil_mode=True) per image (unet.py:231-233): Ho = ceil(Hi/k); argmax (tap in the window,
+ * may be NULL) feeds the backward. */
+int mi_maxpool2d_ceil_fwd(const float* x, float* y, uint8_t* argmax, int N, int Hi, int Wi, int C, int k,
+                          mi_stream_t stream);
+int mi_maxpool2d_ceil_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, int Hi, int Wi, int C,
+                          int k, mi_stream_t stream);
+/* nn.ConvTranspose2d(Ci, Co, 2, stride=2) (unet.py:155-160) = 1x1 conv to 4*Co columns [(a*2+b)*Co + co]
+ * (mi_convnd_fwd_f32) + this shuffle: y[n][2h+a][2w+b][co] = t[n][h][w][(a*2+b)*Co+co] + bias[co], cropped to
+ * (Ho, Wo) <= (2H, 2W) (`autocrop`, unet.py:253-266).  bwd: the inverse scatter (zeros in the cropped rim). */
+int mi_shuffle2x2_fwd(const float* t, const float* bias, float* y, int N, int H, int W, int Co, int Ho, int Wo,
+                      mi_stream_t stream);
+int mi_shuffle2x2_bwd(const float* dy, float* dt, int N, int H, int W, int Co, int Ho, int Wo,
+                      mi_stream_t stream);
+/* torch.cat((a, b), 1) (unet.py:385) over M rows, and its backward. */
+int mi_concat_channels(const float* a, int Ca, const float* b, int Cb, float* out, long M, mi_stream_t stream);
+int mi_split_channels(const float* dout, float* da, int Ca, float* db, int Cb, long M, mi_stream_t stream);
+/* nn.Conv3d(C, K, (3,1,1), padding=(1,0,0), bias=False) with K <= 4 outputs: the `hm` head
+ * (unet_small.py:55-62).  x (N,D,P,C), w [3][C][K], y (N,D,P,K), P = H*W. */
+int mi_zhead_fwd(const float* x, const float* w, float* y, int N, int D, long P, int C, int K,
+                 mi_stream_t stream);
+
 /* nn.BatchNorm3d / BatchNorm1d over rows [M][C] (moco_encoder_3d.py:170,184,199-205), split so a
  * SyncBN all-reduce of `sums` (2*C doubles: sum x, sum x^2) fits between stats and apply.
  * count = rows behind `sums` (global M under SyncBN).  save = mean[C], invstd[C].

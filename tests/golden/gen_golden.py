@@ -101,6 +101,30 @@ def gen_loader():
     save("loader_small.npz", **out)
 
 
+def gen_unet():
+    """a22: TomoConvUNet (unet_small.py:30-97) eval-mode forward, unet_4, heads {'hm': 1, 'proj': 32}."""
+    from cet_pick.models.networks import unet_small as RU
+    heads = {"hm": 1, "proj": 32}
+    net = RU.TomoConvUNet(4, heads, 32, 3)
+    net.load_state_dict(seeded_state_dict(net, seed=321))
+    net.eval()
+    g = torch.Generator().manual_seed(7)
+    res = {}
+    for tag, shape in (("a", (1, 8, 64, 64)), ("odd", (1, 5, 52, 44)), ("b2", (2, 4, 48, 48))):
+        x = torch.randn(shape, generator=g)
+        with torch.no_grad():
+            out = net(x)[0]
+        res[f"x_{tag}"] = x.numpy()
+        res[f"hm_{tag}"] = out["hm"].numpy()
+        pr = out["proj"].numpy()
+        res[f"proj_{tag}"] = pr[:, :, :, ::3, ::3].copy()       # subsampled: keeps the fixture small
+    save("unet4.npz", **res)
+    path = os.path.join(HERE, "ckpt_keys.json")
+    keys = json.load(open(path))
+    keys["unet_4"] = {k: list(v.shape) for k, v in net.state_dict().items()}
+    json.dump(keys, open(path, "w"), indent=0, sort_keys=True)
+
+
 def save(name, **arrs):
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **arrs)
@@ -326,6 +350,6 @@ def gen_lr():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader"]
+    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader", "unet"]
     for w in which:
         globals()["gen_" + w]()

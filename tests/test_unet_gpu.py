@@ -1,0 +1,159 @@
+"""GPU parity of the detector network (row a22) and of its glue kernels with torch fp32 / the reference outputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+HEADS = {"hm": 1, "proj": 32}
+
+
+def _cl(x):       # NCHW / NCDHW -> channels-last contiguous cuda
+    perm = (0,) + tuple(range(2, x.dim())) + (1,)
+    return x.permute(*perm).contiguous().cuda()
+
+
+def _cf(y):       # channels-last cuda -> NC... cpu
+    perm = (0, y.dim() - 1) + tuple(range(1, y.dim() - 1))
+    return y.permute(*perm).cpu()
+
+
+@pytest.mark.parametrize("shape,k,pad,dil", [((2, 6, 20, 24, 32), (3, 3, 3), (1, 4, 4), (1, 4, 4)),
+                                             ((1, 5, 17, 19, 16), (3, 3, 3), (1, 2, 3), (1, 2, 3)),
+                                             ((1, 4, 12, 12, 32), (3, 1, 1), (1, 0, 0), (1, 1, 1))])
+def test_dilated_conv_fwd_dgrad_wgrad(shape, k, pad, dil):
+    from cet_pick_amd import hipops as H, _lib as L
+    n, d, h, w, ci = shape
+    co = 32
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, ci, d, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(co, ci, *k, generator=g) * 0.1).requires_grad_()
+    y = F.conv3d(x, wt, padding=pad, dilation=dil)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    wk = wt.detach().permute(2, 3, 4, 1, 0).contiguous().cuda().permute(4, 3, 0, 1, 2)
+    got = H.conv_fwd(_cl(x.detach()), wk, k, 1, pad, dil=dil)
+    np.testing.assert_allclose(_cf(got).numpy(), y.detach().numpy(), rtol=1e-4, atol=1e-4)
+    lib = L.lib()
+    xc, dyc = _cl(x.detach()), _cl(dy)
+    ws = L.workspace(lib.mi_convnd_dil_workspace_bytes(n, d, h, w, ci, co, *k, *pad, *dil), xc.device, "conv")
+    dx = torch.empty_like(xc)
+    L.check(lib.mi_convnd_dil_dgrad_f32(L.ptr(dyc), L.ptr(wk), L.ptr(dx), None, None, n, d, h, w, ci, co, *k, *pad, *dil,
+                                        L.ptr(ws), ws.numel(), L.stream()), "dgrad")
+    np.testing.assert_allclose(_cf(dx).numpy(), x.grad.numpy(), rtol=1e-4, atol=2e-4)
+    dw = torch.empty(k[0], k[1], k[2], ci, co, device="cuda")
+    L.check(lib.mi_convnd_dil_wgrad_f32(L.ptr(xc), L.ptr(dyc), L.ptr(dw), n, d, h, w, ci, co, *k, *pad, *dil,
+                                        L.ptr(ws), ws.numel(), L.stream()), "wgrad")
+    ref = wt.grad.permute(2, 3, 4, 1, 0).numpy()
+    np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("h,w", [(16, 16), (13, 9), (1, 7)])
+def test_maxpool2d_ceil(h, w):
+    from cet_pick_amd import _lib as L
+    g = torch.Generator().manual_seed(h * w)
+    x = torch.randn(3, 8, h, w, generator=g, requires_grad=True)
+    y = F.max_pool2d(x, 2, ceil_mode=True)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xc = _cl(x.detach())
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    out = torch.empty(3, ho, wo, 8, device="cuda")
+    arg = torch.empty(3, ho, wo, 8, dtype=torch.uint8, device="cuda")
+    lib = L.lib()
+    L.check(lib.mi_maxpool2d_ceil_fwd(L.ptr(xc), L.ptr(out), L.ptr(arg), 3, h, w, 8, 2, L.stream()), "fwd")
+    np.testing.assert_array_equal(_cf(out).numpy(), y.detach().numpy())
+    dx = torch.empty_like(xc)
+    L.check(lib.mi_maxpool2d_ceil_bwd(L.ptr(_cl(dy)), L.ptr(arg), L.ptr(dx), 3, h, w, 8, 2, L.stream()), "bwd")
+    np.testing.assert_array_equal(_cf(dx).numpy(), x.grad.numpy())
+
+
+@pytest.mark.parametrize("h,w,ho,wo", [(6, 5, 12, 10), (6, 5, 11, 9)])
+def test_conv_transpose_as_gemm_plus_shuffle(h, w, ho, wo):
+    from cet_pick_amd import hipops as H, _lib as L
+    g = torch.Generator().manual_seed(ho)
+    ci, co = 32, 16
+    x = torch.randn(2, ci, h, w, generator=g)
+    wt = torch.randn(ci, co, 2, 2, generator=g) * 0.2
+    b = torch.randn(co, generator=g)
+    ref = F.conv_transpose2d(x, wt, b, stride=2)[:, :, :ho, :wo]
+    wk = wt.permute(0, 2, 3, 1).contiguous().cuda().view(1, 1, ci, 4 * co).permute(3, 2, 0, 1)
+    t = H.conv_fwd(_cl(x), wk, 1, 1, 0)
+    out = torch.empty(2, ho, wo, co, device="cuda")
+    lib = L.lib()
+    L.check(lib.mi_shuffle2x2_fwd(L.ptr(t), L.ptr(b.cuda()), L.ptr(out), 2, h, w, co, ho, wo, L.stream()), "shuffle")
+    np.testing.assert_allclose(_cf(out).numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    # backward scatter is the exact inverse (zeros in the cropped rim)
+    dt = torch.empty_like(t)
+    L.check(lib.mi_shuffle2x2_bwd(L.ptr(out), L.ptr(dt), 2, h, w, co, ho, wo, L.stream()), "unshuffle")
+    back = torch.empty_like(out)
+    L.check(lib.mi_shuffle2x2_fwd(L.ptr(dt), None, L.ptr(back), 2, h, w, co, ho, wo, L.stream()), "shuffle")
+    assert torch.equal(back, out)
+
+
+def test_concat_split_and_zhead():
+    from cet_pick_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(50, 16, generator=g).cuda(), torch.randn(50, 32, generator=g).cuda()
+    out = torch.empty(50, 48, device="cuda")
+    lib = L.lib()
+    L.check(lib.mi_concat_channels(L.ptr(a), 16, L.ptr(b), 32, L.ptr(out), 50, L.stream()), "concat")
+    assert torch.equal(out, torch.cat((a, b), 1))
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    L.check(lib.mi_split_channels(L.ptr(out), L.ptr(da), 16, L.ptr(db), 32, 50, L.stream()), "split")
+    assert torch.equal(da, a) and torch.equal(db, b)
+    for k in (1, 3):
+        x = torch.randn(2, 32, 6, 9, 7, generator=g)
+        wt = torch.randn(k, 32, 3, 1, 1, generator=g) * 0.2
+        ref = F.conv3d(x, wt, padding=(1, 0, 0))
+        y = torch.empty(2, 6, 9, 7, k, device="cuda")
+        wk = wt[:, :, :, 0, 0].permute(2, 1, 0).contiguous().cuda()
+        L.check(lib.mi_zhead_fwd(L.ptr(_cl(x)), L.ptr(wk), L.ptr(y), 2, 6, 63, 32, k, L.stream()), "zhead")
+        np.testing.assert_allclose(_cf(y).numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def _net():
+    from cet_pick_amd.models.networks.unet_small import TomoConvUNet
+    from cet_pick_amd.synthetic import seeded_state_dict
+    net = TomoConvUNet(4, HEADS, 32, 3)
+    net.load_state_dict(seeded_state_dict(net, seed=321))
+    return net.cuda().eval()
+
+
+def test_unet_forward_matches_reference_outputs():
+    g = np.load(os.path.join(G, "unet4.npz"))
+    net = _net()
+    with torch.no_grad():
+        for tag in ("a", "odd", "b2"):
+            out = net(torch.from_numpy(g[f"x_{tag}"]).cuda())[0]
+            hm, pr = out["hm"].cpu().numpy(), out["proj"].cpu().numpy()
+            ref = g[f"hm_{tag}"]
+            assert hm.shape == ref.shape
+            np.testing.assert_allclose(hm, ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+            np.testing.assert_allclose(pr[:, :, :, ::3, ::3], g[f"proj_{tag}"], rtol=0, atol=2e-4)
+
+
+def test_unet_forward_vs_oracle_larger():
+    from oracle import unet_ref as O
+    net = _net()
+    x = torch.randn(1, 12, 104, 120, generator=torch.Generator().manual_seed(12))
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    ref = O.tomo_conv_unet_forward(sd, x, 4, HEADS)
+    with torch.no_grad():
+        out = net(x.cuda())[0]
+    for h in HEADS:
+        r = ref[h].numpy()
+        np.testing.assert_allclose(out[h].cpu().numpy(), r, rtol=0, atol=3e-4 * max(1.0, np.abs(r).max()))
+
+
+def test_unet_weight_cache_follows_parameter_updates():
+    net = _net()
+    x = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        a = net(x)[0]["hm"].clone()
+        net.hm.weight.mul_(2.0)
+        b = net(x)[0]["hm"]
+    np.testing.assert_allclose(b.cpu().numpy(), 2 * a.cpu().numpy(), rtol=1e-5, atol=1e-6)
