@@ -29,7 +29,7 @@ __device__ __forceinline__ float produce(const MarchParams& p, long idx, int z, 
     if (p.mode == MI_LOAD_SIGMOID) {
         float v = p.in[idx];
         float s = 1.0f / (1.0f + expf(-v));
-        return fminf(fmaxf(s, 1e-4f), 1.0f - 1e-4f);
+        return s != s ? s : fminf(fmaxf(s, 1e-4f), 1.0f - 1e-4f);       // torch.clamp keeps a NaN
     } else if (p.mode == MI_LOAD_DOG) {
         bool border = (z < p.bz) | (z >= p.D - p.bz) | (y < p.by) | (y >= p.H - p.by) |
                       (x < p.bx) | (x >= p.W - p.bx);
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NT) void nms_march_kernel(MarchParams p) {
             // v_exp_f32 + v_rcp_f32 (about 1e-6 relative on the clamped range, monotone): the exact
             // expf + IEEE divide made this HBM-bound pass VALU-bound
             float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-            return fminf(fmaxf(sg, 1e-4f), 1.0f - 1e-4f);
+            return sg != sg ? sg : fminf(fmaxf(sg, 1e-4f), 1.0f - 1e-4f);   // torch.clamp keeps a NaN
         } else if (p.mode == MI_LOAD_DOG) {
             bool border = (z < p.bz) | (z >= p.D - p.bz) | (yy < p.by) | (yy >= p.H - p.by) |
                           (xx < p.bx) | (xx >= p.W - p.bx);
@@ -338,7 +338,7 @@ __global__ void sigmoid_clamp_kernel(float* x, float* y, size_t n) {
     for (; i < n; i += stride) {
         float s = 1.0f / (1.0f + expf(-x[i]));
         x[i] = s;
-        y[i] = fminf(fmaxf(s, 1e-4f), 1.0f - 1e-4f);
+        y[i] = s != s ? s : fminf(fmaxf(s, 1e-4f), 1.0f - 1e-4f);       // torch.clamp keeps a NaN
     }
 }
 

@@ -122,7 +122,7 @@ def gen_unet():
     path = os.path.join(HERE, "ckpt_keys.json")
     keys = json.load(open(path))
     keys["unet_4"] = {k: list(v.shape) for k, v in net.state_dict().items()}
-    json.dump(keys, open(path, "w"), indent=0, sort_keys=True)
+    json.dump(keys, open(path, "w"), indent=0)
 
 
 def save(name, **arrs):

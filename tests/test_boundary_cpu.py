@@ -70,4 +70,4 @@ def test_factory_and_checkpoint_layout(tmp_path, capsys):
     assert torch.equal(m2.conv1.weight.detach(), m.conv1.weight.detach())
     assert m2.conv1.weight.stride() == m.conv1.weight.stride()            # kernel layout survives loading
     with pytest.raises(NotImplementedError):
-        create_model("unet_4", {"hm": 1, "proj": 32}, 32)
+        create_model("res_18", {"hm": 1}, 64)                             # exists in the reference, outside the hot path
