@@ -54,6 +54,15 @@ SIGNATURES = {
     "mi_concat_channels": (_I, [_P, _I, _P, _I, _P, _L, _P]),
     "mi_split_channels": (_I, [_P, _P, _I, _P, _I, _L, _P]),
     "mi_zhead_fwd": (_I, [_P, _P, _P, _I, _I, _L, _I, _I, _P]),
+    "mi_voxel_loss_workspace_bytes": (_Z, [_L]),
+    "mi_pu_focal_loss_fwd": (_I, [_P, _P, _L, _D, _D, _P, _P, _P, _Z, _P]),
+    "mi_pu_focal_loss_bwd": (_I, [_P, _P, _L, _D, _P, _P, _P, _P]),
+    "mi_focal_loss_fwd": (_I, [_P, _P, _L, _P, _P, _P, _Z, _P]),
+    "mi_focal_loss_bwd": (_I, [_P, _P, _L, _P, _P, _P, _P]),
+    "mi_mse_loss_fwd": (_I, [_P, _P, _L, _P, _P, _P, _Z, _P]),
+    "mi_mse_loss_bwd": (_I, [_P, _P, _L, _P, _P, _P, _P, _P]),
+    "mi_ucl_rowsums_fwd": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    "mi_ucl_rowsums_bwd": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
     "mi_colreduce_workspace_bytes": (_Z, [_L, _I]),
     "mi_bn_stats": (_I, [_P, _L, _I, _P, _P, _Z, _P]),
     "mi_bn_apply_fwd": (_I, [_P, _P, _L, _I, _P, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P]),

@@ -5,10 +5,31 @@ import torch
 from .. import _lib as L
 
 
+class _SigmoidClampFn(torch.autograd.Function):
+    """clamp(sigmoid(x), 1e-4, 1-1e-4) with its gradient s(1-s) inside the clamp, 0 outside (training losses)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xs = x.detach().clone().contiguous()
+        y = torch.empty_like(xs)
+        L.check(L.lib().mi_sigmoid_clamp(L.ptr(xs), L.ptr(y), xs.numel(), L.stream()), "mi_sigmoid_clamp")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        inside = (y > 1e-4) & (y < 1 - 1e-4)
+        return torch.where(inside, dy * y * (1 - y), torch.zeros_like(dy))
+
+
 def _sigmoid(x):
     """clamp(x.sigmoid_(), 1e-4, 1-1e-4): x is overwritten with the un-clamped sigmoid IN PLACE and
-    a new clamped tensor is returned (reference models/utils.py:167-169)."""
+    a new clamped tensor is returned (reference models/utils.py:167-169).  When x carries a gradient the
+    differentiable (out-of-place) form is used."""
     L.require_cuda(x, "x")
+    if x.requires_grad and torch.is_grad_enabled():
+        return _SigmoidClampFn.apply(x)
     if not x.is_contiguous():
         raise L.HipExtensionError("_sigmoid needs a contiguous tensor (it works in place)")
     y = torch.empty_like(x)

@@ -81,3 +81,39 @@ def seeded_state_dict(model, seed=317, gain=1.0):
             fan_in = v[0].numel()
             out[k] = torch.randn(v.shape, generator=g) * (gain * (2.0 / fan_in) ** 0.5)
     return out
+
+
+def losses_inputs(seed=31, n=512, dim=32, shape=(2, 1, 4, 16, 16)):
+    """Seeded inputs of the detector-loss fixtures (tests/golden/losses.npz): heat-map / label volumes with positive (1),
+    soft, labelled-negative (0) and unlabeled (-1) voxels, two views of L2-normalised features, per-voxel labels and
+    predictions with values beyond the 0.99 / 0.01 pseudo-label thresholds."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    pred = torch.rand(shape, generator=g).clamp(1e-4, 1 - 1e-4)
+    gt = torch.full(shape, -1.0)
+    r = torch.rand(shape, generator=g)
+    gt[r < 0.30] = 0.0
+    soft = (r >= 0.30) & (r < 0.40)
+    gt[soft] = (torch.rand(shape, generator=g)[soft] * 0.9)
+    gt[r > 0.97] = 1.0
+    f = torch.nn.functional.normalize(torch.randn(n, dim, generator=g), dim=1)
+    f_cr = torch.nn.functional.normalize(f + 0.3 * torch.randn(n, dim, generator=g), dim=1)
+    lab = torch.full((n,), -1.0)
+    rr = torch.rand(n, generator=g)
+    lab[rr < 0.25] = 0.0
+    lab[(rr >= 0.25) & (rr < 0.35)] = 0.5
+    lab[rr > 0.95] = 1.0
+    o1 = torch.rand(n, generator=g)
+    o1[torch.rand(n, generator=g) < 0.15] = 0.995
+    o1[torch.rand(n, generator=g) < 0.15] = 0.004
+    o2 = (o1 + 0.05 * torch.randn(n, generator=g)).clamp(1e-4, 1 - 1e-4)
+    return pred, gt, f, f_cr, lab, o1, o2
+
+
+def confident_pred(gt, seed=37):
+    """A heat-map that agrees with the labels (high on positives, low elsewhere): drives the PU risk into its
+    `neg_risk_total < -beta` branch (loss.py:305-306)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    r = torch.rand(gt.shape, generator=g)
+    return torch.where(gt == 1, 0.90 + 0.09 * r, 0.02 + 0.05 * r)

@@ -295,6 +295,41 @@ int mi_sgd_step(float* p, const float* g, const float* lr_dev, float lr, float w
 int mi_queue_enqueue(float* queue, int64_t* queue_ptr, const float* keys, int B, int C, int R,
                      mi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Detector-training losses, cet_pick/models/loss.py.  `pred` is the clamped sigmoid
+ * heat-map, `gt` the label map (1 positive, (-1,1) soft, -1 unlabeled).  Each forward writes the scalar loss
+ * (device float) and `sums` (11 doubles: the 8 partial sums, loss, PU branch flag, n) that the backward
+ * reads; nothing synchronises.  ws: mi_voxel_loss_workspace_bytes(n).
+ * ------------------------------------------------------------------------------------------ */
+size_t mi_voxel_loss_workspace_bytes(long n);
+/* `_pu_neg_loss(pred, gt, tau, beta, gamma)` loss.py:255-308 (the `< -beta` branch is taken on the device). */
+int mi_pu_focal_loss_fwd(const float* pred, const float* gt, long n, double tau, double beta, double* sums,
+                         float* loss, void* ws, size_t ws_bytes, mi_stream_t stream);
+int mi_pu_focal_loss_bwd(const float* pred, const float* gt, long n, double tau, const double* sums,
+                         const float* dloss, float* dpred, mi_stream_t stream);
+/* `_neg_loss(pred, gt)` loss.py:378-411 (FocalLoss). */
+int mi_focal_loss_fwd(const float* pred, const float* gt, long n, double* sums, float* loss, void* ws,
+                      size_t ws_bytes, mi_stream_t stream);
+int mi_focal_loss_bwd(const float* pred, const float* gt, long n, const double* sums, const float* dloss,
+                      float* dpred, mi_stream_t stream);
+/* `ConsistencyLoss` loss.py:701-712: mean((a-b)^2); db may be NULL. */
+int mi_mse_loss_fwd(const float* a, const float* b, long n, double* sums, float* loss, void* ws,
+                    size_t ws_bytes, mi_stream_t stream);
+int mi_mse_loss_bwd(const float* a, const float* b, long n, const double* sums, const float* dloss, float* da,
+                    float* db, mi_stream_t stream);
+/* `UnbiasedConLoss.forward` loss.py:594-699 without the (2N)^2 matrix.  feat [n2][dim] (both views stacked,
+ * n2 = 2N, row i and row i +- N are the two views of a voxel; dim 32 or 64), cls[n2]: bit 0 positive label,
+ * bit 1 "other" (label < thresh).  With S = feat feat^T * inv_T, m_i = max_j S_ij and
+ * E_ij = exp((S_ij - m_i) * [i != j]) (loss.py:615-624) the forward returns per row
+ *   rowmax = m_i, s_all = sum_j E_ij, s_pos = sum_j E_ij [pos j], s_other = sum_j E_ij [other j], e_pair = E_i,pair(i)
+ * and the backward, given the gradients of those four sums, d(loss)/d(feat) (m_i is detached like
+ * `logits_max_all.detach()`). */
+int mi_ucl_rowsums_fwd(const float* feat, const uint8_t* cls, int n2, int dim, float inv_T, float* rowmax,
+                       float* s_all, float* s_pos, float* s_other, float* e_pair, mi_stream_t stream);
+int mi_ucl_rowsums_bwd(const float* feat, const uint8_t* cls, int n2, int dim, float inv_T, const float* rowmax,
+                       const float* g_all, const float* g_pos, const float* g_other, const float* g_pair,
+                       float* dfeat, mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY - see oracle/__init__.py) for the detector-training losses, SURVEY.md §8 row a23.
+
+Plain torch restatement of the reference's cet_pick/models/loss.py: `_neg_loss` :378-411, `_pu_neg_loss` :255-308,
+`ConsistencyLoss` :701-712, `UnbiasedConLoss.forward` :594-699 (dense (2N)^2 matrix, fine at test sizes).
+Pinned by tests/golden/losses.npz, produced by the reference's own functions (tests/golden/gen_golden.py: gen_losses).
+"""
+import numpy as np
+import torch
+
+
+def neg_loss(pred, gt):
+    gt = gt.unsqueeze(0)
+    pos = gt.eq(1).float()
+    soft = ((gt.gt(-1).float()) == (gt.lt(1).float())).float()
+    pos_loss = (torch.log(pred) * torch.pow(1 - pred, 2) * pos).sum()
+    neg_loss_ = (torch.log(1 - pred) * torch.pow(pred, 2) * torch.pow(1 - gt, 4) * soft).sum()
+    n = pos.sum()
+    return -neg_loss_ if n == 0 else -(pos_loss + neg_loss_) / n
+
+
+def pu_neg_loss(pred, gt, tau, beta=0.0):
+    pred, gt = pred.squeeze(), gt.squeeze()
+    pos = gt.eq(1).float()
+    soft = ((gt.gt(-1).float()) == (gt.lt(1).float())).float()
+    unl = gt.eq(-1).float()
+    n_pos, n_soft, n_unl = pos.sum(), soft.sum(), unl.sum()
+    if n_pos == 0:
+        raise ValueError("no positives")
+    a = torch.log(pred) * torch.pow(1 - pred, 2)
+    b = torch.log(1 - pred) * torch.pow(pred, 2)
+    pos_tot = -(a * pos).sum() / n_pos
+    negpos_tot = -(b * pos).sum() / n_pos
+    if n_soft > 0:
+        pos_tot = pos_tot - (b * torch.pow(1 - gt, 4) * soft).sum() / n_soft
+        negpos_tot = negpos_tot - (a * torch.pow(gt, 4) * soft).sum() / n_soft
+    pos_risk = pos_tot * tau
+    neg_total = -tau * negpos_tot + (-(b * unl).sum()) / n_unl
+    return pos_risk if neg_total < -beta else pos_risk + neg_total
+
+
+def mse(a, b):
+    return ((a - b) ** 2).mean()
+
+
+def unbiased_con_loss(labels, out_labels, out_labels_cr, f, f_cr, T, tau_plus, thresh):
+    n = f.shape[0]
+    pos1 = labels.gt(thresh) if thresh < 1 else labels.eq(1)
+    n_pos1 = pos1.float().sum()
+    n_neg = 2 * (n - n_pos1)
+    self_mask = torch.zeros(2 * n, 2 * n)
+    self_mask[:n, n:] = torch.eye(n)
+    self_mask[n:, :n] = torch.eye(n)
+    tot = torch.cat([f, f_cr], 0)
+    sims = tot @ tot.t() / T
+    sims = sims - sims.max(dim=1, keepdim=True)[0].detach()
+    sims = torch.exp(sims * (1 - torch.eye(2 * n)))
+    all_labels = torch.cat([labels, labels], 0)
+    preds = torch.cat([out_labels, out_labels_cr], 0)
+    pos = all_labels.gt(thresh) if thresh < 1 else all_labels.eq(1)
+    un = all_labels.lt(0)
+    other = all_labels.lt(thresh).float()
+
+    def calc_g(p, q, c):
+        return torch.clamp((q - c * p) / (1 - c), min=np.e ** (-1 / T))
+
+    pf = sims[pos]
+    pos_mean = (pf * pos.float()).sum(1) / (pos.float().sum() - 1)
+    rem_mean = (pf * other).sum(1) / other.sum()
+    sup = (-torch.log(pos_mean / (pos_mean + calc_g(pos_mean, rem_mean, tau_plus)))).mean()
+    uf, um = sims[un], self_mask[un]
+    up = (uf * um).sum(1)
+    urem = (uf * (1 - um)).sum(1) / n_neg
+    gp, gn = calc_g(up, urem, tau_plus), calc_g(up, urem, 1 - tau_plus)
+    pr = preds[un]
+    lpos = -torch.log(up / (up + gp)) * pr
+    lneg = -torch.log(up / (up + gn)) * (1 - pr)
+    unsup = torch.zeros(())
+    hi, lo = pr.gt(0.99), pr.lt(0.01)
+    mid = pr.gt(0.01) & pr.lt(0.99)
+    if hi.any():
+        unsup = unsup + lpos[hi].mean()
+    if lo.any():
+        unsup = unsup + lneg[lo].mean()
+    if mid.any():
+        unsup = unsup + lpos[mid].mean() + lneg[mid].mean()
+    return sup, unsup
+
+
+def tomo_cr_semi_loss(hm_logits, hm_logits_cr, proj, proj_cr, gt, flip_prob, tau, temp, thresh, cr_weight):
+    """trains/tomo_cr_semi_trainer.py:43-112, train phase with --contrastive (restated: that module does not import
+    here - `progress`, `cv2`, `sknetwork` are absent)."""
+    sig = lambda x: torch.clamp(torch.sigmoid(x), min=1e-4, max=1 - 1e-4)
+    hm, hm_cr = sig(hm_logits), sig(hm_logits_cr)
+    hm_loss = pu_neg_loss(hm, gt, tau)
+    b, ch = proj.shape[:2]
+    fd = -2 if flip_prob > 0.5 else -1
+    pc, hc = proj_cr.flip(fd), hm_cr.flip(fd)
+    f = proj.reshape(b, ch, -1).permute(1, 0, 2).reshape(ch, -1).T
+    fc = pc.reshape(b, ch, -1).permute(1, 0, 2).reshape(ch, -1).T
+    sup, unsup = unbiased_con_loss(gt.reshape(-1), hm.reshape(-1), hc.reshape(-1), f, fc, temp, tau, thresh)
+    cr = sup + 0.1 * unsup
+    cons = mse(hm.reshape(-1), hc.reshape(-1))
+    return hm_loss + cr * cr_weight + cons, hm_loss, cr, cons

@@ -59,7 +59,7 @@ from cet_pick.models.networks import moco_encoder_3d as R_enc3d  # noqa: E402
 from cet_pick.models import moco as R_moco                # noqa: E402
 from cet_pick.utils import utils as R_utils               # noqa: E402
 
-from cet_pick_amd.synthetic import make_tomo, make_logits, seeded_state_dict  # noqa: E402
+from cet_pick_amd.synthetic import make_tomo, make_logits, seeded_state_dict, losses_inputs  # noqa: E402
 
 
 def gen_loader():
@@ -123,6 +123,35 @@ def gen_unet():
     keys = json.load(open(path))
     keys["unet_4"] = {k: list(v.shape) for k, v in net.state_dict().items()}
     json.dump(keys, open(path, "w"), indent=0)
+
+
+def gen_losses():
+    """a23: _neg_loss, _pu_neg_loss, ConsistencyLoss, UnbiasedConLoss of cet_pick/models/loss.py with gradients."""
+    from types import SimpleNamespace
+    from cet_pick.models import loss as RL
+    pred, gt, f, f_cr, lab, o1, o2 = losses_inputs()
+    out = {}
+    p = pred.clone().requires_grad_()
+    l = RL._neg_loss(p, gt); l.backward()
+    out["focal"], out["focal_grad"] = l.detach().numpy(), p.grad.numpy().copy()
+    from cet_pick_amd.synthetic import confident_pred
+    for tag, pr, tau in (("pu_0.05", pred, 0.05), ("pu_conf_0.6", confident_pred(gt), 0.6)):
+        p = pr.clone().requires_grad_()
+        l = RL._pu_neg_loss(p, gt, tau, 0, 1); l.backward()
+        out[tag], out[tag + "_grad"] = l.detach().numpy(), p.grad.numpy().copy()
+    a = o1.clone().requires_grad_()
+    l = RL.ConsistencyLoss()(a, o2); l.backward()
+    out["mse"], out["mse_grad"] = l.detach().numpy(), a.grad.numpy().copy()
+    for thresh in (1.0, 0.4):
+        opt = SimpleNamespace(thresh=thresh, device=torch.device("cpu"))
+        fa, fb = f.clone().requires_grad_(), f_cr.clone().requires_grad_()
+        pa, pb = o1.clone().requires_grad_(), o2.clone().requires_grad_()
+        sup, unsup = RL.UnbiasedConLoss(0.07, 0.03)(lab, pa, pb, fa, fb, opt)
+        (sup + 0.1 * unsup).backward()
+        out[f"ucl_sup_{thresh}"], out[f"ucl_unsup_{thresh}"] = sup.detach().numpy(), unsup.detach().numpy()
+        out[f"ucl_gf_{thresh}"], out[f"ucl_gfcr_{thresh}"] = fa.grad.numpy().copy(), fb.grad.numpy().copy()
+        out[f"ucl_gp_{thresh}"], out[f"ucl_gpcr_{thresh}"] = pa.grad.numpy().copy(), pb.grad.numpy().copy()
+    save("losses.npz", **out)
 
 
 def save(name, **arrs):
@@ -350,6 +379,6 @@ def gen_lr():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader", "unet"]
+    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader", "unet", "losses"]
     for w in which:
         globals()["gen_" + w]()
