@@ -33,6 +33,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+// conv_stem.hip: direct kernels for the 7^3 stride-2 stem; MI_E_UNSUPPORTED = shape declined, take the generic path
+int mi_stem7_fwd(const float* x, const float* w, float* y, const float* res, int relu, int N, int D, int H, int W,
+                 int Co, hipStream_t s);
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -733,8 +737,19 @@ int setup_conv(int mode, const Geom& g, Setup* st) {
     return MI_OK;
 }
 
+bool is_stem7(const Geom& g) {
+    return g.Ci == 1 && g.kd == 7 && g.kh == 7 && g.kw == 7 && g.stride == 2 && g.pd == 3 && g.ph == 3 && g.pw == 3 &&
+           g.dd == 1 && g.dh == 1 && g.dw == 1;
+}
+
 int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, float* out,
              const float* res, const float* mask, int relu, void* ws, size_t ws_bytes, hipStream_t s) {
+    // the 7^3 stride-2 stem has its own direct kernels (conv_stem.hip); anything they decline runs below
+    if (is_stem7(g) && !env_int("MI_CONV_NO_STEM")) {
+        int rc = MI_E_UNSUPPORTED;
+        if (mode == MODE_FWD) rc = mi_stem7_fwd(a_src, b_src, out, res, relu, g.N, g.Di, g.Hi, g.Wi, g.Co, s);
+        if (rc != MI_E_UNSUPPORTED) return rc;
+    }
     Setup st;
     int rc = setup_conv(mode, g, &st);
     if (rc) return rc;

@@ -1,0 +1,176 @@
+// The 7x7x7 stride-2 stem convolution (Cin = 1 -> 64 channels, models/networks/moco_encoder_3d.py:163-169) as a
+// DIRECT convolution on the matrix cores.  With one input channel the implicit GEMM's A operand is just the image:
+// a workgroup stages the input patch of its output tile in LDS once and every MFMA A-fragment is ONE ds_read_b32
+// of that patch at (lane base + compile-time offset) - no im2col gather, no address arithmetic, no LDS stores of
+// A in the reduction loop.  The generic kernel (conv_igemm.hip, STEM path) spends its time on 8 scalar gathers +
+// tap-LUT reads per thread and slice; this one issues 3 LDS reads per 2 MFMAs and nothing else.
+//
+// FWD  tile = 8(x) x 4(y) x 4(z) output voxels x 64 channels, 4 waves = 4 z-planes, 2 accumulators per wave.
+//      patch = 13 x 13 x 21 input voxels (rows padded to 24 floats: the 32 lanes of a half-wave then hit 32
+//      distinct banks).  The weights stream through LDS one kz-slab (49 taps padded to 50 x 64) at a time,
+//      double-buffered, one barrier per slab.  Reduction index inside a slab: k = ky*7 + kx, the lane half h owns
+//      k = 2t + h, whose patch offset differs from that of 2t by 1 (same row) or by PW - 6 (row wrap) - two lane
+//      base registers cover both cases, the rest is an immediate.
+#include "common.h"
+#include "../../include/cetpick_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int K7 = 7, S2 = 2, P3 = 3;
+constexpr int TX = 8, TY = 4, TZ = 4;                    // output tile
+constexpr int PX = S2 * (TX - 1) + K7;                   // 21
+constexpr int PY = S2 * (TY - 1) + K7;                   // 13
+constexpr int PZ = S2 * (TZ - 1) + K7;                   // 13
+constexpr int PW = 24;                                   // padded patch row
+constexpr int PATCH = PZ * PY * PW;                      // 4056 floats
+constexpr int KS = 50;                                   // taps per kz slab (49 + 1 zero row)
+constexpr int WS = 64;                                   // weight row stride in LDS; odd rows are rotated by 32 columns so
+                                                         // the two half-waves (k even / odd) hit disjoint banks
+constexpr int WROWS = 64;                                // rows per LDS slab (4 float4 per thread, stored unconditionally)
+constexpr int CO = 64;
+
+struct StemParams {
+    const float* x;      // (N, D, H, W) image
+    const float* w;      // [343][64]
+    float* y;            // (N, Do, Ho, Wo, 64)
+    const float* res;    // may be null
+    int relu;
+    int N, D, H, W, Do, Ho, Wo;
+    unsigned x_bytes;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+
+__global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
+    constexpr int NP = (PATCH + PW + 255) / 256;         // 16 patch elements per thread
+    __shared__ __attribute__((aligned(16))) float patch[NP * 256];   // PATCH + one zeroed row (pad tap of the last slab)
+    __shared__ __attribute__((aligned(16))) float wl[2][WROWS * WS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    // tile coordinates
+    const int txn = p.Wo / TX, tyn = p.Ho / TY, tzn = p.Do / TZ;
+    int b = blockIdx.x;
+    const int bx = b % txn; b /= txn;
+    const int by = b % tyn; b /= tyn;
+    const int bz = b % tzn;
+    const int n = b / tzn;
+    const int ox0 = bx * TX, oy0 = by * TY, oz0 = bz * TZ;
+
+    // ---- input patch: all loads in flight before the first LDS store (zero padding = buffer range check) ----
+    {
+        const __amdgpu_buffer_rsrc_t xr = rsrc(p.x, p.x_bytes);
+        const int iz0 = oz0 * S2 - P3, iy0 = oy0 * S2 - P3, ix0 = ox0 * S2 - P3;
+        float pv[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int i = tid + u * 256;
+            const int px = i % PW, t = i / PW, py = t % PY, pz = t / PY;
+            const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+            const bool ok = (px < PX) & (pz < PZ) & ((unsigned)iz < (unsigned)p.D) & ((unsigned)iy < (unsigned)p.H) &
+                            ((unsigned)ix < (unsigned)p.W);
+            const unsigned off = ok ? 4u * (unsigned)((((long)n * p.D + iz) * p.H + iy) * p.W + ix) : 0x80000000u;
+            pv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) patch[tid + u * 256] = pv[u];
+    }
+    // ---- weight slabs: thread tid moves float4 #tid, #tid+256, ... of the slab (rows >= 49 read as zeros) ----
+    constexpr int WLD = WROWS * (CO / 4) / 256;          // 4 float4 per thread
+    const __amdgpu_buffer_rsrc_t wr = rsrc(p.w, (unsigned)(sizeof(float) * K7 * K7 * K7 * CO));
+    float4 wreg[WLD];
+    auto wload = [&](int kz) {
+#pragma unroll
+        for (int i = 0; i < WLD; ++i) {
+            const int q = tid + i * 256;
+            const int row = q / (CO / 4);
+            const unsigned off = (row < K7 * K7 && kz < K7)
+                ? 4u * (unsigned)((kz * K7 * K7 + row) * CO + (q % (CO / 4)) * 4) : 0x80000000u;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)off, 0, 0);
+            wreg[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+    };
+    auto wstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WLD; ++i) {
+            const int q = tid + i * 256;
+            const int row = q / (CO / 4), c = (q % (CO / 4)) * 4;
+            *reinterpret_cast<float4*>(&wl[buf][row * WS + ((c + 32 * (row & 1)) & 63)]) = wreg[i];
+        }
+    };
+    wload(0);
+    wstore(0);
+    wload(1);
+
+    // lane bases into the patch: output (ox, oy) = (l32 & 7, l32 >> 3) of z-plane `wave`
+    const int pb = ((S2 * wave) * PY + S2 * (l32 >> 3)) * PW + S2 * (l32 & 7);
+    const float* bA = patch + pb + h;                    // k and k+1 in the same patch row
+    const float* bB = patch + pb + h * (PW - (K7 - 1));  // k = (ky, 6): k+1 wraps to (ky+1, 0)
+    // B fragments: row k = 2t + h; odd rows are stored rotated by 32 columns
+    const int wl0 = h ? WS + 32 + l32 : l32;              // columns  0..31
+    const int wl1 = h ? WS + l32 : 32 + l32;              // columns 32..63
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    __syncthreads();
+    for (int kz = 0; kz < K7; ++kz) {
+        const float* wb0 = wl[kz & 1] + wl0;
+        const float* wb1 = wl[kz & 1] + wl1;
+        const float* a0 = bA + kz * (PY * PW);
+        const float* a1 = bB + kz * (PY * PW);
+#pragma unroll
+        for (int t = 0; t < KS / 2; ++t) {
+            const int k0 = 2 * t, ky = k0 / K7, kx = k0 % K7;
+            const float a = (kx == K7 - 1 ? a1 : a0)[ky * PW + kx];
+            const float b0 = wb0[k0 * WS], b1 = wb1[k0 * WS];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+        }
+        // slab kz+1 (in registers since the previous iteration) -> the other buffer; then fetch slab kz+2
+        wstore((kz + 1) & 1);
+        wload(kz + 2);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane & 31 (channel), row = (r&3) + 8*(r>>2) + 4*h (output voxel) ----
+    const int oz = oz0 + wave;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = j * 32 + l32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ox = ox0 + (m & 7), oy = oy0 + (m >> 3);
+            const long o = ((((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * CO + co;
+            float v = j == 0 ? acc0[r] : acc1[r];
+            if (p.res) v += p.res[o];
+            if (p.relu) v = fmaxf(v, 0.f);
+            p.y[o] = v;
+        }
+    }
+}
+
+}  // namespace
+
+// Called by conv_igemm.hip's dispatcher.  Returns MI_E_UNSUPPORTED when the shape is not the stem this kernel is
+// specialised for (the caller then takes the generic path).
+int mi_stem7_fwd(const float* x, const float* w, float* y, const float* res, int relu, int N, int D, int H, int W,
+                 int Co, hipStream_t s) {
+    if (Co != CO) return MI_E_UNSUPPORTED;
+    const int Do = (D + 2 * P3 - K7) / S2 + 1, Ho = (H + 2 * P3 - K7) / S2 + 1, Wo = (W + 2 * P3 - K7) / S2 + 1;
+    if (Do <= 0 || Ho <= 0 || Wo <= 0 || Do % TZ || Ho % TY || Wo % TX) return MI_E_UNSUPPORTED;
+    const long xb = 4l * N * D * H * W;
+    if (xb >= 0x7fff0000l) return MI_E_UNSUPPORTED;
+    const long blocks = (long)N * (Do / TZ) * (Ho / TY) * (Wo / TX);
+    if (blocks > 0x7fffffffl) return MI_E_UNSUPPORTED;
+    StemParams p = {x, w, y, res, relu, N, D, H, W, Do, Ho, Wo, (unsigned)xb};
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
