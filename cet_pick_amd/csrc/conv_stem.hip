@@ -156,6 +156,158 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// WGRAD: dW[tap][co] = sum over output voxels of patch(voxel, tap) * dy[voxel][co].  GEMM rows = taps (343 -> 11
+// tiles of 32), columns = 64 channels, reduction = voxels.  A workgroup walks `tiles_per_block` output tiles
+// (8 x 4 x 4 voxels each): the tile's input patch and its dy rows go to LDS, the A fragment of (tap, voxel) is
+// patch[off(tap) + base(voxel)] = lane register + immediate, again one ds_read_b32.  Wave w owns tap tiles
+// w, w+4, w+8 (x 2 column tiles = 6 accumulators), so every A / B fragment read feeds 2 / 3 MFMAs.  The next
+// tile's global loads are in flight while the current one is contracted.  Each workgroup writes its partial dW as
+// a slab; a second kernel sums the slabs in slab order (deterministic).
+constexpr int NTAP = K7 * K7 * K7;                       // 343
+constexpr int TAPT = (NTAP + 31) / 32;                   // 11 tap tiles
+constexpr int VOX = TX * TY * TZ;                        // 128 voxels per tile
+
+struct StemWgradParams {
+    const float* x;      // (N, D, H, W)
+    const float* dy;     // (N, Do, Ho, Wo, 64)
+    float* slabs;        // [gridDim.x][352][64]
+    int N, D, H, W, Do, Ho, Wo;
+    int n_tiles, tiles_per_block;
+    unsigned x_bytes, dy_bytes;
+};
+
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradParams p) {
+    constexpr int NP = (PATCH + PW + 255) / 256;         // 16
+    constexpr int ND = VOX * (CO / 4) / 256;             // 8 float4 of dy per thread
+    __shared__ __attribute__((aligned(16))) float patch[NP * 256];
+    __shared__ __attribute__((aligned(16))) float dyl[VOX * CO];      // [voxel][64], odd voxels rotated by 32 columns
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    const __amdgpu_buffer_rsrc_t xr = rsrc(p.x, p.x_bytes), dr = rsrc(p.dy, p.dy_bytes);
+    const int txn = p.Wo / TX, tyn = p.Ho / TY, tzn = p.Do / TZ;
+
+    float pv[NP];
+    float4 dv[ND];
+    auto gload = [&](int tile) {                          // tile >= n_tiles: everything reads as zero
+        int b = tile;
+        const bool live = tile < p.n_tiles;
+        const int bx = b % txn; b /= txn;
+        const int by = b % tyn; b /= tyn;
+        const int bz = b % tzn;
+        const int n = b / tzn;
+        const int ox0 = bx * TX, oy0 = by * TY, oz0 = bz * TZ;
+        const int iz0 = oz0 * S2 - P3, iy0 = oy0 * S2 - P3, ix0 = ox0 * S2 - P3;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int i = tid + u * 256;
+            const int px = i % PW, t = i / PW, py = t % PY, pz = t / PY;
+            const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+            const bool ok = live & (px < PX) & (pz < PZ) & ((unsigned)iz < (unsigned)p.D) &
+                            ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            const unsigned off = ok ? 4u * (unsigned)((((long)n * p.D + iz) * p.H + iy) * p.W + ix) : 0x80000000u;
+            pv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int q = tid + u * 256;
+            const int v = q / (CO / 4), c = (q % (CO / 4)) * 4;
+            const int ox = ox0 + (v & 7), oy = oy0 + ((v >> 3) & 3), oz = oz0 + (v >> 5);
+            const unsigned off = live ? 4u * (unsigned)(((((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * CO + c)
+                                      : 0x80000000u;
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(dr, (int)off, 0, 0);
+            dv[u] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) patch[tid + u * 256] = pv[u];
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int q = tid + u * 256;
+            const int v = q / (CO / 4), c = (q % (CO / 4)) * 4;
+            *reinterpret_cast<float4*>(&dyl[v * CO + ((c + 32 * (v & 1)) & 63)]) = dv[u];
+        }
+    };
+
+    // lane constants: tap offsets of this wave's tap tiles (+ 2h: voxel 2t+h sits 2 floats further along x)
+    constexpr int MYT = 3;
+    int aoff[MYT];
+    bool avalid[MYT];
+#pragma unroll
+    for (int i = 0; i < MYT; ++i) {
+        const int tt = wave + 4 * i;
+        const int tap = tt * 32 + l32;
+        avalid[i] = (tt < TAPT) && (tap < NTAP);
+        const int tc = avalid[i] ? tap : 0;
+        const int kz = tc / (K7 * K7), ky = (tc / K7) % K7, kx = tc % K7;
+        aoff[i] = (kz * PY + ky) * PW + kx + S2 * h;
+    }
+    const int bl0 = h ? CO + 32 + l32 : l32;              // dy columns  0..31 of voxel 2t + h
+    const int bl1 = h ? CO + l32 : 32 + l32;              // dy columns 32..63
+
+    f32x16 acc[MYT][2];
+#pragma unroll
+    for (int i = 0; i < MYT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int tile0 = blockIdx.x * p.tiles_per_block;
+    gload(tile0);
+    for (int it = 0; it < p.tiles_per_block; ++it) {
+        __syncthreads();                                  // every wave is done with the previous tile's LDS
+        lstore();
+        __syncthreads();
+        gload(tile0 + it + 1 < tile0 + p.tiles_per_block ? tile0 + it + 1 : p.n_tiles);   // prefetch (zeros past the end)
+#pragma unroll
+        for (int t = 0; t < VOX / 2; ++t) {
+            const int v0 = 2 * t;
+            const int imm = ((S2 * (v0 >> 5)) * PY + S2 * ((v0 >> 3) & 3)) * PW + S2 * (v0 & 7);
+            const float b0 = dyl[v0 * CO + bl0], b1 = dyl[v0 * CO + bl1];
+#pragma unroll
+            for (int i = 0; i < MYT; ++i) {
+                float a = patch[aoff[i] + imm];
+                // third tap tile: tile 10 holds taps 320..351 (343.. are padding), wave 3's would be tile 11
+                // (all padding - kept as a zero contribution so that the loop has no wave-dependent branch)
+                if (i == MYT - 1) a = avalid[i] ? a : 0.f;
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[i][1], 0, 0, 0);
+            }
+        }
+    }
+    // ---- slab: rows = taps (C/D layout row = (r&3) + 8*(r>>2) + 4*h), cols = channels ----
+    float* slab = p.slabs + (long)blockIdx.x * (TAPT * 32) * CO;
+#pragma unroll
+    for (int i = 0; i < MYT; ++i) {
+        const int tt = wave + 4 * i;
+        if (tt >= TAPT) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tap = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[(long)tap * CO + j * 32 + l32] = acc[i][j][r];
+            }
+    }
+}
+
+// out[g] = sum of slabs [g*group, (g+1)*group) (slab order); two levels keep every pass wide:
+// level 1: grid (22, G) over the workgroup slabs -> G partial slabs, level 2: grid (22, 1) over those -> dW
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* slabs, int n_slabs, int group, float* out,
+                                                               long out_stride) {
+    const int i = blockIdx.x * 256 + threadIdx.x;         // float4 index into [343][64]
+    if (i >= NTAP * CO / 4) return;
+    const int z0 = blockIdx.y * group, z1 = min(z0 + group, n_slabs);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = z0; z < z1; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(slabs + (long)z * (TAPT * 32) * CO + 4 * i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (long)blockIdx.y * out_stride + 4 * i) = s;
+}
+
 }  // namespace
 
 // Called by conv_igemm.hip's dispatcher.  Returns MI_E_UNSUPPORTED when the shape is not the stem this kernel is
@@ -171,6 +323,49 @@ int mi_stem7_fwd(const float* x, const float* w, float* y, const float* res, int
     if (blocks > 0x7fffffffl) return MI_E_UNSUPPORTED;
     StemParams p = {x, w, y, res, relu, N, D, H, W, Do, Ho, Wo, (unsigned)xb};
     hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+constexpr int RED_GROUPS = 32;          // partial slabs of the two-level reduction
+
+static int stem7_wgrad_blocks(long tiles) {
+    // 2 workgroups per CU; each walks >= 1 tile
+    long b = tiles < 512 ? tiles : 512;
+    return (int)b;
+}
+
+size_t mi_stem7_wgrad_workspace_bytes(int N, int D, int H, int W, int Co) {
+    if (Co != CO) return 0;
+    const int Do = (D + 2 * P3 - K7) / S2 + 1, Ho = (H + 2 * P3 - K7) / S2 + 1, Wo = (W + 2 * P3 - K7) / S2 + 1;
+    if (Do <= 0 || Ho <= 0 || Wo <= 0 || Do % TZ || Ho % TY || Wo % TX) return 0;
+    const long tiles = (long)N * (Do / TZ) * (Ho / TY) * (Wo / TX);
+    return sizeof(float) * (size_t)(stem7_wgrad_blocks(tiles) + RED_GROUPS) * (TAPT * 32) * CO;
+}
+
+int mi_stem7_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Co, void* ws,
+                   size_t ws_bytes, hipStream_t s) {
+    if (Co != CO) return MI_E_UNSUPPORTED;
+    const int Do = (D + 2 * P3 - K7) / S2 + 1, Ho = (H + 2 * P3 - K7) / S2 + 1, Wo = (W + 2 * P3 - K7) / S2 + 1;
+    if (Do <= 0 || Ho <= 0 || Wo <= 0 || Do % TZ || Ho % TY || Wo % TX) return MI_E_UNSUPPORTED;
+    const long xb = 4l * N * D * H * W, yb = 4l * N * Do * Ho * Wo * CO;
+    if (xb >= 0x7fff0000l || yb >= 0x7fff0000l) return MI_E_UNSUPPORTED;
+    const long tiles = (long)N * (Do / TZ) * (Ho / TY) * (Wo / TX);
+    if (tiles > 0x3fffffffl) return MI_E_UNSUPPORTED;
+    const int blocks = stem7_wgrad_blocks(tiles);
+    if (!ws || ws_bytes < mi_stem7_wgrad_workspace_bytes(N, D, H, W, Co)) return MI_E_UNSUPPORTED;   // generic path
+    StemWgradParams p = {x, dy, (float*)ws, N, D, H, W, Do, Ho, Wo, (int)tiles, (int)((tiles + blocks - 1) / blocks),
+                         (unsigned)xb, (unsigned)yb};
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(blocks), dim3(256), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    const int rb = (NTAP * CO / 4 + 255) / 256;
+    const long slab = (long)(TAPT * 32) * CO;
+    float* part = (float*)ws + (long)blocks * slab;
+    const int group = (blocks + RED_GROUPS - 1) / RED_GROUPS, groups = (blocks + group - 1) / group;
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(rb, groups), dim3(256), 0, s, (const float*)ws, blocks, group, part,
+                       slab);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(rb, 1), dim3(256), 0, s, (const float*)part, groups, groups, dw, 0l);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
