@@ -54,6 +54,8 @@ SIGNATURES = {
     "mi_concat_channels": (_I, [_P, _I, _P, _I, _P, _L, _P]),
     "mi_split_channels": (_I, [_P, _P, _I, _P, _I, _L, _P]),
     "mi_zhead_fwd": (_I, [_P, _P, _P, _I, _I, _L, _I, _I, _P]),
+    "mi_zhead_bwd_workspace_bytes": (_Z, [_I, _I, _L, _I, _I]),
+    "mi_zhead_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _P, _Z, _P]),
     "mi_voxel_loss_workspace_bytes": (_Z, [_L]),
     "mi_pu_focal_loss_fwd": (_I, [_P, _P, _L, _D, _D, _P, _P, _P, _Z, _P]),
     "mi_pu_focal_loss_bwd": (_I, [_P, _P, _L, _D, _P, _P, _P, _P]),

@@ -161,6 +161,88 @@ __global__ __launch_bounds__(256) void zhead_kernel(const float* x, const float*
     }
 }
 
+// backward of the (3,1,1) head: dx[n][z][p][c] = sum_{dz, k} dy[n][z - dz + 1][p][k] * w[dz][c][k]
+template <int K>
+__global__ __launch_bounds__(256) void zhead_bwd_data_kernel(const float* dy, const float* w, float* dx, int N, int D,
+                                                            long P, int C) {
+    extern __shared__ float ws[];                      // [3][C][K]
+    for (int i = threadIdx.x; i < 3 * C * K; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int CV = C >> 2;
+    const long total = (long)N * D * P * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        const long v = i / CV;                         // voxel (n, z, p)
+        const int z = (int)((v / P) % D);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int dz = 0; dz < 3; ++dz) {
+            const int zo = z - dz + 1;
+            if ((unsigned)zo >= (unsigned)D) continue;
+            const float* dyr = dy + (v + (long)(1 - dz) * P) * K;
+            const float* wr = ws + (dz * C + 4 * cv) * K;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float g = dyr[k];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(g, wr[q * K + k], acc[q]);
+            }
+        }
+        st4(dx + 4 * i, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    }
+}
+
+// dw[dz][c][k] = sum over voxels of x[n][z + dz - 1][p][c] * dy[n][z][p][k]: thread (c, row group) accumulates
+// 3*K partial sums over its voxels; fixed-shape block tree, fp64 partials, deterministic finalize
+template <int K>
+__global__ __launch_bounds__(256) void zhead_bwd_weight_kernel(const float* x, const float* dy, int N, int D, long P,
+                                                              int C, double* partials) {
+    const int RG = 256 / C;                            // C in {16, 32, 64, 128, 256}
+    const int c = threadIdx.x % C, rg = threadIdx.x / C;
+    const long total = (long)N * D * P;
+    float acc[3][K];
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[dz][k] = 0.f;
+    for (long v = (long)blockIdx.x * RG + rg; v < total; v += (long)gridDim.x * RG) {
+        const int z = (int)((v / P) % D);
+        float g[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) g[k] = dy[v * K + k];
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+            const int zz = z + dz - 1;
+            if ((unsigned)zz >= (unsigned)D) continue;
+            const float xv = x[(v + (long)(dz - 1) * P) * C + c];
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[dz][k] = fmaf(xv, g[k], acc[dz][k]);
+        }
+    }
+    __shared__ double red[256];
+    for (int dz = 0; dz < 3; ++dz)
+        for (int k = 0; k < K; ++k) {
+            red[threadIdx.x] = (double)acc[dz][k];
+            __syncthreads();
+            if (rg == 0) {
+                double s = 0;
+                for (int r = 0; r < RG; ++r) s += red[r * C + c];
+                partials[((long)blockIdx.x * 3 + dz) * C * K + c * K + k] = s;
+            }
+            __syncthreads();
+        }
+}
+__global__ __launch_bounds__(256) void zhead_bwd_weight_final_kernel(const double* partials, int n_part, int n_out,
+                                                                    float* dw) {
+    const int o = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    double s = 0;
+    if (o < n_out)
+        for (int b = l; b < n_part; b += 32) s += partials[(long)b * n_out + o];
+#pragma unroll
+    for (int q = 16; q > 0; q >>= 1) s += __shfl_xor(s, q, 32);
+    if (l == 0 && o < n_out) dw[o] = (float)s;
+}
+int zhead_w_blocks(long voxels, int C) { return (int)std::max<long>(1, std::min<long>(voxels / ((256 / C) * 64) + 1, 1024)); }
+
 }  // namespace
 
 extern "C" int mi_maxpool2d_ceil_fwd(const float* x, float* y, uint8_t* argmax, int N, int Hi, int Wi, int C, int k,
@@ -234,5 +316,47 @@ extern "C" int mi_zhead_fwd(const float* x, const float* w, float* y, int N, int
         default: hipLaunchKernelGGL((zhead_kernel<4>), grid, block, lds, s, x, w, y, N, D, P, C); break;
     }
     MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" size_t mi_zhead_bwd_workspace_bytes(int N, int D, long P, int C, int K) {
+    if (N <= 0 || D <= 0 || P <= 0 || C <= 0 || 256 % C || K < 1 || K > 4) return 0;
+    return sizeof(double) * 3 * (size_t)C * K * zhead_w_blocks((long)N * D * P, C);
+}
+
+/* backward of mi_zhead_fwd: dx (may be NULL) and dw [3][C][K] (may be NULL) */
+extern "C" int mi_zhead_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int N, int D, long P,
+                            int C, int K, void* ws, size_t ws_bytes, mi_stream_t stream) {
+    if (!x || !w || !dy || N <= 0 || D <= 0 || P <= 0 || C <= 0 || C % 4 || 256 % C || K < 1 || K > 4) return MI_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long vox = (long)N * D * P;
+    if (dx) {
+        const size_t lds = sizeof(float) * 3 * (size_t)C * K;
+        if (lds > 48 * 1024) return MI_E_UNSUPPORTED;
+        const dim3 grid(ew_blocks(vox * (C / 4))), block(256);
+        switch (K) {
+            case 1: hipLaunchKernelGGL((zhead_bwd_data_kernel<1>), grid, block, lds, s, dy, w, dx, N, D, P, C); break;
+            case 2: hipLaunchKernelGGL((zhead_bwd_data_kernel<2>), grid, block, lds, s, dy, w, dx, N, D, P, C); break;
+            case 3: hipLaunchKernelGGL((zhead_bwd_data_kernel<3>), grid, block, lds, s, dy, w, dx, N, D, P, C); break;
+            default: hipLaunchKernelGGL((zhead_bwd_data_kernel<4>), grid, block, lds, s, dy, w, dx, N, D, P, C); break;
+        }
+        MI_RETURN_IF_LAUNCH_FAILED();
+    }
+    if (dw) {
+        if (!ws || ws_bytes < mi_zhead_bwd_workspace_bytes(N, D, P, C, K)) return MI_E_WORKSPACE;
+        const int blocks = zhead_w_blocks(vox, C);
+        double* part = (double*)ws;
+        switch (K) {
+            case 1: hipLaunchKernelGGL((zhead_bwd_weight_kernel<1>), dim3(blocks), dim3(256), 0, s, x, dy, N, D, P, C, part); break;
+            case 2: hipLaunchKernelGGL((zhead_bwd_weight_kernel<2>), dim3(blocks), dim3(256), 0, s, x, dy, N, D, P, C, part); break;
+            case 3: hipLaunchKernelGGL((zhead_bwd_weight_kernel<3>), dim3(blocks), dim3(256), 0, s, x, dy, N, D, P, C, part); break;
+            default: hipLaunchKernelGGL((zhead_bwd_weight_kernel<4>), dim3(blocks), dim3(256), 0, s, x, dy, N, D, P, C, part); break;
+        }
+        MI_RETURN_IF_LAUNCH_FAILED();
+        const int n_out = 3 * C * K;
+        hipLaunchKernelGGL(zhead_bwd_weight_final_kernel, dim3((n_out + 7) / 8), dim3(256), 0, s, (const double*)part,
+                           blocks, n_out, dw);
+        MI_RETURN_IF_LAUNCH_FAILED();
+    }
     return MI_OK;
 }

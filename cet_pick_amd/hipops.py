@@ -191,7 +191,7 @@ def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None):
     return y
 
 
-def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None):
+def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None, dil=None):
     _f32c(dy, "dy")
     nd5 = len(in_shape) == 5
     k3, p3 = _k3(k, nd5), _p3(pad, nd5)
@@ -200,26 +200,43 @@ def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None):
     co = w.shape[0]
     dx = torch.empty(tuple(in_shape), dtype=torch.float32, device=dy.device)
     lib = L.lib()
+    flops = 2.0 * dy.numel() * ci * k3[0] * k3[1] * k3[2]
+    if dil is not None and tuple(_k3(dil, nd5)) != (1, 1, 1):
+        d3 = _k3(dil, nd5)
+        ws = _ws(lib.mi_convnd_dil_workspace_bytes(n, d, h, wd, ci, co, *k3, *p3, *d3), dy.device, "conv")
+        with _Prof("dgrad", flops):
+            L.check(lib.mi_convnd_dil_dgrad_f32(L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(res), L.ptr(mask), n, d, h, wd, ci,
+                                                co, *k3, *p3, *d3, L.ptr(ws), ws.numel(), L.stream()),
+                    "mi_convnd_dil_dgrad_f32")
+        return dx
     ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), dy.device, "conv")
-    with _Prof("dgrad", 2.0 * dy.numel() * ci * k3[0] * k3[1] * k3[2]):
+    with _Prof("dgrad", flops):
         L.check(lib.mi_convnd_dgrad_f32(L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(res), L.ptr(mask), n, d, h, wd, ci, co,
                                         *k3, stride, *p3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_dgrad_f32")
     return dx
 
 
-def conv_wgrad_into(x, dy, param, k, stride, pad):
+def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
     """dW for `param`, written (or accumulated) into param.grad."""
     nd5 = x.dim() == 5
     k3, p3 = _k3(k, nd5), _p3(pad, nd5)
     n, d, h, wd, ci = _as5d(x).shape
     co = dy.shape[-1]
     lib = L.lib()
-    ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), x.device, "conv")
     g, acc = _grad_target(param)
     tgt = torch.empty_like(g) if acc else g
-    with _Prof("wgrad", 2.0 * dy.numel() * ci * k3[0] * k3[1] * k3[2]):
-        L.check(lib.mi_convnd_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, *k3, stride, *p3,
-                                        L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_wgrad_f32")
+    flops = 2.0 * dy.numel() * ci * k3[0] * k3[1] * k3[2]
+    if dil is not None and tuple(_k3(dil, nd5)) != (1, 1, 1):
+        d3 = _k3(dil, nd5)
+        ws = _ws(lib.mi_convnd_dil_workspace_bytes(n, d, h, wd, ci, co, *k3, *p3, *d3), x.device, "conv")
+        with _Prof("wgrad", flops):
+            L.check(lib.mi_convnd_dil_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, *k3, *p3, *d3,
+                                                L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_dil_wgrad_f32")
+    else:
+        ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), x.device, "conv")
+        with _Prof("wgrad", flops):
+            L.check(lib.mi_convnd_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, *k3, stride, *p3,
+                                            L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_wgrad_f32")
     if acc:
         g.add_(tgt)
 
@@ -237,7 +254,7 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, mod, relu):
         ctx.mod, ctx.relu = mod, relu
-        y = conv_fwd(x, w, mod.k, mod.stride, mod.pad, None, relu)
+        y = conv_fwd(x, w, mod.k, mod.stride, mod.pad, None, relu, dil=getattr(mod, "dil", None))
         ctx.save_for_backward(x, y if relu else None)
         ctx.x_needs_grad = x.requires_grad
         return y
@@ -249,12 +266,34 @@ class _ConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         if ctx.relu:
             dy = relu_mask(dy, y)
+        dil = getattr(mod, "dil", None)
         if mod.weight.requires_grad:
-            conv_wgrad_into(x, dy, mod.weight, mod.k, mod.stride, mod.pad)
+            conv_wgrad_into(x, dy, mod.weight, mod.k, mod.stride, mod.pad, dil=dil)
         dx = None
         if ctx.x_needs_grad:
-            dx = conv_dgrad(dy, mod.weight, x.shape, mod.k, mod.stride, mod.pad)
+            dx = conv_dgrad(dy, mod.weight, x.shape, mod.k, mod.stride, mod.pad, dil=dil)
         return dx, None, None, None
+
+
+def convnd_weight_param(co, ci, k3, device=None):
+    """Parameter with logical shape (co, ci, kd, kh, kw) over physical storage [kd,kh,kw,ci,co]."""
+    phys = torch.empty(*k3, ci, co, device=device)
+    return nn.Parameter(phys.permute(4, 3, 0, 1, 2))
+
+
+class HipConvNd(nn.Module):
+    """nn.Conv3d(ci, co, kernel (kd,kh,kw), stride 1, padding (pd,ph,pw), dilation, bias=False), channels-last."""
+
+    def __init__(self, ci, co, k3, pad3, dil3=(1, 1, 1)):
+        super().__init__()
+        self.ci, self.co, self.k, self.stride, self.pad, self.dil = ci, co, tuple(k3), 1, tuple(pad3), tuple(dil3)
+        self.weight = convnd_weight_param(co, ci, k3)
+        with torch.no_grad():
+            bound = 1.0 / (ci * k3[0] * k3[1] * k3[2]) ** 0.5
+            self.weight.uniform_(-bound, bound)
+
+    def forward(self, x, relu=False):
+        return _ConvFn.apply(x, self.weight, self, relu)
 
 
 class HipConv3d(nn.Module):
@@ -716,3 +755,211 @@ def queue_enqueue_(queue, queue_ptr, keys):
         raise AssertionError("queue size must be a multiple of the batch (models/moco.py:47)")
     L.check(L.lib().mi_queue_enqueue(L.ptr(queue), L.ptr(queue_ptr), L.ptr(keys), b, c, r, L.stream()),
             "mi_queue_enqueue")
+
+
+# ------------------------------------------------------------------------------------------------
+# detector network glue (models/networks/unet.py): ceil-mode max-pool, 2x2 transposed conv, concat, bias, z head
+# ------------------------------------------------------------------------------------------------
+class _MaxPool2dCeilFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        n, h, w, c = x.shape
+        ho, wo = (h + k - 1) // k, (w + k - 1) // k
+        y = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+        arg = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device) if x.requires_grad else None
+        L.check(L.lib().mi_maxpool2d_ceil_fwd(L.ptr(x), L.ptr(y), L.ptr(arg), n, h, w, c, k, L.stream()),
+                "mi_maxpool2d_ceil_fwd")
+        ctx.save_for_backward(arg)
+        ctx.geom = (x.shape, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        shape, k = ctx.geom
+        n, h, w, c = shape
+        dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
+        L.check(L.lib().mi_maxpool2d_ceil_bwd(L.ptr(dy.contiguous()), L.ptr(arg), L.ptr(dx), n, h, w, c, k, L.stream()),
+                "mi_maxpool2d_ceil_bwd")
+        return dx, None
+
+
+def maxpool2d_ceil(x, k=2):
+    """nn.MaxPool2d(k, ceil_mode=True) on (N,H,W,C)."""
+    return _MaxPool2dCeilFn.apply(_f32c(x, "x"), k)
+
+
+def _colsum_into(dy2d, param):
+    """param.grad (+)= column sums of dy2d (M, C)."""
+    m, c = dy2d.shape
+    lib = L.lib()
+    g, acc = _grad_target(param)
+    tgt = torch.empty_like(g) if acc else g
+    ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dy2d.device, "colreduce")
+    sums = torch.empty(2 * c, dtype=torch.float64, device=dy2d.device)
+    L.check(lib.mi_colsum(L.ptr(dy2d), m, c, L.ptr(tgt), L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()), "mi_colsum")
+    if acc:
+        g.add_(tgt)
+
+
+class _ConvT2x2Fn(torch.autograd.Function):
+    """nn.ConvTranspose2d(ci, co, 2, stride=2) cropped to (ho, wo): 1x1 implicit GEMM to 4*co columns + pixel shuffle."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, mod, ho, wo):
+        n, h, wd, ci = x.shape
+        co = mod.co
+        t = conv_fwd(x, mod.gemm_view(), 1, 1, 0)
+        y = torch.empty((n, ho, wo, co), dtype=torch.float32, device=x.device)
+        L.check(L.lib().mi_shuffle2x2_fwd(L.ptr(t), L.ptr(bias), L.ptr(y), n, h, wd, co, ho, wo, L.stream()),
+                "mi_shuffle2x2_fwd")
+        ctx.save_for_backward(x)
+        ctx.mod, ctx.out_hw = mod, (ho, wo)
+        ctx.x_needs_grad = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        mod = ctx.mod
+        n, h, wd, ci = x.shape
+        co = mod.co
+        ho, wo = ctx.out_hw
+        dy = dy.contiguous()
+        dt = torch.empty((n, h, wd, 4 * co), dtype=torch.float32, device=dy.device)
+        L.check(L.lib().mi_shuffle2x2_bwd(L.ptr(dy), L.ptr(dt), n, h, wd, co, ho, wo, L.stream()), "mi_shuffle2x2_bwd")
+        if mod.bias is not None and mod.bias.requires_grad:
+            _colsum_into(dy.view(-1, co), mod.bias)
+        if mod.weight.requires_grad:
+            # the gradient tensor has the parameter's strides, i.e. the GEMM layout [ci][4*co]
+            g, acc = _grad_target(mod.weight)
+            tgt = torch.empty_like(g) if acc else g
+            lib = L.lib()
+            ws = _ws(lib.mi_convnd_workspace_bytes(n, 1, h, wd, ci, 4 * co, 1, 1, 1, 1, 0, 0, 0), x.device, "conv")
+            L.check(lib.mi_convnd_wgrad_f32(L.ptr(x), L.ptr(dt), L.ptr(tgt), n, 1, h, wd, ci, 4 * co, 1, 1, 1, 1, 0, 0, 0,
+                                            L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_wgrad_f32")
+            if acc:
+                g.add_(tgt)
+        dx = conv_dgrad(dt, mod.gemm_view(), x.shape, 1, 1, 0) if ctx.x_needs_grad else None
+        return dx, None, None, None, None, None
+
+
+class HipConvTranspose2x2(nn.Module):
+    """nn.ConvTranspose2d(ci, co, kernel_size=2, stride=2): weight logical (ci, co, 2, 2) over storage [ci][a][b][co]."""
+
+    def __init__(self, ci, co):
+        super().__init__()
+        self.ci, self.co = ci, co
+        self.weight = nn.Parameter(torch.empty(ci, 2, 2, co).permute(0, 3, 1, 2))
+        self.bias = nn.Parameter(torch.zeros(co))
+        with torch.no_grad():
+            bound = 1.0 / (co * 4) ** 0.5             # torch's fan_in of a transposed conv weight = size(1) * k*k
+            self.weight.uniform_(-bound, bound)
+            self.bias.uniform_(-bound, bound)
+
+    def gemm_view(self):
+        """the same storage as a (4*co, ci, 1, 1) convolution weight in kernel layout"""
+        return torch.as_strided(self.weight, (4 * self.co, self.ci, 1, 1), (1, 4 * self.co, 4 * self.co * self.ci,
+                                                                            4 * self.co * self.ci))
+
+    def forward(self, x, ho=None, wo=None):
+        n, h, w, _ = x.shape
+        return _ConvT2x2Fn.apply(_f32c(x, "x"), self.weight, self.bias, self, 2 * h if ho is None else ho,
+                                 2 * w if wo is None else wo)
+
+
+class _ConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ca, cb = a.shape[-1], b.shape[-1]
+        m = a.numel() // ca
+        out = torch.empty(a.shape[:-1] + (ca + cb,), dtype=torch.float32, device=a.device)
+        L.check(L.lib().mi_concat_channels(L.ptr(a), ca, L.ptr(b), cb, L.ptr(out), m, L.stream()), "mi_concat_channels")
+        ctx.shapes = (a.shape, b.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sa, sb = ctx.shapes
+        da = torch.empty(sa, dtype=torch.float32, device=dout.device)
+        db = torch.empty(sb, dtype=torch.float32, device=dout.device)
+        L.check(L.lib().mi_split_channels(L.ptr(dout.contiguous()), L.ptr(da), sa[-1], L.ptr(db), sb[-1],
+                                          da.numel() // sa[-1], L.stream()), "mi_split_channels")
+        return da, db
+
+
+def concat_channels(a, b):
+    """torch.cat((a, b), 1) of the reference (channel axis) on channels-last tensors."""
+    return _ConcatFn.apply(_f32c(a, "a"), _f32c(b, "b"))
+
+
+class _BiasAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, holder):
+        y = x.clone()
+        c = x.shape[-1]
+        L.check(L.lib().mi_bias_add(L.ptr(y), L.ptr(bias), y.numel() // c, c, L.stream()), "mi_bias_add")
+        ctx.holder = holder
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        b = ctx.holder.bias
+        if b.requires_grad:
+            _colsum_into(dy.contiguous().view(-1, dy.shape[-1]), b)
+        return dy, None, None
+
+
+def bias_add(x, holder):
+    """x + holder.bias over the channel axis; the bias gradient goes to holder.bias.grad."""
+    return _BiasAddFn.apply(_f32c(x, "x"), holder.bias, holder)
+
+
+class _ZHeadFn(torch.autograd.Function):
+    """nn.Conv3d(C, K, (3,1,1), padding=(1,0,0), bias=False) with K <= 4 on (N,D,H,W,C)."""
+
+    @staticmethod
+    def forward(ctx, x, w, mod):
+        n, d, h, wd, c = x.shape
+        k = mod.k_out
+        y = torch.empty((n, d, h, wd, k), dtype=torch.float32, device=x.device)
+        L.check(L.lib().mi_zhead_fwd(L.ptr(x), L.ptr(w), L.ptr(y), n, d, h * wd, c, k, L.stream()), "mi_zhead_fwd")
+        ctx.save_for_backward(x)
+        ctx.mod = mod
+        ctx.x_needs_grad = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        mod = ctx.mod
+        n, d, h, wd, c = x.shape
+        k = mod.k_out
+        lib = L.lib()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.x_needs_grad else None
+        tgt, g, acc = None, None, False
+        if mod.weight.requires_grad:
+            g, acc = _grad_target(mod.weight)
+            tgt = torch.empty_like(g) if acc else g
+        ws = _ws(lib.mi_zhead_bwd_workspace_bytes(n, d, h * wd, c, k), x.device, "zhead")
+        L.check(lib.mi_zhead_bwd(L.ptr(x), L.ptr(mod.weight), L.ptr(dy), L.ptr(dx), L.ptr(tgt), n, d, h * wd, c, k,
+                                 L.ptr(ws), ws.numel(), L.stream()), "mi_zhead_bwd")
+        if acc:
+            g.add_(tgt)
+        return dx, None, None
+
+
+class HipZHead(nn.Module):
+    """The (3,1,1) head with <= 4 outputs: weight logical (K, C, 3, 1, 1) over storage [3][C][K]."""
+
+    def __init__(self, c, k_out):
+        super().__init__()
+        self.c, self.k_out = c, k_out
+        self.weight = nn.Parameter(torch.empty(3, 1, 1, c, k_out).permute(4, 3, 0, 1, 2))
+        with torch.no_grad():
+            self.weight.normal_(std=0.001)
+
+    def forward(self, x):
+        return _ZHeadFn.apply(_f32c(x, "x"), self.weight, self)
+

@@ -33,15 +33,40 @@ class ModelWithLossSimSiam(torch.nn.Module):
         return outputs, loss, loss_stats
 
 
+class ModelWithLoss(torch.nn.Module):
+    """base_trainer.py:134-154: the detector tasks - two forward passes (input and its augmented view) in training,
+    one without gradients (and in eval mode) otherwise."""
+
+    def __init__(self, model, loss):
+        super().__init__()
+        self.model = model
+        self.loss = loss
+
+    def forward(self, batch, epoch, phase):
+        if phase == "train":
+            outputs = self.model(batch["input"])
+            outputs_cr = self.model(batch["input_aug"])
+            loss, loss_stats = self.loss(outputs, batch, epoch, phase, output_cr=outputs_cr)
+        else:
+            with torch.no_grad():
+                self.model.eval()
+                outputs = self.model(batch["input"])
+                loss, loss_stats = self.loss(outputs, batch, epoch, phase, output_cr=None)
+        return outputs[-1], loss, loss_stats
+
+
 class BaseTrainer(object):
     def __init__(self, opt, model, optimizer=None):
         self.opt = opt
         self.optimizer = optimizer
         self.loss_stats, self.loss = self._get_losses(opt)
         self.iter = 0
-        if opt.task not in ("simsiam", "moco", "simsiam3d"):
+        if opt.task in ("simsiam", "moco", "simsiam3d"):
+            self.model_with_loss = ModelWithLossSimSiam(model, self.loss)
+        elif opt.task in ("semi", "tomo", "semi3d"):
+            self.model_with_loss = ModelWithLoss(model, self.loss)
+        else:
             raise NotImplementedError("task '%s' is outside the hot path built here (DESIGN.md §7)" % opt.task)
-        self.model_with_loss = ModelWithLossSimSiam(model, self.loss)
         self.engine = None
         self.device = None
 
@@ -106,7 +131,7 @@ class BaseTrainer(object):
                 break
             data_time.update(time.time() - end)
             for k in batch:
-                if k != "meta":
+                if k != "meta" and isinstance(batch[k], torch.Tensor):
                     batch[k] = batch[k].to(device=self.device, non_blocking=True)
             if phase == "train" and self.engine is not None:
                 loss = self.engine.step(batch["input"], batch["input_aug"])

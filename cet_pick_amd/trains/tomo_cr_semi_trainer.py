@@ -2,11 +2,11 @@
 the heat-map + debiased contrastive regularisation between the two augmented views + consistency, composed from the
 HIP losses in models/loss.py.  The `--pn` (SupConLossV2_more) and `--ge` (PUGELoss) variants are outside the hot path.
 
-The trainer class itself needs the detector network's backward pass, which is not built yet: it
-raises instead of silently running something else.
+`TomoCRSemiTrainer` drives it through the shared `BaseTrainer` loop (two forward passes per step).
 """
 import torch
 
+from .base_trainer import BaseTrainer
 from ..models.loss import ConsistencyLoss, FocalLoss, PULoss, UnbiasedConLoss
 from ..models.utils import _sigmoid
 
@@ -57,7 +57,11 @@ class TomoCRSemiLoss(torch.nn.Module):
         return loss, {"loss": loss, "hm_loss": hm_loss, "cr_loss": cr_loss, "consis_loss": consis_loss}
 
 
-class TomoCRSemiTrainer(object):
+class TomoCRSemiTrainer(BaseTrainer):
+    """tomo_cr_semi_trainer.py:114-125: the semi-supervised detector trainer (task 'semi')."""
+
     def __init__(self, opt, model, optimizer=None):
-        raise NotImplementedError("detector training (task 'semi', SURVEY.md C5) needs the TomoConvUNet backward pass, "
-                                  "which this build does not have yet; the losses are in TomoCRSemiLoss")
+        super().__init__(opt, model, optimizer=optimizer)
+
+    def _get_losses(self, opt):
+        return ["loss", "hm_loss", "cr_loss", "consis_loss"], TomoCRSemiLoss(opt)

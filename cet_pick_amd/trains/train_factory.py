@@ -1,9 +1,11 @@
 """Mirror of cet_pick/trains/train_factory.py:16-30 for the tasks on the hot path."""
 from .tomo_moco_trainer import TomoMocoTrainer
 from .tomo_simsiam_trainer import TomoSimSiamTrainer
+from .tomo_cr_semi_trainer import TomoCRSemiTrainer
 
 train_factory = {
     "moco": TomoMocoTrainer,
     "simsiam": TomoSimSiamTrainer,
     "simsiam3d": TomoSimSiamTrainer,
+    "semi": TomoCRSemiTrainer,
 }

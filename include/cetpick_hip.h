@@ -216,6 +216,10 @@ int mi_split_channels(const float* dout, float* da, int Ca, float* db, int Cb, l
  * (unet_small.py:55-62).  x (N,D,P,C), w [3][C][K], y (N,D,P,K), P = H*W. */
 int mi_zhead_fwd(const float* x, const float* w, float* y, int N, int D, long P, int C, int K,
                  mi_stream_t stream);
+/* its backward: dx (N,D,P,C) and dw [3][C][K], either may be NULL; 256 % C == 0 */
+size_t mi_zhead_bwd_workspace_bytes(int N, int D, long P, int C, int K);
+int mi_zhead_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int N, int D, long P, int C,
+                 int K, void* ws, size_t ws_bytes, mi_stream_t stream);
 
 /* nn.BatchNorm3d / BatchNorm1d over rows [M][C] (moco_encoder_3d.py:170,184,199-205), split so a
  * SyncBN all-reduce of `sums` (2*C doubles: sum x, sum x^2) fits between stats and apply.

@@ -38,8 +38,8 @@ def test_oracle_matches_reference_outputs():
         np.testing.assert_allclose(out["proj"].numpy()[:, :, :, ::3, ::3], g[f"proj_{tag}"], rtol=0, atol=1e-6)
 
 
-def test_training_mode_fails_loudly():
+def test_cpu_tensor_fails_loudly():
     import pytest
-    net = _net()
-    with pytest.raises(NotImplementedError):
-        net(torch.zeros(1, 2, 16, 16))
+    from cet_pick_amd._lib import HipExtensionError
+    with pytest.raises(HipExtensionError):
+        _net()(torch.zeros(1, 2, 16, 16))

@@ -38,3 +38,57 @@ def test_moco_main_two_epochs_and_resume(tmp_path, monkeypatch):
     moco_main.main(opts().parse(args[:5] + ["--num_epochs", "3", "--lr", "0.01", "--lr_step", "1", "--exp_id", "t",
                                             "--debug", "0", "--resume"]))
     assert len(open(os.path.join(save_dir, "log.txt")).read().strip().split("\n")) == 3
+
+
+def test_semi_detector_trainer_two_steps_vs_oracle(tmp_path):
+    """unet_4 detector training (task 'semi', --contrastive) through TomoCRSemiTrainer; the first
+    step's loss terms and the updated weights are checked against torch autograd on the CPU oracles."""
+    from types import SimpleNamespace
+    import numpy as np
+    from oracle import loss_ref as OL, unet_ref as OU
+    from cet_pick_amd.models.model import create_model
+    from cet_pick_amd.synthetic import seeded_state_dict
+    from cet_pick_amd.trains.train_factory import train_factory
+    heads = {"hm": 1, "proj": 32}
+    opt = SimpleNamespace(task="semi", arch="unet_4", pn=False, ge=False, tau=0.1, temp=0.07, thresh=0.5, cr_weight=0.1,
+                          num_stacks=1, contrastive=True, device=torch.device("cuda"), num_iters=-1, print_iter=0,
+                          hide_data_time=True, exp_id="t", lr=1e-3, hipgraph=False)
+    model = create_model(opt.arch, heads, 32)
+    sd0 = seeded_state_dict(model, seed=323)
+    for k in ("hm.weight", "proj.weight"):
+        sd0[k] = sd0[k] * 0.3
+    model.load_state_dict(sd0)
+    optim = torch.optim.SGD(model.parameters(), lr=opt.lr)
+    trainer = train_factory["semi"](opt, model, optim)
+    trainer.set_device([0], None, "cuda")
+    g = torch.Generator().manual_seed(2)
+    b, d, h, w = 2, 4, 48, 48
+    x = torch.randn(b, d, h, w, generator=g)
+    x_aug = x.flip(-1) + 0.05 * torch.randn(b, d, h, w, generator=g)
+    gt = torch.full((b, 1, d, h // 2, w // 2), -1.0)
+    r = torch.rand(gt.shape, generator=g)
+    gt[r < 0.3] = 0.0
+    gt[(r >= 0.3) & (r < 0.4)] = 0.6
+    gt[r > 0.96] = 1.0
+    batch = {"input": x, "input_aug": x_aug, "hm": gt, "flip_prob": 0.2, "meta": {}}
+    # reference step on the CPU
+    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(("running_mean", "running_var")))
+              for k, v in sd0.items()}
+    o1 = OU.tomo_conv_unet_forward(ref_sd, x, 4, heads, training=True)
+    o2 = OU.tomo_conv_unet_forward(ref_sd, x_aug, 4, heads, training=True)
+    ref = OL.tomo_cr_semi_loss(o1["hm"], o2["hm"], o1["proj"], o2["proj"], gt, 0.2, opt.tau, opt.temp, opt.thresh, opt.cr_weight)
+    ref[0].backward()
+    stats, _ = trainer.train(1, [dict(batch)])
+    assert set(stats) == {"loss", "hm_loss", "cr_loss", "consis_loss", "time"}
+    for k, v in zip(("loss", "hm_loss", "cr_loss", "consis_loss"), ref):
+        np.testing.assert_allclose(stats[k], v.item(), rtol=2e-3)
+    for name, prm in model.named_parameters():
+        if name.endswith("upconv.bias"):
+            continue
+        want = sd0[name] - opt.lr * ref_sd[name].grad
+        delta = (prm.detach().cpu() - want).norm() / (opt.lr * ref_sd[name].grad.norm() + 1e-12)
+        assert delta < 2e-2, (name, float(delta))
+    stats2, _ = trainer.train(2, [dict(batch)])
+    assert np.isfinite(stats2["loss"])
+    val, _ = trainer.val(2, [dict(batch)])
+    assert np.isfinite(val["loss"]) and val["cr_loss"] == 0
