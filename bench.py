@@ -235,7 +235,7 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "hipgraph": bool(engine.use_graph), "final_loss": final_loss},
             "step_mfma_frac_of_peak": value / world * FLOP_PER_SUBTOMO / 1e12 / PEAK_F32_MATRIX_TFLOPS,
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd/dgrad/wgrad, all layers)",
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel + stem_fwd/stem_wgrad_kernel (fwd/dgrad/wgrad, all 75 conv launches of a step)",
                          "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
                          "launches_per_step": n_launch // 3, "kernel_ms_per_step": ms / 3,
@@ -246,6 +246,10 @@ def main():
         if not args.no_secondary:
             out["secondary"] = inference_secondary(dev)
             log("inference secondary done")
+            # detector-side rows (loader a12, unet_4 forward a22, debiased contrastive loss a23, C5 train step)
+            from tools.bench_detector import run as detector_secondary
+            out["secondary"]["detector"] = detector_secondary()
+            log("detector secondary done")
         if not args.no_cpu_baseline and world == 1:
             v, cores = cpu_baseline(B, 4, 317)
             out["cpu_baseline"] = {"value": v, "unit": "subtomograms/sec", "cores": cores, "kind": "port",

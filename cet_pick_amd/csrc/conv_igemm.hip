@@ -747,6 +747,21 @@ bool is_stem7(const Geom& g) {
 
 int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, float* out,
              const float* res, const float* mask, int relu, void* ws, size_t ws_bytes, hipStream_t s) {
+    // A gathered operand of 2 GiB or more (32-bit buffer offsets): FWD / DGRAD rows are independent per sample,
+    // so the batch is cut in halves until every piece fits
+    if (mode != MODE_WGRAD && g.N > 1) {
+        const long in_per = (long)g.Di * g.Hi * g.Wi * g.Ci, out_per = (long)g.Do * g.Ho * g.Wo * g.Co;
+        const long a_per = (mode == MODE_FWD) ? in_per : out_per, o_per = (mode == MODE_FWD) ? out_per : in_per;
+        if (4 * a_per * g.N >= 0x7fff0000l) {
+            Geom lo = g, hi = g;
+            lo.N = g.N / 2; hi.N = g.N - lo.N;
+            int rc = run_conv(mode, lo, a_src, b_src, out, res, mask, relu, ws, ws_bytes, s);
+            if (rc) return rc;
+            const long ao = a_per * lo.N, oo = o_per * lo.N;
+            return run_conv(mode, hi, a_src + ao, b_src, out + oo, res ? res + oo : nullptr, mask ? mask + oo : nullptr,
+                            relu, ws, ws_bytes, s);
+        }
+    }
     // the 7^3 stride-2 stem has its own direct kernels (conv_stem.hip); anything they decline runs below
     if (is_stem7(g) && !env_int("MI_CONV_NO_STEM")) {
         int rc = MI_E_UNSUPPORTED;

@@ -177,3 +177,39 @@ def simsiam_loss(p1, z1, p2, z2):
     loss = -(cos(p1, z2.detach()).mean() + cos(p2, z1.detach()).mean()) * 0.5
     output_std = torch.std(F.normalize(p1.detach(), dim=1), 0).mean()
     return loss, output_std
+
+
+# ------------------------------------------------------------------------------------------------
+# a3: slice-wise SimSiam encoder (arch 'simsiam')
+# ------------------------------------------------------------------------------------------------
+def simsiam_slice_trunk(sd, x, train=True):
+    """models/networks/simsiam_model.py:368-414 (one view): per-slice conv7x7/s2-bn-relu-maxpool, layer1-3,
+    stack to a volume, feature_3d (Conv3d + BN3d + ReLU), avgpool, fc."""
+    b, d, h, w = x.shape
+    s = x.reshape(b * d, 1, h, w)
+    s = F.relu(_bn(sd, "bn1", F.conv2d(s, sd["conv1.weight"], stride=2, padding=3), train, BN_MOMENTUM))
+    s = F.max_pool2d(s, 3, 2, 1)
+    for li, stride in ((1, 1), (2, 2), (3, 2)):
+        for bi in range(2):
+            s = _block2d(sd, "layer%d.%d" % (li, bi), s, stride if bi == 0 else 1, train)
+    _, ch, hh, ww = s.shape
+    v = s.reshape(b, d, ch, hh, ww).permute(0, 2, 1, 3, 4)
+    v = F.relu(_bn(sd, "feature_3d.1", F.conv3d(v, sd["feature_3d.0.weight"], padding=1), train, BN_MOMENTUM))
+    v = F.adaptive_avg_pool3d(v, 1).reshape(b, -1)
+    return F.linear(v, sd["fc.weight"], sd["fc.bias"])
+
+
+def simsiam_slice_forward(sd, x1, x2, train=True):
+    f1 = simsiam_slice_trunk(sd, x1, train)
+    f2 = simsiam_slice_trunk(sd, x2, train)
+
+    def proj(f):
+        z = F.relu(_bn(sd, "proj.1", F.linear(f, sd["proj.0.weight"]), train, 0.1))
+        z = F.relu(_bn(sd, "proj.4", F.linear(z, sd["proj.3.weight"]), train, 0.1))
+        return _bn(sd, "proj.7", F.linear(z, sd["proj.6.weight"]), train, 0.1, affine=False)
+
+    def pred(z):
+        p = F.relu(_bn(sd, "pred.1", F.linear(z, sd["pred.0.weight"]), train, 0.1))
+        return F.linear(p, sd["pred.3.weight"], sd["pred.3.bias"])
+    z1, z2 = proj(f1), proj(f2)
+    return pred(z1), z1, pred(z2), z2

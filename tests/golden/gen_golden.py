@@ -125,6 +125,44 @@ def gen_unet():
     json.dump(keys, open(path, "w"), indent=0)
 
 
+def gen_simsiam():
+    """a3: TomoResClassifier (simsiam_model.py:159-440), arch 'simsiam': two-view train forward/backward + eval."""
+    from cet_pick.models.networks import simsiam_model as RS
+    heads = {"proj": 256, "pred": 256}
+    net = RS.TomoResClassifier(RS.BasicBlock, [2, 2, 2, 2], heads, 0)
+    net.load_state_dict(seeded_state_dict(net, seed=319))
+    g = torch.Generator().manual_seed(6)
+    x1 = torch.randn(4, 5, 40, 40, generator=g)
+    x2 = x1.flip(3) + 0.1 * torch.randn(4, 5, 40, 40, generator=g)
+    net.train()
+    out = net(x1, x2)
+    p1, z1, p2, z2 = out[0]["pred"], out[0]["proj"], out[1]["pred"], out[1]["proj"]
+    cos = torch.nn.CosineSimilarity(dim=1)
+    loss = -(cos(p1, z2).mean() + cos(p2, z1).mean()) * 0.5
+    loss.backward()
+    res = {"p1": p1.detach().numpy(), "z1": z1.numpy(), "p2": p2.detach().numpy(), "z2": z2.numpy(),
+           "loss": np.asarray(loss.item())}
+    idx = np.random.default_rng(4).integers(0, 2 ** 31, size=64)
+    for k, prm in net.named_parameters():
+        gf = prm.grad.reshape(-1).numpy()
+        res[f"grad_{k}_norm"] = np.asarray(np.linalg.norm(gf.astype(np.float64)))
+        res[f"grad_{k}_sample"] = gf[idx % gf.size]
+    res["sample_idx"] = idx
+    res["feature_3d_running_var"] = net.feature_3d[1].running_var.numpy().copy()
+    net2 = RS.TomoResClassifier(RS.BasicBlock, [2, 2, 2, 2], heads, 0)
+    net2.load_state_dict(seeded_state_dict(net2, seed=319))
+    net2.eval()
+    with torch.no_grad():
+        ft = net2.forward_test(x1[:1])              # b == 1: the permute branch of the reference
+    res["test_proj_b1"] = ft["proj"].numpy()
+    res["test_pred_b1"] = ft["pred"].numpy()
+    save("simsiam_slices.npz", **res)
+    path = os.path.join(HERE, "ckpt_keys.json")
+    keys = json.load(open(path))
+    keys["simsiam_18"] = {k: list(v.shape) for k, v in net.state_dict().items()}
+    json.dump(keys, open(path, "w"), indent=0)
+
+
 def gen_losses():
     """a23: _neg_loss, _pu_neg_loss, ConsistencyLoss, UnbiasedConLoss of cet_pick/models/loss.py with gradients."""
     from types import SimpleNamespace
@@ -379,6 +417,6 @@ def gen_lr():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader", "unet", "losses"]
+    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader", "unet", "losses", "simsiam"]
     for w in which:
         globals()["gen_" + w]()

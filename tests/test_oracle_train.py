@@ -126,3 +126,22 @@ def test_simsiam2d_forward_backward_matches_reference(golden):
         z, p = T.simsiam_heads(sd2, f, False)
     np.testing.assert_allclose(z.numpy(), g["test_proj"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(p.numpy(), g["test_pred"], rtol=1e-4, atol=1e-5)
+
+
+def test_simsiam_slicewise_oracle_matches_reference():
+    """row a3: oracle.train_ref.simsiam_slice_forward vs the reference's TomoResClassifier outputs."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import train_ref as O
+    from cet_pick_amd.models.model import create_model
+    from cet_pick_amd.synthetic import seeded_state_dict
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "simsiam_slices.npz"))
+    net = create_model("simsiam_18", {"proj": 256, "pred": 256}, 0)
+    sd = seeded_state_dict(net, seed=319)
+    gen = torch.Generator().manual_seed(6)
+    x1 = torch.randn(4, 5, 40, 40, generator=gen)
+    x2 = x1.flip(3) + 0.1 * torch.randn(4, 5, 40, 40, generator=gen)
+    p1, z1, p2, z2 = O.simsiam_slice_forward({k: v.clone() for k, v in sd.items()}, x1, x2, True)
+    for got, key in ((p1, "p1"), (z1, "z1"), (p2, "p2"), (z2, "z2")):
+        np.testing.assert_allclose(got.numpy(), g[key], rtol=0, atol=1e-5)

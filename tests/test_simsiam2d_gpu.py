@@ -117,3 +117,45 @@ def test_simsiam_trainer_entry_points(tmp_path, monkeypatch):
     save_model(path, 4, model, optimizer)
     m2 = load_model(create_model(opt.arch, opt.heads, opt.head_conv), path)
     assert torch.equal(m2.fc.weight.cpu(), model.fc.weight.detach().cpu())
+
+
+def test_simsiam_slicewise_encoder_matches_reference_golden(golden):
+    """row a3 (arch 'simsiam'): per-slice 2-D trunk + Conv3d/BN3d head, two-view forward / backward and eval, against
+    outputs of the reference's TomoResClassifier (simsiam_model.py:159-440)."""
+    from cet_pick_amd.models.model import create_model
+    from cet_pick_amd.synthetic import seeded_state_dict
+    from cet_pick_amd.trains.tomo_simsiam_trainer import TomoSimSiamLoss
+    g = golden("simsiam_slices.npz")
+    heads = {"proj": 256, "pred": 256}
+
+    def make():
+        net = create_model("simsiam_18", heads, 0)
+        net.load_state_dict(seeded_state_dict(net, seed=319))
+        return net.cuda()
+    net = make()
+    keys = json.load(open(os.path.join(HERE, "golden", "ckpt_keys.json")))["simsiam_18"]
+    sd = net.state_dict()
+    assert list(sd) == list(keys) and all(list(sd[k].shape) == keys[k] for k in keys)
+    gen = torch.Generator().manual_seed(6)
+    x1 = torch.randn(4, 5, 40, 40, generator=gen)
+    x2 = x1.flip(3) + 0.1 * torch.randn(4, 5, 40, 40, generator=gen)
+    net.train()
+    out = net(x1.cuda(), x2.cuda())
+    for name, ref in (("p1", out[0]["pred"]), ("z1", out[0]["proj"]), ("p2", out[1]["pred"]), ("z2", out[1]["proj"])):
+        np.testing.assert_allclose(ref.detach().cpu().numpy(), g[name], rtol=2e-3, atol=2e-3, err_msg=name)
+    loss, _ = TomoSimSiamLoss(None)(out, None, 0)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-4
+    loss.backward()
+    idx = g["sample_idx"]
+    for n, p in net.named_parameters():
+        gf = p.grad.detach().cpu().contiguous().reshape(-1).numpy()
+        ref = float(g[f"grad_{n}_norm"])
+        assert abs(np.linalg.norm(gf.astype(np.float64)) - ref) <= 1e-2 * ref + 2e-6, (n, ref)
+        rs = g[f"grad_{n}_sample"]
+        np.testing.assert_allclose(gf[idx % gf.size], rs, rtol=0, atol=3e-2 * float(np.abs(rs).max()) + 2e-6, err_msg=n)
+    np.testing.assert_allclose(net.feature_3d[1].running_var.cpu().numpy(), g["feature_3d_running_var"], rtol=1e-3, atol=1e-5)
+    net2 = make().eval()
+    with torch.no_grad():
+        ft = net2.forward_test(x1[:1].cuda())
+    np.testing.assert_allclose(ft["proj"].cpu().numpy(), g["test_proj_b1"], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(ft["pred"].cpu().numpy(), g["test_pred_b1"], rtol=2e-3, atol=2e-3)

@@ -1,0 +1,100 @@
+"""Timings of the detector-side rows (a12, a22, a23, C5) on one MI355X: loader, unet_4 forward on a full tomogram,
+the debiased contrastive loss at N = 12,288 voxels per view, and one semi-supervised training step."""
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def timeit(fn, n=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def run(small=False):
+    from cet_pick_amd.utils import loader
+    from cet_pick_amd.models.model import create_model
+    from cet_pick_amd.models.loss import UnbiasedConLoss
+    from cet_pick_amd.synthetic import seeded_state_dict
+    from cet_pick_amd import hipops as H
+    out = {}
+    # a12: load_rec (xzy order, compress) + preprocess of a 256 x 512 x 512 tomogram already on the host
+    shape = (64, 128, 128) if small else (512, 256, 512)          # file order (x, z, y): 256 slices of 512 x 512
+    rec = np.random.default_rng(0).standard_normal(shape).astype(np.float32)
+    dev_rec = loader.rec_to_device(rec, "xzy", False)
+    t = timeit(lambda: loader.preprocess(loader.zscore(dev_rec), 0))
+    out["loader_zscore_preprocess"] = {"voxels": int(dev_rec.numel()), "ms": t * 1e3, "voxels_per_sec": dev_rec.numel() / t,
+                                       "note": "device-resident volume; z-score + stats + quantise/min-max = 4 passes"}
+    # a22: unet_4 forward, 128 x 512 x 512 (3.4 TFLOP)
+    heads = {"hm": 1, "proj": 32}
+    net = create_model("unet_4", heads, 32)
+    net.load_state_dict(seeded_state_dict(net, seed=321))
+    net = net.cuda().eval()
+    vol = torch.randn((1, 16, 128, 128) if small else (1, 128, 512, 512), device="cuda")
+    with torch.no_grad():
+        t = timeit(lambda: net(vol), n=3, warm=1)
+        H.PROFILE = []                                      # conv launches of one forward: flops and HIP-event times
+        net(vol)
+        torch.cuda.synchronize()
+        prof, H.PROFILE = H.PROFILE, None
+    cflops = sum(p[1] for p in prof)
+    cms = sum(p[2].elapsed_time(p[3]) for p in prof)
+    out["unet4_forward"] = {"input": list(vol.shape), "ms": t * 1e3, "input_voxels_per_sec": vol.numel() / t,
+                            "conv_gflop": cflops / 1e9, "conv_ms": cms, "conv_tflops": cflops / cms / 1e9,
+                            "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+    # a23: debiased contrastive loss, N = 12,288 per view, dim 32, forward + backward
+    n, dim = (2048, 32) if small else (12288, 32)
+    g = torch.Generator().manual_seed(0)
+    f = torch.nn.functional.normalize(torch.randn(n, dim, generator=g), dim=1).cuda().requires_grad_()
+    f2 = torch.nn.functional.normalize(torch.randn(n, dim, generator=g), dim=1).cuda().requires_grad_()
+    lab = torch.full((n,), -1.0)
+    r = torch.rand(n, generator=g)
+    lab[r < 0.3] = 0.0
+    lab[r > 0.97] = 1.0
+    lab = lab.cuda()
+    p1, p2 = torch.rand(n, generator=g).cuda(), torch.rand(n, generator=g).cuda()
+    crit = UnbiasedConLoss(0.07, 0.1)
+    opt = SimpleNamespace(thresh=0.5, device=torch.device("cuda"))
+
+    def ucl():
+        f.grad = None
+        sup, unsup = crit(lab, p1, p2, f, f2, opt)
+        (sup + 0.1 * unsup).backward()
+    t = timeit(ucl)
+    flops = 2.0 * (2 * n) ** 2 * dim * (1 + 4)             # S tiles: 1 forward pass + 2 x (S + W.F) backward passes
+    out["unbiased_con_loss_fwd_bwd"] = {"N": n, "dim": dim, "ms": t * 1e3, "dense_matrix_bytes_avoided": 4 * (2 * n) ** 2,
+                                        "mfma_tflops": flops / t / 1e12}
+    # C5: one semi-supervised training step, 16 pairs of 6 x 64 x 64 crops
+    from cet_pick_amd.trains.train_factory import train_factory
+    topt = SimpleNamespace(task="semi", arch="unet_4", pn=False, ge=False, tau=0.1, temp=0.07, thresh=0.5, cr_weight=0.1,
+                           num_stacks=1, contrastive=True, device=torch.device("cuda"), num_iters=-1, print_iter=0,
+                           hide_data_time=True, exp_id="bench", lr=1e-3, hipgraph=False)
+    model = create_model("unet_4", heads, 32)
+    model.load_state_dict(seeded_state_dict(model, seed=323))
+    trainer = train_factory["semi"](topt, model, torch.optim.Adam(model.parameters(), lr=1e-3))
+    trainer.set_device([0], None, "cuda")
+    b = 4 if small else 16
+    x = torch.randn(b, 6, 64, 64, generator=g)
+    gt = torch.full((b, 1, 6, 32, 32), -1.0)
+    rr = torch.rand(gt.shape, generator=g)
+    gt[rr < 0.3] = 0.0
+    gt[rr > 0.97] = 1.0
+    batch = {"input": x.cuda(), "input_aug": x.flip(-1).cuda(), "hm": gt.cuda(), "flip_prob": 0.2, "meta": {}}
+    t = timeit(lambda: trainer.train(1, [dict(batch)]), n=5, warm=2)
+    out["semi_train_step"] = {"pairs": b, "crop": [6, 64, 64], "ms": t * 1e3, "crops_per_sec": 2 * b / t}
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(run(small="--small" in sys.argv)))
