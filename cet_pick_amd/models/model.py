@@ -10,12 +10,14 @@ import torch
 from .networks.moco_encoder_3d import get_moco_net_small_3d
 from .networks.simsiam_model_2d import get_simsiam2d_net_small
 from .networks.simsiam_model import get_simsiam_net_small
+from .networks.simsiam_model_2d3d import get_simsiam2d3d_net_small
 from .networks.unet_small import get_tomo_unet_small
 
 _model_factory = {
     "moco3d": get_moco_net_small_3d,
     "simsiam2d": get_simsiam2d_net_small,
     "simsiam": get_simsiam_net_small,
+    "simsiam2d3d": get_simsiam2d3d_net_small,
     "unet": get_tomo_unet_small,
 }
 _REFERENCE_ARCHS = ("res", "unet", "class", "small", "ressmall", "p3d", "res3d", "unetcla", "resclass", "simsiam",

@@ -41,7 +41,11 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         out = self.bn1(self.conv1(x), relu=True)
         out = self.conv2(out)
-        residual = x if self.downsample is None else self.downsample[0](x)
+        residual = x
+        if self.downsample is not None:
+            residual = self.downsample[0](x)
+            if len(self.downsample) > 1:                    # the 2d3d variant normalises the shortcut (:601-607 there)
+                residual = self.downsample[1](residual)
         return self.bn2(out, relu=True, res=residual)       # relu(bn2(out) + residual)
 
 

@@ -129,6 +129,8 @@ def _block2d(sd, prefix, x, stride, train):
     res = x
     if prefix + ".downsample.0.weight" in sd:
         res = F.conv2d(x, sd[prefix + ".downsample.0.weight"], stride=stride)
+        if prefix + ".downsample.1.weight" in sd:           # simsiam_model_2d3d.py: BatchNorm2d on the shortcut
+            res = _bn(sd, prefix + ".downsample.1", res, train, BN_MOMENTUM)
     return F.relu(out + res)
 
 
@@ -202,6 +204,32 @@ def simsiam_slice_trunk(sd, x, train=True):
 def simsiam_slice_forward(sd, x1, x2, train=True):
     f1 = simsiam_slice_trunk(sd, x1, train)
     f2 = simsiam_slice_trunk(sd, x2, train)
+
+    def proj(f):
+        z = F.relu(_bn(sd, "proj.1", F.linear(f, sd["proj.0.weight"]), train, 0.1))
+        z = F.relu(_bn(sd, "proj.4", F.linear(z, sd["proj.3.weight"]), train, 0.1))
+        return _bn(sd, "proj.7", F.linear(z, sd["proj.6.weight"]), train, 0.1, affine=False)
+
+    def pred(z):
+        p = F.relu(_bn(sd, "pred.1", F.linear(z, sd["pred.0.weight"]), train, 0.1))
+        return F.linear(p, sd["pred.3.weight"], sd["pred.3.bias"])
+    z1, z2 = proj(f1), proj(f2)
+    return pred(z1), z1, pred(z2), z2
+
+
+def simsiam2d3d_forward(sd, x1_2d, x1_3d, x2_2d, x2_3d, train=True):
+    """models/networks/simsiam_model_2d3d.py:733-790: tilt and tomogram patches stacked along the batch through the
+    shared 2-D trunk, pooled features regrouped (2B,256) -> (B,512), fc, proj / pred."""
+    def trunk(a, b):
+        x = torch.cat([a, b], 0)
+        x = F.relu(_bn(sd, "bn1", F.conv2d(x, sd["conv1.weight"], padding=1), train, BN_MOMENTUM))
+        for li, stride in ((1, 1), (2, 2), (3, 2)):
+            for bi in range(2):
+                x = _block2d(sd, "layer%d.%d" % (li, bi), x, stride if bi == 0 else 1, train)
+        f = F.adaptive_avg_pool2d(x, 1).reshape(x.shape[0], -1)
+        f = torch.cat(torch.chunk(f, 2, dim=0), dim=1)
+        return F.linear(f, sd["fc.weight"], sd["fc.bias"])
+    f1, f2 = trunk(x1_2d, x1_3d), trunk(x2_2d, x2_3d)
 
     def proj(f):
         z = F.relu(_bn(sd, "proj.1", F.linear(f, sd["proj.0.weight"]), train, 0.1))

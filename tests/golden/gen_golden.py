@@ -163,6 +163,35 @@ def gen_simsiam():
     json.dump(keys, open(path, "w"), indent=0)
 
 
+def gen_simsiam2d3d():
+    """a3: TomoResClassifier2D3D (simsiam_model_2d3d.py:560-790), arch 'simsiam2d3d'."""
+    from cet_pick.models.networks import simsiam_model_2d3d as R23
+    heads = {"proj": 128, "pred": 128}
+    net = R23.TomoResClassifier2D3D(R23.BasicBlock, [2, 2, 2, 2], heads, 128)
+    net.load_state_dict(seeded_state_dict(net, seed=320))
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(4, 1, 28, 28, generator=g) for _ in range(4)]
+    net.train()
+    out = net(*xs)
+    p1, z1, p2, z2 = out[0]["pred"], out[0]["proj"], out[1]["pred"], out[1]["proj"]
+    cos = torch.nn.CosineSimilarity(dim=1)
+    loss = -(cos(p1, z2).mean() + cos(p2, z1).mean()) * 0.5
+    loss.backward()
+    res = {"p1": p1.detach().numpy(), "z1": z1.numpy(), "p2": p2.detach().numpy(), "z2": z2.numpy(),
+           "loss": np.asarray(loss.item())}
+    for k, prm in net.named_parameters():
+        res[f"grad_{k}_norm"] = np.asarray(np.linalg.norm(prm.grad.reshape(-1).numpy().astype(np.float64)))
+    net.eval()
+    with torch.no_grad():
+        ft = net.forward_test(xs[0], xs[1])
+    res["test_pred"] = ft["pred"].numpy()
+    save("simsiam2d3d.npz", **res)
+    path = os.path.join(HERE, "ckpt_keys.json")
+    keys = json.load(open(path))
+    keys["simsiam2d3d_18"] = {k: list(v.shape) for k, v in net.state_dict().items()}
+    json.dump(keys, open(path, "w"), indent=0)
+
+
 def gen_losses():
     """a23: _neg_loss, _pu_neg_loss, ConsistencyLoss, UnbiasedConLoss of cet_pick/models/loss.py with gradients."""
     from types import SimpleNamespace
@@ -417,6 +446,6 @@ def gen_lr():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader", "unet", "losses", "simsiam"]
+    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader", "unet", "losses", "simsiam", "simsiam2d3d"]
     for w in which:
         globals()["gen_" + w]()

@@ -159,3 +159,30 @@ def test_simsiam_slicewise_encoder_matches_reference_golden(golden):
         ft = net2.forward_test(x1[:1].cuda())
     np.testing.assert_allclose(ft["proj"].cpu().numpy(), g["test_proj_b1"], rtol=2e-3, atol=2e-3)
     np.testing.assert_allclose(ft["pred"].cpu().numpy(), g["test_pred_b1"], rtol=2e-3, atol=2e-3)
+
+
+def test_simsiam2d3d_encoder_matches_reference_golden(golden):
+    """row a3 (arch 'simsiam2d3d'): tilt + tomogram patches through the shared trunk, against the reference."""
+    from cet_pick_amd.models.model import create_model
+    from cet_pick_amd.synthetic import seeded_state_dict
+    from cet_pick_amd.trains.tomo_simsiam_trainer import TomoSimSiamLoss
+    g = golden("simsiam2d3d.npz")
+    net = create_model("simsiam2d3d_18", {"proj": 128, "pred": 128}, 128)
+    net.load_state_dict(seeded_state_dict(net, seed=320))
+    net = net.cuda().train()
+    gen = torch.Generator().manual_seed(9)
+    xs = [torch.randn(4, 1, 28, 28, generator=gen).cuda() for _ in range(4)]
+    out = net(*xs)
+    for name, ref in (("p1", out[0]["pred"]), ("z1", out[0]["proj"]), ("p2", out[1]["pred"]), ("z2", out[1]["proj"])):
+        np.testing.assert_allclose(ref.detach().cpu().numpy(), g[name], rtol=2e-3, atol=2e-3, err_msg=name)
+    loss, _ = TomoSimSiamLoss(None)(out, None, 0)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-4
+    loss.backward()
+    for n, p in net.named_parameters():
+        ref = float(g[f"grad_{n}_norm"])
+        got = float(np.linalg.norm(p.grad.detach().cpu().contiguous().reshape(-1).numpy().astype(np.float64)))
+        assert abs(got - ref) <= 1e-2 * ref + 2e-6, (n, got, ref)
+    net.eval()
+    with torch.no_grad():
+        ft = net.forward_test(xs[0], xs[1])
+    np.testing.assert_allclose(ft["pred"].cpu().numpy(), g["test_pred"], rtol=2e-3, atol=2e-3)
