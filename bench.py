@@ -240,7 +240,11 @@ def main():
                          "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
                          "launches_per_step": n_launch // 3, "kernel_ms_per_step": ms / 3,
                          "algorithmic_gflop_per_step": flop / 3 / 1e9,
-                         "measured": "HIP events around every launch, 3 eager steps after the timed region"},
+                         "by_mode": {t: {"launches_per_step": v[0] // 3, "gflop_per_step": v[1] / 3 / 1e9,
+                                         "ms_per_step": v[2] / 3, "tflops": v[1] / (v[2] * 1e-3) / 1e12}
+                                     for t, v in sorted(by.items())},
+                         "measured": "HIP events around every conv call (kernel + its split-K reduce), 3 eager steps "
+                                     "after the timed region; compare profiles/r01_train_kernel_stats.csv"},
         }
         log("conv roofline pass done")
         if not args.no_secondary:
