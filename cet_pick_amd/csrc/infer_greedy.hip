@@ -17,6 +17,8 @@
 
 int mi_launch_gauss_axis(const float* in, float* out, int D, int H, int W, int axis, float sigma,
                          hipStream_t s);
+int mi_launch_gauss_march(const float* in0, float* out0a, float* out0b, float sig0a, float sig0b, const float* in1,
+                          float* out1, float sig1, int D, int H, int W, int axis, hipStream_t s);
 
 namespace {
 
@@ -563,19 +565,44 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
 
     // utils/image.py:141-143: 30-voxel xy border, doubled when both H and W exceed 512
     int bxy = (H > 512 && W > 512) ? 60 : 30;
+    const bool no_march = getenv("MI_GAUSS_NO_MARCH") != nullptr;
     auto gauss = [&](float sigma, float* dst) -> int {
         int rc;
-        if ((rc = mi_launch_gauss_axis(rec, dst, D, H, W, 0, sigma, s))) return rc;
-        if ((rc = mi_launch_gauss_axis(dst, w.tmp, D, H, W, 1, sigma, s))) return rc;
+        // z and y: the marching kernel (each element read once); x: the contiguous-axis kernel
+        rc = no_march ? MI_E_UNSUPPORTED : mi_launch_gauss_march(rec, dst, nullptr, sigma, 0.f, nullptr, nullptr, 0.f, D, H, W, 0, s);
+        if (rc == MI_E_UNSUPPORTED) rc = mi_launch_gauss_axis(rec, dst, D, H, W, 0, sigma, s);
+        if (rc) return rc;
+        rc = no_march ? MI_E_UNSUPPORTED : mi_launch_gauss_march(dst, w.tmp, nullptr, sigma, 0.f, nullptr, nullptr, 0.f, D, H, W, 1, s);
+        if (rc == MI_E_UNSUPPORTED) rc = mi_launch_gauss_axis(dst, w.tmp, D, H, W, 1, sigma, s);
+        if (rc) return rc;
         return mi_launch_gauss_axis(w.tmp, dst, D, H, W, 2, sigma, s);
+    };
+    // first DoG level: the z passes of both Gaussians in one launch and the y passes in another (two jobs each;
+    // w.heat is free until the first NMS pass writes it).  The one-read-two-sigmas form of the z pass was measured
+    // slower than two single-sigma jobs (its 82 scalar taps do not fit the SGPR file).
+    auto gauss_pair = [&](float sa, float sb, float* ga, float* gb) -> int {
+        int rc = no_march ? MI_E_UNSUPPORTED : mi_launch_gauss_march(rec, ga, nullptr, sa, 0.f, rec, gb, sb, D, H, W, 0, s);
+        if (rc == MI_E_UNSUPPORTED) {
+            if ((rc = gauss(sa, ga))) return rc;
+            return gauss(sb, gb);
+        }
+        if (rc) return rc;
+        rc = mi_launch_gauss_march(ga, w.tmp, nullptr, sa, 0.f, gb, w.heat, sb, D, H, W, 1, s);
+        if (rc == MI_E_UNSUPPORTED) {
+            if ((rc = mi_launch_gauss_axis(ga, w.tmp, D, H, W, 1, sa, s))) return rc;
+            rc = mi_launch_gauss_axis(gb, w.heat, D, H, W, 1, sb, s);
+        }
+        if (rc) return rc;
+        if ((rc = mi_launch_gauss_axis(w.tmp, ga, D, H, W, 2, sa, s))) return rc;
+        return mi_launch_gauss_axis(w.heat, gb, D, H, W, 2, sb, s);
     };
     int rc;
     int cur = 0;
-    if ((rc = gauss(sigmas_host[0], w.g[cur]))) return rc;
+    if ((rc = gauss_pair(sigmas_host[0], sigmas_host[1], w.g[0], w.g[1]))) return rc;
     float* dense = heat_out ? heat_out : ((n_sigmas > 2) ? w.heat : nullptr);
     for (int i = 1; i < n_sigmas; ++i) {
         int nxt = cur ^ 1;
-        if ((rc = gauss(sigmas_host[i], w.g[nxt]))) return rc;
+        if (i > 1 && (rc = gauss(sigmas_host[i], w.g[nxt]))) return rc;      // level 1 came with the pair above
         const bool last = (i == n_sigmas - 1);
         MarchParams p = {};
         p.in = w.g[cur]; p.in2 = w.g[nxt]; p.mode = MI_LOAD_DOG;
