@@ -154,8 +154,15 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # backend "nccl" IS RCCL on ROCm.  CETPICK_DIST_BACKEND=gloo is the one-GPU rehearsal of the N>1 path (ranks
+        # share the device: RCCL refuses two ranks on one GPU)
+        backend = os.environ.get("CETPICK_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

@@ -88,6 +88,16 @@ class TomoResClassifier3D(nn.Module):
             layers.append(block(self.inplanes, planes, dilation=dilation))
         return nn.Sequential(*layers)
 
+    # Data-parallel training overlaps the gradient exchange with the backward pass: `grad_marker(tag)` (set by
+    # MocoStepEngine) is called from autograd when the gradient of a stage boundary exists, i.e. when every
+    # parameter gradient downstream of it has been enqueued.
+    grad_marker = None
+
+    def _mark(self, x, tag):
+        if self.grad_marker is not None and x.requires_grad:
+            x.register_hook(lambda g, t=tag: self.grad_marker(t))
+        return x
+
     # ---- the trunk, channels-last -------------------------------------------------------------
     def _trunk(self, x1):
         b, c, d, h, w = x1.shape
@@ -96,11 +106,13 @@ class TomoResClassifier3D(nn.Module):
         x = x1.contiguous().float().view(b, d, h, w, 1)      # C == 1: NCDHW is already channels-last
         x = self.conv1(x)
         x = self.bn1(x, relu=True)
-        x = H.maxpool3d(x, 3, 2, 1)
+        x = self._mark(H.maxpool3d(x, 3, 2, 1), "layer1")     # its gradient exists => layer1.. are done
         for blk in self.layer1:
             x = blk(x)
+        x = self._mark(x, "layer2")
         for blk in self.layer2:
             x = blk(x)
+        x = self._mark(x, "layer3")
         for blk in self.layer3:
             x = blk(x)
         x = self.feature_3d[0](x)

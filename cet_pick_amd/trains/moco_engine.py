@@ -29,6 +29,33 @@ class MocoStepEngine:
         self.use_graph = bool(use_graph) and self.world == 1
         self._graph = None
         self._static_q = self._static_k = None
+        self._pending = []
+        self.buckets_sent = []           # tags of the last step's exchanges, in issue order (tests / diagnostics)
+        if self.world > 1:
+            self._setup_buckets()
+
+    # ---- data parallel: bucketed gradient all-reduce overlapped with the backward pass ---------------------
+    def _setup_buckets(self):
+        """Arena ranges whose gradients are complete at each stage boundary of the backward pass (parameters sit in
+        the arena in registration order: stem, layer1, layer2, layer3, feature_3d, fc, heads)."""
+        enc = self.moco.encoder_q
+        first = {}
+        for (name, _), off in zip(enc.named_parameters(), self.arena_q.offsets):
+            first.setdefault(name.split(".")[0], off)
+        end = self.arena_q.numel
+        l1, l2, l3 = first["layer1"], first["layer2"], first["layer3"]
+        # marker tag -> range that is final when the gradient of that stage's INPUT exists
+        self._bucket = {"layer3": (l3, end), "layer2": (l2, l3), "layer1": (l1, l2), "stem": (0, l1)}
+        enc.grad_marker = self._on_marker
+
+    def _reduce_bucket(self, tag):
+        a, b = self._bucket[tag]
+        if b > a:
+            self._pending.append(_dist().all_reduce(self.arena_q.flat_grad[a:b], async_op=True))
+            self.buckets_sent.append(tag)
+
+    def _on_marker(self, tag):
+        self._reduce_bucket(tag)
 
     def set_lr(self, lr):
         """utils/utils.py:58-70 `adjust_learning_rate` target: the schedule reaches a captured graph
@@ -38,13 +65,18 @@ class MocoStepEngine:
 
     def _step_eager(self, im_q, im_k):
         moco = self.moco
+        self.buckets_sent = []
         self.arena_q.zero_grad()
         logits, labels = moco(im_q, im_k)
         loss = H.cross_entropy_label0(logits)
         loss.backward()
         if self.world > 1:
-            d = _dist()
-            d.all_reduce(self.arena_q.flat_grad)            # RCCL ring / direct over xGMI
+            # layer3+heads, layer2 and layer1 went out from the autograd hooks while the backward was still running
+            # (RCCL over xGMI on its own stream); the stem's gradients are the last to exist
+            self._reduce_bucket("stem")
+            for w in self._pending:
+                w.wait()
+            self._pending = []
             self.arena_q.flat_grad.mul_(1.0 / self.world)
         H.sgd_step_(self.arena_q.flat, self.arena_q.flat_grad, self.lr, self.weight_decay, self.lr_dev)
         self.loss.copy_(loss.detach())

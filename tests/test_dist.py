@@ -100,6 +100,9 @@ def _w_step(rank, world, port, out):
     yb.backward(dyb[sl].cuda())
     loss = eng.step(xq[sl].cuda(), xk[sl].cuda())
     torch.cuda.synchronize()
+    # the gradient exchange went out in four buckets, deepest layers first (overlapped with the backward pass)
+    assert eng.buckets_sent == ["layer3", "layer2", "layer1", "stem"], eng.buckets_sent
+    assert sorted(eng._bucket.values())[0][0] == 0 and sorted(eng._bucket.values())[-1][1] == eng.arena_q.numel
     torch.save({"loss": float(loss), "queue": moco.queue.cpu(), "ptr": int(moco.queue_ptr),
                 "q_flat": eng.arena_q.flat.cpu(), "k_flat": eng.arena_k.flat.cpu(),
                 "bn_y": yb.detach().cpu(), "bn_dx": xin.grad.cpu(), "bn_dg": bn.weight.grad.cpu(),
