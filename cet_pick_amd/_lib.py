@@ -142,7 +142,8 @@ _workspaces = {}
 
 def workspace(nbytes, device, tag="default"):
     """A cached device scratch buffer of at least nbytes (grown geometrically, never shrunk)."""
-    key = (str(device), tag)
+    # one buffer per (device, purpose, stream): launches on different streams must not share scratch
+    key = (str(device), tag, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)

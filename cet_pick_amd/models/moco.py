@@ -57,13 +57,33 @@ class MoCo(nn.Module):
         """models/moco.py:41-52, on the device (ptr is read and advanced by the kernel)."""
         H.queue_enqueue_(self.queue, self.queue_ptr, keys.contiguous())
 
-    def forward(self, im_q, im_k):
-        q = self.encoder_q(im_q)[0]["proj"]
-        q = H.l2_normalize(q)
+    # The key branch (momentum update + encoder_k forward, no gradient) does not depend on the query branch: on one
+    # GPU it runs on a second HIP stream next to encoder_q's forward.  The layer-2/3 launches of a batch-64 step are
+    # too small to fill 256 CUs on their own, so the two forwards interleave on the chip.  (Off under
+    # torch.distributed: both branches issue SyncBN collectives and their order must stay fixed.)
+    overlap_key_branch = True
+    _side = None
+
+    def _key_branch(self, im_k):
         with torch.no_grad():
             self._momentum_update_key_encoder()
             k = self.encoder_k(im_k)[0]["proj"]
-            k = H.l2_normalize(k)
+            return H.l2_normalize(k)
+
+    def forward(self, im_q, im_k):
+        if self.overlap_key_branch and _world_size() == 1 and im_q.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=im_q.device)
+            cur = torch.cuda.current_stream()
+            self._side.wait_stream(cur)                    # inputs and last step's SGD are ordered before it
+            with torch.cuda.stream(self._side):
+                k = self._key_branch(im_k)
+            q = H.l2_normalize(self.encoder_q(im_q)[0]["proj"])
+            cur.wait_stream(self._side)
+            k.record_stream(cur)
+        else:
+            q = H.l2_normalize(self.encoder_q(im_q)[0]["proj"])
+            k = self._key_branch(im_k)
         logits = H.moco_logits(q, k, self.queue, self.T)
         labels = torch.zeros(logits.shape[0], dtype=torch.long, device=logits.device)
         keys = concat_all_gather(k) if _world_size() > 1 else k
