@@ -59,8 +59,9 @@ class MoCo(nn.Module):
 
     # The key branch (momentum update + encoder_k forward, no gradient) does not depend on the query branch: on one
     # GPU it runs on a second HIP stream next to encoder_q's forward.  The layer-2/3 launches of a batch-64 step are
-    # too small to fill 256 CUs on their own, so the two forwards interleave on the chip.  (Off under
-    # torch.distributed: both branches issue SyncBN collectives and their order must stay fixed.)
+    # too small to fill 256 CUs on their own, so the two forwards interleave on the chip.  Under torch.distributed
+    # both branches issue SyncBN collectives from their own stream; every rank enqueues them in the same (program)
+    # order, which is the order the process group's communicator stream runs them in.
     overlap_key_branch = True
     _side = None
 
@@ -71,7 +72,7 @@ class MoCo(nn.Module):
             return H.l2_normalize(k)
 
     def forward(self, im_q, im_k):
-        if self.overlap_key_branch and _world_size() == 1 and im_q.is_cuda:
+        if self.overlap_key_branch and im_q.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=im_q.device)
             cur = torch.cuda.current_stream()
