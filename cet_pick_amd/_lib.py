@@ -68,6 +68,8 @@ SIGNATURES = {
     "mi_colreduce_workspace_bytes": (_Z, [_L, _I]),
     "mi_bn_stats": (_I, [_P, _L, _I, _P, _P, _Z, _P]),
     "mi_bn_apply_fwd": (_I, [_P, _P, _L, _I, _P, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P]),
+    "mi_bn_small_fwd": (_I, [_P, _P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P]),
+    "mi_bn_small_bwd": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _P, _P]),
     "mi_bn_eval_fwd": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "mi_bn_bwd_reduce": (_I, [_P, _P, _P, _L, _I, _P, _I, _P, _P, _Z, _P]),
     "mi_bn_bwd_apply": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _D, _I, _P, _P, _P]),

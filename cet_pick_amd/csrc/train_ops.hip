@@ -184,6 +184,138 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, float* y,
     }
 }
 
+// ---- small-M BatchNorm in ONE launch (the BatchNorm1d layers of the projection MLP see M = batch rows, the
+// feature_3d BatchNorm M = batch * 8): a workgroup owns 16 channels, 64 row lanes x 4 float4 channel groups, sums in
+// fp64 through LDS (fixed shape: deterministic), then applies.  Replaces colreduce + finalize + apply (3 launches).
+constexpr int BNS_CH = 16;            // channels per workgroup
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* x, float* y, int M, int C, const float* gamma,
+                                                          const float* beta, float eps, float momentum,
+                                                          float* running_mean, float* running_var,
+                                                          long long* num_batches_tracked, float* save,
+                                                          const float* res, int relu) {
+    const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;            // channel group (float4), row lane
+    const int c = blockIdx.x * BNS_CH + 4 * cg;
+    __shared__ double red[2][64][4][4];
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (c < C)
+        for (int r = rl; r < M; r += 64) {
+            const float4 v = ld4(x + (long)r * C + c);
+            const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s1[k] += (double)a[k]; s2[k] += (double)a[k] * (double)a[k]; }
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[0][rl][cg][k] = s1[k]; red[1][rl][cg][k] = s2[k]; }
+    __syncthreads();
+    __shared__ float s_mean[BNS_CH], s_inv[BNS_CH];
+    if (threadIdx.x < BNS_CH) {
+        const int g = threadIdx.x >> 2, k = threadIdx.x & 3, ch = blockIdx.x * BNS_CH + threadIdx.x;
+        double a = 0, b = 0;
+        for (int r = 0; r < 64; ++r) { a += red[0][r][g][k]; b += red[1][r][g][k]; }
+        const double mean = a / M;
+        double var = b / M - mean * mean;
+        if (var < 0) var = 0;
+        const float inv = (float)(1.0 / sqrt(var + (double)eps));
+        s_mean[threadIdx.x] = (float)mean; s_inv[threadIdx.x] = inv;
+        if (ch < C) {
+            if (save) { save[ch] = (float)mean; save[C + ch] = inv; }
+            if (running_mean) {
+                const double unbiased = M > 1 ? var * M / (M - 1.0) : var;
+                running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
+                running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    }
+    __syncthreads();
+    if (c >= C) return;
+    float m[4], iv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { m[k] = s_mean[4 * cg + k]; iv[k] = s_inv[4 * cg + k]; }
+    const float4 g = gamma ? ld4(gamma + c) : make_float4(1, 1, 1, 1);
+    const float4 b = beta ? ld4(beta + c) : make_float4(0, 0, 0, 0);
+    for (int r = rl; r < M; r += 64) {
+        const long o = (long)r * C + c;
+        const float4 v = ld4(x + o);
+        float4 q;
+        q.x = fmaf((v.x - m[0]) * iv[0], g.x, b.x); q.y = fmaf((v.y - m[1]) * iv[1], g.y, b.y);
+        q.z = fmaf((v.z - m[2]) * iv[2], g.z, b.z); q.w = fmaf((v.w - m[3]) * iv[3], g.w, b.w);
+        if (res) { const float4 t = ld4(res + o); q.x += t.x; q.y += t.y; q.z += t.z; q.w += t.w; }
+        if (relu) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
+        st4(y + o, q);
+    }
+}
+
+// backward in one launch: sums of dy' and dy'*xhat per channel, then dx, dgamma, dbeta
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* dy, const float* x, const float* y, float* dx,
+                                                          int M, int C, const float* save, const float* gamma,
+                                                          int relu, float* dgamma, float* dbeta) {
+    const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    const int c = blockIdx.x * BNS_CH + 4 * cg;
+    __shared__ double red[2][64][4][4];
+    float mean[4] = {0, 0, 0, 0}, inv[4] = {1, 1, 1, 1};
+    if (c < C) {
+        const float4 a = ld4(save + c), b = ld4(save + C + c);
+        mean[0] = a.x; mean[1] = a.y; mean[2] = a.z; mean[3] = a.w;
+        inv[0] = b.x; inv[1] = b.y; inv[2] = b.z; inv[3] = b.w;
+    }
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (c < C)
+        for (int r = rl; r < M; r += 64) {
+            const long o = (long)r * C + c;
+            const float4 d4 = ld4(dy + o), x4 = ld4(x + o);
+            float d[4] = {d4.x, d4.y, d4.z, d4.w};
+            const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+            if (relu) {
+                const float4 y4 = ld4(y + o);
+                const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = yv[k] > 0.f ? d[k] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s1[k] += (double)d[k]; s2[k] += (double)(d[k] * ((xv[k] - mean[k]) * inv[k])); }
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[0][rl][cg][k] = s1[k]; red[1][rl][cg][k] = s2[k]; }
+    __syncthreads();
+    __shared__ float s_dy[BNS_CH], s_dx[BNS_CH];
+    if (threadIdx.x < BNS_CH) {
+        const int g = threadIdx.x >> 2, k = threadIdx.x & 3, ch = blockIdx.x * BNS_CH + threadIdx.x;
+        double a = 0, b = 0;
+        for (int r = 0; r < 64; ++r) { a += red[0][r][g][k]; b += red[1][r][g][k]; }
+        s_dy[threadIdx.x] = (float)a; s_dx[threadIdx.x] = (float)b;
+        if (ch < C) {
+            if (dbeta) dbeta[ch] = (float)a;
+            if (dgamma) dgamma[ch] = (float)b;
+        }
+    }
+    __syncthreads();
+    if (c >= C) return;
+    const float rc = 1.0f / (float)M;
+    float gi[4], sdy[4], sdx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        gi[k] = (gamma ? gamma[c + k] : 1.f) * inv[k];
+        sdy[k] = s_dy[4 * cg + k] * rc; sdx[k] = s_dx[4 * cg + k] * rc;
+    }
+    for (int r = rl; r < M; r += 64) {
+        const long o = (long)r * C + c;
+        const float4 d4 = ld4(dy + o), x4 = ld4(x + o);
+        float d[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+        if (relu) {
+            const float4 y4 = ld4(y + o);
+            const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = yv[k] > 0.f ? d[k] : 0.f;
+        }
+        float q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = gi[k] * (d[k] - sdy[k] - (xv[k] - mean[k]) * inv[k] * sdx[k]);
+        st4(dx + o, make_float4(q[0], q[1], q[2], q[3]));
+    }
+}
+
 // dx = gamma * invstd * (dy' - sum_dy/count - xhat * sum_dyxhat/count); workgroup 0 also writes the affine
 // gradients dbeta = sum_dy, dgamma = sum_dy*xhat when asked to (from `sums`, i.e. the sums of THIS rank's rows
 // only when the caller has not all-reduced them)
@@ -567,6 +699,32 @@ extern "C" int mi_bn_apply_fwd(const float* x, float* y, long M, int C, const do
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, y, n4, C, sums, count, eps,
                        momentum, running_mean, running_var, num_batches_tracked, save_mean_invstd, gamma,
                        beta, res, relu);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+/* One-launch BatchNorm for small M (<= MI_BN_SMALL_MAX_ROWS rows), single process: statistics + running
+ * statistics + affine (+res, ReLU).  Same arithmetic as mi_bn_stats + mi_bn_apply_fwd. */
+extern "C" int mi_bn_small_fwd(const float* x, float* y, long M, int C, const float* gamma, const float* beta,
+                               float eps, float momentum, float* running_mean, float* running_var,
+                               long long* num_batches_tracked, float* save_mean_invstd, const float* res, int relu,
+                               mi_stream_t stream) {
+    if (!x || !y || !save_mean_invstd || M <= 0 || M > MI_BN_SMALL_MAX_ROWS || C <= 0 || C % 4) return MI_E_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return MI_E_ARG;
+    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3((C + BNS_CH - 1) / BNS_CH), dim3(256), 0, (hipStream_t)stream, x, y,
+                       (int)M, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+                       save_mean_invstd, res, relu);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_bn_small_bwd(const float* dy, const float* x, const float* y, float* dx, long M, int C,
+                               const float* save_mean_invstd, const float* gamma, int relu, float* dgamma,
+                               float* dbeta, mi_stream_t stream) {
+    if (!dy || !x || !dx || !save_mean_invstd || (relu && !y) || M <= 0 || M > MI_BN_SMALL_MAX_ROWS || C <= 0 || C % 4)
+        return MI_E_ARG;
+    hipLaunchKernelGGL(bn_small_bwd_kernel, dim3((C + BNS_CH - 1) / BNS_CH), dim3(256), 0, (hipStream_t)stream, dy, x, y,
+                       dx, (int)M, C, save_mean_invstd, gamma, relu, dgamma, dbeta);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

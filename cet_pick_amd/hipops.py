@@ -405,6 +405,9 @@ def _dist_world():
     return 1
 
 
+BN_SMALL_MAX_ROWS = 4096      # == MI_BN_SMALL_MAX_ROWS
+
+
 class _BNFn(torch.autograd.Function):
     """y = act(bn(x) + res); res (optional) is a residual branch added before the activation."""
 
@@ -417,7 +420,19 @@ class _BNFn(torch.autograd.Function):
         dev = x.device
         y = torch.empty_like(x)
         save = torch.empty(2 * c, dtype=torch.float32, device=dev)
-        if mod.training or not mod.track_running_stats:
+        distributed = mod.sync and _dist_world() > 1
+        ctx.small = (mod.training or not mod.track_running_stats) and m <= BN_SMALL_MAX_ROWS and not distributed
+        if ctx.small:
+            # one launch: statistics, running statistics, affine (+res, ReLU)
+            track = mod.track_running_stats and mod.training
+            L.check(lib.mi_bn_small_fwd(L.ptr(x), L.ptr(y), m, c, L.ptr(gamma), L.ptr(beta), mod.eps, mod.momentum,
+                                        L.ptr(mod.running_mean if track else None),
+                                        L.ptr(mod.running_var if track else None),
+                                        L.ptr(mod.num_batches_tracked if track else None),
+                                        L.ptr(save), L.ptr(res), int(relu), L.stream()), "mi_bn_small_fwd")
+            ctx.count = float(m)
+            ctx.train_stats = True
+        elif mod.training or not mod.track_running_stats:
             ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
             sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
             L.check(lib.mi_bn_stats(L.ptr(x), m, c, L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()), "mi_bn_stats")
@@ -461,6 +476,23 @@ class _BNFn(torch.autograd.Function):
                 dy = relu_mask(dy, y)
                 relu = False
             dres = dy
+        if ctx.small:
+            gamma = mod.weight
+            dg = db = None
+            acc_g = acc_b = False
+            if gamma is not None and gamma.requires_grad:
+                gt, acc_g = _grad_target(gamma)
+                dg = torch.empty_like(gt) if acc_g else gt
+                bt, acc_b = _grad_target(mod.bias)
+                db = torch.empty_like(bt) if acc_b else bt
+            dx = torch.empty_like(x)
+            L.check(lib.mi_bn_small_bwd(L.ptr(dy), L.ptr(x), L.ptr(y), L.ptr(dx), m, c, L.ptr(save), L.ptr(gamma),
+                                        int(relu), L.ptr(dg), L.ptr(db), L.stream()), "mi_bn_small_bwd")
+            if acc_g:
+                gamma.grad.add_(dg)
+            if acc_b:
+                mod.bias.grad.add_(db)
+            return dx, None, None, None, None, dres
         ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         L.check(lib.mi_bn_bwd_reduce(L.ptr(dy), L.ptr(x), L.ptr(y), m, c, L.ptr(save), int(relu), L.ptr(sums),
@@ -473,15 +505,19 @@ class _BNFn(torch.autograd.Function):
             dg = torch.empty_like(gt) if acc_g else gt
             bt, acc_b = _grad_target(mod.bias)
             db = torch.empty_like(bt) if acc_b else bt
-            # affine gradients come from the LOCAL sums (torch.nn.SyncBatchNorm does the same); the
-            # data-parallel gradient averaging then treats them like every other parameter
-            L.check(lib.mi_bn_param_grads(L.ptr(sums), c, L.ptr(dg), L.ptr(db), L.stream()), "mi_bn_param_grads")
-        if mod.sync and _dist_world() > 1:
+        distributed = mod.sync and _dist_world() > 1
+        if distributed:
+            if dg is not None:
+                # affine gradients come from the LOCAL sums (torch.nn.SyncBatchNorm does the same); the
+                # data-parallel gradient averaging then treats them like every other parameter
+                L.check(lib.mi_bn_param_grads(L.ptr(sums), c, L.ptr(dg), L.ptr(db), L.stream()), "mi_bn_param_grads")
             import torch.distributed as dist
             dist.all_reduce(sums)                      # dx needs the global sums
         dx = torch.empty_like(x)
+        # single process: the same launch writes dgamma / dbeta from the sums
         L.check(lib.mi_bn_bwd_apply(L.ptr(dy), L.ptr(x), L.ptr(y), L.ptr(dx), m, c, L.ptr(save), L.ptr(gamma),
-                                    L.ptr(sums), ctx.count, int(relu), None, None, L.stream()),
+                                    L.ptr(sums), ctx.count, int(relu), L.ptr(None if distributed else dg),
+                                    L.ptr(None if distributed else db), L.stream()),
                 "mi_bn_bwd_apply")
         if acc_g:
             gamma.grad.add_(dg)

@@ -235,6 +235,16 @@ int mi_bn_apply_fwd(const float* x, float* y, long M, int C, const double* sums,
                     const float* gamma, const float* beta, float eps, float momentum,
                     float* running_mean, float* running_var, long long* num_batches_tracked,
                     float* save_mean_invstd, const float* res, int relu, mi_stream_t stream);
+/* Small-M BatchNorm (M <= MI_BN_SMALL_MAX_ROWS: the BatchNorm1d layers of the projection MLPs,
+ * moco_encoder_3d.py:199-205, and feature_3d's BatchNorm3d) in one launch each way; same results as the split
+ * calls, which remain the path under SyncBN (the all-reduce sits between their halves). */
+#define MI_BN_SMALL_MAX_ROWS 4096
+int mi_bn_small_fwd(const float* x, float* y, long M, int C, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                    float* save_mean_invstd, const float* res, int relu, mi_stream_t stream);
+int mi_bn_small_bwd(const float* dy, const float* x, const float* y, float* dx, long M, int C,
+                    const float* save_mean_invstd, const float* gamma, int relu, float* dgamma, float* dbeta,
+                    mi_stream_t stream);
 int mi_bn_eval_fwd(const float* x, float* y, long M, int C, const float* running_mean,
                    const float* running_var, const float* gamma, const float* beta, float eps,
                    float* save_mean_invstd, const float* res, int relu, mi_stream_t stream);
