@@ -18,7 +18,9 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 // ---------------------------------------------------------------------------------------------
 // column reductions over [M][C] (C % 4 == 0, 256 % (C/4) == 0)
 // ---------------------------------------------------------------------------------------------
-enum { CR_STATS = 0, CR_BNBWD = 1, CR_SUM = 2 };
+enum { CR_STATS = 0, CR_BNBWD = 1, CR_SUM = 2, CR_BNBWD_X = 3 };
+
+struct PoolGeom { int N, Di, Hi, Wi, Do, Ho, Wo, k, s, pad; };
 
 struct ColReduceParams {
     const float* a;      // STATS: x ; BNBWD: dy ; SUM: dy
@@ -28,6 +30,9 @@ struct ColReduceParams {
     long M;
     int C, relu;
     double* partials;    // [gridDim.x][2][C]
+    // BNBWD_X: the ReLU mask is recomputed from x (y = relu(bn(x)) was never stored): y > 0 <=> xhat*gamma + beta > 0
+    const float* gamma;
+    const float* beta;
 };
 
 template <int MODE>
@@ -37,15 +42,32 @@ __global__ __launch_bounds__(256) void colreduce_kernel(ColReduceParams p) {
     const int RS = 256 / CV;
     float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     float mean[4] = {0, 0, 0, 0}, inv[4] = {1, 1, 1, 1};
-    if (MODE == CR_BNBWD) {
+    if (MODE == CR_BNBWD || MODE == CR_BNBWD_X) {
         float4 m = ld4(p.save + 4 * tcol), iv = ld4(p.save + p.C + 4 * tcol);
         mean[0] = m.x; mean[1] = m.y; mean[2] = m.z; mean[3] = m.w;
         inv[0] = iv.x; inv[1] = iv.y; inv[2] = iv.z; inv[3] = iv.w;
     }
     for (long r = (long)blockIdx.x * RS + trow; r < p.M; r += (long)gridDim.x * RS) {
         const long o = r * p.C + 4 * tcol;
+        float a[4];
+        if (MODE == CR_BNBWD_X) {
+            const float4 a4 = ld4(p.a + o);
+            a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
+            const float4 x4 = ld4(p.x + o);
+            const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+            const float4 g4 = p.gamma ? ld4(p.gamma + 4 * tcol) : make_float4(1, 1, 1, 1);
+            const float4 b4 = p.beta ? ld4(p.beta + 4 * tcol) : make_float4(0, 0, 0, 0);
+            const float g[4] = {g4.x, g4.y, g4.z, g4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xh = (x[i] - mean[i]) * inv[i];
+                const float d = fmaf(xh, g[i], b[i]) > 0.f ? a[i] : 0.f;       // ReLU mask from the recomputed y
+                s0[i] += d; s1[i] = fmaf(d, xh, s1[i]);
+            }
+            continue;
+        }
         float4 a4 = ld4(p.a + o);
-        float a[4] = {a4.x, a4.y, a4.z, a4.w};
+        a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
         if (MODE == CR_STATS) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { s0[i] += a[i]; s1[i] = fmaf(a[i], a[i], s1[i]); }
@@ -181,6 +203,115 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, float* y,
         if (res) { float4 r = ld4(res + 4 * i); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         st4(y + 4 * i, o);
+    }
+}
+
+// ---- stem: BatchNorm + ReLU + MaxPool3d fused (moco_encoder_3d.py:170-172, :355-358).  y = relu(bn(x)) is
+// never written: the forward pools bn(x) on the fly, the backward gathers d(pool) through the argmax taps and
+// recomputes the ReLU mask from x.  Saves a write + three reads of the largest activation of the step (67 MB).
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float* x, float* y, uint8_t* arg, PoolGeom g,
+                                                                 int C, const double* sums, double count, float eps,
+                                                                 float momentum, float* running_mean,
+                                                                 float* running_var, long long* num_batches_tracked,
+                                                                 float* save, const float* gamma, const float* beta) {
+    const int CV = C >> 2;
+    const int c = (int)(threadIdx.x % CV) * 4;                  // loop-invariant: 256 % CV == 0
+    float m[4], iv[4];
+    if (sums) {
+        const BnStat4 st = bn_stat4(sums, count, C, c, eps);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { m[k] = st.mean[k]; iv[k] = st.inv[k]; }
+        if (blockIdx.x == 0 && threadIdx.x < CV) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (save) { save[c + k] = m[k]; save[C + c + k] = iv[k]; }
+                if (running_mean) {
+                    const double unbiased = count > 1 ? st.var[k] * count / (count - 1.0) : st.var[k];
+                    running_mean[c + k] = (1.f - momentum) * running_mean[c + k] + momentum * m[k];
+                    running_var[c + k] = (1.f - momentum) * running_var[c + k] + momentum * (float)unbiased;
+                }
+            }
+            if (threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { m[k] = running_mean[c + k]; iv[k] = 1.0f / sqrtf(running_var[c + k] + eps); }
+    }
+    const float4 g4 = gamma ? ld4(gamma + c) : make_float4(1, 1, 1, 1);
+    const float4 b4 = beta ? ld4(beta + c) : make_float4(0, 0, 0, 0);
+    const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+    const long total = (long)g.N * g.Do * g.Ho * g.Wo * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long v = i / CV;
+        const int xo = (int)(v % g.Wo); v /= g.Wo;
+        const int yo = (int)(v % g.Ho); v /= g.Ho;
+        const int zo = (int)(v % g.Do);
+        const int n = (int)(v / g.Do);
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        bool first = true;
+        for (int a = 0; a < g.k; ++a) {
+            const int zi = zo * g.s - g.pad + a;
+            if ((unsigned)zi >= (unsigned)g.Di) continue;
+            for (int b = 0; b < g.k; ++b) {
+                const int yi = yo * g.s - g.pad + b;
+                if ((unsigned)yi >= (unsigned)g.Hi) continue;
+                for (int cc = 0; cc < g.k; ++cc) {
+                    const int xi = xo * g.s - g.pad + cc;
+                    if ((unsigned)xi >= (unsigned)g.Wi) continue;
+                    const float4 t4 = ld4(x + ((((long)n * g.Di + zi) * g.Hi + yi) * g.Wi + xi) * C + c);
+                    const float xv[4] = {t4.x, t4.y, t4.z, t4.w};
+                    const int tap = (a * g.k + b) * g.k + cc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float t = fmaxf(fmaf((xv[q] - m[q]) * iv[q], gg[q], bb[q]), 0.f);
+                        const float tn = xv[q] != xv[q] ? xv[q] : t;          // a NaN input stays a NaN
+                        if (first || tn > best[q] || tn != tn) { best[q] = tn; bi[q] = tap; }
+                    }
+                    first = false;
+                }
+            }
+        }
+        st4(y + 4 * i, make_float4(best[0], best[1], best[2], best[3]));
+        if (arg) *reinterpret_cast<uchar4*>(arg + 4 * i) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+    }
+}
+
+// dx = gamma*invstd*(dy' - sum_dy/count - xhat*sum_dyxhat/count) with dy' = dy * [xhat*gamma + beta > 0]: the backward of
+// relu(bn(x)) when relu(bn(x)) was not stored
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_x_kernel(const float* dy, const float* x, float* dx, long n4, int C,
+                                                                 const float* save, const float* gamma, const float* beta,
+                                                                 const double* sums, double count, float* dgamma,
+                                                                 float* dbeta) {
+    const int CV = C >> 2;
+    const int c = (int)(threadIdx.x % CV) * 4;
+    const float rc = (float)(1.0 / count);
+    float mean[4], inv[4], gi[4], gg[4], bb[4], sdy[4], sdx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mean[k] = save[c + k]; inv[k] = save[C + c + k];
+        gg[k] = gamma ? gamma[c + k] : 1.f; bb[k] = beta ? beta[c + k] : 0.f;
+        gi[k] = gg[k] * inv[k];
+        sdy[k] = (float)sums[c + k] * rc; sdx[k] = (float)sums[C + c + k] * rc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < CV) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (dbeta) dbeta[c + k] = (float)sums[c + k];
+            if (dgamma) dgamma[c + k] = (float)sums[C + c + k];
+        }
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 d4 = ld4(dy + 4 * i), x4 = ld4(x + 4 * i);
+        const float d[4] = {d4.x, d4.y, d4.z, d4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xv[k] - mean[k]) * inv[k];
+            const float dm = fmaf(xh, gg[k], bb[k]) > 0.f ? d[k] : 0.f;
+            o[k] = gi[k] * (dm - sdy[k] - xh * sdx[k]);
+        }
+        st4(dx + 4 * i, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -699,6 +830,55 @@ extern "C" int mi_bn_apply_fwd(const float* x, float* y, long M, int C, const do
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, x, y, n4, C, sums, count, eps,
                        momentum, running_mean, running_var, num_batches_tracked, save_mean_invstd, gamma,
                        beta, res, relu);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+static bool pool_geom(int N, int Di, int Hi, int Wi, int k, int stride, int pad, PoolGeom* g) {
+    if (N <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || k <= 0 || k > 6 || stride <= 0 || pad < 0) return false;
+    const int Do = (Di + 2 * pad - k) / stride + 1, Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
+    if (Do <= 0 || Ho <= 0 || Wo <= 0) return false;
+    *g = PoolGeom{N, Di, Hi, Wi, Do, Ho, Wo, k, stride, pad};
+    return true;
+}
+
+/* relu(bn(x)) pooled by MaxPool3d(k, stride, pad) without materialising relu(bn(x)).  `sums`/`count` as for
+ * mi_bn_apply_fwd (sums == NULL: eval mode, running statistics). */
+extern "C" int mi_bn_relu_maxpool3d_fwd(const float* x, float* y, uint8_t* argmax, int N, int Di, int Hi, int Wi, int C,
+                                        int k, int stride, int pad, const double* sums, double count,
+                                        const float* gamma, const float* beta, float eps, float momentum,
+                                        float* running_mean, float* running_var, long long* num_batches_tracked,
+                                        float* save_mean_invstd, mi_stream_t stream) {
+    PoolGeom g;
+    if (!x || !y || !colreduce_ok(C) || !pool_geom(N, Di, Hi, Wi, k, stride, pad, &g)) return MI_E_ARG;
+    if (sums ? (!save_mean_invstd || !(count > 0)) : (!running_mean || !running_var)) return MI_E_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return MI_E_ARG;
+    const long total = (long)N * g.Do * g.Ho * g.Wo * (C / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax,
+                       g, C, sums, count, eps, momentum, running_mean, running_var, num_batches_tracked,
+                       save_mean_invstd, gamma, beta);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+/* backward of relu(bn(x)) when the activation was not stored (the ReLU mask is recomputed from x): the two halves,
+ * with the SyncBN all-reduce of `sums` between them.  dy = gradient behind the ReLU (here: mi_maxpool3d_bwd's output). */
+extern "C" int mi_bn_relu_bwd_reduce_x(const float* dy, const float* x, long M, int C, const float* save_mean_invstd,
+                                       const float* gamma, const float* beta, double* sums, void* ws, size_t ws_bytes,
+                                       mi_stream_t stream) {
+    if (!dy || !x || !save_mean_invstd || !sums) return MI_E_ARG;
+    ColReduceParams p = {};
+    p.a = dy; p.x = x; p.save = save_mean_invstd; p.M = M; p.C = C; p.gamma = gamma; p.beta = beta;
+    return run_colreduce<CR_BNBWD_X>(p, sums, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mi_bn_relu_bwd_apply_x(const float* dy, const float* x, float* dx, long M, int C,
+                                      const float* save_mean_invstd, const float* gamma, const float* beta,
+                                      const double* sums, double count, float* dgamma, float* dbeta, mi_stream_t stream) {
+    if (!dy || !x || !dx || !save_mean_invstd || !sums || !colreduce_ok(C) || M <= 0 || !(count > 0)) return MI_E_ARG;
+    const long n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_x_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, n4, C,
+                       save_mean_invstd, gamma, beta, sums, count, dgamma, dbeta);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

@@ -526,6 +526,91 @@ class _BNFn(torch.autograd.Function):
         return dx, None, None, None, None, dres
 
 
+class _BNReluPoolFn(torch.autograd.Function):
+    """MaxPool3d(k, s, p)(relu(bn(x))) without materialising relu(bn(x)): the stem of the 3-D encoder."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mod, k, stride, pad):
+        n, d, h, w, c = x.shape
+        lib = L.lib()
+        dev = x.device
+        do, ho, wo = [(v + 2 * pad - k) // stride + 1 for v in (d, h, w)]
+        y = torch.empty((n, do, ho, wo, c), dtype=torch.float32, device=dev)
+        save = torch.empty(2 * c, dtype=torch.float32, device=dev)
+        train = mod.training or not mod.track_running_stats
+        arg = torch.empty((n, do, ho, wo, c), dtype=torch.uint8, device=dev) if (train and x.requires_grad) else None
+        m = n * d * h * w
+        count = float(m)
+        sums = None
+        if train:
+            ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
+            sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+            L.check(lib.mi_bn_stats(L.ptr(x), m, c, L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()), "mi_bn_stats")
+            if mod.sync and _dist_world() > 1:
+                import torch.distributed as dist
+                dist.all_reduce(sums)
+                count = float(m) * _dist_world()
+        track = mod.track_running_stats and mod.training
+        use_running = not train
+        L.check(lib.mi_bn_relu_maxpool3d_fwd(
+            L.ptr(x), L.ptr(y), L.ptr(arg), n, d, h, w, c, k, stride, pad, L.ptr(sums), count, L.ptr(gamma), L.ptr(beta),
+            mod.eps, mod.momentum, L.ptr(mod.running_mean if (track or use_running) else None),
+            L.ptr(mod.running_var if (track or use_running) else None),
+            L.ptr(mod.num_batches_tracked if track else None), L.ptr(save), L.stream()), "mi_bn_relu_maxpool3d_fwd")
+        ctx.mod, ctx.geom, ctx.count, ctx.train = mod, (n, d, h, w, c, k, stride, pad), count, train
+        ctx.save_for_backward(x, save, arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, save, arg = ctx.saved_tensors
+        if not ctx.train or arg is None:
+            raise L.HipExtensionError("fused BatchNorm+ReLU+MaxPool backward needs a training-mode forward")
+        mod = ctx.mod
+        n, d, h, w, c, k, stride, pad = ctx.geom
+        lib = L.lib()
+        dev = x.device
+        dp = dp.contiguous()
+        m = n * d * h * w
+        # gradient behind the ReLU: the pool's backward (materialised once; gathering it inside both BatchNorm passes
+        # was measured slower), then BatchNorm's two halves with the ReLU mask recomputed from x
+        dy = torch.empty_like(x)
+        L.check(lib.mi_maxpool3d_bwd(L.ptr(dp), L.ptr(arg), L.ptr(dy), n, d, h, w, c, k, stride, pad, L.stream()),
+                "mi_maxpool3d_bwd")
+        ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
+        sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+        gamma, beta = mod.weight, mod.bias
+        L.check(lib.mi_bn_relu_bwd_reduce_x(L.ptr(dy), L.ptr(x), m, c, L.ptr(save), L.ptr(gamma), L.ptr(beta), L.ptr(sums),
+                                            L.ptr(ws), ws.numel(), L.stream()), "mi_bn_relu_bwd_reduce_x")
+        dg = db = None
+        acc_g = acc_b = False
+        if gamma is not None and gamma.requires_grad:
+            gt, acc_g = _grad_target(gamma)
+            dg = torch.empty_like(gt) if acc_g else gt
+            bt, acc_b = _grad_target(beta)
+            db = torch.empty_like(bt) if acc_b else bt
+        distributed = mod.sync and _dist_world() > 1
+        if distributed:
+            if dg is not None:           # affine gradients from the LOCAL sums, like torch.nn.SyncBatchNorm
+                L.check(lib.mi_bn_param_grads(L.ptr(sums), c, L.ptr(dg), L.ptr(db), L.stream()), "mi_bn_param_grads")
+            import torch.distributed as dist
+            dist.all_reduce(sums)
+        dx = dy                                            # in place: each element is read, then written, by one thread
+        L.check(lib.mi_bn_relu_bwd_apply_x(L.ptr(dy), L.ptr(x), L.ptr(dx), m, c, L.ptr(save), L.ptr(gamma), L.ptr(beta),
+                                           L.ptr(sums), ctx.count, L.ptr(None if distributed else dg),
+                                           L.ptr(None if distributed else db), L.stream()), "mi_bn_relu_bwd_apply_x")
+        if acc_g:
+            gamma.grad.add_(dg)
+        if acc_b:
+            beta.grad.add_(db)
+        return dx, None, None, None, None, None, None
+
+
+def bn_relu_maxpool3d(x, bn, k, stride, pad):
+    """maxpool3d(bn(x, relu=True), k, stride, pad) as one fused layer (bn: HipBatchNorm)."""
+    return _BNReluPoolFn.apply(_f32c(x, "x"), bn.weight, bn.bias, bn, k, stride, pad)
+
+
 class HipBatchNorm(nn.Module):
     """nn.BatchNorm3d / nn.BatchNorm1d over the last (channel) axis, optional fused ReLU."""
 

@@ -105,8 +105,8 @@ class TomoResClassifier3D(nn.Module):
             raise ValueError("the moco3d encoder takes single-channel sub-tomograms (B,1,D,H,W)")
         x = x1.contiguous().float().view(b, d, h, w, 1)      # C == 1: NCDHW is already channels-last
         x = self.conv1(x)
-        x = self.bn1(x, relu=True)
-        x = self._mark(H.maxpool3d(x, 3, 2, 1), "layer1")     # its gradient exists => layer1.. are done
+        # bn1 + ReLU + MaxPool3d(3, 2, 1) as one fused layer: relu(bn(x)), the largest activation, is never stored
+        x = self._mark(H.bn_relu_maxpool3d(x, self.bn1, 3, 2, 1), "layer1")     # its gradient exists => layer1.. are done
         for blk in self.layer1:
             x = blk(x)
         x = self._mark(x, "layer2")

@@ -235,6 +235,21 @@ int mi_bn_apply_fwd(const float* x, float* y, long M, int C, const double* sums,
                     const float* gamma, const float* beta, float eps, float momentum,
                     float* running_mean, float* running_var, long long* num_batches_tracked,
                     float* save_mean_invstd, const float* res, int relu, mi_stream_t stream);
+/* The stem's BatchNorm3d + ReLU + MaxPool3d(3, 2, 1) (moco_encoder_3d.py:170-172) fused: relu(bn(x)) is never
+ * written.  fwd: after mi_bn_stats (+ SyncBN all-reduce); sums == NULL = eval mode.  x (N,Di,Hi,Wi,C), pooled
+ * (N,Do,Ho,Wo,C), argmax uint8.  bwd: mi_maxpool3d_bwd, then the two halves below (gathering the pooled gradient
+ * inside the BatchNorm passes was measured 100 us slower: the gather would run twice). */
+int mi_bn_relu_maxpool3d_fwd(const float* x, float* y, uint8_t* argmax, int N, int Di, int Hi, int Wi, int C, int k,
+                             int stride, int pad, const double* sums, double count, const float* gamma,
+                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                             long long* num_batches_tracked, float* save_mean_invstd, mi_stream_t stream);
+/* Backward of relu(bn(x)) without the stored activation (mask recomputed from x); dy = mi_maxpool3d_bwd's output. */
+int mi_bn_relu_bwd_reduce_x(const float* dy, const float* x, long M, int C, const float* save_mean_invstd,
+                            const float* gamma, const float* beta, double* sums, void* ws, size_t ws_bytes,
+                            mi_stream_t stream);
+int mi_bn_relu_bwd_apply_x(const float* dy, const float* x, float* dx, long M, int C, const float* save_mean_invstd,
+                           const float* gamma, const float* beta, const double* sums, double count, float* dgamma,
+                           float* dbeta, mi_stream_t stream);
 /* Small-M BatchNorm (M <= MI_BN_SMALL_MAX_ROWS: the BatchNorm1d layers of the projection MLPs,
  * moco_encoder_3d.py:199-205, and feature_3d's BatchNorm3d) in one launch each way; same results as the split
  * calls, which remain the path under SyncBN (the all-reduce sits between their halves). */

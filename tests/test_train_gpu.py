@@ -299,3 +299,37 @@ def test_moco_three_steps_match_reference(golden):
                 dst[n] = t.detach().cpu().contiguous().clone()
         ref.queue = moco.queue.cpu().clone()
     np.testing.assert_allclose(moco.encoder_k.fc.weight.detach().cpu().numpy(), g["k_fc_weight"], rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape,train", [((3, 10, 12, 14, 16), True), ((2, 9, 7, 8, 64), True), ((2, 8, 8, 8, 16), False)])
+def test_fused_bn_relu_maxpool_matches_unfused(shape, train):
+    """stem fusion: maxpool3d(relu(bn(x))) forward / backward against torch (BatchNorm3d + ReLU + MaxPool3d)."""
+    import numpy as np
+    from cet_pick_amd import hipops as H
+    n, d, h, w, c = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, c, d, h, w, generator=g) * 2 + 0.5
+    bn_ref = torch.nn.BatchNorm3d(c)
+    with torch.no_grad():
+        bn_ref.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn_ref.bias.copy_(torch.randn(c, generator=g) * 0.3)
+        bn_ref.running_mean.copy_(torch.randn(c, generator=g) * 0.1)
+        bn_ref.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+    bn = H.HipBatchNorm(c)
+    bn.load_state_dict(bn_ref.state_dict())
+    bn = bn.cuda()
+    bn_ref.train(train); bn.train(train)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.max_pool3d(torch.relu(bn_ref(xr)), 3, 2, 1)
+    xc = x.permute(0, 2, 3, 4, 1).contiguous().cuda().requires_grad_(train)
+    y = H.bn_relu_maxpool3d(xc, bn, 3, 2, 1)
+    np.testing.assert_allclose(y.detach().permute(0, 4, 1, 2, 3).cpu().numpy(), yr.detach().numpy(), rtol=1e-5, atol=1e-5)
+    if train:
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy)
+        y.backward(dy.permute(0, 2, 3, 4, 1).contiguous().cuda())
+        np.testing.assert_allclose(xc.grad.permute(0, 4, 1, 2, 3).cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), bn_ref.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), bn_ref.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), bn_ref.running_var.numpy(), rtol=1e-5, atol=1e-6)
+        assert int(bn.num_batches_tracked) == 1
