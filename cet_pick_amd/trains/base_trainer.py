@@ -33,6 +33,20 @@ class ModelWithLossSimSiam(torch.nn.Module):
         return outputs, loss, loss_stats
 
 
+class ModelWithLossSimSiam2D3D(torch.nn.Module):
+    """base_trainer.py:113-122: tilt-series and tomogram patches of both views."""
+
+    def __init__(self, model, loss):
+        super().__init__()
+        self.model = model
+        self.loss = loss
+
+    def forward(self, batch, epoch, phase):
+        outputs = self.model(batch["input"], batch["input_3d"], batch["input_aug"], batch["input_aug_3d"])
+        loss, loss_stats = self.loss(outputs, batch, epoch)
+        return outputs, loss, loss_stats
+
+
 class ModelWithLoss(torch.nn.Module):
     """base_trainer.py:134-154: the detector tasks - two forward passes (input and its augmented view) in training,
     one without gradients (and in eval mode) otherwise."""
@@ -63,6 +77,8 @@ class BaseTrainer(object):
         self.iter = 0
         if opt.task in ("simsiam", "moco", "simsiam3d"):
             self.model_with_loss = ModelWithLossSimSiam(model, self.loss)
+        elif opt.task == "simsiam2d3d":
+            self.model_with_loss = ModelWithLossSimSiam2D3D(model, self.loss)
         elif opt.task in ("semi", "tomo", "semi3d"):
             self.model_with_loss = ModelWithLoss(model, self.loss)
         else:

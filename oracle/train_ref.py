@@ -241,3 +241,29 @@ def simsiam2d3d_forward(sd, x1_2d, x1_3d, x2_2d, x2_3d, train=True):
         return F.linear(p, sd["pred.3.weight"], sd["pred.3.bias"])
     z1, z2 = proj(f1), proj(f2)
     return pred(z1), z1, pred(z2), z2
+
+
+# ------------------------------------------------------------------------------------------------
+# symmetric MoCo (trains/tomo_moco_small_trainer.py:24-161).  That module needs `progress`, `cv2` and
+# `pytorch_metric_learning` (absent): restated from source, PARITY UNPINNED.
+# ------------------------------------------------------------------------------------------------
+def symmetric_moco_step(sd_q, sd_k, queue, ptr, im1, im2, m, T):
+    """One forward of MoCoModel(symmetric=True) with moco3d encoders: returns loss, new key state dict, queue, ptr."""
+    names = param_names(sd_q)
+    sd_k = dict(sd_k)
+    for n in names:
+        sd_k[n] = sd_k[n] * m + sd_q[n].detach() * (1.0 - m)
+
+    def side(a, b):
+        q = F.normalize(encoder_forward(sd_q, a, train=True), dim=1)
+        with torch.no_grad():
+            k = F.normalize(encoder_forward(sd_k, b, train=True), dim=1)
+        logits = moco_logits(q, k, queue, T)
+        return F.cross_entropy(logits, torch.zeros(logits.shape[0], dtype=torch.long)), k
+    l12, k2 = side(im1, im2)
+    l21, k1 = side(im2, im1)
+    keys = torch.cat([k1, k2], 0)
+    queue = queue.clone()
+    n = keys.shape[0]
+    queue[:, ptr:ptr + n] = keys.t()
+    return l12 + l21, sd_k, queue, (ptr + n) % queue.shape[1]

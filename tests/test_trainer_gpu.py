@@ -92,3 +92,57 @@ def test_semi_detector_trainer_two_steps_vs_oracle(tmp_path):
     assert np.isfinite(stats2["loss"])
     val, _ = trainer.val(2, [dict(batch)])
     assert np.isfinite(val["loss"]) and val["cr_loss"] == 0
+
+
+def test_symmetric_moco_variant_vs_oracle():
+    """MoCoModel(symmetric=True) - EMA first, loss in both directions, one enqueue of both key sets."""
+    import numpy as np
+    from oracle import train_ref as O
+    from cet_pick_amd.models.networks.moco_encoder_3d import get_moco_net_small_3d
+    from cet_pick_amd.synthetic import seeded_state_dict
+    from cet_pick_amd.trains.tomo_moco_small_trainer import MoCoModel, MoCoTrainer
+    from types import SimpleNamespace
+    heads = {"proj": 256, "pred": 256}
+    eq, ek = get_moco_net_small_3d(18, heads, 0), get_moco_net_small_3d(18, heads, 0)
+    sd0 = seeded_state_dict(eq, seed=330)
+    for kk in [k for k in sd0 if k.startswith("pred.")]:      # 'pred' re-registers the 'proj' module: one set of weights
+        sd0["proj." + kk[5:]] = sd0[kk]
+    eq.load_state_dict(sd0)
+    model = MoCoModel(eq, ek, dim=128, K=64, m=0.99, T=0.1, symmetric=True, shuffle=False).cuda().train()
+    g = torch.Generator().manual_seed(12)
+    im1, im2 = torch.randn(8, 1, 32, 32, 32, generator=g), torch.randn(8, 1, 32, 32, 32, generator=g)
+    queue0 = model.queue.cpu().clone()
+    sd_q = {k: v.clone().requires_grad_(k.endswith(O.PARAM_SUFFIX)) for k, v in sd0.items()}
+    sd_k = {k: v.clone() for k, v in sd0.items()}
+    ref_loss, ref_k, ref_queue, ref_ptr = O.symmetric_moco_step(sd_q, sd_k, queue0, 0, im1, im2, 0.99, 0.1)
+    ref_loss.backward()
+    loss, stats = model(im1.cuda(), im2.cuda())
+    loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 2e-4 * max(1.0, abs(float(ref_loss)))
+    assert int(model.queue_ptr) == ref_ptr == 16
+    np.testing.assert_allclose(model.queue.cpu().numpy(), ref_queue.numpy(), rtol=0, atol=2e-5)
+    for name, prm in model.encoder_q.named_parameters():
+        if name.startswith("pred."):
+            continue
+        rg = sd_q[name].grad
+        if float(rg.norm()) < 1e-5:          # fc.bias sits in front of a batch-statistics BatchNorm: exactly-zero gradient
+            assert float(prm.grad.norm()) < 1e-4, name
+            continue
+        err = float((prm.grad.cpu().double() - rg.double()).norm() / (rg.double().norm() + 1e-12))
+        assert err < 5e-3, (name, err)
+    for name, prm in model.encoder_k.named_parameters():
+        np.testing.assert_allclose(prm.detach().cpu().numpy(), ref_k[name].numpy(), rtol=0, atol=1e-6)
+    # shuffle on: same loss up to summation order (BatchNorm statistics do not depend on the row order)
+    model2 = MoCoModel(get_moco_net_small_3d(18, heads, 0), get_moco_net_small_3d(18, heads, 0), dim=128, K=64, m=0.99,
+                       T=0.1, symmetric=True, shuffle=True)
+    model2.encoder_q.load_state_dict(sd0); model2.encoder_k.load_state_dict(sd0)
+    model2.queue.copy_(queue0)
+    model2 = model2.cuda().train()
+    loss2, _ = model2(im1.cuda(), im2.cuda())
+    assert abs(float(loss2) - float(ref_loss)) < 1e-3 * max(1.0, abs(float(ref_loss)))
+    # trainer entry points
+    opt = SimpleNamespace(task="moco2d", num_iters=-1, print_iter=0, hide_data_time=True, exp_id="t", lr=1e-3, hipgraph=False)
+    tr = MoCoTrainer(opt, model2, torch.optim.SGD(model2.encoder_q.parameters(), lr=1e-3))
+    tr.set_device([0], None, "cuda")
+    ret, _ = tr.train(1, [{"input": im1, "input_aug": im2}])
+    assert set(ret) == {"loss", "moco_loss", "time"} and np.isfinite(ret["loss"])
