@@ -46,7 +46,13 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
 constexpr int NTHREADS = 256;
-constexpr int MAX_CLASSES = 8;     // stride <= 2 per axis
+constexpr int MAX_CLASSES = 27;    // parity classes (stride 2: 8) or border classes (3 runs per axis: 27)
+
+// Border class: a box of row positions (pos0 .. pos0+cnt-1 per axis) that all see the same valid tap range
+// (tlo .. tlo+tcnt-1 per axis).  Rows next to the zero padding multiply zeros for the taps that fall outside the
+// tensor (a 3^3 window on a 2^3 volume: 19 of 27 taps); grouping rows by border class removes those taps from the
+// reduction altogether instead of gathering zeros for them.
+struct BorderClass { short pos0[3], cnt[3], tlo[3], tcnt[3]; };
 constexpr int LUT_TAPS = 352;      // 7^3 = 343 rounded up to a multiple of 32
 constexpr int LUT_INVALID = 0x070707;   // bit 7 of a per-axis mask byte is never set (k <= 7)
 
@@ -70,8 +76,12 @@ struct ConvParams {
     int splits;
     long slab_stride;              // elements between split-K slabs (0: direct epilogue)
     long n_red_vox;                // WGRAD: reduction length in voxels
-    int n_classes;                 // DGRAD: stride^3 parity classes (1 otherwise)
+    int n_classes;                 // row classes (1: none): DGRAD stride^3 parity classes, or border classes
+    int border;                    // 1: the classes are border classes (FWD, stride-1 DGRAD), table below
     int cls_tile_start[MAX_CLASSES + 1];
+    BorderClass bcls[MAX_CLASSES];
+    int ny_tiles;                  // column tiles; the grid is 1-D: (row tile, column tile, split) linearised
+    int fold;                      // pair the two ends of the work list on a CU (class launches)
 };
 
 // All gathers are raw buffer loads: 32-bit byte offset against a descriptor of the whole tensor.  An offset
@@ -164,22 +174,48 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, l32 = lane & 31;
-    const int n0 = blockIdx.y * BN;
+    // 1-D grid -> (row tile, column tile, split).  Class launches carry tiles of very different reduction lengths
+    // and every workgroup is co-resident (two per CU: block L shares its CU with block L + 256), so consecutive
+    // groups of 256 blocks walk the work list (heaviest class first) from opposite ends: heavy tiles pair with light.
+    int blk_x, blk_y, blk_z;
+    {
+        const int total = gridDim.x, L = blockIdx.x;
+        int q = L;
+        if (p.fold) {
+            const int g = L >> 8, r = L & 255, m = g >> 1;
+            q = (g & 1) ? total - 1 - (m * 256 + r) : m * 256 + r;
+        }
+        const int per = p.ny_tiles * p.splits;
+        blk_x = q / per;
+        const int rem = q - blk_x * per;
+        blk_y = rem % p.ny_tiles;
+        blk_z = rem / p.ny_tiles;
+    }
+    const int n0 = blk_y * BN;
     const int Kz = p.kd, Ky = p.kh, Kx = p.kw, S = p.stride, Pz = p.pd, Py = p.ph, Px = p.pw;
     const int taps = Kz * Ky * Kx;
     const int Lz = p.dd, Ly = p.dh, Lx = p.dw;        // dilation
 
     // ---- which rows does this workgroup own? ---------------------------------------------------
     int cls = 0;
-    if (MODE == MODE_DGRAD && p.n_classes > 1) {
-        while (cls + 1 < p.n_classes && (int)blockIdx.x >= p.cls_tile_start[cls + 1]) ++cls;
+    if (MODE != MODE_WGRAD && p.n_classes > 1) {
+        while (cls + 1 < p.n_classes && blk_x >= p.cls_tile_start[cls + 1]) ++cls;
     }
-    const long tile_in_cls = (long)blockIdx.x - ((MODE == MODE_DGRAD) ? p.cls_tile_start[cls] : 0);
+    const long tile_in_cls = (long)blk_x - ((MODE != MODE_WGRAD) ? p.cls_tile_start[cls] : 0);
     const long m0 = tile_in_cls * BM;                 // first row (within the class for DGRAD)
     // DGRAD class geometry (stride 1: a single class with cz = cy = cx = 0)
     int cz = 0, cy = 0, cx = 0, zf = 0, yf = 0, xf = 0, Dz = p.Dr, Dy = p.Hr, Dx = p.Wr;
     int nz = Kz, ny = Ky, nx = Kx;                    // taps of the class per axis
-    if (MODE == MODE_DGRAD) {
+    int ta0 = 0, tb0 = 0, tc0 = 0, tstep = 1;         // tap index of the class's i-th tap: t0 + tstep * i
+    int pz0 = 0, py0 = 0, px0 = 0;                    // border class: first row position per axis
+    const bool border = (MODE != MODE_WGRAD) && p.border;
+    if (border) {
+        const BorderClass bc = p.bcls[cls];
+        pz0 = bc.pos0[0]; py0 = bc.pos0[1]; px0 = bc.pos0[2];
+        Dz = bc.cnt[0]; Dy = bc.cnt[1]; Dx = bc.cnt[2];
+        ta0 = bc.tlo[0]; tb0 = bc.tlo[1]; tc0 = bc.tlo[2];
+        nz = bc.tcnt[0]; ny = bc.tcnt[1]; nx = bc.tcnt[2];
+    } else if (MODE == MODE_DGRAD) {
         cz = cls / (S * S); cy = (cls / S) % S; cx = cls % S;
         zf = ((cz - Pz) % S + S) % S; yf = ((cy - Py) % S + S) % S; xf = ((cx - Px) % S + S) % S;
         Dz = zf < p.Dr ? (p.Dr - zf + S - 1) / S : 0;
@@ -188,8 +224,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
         nz = cz < Kz ? (Kz - cz + S - 1) / S : 0;
         ny = cy < Ky ? (Ky - cy + S - 1) / S : 0;
         nx = cx < Kx ? (Kx - cx + S - 1) / S : 0;
+        ta0 = cz; tb0 = cy; tc0 = cx; tstep = S;
     }
-    const long M_here = (MODE == MODE_DGRAD) ? (long)p.N * Dz * Dy * Dx : p.M;
+    const long M_here = (MODE == MODE_DGRAD || border) ? (long)p.N * Dz * Dy * Dx : p.M;
 
     // ---- reduction extent of this workgroup ----------------------------------------------------
     int nk;
@@ -197,7 +234,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     else if (STEM) nk = (taps + BK - 1) / BK;
     else nk = nz * ny * nx * (((MODE == MODE_FWD) ? p.Ci : p.Co) / BK);
     const int nk_per_split = (nk + p.splits - 1) / p.splits;
-    const int kt0 = min((int)blockIdx.z * nk_per_split, nk);
+    const int kt0 = min(blk_z * nk_per_split, nk);
     const int kt1 = min(kt0 + nk_per_split, nk);
 
     if (STEM) {
@@ -234,11 +271,28 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
             if (m < M_here) {
                 if (MODE == MODE_FWD) {
                     int n, z, y, x;
-                    rdec((unsigned)m, n, z, y, x);
-                    const int zb = z * S - Pz, yb = y * S - Py, xb = x * S - Px;
-                    a_msk[i] = axis_mask(zb, Lz, Kz, p.Dg) | (axis_mask(yb, Ly, Ky, p.Hg) << 8) |
-                               (axis_mask(xb, Lx, Kx, p.Wg) << 16);
+                    if (border) {
+                        cdec((unsigned)m, n, z, y, x);
+                        z += pz0; y += py0; x += px0;
+                        if (c == 0) rowmap[row] = (((long)n * p.Dr + z) * p.Hr + y) * p.Wr + x;
+                    } else {
+                        rdec((unsigned)m, n, z, y, x);
+                    }
+                    // (border classes: the window starts at the class's first valid tap)
+                    const int zb = z * S - Pz + ta0 * Lz, yb = y * S - Py + tb0 * Ly, xb = x * S - Px + tc0 * Lx;
+                    a_msk[i] = axis_mask(zb, Lz, nz, p.Dg) | (axis_mask(yb, Ly, ny, p.Hg) << 8) |
+                               (axis_mask(xb, Lx, nx, p.Wg) << 16);
                     a_off[i] = 4u * (unsigned)(((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg + (STEM ? 0 : 4 * c));
+                } else if (border) {
+                    // stride-1 DGRAD: input voxel z receives dy[z + P - a*L] * w[a] for the class's taps a = ta0 + i
+                    int n, z, y, x;
+                    cdec((unsigned)m, n, z, y, x);
+                    z += pz0; y += py0; x += px0;
+                    const int zb = z + Pz - ta0 * Lz, yb = y + Py - tb0 * Ly, xb = x + Px - tc0 * Lx;
+                    a_msk[i] = axis_mask(zb, -Lz, nz, p.Dg) | (axis_mask(yb, -Ly, ny, p.Hg) << 8) |
+                               (axis_mask(xb, -Lx, nx, p.Wg) << 16);
+                    a_off[i] = 4u * (unsigned)(((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg + 4 * c);
+                    if (c == 0) rowmap[row] = (((long)n * p.Dr + z) * p.Hr + y) * p.Wr + x;
                 } else {
                     int n, jz, jy, jx;
                     cdec((unsigned)m, n, jz, jy, jx);
@@ -249,7 +303,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                     a_off[i] = 4u * (unsigned)(((((long)n * p.Dg + zb) * p.Hg + yb) * p.Wg + xb) * p.Cg + 4 * c);
                     if (c == 0 && p.n_classes > 1) rowmap[row] = (((long)n * p.Dr + z) * p.Hr + y) * p.Wr + x;
                 }
-            } else if (MODE == MODE_DGRAD && c == 0 && p.n_classes > 1) {
+            } else if (MODE != MODE_WGRAD && c == 0 && p.n_classes > 1) {
                 rowmap[row] = -1;
             }
         }
@@ -339,10 +393,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                 int wtap;
                 if (MODE == MODE_FWD) {
                     pt_aoff = 4u * (unsigned)(((long)(ia * Lz * p.Hg + ib * Ly) * p.Wg + ic * Lx) * p.Cg + c0);
-                    wtap = (ia * Ky + ib) * Kx + ic;
+                    wtap = ((ta0 + ia) * Ky + (tb0 + ib)) * Kx + (tc0 + ic);
                 } else {
                     pt_aoff = 4u * (unsigned)(-((long)(ia * Lz * p.Hg + ib * Ly) * p.Wg + ic * Lx) * p.Cg + c0);
-                    wtap = ((cz + S * ia) * Ky + (cy + S * ib)) * Kx + (cx + S * ic);
+                    wtap = ((ta0 + tstep * ia) * Ky + (tb0 + tstep * ib)) * Kx + (tc0 + tstep * ic);
                 }
                 // weights: FWD rows (wtap*Ci + c0 + k) of [.][Co]; DGRAD row (wtap*Ci + ci), cols c0 + k
                 const long bo = (MODE == MODE_FWD) ? ((long)wtap * p.Ci + c0) * p.Co : (long)wtap * p.Ci * p.Co + c0;
@@ -529,9 +583,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     if (kt < kt1) iteration(kt, 0, Set0{});
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* outp = p.out + (long)blockIdx.z * p.slab_stride;
+    float* outp = p.out + (long)blk_z * p.slab_stride;
     const bool direct = (p.slab_stride == 0);
-    const bool mapped = (MODE == MODE_DGRAD) && p.n_classes > 1;
+    const bool mapped = (MODE != MODE_WGRAD) && p.n_classes > 1;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -633,7 +687,7 @@ Plan make_plan(int mode, bool stem, long M, int Ncols, long red_len, int red_ch,
 
 template <int MODE, bool STEM>
 int launch_mode(const ConvParams& p, const Plan& pl, hipStream_t s) {
-    dim3 grid((unsigned)pl.tiles_x, (unsigned)((p.Ncols + pl.bn - 1) / pl.bn), pl.splits);
+    dim3 grid((unsigned)(pl.tiles_x * ((p.Ncols + pl.bn - 1) / pl.bn) * pl.splits));    // 1-D, decoded in the kernel
 #define MI_LAUNCH(BM_, BN_, BK_) \
     hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM_, BN_, BK_, STEM>), grid, dim3(NTHREADS), 0, s, p)
     if (pl.bn == 128 && !STEM) {           // 128-wide tiles only with 32-deep slices
@@ -691,7 +745,79 @@ void dgrad_class(const Geom& g, int c, long* rows, int* ntaps) {
     *rows = r; *ntaps = t;
 }
 
+// ---- border classes --------------------------------------------------------------------------------------------
+// Per axis: runs of consecutive row positions with the same valid tap range.  FWD: output o sees tap t iff
+// 0 <= o*S - P + t*L < in;  stride-1 DGRAD: input z gets tap a iff 0 <= z + P - a*L < out.
+struct AxisRun { int pos0, cnt, tlo, tcnt; };
+
+int axis_runs(int mode, int n_pos, int n_src, int K, int S, int P, int L, AxisRun* runs, int max_runs) {
+    int nr = 0;
+    for (int o = 0; o < n_pos; ++o) {
+        int lo = K, hi = -1;
+        for (int t = 0; t < K; ++t) {
+            const int src = (mode == MODE_FWD) ? o * S - P + t * L : o + P - t * L;
+            if (src >= 0 && src < n_src) { lo = std::min(lo, t); hi = std::max(hi, t); }
+        }
+        // a range with holes (possible with dilation) is kept whole: the per-row masks still zero the holes
+        const int tlo = hi < lo ? 0 : lo, tcnt = hi < lo ? 0 : hi - lo + 1;
+        if (nr && runs[nr - 1].tlo == tlo && runs[nr - 1].tcnt == tcnt) { ++runs[nr - 1].cnt; continue; }
+        if (nr == max_runs) return -1;
+        runs[nr++] = AxisRun{o, 1, tlo, tcnt};
+    }
+    return nr;
+}
+
+// fills p.bcls / p.n_classes / p.border; returns false when the layer has no padding to skip (or too many classes)
+bool build_border_classes(int mode, const Geom& g, ConvParams* p) {
+    if (g.Ci == 1 || (mode == MODE_DGRAD && g.stride != 1) || mode == MODE_WGRAD) return false;
+    if (env_int("MI_CONV_NO_BORDER")) return false;
+    AxisRun rz[3], ry[3], rx[3];
+    const bool f = (mode == MODE_FWD);
+    const int nz = axis_runs(mode, f ? g.Do : g.Di, f ? g.Di : g.Do, g.kd, g.stride, g.pd, g.dd, rz, 3);
+    const int ny = axis_runs(mode, f ? g.Ho : g.Hi, f ? g.Hi : g.Ho, g.kh, g.stride, g.ph, g.dh, ry, 3);
+    const int nx = axis_runs(mode, f ? g.Wo : g.Wi, f ? g.Wi : g.Wo, g.kw, g.stride, g.pw, g.dw, rx, 3);
+    if (nz < 1 || ny < 1 || nx < 1 || nz * ny * nx < 2) return false;       // -1: more than 3 runs on an axis
+    int n = 0;
+    for (int a = 0; a < nz; ++a)
+        for (int b = 0; b < ny; ++b)
+            for (int c = 0; c < nx; ++c) {
+                BorderClass& bc = p->bcls[n++];
+                bc.pos0[0] = (short)rz[a].pos0; bc.pos0[1] = (short)ry[b].pos0; bc.pos0[2] = (short)rx[c].pos0;
+                bc.cnt[0] = (short)rz[a].cnt; bc.cnt[1] = (short)ry[b].cnt; bc.cnt[2] = (short)rx[c].cnt;
+                bc.tlo[0] = (short)rz[a].tlo; bc.tlo[1] = (short)ry[b].tlo; bc.tlo[2] = (short)rx[c].tlo;
+                bc.tcnt[0] = (short)rz[a].tcnt; bc.tcnt[1] = (short)ry[b].tcnt; bc.tcnt[2] = (short)rx[c].tcnt;
+            }
+    // heaviest reduction first (the kernel pairs the two ends of the list on a CU)
+    std::stable_sort(p->bcls, p->bcls + n, [](const BorderClass& u, const BorderClass& v) {
+        return u.tcnt[0] * u.tcnt[1] * u.tcnt[2] > v.tcnt[0] * v.tcnt[1] * v.tcnt[2];
+    });
+    p->n_classes = n;
+    p->border = 1;
+    return true;
+}
+
 struct Setup { ConvParams p; Plan pl; };
+
+// plan + tile table of a border-class launch; red_ch = channels of the reduction (FWD: Ci, DGRAD: Co)
+void plan_border(Setup* st, int N, int red_ch, int mode, bool stem) {
+    ConvParams& p = st->p;
+    const int nc = p.n_classes;
+    long rows[MAX_CLASSES], taps_c[MAX_CLASSES];
+    for (int c = 0; c < nc; ++c) {
+        const BorderClass& b = p.bcls[c];
+        rows[c] = (long)N * b.cnt[0] * b.cnt[1] * b.cnt[2];
+        taps_c[c] = (long)b.tcnt[0] * b.tcnt[1] * b.tcnt[2];
+    }
+    auto tiles_of = [&](int bm) { long t = 0; for (int c = 0; c < nc; ++c) t += (rows[c] + bm - 1) / bm; return t; };
+    // reduction length seen by the split model: the tile-weighted mean over the classes
+    long tw = 0, tt = 0;
+    for (int c = 0; c < nc; ++c) { const long t = (rows[c] + 63) / 64; tw += t * taps_c[c]; tt += t; }
+    const long mean_taps = std::max<long>(1, (tw + tt - 1) / std::max<long>(tt, 1));
+    st->pl = make_plan(mode, stem, p.M, p.Ncols, mean_taps * red_ch, red_ch, tiles_of);
+    long acc = 0;
+    for (int c = 0; c < nc; ++c) { p.cls_tile_start[c] = (int)acc; acc += (rows[c] + st->pl.bm - 1) / st->pl.bm; }
+    p.cls_tile_start[nc] = (int)acc;
+}
 
 int setup_conv(int mode, const Geom& g, Setup* st) {
     ConvParams& p = st->p;
@@ -708,7 +834,16 @@ int setup_conv(int mode, const Geom& g, Setup* st) {
         p.Dr = g.Do; p.Hr = g.Ho; p.Wr = g.Wo;
         p.M = Mout; p.Ncols = g.Co;
         const long M = p.M;
-        st->pl = make_plan(mode, stem, p.M, p.Ncols, (long)taps * g.Ci, stem ? 0 : g.Ci, [M](int bm) { return (M + bm - 1) / bm; });
+        if (build_border_classes(mode, g, &p)) {
+            plan_border(st, g.N, g.Ci, mode, stem);
+        } else {
+            st->pl = make_plan(mode, stem, p.M, p.Ncols, (long)taps * g.Ci, stem ? 0 : g.Ci, [M](int bm) { return (M + bm - 1) / bm; });
+        }
+    } else if (mode == MODE_DGRAD && build_border_classes(mode, g, &p)) {
+        p.Dg = g.Do; p.Hg = g.Ho; p.Wg = g.Wo; p.Cg = g.Co;
+        p.Dr = g.Di; p.Hr = g.Hi; p.Wr = g.Wi;
+        p.M = Min; p.Ncols = g.Ci;
+        plan_border(st, g.N, g.Co, mode, stem);
     } else if (mode == MODE_DGRAD) {
         if (stem) return MI_E_UNSUPPORTED;    // the stem's input is the image: no data gradient
         p.Dg = g.Do; p.Hg = g.Ho; p.Wg = g.Wo; p.Cg = g.Co;
@@ -737,6 +872,8 @@ int setup_conv(int mode, const Geom& g, Setup* st) {
     if (ab >= 0x7fff0000l || bb >= 0x7fff0000l) return MI_E_UNSUPPORTED;   // split the batch on the host side
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.splits = st->pl.splits;
+    p.ny_tiles = (p.Ncols + st->pl.bn - 1) / st->pl.bn;
+    p.fold = (p.n_classes > 1 && !env_int("MI_CONV_NO_FOLD")) ? 1 : 0;
     return MI_OK;
 }
 
