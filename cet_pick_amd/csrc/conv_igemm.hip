@@ -82,6 +82,7 @@ struct ConvParams {
     BorderClass bcls[MAX_CLASSES];
     int ny_tiles;                  // column tiles; the grid is 1-D: (row tile, column tile, split) linearised
     int fold;                      // pair the two ends of the work list on a CU (class launches)
+    int wbox;                      // WGRAD: walk only the voxel box that is valid for the tile's tap
 };
 
 // All gathers are raw buffer loads: 32-bit byte offset against a descriptor of the whole tensor.  An offset
@@ -229,8 +230,29 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     const long M_here = (MODE == MODE_DGRAD || border) ? (long)p.N * Dz * Dy * Dx : p.M;
 
     // ---- reduction extent of this workgroup ----------------------------------------------------
+    // WGRAD (not the stem): a row tile that lies inside ONE tap only needs the output voxels whose window position
+    // for that tap is inside the input - a sub-box of the output grid.  The reduction walks that box (the rest would
+    // multiply padding zeros), each thread decoding one voxel per slice for both operands.
+    int wz0 = 0, wy0 = 0, wx0 = 0, wbz = p.Dr, wby = p.Hr, wbx = p.Wr;
+    if (MODE == MODE_WGRAD && !STEM && p.wbox && (p.Ci % BM) == 0) {
+        const int tap = (int)(m0 / p.Ci);
+        const int a = tap / (Ky * Kx), b = (tap / Kx) % Ky, c = tap % Kx;
+        auto range = [&](int t, int L_, int P_, int n_in, int n_out, int& lo, int& cnt) {
+            // 0 <= o*S - P + t*L < n_in
+            const int num = P_ - t * L_;
+            int l = num > 0 ? (num + S - 1) / S : 0;
+            int hsrc = n_in - 1 + P_ - t * L_;
+            int hgh = hsrc < 0 ? -1 : hsrc / S;
+            if (hgh > n_out - 1) hgh = n_out - 1;
+            lo = l; cnt = hgh >= l ? hgh - l + 1 : 0;
+        };
+        range(a, Lz, Pz, p.Dg, p.Dr, wz0, wbz);
+        range(b, Ly, Py, p.Hg, p.Hr, wy0, wby);
+        range(c, Lx, Px, p.Wg, p.Wr, wx0, wbx);
+    }
+    const long w_red = (MODE == MODE_WGRAD && !STEM) ? (long)p.N * wbz * wby * wbx : p.n_red_vox;
     int nk;
-    if (MODE == MODE_WGRAD) nk = (int)((p.n_red_vox + BK - 1) / BK);
+    if (MODE == MODE_WGRAD) nk = (int)((w_red + BK - 1) / BK);
     else if (STEM) nk = (taps + BK - 1) / BK;
     else nk = nz * ny * nx * (((MODE == MODE_FWD) ? p.Ci : p.Co) / BK);
     const int nk_per_split = (nk + p.splits - 1) / p.splits;
@@ -246,7 +268,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     }
 
     const GridDec rdec = {p.Dr, p.Hr, p.Wr, p.mgD, p.mgH, p.mgW, p.shD, p.shH, p.shW};   // row grid
-    const GridDec cdec = make_dec(Dz, Dy, Dx);           // DGRAD class grid
+    const GridDec cdec = (MODE == MODE_WGRAD) ? make_dec(wbz, wby, wbx)       // WGRAD: the tile's voxel box
+                                              : make_dec(Dz, Dy, Dx);          // class grid
 
     // ---- per-thread staging state --------------------------------------------------------------
     const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(p.a_src, p.a_bytes), b_rs = make_rsrc(p.b_src, p.b_bytes);
@@ -340,6 +363,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
             b_lds[i] = b_row[i] * LDK + b_col[i];
             const bool ok = n0 + b_row[i] < p.Ncols;
             b_off[i] = ok ? 4u * (unsigned)((long)(n0 + b_row[i]) * p.Co + b_col[i]) : OOR;
+        } else if (MODE == MODE_WGRAD && !STEM) {
+            // dY row of the voxel this thread decodes (w_kk), chunk (tid % TPV) + TPV*i of its BN columns
+            b_row[i] = w_kk; b_col[i] = 4 * ((tid % TPV) + TPV * i);
+            b_lds[i] = b_row[i] * BN + b_col[i];
+            const bool ok = n0 + b_col[i] < p.Ncols;
+            b_off[i] = ok ? 4u * (unsigned)(n0 + b_col[i]) : OOR;
         } else {                 // LDS [k][n]; global rows k, cols n contiguous
             b_row[i] = q / (BN / 4); b_col[i] = (q % (BN / 4)) * 4;
             b_lds[i] = b_row[i] * BN + b_col[i];
@@ -383,9 +412,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
                 // reduction index = output voxel mv = kt*BK + kk (one decode per thread); a voxel behind
                 // the last one decodes to n >= N: its offsets fall behind the tensors (zeros)
                 const long mv = (long)kt * BK + w_kk;
-                pt_vok = live & (mv < p.n_red_vox);
+                pt_vok = live & (mv < w_red);
                 int n, z, y, x;
-                rdec(pt_vok ? (unsigned)mv : 0u, n, z, y, x);
+                if (STEM) {
+                    rdec(pt_vok ? (unsigned)mv : 0u, n, z, y, x);
+                } else {
+                    cdec(pt_vok ? (unsigned)mv : 0u, n, z, y, x);
+                    z += wz0; y += wy0; x += wx0;
+                    pt_boff = pt_vok ? 4u * (unsigned)(((((long)n * p.Dr + z) * p.Hr + y) * p.Wr + x) * p.Co) : OOR;
+                }
                 pt_zb = z * S - Pz; pt_yb = y * S - Py; pt_xb = x * S - Px;
                 pt_voff = 4u * (unsigned)(((((long)n * p.Dg + pt_zb) * p.Hg + pt_yb) * p.Wg + pt_xb) * p.Cg);
             } else if (!STEM) {
@@ -444,8 +479,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
             }
         } else if (part <= A_CH + B_CH) {
             const int i = part - 1 - A_CH;
-            if (MODE == MODE_WGRAD || STEM) {
-                // rows kt*BK + b_row of dY (WGRAD) / of the stem weights: a row behind the last one is
+            if (MODE == MODE_WGRAD && !STEM) {
+                // the dY row of the voxel decoded in part 0 (OOR behind the box / the last slice)
+                b_reg[SET][i] = bld4(b_rs, b_off[i] + pt_boff);
+            } else if (MODE == MODE_WGRAD || STEM) {
+                // rows kt*BK + b_row of dY (stem WGRAD) / of the stem weights: a row behind the last one is
                 // behind the tensor (zeros)
                 const unsigned so = live ? 4u * (unsigned)((long)kt * BK * p.Co) : OOR;
                 b_reg[SET][i] = bld4(b_rs, b_off[i] + so);
@@ -874,6 +912,7 @@ int setup_conv(int mode, const Geom& g, Setup* st) {
     p.splits = st->pl.splits;
     p.ny_tiles = (p.Ncols + st->pl.bn - 1) / st->pl.bn;
     p.fold = (p.n_classes > 1 && !env_int("MI_CONV_NO_FOLD")) ? 1 : 0;
+    p.wbox = (mode == MODE_WGRAD && !stem && !env_int("MI_CONV_NO_BORDER")) ? 1 : 0;
     return MI_OK;
 }
 
