@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     {
         const int total = gridDim.x, L = blockIdx.x;
         int q = L;
-        if (p.fold) {
+        if (p.fold) {                                      // (tools/cu_map_probe.hip: L and L + 256 do share a CU)
             const int g = L >> 8, r = L & 255, m = g >> 1;
             q = (g & 1) ? total - 1 - (m * 256 + r) : m * 256 + r;
         }
