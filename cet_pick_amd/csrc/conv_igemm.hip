@@ -81,6 +81,7 @@ struct ConvParams {
     int cls_tile_start[MAX_CLASSES + 1];
     BorderClass bcls[MAX_CLASSES];
     int ny_tiles;                  // column tiles; the grid is 1-D: (row tile, column tile, split) linearised
+    int tiles_x;                   // row tiles
     int fold;                      // pair the two ends of the work list on a CU (class launches)
     int wbox;                      // WGRAD: walk only the voxel box that is valid for the tile's tap
 };
@@ -186,11 +187,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
             const int g = L >> 8, r = L & 255, m = g >> 1;
             q = (g & 1) ? total - 1 - (m * 256 + r) : m * 256 + r;
         }
-        const int per = p.ny_tiles * p.splits;
-        blk_x = q / per;
-        const int rem = q - blk_x * per;
-        blk_y = rem % p.ny_tiles;
-        blk_z = rem / p.ny_tiles;
+        if (p.fold) {                                      // work list = row tiles in class order, (column, split) minor
+            const int per = p.ny_tiles * p.splits;
+            blk_x = q / per;
+            const int rem = q - blk_x * per;
+            blk_y = rem % p.ny_tiles;
+            blk_z = rem / p.ny_tiles;
+        } else {                                           // row tiles fastest (neighbours share the weight tile)
+            blk_x = q % p.tiles_x;
+            const int rem = q / p.tiles_x;
+            blk_y = rem % p.ny_tiles;
+            blk_z = rem / p.ny_tiles;
+        }
     }
     const int n0 = blk_y * BN;
     const int Kz = p.kd, Ky = p.kh, Kx = p.kw, S = p.stride, Pz = p.pd, Py = p.ph, Px = p.pw;
@@ -825,6 +833,18 @@ bool build_border_classes(int mode, const Geom& g, ConvParams* p) {
                 bc.tlo[0] = (short)rz[a].tlo; bc.tlo[1] = (short)ry[b].tlo; bc.tlo[2] = (short)rx[c].tlo;
                 bc.tcnt[0] = (short)rz[a].tcnt; bc.tcnt[1] = (short)ry[b].tcnt; bc.tcnt[2] = (short)rx[c].tcnt;
             }
+    // worth it only when a real share of the multiply-adds falls on padding (small volumes); on large images the class
+    // bookkeeping (row map, mapped epilogue) costs more than the few border rows save (unet_4 forward: -7 %)
+    {
+        double useful = 0, full = 0;
+        for (int c = 0; c < n; ++c) {
+            const BorderClass& b = p->bcls[c];
+            const double rows = (double)b.cnt[0] * b.cnt[1] * b.cnt[2];
+            useful += rows * b.tcnt[0] * b.tcnt[1] * b.tcnt[2];
+            full += rows * g.kd * g.kh * g.kw;
+        }
+        if (useful > 0.92 * full) return false;
+    }
     // heaviest reduction first (the kernel pairs the two ends of the list on a CU)
     std::stable_sort(p->bcls, p->bcls + n, [](const BorderClass& u, const BorderClass& v) {
         return u.tcnt[0] * u.tcnt[1] * u.tcnt[2] > v.tcnt[0] * v.tcnt[1] * v.tcnt[2];
@@ -911,8 +931,13 @@ int setup_conv(int mode, const Geom& g, Setup* st) {
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.splits = st->pl.splits;
     p.ny_tiles = (p.Ncols + st->pl.bn - 1) / st->pl.bn;
+    p.tiles_x = (int)st->pl.tiles_x;
     p.fold = (p.n_classes > 1 && !env_int("MI_CONV_NO_FOLD")) ? 1 : 0;
     p.wbox = (mode == MODE_WGRAD && !stem && !env_int("MI_CONV_NO_BORDER")) ? 1 : 0;
+    if (p.wbox) {        // same criterion as the border classes: only when padding is a real share of the work
+        ConvParams tmp = ConvParams{};
+        p.wbox = build_border_classes(MODE_FWD, g, &tmp) ? 1 : 0;
+    }
     return MI_OK;
 }
 
