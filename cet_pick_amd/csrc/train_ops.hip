@@ -316,56 +316,63 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_x_kernel(const float* d
 }
 
 // ---- small-M BatchNorm in ONE launch (the BatchNorm1d layers of the projection MLP see M = batch rows, the
-// feature_3d BatchNorm M = batch * 8): a workgroup owns 16 channels, 64 row lanes x 4 float4 channel groups, sums in
-// fp64 through LDS (fixed shape: deterministic), then applies.  Replaces colreduce + finalize + apply (3 launches).
-constexpr int BNS_CH = 16;            // channels per workgroup
+// feature_3d BatchNorm M = batch * 8): a workgroup owns 4 channels (one float4 column), its 256 threads are row lanes;
+// sums in fp64 through a fixed-shape shuffle + LDS tree (deterministic), then the apply pass over the same rows (they
+// are still in L1/L2).  Replaces colreduce + finalize + apply (3 launches).
+constexpr int BNS_CH = 4;             // channels per workgroup
+
+__device__ __forceinline__ void bns_block_sum8(double (&v)[8], double (*red)[8]) {
+    // v[0..7] summed over the 256 threads of the workgroup; result in every thread
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[wave][k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+}
+
 __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* x, float* y, int M, int C, const float* gamma,
                                                           const float* beta, float eps, float momentum,
                                                           float* running_mean, float* running_var,
                                                           long long* num_batches_tracked, float* save,
                                                           const float* res, int relu) {
-    const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;            // channel group (float4), row lane
-    const int c = blockIdx.x * BNS_CH + 4 * cg;
-    __shared__ double red[2][64][4][4];
-    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    if (c < C)
-        for (int r = rl; r < M; r += 64) {
-            const float4 v = ld4(x + (long)r * C + c);
-            const float a[4] = {v.x, v.y, v.z, v.w};
+    const int c = blockIdx.x * BNS_CH;
+    __shared__ double red[4][8];
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+    for (int r = threadIdx.x; r < M; r += 256) {
+        const float4 v = ld4(x + (long)r * C + c);
+        const float a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { s1[k] += (double)a[k]; s2[k] += (double)a[k] * (double)a[k]; }
-        }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { red[0][rl][cg][k] = s1[k]; red[1][rl][cg][k] = s2[k]; }
-    __syncthreads();
-    __shared__ float s_mean[BNS_CH], s_inv[BNS_CH];
-    if (threadIdx.x < BNS_CH) {
-        const int g = threadIdx.x >> 2, k = threadIdx.x & 3, ch = blockIdx.x * BNS_CH + threadIdx.x;
-        double a = 0, b = 0;
-        for (int r = 0; r < 64; ++r) { a += red[0][r][g][k]; b += red[1][r][g][k]; }
-        const double mean = a / M;
-        double var = b / M - mean * mean;
-        if (var < 0) var = 0;
-        const float inv = (float)(1.0 / sqrt(var + (double)eps));
-        s_mean[threadIdx.x] = (float)mean; s_inv[threadIdx.x] = inv;
-        if (ch < C) {
-            if (save) { save[ch] = (float)mean; save[C + ch] = inv; }
-            if (running_mean) {
-                const double unbiased = M > 1 ? var * M / (M - 1.0) : var;
-                running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
-                running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
-            }
-        }
-        if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+        for (int k = 0; k < 4; ++k) { s[k] += (double)a[k]; s[4 + k] += (double)a[k] * (double)a[k]; }
     }
-    __syncthreads();
-    if (c >= C) return;
+    bns_block_sum8(s, red);
     float m[4], iv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { m[k] = s_mean[4 * cg + k]; iv[k] = s_inv[4 * cg + k]; }
+    for (int k = 0; k < 4; ++k) {
+        const double mean = s[k] / M;
+        double var = s[4 + k] / M - mean * mean;
+        if (var < 0) var = 0;
+        m[k] = (float)mean; iv[k] = (float)(1.0 / sqrt(var + (double)eps));
+        if (threadIdx.x == 0) {
+            if (save) { save[c + k] = m[k]; save[C + c + k] = iv[k]; }
+            if (running_mean) {
+                const double unbiased = M > 1 ? var * M / (M - 1.0) : var;
+                running_mean[c + k] = (1.f - momentum) * running_mean[c + k] + momentum * m[k];
+                running_var[c + k] = (1.f - momentum) * running_var[c + k] + momentum * (float)unbiased;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
     const float4 g = gamma ? ld4(gamma + c) : make_float4(1, 1, 1, 1);
     const float4 b = beta ? ld4(beta + c) : make_float4(0, 0, 0, 0);
-    for (int r = rl; r < M; r += 64) {
+#pragma unroll 4
+    for (int r = threadIdx.x; r < M; r += 256) {
         const long o = (long)r * C + c;
         const float4 v = ld4(x + o);
         float4 q;
@@ -381,55 +388,43 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* x, float
 __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* dy, const float* x, const float* y, float* dx,
                                                           int M, int C, const float* save, const float* gamma,
                                                           int relu, float* dgamma, float* dbeta) {
-    const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
-    const int c = blockIdx.x * BNS_CH + 4 * cg;
-    __shared__ double red[2][64][4][4];
-    float mean[4] = {0, 0, 0, 0}, inv[4] = {1, 1, 1, 1};
-    if (c < C) {
-        const float4 a = ld4(save + c), b = ld4(save + C + c);
-        mean[0] = a.x; mean[1] = a.y; mean[2] = a.z; mean[3] = a.w;
-        inv[0] = b.x; inv[1] = b.y; inv[2] = b.z; inv[3] = b.w;
-    }
-    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    if (c < C)
-        for (int r = rl; r < M; r += 64) {
-            const long o = (long)r * C + c;
-            const float4 d4 = ld4(dy + o), x4 = ld4(x + o);
-            float d[4] = {d4.x, d4.y, d4.z, d4.w};
-            const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
-            if (relu) {
-                const float4 y4 = ld4(y + o);
-                const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+    const int c = blockIdx.x * BNS_CH;
+    __shared__ double red[4][8];
+    const float4 ma = ld4(save + c), ia = ld4(save + C + c);
+    const float mean[4] = {ma.x, ma.y, ma.z, ma.w}, inv[4] = {ia.x, ia.y, ia.z, ia.w};
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+    for (int r = threadIdx.x; r < M; r += 256) {
+        const long o = (long)r * C + c;
+        const float4 d4 = ld4(dy + o), x4 = ld4(x + o);
+        float d[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+        if (relu) {
+            const float4 y4 = ld4(y + o);
+            const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) d[k] = yv[k] > 0.f ? d[k] : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { s1[k] += (double)d[k]; s2[k] += (double)(d[k] * ((xv[k] - mean[k]) * inv[k])); }
+            for (int k = 0; k < 4; ++k) d[k] = yv[k] > 0.f ? d[k] : 0.f;
         }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { red[0][rl][cg][k] = s1[k]; red[1][rl][cg][k] = s2[k]; }
-    __syncthreads();
-    __shared__ float s_dy[BNS_CH], s_dx[BNS_CH];
-    if (threadIdx.x < BNS_CH) {
-        const int g = threadIdx.x >> 2, k = threadIdx.x & 3, ch = blockIdx.x * BNS_CH + threadIdx.x;
-        double a = 0, b = 0;
-        for (int r = 0; r < 64; ++r) { a += red[0][r][g][k]; b += red[1][r][g][k]; }
-        s_dy[threadIdx.x] = (float)a; s_dx[threadIdx.x] = (float)b;
-        if (ch < C) {
-            if (dbeta) dbeta[ch] = (float)a;
-            if (dgamma) dgamma[ch] = (float)b;
+        for (int k = 0; k < 4; ++k) { s[k] += (double)d[k]; s[4 + k] += (double)(d[k] * ((xv[k] - mean[k]) * inv[k])); }
+    }
+    bns_block_sum8(s, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (dbeta) dbeta[c + k] = (float)s[k];
+            if (dgamma) dgamma[c + k] = (float)s[4 + k];
         }
     }
-    __syncthreads();
-    if (c >= C) return;
     const float rc = 1.0f / (float)M;
     float gi[4], sdy[4], sdx[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         gi[k] = (gamma ? gamma[c + k] : 1.f) * inv[k];
-        sdy[k] = s_dy[4 * cg + k] * rc; sdx[k] = s_dx[4 * cg + k] * rc;
+        sdy[k] = (float)s[k] * rc; sdx[k] = (float)s[4 + k] * rc;
     }
-    for (int r = rl; r < M; r += 64) {
+#pragma unroll 4
+    for (int r = threadIdx.x; r < M; r += 256) {
         const long o = (long)r * C + c;
         const float4 d4 = ld4(dy + o), x4 = ld4(x + o);
         float d[4] = {d4.x, d4.y, d4.z, d4.w};
