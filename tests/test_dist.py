@@ -56,6 +56,44 @@ def test_concat_all_gather_gloo_cpu(tmp_path):
     assert torch.equal(r0["s"], r1["s"]) and float(r0["s"][1, 1]) == 3
 
 
+def _w_buckets(rank, world, port, out):
+    """the engine's bucketed gradient exchange on CPU tensors over gloo: four asynchronous all-reduces over disjoint arena
+    ranges, issued deepest layers first, must equal one all-reduce of the whole arena"""
+    _init(rank, world, port)
+    from cet_pick_amd.models.networks.moco_encoder_3d import TomoResClassifier3D, BasicBlock
+    from cet_pick_amd.models.moco import MoCo
+    from cet_pick_amd.trains.moco_engine import MocoStepEngine
+    torch.manual_seed(1)
+    heads = {"proj": 256, "pred": 256}
+    moco = MoCo(TomoResClassifier3D(BasicBlock, [2, 2, 2, 2], heads, 0), TomoResClassifier3D(BasicBlock, [2, 2, 2, 2], heads, 0),
+                dim=128, r=64, m=0.99, T=0.1)
+    eng = MocoStepEngine(moco, lr=0.1)                       # CPU tensors: only the exchange plumbing is exercised
+    ranges = sorted(eng._bucket.values())
+    assert ranges[0][0] == 0 and ranges[-1][1] == eng.arena_q.numel
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))                   # a partition of the arena
+    names = dict(zip([n for n, _ in moco.encoder_q.named_parameters()], eng.arena_q.offsets))
+    assert eng._bucket["stem"][1] == names["layer1.0.conv1.weight"] and eng._bucket["layer3"][0] == names["layer3.0.conv1.weight"]
+    assert moco.encoder_q.grad_marker is not None
+    g = torch.Generator().manual_seed(10 + rank)
+    eng.arena_q.flat_grad.copy_(torch.randn(eng.arena_q.numel, generator=g))
+    whole = eng.arena_q.flat_grad.clone()
+    dist.all_reduce(whole)
+    for tag in ("layer3", "layer2", "layer1"):               # what the autograd hooks do during backward
+        eng._on_marker(tag)
+    eng._reduce_bucket("stem")
+    for w in eng._pending:
+        w.wait()
+    assert eng.buckets_sent == ["layer3", "layer2", "layer1", "stem"]
+    torch.save({"ok": bool(torch.equal(eng.arena_q.flat_grad, whole))}, os.path.join(out, "b%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_exchange_gloo_cpu(tmp_path):
+    port = _free_port()
+    mp.spawn(_w_buckets, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert torch.load(str(tmp_path / "b0.pt"))["ok"] and torch.load(str(tmp_path / "b1.pt"))["ok"]
+
+
 # ------------------------------------------------------------------------------------------- GPU
 def _make_moco(seed=317):
     from cet_pick_amd.models.networks.moco_encoder_3d import TomoResClassifier3D, BasicBlock
