@@ -43,6 +43,9 @@ int mi_stem7_wgrad(const float* x, const float* dy, float* dw, int N, int D, int
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
 constexpr int NTHREADS = 256;
@@ -148,8 +151,20 @@ struct Cursor {
 
 // STEM: Cin == 1 (the 7x7x7 stride-2 stem, moco_encoder_3d.py:163-169): the reduction index is
 // the tap itself and each of a chunk's 4 taps is gathered separately through a tap LUT in LDS.
-template <int MODE, int BM, int BN, int BK, bool STEM>
-__global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
+//
+// BF3 = true: the same GEMM on the bf16 matrix pipe with f32-equivalent arithmetic.  Every f32 operand element is cut
+// (exactly: a = a0 + a1 + a2, three bf16 values of 8 significant bits each) while it is staged into LDS, and the six
+// products of weight <= 2 (a0 b0, a0 b1, a1 b0, a1 b1, a0 b2, a2 b0) are accumulated in f32 by
+// v_mfma_f32_32x32x16_bf16: each product is exact in f32, the dropped terms (a1 b2, a2 b1, a2 b2) are <= 2^-23 |a b|,
+// i.e. of the size of ONE f32 rounding - the result differs from the f32 fmaf chain by rounding-order noise only
+// (tests/test_conv_gpu.py measures both against float64).  Six bf16 MFMAs of K = 16 take 192 cycles against 512 for
+// the eight f32 MFMAs they replace.  LDS holds three bf16 planes per operand:
+//   "RowK" plane [row][BK] bf16, 16-byte chunks XOR-swizzled by row : fragments by ds_read_b128 (8 k's)
+//   "KRow" plane, one [BK][32 columns] sub-tile per 32 columns (64-byte rows) : fragments by ds_read_b64_tr_b16
+//          (the transposing LDS read of gfx950: 4 k's x 16 columns per 16-lane group, conflict-free on 64-byte rows)
+template <int MODE, int BM, int BN, int BK, bool STEM, bool BF3 = false>
+__global__ __launch_bounds__(NTHREADS, BF3 ? 3 : 1) void conv_igemm_kernel(ConvParams p) {
+    static_assert(!BF3 || (!STEM && (BK == 16 || BK == 32)), "bf16x3 path: generic layers, 16- or 32-deep slices");
     static_assert(BK == 16 || BK == 32 || BK == 64, "slice depth");
     static_assert(BN == 64 || BN == 128, "tile width");
     constexpr int WM = 2, WN = 2;
@@ -168,8 +183,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
     constexpr int B_CH = BN * KC / NTHREADS;
     constexpr int TPV = NTHREADS / BK;               // WGRAD: threads sharing one reduction voxel
     static_assert(A_CH >= 1 && B_CH >= 1, "tile too small for 256 threads");
+    // bf16x3 images (bytes)
+    constexpr int RS = 2 * BK;                       // RowK plane: bytes per row; 16-byte chunk c of row r sits at chunk
+                                                     // c ^ rowk_swz(r) (conflict-free ds_read_b128 without padding)
+    constexpr int KSUB = 64 * BK + 64;               // KRow plane: bytes per 32-column sub-tile
+    constexpr int A_PLANE = A_ROWK ? BM * RS : (BM / 32) * KSUB;
+    constexpr int B_PLANE = B_ROWK ? BN * RS : (BN / 32) * KSUB;
+    constexpr int STAGE_B = 3 * (A_PLANE + B_PLANE);
+    constexpr int KS = BK / 16;                      // bf16 MFMA k-steps per slice
 
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    auto rowk_swz = [](int r) { return BK == 32 ? (r >> 2) & 3 : (r >> 3) & 1; };
+    __shared__ __attribute__((aligned(16))) float lds[BF3 ? STAGE_B / 2 : 2 * STAGE];
+    unsigned char* const ldsb = reinterpret_cast<unsigned char*>(lds);
     __shared__ long rowmap[BM];                       // DGRAD classes: tile row -> output row
     __shared__ int2 taplut[STEM ? LUT_TAPS : 1];      // STEM: tap -> (voxel delta, a | b<<8 | c<<16)
 
@@ -295,7 +320,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
             const int q = tid + i * NTHREADS;
             const int row = q / KC, c = q % KC;
             const long m = m0 + row;
-            a_lds[i] = row * LDK + 4 * c;
+            a_lds[i] = BF3 ? row * RS + 16 * ((c >> 1) ^ rowk_swz(row)) + 8 * (c & 1) : row * LDK + 4 * c;
             a_msk[i] = 0;
             a_off[i] = 0;
             w_ok[i] = false;
@@ -345,7 +370,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             const int j = (tid % TPV) + TPV * i;
-            a_lds[i] = w_kk * BM + 4 * j;
+            a_lds[i] = BF3 ? ((4 * j) >> 5) * KSUB + w_kk * 64 + ((4 * j) & 31) * 2 : w_kk * BM + 4 * j;
             const long row = m0 + 4 * j;
             w_ok[i] = row < p.M;
             a_msk[i] = 0;
@@ -368,18 +393,19 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
         const int q = tid + i * NTHREADS;
         if (B_ROWK) {            // DGRAD: LDS [n][k]; global W[tap][ci = n][co = k]
             b_row[i] = q / KC; b_col[i] = (q % KC) * 4;
-            b_lds[i] = b_row[i] * LDK + b_col[i];
+            b_lds[i] = BF3 ? b_row[i] * RS + 16 * ((b_col[i] >> 3) ^ rowk_swz(b_row[i])) + 2 * (b_col[i] & 4)
+                           : b_row[i] * LDK + b_col[i];
             const bool ok = n0 + b_row[i] < p.Ncols;
             b_off[i] = ok ? 4u * (unsigned)((long)(n0 + b_row[i]) * p.Co + b_col[i]) : OOR;
         } else if (MODE == MODE_WGRAD && !STEM) {
             // dY row of the voxel this thread decodes (w_kk), chunk (tid % TPV) + TPV*i of its BN columns
             b_row[i] = w_kk; b_col[i] = 4 * ((tid % TPV) + TPV * i);
-            b_lds[i] = b_row[i] * BN + b_col[i];
+            b_lds[i] = BF3 ? (b_col[i] >> 5) * KSUB + b_row[i] * 64 + (b_col[i] & 31) * 2 : b_row[i] * BN + b_col[i];
             const bool ok = n0 + b_col[i] < p.Ncols;
             b_off[i] = ok ? 4u * (unsigned)(n0 + b_col[i]) : OOR;
         } else {                 // LDS [k][n]; global rows k, cols n contiguous
             b_row[i] = q / (BN / 4); b_col[i] = (q % (BN / 4)) * 4;
-            b_lds[i] = b_row[i] * BN + b_col[i];
+            b_lds[i] = BF3 ? (b_col[i] >> 5) * KSUB + b_row[i] * 64 + (b_col[i] & 31) * 2 : b_row[i] * BN + b_col[i];
             const bool ok = n0 + b_col[i] < p.Ncols;
             b_off[i] = ok ? 4u * (unsigned)((long)b_row[i] * p.Co + n0 + b_col[i]) : OOR;
         }
@@ -519,15 +545,54 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
         for (int part = 0; part < NPARTS; ++part) load_part(kt, live, part, SETc);
     };
+    // bf16x3: exact three-way cut of 4 consecutive f32 (one 16-byte chunk) into 3 x 4 bf16, one 8-byte store per plane.
+    // Truncation keeps every step exact: a0 = top 16 bits of a, r1 = a - a0 (<= 16 significant bits), a1 = top 16 bits
+    // of r1, a2 = r1 - a1 (<= 8 significant bits: a bf16 value).
+    auto split_cut = [&](const float4 v, uint2 (&o)[3]) {
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        unsigned u0[4], u1[4], u2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            u0[t] = __float_as_uint(e[t]);
+#ifdef MI_DBG_BF3_NOCVT    // timing experiment: no arithmetic in the cut (results are garbage)
+            u1[t] = u0[t]; u2[t] = u0[t];
+            continue;
+#endif
+            const float r1 = e[t] - __uint_as_float(u0[t] & 0xffff0000u);
+            u1[t] = __float_as_uint(r1);
+            const float r2 = r1 - __uint_as_float(u1[t] & 0xffff0000u);
+            u2[t] = __float_as_uint(r2);
+        }
+        // v_perm_b32: the high halves of two dwords -> one dword of two bf16 (element t in the low half)
+        constexpr unsigned HI2 = 0x07060302u;
+        o[0] = make_uint2(__builtin_amdgcn_perm(u0[1], u0[0], HI2), __builtin_amdgcn_perm(u0[3], u0[2], HI2));
+        o[1] = make_uint2(__builtin_amdgcn_perm(u1[1], u1[0], HI2), __builtin_amdgcn_perm(u1[3], u1[2], HI2));
+        o[2] = make_uint2(__builtin_amdgcn_perm(u2[1], u2[0], HI2), __builtin_amdgcn_perm(u2[3], u2[2], HI2));
+    };
+    auto split_store = [&](unsigned char* dst, int plane_bytes, const float4 v) {
+        uint2 o[3];
+        split_cut(v, o);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(dst + pl * plane_bytes) = o[pl];
+    };
     auto store_tile = [&](int buf, auto SETc) {
         constexpr int SET = decltype(SETc)::value;
 #ifdef MI_DBG_NOSTORE      // timing experiment: no LDS stores in the loop (results are garbage)
         if (buf >= 0 && kt1 - kt0 > 2) return;
 #endif
+        if constexpr (BF3) {
+            unsigned char* const Ab = ldsb + buf * STAGE_B;
+            unsigned char* const Bb = Ab + 3 * A_PLANE;
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<float4*>(lds + buf * STAGE + a_lds[i]) = a_reg[SET][i];
+            for (int i = 0; i < A_CH; ++i) split_store(Ab + a_lds[i], A_PLANE, a_reg[SET][i]);
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<float4*>(lds + buf * STAGE + A_ELEMS + b_lds[i]) = b_reg[SET][i];
+            for (int i = 0; i < B_CH; ++i) split_store(Bb + b_lds[i], B_PLANE, b_reg[SET][i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) *reinterpret_cast<float4*>(lds + buf * STAGE + a_lds[i]) = a_reg[SET][i];
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) *reinterpret_cast<float4*>(lds + buf * STAGE + A_ELEMS + b_lds[i]) = b_reg[SET][i];
+        }
     };
 
     f32x16 acc[MT][NT];
@@ -550,6 +615,79 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(ConvParams p) {
         using SetCur = std::integral_constant<int, CUR>;
         using SetOther = std::integral_constant<int, CUR ^ 1>;
         const bool more2 = (kt + 2 < kt1);
+        if constexpr (BF3) {
+            // Phase 1: per operand 3 planes x KS k-steps of 8 bf16 (k = 16 s + 8 h + e for both operands)
+            const unsigned char* Ab = ldsb + buf * STAGE_B;
+            const unsigned char* Bb = Ab + 3 * A_PLANE;
+            const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+            // transposing read: lane 4q+pp of a 16-lane group addresses row k0+q, columns 4pp..4pp+3 of the group's
+            // 4 x 16 block and receives column (lane & 15), rows k0 .. k0+3
+            const int tr_off = (i16 >> 2) * 64 + (16 * g16 + 4 * (i16 & 3)) * 2;
+            bf16x8 af[MT][3][KS], bf[NT][3][KS];
+            auto frag = [&](const unsigned char* plane0, int plane_bytes, bool rowk, int r0, bf16x8 (&f)[3][KS]) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int s2 = 0; s2 < KS; ++s2) {
+                        if (rowk) {
+                            f[pl][s2] = *reinterpret_cast<const bf16x8*>(plane0 + pl * plane_bytes + (r0 + l32) * RS +
+                                                                         16 * ((2 * s2 + h) ^ rowk_swz(r0 + l32)));
+                        } else {
+                            const unsigned char* sb = plane0 + pl * plane_bytes + (r0 >> 5) * KSUB + (16 * s2 + 8 * h) * 64 + tr_off;
+                            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sb));
+                            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sb + 4 * 64));
+                            f[pl][s2] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                    }
+            };
+#pragma unroll
+            for (int i = 0; i < MT; ++i) frag(Ab, A_PLANE, A_ROWK, wm * WTM + i * 32, af[i]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) frag(Bb, B_PLANE, B_ROWK, wn * WTN + j * 32, bf[j]);
+            // ... and in the shadow of those LDS reads the cut of slice kt+1 (set CUR^1, landed during the previous
+            // iteration) into its bf16 planes: VALU only
+            constexpr int NCH = A_CH + B_CH;
+            uint2 cv[NCH][3];
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) split_cut(a_reg[CUR ^ 1][i], cv[i]);
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) split_cut(b_reg[CUR ^ 1][i], cv[A_CH + i]);
+            unsigned char* const An = ldsb + (buf ^ 1) * STAGE_B;
+            unsigned char* const Bn = An + 3 * A_PLANE;
+            __builtin_amdgcn_sched_barrier(0);
+            // Phase 2: six products per k-step, smallest first; the gather pieces of slice kt+2 and the LDS stores of
+            // slice kt+1 (other buffer: nobody reads it before the barrier) ride behind the MFMAs
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int NMF3 = 6 * KS * MT * NT;
+            static_assert(NPARTS <= NMF3, "more gather pieces than MFMAs");
+#pragma unroll
+            for (int g = 0; g < NMF3; ++g) {
+                const int ij = g % (MT * NT), pr = (g / (MT * NT)) % 6, s2 = g / (MT * NT * 6);
+                const int i = ij / NT, j = ij % NT;
+#ifdef MI_DBG_BF3_ONEPROD  // timing experiment: one product instead of six (results are garbage)
+                if (pr != 5) { if (g < NPARTS) { load_part(kt + 2, more2, g, SetCur{}); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } continue; }
+#endif
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[pr]][s2], bf[j][PB[pr]][s2], acc[i][j], 0, 0, 0);
+                if (g < NPARTS) load_part(kt + 2, more2, g, SetCur{});
+                // the 3 * NCH plane stores, spread over the MFMAs
+#pragma unroll
+                for (int w = g * 3 * NCH / NMF3; w < (g + 1) * 3 * NCH / NMF3; ++w) {
+                    const int ch = w / 3, pl = w % 3;
+                    unsigned char* dst = ch < A_CH ? An + a_lds[ch < A_CH ? ch : 0] + pl * A_PLANE
+                                                   : Bn + b_lds[ch < A_CH ? 0 : ch - A_CH] + pl * B_PLANE;
+#ifdef MI_DBG_NOSTORE
+                    if (kt1 - kt0 > 2) continue;
+#endif
+                    *reinterpret_cast<uint2*>(dst) = cv[ch][pl];
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#ifndef MI_DBG_NOBARRIER
+            __syncthreads();
+#endif
+            return;
+        }
         // Phase 1: fragments of the current slice from LDS
         const float* Ab = lds + buf * STAGE;
         const float* Bb = Ab + A_ELEMS;
@@ -734,6 +872,14 @@ Plan make_plan(int mode, bool stem, long M, int Ncols, long red_len, int red_ch,
 template <int MODE, bool STEM>
 int launch_mode(const ConvParams& p, const Plan& pl, hipStream_t s) {
     dim3 grid((unsigned)(pl.tiles_x * ((p.Ncols + pl.bn - 1) / pl.bn) * pl.splits));    // 1-D, decoded in the kernel
+    if constexpr (!STEM) {
+        if (env_int("MI_CONV_BF16X3") && pl.bm == 64 && pl.bn == 64 && (pl.bk == 32 || pl.bk == 16)) {
+            if (pl.bk == 32) hipLaunchKernelGGL((conv_igemm_kernel<MODE, 64, 64, 32, false, true>), grid, dim3(NTHREADS), 0, s, p);
+            else hipLaunchKernelGGL((conv_igemm_kernel<MODE, 64, 64, 16, false, true>), grid, dim3(NTHREADS), 0, s, p);
+            MI_RETURN_IF_LAUNCH_FAILED();
+            return MI_OK;
+        }
+    }
 #define MI_LAUNCH(BM_, BN_, BK_) \
     hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM_, BN_, BK_, STEM>), grid, dim3(NTHREADS), 0, s, p)
     if (pl.bn == 128 && !STEM) {           // 128-wide tiles only with 32-deep slices
