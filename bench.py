@@ -7,6 +7,10 @@ step      = one MoCo-3D training step (BASELINE.json configs[1]): q forward + EM
 value     = sub-tomograms/s over all ranks (one PAIR of views counts as one sub-tomogram).
 roofline  = conv_igemm_kernel (every conv / linear fwd, dgrad, wgrad launch): algorithmic FLOPs
             2*M*N*K per launch / HIP-event duration per launch, vs the gfx950 fp32 matrix peak.
+            The generic kernel computes f32 products on the bf16 matrix pipe (three-way bf16 cut of
+            both operands, six products, f32 accumulate: f32-equivalent), so the
+            fraction is also given against that pipe's ceiling (2.5 PFLOP/s / 6).  MI_CONV_ARITH=f32
+            selects the f32 MFMA instruction; its step time is reported next to the default's.
 secondary = the inference half of the metric (voxels/s of sigmoid+NMS+top-K decode and of the DoG
             particle picker) with its own HBM roofline.
 cpu_baseline = the CPU oracle (oracle/train_ref.py, torch fp32 on the host cores) on the same step.
@@ -24,6 +28,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MATRIX_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA; one f32 product = 6 bf16 products
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
 FLOP_PER_SUBTOMO = 3.66e9        # q fwd+bwd 2.70 + k fwd 0.96 GFLOP
 
@@ -45,8 +50,8 @@ def build_views(tomo_dev, n_crops, crop, seed):
 
 
 def conv_profile(engine, pq, pk, batch, steps):
-    """Eager steps with a HIP-event pair around every conv_igemm launch (events are recorded on the
-    stream the kernels are launched on)."""
+    """Eager steps; every conv call is followed by PROFILE_REPEAT more launches of itself between two HIP
+    events on the launch stream (back to back, so the eager-mode gap in front of a lone launch is not counted)."""
     from cet_pick_amd import hipops as H
     H.PROFILE = []
     saved = engine.use_graph
@@ -61,12 +66,12 @@ def conv_profile(engine, pq, pk, batch, steps):
     H.PROFILE = None
     engine.use_graph = saved
     engine.moco.overlap_key_branch = saved_overlap
-    tot_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in recs)
-    tot_flop = sum(f for _, f, _, _ in recs)
+    tot_ms = sum(e0.elapsed_time(e1) / r for _, _, e0, e1, r in recs)
+    tot_flop = sum(f for _, f, _, _, _ in recs)
     by = {}
-    for tag, f, e0, e1 in recs:
+    for tag, f, e0, e1, r in recs:
         d = by.setdefault(tag, [0, 0.0, 0.0])
-        d[0] += 1; d[1] += f; d[2] += e0.elapsed_time(e1)
+        d[0] += 1; d[1] += f; d[2] += e0.elapsed_time(e1) / r
     return tot_flop, tot_ms, len(recs), by
 
 
@@ -233,6 +238,22 @@ def main():
     out = None
     # the roofline pass runs three more steps: EVERY rank takes them (they contain the step's collectives)
     flop, ms, n_launch, by = conv_profile(engine, pq, pk, B, 3)
+    arith = "f32" if os.environ.get("MI_CONV_ARITH", "")[:1] == "f" else "bf16x3"
+    # the same step on the f32 MFMA instruction (fresh graph capture; N = 1 only: a reported comparison, not `value`)
+    f32_ms = None
+    if world == 1 and arith == "bf16x3" and not args.no_secondary:
+        os.environ["MI_CONV_ARITH"] = "f32"
+        engine._graph = None
+        for i in range(3):
+            run(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            run(i)
+        torch.cuda.synchronize()
+        f32_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        os.environ.pop("MI_CONV_ARITH")
+        engine._graph = None
     if rank == 0:
         value = B * world * args.steps / dt
         achieved = flop / (ms * 1e-3) / 1e12
@@ -244,18 +265,25 @@ def main():
             "config": {"workload": "moco_main.py moco3d_18: 3D encoder, synthetic 512x512x128 tomogram, 32^3 subtomo "
                                    "crops, batch 64 per GPU, r=1024, dim=128, m=0.999, T=0.1, SGD lr 1e-3",
                        "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "conv_arithmetic": ("f32 products as 6 bf16 MFMA products of a 3-way bf16 cut, f32 accumulate "
+                                           "(f32-equivalent; MI_CONV_ARITH=f32 for the f32 MFMA)" if arith == "bf16x3"
+                                           else "v_mfma_f32_32x32x2_f32"),
                        "hipgraph": bool(engine.use_graph), "final_loss": final_loss},
             "step_mfma_frac_of_peak": value / world * FLOP_PER_SUBTOMO / 1e12 / PEAK_F32_MATRIX_TFLOPS,
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel + stem_fwd/stem_wgrad_kernel (fwd/dgrad/wgrad, all 75 conv launches of a step)",
                          "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                         "peak_note": "peak = f32 MFMA (the dtype's matrix peak); the bf16x3 arithmetic runs on the bf16 "
+                                      "pipe, whose ceiling for f32-equivalent work is 2500/6 TFLOP/s",
+                         "peak_bf16x3": PEAK_BF16_MATRIX_TFLOPS / 6, "frac_bf16x3": achieved / (PEAK_BF16_MATRIX_TFLOPS / 6),
                          "launches_per_step": n_launch // 3, "kernel_ms_per_step": ms / 3,
                          "algorithmic_gflop_per_step": flop / 3 / 1e9,
                          "by_mode": {t: {"launches_per_step": v[0] // 3, "gflop_per_step": v[1] / 3 / 1e9,
                                          "ms_per_step": v[2] / 3, "tflops": v[1] / (v[2] * 1e-3) / 1e12}
                                      for t, v in sorted(by.items())},
-                         "measured": "HIP events around every conv call (kernel + its split-K reduce), 3 eager steps "
-                                     "after the timed region; compare profiles/r01_train_kernel_stats.csv"},
+                         "measured": "per conv call of 3 eager steps after the timed region: 8 back-to-back launches of the "
+                                     "call (kernel + its split-K reduce) between two HIP events on the launch stream; "
+                                     "compare profiles/r01_train_kernel_stats.csv"},
         }
         # HBM traffic of the conv kernels from PMC counters (collected offline by tools/pmc_traffic.sh: two rocprofv3
         # --pmc passes of this workload; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), per conv call
@@ -263,6 +291,9 @@ def main():
         if os.path.exists(tpath):
             out["roofline"]["traffic"] = json.load(open(tpath))["hbm_bytes_per_conv_call"]
             out["roofline"]["traffic_note"] = "bytes per conv call (75 per step), profiles/r01_conv_traffic.json"
+        if f32_ms is not None:
+            out["f32_mfma_step"] = {"ms_per_step": f32_ms, "value": B / (f32_ms * 1e-3),
+                                    "note": "the same step with MI_CONV_ARITH=f32 (v_mfma_f32_32x32x2_f32 in the generic kernel)"}
         log("conv roofline pass done")
         if not args.no_secondary:
             out["secondary"] = inference_secondary(dev)

@@ -823,6 +823,13 @@ int env_int(const char* name) {
     return v ? atoi(v) : 0;
 }
 
+// Arithmetic of the generic kernel: "bf16x3" (default; f32-equivalent three-way bf16 cut on the bf16 matrix pipe, see
+// the kernel's header) or "f32" (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain) - MI_CONV_ARITH selects.
+bool conv_arith_bf16x3() {
+    const char* v = getenv("MI_CONV_ARITH");
+    return !(v && v[0] == 'f');
+}
+
 // red_ch: reduction channels (FWD: Ci, DGRAD: Co; 0 for WGRAD / stem where any depth works)
 // red_len: longest reduction in elements; tiles_x_of(bm): row tiles for a given BM
 // Tile choice measured on MI355X (tools/bench_conv.py, profiles/r01_conv_tuning.txt): with the
@@ -873,7 +880,7 @@ template <int MODE, bool STEM>
 int launch_mode(const ConvParams& p, const Plan& pl, hipStream_t s) {
     dim3 grid((unsigned)(pl.tiles_x * ((p.Ncols + pl.bn - 1) / pl.bn) * pl.splits));    // 1-D, decoded in the kernel
     if constexpr (!STEM) {
-        if (env_int("MI_CONV_BF16X3") && pl.bm == 64 && pl.bn == 64 && (pl.bk == 32 || pl.bk == 16)) {
+        if (conv_arith_bf16x3() && pl.bm == 64 && pl.bn == 64 && (pl.bk == 32 || pl.bk == 16)) {
             if (pl.bk == 32) hipLaunchKernelGGL((conv_igemm_kernel<MODE, 64, 64, 32, false, true>), grid, dim3(NTHREADS), 0, s, p);
             else hipLaunchKernelGGL((conv_igemm_kernel<MODE, 64, 64, 16, false, true>), grid, dim3(NTHREADS), 0, s, p);
             MI_RETURN_IF_LAUNCH_FAILED();

@@ -15,25 +15,22 @@ import torch.nn as nn
 from . import _lib as L
 
 
-PROFILE = None   # bench.py: list collecting (tag, flops, start_event, end_event) per conv launch
+PROFILE = None          # bench.py: list collecting (tag, flops, start_event, end_event, launches) per conv call
+PROFILE_REPEAT = 8      # timed back-to-back launches per call (hides the eager-mode gap in front of a lone launch)
 
 
-class _Prof:
-    def __init__(self, tag, flops):
-        self.on = PROFILE is not None
-        if self.on:
-            self.tag, self.flops = tag, flops
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-
-    def __enter__(self):
-        if self.on:
-            self.e0.record()
-
-    def __exit__(self, *a):
-        if self.on:
-            self.e1.record()
-            PROFILE.append((self.tag, self.flops, self.e0, self.e1))
+def _prof_run(tag, flops, fn):
+    """Run one conv call; under bench.py's roofline pass also time PROFILE_REPEAT more launches of the same call
+    (idempotent: outputs never alias inputs) between two HIP events on the launch stream."""
+    fn()
+    if PROFILE is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(PROFILE_REPEAT):
+            fn()
+        e1.record()
+        PROFILE.append((tag, flops, e0, e1, PROFILE_REPEAT))
 
 
 def _ws(nbytes, device, tag):
@@ -178,16 +175,18 @@ def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None):
         do, ho, wo = (v + 2 * p - dl * (kk - 1) for v, kk, p, dl in zip((d, h, wd), k3, p3, d3))
         y = torch.empty((n, do, ho, wo, co) if nd5 else (n, ho, wo, co), dtype=torch.float32, device=x.device)
         ws = _ws(lib.mi_convnd_dil_workspace_bytes(n, d, h, wd, ci, co, *k3, *p3, *d3), x.device, "conv")
-        with _Prof("fwd", 2.0 * n * do * ho * wo * co * ci * k3[0] * k3[1] * k3[2]):
-            L.check(lib.mi_convnd_dil_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(res), int(relu), n, d, h, wd, ci, co,
-                                              *k3, *p3, *d3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_dil_fwd_f32")
+        def call():
+            return L.check(lib.mi_convnd_dil_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(res), int(relu), n, d, h,
+                wd, ci, co, *k3, *p3, *d3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_dil_fwd_f32")
+        _prof_run("fwd", 2.0 * n * do * ho * wo * co * ci * k3[0] * k3[1] * k3[2], call)
         return y
     do, ho, wo = _out_dims(x5.shape, k3, stride, p3)
     y = torch.empty((n, do, ho, wo, co) if nd5 else (n, ho, wo, co), dtype=torch.float32, device=x.device)
     ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), x.device, "conv")
-    with _Prof("fwd", 2.0 * n * do * ho * wo * co * ci * k3[0] * k3[1] * k3[2]):
-        L.check(lib.mi_convnd_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(res), int(relu), n, d, h, wd, ci, co,
-                                      *k3, stride, *p3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_fwd_f32")
+    def call():
+        return L.check(lib.mi_convnd_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(res), int(relu), n, d, h, wd, ci,
+            co, *k3, stride, *p3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_fwd_f32")
+    _prof_run("fwd", 2.0 * n * do * ho * wo * co * ci * k3[0] * k3[1] * k3[2], call)
     return y
 
 
@@ -204,15 +203,16 @@ def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None, dil=None):
     if dil is not None and tuple(_k3(dil, nd5)) != (1, 1, 1):
         d3 = _k3(dil, nd5)
         ws = _ws(lib.mi_convnd_dil_workspace_bytes(n, d, h, wd, ci, co, *k3, *p3, *d3), dy.device, "conv")
-        with _Prof("dgrad", flops):
-            L.check(lib.mi_convnd_dil_dgrad_f32(L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(res), L.ptr(mask), n, d, h, wd, ci,
-                                                co, *k3, *p3, *d3, L.ptr(ws), ws.numel(), L.stream()),
-                    "mi_convnd_dil_dgrad_f32")
+        def call():
+            return L.check(lib.mi_convnd_dil_dgrad_f32(L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(res), L.ptr(mask), n, d,
+                h, wd, ci, co, *k3, *p3, *d3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_dil_dgrad_f32")
+        _prof_run("dgrad", flops, call)
         return dx
     ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), dy.device, "conv")
-    with _Prof("dgrad", flops):
-        L.check(lib.mi_convnd_dgrad_f32(L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(res), L.ptr(mask), n, d, h, wd, ci, co,
-                                        *k3, stride, *p3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_dgrad_f32")
+    def call():
+        return L.check(lib.mi_convnd_dgrad_f32(L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(res), L.ptr(mask), n, d, h, wd,
+            ci, co, *k3, stride, *p3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_dgrad_f32")
+    _prof_run("dgrad", flops, call)
     return dx
 
 
@@ -229,14 +229,16 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
     if dil is not None and tuple(_k3(dil, nd5)) != (1, 1, 1):
         d3 = _k3(dil, nd5)
         ws = _ws(lib.mi_convnd_dil_workspace_bytes(n, d, h, wd, ci, co, *k3, *p3, *d3), x.device, "conv")
-        with _Prof("wgrad", flops):
-            L.check(lib.mi_convnd_dil_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, *k3, *p3, *d3,
-                                                L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_dil_wgrad_f32")
+        def call():
+            return L.check(lib.mi_convnd_dil_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, *k3,
+                *p3, *d3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_dil_wgrad_f32")
+        _prof_run("wgrad", flops, call)
     else:
         ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), x.device, "conv")
-        with _Prof("wgrad", flops):
-            L.check(lib.mi_convnd_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, *k3, stride, *p3,
-                                            L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_wgrad_f32")
+        def call():
+            return L.check(lib.mi_convnd_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, *k3, stride,
+                *p3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_wgrad_f32")
+        _prof_run("wgrad", flops, call)
     if acc:
         g.add_(tgt)
 

@@ -45,9 +45,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("arith", ["bf16x3", "f32"])
 @pytest.mark.parametrize("case", CASES)
-def test_conv_fwd_dgrad_wgrad(case):
+def test_conv_fwd_dgrad_wgrad(case, arith, monkeypatch):
     from cet_pick_amd import hipops as H
+    monkeypatch.setenv("MI_CONV_ARITH", arith)      # generic kernel: bf16x3 cut (default) / native f32 MFMA
     n, d, h, w_, ci, co, k, s, p = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(n, ci, d, h, w_, generator=g)
@@ -78,6 +80,37 @@ def test_conv_fwd_dgrad_wgrad(case):
     # second call accumulates (AccumulateGrad contract)
     H.conv_wgrad_into(cl(x), cl(dy), param, k, s, p)
     np.testing.assert_allclose(param.grad.cpu().numpy(), 2 * wr.grad.numpy(), rtol=1e-4, atol=4e-5 * max(scale, 1.0))
+
+
+@pytest.mark.parametrize("case", [(16, 8, 8, 8, 64, 64, 3, 1, 1), (8, 4, 4, 4, 128, 256, 3, 2, 1), (5, 4, 4, 4, 48, 16, 3, 1, 1),
+                                  (16, 2, 2, 2, 256, 512, 1, 2, 0)])
+def test_conv_bf16x3_is_f32_equivalent(case, monkeypatch):
+    """The default arithmetic (three-way bf16 cut, six products, f32 accumulate on the bf16 matrix pipe) against float64:
+    its error may not exceed the error of the f32 MFMA path (an fmaf chain) by more than rounding-order noise."""
+    from cet_pick_amd import hipops as H
+    n, d, h, w_, ci, co, k, s, p = case
+    g = torch.Generator().manual_seed(7 + sum(case))
+    # wide dynamic range: the cut must hold for every exponent, not only for unit-scale data
+    x = torch.randn(n, ci, d, h, w_, generator=g) * torch.exp(3 * torch.randn(n, ci, d, h, w_, generator=g))
+    param, w = make_w(co, ci, k, g)
+    x64 = x.double().cuda().requires_grad_(True)
+    w64 = w.double().cuda().requires_grad_(True)
+    y64 = F.conv3d(x64, w64, stride=s, padding=p)
+    dy = torch.randn(y64.shape, generator=g)
+    gx, gw = torch.autograd.grad(y64, (x64, w64), dy.double().cuda())
+    ref = (y64.detach().permute(0, 2, 3, 4, 1), gx.permute(0, 2, 3, 4, 1), gw)
+    errs = {}
+    for arith in ("f32", "bf16x3"):
+        monkeypatch.setenv("MI_CONV_ARITH", arith)
+        y = H.conv_fwd(cl(x), param, k, s, p)
+        dx = H.conv_dgrad(cl(dy), param, (n, d, h, w_, ci), k, s, p)
+        param.grad = None
+        H.conv_wgrad_into(cl(x), cl(dy), param, k, s, p)
+        outs = (y, dx, param.grad.clone())
+        errs[arith] = [float((a.double() - b).abs().max() / b.abs().max()) for a, b in zip(outs, ref)]
+    for e32, e3 in zip(errs["f32"], errs["bf16x3"]):
+        assert e3 < 2e-6, errs                  # f32-level accuracy in absolute terms ...
+        assert e3 <= 2.0 * e32 + 2e-7, errs     # ... and no worse than the f32 matrix instruction
 
 
 @pytest.mark.parametrize("shape", [(4, 16, 16, 16, 64), (8, 2, 2, 2, 256), (64, 128), (6, 3, 5, 7, 32)])

@@ -49,7 +49,7 @@ def run(small=False):
         torch.cuda.synchronize()
         prof, H.PROFILE = H.PROFILE, None
     cflops = sum(p[1] for p in prof)
-    cms = sum(p[2].elapsed_time(p[3]) for p in prof)
+    cms = sum(p[2].elapsed_time(p[3]) / p[4] for p in prof)
     out["unet4_forward"] = {"input": list(vol.shape), "ms": t * 1e3, "input_voxels_per_sec": vol.numel() / t,
                             "conv_gflop": cflops / 1e9, "conv_ms": cms, "conv_tflops": cflops / cms / 1e9,
                             "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}

@@ -1,4 +1,4 @@
-"""bf16x3 conv path (MI_CONV_BF16X3=1) against the native f32 MFMA path and against float64, on assorted shapes."""
+"""bf16x3 conv path (MI_CONV_ARITH=bf16x3, the default) against the native f32 MFMA path (MI_CONV_ARITH=f32) and against float64, on assorted shapes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,16 +21,15 @@ def run(case, seed):
     dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous()
     ref = (y64.permute(0, 2, 3, 4, 1), gx.permute(0, 2, 3, 4, 1), gw)
     errs = []
-    for env in ("", "1"):
-        if env: os.environ["MI_CONV_BF16X3"] = env
-        else: os.environ.pop("MI_CONV_BF16X3", None)
+    for env in ("f32", "bf16x3"):
+        os.environ["MI_CONV_ARITH"] = env
         y = H.conv_fwd(x, wt, k, s, p)
         dx = H.conv_dgrad(dy_cl, wt, tuple(x.shape), k, s, p)
         wt.grad = None
         H.conv_wgrad_into(x, dy_cl, wt, k, s, p)
         outs = (y, dx, wt.grad.clone())
         errs.append([float((a.double() - b).abs().max() / (b.abs().max() + 1e-30)) for a, b in zip(outs, ref)])
-    os.environ.pop("MI_CONV_BF16X3", None)
+    os.environ.pop("MI_CONV_ARITH", None)
     return errs
 
 
