@@ -242,14 +242,44 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float* x
     const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
     const long total = (long)g.N * g.Do * g.Ho * g.Wo * CV;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        long v = i / CV;
-        const int xo = (int)(v % g.Wo); v /= g.Wo;
-        const int yo = (int)(v % g.Ho); v /= g.Ho;
-        const int zo = (int)(v % g.Do);
-        const int n = (int)(v / g.Do);
+        unsigned v = (unsigned)i / (unsigned)CV;                 // (the host checks total < 2^31)
+        const int xo = (int)(v % (unsigned)g.Wo); v /= (unsigned)g.Wo;
+        const int yo = (int)(v % (unsigned)g.Ho); v /= (unsigned)g.Ho;
+        const int zo = (int)(v % (unsigned)g.Do);
+        const int n = (int)(v / (unsigned)g.Do);
         float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int bi[4] = {0, 0, 0, 0};
         bool first = true;
+        if (g.k == 3) {
+            // 3^3 window: the nine loads of a z-plane are issued together (addresses clamped into the tensor, validity
+            // kept aside) instead of one dependent load per tap; same visiting order, so the same argmax on ties
+            for (int a = 0; a < 3; ++a) {
+                const int zi = zo * g.s - g.pad + a;
+                const bool zok = (unsigned)zi < (unsigned)g.Di;
+                float4 t9[9];
+                bool ok9[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    const int yi = yo * g.s - g.pad + q / 3, xi = xo * g.s - g.pad + q % 3;
+                    ok9[q] = zok & ((unsigned)yi < (unsigned)g.Hi) & ((unsigned)xi < (unsigned)g.Wi);
+                    const int zc = min(max(zi, 0), g.Di - 1), yc = min(max(yi, 0), g.Hi - 1), xc = min(max(xi, 0), g.Wi - 1);
+                    t9[q] = ld4(x + ((((long)n * g.Di + zc) * g.Hi + yc) * g.Wi + xc) * C + c);
+                }
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    if (!ok9[q]) continue;
+                    const float xv[4] = {t9[q].x, t9[q].y, t9[q].z, t9[q].w};
+                    const int tap = a * 9 + q;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = fmaxf(fmaf((xv[r] - m[r]) * iv[r], gg[r], bb[r]), 0.f);
+                        const float tn = xv[r] != xv[r] ? xv[r] : t;          // a NaN input stays a NaN
+                        if (first || tn > best[r] || tn != tn) { best[r] = tn; bi[r] = tap; }
+                    }
+                    first = false;
+                }
+            }
+        } else
         for (int a = 0; a < g.k; ++a) {
             const int zi = zo * g.s - g.pad + a;
             if ((unsigned)zi >= (unsigned)g.Di) continue;
@@ -540,37 +570,71 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, float*
     }
 }
 
+// One workgroup per input row (n, zi, yi): the row's (xi, channel-quad) items are the threads, so the only per-item
+// divisions are by the compile-time stride S (0 = run-time stride) - the element-wise form of this kernel spent its time
+// in integer divisions (7 per item by run-time values), not in memory.
+template <int S>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, const uint8_t* arg,
                                                          float* dx, int N, int Di, int Hi, int Wi,
-                                                         int C, int Do, int Ho, int Wo, int k, int s,
+                                                         int C, int Do, int Ho, int Wo, int k, int s_rt,
                                                          int pad) {
+    const int s = S ? S : s_rt;
     const int CV = C >> 2;
-    const long total = (long)N * Di * Hi * Wi * CV;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        int cv = (int)(i % CV);
-        long v = i / CV;
-        int xi = (int)(v % Wi); v /= Wi;
-        int yi = (int)(v % Hi); v /= Hi;
-        int zi = (int)(v % Di);
-        int n = (int)(v / Di);
-        float acc[4] = {0, 0, 0, 0};
-        // the pooled windows that contain this voxel: o in [ceil((i + pad - k + 1)/s), floor((i + pad)/s)]
-        const int zl = max(0, (zi + pad - k + s) / s), zh = min(Do - 1, (zi + pad) / s);
-        const int yl = max(0, (yi + pad - k + s) / s), yh = min(Ho - 1, (yi + pad) / s);
+    const unsigned row = blockIdx.x;                       // wave-uniform decode
+    const int yi = (int)(row % (unsigned)Hi);
+    const unsigned r2 = row / (unsigned)Hi;
+    const int zi = (int)(r2 % (unsigned)Di), n = (int)(r2 / (unsigned)Di);
+    // the pooled windows that contain this voxel: o in [ceil((i + pad - k + 1)/s), floor((i + pad)/s)]
+    const int zl = max(0, (zi + pad - k + s) / s), zh = min(Do - 1, (zi + pad) / s);
+    const int yl = max(0, (yi + pad - k + s) / s), yh = min(Ho - 1, (yi + pad) / s);
+    const long row_base = (((long)n * Di + zi) * Hi + yi) * Wi;
+    const bool pow2 = (CV & (CV - 1)) == 0;
+    const int sh = 31 - __builtin_clz((unsigned)CV);
+    for (int t = threadIdx.x; t < Wi * CV; t += 256) {
+        const int xi = pow2 ? t >> sh : t / CV, cv = pow2 ? t & (CV - 1) : t % CV;
         const int xl = max(0, (xi + pad - k + s) / s), xh = min(Wo - 1, (xi + pad) / s);
-        for (int zo = zl; zo <= zh; ++zo)
-            for (int yo = yl; yo <= yh; ++yo)
-                for (int xo = xl; xo <= xh; ++xo) {
-                    const long o = ((((long)n * Do + zo) * Ho + yo) * Wo + xo) * C + 4 * cv;
-                    const uchar4 am = *reinterpret_cast<const uchar4*>(arg + o);
-                    const float4 d = ld4(dy + o);
-                    const int tap = ((zi + pad - zo * s) * k + (yi + pad - yo * s)) * k + (xi + pad - xo * s);
-                    if (am.x == tap) acc[0] += d.x;
-                    if (am.y == tap) acc[1] += d.y;
-                    if (am.z == tap) acc[2] += d.z;
-                    if (am.w == tap) acc[3] += d.w;
+        float acc[4] = {0, 0, 0, 0};
+        if (k <= 2 * s) {
+            // at most two windows per axis (k = 3, s = 2).  The eight candidate argmax words (4 bytes each) are loaded
+            // together; the gradient (16 bytes) is fetched only where a channel's argmax names this voxel
+            uchar4 am[8];
+            long off[8];
+            int tp[8];
+            const bool any = (zl <= zh) & (yl <= yh) & (xl <= xh);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int zo = zl + (q >> 2), yo = yl + ((q >> 1) & 1), xo = xl + (q & 1);
+                const bool ok = any & (zo <= zh) & (yo <= yh) & (xo <= xh);
+                off[q] = ok ? ((((long)n * Do + zo) * Ho + yo) * Wo + xo) * C + 4 * cv : 4 * cv;
+                am[q] = *reinterpret_cast<const uchar4*>(arg + off[q]);
+                tp[q] = ok ? ((zi + pad - zo * s) * k + (yi + pad - yo * s)) * k + (xi + pad - xo * s) : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bool hx = am[q].x == tp[q], hy = am[q].y == tp[q], hz = am[q].z == tp[q], hw = am[q].w == tp[q];
+                if (hx | hy | hz | hw) {
+                    const float4 d = ld4(dy + off[q]);
+                    if (hx) acc[0] += d.x;
+                    if (hy) acc[1] += d.y;
+                    if (hz) acc[2] += d.z;
+                    if (hw) acc[3] += d.w;
                 }
-        st4(dx + 4 * i, make_float4(acc[0], acc[1], acc[2], acc[3]));
+            }
+        } else {
+            for (int zo = zl; zo <= zh; ++zo)
+                for (int yo = yl; yo <= yh; ++yo)
+                    for (int xo = xl; xo <= xh; ++xo) {
+                        const long o = ((((long)n * Do + zo) * Ho + yo) * Wo + xo) * C + 4 * cv;
+                        const uchar4 am = *reinterpret_cast<const uchar4*>(arg + o);
+                        const float4 d = ld4(dy + o);
+                        const int tap = ((zi + pad - zo * s) * k + (yi + pad - yo * s)) * k + (xi + pad - xo * s);
+                        if (am.x == tap) acc[0] += d.x;
+                        if (am.y == tap) acc[1] += d.y;
+                        if (am.z == tap) acc[2] += d.z;
+                        if (am.w == tap) acc[3] += d.w;
+                    }
+        }
+        st4(dx + 4 * ((row_base + xi) * CV + cv), make_float4(acc[0], acc[1], acc[2], acc[3]));
     }
 }
 
@@ -849,6 +913,7 @@ extern "C" int mi_bn_relu_maxpool3d_fwd(const float* x, float* y, uint8_t* argma
     if (sums ? (!save_mean_invstd || !(count > 0)) : (!running_mean || !running_var)) return MI_E_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MI_E_ARG;
     const long total = (long)N * g.Do * g.Ho * g.Wo * (C / 4);
+    if (total >= (1l << 31)) return MI_E_UNSUPPORTED;
     hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax,
                        g, C, sums, count, eps, momentum, running_mean, running_var, num_batches_tracked,
                        save_mean_invstd, gamma, beta);
@@ -976,9 +1041,17 @@ extern "C" int mi_maxpool3d_bwd(const float* dy, const uint8_t* argmax, float* d
                                 int Hi, int Wi, int C, int k, int stride, int pad, mi_stream_t stream) {
     if (!dy || !argmax || !dx || C % 4 || k <= 0 || k > 6 || stride <= 0 || pad < 0) return MI_E_ARG;
     int Do = (Di + 2 * pad - k) / stride + 1, Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
-    long total = (long)N * Di * Hi * Wi * (C / 4);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy,
-                       argmax, dx, N, Di, Hi, Wi, C, Do, Ho, Wo, k, stride, pad);
+    const long rows = (long)N * Di * Hi;
+    if (rows >= (1l << 31)) return MI_E_UNSUPPORTED;
+    if (stride == 2)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<2>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, N,
+                           Di, Hi, Wi, C, Do, Ho, Wo, k, stride, pad);
+    else if (stride == 1)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<1>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, N,
+                           Di, Hi, Wi, C, Do, Ho, Wo, k, stride, pad);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<0>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, N,
+                           Di, Hi, Wi, C, Do, Ho, Wo, k, stride, pad);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
