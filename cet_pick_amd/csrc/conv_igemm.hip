@@ -35,7 +35,8 @@
 
 // conv_stem.hip: direct kernels for the 7^3 stride-2 stem; MI_E_UNSUPPORTED = shape declined, take the generic path
 int mi_stem7_fwd(const float* x, const float* w, float* y, const float* res, int relu, int N, int D, int H, int W,
-                 int Co, hipStream_t s);
+                 int Co, int bf16x3, void* ws, size_t ws_bytes, hipStream_t s);
+size_t mi_stem7_fwd_workspace_bytes();
 size_t mi_stem7_wgrad_workspace_bytes(int N, int D, int H, int W, int Co);
 int mi_stem7_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Co, void* ws,
                    size_t ws_bytes, hipStream_t s);
@@ -1119,7 +1120,9 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
     // the 7^3 stride-2 stem has its own direct kernels (conv_stem.hip); anything they decline runs below
     if (is_stem7(g) && !env_int("MI_CONV_NO_STEM")) {
         int rc = MI_E_UNSUPPORTED;
-        if (mode == MODE_FWD) rc = mi_stem7_fwd(a_src, b_src, out, res, relu, g.N, g.Di, g.Hi, g.Wi, g.Co, s);
+        if (mode == MODE_FWD)
+            rc = mi_stem7_fwd(a_src, b_src, out, res, relu, g.N, g.Di, g.Hi, g.Wi, g.Co, conv_arith_bf16x3() ? 1 : 0, ws,
+                              ws_bytes, s);
         else if (mode == MODE_WGRAD) rc = mi_stem7_wgrad(a_src, b_src, out, g.N, g.Di, g.Hi, g.Wi, g.Co, ws, ws_bytes, s);
         if (rc != MI_E_UNSUPPORTED) return rc;
     }
@@ -1158,7 +1161,7 @@ extern "C" size_t mi_conv3d_workspace_bytes(int N, int Di, int Hi, int Wi, int C
                                             int stride, int pad) {
     Geom g = make_geom(N, Di, Hi, Wi, Ci, Co, k, stride, pad);
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
-    size_t best = is_stem7(g) ? mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co) : 0;
+    size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;
@@ -1197,7 +1200,7 @@ extern "C" size_t mi_convnd_workspace_bytes(int N, int Di, int Hi, int Wi, int C
                                             int kw, int stride, int pd, int ph, int pw) {
     Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
-    size_t best = is_stem7(g) ? mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co) : 0;
+    size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;
@@ -1238,7 +1241,7 @@ extern "C" size_t mi_convnd_dil_workspace_bytes(int N, int Di, int Hi, int Wi, i
                                                 int kw, int pd, int ph, int pw, int dd, int dh, int dw) {
     Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, 1, pd, ph, pw, dd, dh, dw);
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
-    size_t best = is_stem7(g) ? mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co) : 0;
+    size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;

@@ -12,6 +12,7 @@
 //      k = 2t + h, whose patch offset differs from that of 2t by 1 (same row) or by PW - 6 (row wrap) - two lane
 //      base registers cover both cases, the rest is an immediate.
 #include "common.h"
+#include <type_traits>
 #include "../../include/cetpick_hip.h"
 
 namespace {
@@ -136,6 +137,197 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
         wstore((kz + 1) & 1);
         wload(kz + 2);
         __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane & 31 (channel), row = (r&3) + 8*(r>>2) + 4*h (output voxel) ----
+    const int oz = oz0 + wave;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = j * 32 + l32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ox = ox0 + (m & 7), oy = oy0 + (m >> 3);
+            const long o = ((((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * CO + co;
+            float v = j == 0 ? acc0[r] : acc1[r];
+            if (p.res) v += p.res[o];
+            if (p.relu) v = fmaxf(v, 0.f);
+            p.y[o] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// FWD on the bf16 matrix pipe with f32-equivalent arithmetic (the "bf16x3" cut of conv_igemm.hip: a = a0 + a1 + a2
+// exactly, six products of weight <= 2 per f32 product, f32 accumulate).  The patch is cut ONCE while it is staged
+// (three bf16 planes of 48-byte rows); the weights are cut once per call by stem_wprep_kernel into the LDS image
+// [kz][plane][ky 0..7][co][kx 0..7] (ky = 7 and kx = 7 are zero padding), streamed one kz slab (24 KB) at a time.
+// One v_mfma_f32_32x32x16_bf16 takes K = 16 = two (kz, ky) rows x 8 kx: lane-half h owns row ky = 2u + h, whose eight
+// kx taps are eight CONSECUTIVE patch elements (stride-2 convolution: x = 2 ox + kx) - four ds_read_b32 per plane,
+// conflict-free on 48-byte rows.  28 k-steps x 6 products x 2 column tiles = 336 MFMAs of 32 cycles per wave against
+// 350 of 64 cycles in the f32 kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int PYP = PY + 1;                              // + one zero row: the padded tap ky = 7 of the last output row
+constexpr int PROW = 2 * PW;                             // bytes per bf16 patch row
+constexpr int PPLANE = PZ * PYP * PROW;                  // 8736 bytes
+constexpr int WPL = 8 * CO * 16;                         // bytes per plane of a kz slab: [ky8][co][kx8] bf16
+constexpr int WSLAB = 3 * WPL;                           // 24576 bytes
+constexpr size_t WPREP_BYTES = (size_t)K7 * WSLAB;       // 172032 bytes
+
+// exact three-way bf16 cut of one f32 (truncation; see conv_igemm.hip): the three bf16 bit patterns
+__device__ __forceinline__ void cut3(float a, unsigned& h0, unsigned& h1, unsigned& h2) {
+    const unsigned u0 = __float_as_uint(a);
+    const float r1 = a - __uint_as_float(u0 & 0xffff0000u);
+    const unsigned u1 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+    h0 = u0 >> 16; h1 = u1 >> 16; h2 = __float_as_uint(r2) >> 16;
+}
+
+__global__ __launch_bounds__(256) void stem_wprep_kernel(const float* w, unsigned short* out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;        // (kz, ky8, co, kx8)
+    if (i >= K7 * 8 * CO * 8) return;
+    const int kx = i & 7, co = (i >> 3) & (CO - 1), ky = (i >> 9) & 7, kz = i >> 12;
+    const float v = (ky < K7 && kx < K7) ? w[((kz * K7 + ky) * K7 + kx) * CO + co] : 0.f;
+    unsigned h0, h1, h2;
+    cut3(v, h0, h1, h2);
+    const int o = kz * (WSLAB / 2) + (ky * CO + co) * 8 + kx;
+    out[o] = (unsigned short)h0; out[o + WPL / 2] = (unsigned short)h1; out[o + WPL] = (unsigned short)h2;
+}
+
+__global__ __launch_bounds__(256, 2) void stem_fwd_bf3_kernel(StemParams p, const unsigned char* wprep) {
+    __shared__ __attribute__((aligned(16))) unsigned char patchb[3 * PPLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char wl[2][WSLAB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    const int txn = p.Wo / TX, tyn = p.Ho / TY, tzn = p.Do / TZ;
+    int b = blockIdx.x;
+    const int bx = b % txn; b /= txn;
+    const int by = b % tyn; b /= tyn;
+    const int bz = b % tzn;
+    const int n = b / tzn;
+    const int ox0 = bx * TX, oy0 = by * TY, oz0 = bz * TZ;
+
+    // ---- weight slab 0 in flight first, then the patch (pairs of x-neighbours -> one packed dword per plane) ----
+    constexpr int WLD = WSLAB / 16 / 256;                // 6 x 16 bytes per thread and slab
+    u32x4 wreg[WLD];
+    auto wload = [&](int kz) {
+        if (kz >= K7) return;
+#pragma unroll
+        for (int i = 0; i < WLD; ++i)
+            wreg[i] = *reinterpret_cast<const u32x4*>(wprep + (size_t)kz * WSLAB + 16 * (tid + i * 256));
+    };
+    auto wstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WLD; ++i) *reinterpret_cast<u32x4*>(&wl[buf][16 * (tid + i * 256)]) = wreg[i];
+    };
+    wload(0);
+    {
+        constexpr int PAIRS = PZ * PYP * (PW / 2);       // 2184
+        constexpr int NPP = (PAIRS + 255) / 256;         // 9 pairs per thread
+        const __amdgpu_buffer_rsrc_t xr = rsrc(p.x, p.x_bytes);
+        const int iz0 = oz0 * S2 - P3, iy0 = oy0 * S2 - P3, ix0 = ox0 * S2 - P3;
+        float pv[NPP][2];
+#pragma unroll
+        for (int u = 0; u < NPP; ++u) {
+            const int i = tid + u * 256;
+#ifdef MI_DBG_STEM_NOPATCH   // timing experiment (results are garbage)
+            pv[u][0] = pv[u][1] = 1.f;
+            continue;
+#endif
+            const int pp = i % (PW / 2), t = i / (PW / 2), py = t % PYP, pz = t / PYP;
+            const int iz = iz0 + pz, iy = iy0 + py;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int px = 2 * pp + e, ix = ix0 + px;
+                const bool ok = (px < PX) & (py < PY) & (pz < PZ) & ((unsigned)iz < (unsigned)p.D) &
+                                ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                const unsigned off = ok ? 4u * (unsigned)((((long)n * p.D + iz) * p.H + iy) * p.W + ix) : 0x80000000u;
+                pv[u][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)off, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NPP; ++u) {
+            const int i = tid + u * 256;
+            if (i < PAIRS) {
+                unsigned a0, a1, a2, b0, b1, b2;
+                cut3(pv[u][0], a0, a1, a2);
+                cut3(pv[u][1], b0, b1, b2);
+                unsigned char* d = patchb + 4 * i;       // pair i of plane 0 (rows are 12 pairs = 48 bytes)
+                *reinterpret_cast<unsigned*>(d) = a0 | (b0 << 16);
+                *reinterpret_cast<unsigned*>(d + PPLANE) = a1 | (b1 << 16);
+                *reinterpret_cast<unsigned*>(d + 2 * PPLANE) = a2 | (b2 << 16);
+            }
+        }
+    }
+    wstore(0);
+    wload(1);
+
+    // lane base into a patch plane: output (ox, oy) = (l32 & 7, l32 >> 3) of z-plane `wave`, row + h
+    const int a_base = ((S2 * wave) * PYP + S2 * (l32 >> 3) + h) * PROW + 4 * (l32 & 7);
+    const int b_base = (h * CO + l32) * 16;              // row ky = 2u + h, column l32 (+32 for the second tile)
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // smallest products first
+
+    // fragments of k-step (kz, u) -> register set u & 1; the reads of step g+1 are issued before the MFMAs of step g
+    bf16x8 af[2][3], bf0[2][3], bf1[2][3];
+    auto frags = [&](int kz, int u, auto SETc) {
+        constexpr int SET = decltype(SETc)::value;
+        const unsigned char* wb = wl[kz & 1] + b_base + u * (2 * CO * 16);
+        const unsigned char* ab = patchb + a_base + (kz * PYP + 2 * u) * PROW;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const unsigned char* ap = ab + pl * PPLANE;
+            u32x4 v;
+            v.x = *reinterpret_cast<const unsigned*>(ap);
+            v.y = *reinterpret_cast<const unsigned*>(ap + 4);
+            v.z = *reinterpret_cast<const unsigned*>(ap + 8);
+            v.w = *reinterpret_cast<const unsigned*>(ap + 12) & 0x0000ffffu;     // kx = 7 is padding: exact zero
+            if (u == 3 && h) v = u32x4{0u, 0u, 0u, 0u};                           // ky = 7 is padding
+            af[SET][pl] = __builtin_bit_cast(bf16x8, v);
+            bf0[SET][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * WPL);
+            bf1[SET][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * WPL + 32 * 16);
+        }
+    };
+    auto mfmas = [&](auto SETc) {
+        constexpr int SET = decltype(SETc)::value;
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) {
+#ifdef MI_DBG_STEM_ONEPROD   // timing experiment (results are garbage)
+            if (pr != 5) continue;
+#endif
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SET][PA[pr]], bf0[SET][PB[pr]], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SET][PA[pr]], bf1[SET][PB[pr]], acc1, 0, 0, 0);
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+
+    __syncthreads();
+    frags(0, 0, S0{});
+    for (int kz = 0; kz < K7; ++kz) {
+        // slab kz+1 (in registers since the previous iteration) -> the other buffer (last read during kz-1, before the
+        // barrier that ended it); then fetch slab kz+2
+        if (kz + 1 < K7) wstore((kz + 1) & 1);
+        wload(kz + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        frags(kz, 1, S1{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(S0{});
+        __builtin_amdgcn_sched_barrier(0);
+        frags(kz, 2, S0{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(S1{});
+        __builtin_amdgcn_sched_barrier(0);
+        frags(kz, 3, S1{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(S0{});
+        __syncthreads();                                   // slab kz+1 visible; slab kz fully read
+        if (kz + 1 < K7) frags(kz + 1, 0, S0{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(S1{});
     }
 
     // ---- epilogue: C/D layout col = lane & 31 (channel), row = (r&3) + 8*(r>>2) + 4*h (output voxel) ----
@@ -312,8 +504,12 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* sla
 
 // Called by conv_igemm.hip's dispatcher.  Returns MI_E_UNSUPPORTED when the shape is not the stem this kernel is
 // specialised for (the caller then takes the generic path).
+size_t mi_stem7_fwd_workspace_bytes() { return WPREP_BYTES; }
+
+// bf16x3 != 0 with a workspace of mi_stem7_fwd_workspace_bytes(): the bf16-pipe kernel (f32-equivalent); otherwise the
+// f32 MFMA kernel
 int mi_stem7_fwd(const float* x, const float* w, float* y, const float* res, int relu, int N, int D, int H, int W,
-                 int Co, hipStream_t s) {
+                 int Co, int bf16x3, void* ws, size_t ws_bytes, hipStream_t s) {
     if (Co != CO) return MI_E_UNSUPPORTED;
     const int Do = (D + 2 * P3 - K7) / S2 + 1, Ho = (H + 2 * P3 - K7) / S2 + 1, Wo = (W + 2 * P3 - K7) / S2 + 1;
     if (Do <= 0 || Ho <= 0 || Wo <= 0 || Do % TZ || Ho % TY || Wo % TX) return MI_E_UNSUPPORTED;
@@ -322,6 +518,13 @@ int mi_stem7_fwd(const float* x, const float* w, float* y, const float* res, int
     const long blocks = (long)N * (Do / TZ) * (Ho / TY) * (Wo / TX);
     if (blocks > 0x7fffffffl) return MI_E_UNSUPPORTED;
     StemParams p = {x, w, y, res, relu, N, D, H, W, Do, Ho, Wo, (unsigned)xb};
+    if (bf16x3 && ws && ws_bytes >= WPREP_BYTES) {
+        hipLaunchKernelGGL(stem_wprep_kernel, dim3((K7 * 8 * CO * 8 + 255) / 256), dim3(256), 0, s, w, (unsigned short*)ws);
+        MI_RETURN_IF_LAUNCH_FAILED();
+        hipLaunchKernelGGL(stem_fwd_bf3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, (const unsigned char*)ws);
+        MI_RETURN_IF_LAUNCH_FAILED();
+        return MI_OK;
+    }
     hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
