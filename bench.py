@@ -307,11 +307,11 @@ def main():
             out["cpu_baseline"] = {"value": v, "unit": "subtomograms/sec", "cores": cores, "kind": "port",
                                    "sample": "4 MoCo steps of batch 64 (after 1 warm-up) of the same workload "
                                              "with oracle/train_ref.py (torch fp32, all host cores)"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)           # the line is out before any tear-down
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
 
 
 if __name__ == "__main__":

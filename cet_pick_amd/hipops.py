@@ -407,6 +407,17 @@ def _dist_world():
     return 1
 
 
+FORCE_COLLECTIVES = False     # tests: issue every collective on a 1-rank group too (one-GPU rehearsal of the N>1 path)
+
+
+def _distributed():
+    """True when the data-parallel exchanges (SyncBN sums, key all-gather, gradient all-reduce) have to be issued."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or FORCE_COLLECTIVES
+
+
 BN_SMALL_MAX_ROWS = 4096      # == MI_BN_SMALL_MAX_ROWS
 
 
@@ -422,7 +433,7 @@ class _BNFn(torch.autograd.Function):
         dev = x.device
         y = torch.empty_like(x)
         save = torch.empty(2 * c, dtype=torch.float32, device=dev)
-        distributed = mod.sync and _dist_world() > 1
+        distributed = mod.sync and _distributed()
         ctx.small = (mod.training or not mod.track_running_stats) and m <= BN_SMALL_MAX_ROWS and not distributed
         if ctx.small:
             # one launch: statistics, running statistics, affine (+res, ReLU)
@@ -439,7 +450,7 @@ class _BNFn(torch.autograd.Function):
             sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
             L.check(lib.mi_bn_stats(L.ptr(x), m, c, L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()), "mi_bn_stats")
             count = float(m)
-            if mod.sync and _dist_world() > 1:
+            if mod.sync and _distributed():
                 import torch.distributed as dist
                 dist.all_reduce(sums)                     # RCCL: 2*C doubles
                 count = float(m) * _dist_world()
@@ -507,7 +518,7 @@ class _BNFn(torch.autograd.Function):
             dg = torch.empty_like(gt) if acc_g else gt
             bt, acc_b = _grad_target(mod.bias)
             db = torch.empty_like(bt) if acc_b else bt
-        distributed = mod.sync and _dist_world() > 1
+        distributed = mod.sync and _distributed()
         if distributed:
             if dg is not None:
                 # affine gradients come from the LOCAL sums (torch.nn.SyncBatchNorm does the same); the
@@ -548,7 +559,7 @@ class _BNReluPoolFn(torch.autograd.Function):
             ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
             sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
             L.check(lib.mi_bn_stats(L.ptr(x), m, c, L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()), "mi_bn_stats")
-            if mod.sync and _dist_world() > 1:
+            if mod.sync and _distributed():
                 import torch.distributed as dist
                 dist.all_reduce(sums)
                 count = float(m) * _dist_world()
@@ -591,7 +602,7 @@ class _BNReluPoolFn(torch.autograd.Function):
             dg = torch.empty_like(gt) if acc_g else gt
             bt, acc_b = _grad_target(beta)
             db = torch.empty_like(bt) if acc_b else bt
-        distributed = mod.sync and _dist_world() > 1
+        distributed = mod.sync and _distributed()
         if distributed:
             if dg is not None:           # affine gradients from the LOCAL sums, like torch.nn.SyncBatchNorm
                 L.check(lib.mi_bn_param_grads(L.ptr(sums), c, L.ptr(dg), L.ptr(db), L.stream()), "mi_bn_param_grads")

@@ -87,7 +87,7 @@ class MoCo(nn.Module):
             k = self._key_branch(im_k)
         logits = H.moco_logits(q, k, self.queue, self.T)
         labels = torch.zeros(logits.shape[0], dtype=torch.long, device=logits.device)
-        keys = concat_all_gather(k) if _world_size() > 1 else k
+        keys = concat_all_gather(k) if H._distributed() else k
         self._dequeue_and_enqueue(keys)
         return logits, labels
 

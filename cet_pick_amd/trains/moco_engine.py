@@ -1,10 +1,15 @@
 """One MoCo training step as the reference's hot loop performs it
 (trains/base_trainer.py:486-508 -> models/moco.py:101-146 -> trains/tomo_moco_trainer.py:73 ->
-optimizer.step), driven without per-iteration host syncs and, on one GPU, replayed from a hipGraph.
+optimizer.step), driven without per-iteration host syncs and replayed from a hipGraph - on one GPU and, with the RCCL
+backend, on N GPUs too (the collectives are captured with the kernels; CETPICK_DIST_GRAPH=0 keeps the N>1 step eager,
+and a capture that fails falls back to the eager step by itself).
 
 Data-parallel ranks (one process per GPU, torch.distributed backend "nccl" = RCCL) exchange per step:
 gradient arena all-reduce (40.4 MB fp32), MoCo key all-gather (B x 128), SyncBN per-channel sums.
 """
+import os
+import warnings
+
 import torch
 
 from .. import hipops as H
@@ -26,12 +31,16 @@ class MocoStepEngine:
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         d = _dist()
         self.world = d.get_world_size() if d else 1
-        self.use_graph = bool(use_graph) and self.world == 1
+        self.dist_on = H._distributed()
+        # an eager N>1 step is launch-bound on the host (3.5 ms against 2.4 ms on one GPU, before any collective); RCCL
+        # collectives can be captured into the graph, gloo's (host-side) cannot
+        graph_ok = (not self.dist_on) or (d.get_backend() == "nccl" and os.environ.get("CETPICK_DIST_GRAPH", "1") != "0")
+        self.use_graph = bool(use_graph) and graph_ok
         self._graph = None
         self._static_q = self._static_k = None
         self._pending = []
         self.buckets_sent = []           # tags of the last step's exchanges, in issue order (tests / diagnostics)
-        if self.world > 1:
+        if self.dist_on:
             self._setup_buckets()
 
     # ---- data parallel: bucketed gradient all-reduce overlapped with the backward pass ---------------------
@@ -70,7 +79,7 @@ class MocoStepEngine:
         logits, labels = moco(im_q, im_k)
         loss = H.cross_entropy_label0(logits)
         loss.backward()
-        if self.world > 1:
+        if self.dist_on:
             # layer3+heads, layer2 and layer1 went out from the autograd hooks while the backward was still running
             # (RCCL over xGMI on its own stream); the stem's gradients are the last to exist
             self._reduce_bucket("stem")
@@ -96,9 +105,23 @@ class MocoStepEngine:
             self._static_q = im_q.clone()
             self._static_k = im_k.clone()
             torch.cuda.synchronize()
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):       # records, does not execute
-                self._step_eager(self._static_q, self._static_k)
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):         # records, does not execute
+                    self._step_eager(self._static_q, self._static_k)
+            except Exception as e:                    # e.g. a collective that cannot be captured: stay eager
+                if not self.dist_on:
+                    raise
+                warnings.warn("hipGraph capture of the data-parallel step failed (%s: %s); running it eagerly"
+                              % (type(e).__name__, e))
+                self.use_graph = False
+                self._pending = []
+                try:
+                    torch.cuda.synchronize()
+                except Exception:
+                    pass
+                return self._step_eager(im_q, im_k)
+            self._graph = graph
         self._static_q.copy_(im_q)
         self._static_k.copy_(im_k)
         self._graph.replay()
