@@ -1,5 +1,7 @@
-// 3-D convolution as implicit GEMM on the gfx950 f32 matrix cores (v_mfma_f32_32x32x2_f32:
-// f32 in, f32 accumulate - bit-for-bit an fmaf chain, so parity with the fp32 reference holds).
+// 3-D convolution as implicit GEMM on the gfx950 matrix cores, f32 in / f32 accumulate, in two arithmetics:
+// BF3 = false: v_mfma_f32_32x32x2_f32 - bit-for-bit an fmaf chain; BF3 = true (the default, MI_CONV_ARITH): the same
+// products formed on the bf16 pipe from an exact three-way bf16 cut of both operands (see the kernel's header below).
+// Either way parity with the fp32 reference holds.
 //
 // Replaces the nn.Conv3d / nn.Linear calls of the reference encoders
 // (cet_pick/models/networks/moco_encoder_3d.py:40-84,156-236) in forward, data-gradient and
@@ -158,7 +160,8 @@ struct Cursor {
 // products of weight <= 2 (a0 b0, a0 b1, a1 b0, a1 b1, a0 b2, a2 b0) are accumulated in f32 by
 // v_mfma_f32_32x32x16_bf16: each product is exact in f32, the dropped terms (a1 b2, a2 b1, a2 b2) are <= 2^-23 |a b|,
 // i.e. of the size of ONE f32 rounding - the result differs from the f32 fmaf chain by rounding-order noise only
-// (tests/test_conv_gpu.py measures both against float64).  Six bf16 MFMAs of K = 16 take 192 cycles against 512 for
+// (tests/test_train_gpu.py::test_conv_bf16x3_is_f32_equivalent measures both against float64; an Inf operand
+// becomes NaN - Inf - Inf in the cut - where an f32 multiply would keep Inf).  Six bf16 MFMAs of K = 16 take 192 cycles against 512 for
 // the eight f32 MFMAs they replace.  LDS holds three bf16 planes per operand:
 //   "RowK" plane [row][BK] bf16, 16-byte chunks XOR-swizzled by row : fragments by ds_read_b128 (8 k's)
 //   "KRow" plane, one [BK][32 columns] sub-tile per 32 columns (64-byte rows) : fragments by ds_read_b64_tr_b16

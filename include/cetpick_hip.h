@@ -141,7 +141,11 @@ int mi_crop_normalize(const float* vol, int D, int H, int W, const int32_t* cent
  * ------------------------------------------------------------------------------------------ */
 
 /* nn.Conv3d (cubic kernel k, stride, pad, no bias) / nn.Linear (k=1, D=H=W=1) as implicit GEMM
- * on v_mfma_f32_32x32x2_f32.  Replaces models/networks/moco_encoder_3d.py:40-84 (conv3x3x3,
+ * on the matrix cores: f32 operands, f32 accumulation.  The environment variable MI_CONV_ARITH selects how the f32
+ * products are formed: "bf16x3" (default) - every operand element is cut exactly into three bf16 values and the six
+ * products of weight <= 2 are accumulated by v_mfma_f32_32x32x16_bf16 (f32-equivalent: the dropped terms are below one
+ * f32 rounding; non-finite inputs give NaN where an f32 multiply would give Inf) - or "f32" - v_mfma_f32_32x32x2_f32,
+ * bit-for-bit an fmaf chain.  Replaces models/networks/moco_encoder_3d.py:40-84 (conv3x3x3,
  * BasicBlock), :163-169 (7x7x7 stem, Ci == 1), :183, :189, :198-205 (feature conv, fc, proj).
  * Ci % 16 == 0 (or Ci == 1), Co % 16 == 0.
  *   fwd:   y  = act(conv(x, w) + res)                 res may be NULL, relu 0/1
