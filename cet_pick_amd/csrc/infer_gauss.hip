@@ -15,6 +15,12 @@ inline int mi_gauss_radius_host(float sigma) { return (int)(4.0f * sigma + 0.5f)
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     // scipy 'reflect': d c b a | a b c d | d c b a
+    // The common cases - inside, or one reflection away - without the modulo: an integer division per fetched element
+    // was most of the instruction stream of these kernels (the scalar unit, shared by the CU's four SIMDs, was the
+    // bottleneck of the marching filter).
+    if ((unsigned)i < (unsigned)n) return i;
+    if (i < 0 && i >= -n) return -i - 1;
+    if (i >= n && i < 2 * n) return 2 * n - 1 - i;
     int period = 2 * n;
     i %= period;
     if (i < 0) i += period;
@@ -176,7 +182,10 @@ struct RegMarchWeights { float w[2][2 * R + 1]; };
 
 template <int NS, int R>
 __global__ __launch_bounds__(GT) void gauss_regmarch_kernel(GaussMarchParams p, RegMarchWeights<R> wt0, RegMarchWeights<R> wt1) {
-    constexpr int PD = 2;
+#ifndef MI_GAUSS_PD
+#define MI_GAUSS_PD 2
+#endif
+    constexpr int PD = MI_GAUSS_PD;
     constexpr int LEAD = 2 * R + 4 + 4 * (PD - 1);        // rows resident ahead of output i: q in [i, i + LEAD)
     constexpr int RW = LEAD + 4;                          // ring registers
     const GaussJob jb = p.job[blockIdx.y];
@@ -195,7 +204,15 @@ __global__ __launch_bounds__(GT) void gauss_regmarch_kernel(GaussMarchParams p, 
         for (int ph = 0; ph < RW / 4; ++ph) {
             const int i = i0 + 4 * ph;                    // slot of row q is (q - i0) mod RW: static per phase
 #pragma unroll
-            for (int u = 0; u < 4; ++u) win[(4 * ph + LEAD + u) % RW] = fetch(i + LEAD + u);
+            for (int u = 0; u < 4; ++u) {
+                // row i + LEAD + u - R is never below 0 here (LEAD >= R): only the far end can reflect
+                const int j = i + LEAD + u - R;
+#ifdef MI_DBG_G_NOLOAD     // timing experiment: no loads in the loop (results are garbage)
+                win[(4 * ph + LEAD + u) % RW] = (float)j;
+                continue;
+#endif
+                win[(4 * ph + LEAD + u) % RW] = src[(long)(j < n ? j : reflect_idx(j, n)) * p.conv_stride];
+            }
             float acc[NS][4];
 #pragma unroll
             for (int sI = 0; sI < NS; ++sI)
@@ -205,6 +222,9 @@ __global__ __launch_bounds__(GT) void gauss_regmarch_kernel(GaussMarchParams p, 
             for (int t = 0; t < 2 * R + 1; ++t)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
+#ifdef MI_DBG_G_NOFMA      // timing experiment: a quarter of the taps (results are garbage)
+                    if (t & 3) continue;
+#endif
                     const float v = win[(4 * ph + t + u) % RW];
 #pragma unroll
                     for (int sI = 0; sI < NS; ++sI) acc[sI][u] = fmaf(wt.w[sI][t], v, acc[sI][u]);
@@ -219,6 +239,77 @@ __global__ __launch_bounds__(GT) void gauss_regmarch_kernel(GaussMarchParams p, 
                 }
             }
         }
+    }
+}
+
+// ---- filter along x with the radius a compile-time constant ------------------------------------------------------
+// Same tile as gauss_x_kernel (4 rows x 256 outputs, rows 4-way interleaved in LDS), but the taps come from the host as
+// kernel arguments (scalar registers) instead of being rebuilt - a double-precision exp per tap, a serial sum and
+// three barriers - by every workgroup for its 1024 outputs, and the window is a fully unrolled register array: 2R+4 LDS
+// reads at (lane base + immediate) and 4 (2R+1) FMAs per thread.
+template <int R>
+__global__ __launch_bounds__(GT) void gauss_x_fixed_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          long n_rows, int W, int groups_per_block, RegMarchWeights<R> wt) {
+    constexpr int LX = 256, NEL = LX + 2 * R;
+    constexpr int Q = (NEL + 3) / 4;
+    constexpr int PITCH = Q + ((8 - (Q & 31) + 32) & 31);      // PITCH % 32 == 8: conflict-free interleaved stores
+    constexpr int NLD = (NEL + 63) / 64;                       // elements a thread stages per row group
+    __shared__ float tiles[2][4][4 * PITCH];
+    const int tid = threadIdx.x, ti = tid & 63, tr = tid >> 6;
+    const int xs0 = blockIdx.x * LX;
+    // a workgroup walks `groups_per_block` groups of 4 rows; the next group's elements are in flight (registers) while
+    // the current one is filtered out of LDS - a workgroup that does one group only spends its life waiting for its loads
+    const long g0 = (long)blockIdx.y * groups_per_block;
+    int src_idx[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) src_idx[k] = reflect_idx(xs0 - R + ti + 64 * k, W);
+    float pre[NLD];
+    auto fetch = [&](long g) {
+        const long row = 4 * g + tr;
+        const bool ok = row < n_rows;
+        const float* src = in + (ok ? row : 0) * (long)W;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) pre[k] = (ok && ti + 64 * k < NEL) ? src[src_idx[k]] : 0.f;
+    };
+    auto stage = [&](int buf) {
+        float* tile = tiles[buf][tr];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = ti + 64 * k;
+            if (e < NEL) tile[(e & 3) * PITCH + (e >> 2)] = pre[k];
+        }
+    };
+    fetch(g0);
+    stage(0);
+    __syncthreads();
+    for (int it = 0; it < groups_per_block; ++it) {
+        const long g = g0 + it;
+        if (4 * g >= n_rows) break;                            // (block-uniform)
+        const bool more = it + 1 < groups_per_block && 4 * (g + 1) < n_rows;
+        if (more) fetch(g + 1);
+        const long row = 4 * g + tr;
+        const float* tile = tiles[it & 1][tr];
+        float val[2 * R + 4];
+#pragma unroll
+        for (int e = 0; e < 2 * R + 4; ++e) val[e] = tile[(e & 3) * PITCH + ti + (e >> 2)];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2 * R + 1; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = fmaf(wt.w[0][t], val[t + u], acc[u]);
+        if (row < n_rows) {
+            const int x = xs0 + 4 * ti;
+            float* dst = out + row * (long)W + x;
+            if (x + 3 < W && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+                *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (x + i < W) dst[i] = acc[i];
+            }
+        }
+        if (more) stage((it + 1) & 1);                         // the other buffer: last read in iteration it-1
+        __syncthreads();
     }
 }
 
@@ -245,6 +336,21 @@ int launch_regmarch(const GaussMarchParams& p, bool dual, int n_jobs, hipStream_
     const dim3 grid((unsigned)((p.n_cols + GT - 1) / GT), n_jobs);
     if (dual) hipLaunchKernelGGL((gauss_regmarch_kernel<2, R>), grid, dim3(GT), 0, s, p, w0, w1);
     else hipLaunchKernelGGL((gauss_regmarch_kernel<1, R>), grid, dim3(GT), 0, s, p, w0, w1);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+template <int R>
+int launch_x_fixed(const float* in, float* out, long n_rows, int W, float sigma, hipStream_t s) {
+    RegMarchWeights<R> w0 = {};
+    fill_weights<R>(sigma, w0.w[0]);
+    // enough workgroups for ~8 per CU, each walking several 4-row groups
+    const long groups = mi_cdiv(n_rows, 4);
+    const long xb = mi_cdiv(W, 256);
+    long gpb = groups * xb / 2048;
+    gpb = gpb < 1 ? 1 : (gpb > 64 ? 64 : gpb);
+    dim3 grid((unsigned)xb, (unsigned)mi_cdiv(groups, gpb));
+    hipLaunchKernelGGL((gauss_x_fixed_kernel<R>), grid, dim3(GT), 0, s, in, out, n_rows, W, (int)gpb, w0);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -295,6 +401,12 @@ int mi_launch_gauss_axis(const float* in, float* out, int D, int H, int W, int a
         long n_rows = (long)D * H;
         dim3 grid(mi_cdiv(W, LX), mi_cdiv(n_rows, 4));
         if (grid.y > 65535u * 32u) return MI_E_UNSUPPORTED;
+        if (r <= 20 && !getenv("MI_GAUSS_NO_XFIXED")) {       // radius-specialised variant (taps from the host)
+            if (r <= 8) return launch_x_fixed<8>(in, out, n_rows, W, sigma, s);
+            if (r <= 12) return launch_x_fixed<12>(in, out, n_rows, W, sigma, s);
+            if (r <= 16) return launch_x_fixed<16>(in, out, n_rows, W, sigma, s);
+            return launch_x_fixed<20>(in, out, n_rows, W, sigma, s);
+        }
         hipLaunchKernelGGL(gauss_x_kernel, grid, dim3(GT), lds, s, in, out, n_rows, W, r, nt4, pitch, sigma);
     } else {
         constexpr int OUTS = 16, L = 64;
