@@ -23,8 +23,10 @@ int mi_launch_gauss_march(const float* in0, float* out0a, float* out0b, float si
 namespace {
 
 constexpr int CAPN = 32;          // stored higher-priority neighbours per candidate
-constexpr int GREEDY_WIDE_ROUNDS = 24;   // chip-wide rounds before the single-workgroup finisher
+constexpr int GREEDY_WIDE_ROUNDS = 8;    // chip-wide launches (GREEDY_INNER passes each) before the single-workgroup finisher
+constexpr int GREEDY_INNER = 3;
 constexpr int MAX_DELTAS = 36000; // (2*16+1)^3
+constexpr int MAX_RUNS = 33 * 33; // (dz, dy) rows of the ball
 
 struct GreedyHeader {
     unsigned cand_count;     // positive NMS survivors (march kernel)
@@ -33,8 +35,13 @@ struct GreedyHeader {
     unsigned n_deltas;
     unsigned overflow;       // bit0: candidate buffer overflow, bit1: too many picks for max_out
     float cutoff;
-    unsigned pad[2];
+    unsigned n_runs;         // rows of the ball: runs of consecutive flat offsets
+    unsigned pad[1];
 };
+
+// A row (dz, dy) of the ball is a run of consecutive flat offsets (the reference's ball lives in flat index space, no
+// bounds check): first offset and length.
+struct BallRun { long start; int len; int pad; };
 
 __device__ __forceinline__ unsigned order_bits(float v) {
     unsigned b = __float_as_uint(v);
@@ -74,10 +81,10 @@ __global__ void stats_finalize_kernel(const double* partials, int n_part, Greedy
 __global__ void set_cutoff_kernel(GreedyHeader* hdr, float v) { hdr->cutoff = v; }
 
 // ---- ball offsets (decode.py:43-54) ------------------------------------------------------------
-__global__ void build_deltas_kernel(GreedyHeader* hdr, long* deltas, double r, int width, long zs,
+__global__ void build_deltas_kernel(GreedyHeader* hdr, long* deltas, BallRun* runs, double r, int width, long zs,
                                     long ys) {
-    __shared__ unsigned cnt;
-    if (threadIdx.x == 0) cnt = 0;
+    __shared__ unsigned cnt, rcnt;
+    if (threadIdx.x == 0) { cnt = 0; rcnt = 0; }
     __syncthreads();
     int side = 2 * width + 1;
     int total = side * side * side;
@@ -89,14 +96,26 @@ __global__ void build_deltas_kernel(GreedyHeader* hdr, long* deltas, double r, i
             if (slot < MAX_DELTAS) deltas[slot] = (long)a * zs + (long)b * ys + (long)c;
         }
     }
+    for (int t = threadIdx.x; t < side * side; t += blockDim.x) {
+        const int a = t / side - width, b = t % side - width;
+        const double rest = r2 - (double)(a * a + b * b);
+        if (rest >= 0.0) {
+            int cm = (int)sqrt(rest);
+            while ((double)((cm + 1) * (cm + 1)) <= rest) ++cm;          // exact integer bound of c^2 <= rest
+            while ((double)(cm * cm) > rest) --cm;
+            if (cm > width) cm = width;
+            const unsigned slot = atomicAdd(&rcnt, 1u);
+            runs[slot] = BallRun{(long)a * zs + (long)b * ys - (long)cm, 2 * cm + 1, 0};
+        }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) hdr->n_deltas = min(cnt, (unsigned)MAX_DELTAS);
+    if (threadIdx.x == 0) { hdr->n_deltas = min(cnt, (unsigned)MAX_DELTAS); hdr->n_runs = rcnt; }
 }
 
 // ---- dense volume -> candidate list (values > cutoff) ------------------------------------------
 __global__ __launch_bounds__(256) void dense_filter_kernel(const float* vol, size_t n_vox,
                                                           GreedyHeader* hdr,
-                                                          unsigned long long* G, int* map,
+                                                          unsigned long long* G, int* map, unsigned* bits,
                                                           unsigned cap) {
     const float cut = hdr->cutoff;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -108,6 +127,7 @@ __global__ __launch_bounds__(256) void dense_filter_kernel(const float* vol, siz
             if (slot < cap) {
                 G[slot] = ((unsigned long long)order_bits(v) << 32) | (unsigned long long)i;
                 map[i] = (int)slot;
+                atomicOr(&bits[i >> 5], 1u << (i & 31));
             } else {
                 atomicOr(&hdr->overflow, 1u);
             }
@@ -118,7 +138,7 @@ __global__ __launch_bounds__(256) void dense_filter_kernel(const float* vol, siz
 // ---- sparse candidates (score bits, idx) -> candidate list (values > cutoff) -------------------
 __global__ __launch_bounds__(256) void cand_filter_kernel(const uint2* cands, unsigned cand_cap,
                                                          GreedyHeader* hdr, unsigned long long* G,
-                                                         int* map, unsigned cap) {
+                                                         int* map, unsigned* bits, unsigned cap) {
     const float cut = hdr->cutoff;
     unsigned total = hdr->cand_count;
     if (total > cand_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&hdr->overflow, 1u); total = cand_cap; }
@@ -130,6 +150,7 @@ __global__ __launch_bounds__(256) void cand_filter_kernel(const uint2* cands, un
             if (slot < cap) {
                 G[slot] = ((unsigned long long)order_bits(v) << 32) | (unsigned long long)c.y;
                 map[c.y] = (int)slot;
+                atomicOr(&bits[c.y >> 5], 1u << (c.y & 31));
             } else {
                 atomicOr(&hdr->overflow, 1u);
             }
@@ -138,12 +159,16 @@ __global__ __launch_bounds__(256) void cand_filter_kernel(const uint2* cands, un
 }
 
 // ---- higher-priority ball neighbours of every candidate (one wave per candidate) ---------------
+// The candidates are sparse (one voxel in ~1000), so "is there a candidate at voxel j" is answered by a BITMAP of the
+// volume (1 bit per voxel: 8 MB for 256 x 512 x 512, resident in L2) and the dense id map - which is then never cleared
+// and only read where a bit is set - is touched for actual candidates only.  A lane takes one row of the ball (a run of
+// <= 33 consecutive flat offsets = one or two bitmap words) instead of one offset.
 __global__ __launch_bounds__(256) void neighbors_kernel(const GreedyHeader* hdr,
                                                        const unsigned long long* G, const int* map,
-                                                       const long* deltas, long n_vox, unsigned cap,
-                                                       int* nbr, int* nbr_count) {
+                                                       const unsigned* bits, const BallRun* runs, long n_vox,
+                                                       unsigned cap, int* nbr, int* nbr_count) {
     const unsigned n = min(hdr->n, cap);
-    const int nd = (int)hdr->n_deltas;
+    const int nr = (int)hdr->n_runs;
     const int lane = threadIdx.x & 63;
     const unsigned wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const unsigned n_waves = (gridDim.x * 256) >> 6;
@@ -151,22 +176,44 @@ __global__ __launch_bounds__(256) void neighbors_kernel(const GreedyHeader* hdr,
         const unsigned long long ki = G[i];
         const long idx = (long)(ki & 0xffffffffull);
         int count = 0;
-        for (int q0 = 0; q0 < nd; q0 += 64) {
-            int q = q0 + lane;
-            int m = -1;
-            if (q < nd) {
-                long j = idx + deltas[q];
-                if (j >= 0 && j < n_vox) {
-                    int mm = map[j];
-                    if (mm >= 0 && (unsigned)mm != i && G[mm] > ki) m = mm;
+        for (int q0 = 0; q0 < nr; q0 += 64) {
+            const int q = q0 + lane;
+            // this lane's run, clipped to the volume: voxels [lo, hi)
+            long lo = 0, hi = 0;
+            if (q < nr) {
+                const BallRun rn = runs[q];
+                lo = max(idx + rn.start, 0l);
+                hi = min(idx + rn.start + rn.len, n_vox);
+            }
+            unsigned long long pend = 0;          // candidate bits of [lo, lo + 64): a run covers at most 33 voxels
+            if (hi > lo) {
+                const long w0 = lo >> 5;
+                const long last_w = (n_vox - 1) >> 5;
+                const unsigned long long b0 = bits[w0];
+                const unsigned long long b1 = w0 + 1 <= last_w ? bits[w0 + 1] : 0ull;
+                const unsigned long long b2 = w0 + 2 <= last_w ? bits[w0 + 2] : 0ull;
+                const int sh = (int)(lo & 31);
+                unsigned long long win = (b0 | (b1 << 32)) >> sh;
+                if (sh) win |= b2 << (64 - sh);
+                const int len = (int)(hi - lo);
+                pend = win & (len >= 64 ? ~0ull : ((1ull << len) - 1ull));
+            }
+            // pop the set bits (rare) in wave-uniform steps, compacting the hits into the neighbour list
+            while (__ballot(pend != 0ull)) {
+                int m = -1;
+                if (pend) {
+                    const int b = __ffsll((long long)pend) - 1;
+                    pend &= pend - 1ull;
+                    const int mm = map[lo + b];
+                    if ((unsigned)mm != i && G[mm] > ki) m = mm;
                 }
+                const unsigned long long ball = __ballot(m >= 0);
+                if (m >= 0) {
+                    const int pos = count + __popcll(ball & ((1ull << lane) - 1ull));
+                    if (pos < CAPN) nbr[(size_t)i * CAPN + pos] = m;
+                }
+                count += __popcll(ball);
             }
-            unsigned long long ball = __ballot(m >= 0);
-            if (m >= 0) {
-                int pos = count + __popcll(ball & ((1ull << lane) - 1ull));
-                if (pos < CAPN) nbr[(size_t)i * CAPN + pos] = m;
-            }
-            count += __popcll(ball);
         }
         if (lane == 0) nbr_count[i] = count;   // > CAPN -> overflow: re-probe in the rounds
     }
@@ -174,9 +221,9 @@ __global__ __launch_bounds__(256) void neighbors_kernel(const GreedyHeader* hdr,
 
 // ---- rounds: single workgroup, all candidates --------------------------------------------------
 // state: 0 undecided, 1 pick, 2 suppressed
-__device__ __forceinline__ int decide(unsigned i, const unsigned long long* G, const int* map,
+__device__ __forceinline__ int decide(unsigned i, const unsigned long long* G, const int* map, const unsigned* bits,
                                       const long* deltas, int nd, long n_vox, const int* nbr,
-                                      const int* nbr_count, const unsigned char* state) {
+                                      const int* nbr_count, const volatile unsigned char* state) {
     int cnt = nbr_count[i];
     bool all_decided = true;
     if (cnt <= CAPN) {
@@ -191,8 +238,9 @@ __device__ __forceinline__ int decide(unsigned i, const unsigned long long* G, c
         for (int q = 0; q < nd; ++q) {
             long j = idx + deltas[q];
             if (j < 0 || j >= n_vox) continue;
+            if (!((bits[j >> 5] >> (j & 31)) & 1u)) continue;       // (the id map is only valid where a bit is set)
             int mm = map[j];
-            if (mm < 0 || (unsigned)mm == i || !(G[mm] > ki)) continue;
+            if ((unsigned)mm == i || !(G[mm] > ki)) continue;
             unsigned char st = state[mm];
             if (st == 1) return 2;
             if (st == 0) all_decided = false;
@@ -212,23 +260,28 @@ __global__ __launch_bounds__(256) void rounds_init_kernel(GreedyHeader* hdr, uns
 }
 
 __global__ __launch_bounds__(256) void round_step_kernel(GreedyHeader* hdr, const unsigned long long* G,
-                                                        const int* map, const long* deltas, long n_vox,
-                                                        unsigned cap, const int* nbr, const int* nbr_count,
-                                                        unsigned char* state, unsigned* undecided,
+                                                        const int* map, const unsigned* bits, const long* deltas,
+                                                        long n_vox, unsigned cap, const int* nbr, const int* nbr_count,
+                                                        volatile unsigned char* state, unsigned* undecided,
                                                         unsigned long long* kept, unsigned kept_cap) {
     if (*reinterpret_cast<volatile unsigned*>(undecided) == 0) return;
     const unsigned n = min(hdr->n, cap);
     const int nd = (int)hdr->n_deltas;
     unsigned decided_here = 0;
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        if (state[i] != 0) continue;
-        int d = decide(i, G, map, deltas, nd, n_vox, nbr, nbr_count, state);
-        if (d != 0) {
-            state[i] = (unsigned char)d;
-            ++decided_here;
-            if (d == 1) {
-                unsigned slot = atomicAdd(&hdr->n_kept, 1u);
-                if (slot < kept_cap) kept[slot] = G[i];
+    // GREEDY_INNER passes per launch: the states are read past the L1 (volatile), so decisions other workgroups have
+    // already written are seen within the launch and a dependency chain advances several links per launch - a launch
+    // boundary costs ~7 us here, a pass over the few still-open candidates next to nothing
+    for (int pass = 0; pass < GREEDY_INNER; ++pass) {
+        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+            if (state[i] != 0) continue;
+            int d = decide(i, G, map, bits, deltas, nd, n_vox, nbr, nbr_count, state);
+            if (d != 0) {
+                state[i] = (unsigned char)d;
+                ++decided_here;
+                if (d == 1) {
+                    unsigned slot = atomicAdd(&hdr->n_kept, 1u);
+                    if (slot < kept_cap) kept[slot] = G[i];
+                }
             }
         }
     }
@@ -240,7 +293,7 @@ __global__ __launch_bounds__(256) void round_step_kernel(GreedyHeader* hdr, cons
 }
 
 __global__ __launch_bounds__(1024) void rounds_kernel(GreedyHeader* hdr, const unsigned long long* G,
-                                                      const int* map, const long* deltas, long n_vox,
+                                                      const int* map, const unsigned* bits, const long* deltas, long n_vox,
                                                       unsigned cap, const int* nbr,
                                                       const int* nbr_count,
                                                       volatile unsigned char* state,
@@ -266,8 +319,7 @@ __global__ __launch_bounds__(1024) void rounds_kernel(GreedyHeader* hdr, const u
     while (n_act > 0) {
         for (unsigned t = tid; t < n_act; t += 1024) {
             unsigned i = first ? t : cur[t];
-            int d = decide(i, G, map, deltas, nd, n_vox, nbr, nbr_count,
-                           const_cast<const unsigned char*>(state));
+            int d = decide(i, G, map, bits, deltas, nd, n_vox, nbr, nbr_count, state);
             if (d == 0) {
                 nxt[atomicAdd(&s_next, 1u)] = i;
             } else {
@@ -397,7 +449,9 @@ struct GreedyWs {
     unsigned* act_a;
     unsigned* act_b;
     unsigned* undecided;
-    int* map;          // dense, n_vox ints
+    int* map;          // dense, n_vox ints; valid only where `bits` is set (never cleared)
+    unsigned* bits;    // candidate bitmap of the volume, (n_vox + 31) / 32 words (+2 words of slack)
+    BallRun* runs;
     unsigned cap, kept_cap;
 };
 
@@ -424,6 +478,8 @@ size_t greedy_ws_layout(size_t n_vox, size_t cap, GreedyWs* w, char* base, bool 
     p = take(sizeof(unsigned) * cap); if (w) w->act_a = (unsigned*)p;
     p = take(sizeof(unsigned) * cap); if (w) w->act_b = (unsigned*)p;
     p = take(256); if (w) w->undecided = (unsigned*)p;
+    p = take(sizeof(BallRun) * MAX_RUNS); if (w) w->runs = (BallRun*)p;
+    p = take(sizeof(unsigned) * ((n_vox + 31) / 32 + 2)); if (w) w->bits = (unsigned*)p;
     if (with_map) { p = take(sizeof(int) * n_vox); if (w) w->map = (int*)p; }
     if (w) { w->cap = (unsigned)cap; w->kept_cap = (unsigned)kept_cap; }
     return off;
@@ -436,20 +492,20 @@ int greedy_tail(const GreedyWs& w, int D, int H, int W, float d, float scale, fl
     double r = (double)scale * (double)d / 2.0;
     int width = (int)ceil(r);
     if (width > 16 || width < 0) return MI_E_UNSUPPORTED;
-    hipLaunchKernelGGL(build_deltas_kernel, dim3(1), dim3(1024), 0, s, w.hdr, w.deltas, r, width,
+    hipLaunchKernelGGL(build_deltas_kernel, dim3(1), dim3(1024), 0, s, w.hdr, w.deltas, w.runs, r, width,
                        (long)H * W, (long)W);
     MI_RETURN_IF_LAUNCH_FAILED();
-    hipLaunchKernelGGL(neighbors_kernel, dim3(2048), dim3(256), 0, s, w.hdr, w.G, w.map, w.deltas,
+    hipLaunchKernelGGL(neighbors_kernel, dim3(2048), dim3(256), 0, s, w.hdr, w.G, w.map, w.bits, w.runs,
                        n_vox, w.cap, w.nbr, w.nbr_count);
     MI_RETURN_IF_LAUNCH_FAILED();
     hipLaunchKernelGGL(rounds_init_kernel, dim3(256), dim3(256), 0, s, w.hdr, w.cap, w.state, w.undecided);
     MI_RETURN_IF_LAUNCH_FAILED();
     for (int r = 0; r < GREEDY_WIDE_ROUNDS; ++r) {
-        hipLaunchKernelGGL(round_step_kernel, dim3(1024), dim3(256), 0, s, w.hdr, w.G, w.map, w.deltas, n_vox,
+        hipLaunchKernelGGL(round_step_kernel, dim3(1024), dim3(256), 0, s, w.hdr, w.G, w.map, w.bits, w.deltas, n_vox,
                            w.cap, w.nbr, w.nbr_count, w.state, w.undecided, w.kept, w.kept_cap);
         MI_RETURN_IF_LAUNCH_FAILED();
     }
-    hipLaunchKernelGGL(rounds_kernel, dim3(1), dim3(1024), 0, s, w.hdr, w.G, w.map, w.deltas, n_vox,
+    hipLaunchKernelGGL(rounds_kernel, dim3(1), dim3(1024), 0, s, w.hdr, w.G, w.map, w.bits, w.deltas, n_vox,
                        w.cap, w.nbr, w.nbr_count, w.state, w.act_a, w.act_b, w.kept, w.kept_cap);
     MI_RETURN_IF_LAUNCH_FAILED();
     // sort: bitonic network over P = pow2 >= n_kept; stages above the picks' P exit at once
@@ -496,12 +552,12 @@ extern "C" int mi_greedy_nms3d(const float* vol, int D, int H, int W, float d, f
     GreedyWs w;
     greedy_ws_layout(n_vox, greedy_default_cap(n_vox, true), &w, (char*)workspace, true);
     MI_HIP(hipMemsetAsync(w.hdr, 0, sizeof(GreedyHeader), s));
-    MI_HIP(hipMemsetAsync(w.map, 0xff, sizeof(int) * n_vox, s));
+    MI_HIP(hipMemsetAsync(w.bits, 0, sizeof(unsigned) * ((n_vox + 31) / 32 + 2), s));
     hipLaunchKernelGGL(set_cutoff_kernel, dim3(1), dim3(1), 0, s, w.hdr, threshold);
     MI_RETURN_IF_LAUNCH_FAILED();
     int blocks = (int)std::min<size_t>((n_vox + 255) / 256, 4096);
     hipLaunchKernelGGL(dense_filter_kernel, dim3(blocks), dim3(256), 0, s, vol, n_vox, w.hdr, w.G,
-                       w.map, w.cap);
+                       w.map, w.bits, w.cap);
     MI_RETURN_IF_LAUNCH_FAILED();
     return greedy_tail(w, D, H, W, d, scale, scores, coords, n_out, max_out, s);
 }
@@ -621,9 +677,9 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
     MI_RETURN_IF_LAUNCH_FAILED();
     // dense candidate-id map in the Gaussian buffer that is no longer needed
     gw.map = reinterpret_cast<int*>(w.g[cur ^ 1]);
-    MI_HIP(hipMemsetAsync(gw.map, 0xff, sizeof(int) * n_vox, s));
+    MI_HIP(hipMemsetAsync(gw.bits, 0, sizeof(unsigned) * ((n_vox + 31) / 32 + 2), s));
     hipLaunchKernelGGL(cand_filter_kernel, dim3(512), dim3(256), 0, s, w.cands, w.cand_cap, gw.hdr,
-                       gw.G, gw.map, gw.cap);
+                       gw.G, gw.map, gw.bits, gw.cap);
     MI_RETURN_IF_LAUNCH_FAILED();
     return greedy_tail(gw, D, H, W, (float)nms_d, 1.0f, scores, coords, n_out, max_out, s);
 }
