@@ -118,12 +118,22 @@ __global__ __launch_bounds__(256) void dense_filter_kernel(const float* vol, siz
                                                           unsigned long long* G, int* map, unsigned* bits,
                                                           unsigned cap) {
     const float cut = hdr->cutoff;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    size_t stride = (size_t)gridDim.x * 256;
-    for (; i < n_vox; i += stride) {
-        float v = vol[i];
-        if (v > cut) {
-            unsigned slot = atomicAdd(&hdr->n, 1u);
+    const size_t stride = (size_t)gridDim.x * 256;
+    const int lane = threadIdx.x & 63;
+    // wave-uniform trip count: the slot counter is bumped once per wave (one atomic for all its candidates), not once
+    // per candidate
+    for (size_t i0 = (size_t)blockIdx.x * 256; i0 < n_vox; i0 += stride) {
+        const size_t i = i0 + threadIdx.x;
+        const float v = i < n_vox ? vol[i] : 0.f;
+        const bool keep = i < n_vox && v > cut;
+        const unsigned long long km = __ballot(keep);
+        if (!km) continue;
+        unsigned base = 0;
+        const int leader = __ffsll((long long)km) - 1;
+        if (lane == leader) base = atomicAdd(&hdr->n, (unsigned)__popcll(km));
+        base = __shfl(base, leader, 64);
+        if (keep) {
+            const unsigned slot = base + (unsigned)__popcll(km & ((1ull << lane) - 1ull));
             if (slot < cap) {
                 G[slot] = ((unsigned long long)order_bits(v) << 32) | (unsigned long long)i;
                 map[i] = (int)slot;
@@ -142,11 +152,20 @@ __global__ __launch_bounds__(256) void cand_filter_kernel(const uint2* cands, un
     const float cut = hdr->cutoff;
     unsigned total = hdr->cand_count;
     if (total > cand_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&hdr->overflow, 1u); total = cand_cap; }
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        uint2 c = cands[i];
-        float v = __uint_as_float(c.x);
-        if (v > cut) {
-            unsigned slot = atomicAdd(&hdr->n, 1u);
+    const int lane = threadIdx.x & 63;
+    for (unsigned i0 = blockIdx.x * 256; i0 < total; i0 += gridDim.x * 256) {     // wave-uniform trip count
+        const unsigned i = i0 + threadIdx.x;
+        const uint2 c = i < total ? cands[i] : make_uint2(0u, 0u);
+        const float v = __uint_as_float(c.x);
+        const bool keep = i < total && v > cut;
+        const unsigned long long km = __ballot(keep);
+        if (!km) continue;
+        unsigned base = 0;
+        const int leader = __ffsll((long long)km) - 1;
+        if (lane == leader) base = atomicAdd(&hdr->n, (unsigned)__popcll(km));   // one atomic per wave
+        base = __shfl(base, leader, 64);
+        if (keep) {
+            const unsigned slot = base + (unsigned)__popcll(km & ((1ull << lane) - 1ull));
             if (slot < cap) {
                 G[slot] = ((unsigned long long)order_bits(v) << 32) | (unsigned long long)c.y;
                 map[c.y] = (int)slot;
@@ -172,47 +191,64 @@ __global__ __launch_bounds__(256) void neighbors_kernel(const GreedyHeader* hdr,
     const int lane = threadIdx.x & 63;
     const unsigned wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const unsigned n_waves = (gridDim.x * 256) >> 6;
+    // the ball's rows in LDS (one dependent global load less per candidate)
+    __shared__ BallRun s_runs[MAX_RUNS];
+    for (int q = threadIdx.x; q < nr; q += 256) s_runs[q] = runs[q];
+    __syncthreads();
+    const long last_w = (n_vox - 1) >> 5;
+    constexpr int QB = 4;                         // row groups whose bitmap words are fetched together
     for (unsigned i = wave; i < n; i += n_waves) {
         const unsigned long long ki = G[i];
         const long idx = (long)(ki & 0xffffffffull);
         int count = 0;
-        for (int q0 = 0; q0 < nr; q0 += 64) {
-            const int q = q0 + lane;
-            // this lane's run, clipped to the volume: voxels [lo, hi)
-            long lo = 0, hi = 0;
-            if (q < nr) {
-                const BallRun rn = runs[q];
-                lo = max(idx + rn.start, 0l);
-                hi = min(idx + rn.start + rn.len, n_vox);
+        for (int q0 = 0; q0 < nr; q0 += 64 * QB) {
+            // this lane's rows, clipped to the volume: voxels [lo, hi); candidate bits of [lo, lo + 64) - a row covers
+            // at most 33 voxels.  All QB rows' words are in flight before the first is used.
+            long lo[QB];
+            unsigned long long pend[QB];
+            unsigned b0[QB], b1[QB], b2[QB];
+            int len[QB];
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+                const int q = q0 + 64 * u + lane;
+                lo[u] = 0; len[u] = 0; b0[u] = b1[u] = b2[u] = 0u;
+                if (q < nr) {
+                    const BallRun rn = s_runs[q];
+                    const long l = max(idx + rn.start, 0l), h = min(idx + rn.start + rn.len, n_vox);
+                    if (h > l) {
+                        lo[u] = l; len[u] = (int)(h - l);
+                        const long w0 = l >> 5;
+                        b0[u] = bits[w0];
+                        b1[u] = w0 + 1 <= last_w ? bits[w0 + 1] : 0u;
+                        b2[u] = w0 + 2 <= last_w ? bits[w0 + 2] : 0u;
+                    }
+                }
             }
-            unsigned long long pend = 0;          // candidate bits of [lo, lo + 64): a run covers at most 33 voxels
-            if (hi > lo) {
-                const long w0 = lo >> 5;
-                const long last_w = (n_vox - 1) >> 5;
-                const unsigned long long b0 = bits[w0];
-                const unsigned long long b1 = w0 + 1 <= last_w ? bits[w0 + 1] : 0ull;
-                const unsigned long long b2 = w0 + 2 <= last_w ? bits[w0 + 2] : 0ull;
-                const int sh = (int)(lo & 31);
-                unsigned long long win = (b0 | (b1 << 32)) >> sh;
-                if (sh) win |= b2 << (64 - sh);
-                const int len = (int)(hi - lo);
-                pend = win & (len >= 64 ? ~0ull : ((1ull << len) - 1ull));
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+                const int sh = (int)(lo[u] & 31);
+                unsigned long long win = ((unsigned long long)b0[u] | ((unsigned long long)b1[u] << 32)) >> sh;
+                if (sh) win |= (unsigned long long)b2[u] << (64 - sh);
+                pend[u] = len[u] > 0 ? (win & ((1ull << len[u]) - 1ull)) : 0ull;     // len <= 33
             }
             // pop the set bits (rare) in wave-uniform steps, compacting the hits into the neighbour list
-            while (__ballot(pend != 0ull)) {
-                int m = -1;
-                if (pend) {
-                    const int b = __ffsll((long long)pend) - 1;
-                    pend &= pend - 1ull;
-                    const int mm = map[lo + b];
-                    if ((unsigned)mm != i && G[mm] > ki) m = mm;
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+                while (__ballot(pend[u] != 0ull)) {
+                    int m = -1;
+                    if (pend[u]) {
+                        const int b = __ffsll((long long)pend[u]) - 1;
+                        pend[u] &= pend[u] - 1ull;
+                        const int mm = map[lo[u] + b];
+                        if ((unsigned)mm != i && G[mm] > ki) m = mm;
+                    }
+                    const unsigned long long ball = __ballot(m >= 0);
+                    if (m >= 0) {
+                        const int pos = count + __popcll(ball & ((1ull << lane) - 1ull));
+                        if (pos < CAPN) nbr[(size_t)i * CAPN + pos] = m;
+                    }
+                    count += __popcll(ball);
                 }
-                const unsigned long long ball = __ballot(m >= 0);
-                if (m >= 0) {
-                    const int pos = count + __popcll(ball & ((1ull << lane) - 1ull));
-                    if (pos < CAPN) nbr[(size_t)i * CAPN + pos] = m;
-                }
-                count += __popcll(ball);
             }
         }
         if (lane == 0) nbr_count[i] = count;   // > CAPN -> overflow: re-probe in the rounds
@@ -379,8 +415,9 @@ __global__ __launch_bounds__(1024) void sort_local_kernel(const GreedyHeader* hd
     if (k_global == 0) {
         for (unsigned k = 2; k <= SORT_TILE; k <<= 1)
             for (unsigned j = k >> 1; j > 0; j >>= 1) {
+                const int lj = 31 - __builtin_clz(j);                    // j is a power of two: no divisions
                 for (unsigned t = tid; t < SORT_TILE / 2; t += 1024) {
-                    unsigned i = ((t / j) * (j << 1)) + (t % j), l = i + j;
+                    unsigned i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
                     bool desc = (((tile0 + i) & k) == 0);
                     unsigned long long a = keys[i], b = keys[l];
                     if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[l] = a; }
@@ -390,8 +427,9 @@ __global__ __launch_bounds__(1024) void sort_local_kernel(const GreedyHeader* hd
     } else {
         const unsigned k = k_global;
         for (unsigned j = SORT_TILE >> 1; j > 0; j >>= 1) {
+            const int lj = 31 - __builtin_clz(j);
             for (unsigned t = tid; t < SORT_TILE / 2; t += 1024) {
-                unsigned i = ((t / j) * (j << 1)) + (t % j), l = i + j;
+                unsigned i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
                 bool desc = (((tile0 + i) & k) == 0);
                 unsigned long long a = keys[i], b = keys[l];
                 if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[l] = a; }
@@ -678,7 +716,8 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
     // dense candidate-id map in the Gaussian buffer that is no longer needed
     gw.map = reinterpret_cast<int*>(w.g[cur ^ 1]);
     MI_HIP(hipMemsetAsync(gw.bits, 0, sizeof(unsigned) * ((n_vox + 31) / 32 + 2), s));
-    hipLaunchKernelGGL(cand_filter_kernel, dim3(512), dim3(256), 0, s, w.cands, w.cand_cap, gw.hdr,
+    // (many short workgroups: the loop is one dependent load per trip)
+    hipLaunchKernelGGL(cand_filter_kernel, dim3(4096), dim3(256), 0, s, w.cands, w.cand_cap, gw.hdr,
                        gw.G, gw.map, gw.bits, gw.cap);
     MI_RETURN_IF_LAUNCH_FAILED();
     return greedy_tail(gw, D, H, W, (float)nms_d, 1.0f, scores, coords, n_out, max_out, s);
