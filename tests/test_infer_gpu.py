@@ -136,14 +136,15 @@ def test_gaussian_vs_oracle(golden, sigma):
         np.testing.assert_allclose(got[0, ::3], g[f"gauss{int(sigma)}_z0"], rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("shape", [(7, 9, 11), (24, 50, 300), (40, 70, 65)])
-def test_gaussian_small_and_ragged(shape):
+@pytest.mark.parametrize("sigma", [2.5, 5.0, 6.0])     # radius 10 / 20 (specialised kernels) / 24 (generic fallback)
+@pytest.mark.parametrize("shape", [(7, 9, 11), (24, 50, 300), (40, 70, 65), (13, 21, 515)])
+def test_gaussian_small_and_ragged(shape, sigma):
     from oracle import infer_ref as O
     from cet_pick_amd.utils import image as Im
     rng = np.random.default_rng(2)
     vol = rng.standard_normal(shape).astype(np.float32)
-    got = Im.gaussian_filter(vol, 2.5).cpu().numpy()    # radius 10 > some dims: multi-reflection
-    want = O.gaussian_filter(vol.astype(np.float64), 2.5)
+    got = Im.gaussian_filter(vol, sigma).cpu().numpy()   # radius > some dims: multi-reflection; rows % 4, W % 4 != 0
+    want = O.gaussian_filter(vol.astype(np.float64), sigma)
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
 
 
