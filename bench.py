@@ -312,8 +312,14 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)           # the line is out before any tear-down
     if world > 1:
+        # every rank is past its last collective; leave without tearing the process group down (the watchdog thread of a
+        # group that holds captured work was once seen to raise during destruction, which would turn a finished run
+        # into a failed one)
         dist.barrier()
-        dist.destroy_process_group()
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
