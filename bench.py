@@ -144,22 +144,69 @@ def log(msg):
     print("[bench %7.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: this parent makes no GPU call (importing torch does not
+    initialise HIP; torch.cuda.device_count() does not either on this image), starts N fresh ranks as a CHILD process
+    (never an exec), relays rank 0's JSON line and exits with the child's code."""
+    import socket
+    import subprocess
+    backend = os.environ.get("CETPICK_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < args.gpus:
+        log("--gpus %d asked for, %d visible: RCCL wants one GPU per rank (CETPICK_DIST_BACKEND=gloo shares one GPU "
+            "as a rehearsal)" % (args.gpus, ndev))
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    log("launching %d ranks: %s" % (args.gpus, " ".join(cmd[1:])))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--crops", type=int, default=2048)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
+    # CETPICK_BENCH_REHEARSE_RCCL=1 (one-GPU box): the N>1 code path - SyncBN sums, key all-gather, bucketed gradient
+    # all-reduce, the collectives captured into the hipGraph, ordered tear-down - on a 1-rank RCCL group
+    rehearse = world == 1 and os.environ.get("CETPICK_BENCH_REHEARSE_RCCL", "") == "1"
+    if rehearse:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    dist_active = world > 1 or rehearse
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # backend "nccl" IS RCCL on ROCm.  CETPICK_DIST_BACKEND=gloo is the one-GPU rehearsal of the N>1 path (ranks
@@ -191,7 +238,9 @@ def main():
     enc_q = get_moco_net_small_3d(18, heads, 0)
     enc_k = get_moco_net_small_3d(18, heads, 0)
     moco = MoCo(enc_q, enc_k, dim=128, r=1024, m=0.999, T=0.1).to(dev)
-    if world > 1:
+    if rehearse:
+        H.FORCE_COLLECTIVES = True
+    if dist_active:
         H.convert_sync_batchnorm(moco)
         for p in moco.parameters():                 # identical replicas
             dist.broadcast(p.data, 0)
@@ -235,6 +284,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    ranks_seen = 1
+    if dist_active:
+        ones = torch.ones(1, dtype=torch.float32, device=dev)     # every rank adds one: the number of ranks that really
+        dist.all_reduce(ones)                                     # took part in the collectives of the timed steps
+        ranks_seen = int(ones.item())
     log("timed region: %d steps in %.3f s" % (args.steps, dt))
 
     out = None
@@ -243,9 +297,9 @@ def main():
     arith = "f32" if os.environ.get("MI_CONV_ARITH", "")[:1] == "f" else "bf16x3"
     # the same step on the f32 MFMA instruction (fresh graph capture; N = 1 only: a reported comparison, not `value`)
     f32_ms = None
-    if world == 1 and arith == "bf16x3" and not args.no_secondary:
+    if not dist_active and arith == "bf16x3" and not args.no_secondary:
         os.environ["MI_CONV_ARITH"] = "f32"
-        engine._graph = None
+        engine.close()
         for i in range(3):
             run(i)
         torch.cuda.synchronize()
@@ -255,14 +309,16 @@ def main():
         torch.cuda.synchronize()
         f32_ms = (time.perf_counter() - t1) / args.steps * 1e3
         os.environ.pop("MI_CONV_ARITH")
-        engine._graph = None
+        engine.close()
     if rank == 0:
         value = B * world * args.steps / dt
         achieved = flop / (ms * 1e-3) / 1e12
+        peak = PEAK_BF16_MATRIX_TFLOPS / 6 if arith == "bf16x3" else PEAK_F32_MATRIX_TFLOPS
         out = {
             "metric": "subtomograms/sec (MoCo-3D train) + voxels/sec (heatmap+NMS) at 1/2/4/8 GPU",
             "value": value, "unit": "subtomograms/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "rccl_ranks": ranks_seen, "dist_backend": (dist.get_backend() if dist_active else None),
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "moco_main.py moco3d_18: 3D encoder, synthetic 512x512x128 tomogram, 32^3 subtomo "
                                    "crops, batch 64 per GPU, r=1024, dim=128, m=0.999, T=0.1, SGD lr 1e-3",
@@ -271,13 +327,15 @@ def main():
                                            "(f32-equivalent; MI_CONV_ARITH=f32 for the f32 MFMA)" if arith == "bf16x3"
                                            else "v_mfma_f32_32x32x2_f32"),
                        "hipgraph": bool(engine.use_graph), "final_loss": final_loss},
-            "step_mfma_frac_of_peak": value / world * FLOP_PER_SUBTOMO / 1e12 / PEAK_F32_MATRIX_TFLOPS,
+            "step_mfma_frac_of_peak": value / world * FLOP_PER_SUBTOMO / 1e12 / peak,
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel + stem_fwd/stem_wgrad_kernel (fwd/dgrad/wgrad, all 75 conv launches of a step)",
-                         "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
-                         "peak_note": "peak = f32 MFMA (the dtype's matrix peak); the bf16x3 arithmetic runs on the bf16 "
-                                      "pipe, whose ceiling for f32-equivalent work is 2500/6 TFLOP/s",
-                         "peak_bf16x3": PEAK_BF16_MATRIX_TFLOPS / 6, "frac_bf16x3": achieved / (PEAK_BF16_MATRIX_TFLOPS / 6),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "peak_note": ("peak = the pipe the kernel runs on: the bf16x3 arithmetic executes 6 bf16 MFMA "
+                                       "products per f32 product, so f32-equivalent work tops out at 2500/6 TFLOP/s; "
+                                       "frac_f32_mfma_peak is the same rate against the f32 MFMA peak (157.3)"
+                                       if arith == "bf16x3" else "peak = f32 MFMA (v_mfma_f32_32x32x2_f32)"),
+                         "frac_f32_mfma_peak": achieved / PEAK_F32_MATRIX_TFLOPS,
                          "launches_per_step": n_launch // 3, "kernel_ms_per_step": ms / 3,
                          "algorithmic_gflop_per_step": flop / 3 / 1e9,
                          "by_mode": {t: {"launches_per_step": v[0] // 3, "gflop_per_step": v[1] / 3 / 1e9,
@@ -311,15 +369,22 @@ def main():
                                              "with oracle/train_ref.py (torch fp32, all host cores)"}
     if rank == 0:
         print(json.dumps(out), flush=True)           # the line is out before any tear-down
-    if world > 1:
-        # every rank is past its last collective; leave without tearing the process group down (the watchdog thread of a
-        # group that holds captured work was once seen to raise during destruction, which would turn a finished run
-        # into a failed one)
-        dist.barrier()
-        torch.cuda.synchronize()
+    if dist_active:
+        # tear-down in dependency order: the captured hipGraph (it holds the RCCL kernels and the events of the async
+        # work handles recorded during capture) goes before the communicator it refers to
+        rc = 0
+        try:
+            dist.barrier()
+            engine.close()
+            dist.destroy_process_group()
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            rc = 3                                   # a failed tear-down is a failed run, never a silent exit 0
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)
+        if rc:
+            sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -89,6 +89,8 @@ def main(opt):
                 save_model(os.path.join(opt.save_dir, "model_{}.pth".format(epoch)), epoch, model, optimizer)
     if log:
         log.close()
+    if trainer.engine is not None:
+        trainer.engine.close()               # the captured step (and its RCCL work) goes before the communicator
     if opt.distributed:
         dist.destroy_process_group()
 

@@ -91,38 +91,72 @@ class MocoStepEngine:
         self.loss.copy_(loss.detach())
         return self.loss
 
+    def _capture(self, im_q, im_k):
+        """Record one step into a hipGraph.  Returns the graph, or None when the data-parallel ranks agreed to stay
+        eager.  With collectives in the step every rank must take the same decision: a rank that replays a graph
+        and a rank that launches eagerly no longer issue their collectives in one order."""
+        self._static_q = im_q.clone()
+        self._static_k = im_k.clone()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        err = None
+        try:
+            with torch.cuda.graph(graph):             # records, does not execute
+                self._step_eager(self._static_q, self._static_k)
+        except Exception as e:                        # e.g. a collective that cannot be captured
+            if not self.dist_on:
+                raise
+            err = e
+            self._pending = []
+        if self.dist_on:
+            # the outcome is agreed on eagerly (outside any capture); a stream or communicator left in an error
+            # state by the aborted capture surfaces here instead of being swallowed
+            torch.cuda.synchronize()
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self.lr_dev.device)
+            _dist().all_reduce(ok, op=_dist().ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                warnings.warn("hipGraph capture of the data-parallel step failed on %s (%s); every rank runs it eagerly"
+                              % ("this rank" if err is not None else "another rank", err))
+                del graph
+                self.use_graph = False
+                self._static_q = self._static_k = None
+                return None
+        return graph
+
     def step(self, im_q, im_k):
         """Returns the loss as a 0-d device tensor (no host sync).
 
         Graph mode: the first two calls run eagerly (they size every workspace), the third call
-        captures the step into a hipGraph and from then on each call is one graph replay."""
+        captures the step into a hipGraph and from then on each call is one graph replay.  A batch whose
+        shape differs from the captured one (a short last batch) runs eagerly."""
         if not self.use_graph:
             return self._step_eager(im_q, im_k)
         if self._graph is None:
             self._calls = getattr(self, "_calls", 0) + 1
             if self._calls <= 2:
                 return self._step_eager(im_q, im_k)
-            self._static_q = im_q.clone()
-            self._static_k = im_k.clone()
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            try:
-                with torch.cuda.graph(graph):         # records, does not execute
-                    self._step_eager(self._static_q, self._static_k)
-            except Exception as e:                    # e.g. a collective that cannot be captured: stay eager
-                if not self.dist_on:
-                    raise
-                warnings.warn("hipGraph capture of the data-parallel step failed (%s: %s); running it eagerly"
-                              % (type(e).__name__, e))
-                self.use_graph = False
-                self._pending = []
-                try:
-                    torch.cuda.synchronize()
-                except Exception:
-                    pass
+            self._graph = self._capture(im_q, im_k)
+            if self._graph is None:
                 return self._step_eager(im_q, im_k)
-            self._graph = graph
+        if im_q.shape != self._static_q.shape or im_k.shape != self._static_k.shape:
+            if self.dist_on:
+                raise ValueError("data-parallel graph step: batch %s differs from the captured %s (use drop_last)"
+                                 % (tuple(im_q.shape), tuple(self._static_q.shape)))
+            return self._step_eager(im_q, im_k)
         self._static_q.copy_(im_q)
         self._static_k.copy_(im_k)
         self._graph.replay()
         return self.loss
+
+    def close(self):
+        """Release everything that refers to the process group's communicator BEFORE the group is destroyed: the
+        captured hipGraph holds the RCCL kernels (and the events recorded by the async work handles) of its
+        collectives, so it has to go first; then the device is drained.  Call before dist.destroy_process_group()."""
+        self._pending = []
+        if self._graph is not None:
+            torch.cuda.synchronize()
+            self._graph.reset()
+            self._graph = None
+        self._static_q = self._static_k = None
+        self._calls = 0
+        torch.cuda.synchronize()

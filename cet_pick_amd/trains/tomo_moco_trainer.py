@@ -7,8 +7,8 @@ from .base_trainer import BaseTrainer
 
 class TomoMocoLoss(torch.nn.Module):
     """:17-77: CrossEntropyLoss(logits, labels) -> (loss, {'loss', 'infoNCE'}).  MoCo's labels are
-    all zero (models/moco.py:141), which is what the fused kernel assumes; anything else falls back
-    to the definition."""
+    all zero (models/moco.py:141), which is what the fused kernel assumes.  There is no host path: a
+    logits tensor that is not on the GPU raises (hipops.HipExtensionError)."""
 
     def __init__(self, opt):
         super().__init__()
@@ -16,10 +16,7 @@ class TomoMocoLoss(torch.nn.Module):
 
     def forward(self, outputs, batch, epoch):
         logits, labels = outputs[0], outputs[1]
-        if logits.is_cuda:
-            loss = H.cross_entropy_label0(logits.contiguous())
-        else:
-            loss = torch.nn.functional.cross_entropy(logits, labels)
+        loss = H.cross_entropy_label0(logits.contiguous())
         return loss, {"loss": loss, "infoNCE": loss}
 
 

@@ -42,9 +42,11 @@ out = {"losses": losses, "graph": engine._graph is not None, "buckets": engine.b
        "w": float(engine.arena_q.flat.double().abs().sum()), "k": float(engine.arena_k.flat.double().abs().sum()),
        "queue": float(moco.queue.double().abs().sum())}
 print("RESULT " + json.dumps(out), flush=True)
-# (no process-group tear-down: the rehearsal is about the captured step, and the watchdog thread of a 1-rank group was
-# once seen to raise while being destroyed)
-os._exit(0)
+# tear-down in dependency order: the graph that holds the captured RCCL work goes before the communicator
+engine.close()
+if mode != "single":
+    dist.destroy_process_group()
+print("TEARDOWN ok", flush=True)
 '''
 
 
@@ -55,6 +57,7 @@ def run(mode, port):
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"repo": REPO}, mode], env=env, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
+    assert "TEARDOWN ok" in r.stdout, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
     import json
     return json.loads(line[7:])
@@ -75,3 +78,17 @@ def test_data_parallel_step_is_captured_with_its_collectives():
     # a launch of its own (the single-process run uses the one-launch small-batch kernel), a last-ulp difference that
     # this learning rate amplifies from the second step on
     assert abs(graph["losses"][0] - single["losses"][0]) <= 1e-5 * abs(single["losses"][0])
+
+
+def test_bench_n_gt_1_path_on_one_rank_rccl_group_tears_down():
+    """bench.py's N>1 code path (captured collectives, rccl_ranks, ordered tear-down with destroy_process_group) on the
+    one GPU of a test box: a 1-rank RCCL group with every collective forced on.  A failed tear-down is a non-zero exit."""
+    import json
+    env = dict(os.environ, CETPICK_BENCH_REHEARSE_RCCL="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29634",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "10", "--warmup", "4", "--no-secondary",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["rccl_ranks"] == 1 and line["dist_backend"] == "nccl" and line["config"]["hipgraph"] is True
+    assert line["n_gpus"] == 1 and line["value"] > 0

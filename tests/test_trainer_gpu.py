@@ -40,6 +40,59 @@ def test_moco_main_two_epochs_and_resume(tmp_path, monkeypatch):
     assert len(open(os.path.join(save_dir, "log.txt")).read().strip().split("\n")) == 3
 
 
+def test_moco_main_hipgraph_follows_lr_schedule_and_equals_eager(tmp_path, monkeypatch):
+    """The CLI's default (--hipgraph for task moco) replays the step from a hipGraph: the per-epoch learning rate
+    reaches it through the engine's device scalar, and two epochs end in the weights of the eager run bit for bit."""
+    from cet_pick_amd.opts import opts
+    from cet_pick_amd import moco_main
+    monkeypatch.chdir(tmp_path)
+    base = ["moco", "--arch", "moco3d_18", "--batch_size", "16", "--num_epochs", "2", "--lr", "0.02", "--lr_step", "1",
+            "--debug", "0", "--val_intervals", "2"]
+    o = opts().parse(base + ["--exp_id", "g"])
+    assert o.hipgraph is True and opts().parse(["semi"]).hipgraph is False
+    seen = []
+    from cet_pick_amd.trains.moco_engine import MocoStepEngine
+    orig = MocoStepEngine.set_lr
+
+    def spy(self, lr):
+        orig(self, lr)
+        seen.append((lr, float(self.lr_dev.item()), self.use_graph))
+    monkeypatch.setattr(MocoStepEngine, "set_lr", spy)
+    moco_main.main(o)
+    assert [round(a, 6) for a, _, _ in seen] == [0.02, 0.002] and all(abs(a - b) < 1e-9 for a, b, _ in seen)
+    assert all(g for _, _, g in seen)
+    moco_main.main(opts().parse(base + ["--exp_id", "e", "--no_hipgraph"]))
+    assert seen[-1][2] is False
+    a = torch.load(os.path.join(str(tmp_path), "exp", "moco", "g", "model_last.pth"))["state_dict"]
+    b = torch.load(os.path.join(str(tmp_path), "exp", "moco", "e", "model_last.pth"))["state_dict"]
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_engine_short_batch_runs_eagerly():
+    """A batch whose shape differs from the captured one never reaches the graph's static buffers."""
+    from cet_pick_amd.models.networks.moco_encoder_3d import get_moco_net_small_3d
+    from cet_pick_amd.models.moco import MoCo
+    from cet_pick_amd.trains.moco_engine import MocoStepEngine
+    torch.manual_seed(3)
+    heads = {"proj": 256, "pred": 256}
+    moco = MoCo(get_moco_net_small_3d(18, heads, 0), get_moco_net_small_3d(18, heads, 0), dim=128, r=64).cuda().train()
+    eng = MocoStepEngine(moco, lr=1e-3, use_graph=True)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(8, 1, 32, 32, 32, device="cuda", generator=g)
+    for _ in range(4):
+        eng.step(x, x.flip(4))
+    assert eng._graph is not None
+    ptr = int(moco.queue_ptr)
+    l = eng.step(x[:4], x[:4].flip(4))                       # short batch: eager, queue advances by 4
+    assert np.isfinite(float(l)) and int(moco.queue_ptr) == (ptr + 4) % 64
+    l = eng.step(x, x.flip(4))                               # and the graph still replays afterwards
+    assert np.isfinite(float(l)) and int(moco.queue_ptr) == (ptr + 12) % 64
+    eng.close()
+    assert eng._graph is None
+
+
 def test_semi_detector_trainer_two_steps_vs_oracle(tmp_path):
     """unet_4 detector training (task 'semi', --contrastive) through TomoCRSemiTrainer; the first
     step's loss terms and the updated weights are checked against torch autograd on the CPU oracles."""
