@@ -21,6 +21,7 @@ SIGNATURES = {
     "mi_sigmoid_clamp": (_I, [_P, _P, _Z, _P]),
     "mi_nms3d": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mi_decode_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "mi_decode_workspace_init": (_I, [_P, _Z, _P]),
     "mi_sigmoid_nms_topk": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "mi_gauss3d_sep": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "mi_dog_pick_workspace_bytes": (_Z, [_I, _I, _I, _I]),
@@ -145,12 +146,24 @@ def require_cuda(t, name="tensor", dtype=torch.float32):
 _workspaces = {}
 
 
-def workspace(nbytes, device, tag="default"):
-    """A cached device scratch buffer of at least nbytes (grown geometrically, never shrunk)."""
+def _ws_key(device, tag):
+    return (str(device), tag, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
+
+
+def workspace(nbytes, device, tag="default", init=None):
+    """A cached device scratch buffer of at least nbytes (grown geometrically, never shrunk).
+    `init(buf)` runs once per (re)allocation - for workspaces whose header is kept clean from call to call."""
     # one buffer per (device, purpose, stream): launches on different streams must not share scratch
-    key = (str(device), tag, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
+    key = _ws_key(device, tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        if init is not None:
+            init(buf)
         _workspaces[key] = buf
     return buf
+
+
+def drop_workspace(device, tag):
+    """Forget a cached workspace (after a failed call its kept-clean header can no longer be trusted)."""
+    _workspaces.pop(_ws_key(device, tag), None)

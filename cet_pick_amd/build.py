@@ -28,13 +28,24 @@ def _headers_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
+def _extra_flags(path):
+    """Per-file compiler flags: a source line `// hipcc-flags: <flags>` (e.g. -fno-slp-vectorize for a kernel whose
+    scalar FMA chains the SLP vectoriser would turn into register-pair shuffles)."""
+    out = []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("// hipcc-flags:"):
+                out += line.split(":", 1)[1].split()
+    return out
+
+
 def _compile(src, force):
     obj = os.path.join(OBJ, src[:-4] + ".o")
     sp = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) >= max(os.path.getmtime(sp), _headers_mtime())):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", sp, "-o", obj]
+    cmd = [HIPCC] + FLAGS + _extra_flags(sp) + ["-c", sp, "-o", obj]
     subprocess.check_call(cmd)
     return obj, True
 

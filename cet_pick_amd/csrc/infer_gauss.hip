@@ -155,92 +155,101 @@ __global__ __launch_bounds__(GT) void gauss_x_kernel(const float* __restrict__ i
 // ---- marching filter along a strided axis (z or y) --------------------------------------------------------
 // A thread owns one column (fixed position on the other two axes) and walks along the filtered axis: every input
 // element is read from memory exactly once - no halo re-reads (the tiled kernel above re-reads (64 + 2r)/64).
-// grid = (columns / 256, jobs); a launch carries up to two jobs (in -> out, sigma).
-struct GaussJob {
-    const float* in;
-    float* out[2];
-    float sigma[2];
-};
-struct GaussMarchParams {
-    GaussJob job[2];
+// The window of a column lives in REGISTERS: the ring of the last 2R+4+.. rows is a statically indexed register array
+// (the step loop is unrolled over one full turn of the ring), a row's global load targets its ring register directly
+// and is issued PD steps before the first FMA that reads it, so the prefetch costs no extra registers and there is no
+// LDS traffic at all.  An LDS-ring version of the same walk (dynamic indexing) was measured at 2 TB/s (instruction-issue
+// bound).  The taps are symmetric and sit in scalar registers as w[|d|]: R + 1 of them per sigma, so ONE read of the
+// input can feed TWO sigmas (13 + 21 taps for sigma 3 and 5; the 82 two-sided taps of that pair did not fit the scalar
+// file and the picker used two single-sigma jobs, reading the tomogram twice).  Three launch shapes:
+//   single  in -> out (sigma);            dual  in -> out_a (small sigma), out_b (large sigma), one read;
+//   two     blockIdx.y picks (in0 -> out0, sigma0) or (in1 -> out1, sigma1), each with its own radius.
+template <int R>
+struct SymTaps1 { float w[R + 1]; };         // w[t] = tap at distance t from the centre
+
+struct MarchGeom {
     int n_conv;            // extent of the filtered axis
     long conv_stride;      // elements between consecutive positions on it
     long other_stride;     // column c -> base = (c / w_inner) * other_stride + c % w_inner
     int w_inner;
     long n_cols;
-    int r, nt4, ring;      // max radius, taps rounded up to 4, ring rows (>= 2r + 4 + 4*PD)
 };
-// ---- register-ring march: the window of a column lives in REGISTERS ------------------------------------------
-// The ring of the last 2R+4+.. rows is a statically indexed register array (the step loop is unrolled over one full
-// turn of the ring), the taps are scalar operands, and a row's global load targets its ring register directly: it is
-// issued PD steps before the first FMA that reads it, so the prefetch costs no extra registers and there is no LDS
-// traffic at all.  Per voxel: (2R+1) * NS FMAs - the arithmetic floor of a direct filter.  An LDS-ring version of the
-// same walk (dynamic indexing) was measured at 2 TB/s (instruction-issue bound); this one reaches 4.3 TB/s.
-// NS == 2 (two sigmas per read) exists but its 82 scalar taps spill: the picker uses two NS == 1 jobs instead.
-template <int R>
-struct RegMarchWeights { float w[2][2 * R + 1]; };
 
-template <int NS, int R>
-__global__ __launch_bounds__(GT) void gauss_regmarch_kernel(GaussMarchParams p, RegMarchWeights<R> wt0, RegMarchWeights<R> wt1) {
-#ifndef MI_GAUSS_PD
-#define MI_GAUSS_PD 2
-#endif
-    constexpr int PD = MI_GAUSS_PD;
-    constexpr int LEAD = 2 * R + 4 + 4 * (PD - 1);        // rows resident ahead of output i: q in [i, i + LEAD)
-    constexpr int RW = LEAD + 4;                          // ring registers
-    const GaussJob jb = p.job[blockIdx.y];
-    const RegMarchWeights<R>& wt = blockIdx.y ? wt1 : wt0;
-    const long c = (long)blockIdx.x * GT + threadIdx.x;
-    if (c >= p.n_cols) return;
+// RB: radius of the ring (the larger sigma); RA: radius of the second output (DUAL), RA <= RB.
+template <int RB, int RA, bool DUAL>
+__device__ __forceinline__ void march_column(const float* __restrict__ in, float* __restrict__ out_b,
+                                             float* __restrict__ out_a, const SymTaps1<RB>& wb, const SymTaps1<RA>& wa,
+                                             const MarchGeom& p, long c) {
+    constexpr int PD = 2;
+    constexpr int LEAD = 2 * RB + 4 + 4 * (PD - 1);        // rows resident ahead of output i: q in [i, i + LEAD)
+    constexpr int RW = LEAD + 4;                           // ring registers
     const long base = (c / p.w_inner) * p.other_stride + (c % p.w_inner);
-    const float* src = jb.in + base;
+    const float* src = in + base;
     const int n = p.n_conv;
-    auto fetch = [&](int q) { return src[(long)reflect_idx(q - R, n) * p.conv_stride]; };
     float win[RW];
 #pragma unroll
-    for (int q = 0; q < LEAD; ++q) win[q] = fetch(q);
+    for (int q = 0; q < LEAD; ++q) win[q] = src[(long)reflect_idx(q - RB, n) * p.conv_stride];
     for (int i0 = 0; i0 < n; i0 += RW) {
 #pragma unroll
         for (int ph = 0; ph < RW / 4; ++ph) {
-            const int i = i0 + 4 * ph;                    // slot of row q is (q - i0) mod RW: static per phase
+            const int i = i0 + 4 * ph;                     // slot of row q is (q - i0) mod RW: static per phase
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                // row i + LEAD + u - R is never below 0 here (LEAD >= R): only the far end can reflect
-                const int j = i + LEAD + u - R;
-#ifdef MI_DBG_G_NOLOAD     // timing experiment: no loads in the loop (results are garbage)
-                win[(4 * ph + LEAD + u) % RW] = (float)j;
-                continue;
-#endif
+                // row i + LEAD + u - RB is never below 0 here (LEAD >= RB): only the far end can reflect
+                const int j = i + LEAD + u - RB;
                 win[(4 * ph + LEAD + u) % RW] = src[(long)(j < n ? j : reflect_idx(j, n)) * p.conv_stride];
             }
-            float acc[NS][4];
+            float accb[4], acca[4];
 #pragma unroll
-            for (int sI = 0; sI < NS; ++sI)
+            for (int u = 0; u < 4; ++u) {
+                const float ctr = win[(4 * ph + RB + u) % RW];
+                accb[u] = wb.w[0] * ctr;
+                if (DUAL) acca[u] = wa.w[0] * ctr;
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[sI][u] = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2 * R + 1; ++t)
+            for (int t = 1; t <= RB; ++t)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-#ifdef MI_DBG_G_NOFMA      // timing experiment: a quarter of the taps (results are garbage)
-                    if (t & 3) continue;
-#endif
-                    const float v = win[(4 * ph + t + u) % RW];
-#pragma unroll
-                    for (int sI = 0; sI < NS; ++sI) acc[sI][u] = fmaf(wt.w[sI][t], v, acc[sI][u]);
+                    const float pair = win[(4 * ph + RB + u - t + RW) % RW] + win[(4 * ph + RB + u + t) % RW];
+                    accb[u] = fmaf(wb.w[t], pair, accb[u]);
+                    if (DUAL && t <= RA) acca[u] = fmaf(wa.w[t], pair, acca[u]);
                 }
             if (i < n) {
 #pragma unroll
-                for (int sI = 0; sI < NS; ++sI) {
-                    float* dst = jb.out[sI] + base;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (i + u < n) dst[(long)(i + u) * p.conv_stride] = acc[sI][u];
-                }
+                for (int u = 0; u < 4; ++u)
+                    if (i + u < n) {
+                        out_b[base + (long)(i + u) * p.conv_stride] = accb[u];
+                        if (DUAL) out_a[base + (long)(i + u) * p.conv_stride] = acca[u];
+                    }
             }
         }
     }
 }
+
+template <int R>
+__global__ __launch_bounds__(GT) void gauss_march_single_kernel(const float* in, float* out, MarchGeom p, SymTaps1<R> w) {
+    const long c = (long)blockIdx.x * GT + threadIdx.x;
+    if (c >= p.n_cols) return;
+    march_column<R, R, false>(in, out, nullptr, w, w, p, c);
+}
+template <int RB, int RA>
+__global__ __launch_bounds__(GT) void gauss_march_dual_kernel(const float* in, float* out_a, float* out_b, MarchGeom p,
+                                                             SymTaps1<RA> wa, SymTaps1<RB> wb) {
+    const long c = (long)blockIdx.x * GT + threadIdx.x;
+    if (c >= p.n_cols) return;
+    march_column<RB, RA, true>(in, out_b, out_a, wb, wa, p, c);
+}
+template <int R0, int R1>
+__global__ __launch_bounds__(GT) void gauss_march_two_kernel(const float* in0, float* out0, const float* in1, float* out1,
+                                                            MarchGeom p, SymTaps1<R0> w0, SymTaps1<R1> w1) {
+    const long c = (long)blockIdx.x * GT + threadIdx.x;
+    if (c >= p.n_cols) return;
+    if (blockIdx.y == 0) march_column<R0, R0, false>(in0, out0, nullptr, w0, w0, p, c);      // (workgroup-uniform)
+    else march_column<R1, R1, false>(in1, out1, nullptr, w1, w1, p, c);
+}
+
+template <int R>
+struct RegMarchWeights { float w[2][2 * R + 1]; };
 
 // ---- filter along x with the radius a compile-time constant ------------------------------------------------------
 // Same tile as gauss_x_kernel (4 rows x 256 outputs, rows 4-way interleaved in LDS), but the taps come from the host as
@@ -327,15 +336,49 @@ void fill_weights(float sigma, float* w) {
     for (int t = 0; t < 2 * R + 1; ++t) w[t] = (float)(tmp[t] / sum);
 }
 
+// scipy's normalised kernel for `sigma` as symmetric taps w[|d|], zeros beyond its own radius
 template <int R>
-int launch_regmarch(const GaussMarchParams& p, bool dual, int n_jobs, hipStream_t s) {
-    RegMarchWeights<R> w0 = {}, w1 = {};
-    fill_weights<R>(p.job[0].sigma[0], w0.w[0]);
-    if (dual) fill_weights<R>(p.job[0].sigma[1], w0.w[1]);
-    if (n_jobs > 1) fill_weights<R>(p.job[1].sigma[0], w1.w[0]);
-    const dim3 grid((unsigned)((p.n_cols + GT - 1) / GT), n_jobs);
-    if (dual) hipLaunchKernelGGL((gauss_regmarch_kernel<2, R>), grid, dim3(GT), 0, s, p, w0, w1);
-    else hipLaunchKernelGGL((gauss_regmarch_kernel<1, R>), grid, dim3(GT), 0, s, p, w0, w1);
+void fill_sym1(float sigma, SymTaps1<R>& t) {
+    const int rs = mi_gauss_radius_host(sigma);
+    double tmp[R + 1], sum = 0;
+    const double c = -0.5 / ((double)sigma * (double)sigma);
+    for (int d = 0; d <= R; ++d) {
+        tmp[d] = d <= rs ? exp(c * (double)d * (double)d) : 0.0;
+        sum += d == 0 ? tmp[d] : 2.0 * tmp[d];
+    }
+    for (int d = 0; d <= R; ++d) t.w[d] = (float)(tmp[d] / sum);
+}
+
+inline int march_radius_class(int r) { return r <= 8 ? 8 : r <= 12 ? 12 : r <= 16 ? 16 : 20; }
+
+template <int R>
+int launch_march_single(const float* in, float* out, const MarchGeom& g, float sigma, hipStream_t s) {
+    SymTaps1<R> w;
+    fill_sym1<R>(sigma, w);
+    hipLaunchKernelGGL((gauss_march_single_kernel<R>), dim3((unsigned)((g.n_cols + GT - 1) / GT)), dim3(GT), 0, s, in, out, g, w);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+template <int RB, int RA>
+int launch_march_dual(const float* in, float* out_a, float* out_b, const MarchGeom& g, float sa, float sb, hipStream_t s) {
+    SymTaps1<RA> wa;
+    SymTaps1<RB> wb;
+    fill_sym1<RA>(sa, wa);
+    fill_sym1<RB>(sb, wb);
+    hipLaunchKernelGGL((gauss_march_dual_kernel<RB, RA>), dim3((unsigned)((g.n_cols + GT - 1) / GT)), dim3(GT), 0, s, in,
+                       out_a, out_b, g, wa, wb);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+template <int R0, int R1>
+int launch_march_two(const float* in0, float* out0, float s0, const float* in1, float* out1, float s1, const MarchGeom& g,
+                     hipStream_t s) {
+    SymTaps1<R0> w0;
+    SymTaps1<R1> w1;
+    fill_sym1<R0>(s0, w0);
+    fill_sym1<R1>(s1, w1);
+    hipLaunchKernelGGL((gauss_march_two_kernel<R0, R1>), dim3((unsigned)((g.n_cols + GT - 1) / GT), 2), dim3(GT), 0, s, in0,
+                       out0, in1, out1, g, w0, w1);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -359,7 +402,8 @@ int launch_x_fixed(const float* in, float* out, long n_rows, int W, float sigma,
 
 int mi_gauss_radius(float sigma) { return (int)(4.0f * sigma + 0.5f); }
 
-// Marching variant: up to two jobs (in -> out with sigma), or one job producing two sigmas from one read.
+// Marching variant: up to two jobs (in -> out with sigma), or one job producing two sigmas from one read
+// (out0b != null: out0a <- sig0a, out0b <- sig0b, sig0a <= sig0b).
 // Returns MI_E_UNSUPPORTED for radii it is not instantiated for (sigma > 5.1: callers fall back to the tiled kernels).
 int mi_launch_gauss_march(const float* in0, float* out0a, float* out0b, float sig0a, float sig0b, const float* in1,
                           float* out1, float sig1, int D, int H, int W, int axis, hipStream_t s) {
@@ -368,23 +412,55 @@ int mi_launch_gauss_march(const float* in0, float* out0a, float* out0b, float si
     float smax = sig0a;
     if (dual) smax = std::max(smax, sig0b);
     if (in1) smax = std::max(smax, sig1);
-    const int r = mi_gauss_radius(smax);
-    if (r <= 20 && !getenv("MI_GAUSS_NO_REGMARCH")) {     // register-ring variant for the radii it is instantiated for
-        GaussMarchParams q = {};
-        q.job[0].in = in0; q.job[0].out[0] = out0a; q.job[0].out[1] = out0b; q.job[0].sigma[0] = sig0a; q.job[0].sigma[1] = sig0b;
-        q.job[1].in = in1; q.job[1].out[0] = out1; q.job[1].sigma[0] = sig1;
-        q.n_conv = axis == 0 ? D : H;
-        q.conv_stride = axis == 0 ? (long)H * W : (long)W;
-        if (axis == 0) { q.other_stride = 0; q.w_inner = H * W; q.n_cols = (long)H * W; }
-        else { q.other_stride = (long)H * W; q.w_inner = W; q.n_cols = (long)D * W; }
-        if (q.n_conv < 1) return MI_E_ARG;
-        const int nj = in1 ? 2 : 1;
-        if (r <= 8) return launch_regmarch<8>(q, dual, nj, s);
-        if (r <= 12) return launch_regmarch<12>(q, dual, nj, s);
-        if (r <= 16) return launch_regmarch<16>(q, dual, nj, s);
-        return launch_regmarch<20>(q, dual, nj, s);
+    if (mi_gauss_radius(smax) > 20 || getenv("MI_GAUSS_NO_REGMARCH")) return MI_E_UNSUPPORTED;
+    MarchGeom g = {};
+    g.n_conv = axis == 0 ? D : H;
+    g.conv_stride = axis == 0 ? (long)H * W : (long)W;
+    if (axis == 0) { g.other_stride = 0; g.w_inner = H * W; g.n_cols = (long)H * W; }
+    else { g.other_stride = (long)H * W; g.w_inner = W; g.n_cols = (long)D * W; }
+    if (g.n_conv < 1) return MI_E_ARG;
+    const int ra = march_radius_class(mi_gauss_radius(sig0a));
+#define MI_R4(FN, R, ...)                                                       \
+    switch (R) {                                                                \
+        case 8: return FN<8>(__VA_ARGS__);                                      \
+        case 12: return FN<12>(__VA_ARGS__);                                    \
+        case 16: return FN<16>(__VA_ARGS__);                                    \
+        default: return FN<20>(__VA_ARGS__);                                    \
     }
-    return MI_E_UNSUPPORTED;
+    if (dual) {
+        if (in1 || sig0a > sig0b) return MI_E_ARG;
+        const int rb = march_radius_class(mi_gauss_radius(sig0b));
+        // (RB, RA) pairs with RA <= RB
+        if (rb == 20) { if (ra == 8) return launch_march_dual<20, 8>(in0, out0a, out0b, g, sig0a, sig0b, s);
+                        if (ra == 12) return launch_march_dual<20, 12>(in0, out0a, out0b, g, sig0a, sig0b, s);
+                        if (ra == 16) return launch_march_dual<20, 16>(in0, out0a, out0b, g, sig0a, sig0b, s);
+                        return launch_march_dual<20, 20>(in0, out0a, out0b, g, sig0a, sig0b, s); }
+        if (rb == 16) { if (ra == 8) return launch_march_dual<16, 8>(in0, out0a, out0b, g, sig0a, sig0b, s);
+                        if (ra == 12) return launch_march_dual<16, 12>(in0, out0a, out0b, g, sig0a, sig0b, s);
+                        return launch_march_dual<16, 16>(in0, out0a, out0b, g, sig0a, sig0b, s); }
+        if (rb == 12) { if (ra == 8) return launch_march_dual<12, 8>(in0, out0a, out0b, g, sig0a, sig0b, s);
+                        return launch_march_dual<12, 12>(in0, out0a, out0b, g, sig0a, sig0b, s); }
+        return launch_march_dual<8, 8>(in0, out0a, out0b, g, sig0a, sig0b, s);
+    }
+    if (!in1) { MI_R4(launch_march_single, ra, in0, out0a, g, sig0a, s) }
+    const int r1 = march_radius_class(mi_gauss_radius(sig1));
+    if (ra > r1)          // instantiated for R0 <= R1 only: the two jobs are independent, swap them
+        return mi_launch_gauss_march(in1, out1, nullptr, sig1, 0.f, in0, out0a, sig0a, D, H, W, axis, s);
+#define MI_TWO(R0)                                                                                   \
+    switch (r1) {                                                                                    \
+        case 8: if (R0 <= 8) return launch_march_two<(R0 <= 8 ? R0 : 8), 8>(in0, out0a, sig0a, in1, out1, sig1, g, s);      \
+        case 12: if (R0 <= 12) return launch_march_two<(R0 <= 12 ? R0 : 12), 12>(in0, out0a, sig0a, in1, out1, sig1, g, s);  \
+        case 16: if (R0 <= 16) return launch_march_two<(R0 <= 16 ? R0 : 16), 16>(in0, out0a, sig0a, in1, out1, sig1, g, s);  \
+        default: return launch_march_two<R0, 20>(in0, out0a, sig0a, in1, out1, sig1, g, s);          \
+    }
+    switch (ra) {
+        case 8: MI_TWO(8)
+        case 12: MI_TWO(12)
+        case 16: MI_TWO(16)
+        default: MI_TWO(20)
+    }
+#undef MI_TWO
+#undef MI_R4
 }
 
 // One axis of the separable filter.  axis: 0 = z, 1 = y, 2 = x.

@@ -19,11 +19,12 @@ int mi_launch_gauss_axis(const float* in, float* out, int D, int H, int W, int a
                          hipStream_t s);
 int mi_launch_gauss_march(const float* in0, float* out0a, float* out0b, float sig0a, float sig0b, const float* in1,
                           float* out1, float sig1, int D, int H, int W, int axis, hipStream_t s);
+int mi_gauss_radius(float sigma);
 
 namespace {
 
 constexpr int CAPN = 32;          // stored higher-priority neighbours per candidate
-constexpr int GREEDY_WIDE_ROUNDS = 8;    // chip-wide launches (GREEDY_INNER passes each) before the single-workgroup finisher
+constexpr int GREEDY_WIDE_ROUNDS = 5;    // chip-wide launches (GREEDY_INNER passes each) before the single-workgroup finisher
 constexpr int GREEDY_INNER = 3;
 constexpr int MAX_DELTAS = 36000; // (2*16+1)^3
 constexpr int MAX_RUNS = 33 * 33; // (dz, dy) rows of the ball
@@ -37,6 +38,7 @@ struct GreedyHeader {
     float cutoff;
     unsigned n_runs;         // rows of the ball: runs of consecutive flat offsets
     unsigned pad[1];
+    unsigned trace[16];      // candidates still undecided at the start of each chip-wide round launch (diagnostics)
 };
 
 // A row (dz, dy) of the ball is a run of consecutive flat offsets (the reference's ball lives in flat index space, no
@@ -96,17 +98,52 @@ __global__ void build_deltas_kernel(GreedyHeader* hdr, long* deltas, BallRun* ru
             if (slot < MAX_DELTAS) deltas[slot] = (long)a * zs + (long)b * ys + (long)c;
         }
     }
+    // rows in (dz, dy) order - consecutive lanes of the neighbour search then read adjacent rows of the bitmap (64 bytes
+    // apart at W = 512: two rows per cache line) instead of rows scattered by an atomic slot counter
+    __shared__ int s_cm[MAX_RUNS];
     for (int t = threadIdx.x; t < side * side; t += blockDim.x) {
         const int a = t / side - width, b = t % side - width;
         const double rest = r2 - (double)(a * a + b * b);
+        int cm = -1;
         if (rest >= 0.0) {
-            int cm = (int)sqrt(rest);
+            cm = (int)sqrt(rest);
             while ((double)((cm + 1) * (cm + 1)) <= rest) ++cm;          // exact integer bound of c^2 <= rest
             while ((double)(cm * cm) > rest) --cm;
             if (cm > width) cm = width;
-            const unsigned slot = atomicAdd(&rcnt, 1u);
-            runs[slot] = BallRun{(long)a * zs + (long)b * ys - (long)cm, 2 * cm + 1, 0};
         }
+        s_cm[t] = cm;
+    }
+    __syncthreads();
+    // order-preserving compaction: ballot prefix inside a wave, wave totals through LDS (side^2 <= 1089 entries; the
+    // block has 1024 threads: at most two entries per thread)
+    __shared__ unsigned s_wtot[2][16];
+    const int lane_ = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+    unsigned pre[2];
+    bool valid[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int t = h * 1024 + (int)threadIdx.x;
+        valid[h] = t < side * side && s_cm[t] >= 0;
+        const unsigned long long m = __ballot(valid[h]);
+        pre[h] = (unsigned)__popcll(m & ((1ull << lane_) - 1ull));
+        if (lane_ == 0) s_wtot[h][wv_] = (unsigned)__popcll(m);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned off = 0;
+        if (h == 1) for (int w2 = 0; w2 < 16; ++w2) off += s_wtot[0][w2];
+        for (int w2 = 0; w2 < wv_; ++w2) off += s_wtot[h][w2];
+        const int t = h * 1024 + (int)threadIdx.x;
+        if (valid[h]) {
+            const int a = t / side - width, b = t % side - width, cm = s_cm[t];
+            runs[off + pre[h]] = BallRun{(long)a * zs + (long)b * ys - (long)cm, 2 * cm + 1, 0};
+        }
+    }
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int w2 = 0; w2 < 16; ++w2) tot += s_wtot[0][w2] + s_wtot[1][w2];
+        rcnt = tot;
     }
     __syncthreads();
     if (threadIdx.x == 0) { hdr->n_deltas = min(cnt, (unsigned)MAX_DELTAS); hdr->n_runs = rcnt; }
@@ -148,7 +185,7 @@ __global__ __launch_bounds__(256) void dense_filter_kernel(const float* vol, siz
 // ---- sparse candidates (score bits, idx) -> candidate list (values > cutoff) -------------------
 __global__ __launch_bounds__(256) void cand_filter_kernel(const uint2* cands, unsigned cand_cap,
                                                          GreedyHeader* hdr, unsigned long long* G,
-                                                         int* map, unsigned* bits, unsigned cap) {
+                                                         int* map, unsigned* vmap, unsigned* bits, unsigned cap) {
     const float cut = hdr->cutoff;
     unsigned total = hdr->cand_count;
     if (total > cand_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&hdr->overflow, 1u); total = cand_cap; }
@@ -169,6 +206,7 @@ __global__ __launch_bounds__(256) void cand_filter_kernel(const uint2* cands, un
             if (slot < cap) {
                 G[slot] = ((unsigned long long)order_bits(v) << 32) | (unsigned long long)c.y;
                 map[c.y] = (int)slot;
+                vmap[c.y] = order_bits(v);
                 atomicOr(&bits[c.y >> 5], 1u << (c.y & 31));
             } else {
                 atomicOr(&hdr->overflow, 1u);
@@ -177,59 +215,132 @@ __global__ __launch_bounds__(256) void cand_filter_kernel(const uint2* cands, un
     }
 }
 
+// ---- segmented candidates (infer_dogx.hip: one segment per wave of the fused kernel) -> candidate list ----------
+// The survivors of a workgroup are staged in LDS and take their slots in G with ONE returning atomic per workgroup: a
+// returning atomic on a single word costs ~11 ns, and one per wave and 64-candidate step (~10^4 of them for 83 k
+// survivors) made the linear-list kernel above 58 us for 2.4 MB of candidates.
+constexpr int CF_STAGE = 3072;
+__global__ __launch_bounds__(256) void cand_filter_seg_kernel(const uint2* cands, const unsigned* seg_count,
+                                                             unsigned n_seg, unsigned seg_cap, GreedyHeader* hdr,
+                                                             unsigned long long* G, int* map, unsigned* vmap,
+                                                             unsigned* bits, unsigned cap) {
+    __shared__ uint2 stage[CF_STAGE];
+    __shared__ unsigned s_n, s_base;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const float cut = hdr->cutoff;
+    auto place = [&](uint2 c, unsigned slot) {
+        if (slot < cap) {
+            G[slot] = ((unsigned long long)order_bits(__uint_as_float(c.x)) << 32) | (unsigned long long)c.y;
+            map[c.y] = (int)slot;
+            vmap[c.y] = order_bits(__uint_as_float(c.x));
+            atomicOr(&bits[c.y >> 5], 1u << (c.y & 31));
+        } else {
+            atomicOr(&hdr->overflow, 1u);
+        }
+    };
+    const unsigned n_waves = gridDim.x * 4;
+    constexpr int PF = 4;
+    for (unsigned sg = blockIdx.x * 4 + (tid >> 6); sg < n_seg; sg += n_waves) {
+        const unsigned cnt = min(seg_count[sg], seg_cap);
+        const uint2* base = cands + (size_t)sg * seg_cap;
+        for (unsigned i0 = 0; i0 < cnt; i0 += 64 * PF) {
+            uint2 c[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {                        // all loads of the step in flight together
+                const unsigned i = i0 + 64 * u + lane;
+                c[u] = i < cnt ? base[i] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (i0 + 64 * u >= cnt) break;                    // (wave-uniform)
+                const unsigned i = i0 + 64 * u + lane;
+                const bool keep = i < cnt && __uint_as_float(c[u].x) > cut;
+                const unsigned long long km = __ballot(keep);
+                if (!km) continue;
+                unsigned b0 = 0;
+                const int leader = __ffsll((long long)km) - 1;
+                if (lane == leader) b0 = atomicAdd(&s_n, (unsigned)__popcll(km));     // LDS
+                b0 = __shfl(b0, leader, 64);
+                if (keep) {
+                    const unsigned slot = b0 + (unsigned)__popcll(km & ((1ull << lane) - 1ull));
+                    if (slot < CF_STAGE) stage[slot] = c[u];
+                    else place(c[u], atomicAdd(&hdr->n, 1u));     // stage full: straight to the list
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned n = min(s_n, (unsigned)CF_STAGE);
+    if (n == 0) return;
+    if (tid == 0) s_base = atomicAdd(&hdr->n, n);
+    __syncthreads();
+    const unsigned gb = s_base;
+    for (unsigned i = tid; i < n; i += 256) place(stage[i], gb + i);
+}
+
 // ---- higher-priority ball neighbours of every candidate (one wave per candidate) ---------------
 // The candidates are sparse (one voxel in ~1000), so "is there a candidate at voxel j" is answered by a BITMAP of the
 // volume (1 bit per voxel: 8 MB for 256 x 512 x 512, resident in L2) and the dense id map - which is then never cleared
 // and only read where a bit is set - is touched for actual candidates only.  A lane takes one row of the ball (a run of
 // <= 33 consecutive flat offsets = one or two bitmap words) instead of one offset.
-__global__ __launch_bounds__(256) void neighbors_kernel(const GreedyHeader* hdr,
+// Row i of `nbr` = [count, neighbour slots ...] (CAPN ints: count and the first three neighbours come with one 16-byte
+// load).  The priority of a hit voxel is read from a dense value array (the volume itself, or order_bits scattered next
+// to the id map) - independent of the id-map load, not behind it - and the candidate's own voxel is masked out before
+// the hits are popped: half of the candidates have no other candidate in their ball and skip the loop altogether.
+// The kernel also opens the rounds (state = undecided, counters).
+__global__ __launch_bounds__(256) void neighbors_kernel(GreedyHeader* hdr,
                                                        const unsigned long long* G, const int* map,
+                                                       const unsigned* vmap, const float* vol,
                                                        const unsigned* bits, const BallRun* runs, long n_vox,
-                                                       unsigned cap, int* nbr, int* nbr_count) {
+                                                       unsigned cap, int* nbr, unsigned char* state, unsigned* undecided) {
     const unsigned n = min(hdr->n, cap);
     const int nr = (int)hdr->n_runs;
     const int lane = threadIdx.x & 63;
     const unsigned wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const unsigned n_waves = (gridDim.x * 256) >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *undecided = n; hdr->n_kept = 0; }
     // the ball's rows in LDS (one dependent global load less per candidate)
     __shared__ BallRun s_runs[MAX_RUNS];
     for (int q = threadIdx.x; q < nr; q += 256) s_runs[q] = runs[q];
     __syncthreads();
-    const long last_w = (n_vox - 1) >> 5;
     constexpr int QB = 4;                         // row groups whose bitmap words are fetched together
     for (unsigned i = wave; i < n; i += n_waves) {
         const unsigned long long ki = G[i];
         const long idx = (long)(ki & 0xffffffffull);
+        const unsigned vi = (unsigned)(ki >> 32);
         int count = 0;
         for (int q0 = 0; q0 < nr; q0 += 64 * QB) {
             // this lane's rows, clipped to the volume: voxels [lo, hi); candidate bits of [lo, lo + 64) - a row covers
             // at most 33 voxels.  All QB rows' words are in flight before the first is used.
+            // (a row is at most 33 voxels and starts at most 31 bits into its first word: two words always hold it -
+            // one 8-byte load; the bitmap has two words of slack behind the volume)
             long lo[QB];
             unsigned long long pend[QB];
-            unsigned b0[QB], b1[QB], b2[QB];
+            uint2 bw[QB];
             int len[QB];
 #pragma unroll
             for (int u = 0; u < QB; ++u) {
                 const int q = q0 + 64 * u + lane;
-                lo[u] = 0; len[u] = 0; b0[u] = b1[u] = b2[u] = 0u;
+                lo[u] = 0; len[u] = 0; bw[u] = make_uint2(0u, 0u);
                 if (q < nr) {
                     const BallRun rn = s_runs[q];
                     const long l = max(idx + rn.start, 0l), h = min(idx + rn.start + rn.len, n_vox);
                     if (h > l) {
                         lo[u] = l; len[u] = (int)(h - l);
-                        const long w0 = l >> 5;
-                        b0[u] = bits[w0];
-                        b1[u] = w0 + 1 <= last_w ? bits[w0 + 1] : 0u;
-                        b2[u] = w0 + 2 <= last_w ? bits[w0 + 2] : 0u;
+                        typedef unsigned u2a4 __attribute__((ext_vector_type(2), aligned(4)));
+                        const u2a4 t2 = *reinterpret_cast<const u2a4*>(bits + (l >> 5));     // one dwordx2 load
+                        bw[u] = make_uint2(t2.x, t2.y);
                     }
                 }
             }
 #pragma unroll
             for (int u = 0; u < QB; ++u) {
                 const int sh = (int)(lo[u] & 31);
-                unsigned long long win = ((unsigned long long)b0[u] | ((unsigned long long)b1[u] << 32)) >> sh;
-                if (sh) win |= (unsigned long long)b2[u] << (64 - sh);
-                pend[u] = len[u] > 0 ? (win & ((1ull << len[u]) - 1ull)) : 0ull;     // len <= 33
+                const unsigned long long win = ((unsigned long long)bw[u].x | ((unsigned long long)bw[u].y << 32)) >> sh;
+                pend[u] = len[u] > 0 ? (win & ((1ull << len[u]) - 1ull)) : 0ull;     // len <= 33 <= 64 - sh
+                if (idx >= lo[u] && idx < lo[u] + len[u]) pend[u] &= ~(1ull << (idx - lo[u]));   // not its own neighbour
             }
             // pop the set bits (rare) in wave-uniform steps, compacting the hits into the neighbour list
 #pragma unroll
@@ -239,32 +350,38 @@ __global__ __launch_bounds__(256) void neighbors_kernel(const GreedyHeader* hdr,
                     if (pend[u]) {
                         const int b = __ffsll((long long)pend[u]) - 1;
                         pend[u] &= pend[u] - 1ull;
-                        const int mm = map[lo[u] + b];
-                        if ((unsigned)mm != i && G[mm] > ki) m = mm;
+                        const long j = lo[u] + b;
+                        const int mm = map[j];                                          // two independent loads
+                        const unsigned vj = vol ? order_bits(vol[j]) : vmap[j];
+                        if (vj > vi || (vj == vi && j > idx)) m = mm;                   // (value, index) both descending
                     }
                     const unsigned long long ball = __ballot(m >= 0);
                     if (m >= 0) {
                         const int pos = count + __popcll(ball & ((1ull << lane) - 1ull));
-                        if (pos < CAPN) nbr[(size_t)i * CAPN + pos] = m;
+                        if (pos < CAPN - 1) nbr[(size_t)i * CAPN + 1 + pos] = m;
                     }
                     count += __popcll(ball);
                 }
             }
         }
-        if (lane == 0) nbr_count[i] = count;   // > CAPN -> overflow: re-probe in the rounds
+        if (lane == 0) { nbr[(size_t)i * CAPN] = count; state[i] = 0; }   // count > CAPN-1 -> overflow: re-probe in the rounds
     }
 }
 
 // ---- rounds: single workgroup, all candidates --------------------------------------------------
 // state: 0 undecided, 1 pick, 2 suppressed
-__device__ __forceinline__ int decide(unsigned i, const unsigned long long* G, const int* map, const unsigned* bits,
+__device__ __forceinline__ int decide(unsigned i, int4 r0, const unsigned long long* G, const int* map, const unsigned* bits,
                                       const long* deltas, int nd, long n_vox, const int* nbr,
-                                      const int* nbr_count, const volatile unsigned char* state) {
-    int cnt = nbr_count[i];
+                                      const volatile unsigned char* state) {
+    const int cnt = r0.x;                                  // r0 = the first 16 bytes of row i: count + three neighbours
     bool all_decided = true;
-    if (cnt <= CAPN) {
-        for (int q = 0; q < cnt; ++q) {
-            unsigned char st = state[nbr[(size_t)i * CAPN + q]];
+    if (cnt <= CAPN - 1) {
+        // the states of the first three neighbours are independent loads; the rare longer lists walk the row
+        const unsigned char s0 = cnt > 0 ? state[r0.y] : 2, s1 = cnt > 1 ? state[r0.z] : 2, s2 = cnt > 2 ? state[r0.w] : 2;
+        if (s0 == 1 || s1 == 1 || s2 == 1) return 2;
+        all_decided = s0 != 0 && s1 != 0 && s2 != 0;
+        for (int q = 3; q < cnt; ++q) {
+            unsigned char st = state[nbr[(size_t)i * CAPN + 1 + q]];
             if (st == 1) return 2;
             if (st == 0) all_decided = false;
         }
@@ -288,19 +405,14 @@ __device__ __forceinline__ int decide(unsigned i, const unsigned long long* G, c
 // Chip-wide rounds: every launch decides whatever can be decided from the states left by the
 // previous launches (reads of states written in the same launch may be stale: that only defers a
 // decision).  `undecided` counts candidates still open; a launch that finds 0 returns at once.
-__global__ __launch_bounds__(256) void rounds_init_kernel(GreedyHeader* hdr, unsigned cap,
-                                                         unsigned char* state, unsigned* undecided) {
-    const unsigned n = min(hdr->n, cap);
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) state[i] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *undecided = n; hdr->n_kept = 0; }
-}
-
 __global__ __launch_bounds__(256) void round_step_kernel(GreedyHeader* hdr, const unsigned long long* G,
                                                         const int* map, const unsigned* bits, const long* deltas,
-                                                        long n_vox, unsigned cap, const int* nbr, const int* nbr_count,
+                                                        long n_vox, unsigned cap, const int* nbr,
                                                         volatile unsigned char* state, unsigned* undecided,
-                                                        unsigned long long* kept, unsigned kept_cap) {
-    if (*reinterpret_cast<volatile unsigned*>(undecided) == 0) return;
+                                                        unsigned long long* kept, unsigned kept_cap, int round) {
+    const unsigned open_now = *reinterpret_cast<volatile unsigned*>(undecided);
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr->trace[round & 15] = open_now;
+    if (open_now == 0) return;
     const unsigned n = min(hdr->n, cap);
     const int nd = (int)hdr->n_deltas;
     unsigned decided_here = 0;
@@ -310,7 +422,8 @@ __global__ __launch_bounds__(256) void round_step_kernel(GreedyHeader* hdr, cons
     for (int pass = 0; pass < GREEDY_INNER; ++pass) {
         for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
             if (state[i] != 0) continue;
-            int d = decide(i, G, map, bits, deltas, nd, n_vox, nbr, nbr_count, state);
+            const int4 r0 = *reinterpret_cast<const int4*>(nbr + (size_t)i * CAPN);
+            int d = decide(i, r0, G, map, bits, deltas, nd, n_vox, nbr, state);
             if (d != 0) {
                 state[i] = (unsigned char)d;
                 ++decided_here;
@@ -331,7 +444,6 @@ __global__ __launch_bounds__(256) void round_step_kernel(GreedyHeader* hdr, cons
 __global__ __launch_bounds__(1024) void rounds_kernel(GreedyHeader* hdr, const unsigned long long* G,
                                                       const int* map, const unsigned* bits, const long* deltas, long n_vox,
                                                       unsigned cap, const int* nbr,
-                                                      const int* nbr_count,
                                                       volatile unsigned char* state,
                                                       unsigned* act_a, unsigned* act_b,
                                                       unsigned long long* kept, unsigned kept_cap) {
@@ -342,9 +454,24 @@ __global__ __launch_bounds__(1024) void rounds_kernel(GreedyHeader* hdr, const u
     // finisher: picks up whatever the chip-wide rounds left undecided (usually nothing)
     if (tid == 0) { s_next = 0; s_kept = hdr->n_kept; }
     __syncthreads();
-    for (unsigned i = tid; i < n; i += 1024)
-        if (state[i] == 0) act_a[atomicAdd(&s_next, 1u)] = i;
+    // (16 states per load: the byte-at-a-time volatile scan of all n candidates was most of this kernel's 24 us)
+    {
+        const uint4* sv = reinterpret_cast<const uint4*>(const_cast<const unsigned char*>(state));
+        const unsigned n16 = n >> 4;
+        for (unsigned q = tid; q < n16; q += 1024) {
+            const uint4 v = sv[q];
+            const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (((w4[c] >> (8 * b)) & 0xffu) == 0u) act_a[atomicAdd(&s_next, 1u)] = 16 * q + 4 * c + b;
+        }
+        for (unsigned i = (n16 << 4) + tid; i < n; i += 1024)
+            if (state[i] == 0) act_a[atomicAdd(&s_next, 1u)] = i;
+    }
     __syncthreads();
+    if (tid == 0) hdr->trace[14] = s_next;
     unsigned n_act = s_next;
     __syncthreads();
     if (tid == 0) s_next = 0;
@@ -355,7 +482,8 @@ __global__ __launch_bounds__(1024) void rounds_kernel(GreedyHeader* hdr, const u
     while (n_act > 0) {
         for (unsigned t = tid; t < n_act; t += 1024) {
             unsigned i = first ? t : cur[t];
-            int d = decide(i, G, map, bits, deltas, nd, n_vox, nbr, nbr_count, state);
+            const int4 r0 = *reinterpret_cast<const int4*>(nbr + (size_t)i * CAPN);
+            int d = decide(i, r0, G, map, bits, deltas, nd, n_vox, nbr, state);
             if (d == 0) {
                 nxt[atomicAdd(&s_next, 1u)] = i;
             } else {
@@ -383,94 +511,78 @@ __global__ __launch_bounds__(1024) void rounds_kernel(GreedyHeader* hdr, const u
 }
 
 // ---- sort picks (descending priority) and write outputs ----------------------------------------
-constexpr int SORT_TILE = 8192;   // keys per workgroup in LDS (64 KiB)
+// Two launches whatever the number of picks (the bitonic network over the padded array was 1 + 5 + 10 + 1 launches for
+// max_out = 2^17, most of them leaving at once): every tile of SORT_TILE picks is sorted in LDS, then each pick finds its
+// final row by itself - its position in its own tile plus, by binary search, the number of greater keys in every other
+// tile (keys are unique) - and writes score and coordinates there.
+// An in-LDS bitonic sort is bound by LDS store bandwidth (~85 B/clk/CU: 91 steps x 128 KB for 8192 keys = 67 us in one
+// workgroup, 18 us for 2048 keys): small tiles on many CUs, and the rank pass pays for it with more - but independent,
+// interleaved - binary searches.
+constexpr int SORT_TILE = 2048;   // keys per workgroup
+constexpr int SORT_TILE_LOG2 = 11;
 
-// pads kept[n_kept, P) with zero keys, P = pow2 >= max(n_kept, SORT_TILE)
-__global__ void sort_pad_kernel(const GreedyHeader* hdr, unsigned long long* kept, unsigned kept_pow2_cap) {
-    unsigned n = hdr->n_kept;
-    unsigned P = SORT_TILE;
-    while (P < n) P <<= 1;
-    if (P > kept_pow2_cap) P = kept_pow2_cap;
-    for (unsigned i = n + blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) kept[i] = 0ull;
-}
-
-__device__ __forceinline__ unsigned sort_P(const GreedyHeader* hdr, unsigned cap) {
-    unsigned n = hdr->n_kept, P = SORT_TILE;
-    while (P < n) P <<= 1;
-    return min(P, cap);
-}
-
-// all stages with j < SORT_TILE for the given k (k_log2 == 0: full local sort up to SORT_TILE)
-__global__ __launch_bounds__(1024) void sort_local_kernel(const GreedyHeader* hdr,
-                                                          unsigned long long* kept, unsigned cap,
-                                                          unsigned k_global) {
+__global__ __launch_bounds__(1024) void sort_tiles_kernel(const GreedyHeader* hdr, unsigned long long* kept, unsigned cap) {
     __shared__ unsigned long long keys[SORT_TILE];
-    const unsigned P = sort_P(hdr, cap);
+    const unsigned n = min(hdr->n_kept, cap);
     const unsigned tile0 = blockIdx.x * SORT_TILE;
-    if (tile0 >= P) return;
-    if (k_global != 0 && k_global > P) return;
+    if (tile0 >= n) return;
     const int tid = threadIdx.x;
-    for (int i = tid; i < SORT_TILE; i += 1024) keys[i] = kept[tile0 + i];
-    __syncthreads();
-    if (k_global == 0) {
-        for (unsigned k = 2; k <= SORT_TILE; k <<= 1)
-            for (unsigned j = k >> 1; j > 0; j >>= 1) {
-                const int lj = 31 - __builtin_clz(j);                    // j is a power of two: no divisions
-                for (unsigned t = tid; t < SORT_TILE / 2; t += 1024) {
-                    unsigned i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
-                    bool desc = (((tile0 + i) & k) == 0);
-                    unsigned long long a = keys[i], b = keys[l];
-                    if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[l] = a; }
+    const unsigned m = min(n - tile0, (unsigned)SORT_TILE);
+    unsigned P = 1024;                                   // sort only what the tile holds
+    while (P < m) P <<= 1;
+    for (unsigned i = tid; i < P; i += 1024) keys[i] = i < m ? kept[tile0 + i] : 0ull;     // zero keys sink to the end
+    block_sort_desc_fast(keys, (int)P, tid, 1024);
+    for (unsigned i = tid; i < m; i += 1024) kept[tile0 + i] = keys[i];
+}
+
+__global__ __launch_bounds__(256) void merge_emit_kernel(GreedyHeader* hdr, const unsigned long long* kept, unsigned cap,
+                                                        int H, int W, float* scores, int32_t* coords, int32_t* n_out,
+                                                        int max_out) {
+    const unsigned n = min(hdr->n_kept, cap);
+    const unsigned n_tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const long hw = (long)H * W;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const unsigned long long key = kept[i];
+        const unsigned my_tile = i / SORT_TILE;
+        unsigned rank = i - my_tile * SORT_TILE;
+        // the searches in the other tiles are independent: eight of them advance in lockstep, their loads in flight together
+        constexpr int TG = 8;
+        for (unsigned t0 = 0; t0 < n_tiles; t0 += TG) {
+            unsigned lo[TG], hi[TG];
+#pragma unroll
+            for (int u = 0; u < TG; ++u) {
+                const unsigned t = t0 + u;
+                lo[u] = 0;
+                hi[u] = (t < n_tiles && t != my_tile) ? min(n - t * SORT_TILE, (unsigned)SORT_TILE) : 0u;   // keys in [0, lo) are > key
+            }
+            for (int step = 0; step <= SORT_TILE_LOG2; ++step) {
+                unsigned long long v[TG];
+                unsigned mid[TG];
+#pragma unroll
+                for (int u = 0; u < TG; ++u) {
+                    mid[u] = (lo[u] + hi[u]) >> 1;
+                    v[u] = lo[u] < hi[u] ? kept[(size_t)(t0 + u) * SORT_TILE + mid[u]] : 0ull;
                 }
-                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < TG; ++u)
+                    if (lo[u] < hi[u]) { if (v[u] > key) lo[u] = mid[u] + 1; else hi[u] = mid[u]; }
             }
-    } else {
-        const unsigned k = k_global;
-        for (unsigned j = SORT_TILE >> 1; j > 0; j >>= 1) {
-            const int lj = 31 - __builtin_clz(j);
-            for (unsigned t = tid; t < SORT_TILE / 2; t += 1024) {
-                unsigned i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
-                bool desc = (((tile0 + i) & k) == 0);
-                unsigned long long a = keys[i], b = keys[l];
-                if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[l] = a; }
-            }
-            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < TG; ++u) rank += lo[u];
+        }
+        if (rank < (unsigned)max_out) {
+            const long idx = (long)(key & 0xffffffffull);
+            scores[rank] = unorder_bits((unsigned)(key >> 32));
+            const long z = idx / hw, t2 = idx - z * hw;
+            coords[3 * rank + 0] = (int)(t2 % W);
+            coords[3 * rank + 1] = (int)(t2 / W);
+            coords[3 * rank + 2] = (int)z;
         }
     }
-    for (int i = tid; i < SORT_TILE; i += 1024) kept[tile0 + i] = keys[i];
-}
-
-__global__ void sort_global_step_kernel(const GreedyHeader* hdr, unsigned long long* kept,
-                                        unsigned cap, unsigned k, unsigned j) {
-    const unsigned P = sort_P(hdr, cap);
-    if (k > P) return;
-    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < P / 2; t += gridDim.x * blockDim.x) {
-        unsigned i = ((t / j) * (j << 1)) + (t % j), l = i + j;
-        bool desc = ((i & k) == 0);
-        unsigned long long a = kept[i], b = kept[l];
-        if (desc ? (a < b) : (a > b)) { kept[i] = b; kept[l] = a; }
-    }
-}
-
-__global__ void emit_picks_kernel(GreedyHeader* hdr, const unsigned long long* kept, int H,
-                                  int W, float* scores, int32_t* coords, int32_t* n_out,
-                                  int max_out, unsigned sorted_pow2) {
-    unsigned n = hdr->n_kept;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n > sorted_pow2) atomicOr(&hdr->overflow, 2u);
-    if (n > (unsigned)max_out) n = (unsigned)max_out;
-    const long hw = (long)H * W;
-    for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        unsigned long long key = kept[r];
-        long idx = (long)(key & 0xffffffffull);
-        scores[r] = unorder_bits((unsigned)(key >> 32));
-        long z = idx / hw, t = idx - z * hw;
-        coords[3 * r + 0] = (int)(t % W);
-        coords[3 * r + 1] = (int)(t / W);
-        coords[3 * r + 2] = (int)z;
-    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int v = (int)n;
-        unsigned ov = hdr->overflow | ((hdr->n_kept > sorted_pow2) ? 2u : 0u);
+        unsigned ov = hdr->overflow;
+        if (hdr->n_kept > cap || hdr->n_kept > (unsigned)max_out) ov |= 2u;
+        int v = (int)min(n, (unsigned)max_out);
         if (ov) v = -(int)ov;   // -1: candidate overflow, -2: pick overflow
         *n_out = v;
     }
@@ -482,12 +594,13 @@ struct GreedyWs {
     unsigned long long* G;
     unsigned long long* kept;
     int* nbr;
-    int* nbr_count;
     unsigned char* state;
     unsigned* act_a;
     unsigned* act_b;
     unsigned* undecided;
     int* map;          // dense, n_vox ints; valid only where `bits` is set (never cleared)
+    unsigned* vmap;    // dense order_bits(value) of the candidates (valid where `bits` is set), or null when
+    const float* vol;  // ... the dense value volume itself is at hand (mi_greedy_nms3d)
     unsigned* bits;    // candidate bitmap of the volume, (n_vox + 31) / 32 words (+2 words of slack)
     BallRun* runs;
     unsigned cap, kept_cap;
@@ -511,7 +624,6 @@ size_t greedy_ws_layout(size_t n_vox, size_t cap, GreedyWs* w, char* base, bool 
     p = take(sizeof(unsigned long long) * cap); if (w) w->G = (unsigned long long*)p;
     p = take(sizeof(unsigned long long) * kept_cap); if (w) w->kept = (unsigned long long*)p;
     p = take(sizeof(int) * cap * CAPN); if (w) w->nbr = (int*)p;
-    p = take(sizeof(int) * cap); if (w) w->nbr_count = (int*)p;
     p = take(cap); if (w) w->state = (unsigned char*)p;
     p = take(sizeof(unsigned) * cap); if (w) w->act_a = (unsigned*)p;
     p = take(sizeof(unsigned) * cap); if (w) w->act_b = (unsigned*)p;
@@ -533,39 +645,23 @@ int greedy_tail(const GreedyWs& w, int D, int H, int W, float d, float scale, fl
     hipLaunchKernelGGL(build_deltas_kernel, dim3(1), dim3(1024), 0, s, w.hdr, w.deltas, w.runs, r, width,
                        (long)H * W, (long)W);
     MI_RETURN_IF_LAUNCH_FAILED();
-    hipLaunchKernelGGL(neighbors_kernel, dim3(2048), dim3(256), 0, s, w.hdr, w.G, w.map, w.bits, w.runs,
-                       n_vox, w.cap, w.nbr, w.nbr_count);
-    MI_RETURN_IF_LAUNCH_FAILED();
-    hipLaunchKernelGGL(rounds_init_kernel, dim3(256), dim3(256), 0, s, w.hdr, w.cap, w.state, w.undecided);
+    hipLaunchKernelGGL(neighbors_kernel, dim3(2048), dim3(256), 0, s, w.hdr, w.G, w.map, w.vmap, w.vol, w.bits, w.runs,
+                       n_vox, w.cap, w.nbr, w.state, w.undecided);
     MI_RETURN_IF_LAUNCH_FAILED();
     for (int r = 0; r < GREEDY_WIDE_ROUNDS; ++r) {
         hipLaunchKernelGGL(round_step_kernel, dim3(1024), dim3(256), 0, s, w.hdr, w.G, w.map, w.bits, w.deltas, n_vox,
-                           w.cap, w.nbr, w.nbr_count, w.state, w.undecided, w.kept, w.kept_cap);
+                           w.cap, w.nbr, w.state, w.undecided, w.kept, w.kept_cap, r);
         MI_RETURN_IF_LAUNCH_FAILED();
     }
     hipLaunchKernelGGL(rounds_kernel, dim3(1), dim3(1024), 0, s, w.hdr, w.G, w.map, w.bits, w.deltas, n_vox,
-                       w.cap, w.nbr, w.nbr_count, w.state, w.act_a, w.act_b, w.kept, w.kept_cap);
+                       w.cap, w.nbr, w.state, w.act_a, w.act_b, w.kept, w.kept_cap);
     MI_RETURN_IF_LAUNCH_FAILED();
-    // sort: bitonic network over P = pow2 >= n_kept; stages above the picks' P exit at once
-    hipLaunchKernelGGL(sort_pad_kernel, dim3(64), dim3(256), 0, s, w.hdr, w.kept, w.kept_cap);
+    // sort + emit: two launches (tiles beyond the picks leave at once)
+    unsigned tiles = (unsigned)mi_cdiv((long)std::min<size_t>((size_t)max_out, w.kept_cap), SORT_TILE);
+    hipLaunchKernelGGL(sort_tiles_kernel, dim3(tiles), dim3(1024), 0, s, w.hdr, w.kept, w.kept_cap);
     MI_RETURN_IF_LAUNCH_FAILED();
-    // launch only as many stages as max_out can need
-    unsigned Pmax = SORT_TILE;
-    while (Pmax < (unsigned)max_out && Pmax < w.kept_cap) Pmax <<= 1;
-    unsigned tiles = Pmax / SORT_TILE;
-    hipLaunchKernelGGL(sort_local_kernel, dim3(tiles), dim3(1024), 0, s, w.hdr, w.kept, w.kept_cap, 0u);
-    MI_RETURN_IF_LAUNCH_FAILED();
-    for (unsigned k = 2 * SORT_TILE; k <= Pmax; k <<= 1) {
-        for (unsigned j = k >> 1; j >= SORT_TILE; j >>= 1) {
-            hipLaunchKernelGGL(sort_global_step_kernel, dim3(256), dim3(256), 0, s, w.hdr, w.kept,
-                               w.kept_cap, k, j);
-            MI_RETURN_IF_LAUNCH_FAILED();
-        }
-        hipLaunchKernelGGL(sort_local_kernel, dim3(tiles), dim3(1024), 0, s, w.hdr, w.kept, w.kept_cap, k);
-        MI_RETURN_IF_LAUNCH_FAILED();
-    }
-    hipLaunchKernelGGL(emit_picks_kernel, dim3(64), dim3(256), 0, s, w.hdr, w.kept, H, W, scores,
-                       coords, n_out, max_out, Pmax);
+    hipLaunchKernelGGL(merge_emit_kernel, dim3(std::min(tiles * 32u, 1024u)), dim3(256), 0, s, w.hdr, w.kept, w.kept_cap, H, W,
+                       scores, coords, n_out, max_out);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -589,6 +685,7 @@ extern "C" int mi_greedy_nms3d(const float* vol, int D, int H, int W, float d, f
     hipStream_t s = (hipStream_t)stream;
     GreedyWs w;
     greedy_ws_layout(n_vox, greedy_default_cap(n_vox, true), &w, (char*)workspace, true);
+    w.vmap = nullptr; w.vol = vol;                          // the dense values are the volume itself
     MI_HIP(hipMemsetAsync(w.hdr, 0, sizeof(GreedyHeader), s));
     MI_HIP(hipMemsetAsync(w.bits, 0, sizeof(unsigned) * ((n_vox + 31) / 32 + 2), s));
     hipLaunchKernelGGL(set_cutoff_kernel, dim3(1), dim3(1), 0, s, w.hdr, threshold);
@@ -610,8 +707,10 @@ struct DogWs {
     float* heat;
     uint2* cands;
     double* stats;
+    unsigned* seg_count;
     unsigned cand_cap;
     size_t n_stats;
+    DogxGrid xg;
     GreedyWs gw;
 };
 
@@ -624,12 +723,16 @@ size_t dog_ws_layout(int D, int H, int W, DogWs* w, char* base) {
     p = take(sizeof(float) * n_vox); if (w) w->g[1] = (float*)p;
     p = take(sizeof(float) * n_vox); if (w) w->tmp = (float*)p;
     p = take(sizeof(float) * n_vox); if (w) w->heat = (float*)p;
+    // candidates: the linear list of the generic march, or one segment per wave of the fused x-pass kernel
+    const DogxGrid xg = mi_dogx_grid(D, H, W);
     size_t cand_cap = n_vox / 4 + 1024;
-    p = take(sizeof(uint2) * cand_cap); if (w) { w->cands = (uint2*)p; w->cand_cap = (unsigned)cand_cap; }
+    p = take(sizeof(uint2) * std::max(cand_cap, (size_t)xg.n_seg * xg.seg_cap));
+    if (w) { w->cands = (uint2*)p; w->cand_cap = (unsigned)cand_cap; w->xg = xg; }
     int zc;
     dim3 grid = mi_march_grid(D, H, W, &zc);
     size_t n_stats = (size_t)grid.x * grid.y * grid.z;
-    p = take(sizeof(double) * 3 * n_stats); if (w) { w->stats = (double*)p; w->n_stats = n_stats; }
+    p = take(sizeof(double) * 3 * std::max(n_stats, (size_t)xg.n_seg)); if (w) { w->stats = (double*)p; w->n_stats = n_stats; }
+    p = take(sizeof(unsigned) * xg.n_seg); if (w) w->seg_count = (unsigned*)p;
     // the dense candidate map reuses a Gaussian buffer (free once the last DoG level is consumed)
     off += greedy_ws_layout(n_vox, greedy_default_cap(n_vox, false), w ? &w->gw : nullptr, base ? base + off : nullptr, false);
     return off;
@@ -675,7 +778,9 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
     // w.heat is free until the first NMS pass writes it).  The one-read-two-sigmas form of the z pass was measured
     // slower than two single-sigma jobs (its 82 scalar taps do not fit the SGPR file).
     auto gauss_pair = [&](float sa, float sb, float* ga, float* gb) -> int {
-        int rc = no_march ? MI_E_UNSUPPORTED : mi_launch_gauss_march(rec, ga, nullptr, sa, 0.f, rec, gb, sb, D, H, W, 0, s);
+        int rc = no_march ? MI_E_UNSUPPORTED
+                 : sa <= sb ? mi_launch_gauss_march(rec, ga, gb, sa, sb, nullptr, nullptr, 0.f, D, H, W, 0, s)
+                            : mi_launch_gauss_march(rec, ga, nullptr, sa, 0.f, rec, gb, sb, D, H, W, 0, s);
         if (rc == MI_E_UNSUPPORTED) {
             if ((rc = gauss(sa, ga))) return rc;
             return gauss(sb, gb);
@@ -692,6 +797,35 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
     };
     int rc;
     int cur = 0;
+    // Two sigmas, 3x3 window, one 512-wide row segment: z and y passes, then ONE kernel for the x passes of both
+    // Gaussians + DoG + border + xy-NMS + statistics + candidates (infer_dogx.hip) instead of two x passes and a march.
+    if (n_sigmas == 2 && !no_march &&
+        mi_dogx_usable(w.tmp, w.heat, heat_out, D, H, W, sigmas_host[0], sigmas_host[1], k) &&
+        (bxy >= mi_gauss_radius(sigmas_host[1]) || W > 2 * mi_gauss_radius(sigmas_host[1]))) {
+        const float sa = sigmas_host[0], sb = sigmas_host[1];
+        // z: ONE read of the tomogram feeds both sigmas; y: two jobs, each with its own radius
+        rc = sa <= sb ? mi_launch_gauss_march(rec, w.g[0], w.g[1], sa, sb, nullptr, nullptr, 0.f, D, H, W, 0, s)
+                      : mi_launch_gauss_march(rec, w.g[0], nullptr, sa, 0.f, rec, w.g[1], sb, D, H, W, 0, s);
+        if (rc == MI_OK) rc = mi_launch_gauss_march(w.g[0], w.tmp, nullptr, sa, 0.f, w.g[1], w.heat, sb, D, H, W, 1, s);
+        if (rc == MI_OK) {
+            DogxParams q = {};
+            q.y1 = w.tmp; q.y2 = w.heat; q.nms_out = heat_out;
+            q.D = D; q.H = H; q.W = W; q.bz = border_z; q.by = bxy; q.bx = bxy;
+            q.cands = w.cands; q.seg_count = w.seg_count; q.overflow = &gw.hdr->overflow; q.stats = w.stats;
+            if ((rc = mi_launch_dogx(q, w.xg, sa, sb, s))) return rc;
+            hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(256), 0, s, w.stats, (int)w.xg.n_seg, gw.hdr, cutoff_out);
+            MI_RETURN_IF_LAUNCH_FAILED();
+            gw.map = reinterpret_cast<int*>(w.g[0]);              // both z-pass outputs are consumed
+            gw.vmap = reinterpret_cast<unsigned*>(w.g[1]); gw.vol = nullptr;
+            MI_HIP(hipMemsetAsync(gw.bits, 0, sizeof(unsigned) * ((n_vox + 31) / 32 + 2), s));
+            const unsigned fb = std::min<unsigned>((w.xg.n_seg + 7) / 8, 1024u);
+            hipLaunchKernelGGL(cand_filter_seg_kernel, dim3(fb), dim3(256), 0, s, w.cands, w.seg_count, w.xg.n_seg,
+                               w.xg.seg_cap, gw.hdr, gw.G, gw.map, gw.vmap, gw.bits, gw.cap);
+            MI_RETURN_IF_LAUNCH_FAILED();
+            return greedy_tail(gw, D, H, W, (float)nms_d, 1.0f, scores, coords, n_out, max_out, s);
+        }
+        if (rc != MI_E_UNSUPPORTED) return rc;                    // radius not instantiated: the generic chain below
+    }
     if ((rc = gauss_pair(sigmas_host[0], sigmas_host[1], w.g[0], w.g[1]))) return rc;
     float* dense = heat_out ? heat_out : ((n_sigmas > 2) ? w.heat : nullptr);
     for (int i = 1; i < n_sigmas; ++i) {
@@ -715,10 +849,11 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
     MI_RETURN_IF_LAUNCH_FAILED();
     // dense candidate-id map in the Gaussian buffer that is no longer needed
     gw.map = reinterpret_cast<int*>(w.g[cur ^ 1]);
+    gw.vmap = reinterpret_cast<unsigned*>(w.tmp); gw.vol = nullptr;      // the x-pass scratch volume is free by now
     MI_HIP(hipMemsetAsync(gw.bits, 0, sizeof(unsigned) * ((n_vox + 31) / 32 + 2), s));
     // (many short workgroups: the loop is one dependent load per trip)
     hipLaunchKernelGGL(cand_filter_kernel, dim3(4096), dim3(256), 0, s, w.cands, w.cand_cap, gw.hdr,
-                       gw.G, gw.map, gw.bits, gw.cap);
+                       gw.G, gw.map, gw.vmap, gw.bits, gw.cap);
     MI_RETURN_IF_LAUNCH_FAILED();
     return greedy_tail(gw, D, H, W, (float)nms_d, 1.0f, scores, coords, n_out, max_out, s);
 }

@@ -377,20 +377,142 @@ __device__ int hist_threshold_bin(const unsigned* hist, int K, unsigned* s_scan 
     return s_T;
 }
 
+// The same threshold by ONE wave without a barrier: lane l owns bins [32 l, 32 l + 32) (eight 16-byte loads), the
+// suffix sums cross the lanes by shuffles.  Every wave of the filter computes it for itself.
+__device__ __forceinline__ int hist_threshold_bin_wave(const unsigned* hist, int K, int lane) {
+    constexpr int PER = MI_HIST_BINS / 64;      // 32
+    unsigned h[PER];
+    const uint4* src = reinterpret_cast<const uint4*>(hist + lane * PER);
+#pragma unroll
+    for (int q = 0; q < PER / 4; ++q) {
+        const uint4 v = src[q];
+        h[4 * q] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w;
+    }
+    unsigned mine = 0;
+#pragma unroll
+    for (int b = 0; b < PER; ++b) mine += h[b];
+    unsigned incl = mine;                        // inclusive suffix sum over lanes >= this one
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = __shfl_down(incl, off, 64);
+        if (lane + off < 64) incl += v;
+    }
+    const unsigned above = incl - mine;
+    int T = -1;
+    if (incl >= (unsigned)K && above < (unsigned)K) {
+        unsigned acc = above;
+        bool done = false;
+        T = lane * PER;
+#pragma unroll
+        for (int b = PER - 1; b >= 0; --b)
+            if (!done) {
+                acc += h[b];
+                if (acc >= (unsigned)K) { T = lane * PER + b; done = true; }
+            }
+    }
+    // exactly one lane (or none: fewer than K candidates) holds T >= 0
+    const unsigned long long m = __ballot(T >= 0);
+    if (!m) return 0;
+    return __shfl(T, __ffsll((long long)m) - 1, 64);
+}
+
+// survivors of the histogram threshold -> sel; one atomic per wave (a per-survivor atomic on the single counter
+// serialised ~2000 returning atomics: 15 us for this kernel)
+__device__ __forceinline__ void append_selected(uint2 c, bool keep, DecodeHeader* hdr, uint2* sel, unsigned sel_cap,
+                                                int lane) {
+    const unsigned long long km = __ballot(keep);
+    if (!km) return;
+    unsigned base = 0;
+    const int leader = __ffsll((long long)km) - 1;
+    if (lane == leader) base = atomicAdd(&hdr->sel_count, (unsigned)__popcll(km));
+    base = __shfl(base, leader, 64);
+    if (keep) {
+        const unsigned slot = base + (unsigned)__popcll(km & ((1ull << lane) - 1ull));
+        if (slot < sel_cap) sel[slot] = c;
+    }
+}
+
 __global__ __launch_bounds__(256) void topk_filter_kernel(const uint2* cands, DecodeHeader* hdr,
                                                          unsigned cand_cap, uint2* sel,
                                                          unsigned sel_cap, int K) {
     __shared__ unsigned s_scan[256];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     int T = hist_threshold_bin(hdr->hist, K, s_scan, tid);
     unsigned n = min(hdr->cand_count, cand_cap);
-    for (unsigned i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
-        uint2 c = cands[i];
-        if ((int)(c.x >> MI_HIST_SHIFT) >= T) {
-            unsigned slot = atomicAdd(&hdr->sel_count, 1u);
-            if (slot < sel_cap) sel[slot] = c;
+    for (unsigned i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {       // wave-uniform trip count
+        const unsigned i = i0 + tid;
+        const uint2 c = i < n ? cands[i] : make_uint2(0u, 0u);
+        append_selected(c, i < n && (int)(c.x >> MI_HIST_SHIFT) >= T, hdr, sel, sel_cap, lane);
+    }
+}
+
+// segmented candidates (infer_peak3.hip): a wave walks whole segments; the workgroup's survivors are staged in LDS and
+// leave with ONE returning atomic per workgroup (a returning atomic on one word costs ~11 ns: one per wave and
+// 64-candidate step - ~1400 of them - made this kernel 15 us)
+constexpr int FSEG_STAGE = 2048;
+__global__ __launch_bounds__(256) void topk_filter_seg_kernel(const uint2* cands, const unsigned* seg_count,
+                                                             unsigned n_seg, unsigned seg_cap, DecodeHeader* hdr,
+                                                             uint2* sel, unsigned sel_cap, int K) {
+    __shared__ uint2 stage[FSEG_STAGE];
+    __shared__ unsigned s_n, s_base;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_n = 0;
+    const int T = hist_threshold_bin_wave(hdr->hist, K, lane);
+    __syncthreads();
+    // The kernel is a chain of dependent memory round trips (count -> entries -> LDS -> one atomic -> store), not a
+    // bandwidth problem: a wave fetches the counts of both its segments first and then up to 8 x 64 entries of a
+    // segment back to back, before it looks at any of them.
+    const unsigned n_waves = gridDim.x * 4;
+    const unsigned w0 = blockIdx.x * 4 + (tid >> 6);
+    constexpr int PF = 8;
+    auto stage_one = [&](uint2 c, bool keep) {
+        const unsigned long long km = __ballot(keep);
+        if (!km) return;
+        unsigned b0 = 0;
+        const int leader = __ffsll((long long)km) - 1;
+        if (lane == leader) b0 = atomicAdd(&s_n, (unsigned)__popcll(km));      // LDS
+        b0 = __shfl(b0, leader, 64);
+        if (keep) {
+            const unsigned slot = b0 + (unsigned)__popcll(km & ((1ull << lane) - 1ull));
+            if (slot < FSEG_STAGE) stage[slot] = c;
+            else {                                                              // stage full (plateaus): go direct
+                const unsigned g = atomicAdd(&hdr->sel_count, 1u);
+                if (g < sel_cap) sel[g] = c;
+            }
+        }
+    };
+    for (unsigned sg = w0; sg < n_seg; sg += 2 * n_waves) {
+        const unsigned sg2 = sg + n_waves;
+        const unsigned cnt_a = min(seg_count[sg], seg_cap);
+        const unsigned cnt_b = sg2 < n_seg ? min(seg_count[sg2], seg_cap) : 0u;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const unsigned cnt = half ? cnt_b : cnt_a;
+            const uint2* base = cands + (size_t)(half ? sg2 : sg) * seg_cap;
+            for (unsigned i0 = 0; i0 < cnt; i0 += 64 * PF) {
+                uint2 c[PF];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const unsigned i = i0 + 64 * u + lane;
+                    c[u] = i < cnt ? base[i] : make_uint2(0u, 0u);
+                }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    if (i0 + 64 * u >= cnt) break;                              // (wave-uniform)
+                    const unsigned i = i0 + 64 * u + lane;
+                    stage_one(c[u], i < cnt && (int)(c[u].x >> MI_HIST_SHIFT) >= T);
+                }
+            }
         }
     }
+    __syncthreads();
+    const unsigned n = min(s_n, (unsigned)FSEG_STAGE);
+    if (n == 0) return;
+    if (tid == 0) s_base = atomicAdd(&hdr->sel_count, n);
+    __syncthreads();
+    const unsigned gb = s_base;
+    for (unsigned i = tid; i < n; i += 256)
+        if (gb + i < sel_cap) sel[gb + i] = stage[i];
 }
 
 __device__ __forceinline__ void emit_det(float* dets, int r, unsigned long long key, int H, int W,
@@ -409,19 +531,70 @@ __device__ __forceinline__ void emit_det(float* dets, int r, unsigned long long 
     o[0] = (float)x + 0.25f; o[1] = yf + 0.25f; o[2] = (float)z; o[3] = score; o[4] = score;
 }
 
-// Single block.  Fast path: the filtered set fits LDS -> bitonic sort.  Slow path (degenerate
-// plateaus): exact 64-bit radix select over the whole candidate list, then sort the survivors.
-__global__ __launch_bounds__(1024) void topk_final_kernel(const uint2* cands, DecodeHeader* hdr,
-                                                          unsigned cand_cap, const uint2* sel,
+// Final selection, MI_FINAL_BLOCKS workgroups of 1024 threads.
+//   * n_sel <= MI_RANK_MAX (the usual case: K plus the occupants of the threshold bin): no sort at all.  Every workgroup
+//     stages the selected keys in LDS, a thread owns one key and counts the keys greater than it (broadcast LDS reads,
+//     two keys per ds_read_b128): that count IS its output row.  Keys are unique (the voxel index is part of the key), so
+//     ranks are a permutation; the work is n_sel^2 / 2 compares spread over 16 CUs, ~4 us at n_sel = 1100 against 20 us for
+//     the single-workgroup bitonic network it replaces.
+//   * otherwise workgroup 0 alone: the filtered set fits LDS -> sort; or (degenerate plateaus) exact 64-bit radix select
+//     over the whole candidate list, then sort the survivors.  Candidates are n_seg segments of seg_cap entries (a linear
+//     list = one segment whose count is hdr->cand_count).
+// The last workgroup to finish leaves the header zeroed when `self_clean` is set (see mi_sigmoid_nms_topk).
+constexpr int MI_RANK_MAX = 8192;
+constexpr int MI_FINAL_BLOCKS = 16;
+
+__global__ __launch_bounds__(1024) void topk_final_kernel(const uint2* cands, const unsigned* seg_count, unsigned n_seg,
+                                                          unsigned seg_cap, DecodeHeader* hdr, const uint2* sel,
                                                           int K, int H, int W, float* dets,
-                                                          int* n_valid_out) {
-    extern __shared__ unsigned long long keys[];   // MI_SEL_CAP entries
+                                                          int* n_valid_out, int self_clean) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // MI_SEL_CAP entries
     __shared__ unsigned s_hist[256];
     __shared__ unsigned long long s_prefix;
-    __shared__ unsigned s_remaining, s_n;
+    __shared__ unsigned s_remaining, s_n, s_ticket;
     const int tid = threadIdx.x;
-    unsigned n_sel = hdr->sel_count;
-    unsigned n_cand = min(hdr->cand_count, cand_cap);
+    const unsigned n_sel = hdr->sel_count;
+    auto finish = [&]() {
+        if (!self_clean) return;
+        __syncthreads();
+        if (tid == 0) s_ticket = atomicAdd(&hdr->pad0, 1u);           // every workgroup has read the header by now
+        __syncthreads();
+        if (s_ticket == gridDim.x - 1) {                                // the last one out cleans up for the next call
+            for (int i = tid; i < MI_HIST_BINS; i += 1024) hdr->hist[i] = 0u;
+            if (tid == 0) { hdr->cand_count = 0u; hdr->sel_count = 0u; hdr->pad0 = 0u; hdr->pad1 = 0u; }
+        }
+    };
+    if (n_sel <= (unsigned)MI_RANK_MAX) {
+        const int n = (int)n_sel;
+        const int n4 = (n + 3) & ~3;
+        for (int i = tid; i < n4; i += 1024) {
+            unsigned long long k = 0ull;                                // padding: below every real key (scores are > 0)
+            if (i < n) { const uint2 c = sel[i]; k = ((unsigned long long)c.x << 32) | (unsigned long long)(~c.y); }
+            keys[i] = k;
+        }
+        __syncthreads();
+        // PARTS consecutive lanes share one key and take every PARTS-th key of the list each (a lone thread per key
+        // would walk all n keys: 4 VALU instructions per key at one wave per SIMD = 7 us at n = 1100)
+        const int total = (int)gridDim.x * 1024;
+        int lp = 0;                                                     // PARTS = 2^lp <= 16, n * PARTS <= total
+        while (lp < 4 && (n << (lp + 1)) <= total) ++lp;
+        const int parts = 1 << lp;
+        const int gid = (int)blockIdx.x * 1024 + tid;
+        const int mine_i = gid >> lp, part = gid & (parts - 1);
+        const bool have = mine_i < n;
+        const unsigned long long mine = have ? keys[mine_i] : ~0ull;
+        int rank = 0;
+        // keys are < 2^63 (positive floats in the upper word): key_j > mine  <=>  the sign of mine - key_j
+        for (int j = part; j < n4; j += parts) rank += (int)((unsigned long long)(mine - keys[j]) >> 63);
+        for (int o = 1; o < parts; o <<= 1) rank += __shfl_xor(rank, o, 64);
+        if (have && part == 0 && rank < K) emit_det(dets, rank, mine, H, W, true);
+        const int n_valid = min(n, K);
+        for (int r = n_valid + (int)blockIdx.x * 1024 + tid; r < K; r += (int)gridDim.x * 1024) emit_det(dets, r, 0ull, H, W, false);
+        if (blockIdx.x == 0 && tid == 0 && n_valid_out) *n_valid_out = n_valid;
+        finish();
+        return;
+    }
+    if (blockIdx.x != 0) { finish(); return; }
     int n = 0;
     if (n_sel <= MI_SEL_CAP) {
         n = (int)n_sel;
@@ -430,6 +603,19 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const uint2* cands, De
             keys[i] = ((unsigned long long)c.x << 32) | (unsigned long long)(~c.y);
         }
     } else {
+        // visit every candidate: one segment -> all threads stride over it; many -> one wave per segment
+        auto for_each = [&](auto&& f) {
+            if (n_seg == 1) {
+                const unsigned cnt = min(seg_count[0], seg_cap);
+                for (unsigned i = tid; i < cnt; i += 1024) f(cands[i]);
+            } else {
+                for (unsigned sg = tid >> 6; sg < n_seg; sg += 16) {
+                    const unsigned cnt = min(seg_count[sg], seg_cap);
+                    const uint2* base = cands + (size_t)sg * seg_cap;
+                    for (unsigned i = tid & 63; i < cnt; i += 64) f(base[i]);
+                }
+            }
+        };
         // exact select of the K-th largest key among cands (keys are unique: idx is unique)
         if (tid == 0) { s_prefix = 0ull; s_remaining = (unsigned)K; }
         __syncthreads();
@@ -438,11 +624,10 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const uint2* cands, De
             __syncthreads();
             unsigned long long prefix = s_prefix;
             unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
-            for (unsigned i = tid; i < n_cand; i += 1024) {
-                uint2 c = cands[i];
+            for_each([&](uint2 c) {
                 unsigned long long k = ((unsigned long long)c.x << 32) | (unsigned long long)(~c.y);
                 if ((k & himask) == prefix) atomicAdd(&s_hist[(unsigned)(k >> shift) & 255u], 1u);
-            }
+            });
             __syncthreads();
             if (tid == 0) {
                 unsigned rem = s_remaining, acc = 0;
@@ -459,24 +644,30 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const uint2* cands, De
         unsigned long long thr = s_prefix;   // K-th largest key (or smallest key if fewer than K)
         if (tid == 0) s_n = 0;
         __syncthreads();
-        for (unsigned i = tid; i < n_cand; i += 1024) {
-            uint2 c = cands[i];
+        for_each([&](uint2 c) {
             unsigned long long k = ((unsigned long long)c.x << 32) | (unsigned long long)(~c.y);
             if (k >= thr) {
                 unsigned slot = atomicAdd(&s_n, 1u);
                 if (slot < MI_SEL_CAP) keys[slot] = k;
             }
-        }
+        });
         __syncthreads();
         n = (int)min(s_n, (unsigned)MI_SEL_CAP);
     }
     int P = 1024;
     while (P < n) P <<= 1;
     for (int i = n + tid; i < P; i += 1024) keys[i] = 0ull;
-    block_bitonic_sort_desc(keys, P, tid, 1024);
+    block_sort_desc_fast(keys, P, tid, 1024);
     int n_valid = min(n, K);
     for (int r = tid; r < K; r += 1024) emit_det(dets, r, r < n_valid ? keys[r] : 0ull, H, W, r < n_valid);
     if (tid == 0 && n_valid_out) *n_valid_out = n_valid;
+    finish();
+}
+
+// zero the header of a decode workspace (mi_decode_workspace_init)
+__global__ void zero_header_kernel(DecodeHeader* hdr) {
+    for (int i = threadIdx.x; i < MI_HIST_BINS; i += blockDim.x) hdr->hist[i] = 0u;
+    if (threadIdx.x == 0) { hdr->cand_count = 0u; hdr->sel_count = 0u; hdr->pad0 = 0u; hdr->pad1 = 0u; }
 }
 
 }  // namespace
@@ -526,6 +717,11 @@ extern "C" int mi_sigmoid_clamp(float* x, float* y, size_t n, mi_stream_t stream
 extern "C" int mi_nms3d(const float* heat, float* out, int D, int H, int W, int kd, int kh,
                         mi_stream_t stream) {
     if (!heat || !out || heat == out) return MI_E_ARG;
+    if (kd == 3 && kh == 3 && mi_peak3_usable(heat, nullptr, out, D, H, W)) {
+        Peak3Params q = {};
+        q.in = heat; q.nms_out = out; q.D = D; q.H = H; q.W = W;
+        return mi_launch_peak3(q, mi_peak3_grid(D, H, W), false, (hipStream_t)stream);
+    }
     MarchParams p = {};
     p.in = heat; p.nms_out = out; p.mode = MI_LOAD_PLAIN;
     p.D = D; p.H = H; p.W = W;
@@ -535,8 +731,12 @@ extern "C" int mi_nms3d(const float* heat, float* out, int D, int H, int W, int 
 extern "C" size_t mi_decode_workspace_bytes(int D, int H, int W, int K) {
     (void)K;
     size_t n = (size_t)D * H * W;
-    return mi_align_up(sizeof(DecodeHeader), 256) + mi_align_up(n * sizeof(uint2), 256) +
-           mi_align_up((size_t)MI_SEL_CAP * sizeof(uint2), 256);
+    // candidate storage: the linear list of the generic march (n entries) or the per-wave segments of the register
+    // march (padded to whole strips / z-chunks)
+    const Peak3Grid g = mi_peak3_grid(D, H, W);
+    size_t n_cand = std::max(n, (size_t)g.n_seg * g.seg_cap);
+    return mi_align_up(sizeof(DecodeHeader), 256) + mi_align_up(n_cand * sizeof(uint2), 256) +
+           mi_align_up((size_t)MI_SEL_CAP * sizeof(uint2), 256) + mi_align_up((size_t)g.n_seg * sizeof(unsigned), 256);
 }
 
 extern "C" int mi_sigmoid_nms_topk(const float* logits, float* heat_out, int D, int H, int W,
@@ -549,16 +749,53 @@ extern "C" int mi_sigmoid_nms_topk(const float* logits, float* heat_out, int D, 
     if (workspace_bytes < mi_decode_workspace_bytes(D, H, W, K)) return MI_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     size_t n = (size_t)D * H * W;
+    const Peak3Grid g = mi_peak3_grid(D, H, W);
+    size_t n_cand = std::max(n, (size_t)g.n_seg * g.seg_cap);
     char* w = (char*)workspace;
     DecodeHeader* hdr = (DecodeHeader*)w;
     w += mi_align_up(sizeof(DecodeHeader), 256);
     uint2* cands = (uint2*)w;
-    w += mi_align_up(n * sizeof(uint2), 256);
+    w += mi_align_up(n_cand * sizeof(uint2), 256);
     uint2* sel = (uint2*)w;
-    MI_HIP(hipMemsetAsync(hdr, 0, sizeof(DecodeHeader), s));
+    w += mi_align_up((size_t)MI_SEL_CAP * sizeof(uint2), 256);
+    unsigned* seg_count = (unsigned*)w;
+    // bit 1 of `apply_sigmoid`: the caller vouches that the workspace header is clean - zeroed once by
+    // mi_decode_workspace_init and, since then, only used by calls that passed this bit (they leave it clean again)
+    const int self_clean = (apply_sigmoid & 2) ? 1 : 0;
+    apply_sigmoid &= 1;
+    if (!self_clean) MI_HIP(hipMemsetAsync(hdr, 0, sizeof(DecodeHeader), s));
+    // 128 KiB of dynamic LDS for the single-workgroup sorter (above the 64 KiB default limit)
+    static bool attr_set = false;
+    if (!attr_set) {
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_final_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(MI_SEL_CAP * sizeof(unsigned long long))));
+        attr_set = true;
+    }
+    float* val_out = apply_sigmoid ? heat_out : nullptr;
+
+    if (!fiber && k == 3 && mi_peak3_usable(logits, val_out, nullptr, D, H, W)) {
+        // register march: per-wave candidate segments, no global candidate counter
+        Peak3Params q = {};
+        q.in = logits; q.val_out = val_out; q.D = D; q.H = H; q.W = W;
+        q.cands = cands; q.seg_count = seg_count; q.hist = hdr->hist;
+        if (const char* e = getenv("MI_DBG_P3")) {       // timing experiments (results are garbage): 1 = no histogram
+            if (atoi(e) & 1) q.hist = nullptr;
+        }
+        int rc = mi_launch_peak3(q, g, apply_sigmoid != 0, s);
+        if (rc) return rc;
+        const int fblocks = (int)std::min<unsigned>((g.n_seg + 7) / 8, 256u);       // two segments per wave
+        hipLaunchKernelGGL(topk_filter_seg_kernel, dim3(fblocks), dim3(256), 0, s, cands, seg_count, g.n_seg, g.seg_cap,
+                           hdr, sel, (unsigned)MI_SEL_CAP, K);
+        MI_RETURN_IF_LAUNCH_FAILED();
+        hipLaunchKernelGGL(topk_final_kernel, dim3(MI_FINAL_BLOCKS), dim3(1024), MI_SEL_CAP * sizeof(unsigned long long), s,
+                           cands, seg_count, g.n_seg, g.seg_cap, hdr, sel, K, H, W, dets, (int*)n_valid_out, self_clean);
+        MI_RETURN_IF_LAUNCH_FAILED();
+        return MI_OK;
+    }
 
     MarchParams p = {};
-    p.in = logits; p.val_out = apply_sigmoid ? heat_out : nullptr;
+    p.in = logits; p.val_out = val_out;
     p.mode = apply_sigmoid ? MI_LOAD_SIGMOID : MI_LOAD_PLAIN;
     p.D = D; p.H = H; p.W = W; p.fiber = fiber ? 1 : 0;
     p.cands = cands; p.cand_count = &hdr->cand_count; p.cand_cap = (unsigned)n; p.hist = hdr->hist;
@@ -568,12 +805,15 @@ extern "C" int mi_sigmoid_nms_topk(const float* logits, float* heat_out, int D, 
     hipLaunchKernelGGL(topk_filter_kernel, dim3(fblocks), dim3(256), 0, s, cands, hdr, (unsigned)n,
                        sel, (unsigned)MI_SEL_CAP, K);
     MI_RETURN_IF_LAUNCH_FAILED();
-    // 128 KiB of dynamic LDS for the single-workgroup sorter (above the 64 KiB default limit)
-    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_final_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(MI_SEL_CAP * sizeof(unsigned long long))));
-    hipLaunchKernelGGL(topk_final_kernel, dim3(1), dim3(1024), MI_SEL_CAP * sizeof(unsigned long long),
-                       s, cands, hdr, (unsigned)n, sel, K, H, W, dets, (int*)n_valid_out);
+    hipLaunchKernelGGL(topk_final_kernel, dim3(MI_FINAL_BLOCKS), dim3(1024), MI_SEL_CAP * sizeof(unsigned long long),
+                       s, cands, &hdr->cand_count, 1u, (unsigned)n, hdr, sel, K, H, W, dets, (int*)n_valid_out, self_clean);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_decode_workspace_init(void* workspace, size_t workspace_bytes, mi_stream_t stream) {
+    if (!workspace || workspace_bytes < sizeof(DecodeHeader)) return MI_E_ARG;
+    hipLaunchKernelGGL(zero_header_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (DecodeHeader*)workspace);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

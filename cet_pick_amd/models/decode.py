@@ -49,17 +49,33 @@ def _convert_1d_to_3d(inds, d, h, w):
     return z_coord, y_coord, x_coord
 
 
-def _decode_fused(vol, kernel, K, fiber, apply_sigmoid, heat_out):
+def _decode_fused(vol, kernel, K, fiber, apply_sigmoid, heat_out, dets=None):
+    """One volume through mi_sigmoid_nms_topk; `dets` (K,5) is written in place when given (a row of the batch's
+    output: no stack / copy kernel afterwards)."""
     d, h, w = vol.shape
     lib = L.lib()
-    nbytes = lib.mi_decode_workspace_bytes(d, h, w, K)
-    ws = L.workspace(nbytes, vol.device, "decode")
-    dets = torch.empty((K, 5), dtype=torch.float32, device=vol.device)
+    ws = _decode_workspace(lib.mi_decode_workspace_bytes(d, h, w, K), vol.device)
+    if dets is None:
+        dets = torch.empty((K, 5), dtype=torch.float32, device=vol.device)
     nvalid = torch.empty((1,), dtype=torch.int32, device=vol.device)
-    L.check(lib.mi_sigmoid_nms_topk(L.ptr(vol), L.ptr(heat_out), d, h, w, kernel, int(bool(fiber)),
-                                    int(bool(apply_sigmoid)), K, L.ptr(dets), L.ptr(nvalid),
-                                    L.ptr(ws), ws.numel(), L.stream()), "mi_sigmoid_nms_topk")
+    rc = lib.mi_sigmoid_nms_topk(L.ptr(vol), L.ptr(heat_out), d, h, w, kernel, int(bool(fiber)),
+                                 int(bool(apply_sigmoid)) | _WS_CLEAN, K, L.ptr(dets), L.ptr(nvalid),
+                                 L.ptr(ws), ws.numel(), L.stream())
+    if rc:
+        L.drop_workspace(vol.device, "decode")
+    L.check(rc, "mi_sigmoid_nms_topk")
     return dets, nvalid
+
+
+_WS_CLEAN = 2       # include/cetpick_hip.h: bit 1 of `apply_sigmoid` - the header of this workspace is kept clean
+
+
+def _decode_workspace(nbytes, device):
+    """The decode workspace, its header zeroed once per allocation (mi_decode_workspace_init); every call made with
+    _WS_CLEAN leaves it zeroed again, so a decode is march + filter + final and no clearing pass."""
+    def init(buf):
+        L.check(L.lib().mi_decode_workspace_init(L.ptr(buf), buf.numel(), L.stream()), "mi_decode_workspace_init")
+    return L.workspace(nbytes, device, "decode", init=init)
 
 
 def tomo_decode(heat, kernel=3, reg=None, K=900, if_fiber=False):
@@ -69,11 +85,9 @@ def tomo_decode(heat, kernel=3, reg=None, K=900, if_fiber=False):
     if cat != 1:
         raise ValueError("tomo_decode expects one heat-map channel")
     heat = heat.contiguous()
-    outs = []
+    detections = torch.empty((batch, K, 5), dtype=torch.float32, device=heat.device)
     for b in range(batch):
-        dets, _ = _decode_fused(heat[b, 0], kernel, K, if_fiber, False, None)
-        outs.append(dets)
-    detections = torch.stack(outs, 0)
+        _decode_fused(heat[b, 0], kernel, K, if_fiber, False, None, detections[b])
     if reg is not None:
         # decode.py:134-140: sub-voxel offsets gathered at the peak indices
         xs = (detections[:, :, 0] - 0.25).long()
@@ -94,11 +108,10 @@ def sigmoid_tomo_decode(logits, kernel=3, K=900, if_fiber=False):
     batch, cat, depth, height, width = logits.size()
     logits = logits.contiguous()
     heat = torch.empty_like(logits)
-    outs = []
+    detections = torch.empty((batch, K, 5), dtype=torch.float32, device=logits.device)
     for b in range(batch):
-        dets, _ = _decode_fused(logits[b, 0], kernel, K, if_fiber, True, heat[b, 0])
-        outs.append(dets)
-    return heat, torch.stack(outs, 0)
+        _decode_fused(logits[b, 0], kernel, K, if_fiber, True, heat[b, 0], detections[b])
+    return heat, detections
 
 
 def _topk(scores, K=900):
@@ -112,7 +125,7 @@ def _topk(scores, K=900):
     for b in range(batch):
         d, h, w = depth, height, width
         lib = L.lib()
-        ws = L.workspace(lib.mi_decode_workspace_bytes(d, h, w, K), scores.device, "decode")
+        ws = _decode_workspace(lib.mi_decode_workspace_bytes(d, h, w, K), scores.device)
         dets = torch.empty((K, 5), dtype=torch.float32, device=scores.device)
         # window (1,1,1): every positive voxel is its own maximum -> plain top-K
         vol = scores[b, 0]
@@ -130,8 +143,11 @@ def _topk(scores, K=900):
 def _topk_plain(vol, K, dets, ws):
     d, h, w = vol.shape
     # fiber mode with k=1 pools nothing (windows (1,1,1) then (1,1,1))
-    return L.lib().mi_sigmoid_nms_topk(L.ptr(vol), None, d, h, w, 1, 1, 0, K, L.ptr(dets), None,
-                                       L.ptr(ws), ws.numel(), L.stream())
+    rc = L.lib().mi_sigmoid_nms_topk(L.ptr(vol), None, d, h, w, 1, 1, _WS_CLEAN, K, L.ptr(dets), None,
+                                     L.ptr(ws), ws.numel(), L.stream())
+    if rc:
+        L.drop_workspace(vol.device, "decode")
+    return rc
 
 
 def non_maximum_suppression_3d(x, d, scale=1.0, threshold=-np.inf):

@@ -61,8 +61,13 @@ int mi_nms3d(const float* heat, float* out, int D, int H, int W, int kd, int kh,
  * x,y,z follow `_convert_1d_to_3d` (decode.py:35-41).  Rows past the number of positive local
  * maxima are {0.25,0.25,0,0,0} (torch.topk leaves their order unspecified).
  * n_valid_out (device int32, may be NULL) receives min(K, #positive maxima).
- * logits must not alias heat_out. */
+ * logits must not alias heat_out.
+ * apply_sigmoid: bit 0 = apply `_sigmoid`; bit 1 = "the workspace header is clean": the caller zeroed it once with
+ * mi_decode_workspace_init and has since used the workspace only through calls that passed this bit - such a call
+ * skips its own clearing pass and leaves the header clean again (one launch less per decode).  Without bit 1 the
+ * workspace needs no initialisation. */
 size_t mi_decode_workspace_bytes(int D, int H, int W, int K);
+int mi_decode_workspace_init(void* workspace, size_t workspace_bytes, mi_stream_t stream);
 int mi_sigmoid_nms_topk(const float* logits, float* heat_out, int D, int H, int W, int k,
                         int fiber, int apply_sigmoid, int K, float* dets, int32_t* n_valid_out,
                         void* workspace, size_t workspace_bytes, mi_stream_t stream);

@@ -197,3 +197,85 @@ def test_get_potential_coords(golden):
     got = set(zip(z[0].cpu().numpy().tolist(), y[0].cpu().numpy().tolist(), x[0].cpu().numpy().tolist()))
     want = set(zip(g["gpc_z"].tolist(), g["gpc_y"].tolist(), g["gpc_x"].tolist()))
     assert len(got & want) >= 62    # fp32 vs fp64 DoG may reorder the last near-ties
+
+
+@pytest.mark.parametrize("shape", [(5, 17, 24), (9, 64, 64), (20, 33, 260), (3, 16, 512), (17, 70, 256), (23, 130, 768),
+                                   (1, 4, 4), (2, 3, 8)])
+def test_register_march_333_exact(shape, monkeypatch):
+    """The (3,3,3) register march (infer_peak3.hip: wave strips, DPP x neighbours, per-wave candidate segments) against
+    the oracle and against the LDS-tile march it replaces, on plateau-rich volumes: W <= 256 (one strip per row), wider
+    rows (strip-edge halo loads), ragged H and a last strip with a single active lane."""
+    from oracle import infer_ref as O
+    from cet_pick_amd.models import decode as Dm
+    rng = np.random.default_rng(shape[1])
+    vol = np.round(rng.standard_normal(shape) * 2).astype(np.float32) / 2
+    t = dev(vol)[None, None]
+    want = O.nms_window(vol, (3, 3, 3))
+    got = Dm._nms(t, 3)[0, 0].cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    monkeypatch.setenv("MI_NO_PEAK3", "1")
+    np.testing.assert_array_equal(Dm._nms(t, 3)[0, 0].cpu().numpy(), want)
+    monkeypatch.delenv("MI_NO_PEAK3")
+    # fused decode on the same shape: positive heat with ties; K above and below the number of maxima
+    heat = (np.abs(vol) / 8 + 0.05).astype(np.float32)
+    for K in (7, 300):
+        dets = Dm.tomo_decode(dev(heat)[None, None], kernel=3, K=K)[0].cpu().numpy()
+        _cmp_dets(dets, O.tomo_decode(heat, kernel=3, K=K), floor=0)
+        monkeypatch.setenv("MI_NO_PEAK3", "1")
+        dets2 = Dm.tomo_decode(dev(heat)[None, None], kernel=3, K=K)[0].cpu().numpy()
+        monkeypatch.delenv("MI_NO_PEAK3")
+        np.testing.assert_array_equal(dets, dets2)
+
+
+def test_register_march_inf_peak():
+    """An infinite peak is a maximum and suppresses its window, as in torch's max_pool3d form of `_nms`."""
+    from oracle import infer_ref as O
+    from cet_pick_amd.models import decode as Dm
+    rng = np.random.default_rng(5)
+    vol = rng.standard_normal((6, 20, 64)).astype(np.float32)
+    vol[2, 7, 9] = np.inf
+    t = dev(vol)[None, None]
+    got = Dm._nms(t, 3)[0, 0].cpu().numpy()
+    want = torch.nn.functional.max_pool3d(torch.as_tensor(vol)[None, None], 3, 1, 1)
+    want = (torch.as_tensor(vol)[None, None] * (want == torch.as_tensor(vol)[None, None]).float())[0, 0].numpy()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_decode_large_k_sorts_exactly():
+    """K = 5000 (the `_topk` of get_potential_coords): the single-workgroup sorter works on 8192 keys."""
+    from oracle import infer_ref as O
+    from cet_pick_amd.models import decode as Dm
+    rng = np.random.default_rng(11)
+    heat = rng.random((12, 64, 128)).astype(np.float32) * 0.9 + 0.05
+    dets = Dm.tomo_decode(dev(heat)[None, None], kernel=3, K=5000)[0].cpu().numpy()
+    _cmp_dets(dets, O.tomo_decode(heat, kernel=3, K=5000), floor=0)
+    s = dets[:, 3][dets[:, 3] > 0]
+    assert np.all(np.diff(s) <= 0)
+
+
+def test_decode_workspace_stays_clean_between_calls():
+    """The Python mirror passes the 'header is clean' bit: no clearing pass per decode, the final kernel's last workgroup
+    zeroes the header.  Repeated and interleaved calls (different shapes, K, the plateau slow path, the generic march)
+    must keep giving the oracle's answer."""
+    from oracle import infer_ref as O
+    from cet_pick_amd.models import decode as Dm
+    rng = np.random.default_rng(21)
+    a = (rng.random((10, 40, 64)) * 0.9 + 0.05).astype(np.float32)
+    b = (rng.random((7, 33, 72)) * 0.9 + 0.05).astype(np.float32)
+    wa, wb = O.tomo_decode(a, kernel=3, K=200), O.tomo_decode(b, kernel=5, K=60)
+    plateau = torch.full((1, 1, 6, 40, 72), 0.5, device="cuda")
+    for _ in range(3):
+        _cmp_dets(Dm.tomo_decode(dev(a)[None, None], kernel=3, K=200)[0].cpu().numpy(), wa, floor=0)
+        _cmp_dets(Dm.tomo_decode(dev(b)[None, None], kernel=5, K=60)[0].cpu().numpy(), wb, floor=0)
+        d = Dm.tomo_decode(plateau, kernel=3, K=100)[0].cpu().numpy()       # > MI_SEL_CAP ties: radix-select path
+        assert np.all(d[:, 3] == 0.5)
+    # the C-ABI without the bit needs no initialisation and tolerates a dirty header
+    from cet_pick_amd import _lib as L
+    lib = L.lib()
+    ws = torch.full((int(lib.mi_decode_workspace_bytes(10, 40, 64, 200)),), 0xAB, dtype=torch.uint8, device="cuda")
+    dets = torch.empty((200, 5), device="cuda")
+    t = dev(a)
+    for _ in range(2):
+        L.check(lib.mi_sigmoid_nms_topk(L.ptr(t), None, 10, 40, 64, 3, 0, 0, 200, L.ptr(dets), None, L.ptr(ws), ws.numel(),
+                                        L.stream()), "mi_sigmoid_nms_topk")
+        _cmp_dets(dets.cpu().numpy(), wa, floor=0)
