@@ -102,13 +102,35 @@ def cpu_baseline(batch, steps, seed):
     return batch * steps / dt, torch.get_num_threads()
 
 
-def inference_secondary(dev):
-    """voxels/s of the inference half on BASELINE configs[2] sizes (one rank, after the timed region)."""
+def _traffic(fname, kernels):
+    """HBM bytes per launch of `kernels` from a PMC summary under profiles/ (tools/pmc_summary.py), or None when the
+    summary was measured on other kernel sources than the ones in the tree (its source hash no longer matches)."""
+    path = os.path.join(REPO, "profiles", fname)
+    if not os.path.exists(path):
+        return None, "no %s" % fname
+    from cet_pick_amd.build import source_sha16
+    d = json.load(open(path))
+    if d.get("source_sha16") != source_sha16(d.get("source_prefixes")):
+        return None, "stale: %s was measured on sources %s" % (fname, d.get("source_sha16"))
+    tot = 0.0
+    for k in kernels:
+        hit = [v for name, v in d["kernels"].items() if name.startswith(k) and "hbm_bytes_per_launch" in v]
+        if not hit:
+            return None, "%s has no %s" % (fname, k)
+        tot += sum(v["hbm_bytes_per_launch"] * kernels[k] for v in hit)
+    return tot, "PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch, profiles/%s" % fname
+
+
+def inference_secondary(dev, with_cpu=True):
+    """voxels/s of the inference half on BASELINE configs[2] sizes (one rank, after the timed region).
+    Each entry carries its own HBM roofline (8 B per voxel algorithmic) and CPU baseline(s)."""
     from cet_pick_amd.synthetic import make_tomo, make_logits
     from cet_pick_amd.models import decode as Dm
     from cet_pick_amd.utils import image as Im
 
-    def timeit(fn, n, warm=2):
+    def timeit(fn, n, warm=3):
+        """(eager ms, hipGraph-replay ms): the chain is a handful of short launches, so the product call is also timed
+        captured in a hipGraph and replayed (launch-bound inner loops belong in graphs)."""
         for _ in range(warm):
             fn()
         torch.cuda.synchronize()
@@ -118,23 +140,80 @@ def inference_secondary(dev):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
+        eager = e0.elapsed_time(e1) / n
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return eager, e0.elapsed_time(e1) / n
 
-    logits = torch.as_tensor(make_logits((128, 256, 256), seed=317)).to(dev)[None, None]
-    ms_dec = timeit(lambda: Dm.sigmoid_tomo_decode(logits, kernel=3, K=900), 20)
+    def entry(workload, n_vox, eager, graph, kernels, traffic_file):
+        ms = min(eager, graph)
+        achieved = n_vox * 8 / (ms * 1e-3) / 1e9
+        traffic, tnote = _traffic(traffic_file, kernels)
+        return {"workload": workload, "ms": round(ms, 4), "ms_eager": round(eager, 4), "ms_hipgraph": round(graph, 4),
+                "voxels_per_sec": n_vox / ms * 1e3,
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_note": tnote,
+                             "algorithmic_bytes": n_vox * 8,
+                             "measured": "whole chain (every launch of the call) between two HIP events on the launch "
+                                         "stream, per call; algorithmic 8 B per voxel (SURVEY.md 8d)"}}
+
+    logits_np = make_logits((128, 256, 256), seed=317)
+    logits = torch.as_tensor(logits_np).to(dev)[None, None]
+    e_dec, g_dec = timeit(lambda: Dm.sigmoid_tomo_decode(logits, kernel=3, K=900), 30)
     vol, _ = make_tomo((256, 512, 512), seed=317)
     v = torch.as_tensor(vol).to(dev)
-    ms_dog = timeit(lambda: Im.dog_pick(v, [3, 5]), 5)
-    n_dec, n_dog = logits.numel(), v.numel()
-    return {
+    e_dog, g_dog = timeit(lambda: Im.dog_pick(v, [3, 5]), 8)
+    out = {
         "metric": "voxels/sec (heatmap+NMS)",
-        "decode_sigmoid_nms_topk": {"workload": "logits 1x1x128x256x256, k=3, K=900", "ms": round(ms_dec, 4),
-                                    "voxels_per_sec": n_dec / ms_dec * 1e3,
-                                    "hbm_frac_8B_per_voxel": n_dec * 8 / ms_dec * 1e3 / 1e9 / PEAK_HBM_GBS},
-        "dog_pick": {"workload": "tomogram 256x512x512, sigma=(3,5), nms_xy k=3, greedy d=14", "ms": round(ms_dog, 4),
-                     "voxels_per_sec": n_dog / ms_dog * 1e3,
-                     "hbm_frac_8B_per_voxel": n_dog * 8 / ms_dog * 1e3 / 1e9 / PEAK_HBM_GBS},
+        "decode_sigmoid_nms_topk": entry("logits 1x1x128x256x256, k=3, K=900: sigmoid+clamp -> (3,3,3) NMS -> top-K", logits.numel(),
+                                         e_dec, g_dec, {"peak3_march_kernel": 1, "topk_filter_seg_kernel": 1, "topk_final_kernel": 1},
+                                         "r02_infer_traffic.json"),
+        "dog_pick": entry("tomogram 256x512x512, sigma=(3,5), nms_xy k=3, greedy d=14", v.numel(), e_dog, g_dog,
+                          {"gauss_march_dual_kernel": 1, "gauss_march_two_kernel": 1, "dogx_nms_kernel": 1},
+                          "r02_infer_traffic.json"),
     }
+    if with_cpu:
+        # CPU baselines on a bounded sample: the oracle (numpy / C port), and for the picker also the reference's own
+        # arithmetic for the Gaussians - scipy.ndimage.gaussian_filter, single-threaded - in front of the oracle's tail
+        from oracle import infer_ref as O
+        t0 = time.perf_counter()
+        hm = O.sigmoid_clamp(logits_np)
+        O.tomo_decode(hm, kernel=3, K=900)
+        dt = time.perf_counter() - t0
+        out["decode_sigmoid_nms_topk"]["cpu_baseline"] = {
+            "value": logits_np.size / dt, "unit": "voxels/sec", "cores": 1, "kind": "port",
+            "sample": "the whole 128x256x256 logit volume once: oracle/infer_ref.py sigmoid_clamp + tomo_decode (numpy)"}
+        sub = np.ascontiguousarray(vol[:64]).astype(np.float64)
+        t0 = time.perf_counter()
+        O.get_potential_coords_pyramid(sub, sigmas=(3, 5))
+        dt = time.perf_counter() - t0
+        out["dog_pick"]["cpu_baseline"] = {
+            "value": sub.size / dt, "unit": "voxels/sec", "cores": 1, "kind": "port",
+            "sample": "the first 64 slices (64x512x512) once: oracle/infer_ref.py get_potential_coords_pyramid (numpy fp64 + C greedy loop)"}
+        try:
+            from scipy import ndimage
+            t0 = time.perf_counter()
+            diff = ndimage.gaussian_filter(sub, 5) - ndimage.gaussian_filter(sub, 3)
+            diff[:10] = 0; diff[-10:] = 0
+            diff[:, :30, :] = 0; diff[:, -30:, :] = 0; diff[:, :, :30] = 0; diff[:, :, -30:] = 0
+            heat = O.nms_window(diff, (1, 3, 3))
+            O.non_maximum_suppression_3d(heat, 14, threshold=O.pos_threshold(heat))
+            dt = time.perf_counter() - t0
+            out["dog_pick"]["cpu_baseline_scipy"] = {
+                "value": sub.size / dt, "unit": "voxels/sec", "cores": 1, "kind": "port",
+                "sample": "same 64x512x512 sample with scipy.ndimage.gaussian_filter (the reference's Gaussian, single-threaded) "
+                          "in front of the oracle's NMS / threshold / greedy tail"}
+        except ImportError:
+            pass
+    return out
 
 
 T_START = time.perf_counter()
@@ -343,20 +422,27 @@ def main():
                                      for t, v in sorted(by.items())},
                          "measured": "per conv call of 3 eager steps after the timed region: 8 back-to-back launches of the "
                                      "call (kernel + its split-K reduce) between two HIP events on the launch stream; "
-                                     "compare profiles/r01_train_kernel_stats.csv"},
+                                     "compare profiles/r02_train_kernel_stats.csv"},
         }
-        # HBM traffic of the conv kernels from PMC counters (collected offline by tools/pmc_traffic.sh: two rocprofv3
-        # --pmc passes of this workload; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), per conv call
-        tpath = os.path.join(REPO, "profiles", "r01_conv_traffic.json")
+        # HBM traffic of the conv kernels from PMC counters (tools/pmc_run.sh + tools/pmc_summary.py: separate rocprofv3
+        # --pmc passes of this workload; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), per conv call.
+        # The summary carries the hash of the kernel sources it was measured on: a stale one is not quoted.
+        tpath = os.path.join(REPO, "profiles", "r02_conv_traffic.json")
         if os.path.exists(tpath):
-            out["roofline"]["traffic"] = json.load(open(tpath))["hbm_bytes_per_conv_call"]
-            out["roofline"]["traffic_note"] = "bytes per conv call (75 per step), profiles/r01_conv_traffic.json"
+            from cet_pick_amd.build import source_sha16
+            tj = json.load(open(tpath))
+            if tj.get("source_sha16") == source_sha16(tj.get("source_prefixes")):
+                out["roofline"]["traffic"] = tj["hbm_bytes_per_step"] / (n_launch // 3)
+                out["roofline"]["traffic_note"] = ("bytes per conv call (%d per step), profiles/r02_conv_traffic.json"
+                                                   % (n_launch // 3))
+            else:
+                out["roofline"]["traffic_note"] = "stale: profiles/r02_conv_traffic.json was measured on other kernel sources"
         if f32_ms is not None:
             out["f32_mfma_step"] = {"ms_per_step": f32_ms, "value": B / (f32_ms * 1e-3),
                                     "note": "the same step with MI_CONV_ARITH=f32 (v_mfma_f32_32x32x2_f32 in the generic kernel)"}
         log("conv roofline pass done")
         if not args.no_secondary:
-            out["secondary"] = inference_secondary(dev)
+            out["secondary"] = inference_secondary(dev, with_cpu=not args.no_cpu_baseline)
             log("inference secondary done")
             # detector-side rows (loader a12, unet_4 forward a22, debiased contrastive loss a23, C5 train step)
             from tools.bench_detector import run as detector_secondary

@@ -18,6 +18,23 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+def source_sha16(prefixes=None):
+    """Hash of the kernel sources whose file name starts with one of `prefixes` (all of csrc/*.hip, csrc/*.h and the
+    C-ABI header when None): profiles/ files carry it so a reader (and bench.py) can tell whether a measurement belongs
+    to the kernels that are in the tree now."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    if prefixes is None:
+        files.append(os.path.join(os.path.dirname(HERE), "include", "cetpick_hip.h"))
+    else:
+        files = [f for f in files if os.path.basename(f).startswith(tuple(prefixes))]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
