@@ -4,15 +4,94 @@
 //   datasets/tomo_pre_proj_angle_select_new3d_vol.py:117-128 `extract_subvols`
 //        v[z-sz//2 : z+sz//2+1, y-sy//2 : y+sy//2, x-sx//2 : x+sx//2] -> sum over z -> min-max
 //   :130-138 `extract_subvols_3d` (plain crop)
-//   and the z-normalised 3-D crop that feeds the MoCo-3D encoder.
+//   and the z-normalised 3-D crop that feeds the MoCo-3D encoder;
+//   datasets/tomo_pre.py:57-60 the deterministic tail of the 3-D chain on a cutup window:
+//        Crop -> ZNormalization -> RescaleIntensity(-3, 3) -> ZNormalization      (mode 3; the Crop is the window itself)
+//   simsiam_test_hm_3d.py:45-51  ToPILImage -> ToTensor -> Normalize(mean, std)   (mi_u8_roundtrip_normalize)
 // HBM-bound gather: rows of the crop are contiguous along x, so lanes read consecutive floats.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
-enum { CROP_RAW = 0, CROP_SUMZ_MINMAX = 1, CROP_ZNORM = 2 };
-
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+enum { CROP_RAW = 0, CROP_SUMZ_MINMAX = 1, CROP_ZNORM = 2, CROP_ZNORM_RESCALE_ZNORM = 3 };
+
+// block-wide (sum, sum of squares) in fp64 and (min, max) of per-thread partials; every thread gets the result
+__device__ __forceinline__ void block_stats(double s, double ss, float mn, float mx, double* out_s, double* out_ss,
+                                            float* out_mn, float* out_mx) {
+    __shared__ double rs[2][4];
+    __shared__ float rm[2][4];
+    s = wave_sum(s); ss = wave_sum(ss);
+    mn = -wave_max(-mn); mx = wave_max(mx);
+    __syncthreads();                                  // (the buffers may still be read from the previous round)
+    if ((threadIdx.x & 63) == 0) {
+        rs[0][threadIdx.x >> 6] = s; rs[1][threadIdx.x >> 6] = ss;
+        rm[0][threadIdx.x >> 6] = mn; rm[1][threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    *out_s = rs[0][0] + rs[0][1] + rs[0][2] + rs[0][3];
+    *out_ss = rs[1][0] + rs[1][1] + rs[1][2] + rs[1][3];
+    *out_mn = fminf(fminf(rm[0][0], rm[0][1]), fminf(rm[0][2], rm[0][3]));
+    *out_mx = fmaxf(fmaxf(rm[1][0], rm[1][1]), fmaxf(rm[1][2], rm[1][3]));
+}
+
+// mode 3: the crop sits in LDS; three in-place passes, statistics of each pass in fp64
+__global__ __launch_bounds__(256) void crop_chain_kernel(const float* __restrict__ vol, int D, int H, int W,
+                                                        const int* __restrict__ centres, int cz, int cy, int cx,
+                                                        int flip_x, float* __restrict__ out) {
+    extern __shared__ float buf[];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int x0 = centres[3 * n + 0] - cx / 2, y0 = centres[3 * n + 1] - cy / 2, z0 = centres[3 * n + 2] - cz / 2;
+    const long HW = (long)H * W;
+    const int vox = cz * cy * cx, pix = cy * cx;
+    double s = 0, ss = 0, S, SS;
+    float mn = INFINITY, mx = -INFINITY, MN, MX;
+    for (int i = tid; i < vox; i += 256) {
+        const int z = i / pix, y = (i / cx) % cy, x = i % cx;
+        const int sx = flip_x ? (cx - 1 - x) : x;
+        const float v = vol[(long)clampi(z0 + z, 0, D - 1) * HW + (long)clampi(y0 + y, 0, H - 1) * W + clampi(x0 + sx, 0, W - 1)];
+        buf[i] = v;
+        s += v; ss += (double)v * v;
+    }
+    block_stats(s, ss, 0.f, 0.f, &S, &SS, &MN, &MX);
+    // ZNormalization: (x - mean) / std, unbiased
+    double mean = S / vox, var = (SS - vox * mean * mean) / (vox - 1);
+    float m = (float)mean, inv = (float)(1.0 / sqrt(var > 0 ? var : 0.0));
+    for (int i = tid; i < vox; i += 256) {
+        const float v = (buf[i] - m) * inv;
+        buf[i] = v;
+        mn = fminf(mn, v); mx = fmaxf(mx, v);
+    }
+    block_stats(0, 0, mn, mx, &S, &SS, &MN, &MX);
+    // RescaleIntensity(out_min_max = (-3, 3)): (x - min) / (max - min) * 6 - 3
+    const float sc = 6.0f / (MX - MN);
+    s = 0; ss = 0;
+    for (int i = tid; i < vox; i += 256) {
+        const float v = (buf[i] - MN) * sc - 3.0f;
+        buf[i] = v;
+        s += v; ss += (double)v * v;
+    }
+    block_stats(s, ss, 0.f, 0.f, &S, &SS, &MN, &MX);
+    mean = S / vox; var = (SS - vox * mean * mean) / (vox - 1);
+    m = (float)mean; inv = (float)(1.0 / sqrt(var > 0 ? var : 0.0));
+    float* o = out + (long)n * vox;
+    for (int i = tid; i < vox; i += 256) o[i] = (buf[i] - m) * inv;
+}
+
+__global__ void u8_roundtrip_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float mean,
+                                              float inv_std_unused, float std) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        // ToPILImage on a float tensor: mul(255).byte() (truncation, values of a min-max'ed crop are in [0, 1]);
+        // ToTensor: / 255; Normalize: (q - mean) / std
+        const float q = floorf(fminf(fmaxf(x[i] * 255.0f, 0.0f), 255.0f)) / 255.0f;
+        y[i] = (q - mean) / std;
+    }
+}
+
 
 // window start along an axis: the reference slices [c - s//2, c - s//2 + s) (z windows are odd:
 // c - s//2 .. c + s//2, xy windows even: c - s/2 .. c + s/2 - 1)
@@ -75,11 +154,34 @@ extern "C" int mi_crop_normalize(const float* vol, int D, int H, int W, const in
                                  mi_stream_t stream) {
     if (n == 0) return MI_OK;
     if (!vol || !centres_xyz || !out || D <= 0 || H <= 0 || W <= 0 || n < 0) return MI_E_ARG;
-    if (cz <= 0 || cy <= 0 || cx <= 0 || mode < 0 || mode > 2) return MI_E_ARG;
+    if (cz <= 0 || cy <= 0 || cx <= 0 || mode < 0 || mode > 3) return MI_E_ARG;
+    if (mode == CROP_ZNORM_RESCALE_ZNORM) {
+        const size_t bytes = sizeof(float) * (size_t)cz * cy * cx;
+        if (bytes > 128 * 1024) return MI_E_UNSUPPORTED;            // (6, 48, 48) = 54 KiB; 32^3 = 128 KiB
+        static bool attr_set = false;
+        if (!attr_set) {
+            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(crop_chain_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(crop_chain_kernel, dim3(n), dim3(256), bytes, (hipStream_t)stream, vol, D, H, W,
+                           (const int*)centres_xyz, cz, cy, cx, flip_x, out);
+        MI_RETURN_IF_LAUNCH_FAILED();
+        return MI_OK;
+    }
     size_t lds = (mode == CROP_SUMZ_MINMAX) ? sizeof(float) * (size_t)cy * cx : 0;
     if (lds > 64 * 1024) return MI_E_UNSUPPORTED;
     hipLaunchKernelGGL(crop_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, vol, D, H, W,
                        (const int*)centres_xyz, cz, cy, cx, mode, flip_x, out);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_u8_roundtrip_normalize(const float* x, float* y, size_t n, float mean, float std, mi_stream_t stream) {
+    if (n == 0) return MI_OK;
+    if (!x || !y || !(std > 0.f)) return MI_E_ARG;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(u8_roundtrip_normalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n, mean, 0.f, std);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

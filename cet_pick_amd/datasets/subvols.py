@@ -10,7 +10,7 @@ import torch
 
 from .. import _lib as L
 
-RAW, SUMZ_MINMAX, ZNORM = 0, 1, 2
+RAW, SUMZ_MINMAX, ZNORM, ZNORM_RESCALE_ZNORM = 0, 1, 2, 3
 
 
 def _centres(c, device):
@@ -49,3 +49,52 @@ def extract_subvols_3d(v, tomo_coords, subvol_size):
 def crop_znorm(v, tomo_coords, size, flip_x=False):
     """(n, 1, cz, cy, cx) z-normalised crops (mean 0, unbiased std 1), optionally mirrored along x."""
     return _crop(v, tomo_coords, size, ZNORM, flip_x).unsqueeze(1)
+
+
+def extract_3d_tomo(rec, tomo_coords, crop_size_x, crop_size_y):
+    """datasets/tomo_pre_proj_angle_select_new3d_vol.py:109-115 for every pick: the min-max'ed patch of slice z,
+    (n, 1, crop_y, crop_x)."""
+    return _crop(rec, tomo_coords, (1, crop_size_y, crop_size_x), SUMZ_MINMAX).unsqueeze(1)
+
+
+def subvol_mean_std(subvols):
+    """...:238-239 `torch.mean(torch.stack(sub_vols_3d))`, `torch.std(...)` (unbiased) over all crops, on the device:
+    returns two Python floats (one read-back per dataset, like the reference's two scalars)."""
+    L.require_cuda(subvols, "subvols")
+    x = subvols.contiguous().view(-1)
+    n = x.numel()
+    lib = L.lib()
+    ws = L.workspace(lib.mi_vol_stats_workspace_bytes(1, n), x.device, "stats")
+    st = torch.empty(4, dtype=torch.float64, device=x.device)
+    L.check(lib.mi_vol_stats(L.ptr(x), 1, n, L.ptr(st), L.ptr(ws), ws.numel(), L.stream()), "mi_vol_stats")
+    mean, std0 = float(st[0]), float(st[1])
+    return mean, std0 * (n / (n - 1.0)) ** 0.5
+
+
+def to_uint8_normalize(subvols, mean, std):
+    """simsiam_test_hm_3d.py:45-51 `T.ToPILImage() -> T.ToTensor() -> T.Normalize(mean, std)` for a batch of min-max'ed
+    crops (the 8-bit round trip truncates: floor(255 x) / 255)."""
+    L.require_cuda(subvols, "subvols")
+    x = subvols.contiguous()
+    y = torch.empty_like(x)
+    L.check(L.lib().mi_u8_roundtrip_normalize(L.ptr(x), L.ptr(y), x.numel(), float(mean), float(std), L.stream()),
+            "mi_u8_roundtrip_normalize")
+    return y
+
+
+def cutup_centres(shape, size, stride, margin=(0, 0, 0)):
+    """Centres (x, y, z) of the inner crop of every `cutup(v, size, stride)` window (utils/loader.py:124-132 as used at
+    datasets/tomo_pre.py:104), window order (i, j, k) row-major; `margin` = voxels the chain's Crop removes per side.
+    Returns (centres (n,3) int32, inner size)."""
+    nb = [(int(shape[a]) - int(size[a])) // int(stride[a]) + 1 for a in range(3)]
+    inner = [int(size[a]) - 2 * int(margin[a]) for a in range(3)]
+    iz, iy, ix = np.meshgrid(np.arange(nb[0]), np.arange(nb[1]), np.arange(nb[2]), indexing="ij")
+    o = [iz.ravel() * stride[0] + margin[0], iy.ravel() * stride[1] + margin[1], ix.ravel() * stride[2] + margin[2]]
+    c = np.stack([o[2] + inner[2] // 2, o[1] + inner[1] // 2, o[0] + inner[0] // 2], 1).astype(np.int32)
+    return c, tuple(inner)
+
+
+def crop_znorm_rescale_znorm(v, tomo_coords, size, flip_x=False):
+    """datasets/tomo_pre.py:57-60 (deterministic tail of the torchio chain) for every window: (n, 1, cz, cy, cx) =
+    ZNormalization(RescaleIntensity(-3, 3)(ZNormalization(crop)))."""
+    return _crop(v, tomo_coords, size, ZNORM_RESCALE_ZNORM, flip_x).unsqueeze(1)

@@ -136,9 +136,14 @@ int mi_greedy_nms3d(const float* vol, int D, int H, int W, float d, float scale,
  *   mode 0: raw crop (n, cz, cy, cx)         datasets/tomo_pre_proj_angle_select_new3d_vol.py:130-138
  *   mode 1: sum over z, min-max -> (n, cy, cx)                                          ...:117-128
  *   mode 2: z-normalised 3-D crop (mean 0, unbiased std 1) -> (n, cz, cy, cx)   (MoCo-3D input, §8d C2)
+ *   mode 3: ZNormalization -> RescaleIntensity(-3, 3) -> ZNormalization of the crop -> (n, cz, cy, cx)
+ *           (datasets/tomo_pre.py:57-60; the `Crop` of that chain is the window the centre and size describe)
  * flip_x mirrors the crop along x (second contrastive view). */
 int mi_crop_normalize(const float* vol, int D, int H, int W, const int32_t* centres_xyz, int n,
                       int cz, int cy, int cx, int mode, int flip_x, float* out, mi_stream_t stream);
+/* simsiam_test_hm_3d.py:45-51 on min-max'ed crops: y = (floor(255 x) / 255 - mean) / std  (ToPILImage -> ToTensor ->
+ * Normalize; mean / std = the dataset statistics of tomo_pre_proj_angle_select_new3d_vol.py:238-239).  y may alias x. */
+int mi_u8_roundtrip_normalize(const float* x, float* y, size_t n, float mean, float std, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training path: channels-last fp32 activations (N,D,H,W,C),

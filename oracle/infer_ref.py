@@ -212,10 +212,11 @@ def get_potential_coords_pyramid(rec, sigmas=(2, 4), kernel=3, border_z=10, nms_
 
 
 # --------------------------------------------------------------------------- a13
+# Pinned by tests/golden/crops.npz (the reference's own methods, imported by tests/golden/gen_golden.py:gen_crops), except
+# the torchio chain (znorm_rescale_znorm) and the torchvision 8-bit round trip (u8_roundtrip_normalize): those two
+# packages are absent here (un-vendored) - their published arithmetic is restated: parity unpinned.
 def extract_subvols(v, coord, size):
-    """datasets/tomo_pre_proj_angle_select_new3d_vol.py:117-128 (one pick, numpy like the reference).
-    Parity unpinned: that module is not importable here (mrcfile, cwd-relative imports); restated
-    from its source."""
+    """datasets/tomo_pre_proj_angle_select_new3d_vol.py:117-128 (one pick, numpy like the reference)."""
     sz, sy, sx = size
     x, y, z = coord
     sub = v[z - sz // 2:z + sz // 2 + 1, y - sy // 2:y + sy // 2, x - sx // 2:x + sx // 2].copy()
@@ -229,3 +230,48 @@ def extract_subvols_3d(v, coord, size):
     sz, sy, sx = size
     x, y, z = coord
     return v[z - sz // 2:z + sz // 2 + 1, y - sy // 2:y + sy // 2, x - sx // 2:x + sx // 2].copy()
+
+
+def extract_3d_tomo(rec, coord, crop_x, crop_y):
+    """...:109-115: one slice, min-max."""
+    x, y, z = coord
+    p = rec[z, y - crop_y // 2:y + crop_y // 2, x - crop_x // 2:x + crop_x // 2].copy()
+    p = (p - np.min(p)) / (np.max(p) - np.min(p))
+    return p.astype(np.float32)[None]
+
+
+def subvol_mean_std(subvols):
+    """...:238-239: torch.mean / torch.std (unbiased) over the stack of all crops."""
+    a = np.asarray(subvols, dtype=np.float64)
+    return float(a.mean()), float(a.std(ddof=1))
+
+
+def cutup(data, blck, strd):
+    """utils/loader.py:124-132: sliding windows as a strided view."""
+    data = np.asarray(data)
+    sh = np.array(data.shape)
+    blck, strd = np.asanyarray(blck), np.asanyarray(strd)
+    nbl = (sh - blck) // strd + 1
+    return np.lib.stride_tricks.as_strided(data, shape=tuple(np.r_[nbl, blck]),
+                                           strides=tuple(np.r_[np.array(data.strides) * strd, data.strides]))
+
+
+def znorm_rescale_znorm(window, margin):
+    """datasets/tomo_pre.py:57-60 on one cutup window (the deterministic tail of the torchio chain; torchio 0.18 semantics
+    restated - parity unpinned): Crop(margin per side) -> ZNormalization (mean, unbiased std of all voxels) ->
+    RescaleIntensity(out_min_max=(-3, 3), percentiles (0, 100)) -> ZNormalization."""
+    mz, my, mx = margin
+    w = np.asarray(window, dtype=np.float32)
+    c = w[mz:w.shape[0] - mz, my:w.shape[1] - my, mx:w.shape[2] - mx].astype(np.float64)
+    c = (c - c.mean()) / c.std(ddof=1)
+    lo, hi = c.min(), c.max()
+    c = (c - lo) / (hi - lo) * 6.0 - 3.0
+    c = (c - c.mean()) / c.std(ddof=1)
+    return c.astype(np.float32)
+
+
+def u8_roundtrip_normalize(sub, mean, std):
+    """simsiam_test_hm_3d.py:45-51: T.ToPILImage() (float tensor: mul(255).byte(), i.e. truncation) -> T.ToTensor()
+    (/255) -> T.Normalize(mean, std).  torchvision 0.12 semantics restated - parity unpinned."""
+    q = np.floor(np.asarray(sub, dtype=np.float32) * np.float32(255.0)).astype(np.uint8).astype(np.float32) / np.float32(255.0)
+    return ((q - np.float32(mean)) / np.float32(std)).astype(np.float32)

@@ -431,6 +431,43 @@ def gen_simsiam2d():
     json.dump(d, open(path, "w"), indent=1)
 
 
+def gen_crops():
+    """a13: the reference's own crop methods - TOMOPreProjAngleSelect3DVol.extract_subvols / extract_subvols_3d /
+    extract_3d_tomo (datasets/tomo_pre_proj_angle_select_new3d_vol.py:110-138, called unbound: they only read crop sizes
+    from `self`), the dataset mean / std of the stacked crops (:238-239, torch.mean / torch.std) and utils/loader.py `cutup`
+    with the (2,4,4) stride of datasets/tomo_pre.py:104.  The module does cwd-relative imports (`from utils.image import
+    ...`), so /root/reference/cet_pick goes on sys.path too; torchio (absent, unpinned in requirements.txt) is an inert
+    stub: its transforms are never reached by these methods.  -> crops.npz"""
+    from types import SimpleNamespace
+    sys.path.insert(0, "/root/reference/cet_pick")
+    _stub("torchio", Compose=None)
+    from cet_pick.datasets import tomo_pre_proj_angle_select_new3d_vol as RD
+    from cet_pick.utils import loader as R_loader
+    cls = RD.TOMOPreProjAngleSelect3DVol
+    vol, _ = make_tomo((20, 72, 80), seed=41, margin_xy=20, margin_z=4)
+    rng = np.random.default_rng(9)
+    n = 8
+    coords = np.stack([rng.integers(16, 80 - 16, n), rng.integers(16, 72 - 16, n), rng.integers(3, 20 - 3, n)], 1).astype(np.int32)
+    out = {"coords": coords}
+    for size in ((3, 24, 24), (3, 16, 20), (5, 8, 12)):
+        tag = "%d_%d_%d" % size
+        sub2d = [cls.extract_subvols(None, vol, c, size) for c in coords]
+        sub3d = [cls.extract_subvols_3d(None, vol, c, size) for c in coords]
+        out["sub2d_" + tag] = torch.stack(sub2d).numpy()
+        if size[1] < 24:
+            out["sub3d_" + tag] = torch.stack(sub3d).numpy()
+        st = torch.stack(sub2d)
+        out["mean_" + tag] = np.float64(torch.mean(st).item())
+        out["std_" + tag] = np.float64(torch.std(st).item())
+    me = SimpleNamespace(crop_size_x=24, crop_size_y=16)
+    out["tomo2d_24_16"] = torch.stack([cls.extract_3d_tomo(me, vol, c) for c in coords]).numpy()
+    blks = R_loader.cutup(vol, (8, 64, 64), (2, 4, 4))
+    out["cutup_shape"] = np.array(blks.shape)
+    out["cutup_samples_idx"] = np.array([[0, 0, 0], [3, 1, 2], [6, 2, 4], [5, 0, 3]])
+    out["cutup_samples"] = np.stack([blks[i, j, k] for i, j, k in out["cutup_samples_idx"]])
+    save("crops.npz", **out)
+
+
 def gen_lr():
     class A:
         pass
@@ -446,6 +483,6 @@ def gen_lr():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader", "unet", "losses", "simsiam", "simsiam2d3d"]
+    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader", "unet", "losses", "simsiam", "simsiam2d3d", "crops"]
     for w in which:
         globals()["gen_" + w]()
