@@ -73,6 +73,17 @@ def _phys_ok(p):
     return p.is_contiguous()
 
 
+def _dense_layout(p):
+    """True when the tensor's strides are a permutation of a contiguous layout (every element of a numel-sized storage
+    block is addressed exactly once): such a parameter can live in a flat arena under its own strides."""
+    exp = 1
+    for st, sz in sorted((st, sz) for st, sz in zip(p.stride(), p.shape) if sz != 1):
+        if st != exp:
+            return False
+        exp *= sz
+    return True
+
+
 def _grad_target(param):
     """(tensor to write into, accumulate?) for a parameter's gradient."""
     g = param.grad
@@ -105,8 +116,8 @@ class ParamArena:
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.params, self.offsets = params, offs
         for p, o in zip(params, offs):
-            if not (_phys_ok(p) or p.is_contiguous()):
-                raise L.HipExtensionError("unexpected parameter layout")
+            if not _dense_layout(p):
+                raise L.HipExtensionError("parameter %s is not densely laid out" % (tuple(p.shape),))
             view = torch.as_strided(self.flat, p.shape, p.stride(), o)
             view.copy_(p.data)
             p.data = view
@@ -122,6 +133,44 @@ class ParamArena:
         """set_to_none semantics: the next backward overwrites the arena views."""
         for p in self.params:
             p.grad = None
+
+
+class GradExchange:
+    """Data-parallel gradient exchange for a module trained with a stock optimizer (main.py:34-56, simsiam_main.py:
+    the reference wraps the model in DistributedDataParallel): the parameters are re-homed in one flat fp32 arena, the
+    backward pass writes their gradients into a second arena, and `sync()` - between `backward()` and
+    `optimizer.step()` - averages that arena over the ranks with a few large asynchronous all-reduces (RCCL over xGMI:
+    bucket = a quarter of the arena, >= 1 Mi floats) instead of one collective per tensor.  SyncBN statistics are
+    exchanged by the BatchNorm modules themselves (convert_sync_batchnorm)."""
+
+    def __init__(self, module, n_buckets=4):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = dist.get_world_size()
+        self.arena = ParamArena(module)
+        n = self.arena.numel
+        per = max((n + n_buckets - 1) // n_buckets, 1 << 20)
+        per = (per + 3) // 4 * 4
+        self.buckets = [(a, min(a + per, n)) for a in range(0, n, per)]
+        self.calls = 0
+
+    def sync(self):
+        for prm in self.arena.params:
+            view = prm._mi_grad_view
+            if prm.grad is None:
+                view.zero_()                       # a parameter the step did not reach contributes zeros
+            elif prm.grad.data_ptr() != view.data_ptr():
+                view.copy_(prm.grad)               # gradient produced outside the arena (plain autograd)
+            prm.grad = view
+        pending = [self.dist.all_reduce(self.arena.flat_grad[a:b], async_op=True) for a, b in self.buckets]
+        for w in pending:
+            w.wait()
+        self.arena.flat_grad.mul_(1.0 / self.world)
+        self.calls += 1
+
+    def broadcast_parameters(self, src=0):
+        """identical replicas before the first step (DistributedDataParallel does this at construction)"""
+        self.dist.broadcast(self.arena.flat, src)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -104,3 +104,32 @@ def concat_all_gather(tensor):
     tensors_gather = [torch.empty_like(tensor) for _ in range(dist.get_world_size())]
     dist.all_gather(tensors_gather, tensor.contiguous(), async_op=False)
     return torch.cat(tensors_gather, dim=0)
+
+
+@torch.no_grad()
+def batch_shuffle_ddp(x):
+    """models/moco.py:55-82 `_batch_shuffle_ddp` (shuffle-BN across ranks): all-gather the key batch, draw ONE
+    permutation of the global batch (rank 0's, broadcast), keep this rank's share of the shuffled batch.
+    Returns (x_this, idx_unshuffle).  The permutation is drawn on the device the batch lives on."""
+    import torch.distributed as dist
+    batch_size_this = x.shape[0]
+    x_gather = concat_all_gather(x)
+    batch_size_all = x_gather.shape[0]
+    num_gpus = batch_size_all // batch_size_this
+    idx_shuffle = torch.randperm(batch_size_all, device=x.device)
+    dist.broadcast(idx_shuffle, src=0)
+    idx_unshuffle = torch.argsort(idx_shuffle)
+    idx_this = idx_shuffle.view(num_gpus, -1)[dist.get_rank()]
+    return x_gather[idx_this].contiguous(), idx_unshuffle
+
+
+@torch.no_grad()
+def batch_unshuffle_ddp(x, idx_unshuffle):
+    """models/moco.py:84-99 `_batch_unshuffle_ddp`: gather the keys of the shuffled shares and take back this rank's
+    rows in their original order."""
+    import torch.distributed as dist
+    batch_size_this = x.shape[0]
+    x_gather = concat_all_gather(x)
+    num_gpus = x_gather.shape[0] // batch_size_this
+    idx_this = idx_unshuffle.view(num_gpus, -1)[dist.get_rank()]
+    return x_gather[idx_this].contiguous()

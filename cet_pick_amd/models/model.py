@@ -17,6 +17,7 @@ _model_factory = {
     "moco3d": get_moco_net_small_3d,
     "simsiam2d": get_simsiam2d_net_small,
     "simsiam": get_simsiam_net_small,
+    "simsiam3d": get_simsiam_net_small,          # models/model.py:43: the same factory as 'simsiam'
     "simsiam2d3d": get_simsiam2d3d_net_small,
     "unet": get_tomo_unet_small,
 }

@@ -14,6 +14,7 @@ import time
 
 import torch
 
+from .. import hipops as H
 from ..models.moco import MoCo
 from ..utils.utils import AverageMeter
 from .moco_engine import MocoStepEngine
@@ -84,6 +85,7 @@ class BaseTrainer(object):
         else:
             raise NotImplementedError("task '%s' is outside the hot path built here (DESIGN.md §7)" % opt.task)
         self.engine = None
+        self.exchange = None        # hipops.GradExchange of a non-MoCo model under torch.distributed
         self.device = None
 
     # ---- device placement ----------------------------------------------------------------------
@@ -98,6 +100,18 @@ class BaseTrainer(object):
             wd = self.optimizer.param_groups[0].get("weight_decay", 0.0) if self.optimizer is not None else 0.0
             self.engine = MocoStepEngine(model, lr=self._lr(), weight_decay=wd,
                                          use_graph=bool(getattr(self.opt, "hipgraph", False)))
+        elif H._distributed():
+            # every other task: stock optimizer, gradients averaged over the ranks between backward() and step()
+            self.exchange = H.GradExchange(model)
+            self.exchange.broadcast_parameters(0)
+            import torch.distributed as dist
+            for b in model.buffers():
+                dist.broadcast(b, 0)
+
+    def close(self):
+        """Release what refers to the process group before it is destroyed (a captured step holds RCCL work)."""
+        if self.engine is not None:
+            self.engine.close()
 
     def set_device(self, gpus, chunk_sizes, device):
         """base_trainer.py:240-249 (single process).  More than one GPU per process (the reference's
@@ -158,6 +172,8 @@ class BaseTrainer(object):
                 if phase == "train":
                     self.optimizer.zero_grad()
                     loss.backward()
+                    if self.exchange is not None:
+                        self.exchange.sync()
                     self.optimizer.step()
             for l in self.loss_stats:
                 v = loss_stats[l].detach().float().mean()

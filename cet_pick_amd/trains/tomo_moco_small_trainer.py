@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import hipops as H
-from ..models.moco import _world_size, concat_all_gather
+from ..models.moco import _world_size, batch_shuffle_ddp, batch_unshuffle_ddp, concat_all_gather
 from .base_trainer import BaseTrainer
 
 
@@ -70,7 +70,13 @@ class MoCoModel(nn.Module):
     def contrastive_loss(self, im_q, im_k):
         q = H.l2_normalize(_embed(self.encoder_q, im_q))
         with torch.no_grad():
-            if self.shuffle:
+            if self.shuffle and _world_size() > 1:
+                # shuffle-BN across the ranks (models/moco.py:55-99): every rank encodes a random share of the GLOBAL
+                # key batch, so the key encoder's batch statistics are not those of the rank's own queries
+                im_k_, idx_unshuffle = batch_shuffle_ddp(im_k)
+                k = H.l2_normalize(_embed(self.encoder_k, im_k_))
+                k = batch_unshuffle_ddp(k, idx_unshuffle)
+            elif self.shuffle:
                 im_k_, idx_unshuffle = self._batch_shuffle_single_gpu(im_k)
                 k = H.l2_normalize(_embed(self.encoder_k, im_k_.contiguous()))
                 k = self._batch_unshuffle_single_gpu(k, idx_unshuffle).contiguous()
@@ -114,8 +120,14 @@ class MoCoTrainer(BaseTrainer):
         self.loss_stats = ["loss", "moco_loss"]
         self.model_with_loss = _LossModule(model)
         self.engine = None
+        self.exchange = None
         self.device = None
         self.iter = 0
 
     def _make_engine(self):
+        """No step engine (the model computes its own symmetric loss); under torch.distributed the query encoder's
+        gradients are averaged over the ranks (the key encoder has none: it follows by EMA)."""
         self.engine = None
+        if H._distributed():
+            self.exchange = H.GradExchange(self.model_with_loss.model.encoder_q)
+            self.exchange.broadcast_parameters(0)

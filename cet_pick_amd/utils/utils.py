@@ -44,3 +44,29 @@ def adjust_learning_rate(args, optimizer, epoch):
         for param_group in optimizer.param_groups:
             param_group["lr"] = lr
     return lr
+
+
+class TextLog(object):
+    """The `log.txt` of the reference's Logger (logger.py: `write` appends to save_dir/log.txt); tensorboard summaries are
+    out of scope, `scalar_summary` is accepted and ignored."""
+
+    def __init__(self, opt, enabled=True):
+        import os
+        self.f = None
+        if enabled:
+            os.makedirs(opt.save_dir, exist_ok=True)
+            self.f = open(os.path.join(opt.save_dir, "log.txt"), "a")
+
+    def write(self, txt):
+        if self.f:
+            self.f.write(txt)
+            if txt.endswith("\n"):
+                self.f.flush()
+
+    def scalar_summary(self, tag, value, step):
+        pass
+
+    def close(self):
+        if self.f:
+            self.f.close()
+            self.f = None

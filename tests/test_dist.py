@@ -187,3 +187,192 @@ def test_two_ranks_equal_one_process_on_the_full_batch(tmp_path):
     assert float((a - b).norm()) <= 1e-4 * float(b.norm())
     np.testing.assert_allclose(r0["k_flat"].numpy(), eng.arena_k.flat.cpu().numpy(), rtol=0, atol=1e-5)
     np.testing.assert_allclose(r0["bn1_rv"].numpy(), moco.encoder_q.bn1.running_var.cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------ f4: DDP shuffle-BN, config 5: GradExchange (CPU, gloo)
+def _w_shuffle(rank, world, port, out):
+    _init(rank, world, port)
+    from cet_pick_amd.models.moco import batch_shuffle_ddp, batch_unshuffle_ddp
+    torch.manual_seed(100 + rank)                    # ranks draw different permutations: rank 0's must win
+    x = (torch.arange(6, dtype=torch.float32) + 10 * rank).view(6, 1).repeat(1, 3)
+    xs, idx_un = batch_shuffle_ddp(x)
+    back = batch_unshuffle_ddp(xs * 2.0, idx_un)     # "encode" = x2
+    torch.save({"xs": xs, "idx": idx_un, "back": back}, os.path.join(out, "s%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_batch_shuffle_ddp_roundtrip_gloo_cpu(tmp_path):
+    """models/moco.py:55-99: the shares of the two ranks are a partition of the global batch under ONE permutation, and
+    unshuffle hands every rank its own rows back in order."""
+    port = _free_port()
+    mp.spawn(_w_shuffle, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    s0, s1 = torch.load(str(tmp_path / "s0.pt")), torch.load(str(tmp_path / "s1.pt"))
+    assert torch.equal(s0["idx"], s1["idx"])
+    allrows = sorted(torch.cat([s0["xs"][:, 0], s1["xs"][:, 0]]).tolist())
+    assert allrows == [0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 15]
+    assert not torch.equal(s0["xs"][:, 0], torch.arange(6, dtype=torch.float32))           # actually shuffled
+    assert torch.equal(s0["back"][:, 0], 2 * torch.arange(6, dtype=torch.float32))
+    assert torch.equal(s1["back"][:, 0], 2 * (torch.arange(6, dtype=torch.float32) + 10))
+
+
+def _w_exchange(rank, world, port, out):
+    _init(rank, world, port)
+    from cet_pick_amd import hipops as H
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 2), torch.nn.Linear(2, 2))
+    ex = H.GradExchange(net, n_buckets=3)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(float(rank))                      # replicas differ until broadcast
+    ex.broadcast_parameters(0)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(20 + rank)
+    x = torch.randn(4, 5, generator=g)
+    opt.zero_grad()
+    net[:3](x).pow(2).mean().backward()              # the last Linear gets no gradient: zeros, not stale memory
+    ex.sync()
+    grads = [p.grad.clone() for p in net.parameters()]
+    opt.step()
+    torch.save({"w": ex.arena.flat.clone(), "g": grads, "x": x}, os.path.join(out, "e%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_grad_exchange_averages_flat_arena_gloo_cpu(tmp_path):
+    """hipops.GradExchange (main.py:34-56's DistributedDataParallel replaced by a flat arena + bucketed all-reduce)."""
+    port = _free_port()
+    mp.spawn(_w_exchange, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    e0, e1 = torch.load(str(tmp_path / "e0.pt")), torch.load(str(tmp_path / "e1.pt"))
+    assert torch.equal(e0["w"], e1["w"])                                  # identical replicas after the step
+    for a, b in zip(e0["g"], e1["g"]):
+        assert torch.equal(a, b)
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 2), torch.nn.Linear(2, 2))
+    tot = [torch.zeros_like(p) for p in net.parameters()]
+    for e in (e0, e1):
+        net.zero_grad()
+        net[:3](e["x"]).pow(2).mean().backward()
+        for t, p in zip(tot, net.parameters()):
+            if p.grad is not None:
+                t += p.grad / 2
+    for t, gavg in zip(tot, e0["g"]):
+        np.testing.assert_allclose(gavg.numpy(), t.numpy(), rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------- GPU: trainers under DP
+def _simsiam_setup():
+    from types import SimpleNamespace
+    from cet_pick_amd.models.model import create_model
+    from cet_pick_amd.synthetic import seeded_state_dict
+    net = create_model("simsiam2d_18", {"proj": 128, "pred": 128}, 128)
+    net.load_state_dict(seeded_state_dict(net, seed=318))
+    opt = SimpleNamespace(task="simsiam3d", num_iters=-1, print_iter=0, hide_data_time=True, exp_id="t", lr=0.05, hipgraph=False)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(8, 1, 36, 36, generator=g)
+    return net, opt, x, x.flip(-1) + 0.1 * torch.randn(8, 1, 36, 36, generator=g)
+
+
+def _w_simsiam(rank, world, port, out):
+    _init(rank, world, port)
+    torch.cuda.set_device(0)
+    from cet_pick_amd import hipops as H
+    from cet_pick_amd.trains.train_factory import train_factory
+    net, opt, x, xa = _simsiam_setup()
+    H.convert_sync_batchnorm(net)
+    tr = train_factory["simsiam3d"](opt, net, torch.optim.SGD(net.parameters(), lr=opt.lr))
+    tr.set_distributed_device(0)
+    assert tr.exchange is not None
+    sl = slice(4 * rank, 4 * rank + 4)
+    ret, _ = tr.train(1, [{"input": x[sl], "input_aug": xa[sl]}])
+    torch.cuda.synchronize()
+    torch.save({"w": tr.exchange.arena.flat.cpu(), "loss": ret["loss"]}, os.path.join(out, "m%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_simsiam_trainer_two_ranks_equal_full_batch(tmp_path):
+    """simsiam_main.py under torch.distributed: SyncBN + averaged gradients of two half batches == one process on the
+    whole batch (the SimSiam loss is a batch mean)."""
+    from cet_pick_amd import hipops as H
+    from cet_pick_amd.trains.train_factory import train_factory
+    port = _free_port()
+    mp.spawn(_w_simsiam, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    m0, m1 = torch.load(str(tmp_path / "m0.pt")), torch.load(str(tmp_path / "m1.pt"))
+    assert torch.equal(m0["w"], m1["w"])
+    net, opt, x, xa = _simsiam_setup()
+    w_init = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    tr = train_factory["simsiam3d"](opt, net, torch.optim.SGD(net.parameters(), lr=opt.lr))
+    tr.set_device([0], None, "cuda")
+    ret, _ = tr.train(1, [{"input": x, "input_aug": xa}])
+    arena = H.ParamArena(net)                               # same flat order as the ranks' arenas
+    want = arena.flat.cpu()
+    assert abs(0.5 * (m0["loss"] + m1["loss"]) - ret["loss"]) < 1e-4
+    step = float((want - m0["w"]).norm()) / (float((want - 0).norm()) + 1e-12)
+    assert step < 1e-5, step
+    assert want.numel() == m0["w"].numel() and w_init.numel() > 0
+
+
+def _det_setup(seed_batch):
+    from types import SimpleNamespace
+    from cet_pick_amd.models.model import create_model
+    from cet_pick_amd.synthetic import seeded_state_dict
+    heads = {"hm": 1, "proj": 32}
+    opt = SimpleNamespace(task="semi", arch="unet_4", pn=False, ge=False, tau=0.1, temp=0.07, thresh=0.5, cr_weight=0.1,
+                          num_stacks=1, contrastive=True, device=torch.device("cuda"), num_iters=-1, print_iter=0,
+                          hide_data_time=True, exp_id="t", lr=1e-3, hipgraph=False)
+    model = create_model(opt.arch, heads, 32)
+    sd0 = seeded_state_dict(model, seed=323)
+    for k in ("hm.weight", "proj.weight"):
+        sd0[k] = sd0[k] * 0.3
+    model.load_state_dict(sd0)
+    g = torch.Generator().manual_seed(seed_batch)
+    b, d, h, w = 2, 4, 48, 48
+    x = torch.randn(b, d, h, w, generator=g)
+    gt = torch.full((b, 1, d, h // 2, w // 2), -1.0)
+    r = torch.rand(gt.shape, generator=g)
+    gt[r < 0.3] = 0.0
+    gt[r > 0.96] = 1.0
+    batch = {"input": x, "input_aug": x.flip(-1) + 0.05 * torch.randn(b, d, h, w, generator=g), "hm": gt, "flip_prob": 0.2, "meta": {}}
+    return model, opt, batch
+
+
+def _w_det(rank, world, port, out, same):
+    _init(rank, world, port)
+    torch.cuda.set_device(0)
+    from cet_pick_amd import hipops as H
+    from cet_pick_amd.trains.train_factory import train_factory
+    model, opt, batch = _det_setup(2 if same else 2 + rank)
+    H.convert_sync_batchnorm(model)
+    tr = train_factory["semi"](opt, model, torch.optim.SGD(model.parameters(), lr=opt.lr))
+    tr.set_distributed_device(0)
+    ret, _ = tr.train(1, [dict(batch)])
+    torch.cuda.synchronize()
+    torch.save({"w": tr.exchange.arena.flat.cpu(), "loss": ret["loss"], "calls": tr.exchange.calls},
+               os.path.join(out, "d%d_%d.pt" % (int(same), rank)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_detector_trainer_data_parallel(tmp_path):
+    """main.py:34-56 (BASELINE config 5) through TomoCRSemiTrainer: (1) two ranks fed the SAME crop pairs - SyncBN over
+    two identical halves has the statistics of one, the averaged gradient is the gradient - land on the single-process
+    step; (2) two ranks with different crop pairs exchange and stay identical replicas."""
+    from cet_pick_amd import hipops as H
+    from cet_pick_amd.trains.train_factory import train_factory
+    for same in (True, False):
+        mp.spawn(_w_det, args=(2, _free_port(), str(tmp_path), same), nprocs=2, join=True)
+    s0, s1 = torch.load(str(tmp_path / "d1_0.pt")), torch.load(str(tmp_path / "d1_1.pt"))
+    d0, d1 = torch.load(str(tmp_path / "d0_0.pt")), torch.load(str(tmp_path / "d0_1.pt"))
+    assert s0["calls"] == 1 and torch.equal(s0["w"], s1["w"]) and torch.equal(d0["w"], d1["w"])
+    assert d0["loss"] != d1["loss"]                                       # different data per rank
+    model, opt, batch = _det_setup(2)
+    tr = train_factory["semi"](opt, model, torch.optim.SGD(model.parameters(), lr=opt.lr))
+    tr.set_device([0], None, "cuda")
+    w0 = H.ParamArena(model)                                              # flat order of the ranks' arenas
+    start = w0.flat.clone()
+    ret, _ = tr.train(1, [dict(batch)])
+    want = w0.flat.cpu()
+    upd = float((want - start.cpu()).norm())
+    assert upd > 0
+    assert float((s0["w"] - want).norm()) <= 2e-3 * upd, (float((s0["w"] - want).norm()), upd)
+    assert abs(s0["loss"] - ret["loss"]) <= 1e-4 * abs(ret["loss"])
+    assert float((d0["w"] - want).norm()) > 1e-2 * upd                     # other data: another step
