@@ -31,3 +31,16 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     return load
+
+
+def f32_equivalent(got, cpu32, ref64, factor=2.0, floor=2e-6, what=""):
+    """fp64-arbitrated equivalence, in place of a widened tolerance: the GPU result may sit as far
+    from the float64 evaluation of the same arithmetic as `factor` x the CPU fp32 evaluation does (both as norm-relative
+    errors), + `floor` for results that are rounding noise on both sides.  Returns (err_gpu, err_cpu32)."""
+    g = np.asarray(got, np.float64).ravel()
+    c = np.asarray(cpu32, np.float64).ravel()
+    r = np.asarray(ref64, np.float64).ravel()
+    scale = float(np.linalg.norm(r)) + 1e-30
+    e_g, e_c = float(np.linalg.norm(g - r)) / scale, float(np.linalg.norm(c - r)) / scale
+    assert e_g <= factor * e_c + floor, "%s: GPU %.3e from float64, CPU fp32 %.3e" % (what, e_g, e_c)
+    return e_g, e_c

@@ -43,6 +43,40 @@ def test_conv2d_fwd_dgrad_wgrad(case):
     np.testing.assert_allclose(param.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol=2e-5 * sc)
 
 
+def _oracle_grads(forward, sd0, inputs, dt):
+    """Gradients of the SimSiam loss by the CPU oracle (oracle/train_ref.py) evaluated in dtype `dt`."""
+    from oracle import train_ref as T
+    sd = {k: (v.to(dt) if v.is_floating_point() else v.clone()).clone() for k, v in sd0.items()}
+    names = [k for k in sd if k.endswith((".weight", ".bias"))]
+    for n in names:
+        sd[n].requires_grad_(True)
+    p1, z1, p2, z2 = forward(sd, *[x.to(dt) for x in inputs], True)
+    loss, _ = T.simsiam_loss(p1, z1, p2, z2)
+    return dict(zip(names, torch.autograd.grad(loss, [sd[n] for n in names], allow_unused=True)))
+
+
+def _arbitrated_grads(net, forward, sd0, inputs, g, norm_key="grad_%s_norm"):
+    """Every parameter gradient of `net` against the oracle in float64, arbitrated by the oracle in fp32 (the GPU may sit as
+    far from float64 as twice the CPU fp32 evaluation), and its norm against the reference's golden norm within the two
+    measured fp32 errors.  Returns the worst GPU error."""
+    from conftest import f32_equivalent
+    g32 = _oracle_grads(forward, sd0, inputs, torch.float32)
+    g64 = _oracle_grads(forward, sd0, inputs, torch.float64)
+    gscale = max(float(v.norm()) for v in g64.values() if v is not None)
+    worst = 0.0
+    for n, p in net.named_parameters():
+        if g64.get(n) is None:
+            continue
+        gf = p.grad.detach().cpu().contiguous()
+        floor = 2e-5 * gscale / (float(g64[n].norm()) + 1e-30) + 2e-6
+        e_g, e_c = f32_equivalent(gf.numpy(), g32[n].numpy(), g64[n].numpy(), floor=floor, what=n)
+        worst = max(worst, e_g)
+        ref = float(g[norm_key % n])                       # the reference's own fp32 run
+        got = float(np.linalg.norm(gf.reshape(-1).numpy().astype(np.float64)))
+        assert abs(got - ref) <= (e_g + e_c + floor + 1e-3) * ref + 2e-6, (n, got, ref)
+    return worst
+
+
 def _seeded_net():
     from cet_pick_amd.models.model import create_model
     from cet_pick_amd.synthetic import seeded_state_dict
@@ -70,16 +104,17 @@ def test_simsiam2d_matches_reference_golden(golden):
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4
     assert abs(float(stats["output_std"]) - float(g["output_std"])) < 1e-5
     loss.backward()
+    # gradients: fp32 entries of the REFERENCE run are themselves far from a float64 evaluation (BatchNorm backward cancels
+    # large terms in every block), so they are arbitrated by the oracle in float64 instead of held to a widened tolerance
+    from oracle import train_ref as T
+    from cet_pick_amd.synthetic import seeded_state_dict
+    sd0 = seeded_state_dict(net, seed=318)
+    _arbitrated_grads(net, T.simsiam_forward, sd0, (x1, x2), g)
     idx = g["sample_idx"]
-    for n, p in net.named_parameters():
-        gf = p.grad.detach().cpu().contiguous().reshape(-1).numpy()
-        ref = float(g[f"grad_{n}_norm"])
-        assert abs(np.linalg.norm(gf.astype(np.float64)) - ref) <= 3e-3 * ref + 2e-6, n
-        rs = g[f"grad_{n}_sample"]
-        # single entries of the fp32 REFERENCE gradient are themselves ~1e-2 (of the tensor's scale)
-        # away from an fp64 evaluation (BatchNorm backward cancels large terms in every block), so
-        # entries are held to 2e-2 of the scale while the norms above are held to 3e-3
-        np.testing.assert_allclose(gf[idx % gf.size], rs, rtol=0, atol=2e-2 * float(np.abs(rs).max()) + 2e-6, err_msg=n)
+    g32 = _oracle_grads(T.simsiam_forward, sd0, (x1, x2), torch.float32)
+    for n, p in net.named_parameters():                      # the oracle's fp32 samples ARE the reference's (CPU test)
+        np.testing.assert_allclose(g32[n].reshape(-1).numpy()[idx % g32[n].numel()], g[f"grad_{n}_sample"], rtol=0,
+                                   atol=2e-3 * float(np.abs(g[f"grad_{n}_sample"]).max()) + 2e-6, err_msg=n)
     np.testing.assert_allclose(net.bn1.running_var.cpu().numpy(), g["bn1_running_var"], rtol=1e-4, atol=1e-5)
     assert int(net.bn1.num_batches_tracked) == int(g["nbt"])          # two views -> two updates
     net2 = _seeded_net()
@@ -146,13 +181,9 @@ def test_simsiam_slicewise_encoder_matches_reference_golden(golden):
     loss, _ = TomoSimSiamLoss(None)(out, None, 0)
     assert abs(float(loss.detach()) - float(g["loss"])) < 2e-4
     loss.backward()
-    idx = g["sample_idx"]
-    for n, p in net.named_parameters():
-        gf = p.grad.detach().cpu().contiguous().reshape(-1).numpy()
-        ref = float(g[f"grad_{n}_norm"])
-        assert abs(np.linalg.norm(gf.astype(np.float64)) - ref) <= 1e-2 * ref + 2e-6, (n, ref)
-        rs = g[f"grad_{n}_sample"]
-        np.testing.assert_allclose(gf[idx % gf.size], rs, rtol=0, atol=3e-2 * float(np.abs(rs).max()) + 2e-6, err_msg=n)
+    from oracle import train_ref as T
+    from cet_pick_amd.synthetic import seeded_state_dict
+    _arbitrated_grads(net, T.simsiam_slice_forward, seeded_state_dict(net, seed=319), (x1, x2), g)
     np.testing.assert_allclose(net.feature_3d[1].running_var.cpu().numpy(), g["feature_3d_running_var"], rtol=1e-3, atol=1e-5)
     net2 = make().eval()
     with torch.no_grad():
@@ -178,10 +209,8 @@ def test_simsiam2d3d_encoder_matches_reference_golden(golden):
     loss, _ = TomoSimSiamLoss(None)(out, None, 0)
     assert abs(float(loss.detach()) - float(g["loss"])) < 2e-4
     loss.backward()
-    for n, p in net.named_parameters():
-        ref = float(g[f"grad_{n}_norm"])
-        got = float(np.linalg.norm(p.grad.detach().cpu().contiguous().reshape(-1).numpy().astype(np.float64)))
-        assert abs(got - ref) <= 1e-2 * ref + 2e-6, (n, got, ref)
+    from oracle import train_ref as T
+    _arbitrated_grads(net, T.simsiam2d3d_forward, seeded_state_dict(net, seed=320), tuple(x.cpu() for x in xs), g)
     net.eval()
     with torch.no_grad():
         ft = net.forward_test(xs[0], xs[1])

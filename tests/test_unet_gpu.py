@@ -175,6 +175,12 @@ def test_unet_training_forward_backward_vs_oracle():
     ref = O.tomo_conv_unet_forward(ref_sd, x, 4, HEADS, training=True)
     r1, r2 = torch.randn(ref["hm"].shape, generator=g), torch.randn(ref["proj"].shape, generator=g)
     ((ref["hm"] * r1).sum() + (ref["proj"] * r2).sum()).backward()
+    # the same in float64: arbiter of the gradient comparison
+    ref_sd64 = {k: (v.double() if v.is_floating_point() else v.clone()).clone().requires_grad_(
+        v.is_floating_point() and not k.endswith(("running_mean", "running_var"))) for k, v in sd0.items()}
+    ref64 = O.tomo_conv_unet_forward(ref_sd64, x.double(), 4, HEADS, training=True)
+    ((ref64["hm"] * r1.double()).sum() + (ref64["proj"] * r2.double()).sum()).backward()
+    from conftest import f32_equivalent
     out = net(x.cuda())[0]
     ((out["hm"] * r1.cuda()).sum() + (out["proj"] * r2.cuda()).sum()).backward()
     for h in HEADS:
@@ -190,11 +196,10 @@ def test_unet_training_forward_backward_vs_oracle():
             wn = float(ref_sd[name.replace("bias", "weight")].grad.norm())
             assert float(a.norm()) < 1e-4 * wn and float(b.norm()) < 1e-4 * wn, name
             continue
-        err = (a - b).norm() / (b.norm() + 1e-12)
-        worst = max(worst, float(err))
         # deepest gradients (conv1, first blocks) accumulate fp32 rounding through ~25 layers with batch-statistics
-        # BatchNorm; torch's own fp32 result moves by this much against fp64
-        assert err < 1e-2, (name, float(err), float(b.norm()))
+        # BatchNorm: the GPU may sit as far from the float64 gradient as twice torch's own fp32 gradient does
+        e_g, e_c = f32_equivalent(a.numpy(), b.numpy(), ref_sd64[name].grad.numpy(), floor=1e-5, what=name)
+        worst = max(worst, e_g)
     # running statistics follow nn.BatchNorm2d's update
     np.testing.assert_allclose(net.bn1.running_var.cpu().numpy(), ref_sd["bn1.running_var"].numpy(), rtol=1e-4)
     assert int(net.bn1.num_batches_tracked) == 1
