@@ -269,6 +269,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-conv-profile", action="store_true", help="skip the per-launch roofline pass (clean rocprofv3 runs of the step)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
@@ -321,11 +322,10 @@ def main():
         H.FORCE_COLLECTIVES = True
     if dist_active:
         H.convert_sync_batchnorm(moco)
-        for p in moco.parameters():                 # identical replicas
-            dist.broadcast(p.data, 0)
-        dist.broadcast(moco.queue, 0)
     moco.train()
     engine = MocoStepEngine(moco, lr=1e-3, use_graph=not args.no_graph)
+    if dist_active:
+        engine.broadcast_state(0)                   # identical replicas (parameter arenas, buffers, queue)
 
     # synthetic tomogram for this rank (seed 317 + rank), crops resident in HBM
     vol, _ = make_tomo((128, 512, 512), seed=317 + rank)
@@ -372,6 +372,18 @@ def main():
 
     out = None
     # the roofline pass runs three more steps: EVERY rank takes them (they contain the step's collectives)
+    step_nodes = engine.node_counts() if engine.use_graph else None
+    if args.no_conv_profile:
+        if rank == 0:
+            print(json.dumps({"metric": "subtomograms/sec (MoCo-3D train) + voxels/sec (heatmap+NMS) at 1/2/4/8 GPU",
+                              "value": B * world * args.steps / dt, "unit": "subtomograms/sec", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                              "step_graph_nodes": step_nodes, "note": "--no-conv-profile: no roofline pass"}), flush=True)
+        if dist_active:
+            dist.barrier()
+            engine.close()
+            dist.destroy_process_group()
+        return
     flop, ms, n_launch, by = conv_profile(engine, pq, pk, B, 3)
     arith = "f32" if os.environ.get("MI_CONV_ARITH", "")[:1] == "f" else "bf16x3"
     # the same step on the f32 MFMA instruction (fresh graph capture; N = 1 only: a reported comparison, not `value`)
@@ -406,6 +418,7 @@ def main():
                                            "(f32-equivalent; MI_CONV_ARITH=f32 for the f32 MFMA)" if arith == "bf16x3"
                                            else "v_mfma_f32_32x32x2_f32"),
                        "hipgraph": bool(engine.use_graph), "final_loss": final_loss},
+            "step_graph_nodes": step_nodes,
             "step_mfma_frac_of_peak": value / world * FLOP_PER_SUBTOMO / 1e12 / peak,
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel + stem_fwd/stem_wgrad_kernel (fwd/dgrad/wgrad, all 75 conv launches of a step)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -17,6 +17,7 @@ _P, _I, _F, _Z, _D, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_do
 # name -> (restype, argtypes); kept in step with include/cetpick_hip.h (tests/test_abi.py checks)
 SIGNATURES = {
     "mi_abi_version": (_I, []),
+    "mi_graph_node_counts": (_I, [_P, _P]),
     "mi_build_arch": (_c.c_char_p, []),
     "mi_sigmoid_clamp": (_I, [_P, _P, _Z, _P]),
     "mi_nms3d": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
@@ -94,6 +95,8 @@ SIGNATURES = {
     "mi_rowdot_mean_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "mi_column_std_mean": (_I, [_P, _P, _I, _I, _P]),
     "mi_ce_label0": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "mi_ce_label0_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "mi_ce_label0_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "mi_ema_update": (_I, [_P, _P, _F, _L, _P]),
     "mi_sgd_step": (_I, [_P, _P, _P, _F, _F, _L, _P]),
     "mi_queue_enqueue": (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -104,14 +104,17 @@ __global__ __launch_bounds__(256) void colreduce_kernel(ColReduceParams p) {
 
 // 8 columns per workgroup, 32 lanes per column: fixed-shape tree -> deterministic
 __global__ __launch_bounds__(256) void colreduce_finalize_kernel(const double* partials, int n_part,
-                                                                int C, double* sums) {
+                                                                int C, double* sums, float* sums_f32, int n_f32) {
     const int c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
     double s = 0;
     if (c < 2 * C)
         for (int b = l; b < n_part; b += 32) s += partials[(long)b * 2 * C + c];
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
-    if (l == 0 && c < 2 * C) sums[c] = s;
+    if (l == 0 && c < 2 * C) {
+        sums[c] = s;
+        if (sums_f32 && c < n_f32) sums_f32[c] = (float)s;       // (the column sums of a bias gradient leave as fp32 here)
+    }
 }
 
 int colreduce_blocks(long M, int C) {
@@ -122,7 +125,8 @@ int colreduce_blocks(long M, int C) {
 bool colreduce_ok(int C) { return C >= 4 && (C % 4) == 0 && (C / 4) <= 256 && (256 % (C / 4)) == 0; }
 
 template <int MODE>
-int run_colreduce(ColReduceParams p, double* sums, void* ws, size_t ws_bytes, hipStream_t s) {
+int run_colreduce(ColReduceParams p, double* sums, void* ws, size_t ws_bytes, hipStream_t s, float* sums_f32 = nullptr,
+                  int n_f32 = 0) {
     if (!colreduce_ok(p.C) || p.M <= 0) return MI_E_ARG;
     int blocks = colreduce_blocks(p.M, p.C);
     if (!ws || ws_bytes < sizeof(double) * 2 * p.C * (size_t)blocks) return MI_E_WORKSPACE;
@@ -130,7 +134,7 @@ int run_colreduce(ColReduceParams p, double* sums, void* ws, size_t ws_bytes, hi
     hipLaunchKernelGGL((colreduce_kernel<MODE>), dim3(blocks), dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((2 * p.C + 7) / 8), dim3(256), 0, s,
-                       (const double*)ws, blocks, p.C, sums);
+                       (const double*)ws, blocks, p.C, sums, sums_f32, n_f32);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -808,6 +812,39 @@ __global__ __launch_bounds__(256) void ce0_kernel(const float* logits, float* ro
         }
     }
 }
+// Small batches (B <= 256 rows): ONE workgroup of 16 waves, a wave per row at a time; the mean over the rows is taken in
+// the same launch (fixed order).  lse[b] is kept for the backward kernel.
+__global__ __launch_bounds__(1024) void ce0_small_kernel(const float* logits, float* loss, float* loss_copy, float* row_lse,
+                                                        int B, int n) {
+    __shared__ float s_row[256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int b = wv; b < B; b += 16) {
+        const float* l = logits + (long)b * n;
+        float m = -INFINITY;
+        for (int j = lane; j < n; j += 64) m = fmaxf(m, l[j]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int j = lane; j < n; j += 64) s += expf(l[j] - m);
+        s = wave_sum(s);
+        const float lse = m + logf(s);
+        if (lane == 0) { s_row[b] = lse - l[0]; row_lse[b] = lse; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) t += s_row[b];
+        *loss = t / (float)B;
+        if (loss_copy) *loss_copy = t / (float)B;
+    }
+}
+// dlogits = g * (softmax - onehot0) / B with the upstream gradient g read on the device
+__global__ __launch_bounds__(256) void ce0_bwd_kernel(const float* logits, const float* row_lse, const float* g_dev,
+                                                     float* dlogits, int B, int n) {
+    const int b = blockIdx.x;
+    const float g = (*g_dev) / (float)B, lse = row_lse[b];
+    const float* l = logits + (long)b * n;
+    for (int j = threadIdx.x; j < n; j += 256) dlogits[(long)b * n + j] = g * (expf(l[j] - lse) - (j == 0 ? 1.f : 0.f));
+}
 __global__ void mean_kernel(const float* v, int n, float* out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         float s = 0.f;
@@ -856,6 +893,17 @@ __global__ void enqueue_kernel(float* queue, long long* ptr, const float* keys, 
     }
 }
 __global__ void advance_ptr_kernel(long long* ptr, int B, int R) { *ptr = (*ptr + B) % R; }
+// the same in one launch for the usual key batches (B * C <= 64 Ki elements): one workgroup copies, then moves the pointer
+__global__ __launch_bounds__(1024) void enqueue_small_kernel(float* queue, long long* ptr, const float* keys, int B, int C, int R) {
+    const long long p0 = *ptr;
+    for (int i = threadIdx.x; i < B * C; i += 1024) {
+        int b = i % B, c = i / B;
+        long long col = p0 + b;
+        if (col < R) queue[(long)c * R + col] = keys[(long)b * C + c];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *ptr = (p0 + B) % R;
+}
 
 int ew_blocks(long n) { return (int)std::max<long>(1, std::min<long>((n + 255) / 256, 2048)); }
 
@@ -1017,12 +1065,7 @@ extern "C" int mi_colsum(const float* dy, long M, int C, float* out, double* sum
     if (!dy || !out || !sums_scratch) return MI_E_ARG;
     ColReduceParams p = {};
     p.a = dy; p.M = M; p.C = C;
-    int rc = run_colreduce<CR_SUM>(p, sums_scratch, ws, ws_bytes, (hipStream_t)stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(cast_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       (const double*)sums_scratch, C, out);
-    MI_RETURN_IF_LAUNCH_FAILED();
-    return MI_OK;
+    return run_colreduce<CR_SUM>(p, sums_scratch, ws, ws_bytes, (hipStream_t)stream, out, C);
 }
 
 extern "C" int mi_maxpool3d_fwd(const float* x, float* y, uint8_t* argmax, int N, int Di, int Hi,
@@ -1149,6 +1192,21 @@ extern "C" int mi_ce_label0(const float* logits, float* loss, float* row_loss, f
     return MI_OK;
 }
 
+extern "C" int mi_ce_label0_fwd(const float* logits, float* loss, float* loss_copy, float* row_lse, int B, int n,
+                                mi_stream_t stream) {
+    if (!logits || !loss || !row_lse || B <= 0 || B > 256 || n <= 0) return MI_E_ARG;
+    hipLaunchKernelGGL(ce0_small_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, loss, loss_copy, row_lse, B, n);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+extern "C" int mi_ce_label0_bwd(const float* logits, const float* row_lse, const float* grad_loss, float* dlogits, int B,
+                                int n, mi_stream_t stream) {
+    if (!logits || !row_lse || !grad_loss || !dlogits || B <= 0 || n <= 0) return MI_E_ARG;
+    hipLaunchKernelGGL(ce0_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, row_lse, grad_loss, dlogits, B, n);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
 extern "C" int mi_ema_update(float* k, const float* q, float m, long n, mi_stream_t stream) {
     if (!k || !q || n <= 0 || ((uintptr_t)k & 15) || ((uintptr_t)q & 15)) return MI_E_ARG;
     hipLaunchKernelGGL(ema_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, k, q, m, n);
@@ -1168,6 +1226,11 @@ extern "C" int mi_queue_enqueue(float* queue, int64_t* queue_ptr, const float* k
                                 mi_stream_t stream) {
     if (!queue || !queue_ptr || !keys || B <= 0 || C <= 0 || R <= 0 || (R % B)) return MI_E_ARG;  // moco.py:47
     hipStream_t s = (hipStream_t)stream;
+    if ((long)B * C <= 65536) {
+        hipLaunchKernelGGL(enqueue_small_kernel, dim3(1), dim3(1024), 0, s, queue, (long long*)queue_ptr, keys, B, C, R);
+        MI_RETURN_IF_LAUNCH_FAILED();
+        return MI_OK;
+    }
     hipLaunchKernelGGL(enqueue_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, queue, (long long*)queue_ptr, keys, B, C, R);
     MI_RETURN_IF_LAUNCH_FAILED();
     hipLaunchKernelGGL(advance_ptr_kernel, dim3(1), dim3(1), 0, s, (long long*)queue_ptr, B, R);

@@ -459,6 +459,24 @@ def _dist_world():
 FORCE_COLLECTIVES = False     # tests: issue every collective on a 1-rank group too (one-GPU rehearsal of the N>1 path)
 
 
+# Collectives under hipGraph capture are issued SYNCHRONOUSLY (async_op=False), always.  A collective issued with
+# async_op=True while its stream is being captured ends up polled by the process group's watchdog thread, whose
+# hipEventQuery on the Work's end event - last recorded in a capturing stream - raises hipErrorCapturedEvent and
+# terminates the process ("operation not permitted on an event last recorded in a capturing stream"; measured with
+# tools/diag_watchdog.sh: 4 of 4 captured runs die with async works, 0 of 4 without).  That was the intermittent abort of
+# the N > 1 captured step that round 1 hid behind os._exit: the engine's four bucket all-reduces were async.  Overlap
+# with the backward pass comes from issuing the (synchronous) collective on a side stream instead - see
+# MocoStepEngine._reduce_bucket.
+def dist_all_reduce(tensor):
+    import torch.distributed as dist
+    dist.all_reduce(tensor)
+
+
+def dist_all_gather(tensor_list, tensor):
+    import torch.distributed as dist
+    dist.all_gather(tensor_list, tensor)
+
+
 def _distributed():
     """True when the data-parallel exchanges (SyncBN sums, key all-gather, gradient all-reduce) have to be issued."""
     import torch.distributed as dist
@@ -501,7 +519,7 @@ class _BNFn(torch.autograd.Function):
             count = float(m)
             if mod.sync and _distributed():
                 import torch.distributed as dist
-                dist.all_reduce(sums)                     # RCCL: 2*C doubles
+                dist_all_reduce(sums)                     # RCCL: 2*C doubles
                 count = float(m) * _dist_world()
             track = mod.track_running_stats and mod.training
             L.check(lib.mi_bn_apply_fwd(L.ptr(x), L.ptr(y), m, c, L.ptr(sums), count, L.ptr(gamma), L.ptr(beta),
@@ -574,7 +592,7 @@ class _BNFn(torch.autograd.Function):
                 # data-parallel gradient averaging then treats them like every other parameter
                 L.check(lib.mi_bn_param_grads(L.ptr(sums), c, L.ptr(dg), L.ptr(db), L.stream()), "mi_bn_param_grads")
             import torch.distributed as dist
-            dist.all_reduce(sums)                      # dx needs the global sums
+            dist_all_reduce(sums)                      # dx needs the global sums
         dx = torch.empty_like(x)
         # single process: the same launch writes dgamma / dbeta from the sums
         L.check(lib.mi_bn_bwd_apply(L.ptr(dy), L.ptr(x), L.ptr(y), L.ptr(dx), m, c, L.ptr(save), L.ptr(gamma),
@@ -610,7 +628,7 @@ class _BNReluPoolFn(torch.autograd.Function):
             L.check(lib.mi_bn_stats(L.ptr(x), m, c, L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()), "mi_bn_stats")
             if mod.sync and _distributed():
                 import torch.distributed as dist
-                dist.all_reduce(sums)
+                dist_all_reduce(sums)
                 count = float(m) * _dist_world()
         track = mod.track_running_stats and mod.training
         use_running = not train
@@ -656,7 +674,7 @@ class _BNReluPoolFn(torch.autograd.Function):
             if dg is not None:           # affine gradients from the LOCAL sums, like torch.nn.SyncBatchNorm
                 L.check(lib.mi_bn_param_grads(L.ptr(sums), c, L.ptr(dg), L.ptr(db), L.stream()), "mi_bn_param_grads")
             import torch.distributed as dist
-            dist.all_reduce(sums)
+            dist_all_reduce(sums)
         dx = dy                                            # in place: each element is read, then written, by one thread
         L.check(lib.mi_bn_relu_bwd_apply_x(L.ptr(dy), L.ptr(x), L.ptr(dx), m, c, L.ptr(save), L.ptr(gamma), L.ptr(beta),
                                            L.ptr(sums), ctx.count, L.ptr(None if distributed else dg),
@@ -864,26 +882,46 @@ def moco_logits(q, k, queue, T):
 
 
 class _CELabel0Fn(torch.autograd.Function):
+    """Small batches (<= 256 rows, every MoCo configuration here): forward = one launch that also drops the mean loss into
+    `out` (the engine's loss buffer: no copy afterwards), backward = one launch that reads the upstream gradient on the
+    device.  Larger batches: the per-row kernel + mean, gradient scaled on the way back."""
+
     @staticmethod
-    def forward(ctx, logits):
+    def forward(ctx, logits, out):
         b, n = logits.shape
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
         row = torch.empty(b, dtype=torch.float32, device=logits.device)
-        dl = torch.empty_like(logits)
-        L.check(L.lib().mi_ce_label0(L.ptr(logits), L.ptr(loss), L.ptr(row), L.ptr(dl), b, n, 1.0, L.stream()),
-                "mi_ce_label0")
-        ctx.save_for_backward(dl)
+        ctx.small = b <= 256
+        if ctx.small:
+            L.check(L.lib().mi_ce_label0_fwd(L.ptr(logits), L.ptr(loss), L.ptr(out), L.ptr(row), b, n, L.stream()),
+                    "mi_ce_label0_fwd")
+            ctx.save_for_backward(logits, row)
+        else:
+            dl = torch.empty_like(logits)
+            L.check(L.lib().mi_ce_label0(L.ptr(logits), L.ptr(loss), L.ptr(row), L.ptr(dl), b, n, 1.0, L.stream()),
+                    "mi_ce_label0")
+            ctx.save_for_backward(dl)
+            if out is not None:
+                out.copy_(loss)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        (dl,) = ctx.saved_tensors
-        return dl * g
+        if not ctx.small:
+            (dl,) = ctx.saved_tensors
+            return dl * g, None
+        logits, row = ctx.saved_tensors
+        b, n = logits.shape
+        dl = torch.empty_like(logits)
+        L.check(L.lib().mi_ce_label0_bwd(L.ptr(logits), L.ptr(row), L.ptr(g.contiguous()), L.ptr(dl), b, n, L.stream()),
+                "mi_ce_label0_bwd")
+        return dl, None
 
 
-def cross_entropy_label0(logits):
-    """nn.CrossEntropyLoss()(logits, zeros) (trains/tomo_moco_trainer.py:52,73)."""
-    return _CELabel0Fn.apply(_f32c(logits, "logits"))
+def cross_entropy_label0(logits, out=None):
+    """nn.CrossEntropyLoss()(logits, zeros) (trains/tomo_moco_trainer.py:52,73).  `out`: a 0-d fp32 device tensor that
+    receives the loss (and is returned)."""
+    return _CELabel0Fn.apply(_f32c(logits, "logits"), out)
 
 
 class _RowDotMeanFn(torch.autograd.Function):

@@ -59,9 +59,7 @@ def main(opt):
     trainer = train_factory[opt.task](opt, model, optimizer)
     if opt.distributed:
         trainer.set_distributed_device(opt.gpu)
-        for p in model.parameters():
-            dist.broadcast(p.data, 0)
-        dist.broadcast(model.queue, 0)
+        trainer.engine.broadcast_state(0)
     else:
         trainer.set_device(opt.gpus, opt.chunk_sizes, opt.device)
     loader = SyntheticMocoLoader(batch_size=opt.batch_size, seed=opt.seed, device=opt.device, rank=rank, world=world,

@@ -65,6 +65,14 @@ class MoCo(nn.Module):
     overlap_key_branch = True
     _side = None
 
+    def _zero_labels(self, logits):
+        """labels = zeros(B) (models/moco.py:140-141), allocated once per batch size instead of filled every step"""
+        lab = getattr(self, "_labels", None)
+        if lab is None or lab.shape[0] != logits.shape[0] or lab.device != logits.device:
+            lab = torch.zeros(logits.shape[0], dtype=torch.long, device=logits.device)
+            self._labels = lab
+        return lab
+
     def _key_branch(self, im_k):
         with torch.no_grad():
             self._momentum_update_key_encoder()
@@ -86,7 +94,7 @@ class MoCo(nn.Module):
             q = H.l2_normalize(self.encoder_q(im_q)[0]["proj"])
             k = self._key_branch(im_k)
         logits = H.moco_logits(q, k, self.queue, self.T)
-        labels = torch.zeros(logits.shape[0], dtype=torch.long, device=logits.device)
+        labels = self._zero_labels(logits)
         keys = concat_all_gather(k) if H._distributed() else k
         self._dequeue_and_enqueue(keys)
         return logits, labels
@@ -102,7 +110,7 @@ def concat_all_gather(tensor):
     """models/moco.py:149-162: all_gather (RCCL) + cat along the batch; no gradient."""
     import torch.distributed as dist
     tensors_gather = [torch.empty_like(tensor) for _ in range(dist.get_world_size())]
-    dist.all_gather(tensors_gather, tensor.contiguous(), async_op=False)
+    H.dist_all_gather(tensors_gather, tensor.contiguous())
     return torch.cat(tensors_gather, dim=0)
 
 

@@ -29,6 +29,7 @@ class MocoStepEngine:
         dev = self.arena_q.flat.device
         self.lr_dev = torch.full((1,), self.lr, dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self._loss_buf = self.loss
         d = _dist()
         self.world = d.get_world_size() if d else 1
         self.dist_on = H._distributed()
@@ -38,7 +39,7 @@ class MocoStepEngine:
         self.use_graph = bool(use_graph) and graph_ok
         self._graph = None
         self._static_q = self._static_k = None
-        self._pending = []
+        self._xchg = None                # side stream of the gradient exchange (overlaps the backward pass)
         self.buckets_sent = []           # tags of the last step's exchanges, in issue order (tests / diagnostics)
         if self.dist_on:
             self._setup_buckets()
@@ -58,13 +59,37 @@ class MocoStepEngine:
         enc.grad_marker = self._on_marker
 
     def _reduce_bucket(self, tag):
+        """One bucket of the gradient arena goes out on the exchange stream: forked from the stream the backward pass is
+        on (this runs in an autograd hook, i.e. right behind the last kernel that wrote the bucket), joined again before
+        the optimizer step.  The collective itself is issued synchronously - its internal wait only holds the exchange
+        stream - because an async Work under hipGraph capture kills the process-group watchdog (hipops.dist_all_reduce)."""
         a, b = self._bucket[tag]
-        if b > a:
-            self._pending.append(_dist().all_reduce(self.arena_q.flat_grad[a:b], async_op=True))
+        if b > a and not self.arena_q.flat_grad.is_cuda:        # (CPU tensors over gloo: plumbing tests)
+            H.dist_all_reduce(self.arena_q.flat_grad[a:b])
+            self.buckets_sent.append(tag)
+        elif b > a:
+            cur = torch.cuda.current_stream()
+            if self._xchg is None:
+                self._xchg = torch.cuda.Stream(device=self.arena_q.flat_grad.device)
+            self._xchg.wait_stream(cur)
+            with torch.cuda.stream(self._xchg):
+                H.dist_all_reduce(self.arena_q.flat_grad[a:b])
             self.buckets_sent.append(tag)
 
     def _on_marker(self, tag):
         self._reduce_bucket(tag)
+
+    def broadcast_state(self, src=0):
+        """Identical replicas before the first step (what DistributedDataParallel does at construction): the two flat
+        parameter arenas (the parameters themselves are kernel-layout views, which RCCL refuses as non-contiguous), the
+        buffers and the queue."""
+        d = _dist()
+        if d is None:
+            return
+        d.broadcast(self.arena_q.flat, src)
+        d.broadcast(self.arena_k.flat, src)
+        for b in self.moco.buffers():
+            d.broadcast(b, src)
 
     def set_lr(self, lr):
         """utils/utils.py:58-70 `adjust_learning_rate` target: the schedule reaches a captured graph
@@ -77,18 +102,16 @@ class MocoStepEngine:
         self.buckets_sent = []
         self.arena_q.zero_grad()
         logits, labels = moco(im_q, im_k)
-        loss = H.cross_entropy_label0(logits)
+        loss = H.cross_entropy_label0(logits, out=self._loss_buf)      # lands in the engine's loss buffer: no copy
         loss.backward()
         if self.dist_on:
             # layer3+heads, layer2 and layer1 went out from the autograd hooks while the backward was still running
             # (RCCL over xGMI on its own stream); the stem's gradients are the last to exist
             self._reduce_bucket("stem")
-            for w in self._pending:
-                w.wait()
-            self._pending = []
+            if self._xchg is not None:
+                torch.cuda.current_stream().wait_stream(self._xchg)
             self.arena_q.flat_grad.mul_(1.0 / self.world)
         H.sgd_step_(self.arena_q.flat, self.arena_q.flat_grad, self.lr, self.weight_decay, self.lr_dev)
-        self.loss.copy_(loss.detach())
         return self.loss
 
     def _capture(self, im_q, im_k):
@@ -98,7 +121,7 @@ class MocoStepEngine:
         self._static_q = im_q.clone()
         self._static_k = im_k.clone()
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph(keep_graph=True)      # the hipGraph_t stays queryable (node_counts)
         err = None
         try:
             with torch.cuda.graph(graph):             # records, does not execute
@@ -107,7 +130,6 @@ class MocoStepEngine:
             if not self.dist_on:
                 raise
             err = e
-            self._pending = []
         if self.dist_on:
             # the outcome is agreed on eagerly (outside any capture); a stream or communicator left in an error
             # state by the aborted capture surfaces here instead of being swallowed
@@ -148,11 +170,21 @@ class MocoStepEngine:
         self._graph.replay()
         return self.loss
 
+    def node_counts(self):
+        """{'kernel', 'memcpy', 'memset', 'other'} nodes of the captured step (None while the step runs eagerly)."""
+        if self._graph is None:
+            return None
+        import ctypes
+        from .. import _lib as L
+        counts = (ctypes.c_int * 4)()
+        L.check(L.lib().mi_graph_node_counts(ctypes.c_void_p(self._graph.raw_cuda_graph()), ctypes.cast(counts, ctypes.c_void_p)),
+                "mi_graph_node_counts")
+        return dict(zip(("kernel", "memcpy", "memset", "other"), [int(c) for c in counts]))
+
     def close(self):
         """Release everything that refers to the process group's communicator BEFORE the group is destroyed: the
-        captured hipGraph holds the RCCL kernels (and the events recorded by the async work handles) of its
-        collectives, so it has to go first; then the device is drained.  Call before dist.destroy_process_group()."""
-        self._pending = []
+        captured hipGraph holds the RCCL kernels of its collectives, so it has to go first; then the device is drained.
+        Call before dist.destroy_process_group()."""
         if self._graph is not None:
             torch.cuda.synchronize()
             self._graph.reset()

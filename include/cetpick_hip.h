@@ -36,6 +36,8 @@ typedef void* mi_stream_t; /* hipStream_t */
 
 /* Library identity: returns the ABI version (bumped on any signature change). */
 int mi_abi_version(void);
+/* measurement aid: nodes of a captured hipGraph (hipGraph_t) by type: counts[4] = kernel, memcpy, memset, other */
+int mi_graph_node_counts(void* graph, int* counts);
 /* gfx target the code objects were built for, e.g. "gfx950". */
 const char* mi_build_arch(void);
 
@@ -326,6 +328,13 @@ int mi_column_std_mean(const float* x, float* out, int B, int C, mi_stream_t str
  * loss = mean_b(logsumexp(l_b) - l_b[0]); dlogits = grad_scale*(softmax - onehot0)/B (may be NULL). */
 int mi_ce_label0(const float* logits, float* loss, float* row_loss, float* dlogits, int B, int n,
                  float grad_scale, mi_stream_t stream);
+/* The same loss for B <= 256 rows in ONE launch (row maxima, log-sum-exp and the mean), row_lse[B] kept for the backward
+ * pass; the backward reads the upstream gradient from the device (no host value, no extra scaling launch):
+ * dlogits = grad_loss * (softmax - onehot0) / B. */
+int mi_ce_label0_fwd(const float* logits, float* loss, float* loss_copy /* may be NULL: a second place for the value */,
+                     float* row_lse, int B, int n, mi_stream_t stream);
+int mi_ce_label0_bwd(const float* logits, const float* row_lse, const float* grad_loss, float* dlogits, int B, int n,
+                     mi_stream_t stream);
 
 /* models/moco.py:31-39: k <- m*k + (1-m)*q over a flat parameter arena (16-B aligned). */
 int mi_ema_update(float* k, const float* q, float m, long n, mi_stream_t stream);

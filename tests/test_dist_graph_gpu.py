@@ -56,7 +56,7 @@ def run(mode, port):
         env["CETPICK_DIST_GRAPH"] = "0"
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"repo": REPO}, mode], env=env, capture_output=True, text=True,
                        timeout=300)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode == 0, "stdout tail: " + r.stdout[-600:] + "\nstderr tail: " + r.stderr[-3000:]
     assert "TEARDOWN ok" in r.stdout, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
     import json

@@ -5,7 +5,7 @@ print("value %.1f %s  ms/step %.4f  n_gpus %d steps %d  rccl_ranks %s" % (d["val
 r = d["roofline"]
 print("roofline: achieved %.1f %s  peak %.1f  frac %.4f  kernel_ms/step %.4f  launches/step %s  traffic %s" % (
     r["achieved"], r["unit"], r["peak"], r["frac"], r.get("kernel_ms_per_step", 0), r.get("launches_per_step"), r.get("traffic")))
-for k in ("step_kernel_launches", "f32_mfma_step", "cpu_baseline"):
+for k in ("step_graph_nodes", "f32_mfma_step", "cpu_baseline"):
     if k in d:
         print(k, d[k])
 s = d.get("secondary") or {}
