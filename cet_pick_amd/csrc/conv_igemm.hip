@@ -442,9 +442,6 @@ __global__ __launch_bounds__(NTHREADS, BF3 ? 3 : 1) void conv_igemm_kernel(ConvP
     // constants or the register arrays spill to scratch)
     auto load_part = [&](int kt, bool live, int part, auto SETc) {
         constexpr int SET = decltype(SETc)::value;
-#ifdef MI_DBG_NOGLOAD      // timing experiment: no gathers in the loop (results are garbage)
-        if (kt >= kt0 + 2) return;
-#endif
         if (part == 0) {
             if (MODE == MODE_WGRAD) {
                 // reduction index = output voxel mv = kt*BK + kk (one decode per thread); a voxel behind
@@ -558,10 +555,6 @@ __global__ __launch_bounds__(NTHREADS, BF3 ? 3 : 1) void conv_igemm_kernel(ConvP
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             u0[t] = __float_as_uint(e[t]);
-#ifdef MI_DBG_BF3_NOCVT    // timing experiment: no arithmetic in the cut (results are garbage)
-            u1[t] = u0[t]; u2[t] = u0[t];
-            continue;
-#endif
             const float r1 = e[t] - __uint_as_float(u0[t] & 0xffff0000u);
             u1[t] = __float_as_uint(r1);
             const float r2 = r1 - __uint_as_float(u1[t] & 0xffff0000u);
@@ -581,9 +574,6 @@ __global__ __launch_bounds__(NTHREADS, BF3 ? 3 : 1) void conv_igemm_kernel(ConvP
     };
     auto store_tile = [&](int buf, auto SETc) {
         constexpr int SET = decltype(SETc)::value;
-#ifdef MI_DBG_NOSTORE      // timing experiment: no LDS stores in the loop (results are garbage)
-        if (buf >= 0 && kt1 - kt0 > 2) return;
-#endif
         if constexpr (BF3) {
             unsigned char* const Ab = ldsb + buf * STAGE_B;
             unsigned char* const Bb = Ab + 3 * A_PLANE;
@@ -668,9 +658,6 @@ __global__ __launch_bounds__(NTHREADS, BF3 ? 3 : 1) void conv_igemm_kernel(ConvP
             for (int g = 0; g < NMF3; ++g) {
                 const int ij = g % (MT * NT), pr = (g / (MT * NT)) % 6, s2 = g / (MT * NT * 6);
                 const int i = ij / NT, j = ij % NT;
-#ifdef MI_DBG_BF3_ONEPROD  // timing experiment: one product instead of six (results are garbage)
-                if (pr != 5) { if (g < NPARTS) { load_part(kt + 2, more2, g, SetCur{}); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } continue; }
-#endif
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[pr]][s2], bf[j][PB[pr]][s2], acc[i][j], 0, 0, 0);
                 if (g < NPARTS) load_part(kt + 2, more2, g, SetCur{});
                 // the 3 * NCH plane stores, spread over the MFMAs
@@ -679,17 +666,12 @@ __global__ __launch_bounds__(NTHREADS, BF3 ? 3 : 1) void conv_igemm_kernel(ConvP
                     const int ch = w / 3, pl = w % 3;
                     unsigned char* dst = ch < A_CH ? An + a_lds[ch < A_CH ? ch : 0] + pl * A_PLANE
                                                    : Bn + b_lds[ch < A_CH ? 0 : ch - A_CH] + pl * B_PLANE;
-#ifdef MI_DBG_NOSTORE
-                    if (kt1 - kt0 > 2) continue;
-#endif
                     *reinterpret_cast<uint2*>(dst) = cv[ch][pl];
                 }
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
-#ifndef MI_DBG_NOBARRIER
             __syncthreads();
-#endif
             return;
         }
         // Phase 1: fragments of the current slice from LDS
@@ -749,9 +731,7 @@ __global__ __launch_bounds__(NTHREADS, BF3 ? 3 : 1) void conv_igemm_kernel(ConvP
         // Phase 3: slice kt+1 (set CUR^1, in flight since the previous iteration) goes to the other
         // LDS buffer; the wait only covers those older loads (counted vmcnt)
         store_tile(buf ^ 1, SetOther{});
-#ifndef MI_DBG_NOBARRIER
         __syncthreads();
-#endif
     };
 
     if (kt0 < kt1) {

@@ -230,10 +230,6 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_bf3_kernel(StemParams p, cons
 #pragma unroll
         for (int u = 0; u < NPP; ++u) {
             const int i = tid + u * 256;
-#ifdef MI_DBG_STEM_NOPATCH   // timing experiment (results are garbage)
-            pv[u][0] = pv[u][1] = 1.f;
-            continue;
-#endif
             const int pp = i % (PW / 2), t = i / (PW / 2), py = t % PYP, pz = t / PYP;
             const int iz = iz0 + pz, iy = iy0 + py;
 #pragma unroll
@@ -295,9 +291,6 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_bf3_kernel(StemParams p, cons
         constexpr int SET = decltype(SETc)::value;
 #pragma unroll
         for (int pr = 0; pr < 6; ++pr) {
-#ifdef MI_DBG_STEM_ONEPROD   // timing experiment (results are garbage)
-            if (pr != 5) continue;
-#endif
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SET][PA[pr]], bf0[SET][PB[pr]], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SET][PA[pr]], bf1[SET][PB[pr]], acc1, 0, 0, 0);
         }

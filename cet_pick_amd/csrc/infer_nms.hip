@@ -779,9 +779,6 @@ extern "C" int mi_sigmoid_nms_topk(const float* logits, float* heat_out, int D, 
         Peak3Params q = {};
         q.in = logits; q.val_out = val_out; q.D = D; q.H = H; q.W = W;
         q.cands = cands; q.seg_count = seg_count; q.hist = hdr->hist;
-        if (const char* e = getenv("MI_DBG_P3")) {       // timing experiments (results are garbage): 1 = no histogram
-            if (atoi(e) & 1) q.hist = nullptr;
-        }
         int rc = mi_launch_peak3(q, g, apply_sigmoid != 0, s);
         if (rc) return rc;
         const int fblocks = (int)std::min<unsigned>((g.n_seg + 7) / 8, 256u);       // two segments per wave
