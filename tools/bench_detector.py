@@ -52,7 +52,12 @@ def run(small=False):
     cms = sum(p[2].elapsed_time(p[3]) / p[4] for p in prof)
     out["unet4_forward"] = {"input": list(vol.shape), "ms": t * 1e3, "input_voxels_per_sec": vol.numel() / t,
                             "conv_gflop": cflops / 1e9, "conv_ms": cms, "conv_tflops": cflops / cms / 1e9,
-                            "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+                            "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+                            # the convolutions run in the bf16x3 arithmetic: ceiling 2500 / 6 TFLOP/s of f32-equivalent work
+                            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (every conv of one forward)",
+                                         "achieved": cflops / cms / 1e9, "peak": 2500.0 / 6, "unit": "TFLOP/s",
+                                         "frac": cflops / cms / 1e9 / (2500.0 / 6), "traffic": None,
+                                         "whole_forward_tflops": cflops / t / 1e12}}
     # a23: debiased contrastive loss, N = 12,288 per view, dim 32, forward + backward
     n, dim = (2048, 32) if small else (12288, 32)
     g = torch.Generator().manual_seed(0)
@@ -92,7 +97,19 @@ def run(small=False):
     gt[rr > 0.97] = 1.0
     batch = {"input": x.cuda(), "input_aug": x.flip(-1).cuda(), "hm": gt.cuda(), "flip_prob": 0.2, "meta": {}}
     t = timeit(lambda: trainer.train(1, [dict(batch)]), n=5, warm=2)
-    out["semi_train_step"] = {"pairs": b, "crop": [6, 64, 64], "ms": t * 1e3, "crops_per_sec": 2 * b / t}
+    # the step is the debiased contrastive loss: N = b*6*32*32 voxels per view, S = F F^T over 2N rows is formed on the
+    # f32 matrix cores once in the forward and twice in each of the two backward kernels, for the supervised and the
+    # unsupervised term (models/loss.py): 2 terms x 5 passes x 2 (2N)^2 dim FLOP; the U-Net is noise next to it
+    n_vox = b * 6 * 32 * 32
+    ucl_flop = 2 * 5 * 2.0 * (2 * n_vox) ** 2 * 32
+    out["semi_train_step"] = {"pairs": b, "crop": [6, 64, 64], "ms": t * 1e3, "crops_per_sec": 2 * b / t,
+                              "voxels_per_view": n_vox, "ucl_gflop": ucl_flop / 1e9,
+                              "roofline": {"bound": "mfma", "kernel": "ucl_fwd_kernel + ucl_bwd_kernel<.,0/1> (v_mfma_f32_32x32x2_f32)",
+                                           "achieved": ucl_flop / t / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                           "frac": ucl_flop / t / 1e12 / 157.3, "traffic": None,
+                                           "note": "whole step time against the loss kernels' FLOPs (they are 97 % of it, "
+                                                   "profiles/r02_detector_kernel_stats.csv); not launch-bound: a hipGraph "
+                                                   "of the step would not change it"}}
     return out
 
 
