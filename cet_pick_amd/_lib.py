@@ -46,6 +46,8 @@ SIGNATURES = {
     "mi_convnd_fwd_f32": (_I, [_P, _P, _P, _P, _I] + [_I] * 13 + [_P, _Z, _P]),
     "mi_convnd_dgrad_f32": (_I, [_P, _P, _P, _P, _P] + [_I] * 13 + [_P, _Z, _P]),
     "mi_convnd_wgrad_f32": (_I, [_P, _P, _P] + [_I] * 13 + [_P, _Z, _P]),
+    "mi_convnd_wgrad_slabs_f32": (_I, [_P, _P, _P] + [_I] * 13 + [_P, _Z, _P, _P]),
+    "mi_splitk_reduce_batch": (_I, [_P, _P, _P, _P, _I, _P]),
     "mi_convnd_dil_workspace_bytes": (_Z, [_I] * 15),
     "mi_convnd_dil_fwd_f32": (_I, [_P, _P, _P, _P, _I] + [_I] * 15 + [_P, _Z, _P]),
     "mi_convnd_dil_dgrad_f32": (_I, [_P, _P, _P, _P, _P] + [_I] * 15 + [_P, _Z, _P]),
@@ -95,7 +97,7 @@ SIGNATURES = {
     "mi_rowdot_mean_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "mi_column_std_mean": (_I, [_P, _P, _I, _I, _P]),
     "mi_ce_label0": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
-    "mi_ce_label0_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "mi_ce_label0_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "mi_ce_label0_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "mi_ema_update": (_I, [_P, _P, _F, _L, _P]),
     "mi_sgd_step": (_I, [_P, _P, _P, _F, _F, _L, _P]),

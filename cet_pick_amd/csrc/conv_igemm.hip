@@ -800,6 +800,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
     }
 }
 
+// the split-K slabs of up to MI_REDUCE_BATCH launches summed in ONE launch (blockIdx.y = launch): the weight gradients of
+// a whole backward pass are reduced together instead of one tiny launch behind every wgrad
+constexpr int MI_REDUCE_BATCH = 24;
+struct SplitDesc { const float* slabs; float* out; long slab_stride; long n4; int n_slabs; int pad; };
+struct SplitBatch { SplitDesc d[MI_REDUCE_BATCH]; };
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(SplitBatch bt) {
+    const SplitDesc& d = bt.d[blockIdx.y];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < d.n4; i += (long)gridDim.x * 256) {
+        float4 s = ld4(d.slabs + 4 * i);
+        for (int z = 1; z < d.n_slabs; ++z) {
+            float4 v = ld4(d.slabs + (long)z * d.slab_stride + 4 * i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(d.out + 4 * i) = s;
+    }
+}
+
 struct Plan { int bm, bn, bk, splits; long tiles_x; };
 
 int env_int(const char* name) {
@@ -864,6 +881,9 @@ template <int MODE, bool STEM>
 int launch_mode(const ConvParams& p, const Plan& pl, hipStream_t s) {
     dim3 grid((unsigned)(pl.tiles_x * ((p.Ncols + pl.bn - 1) / pl.bn) * pl.splits));    // 1-D, decoded in the kernel
     if constexpr (!STEM) {
+        // (a 128 x 64 bf16x3 tile was built and measured in round 2: layer-1 forward 100.6 us against 52.8 us, layer-2
+        // 43.4 against 33.4, layer-3 25.0 against 23.7 - a batch-64 step does not have the rows for it: 32,768 im2col
+        // rows are 256 tiles of 128, one per CU)
         if (conv_arith_bf16x3() && pl.bm == 64 && pl.bn == 64 && (pl.bk == 32 || pl.bk == 16)) {
             if (pl.bk == 32) hipLaunchKernelGGL((conv_igemm_kernel<MODE, 64, 64, 32, false, true>), grid, dim3(NTHREADS), 0, s, p);
             else hipLaunchKernelGGL((conv_igemm_kernel<MODE, 64, 64, 16, false, true>), grid, dim3(NTHREADS), 0, s, p);
@@ -1083,8 +1103,13 @@ bool is_stem7(const Geom& g) {
            g.dd == 1 && g.dh == 1 && g.dw == 1;
 }
 
+// defer_splits != null (weight gradients only): a split launch leaves its slabs in `ws` un-reduced and reports the split
+// count - the caller sums many layers' slabs in one mi_splitk_reduce_batch launch; an unsplit launch (or the stem,
+// which reduces by itself) reports 1 and `out` is final.
 int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, float* out,
-             const float* res, const float* mask, int relu, void* ws, size_t ws_bytes, hipStream_t s) {
+             const float* res, const float* mask, int relu, void* ws, size_t ws_bytes, hipStream_t s,
+             int* defer_splits = nullptr) {
+    if (defer_splits) *defer_splits = 1;
     // A gathered operand of 2 GiB or more (32-bit buffer offsets): FWD / DGRAD rows are independent per sample,
     // so the batch is cut in halves until every piece fits
     if (mode != MODE_WGRAD && g.N > 1) {
@@ -1128,6 +1153,7 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
     else if (mode == MODE_DGRAD) rc = launch_mode<MODE_DGRAD, false>(p, pl, s);
     else rc = stem ? launch_mode<MODE_WGRAD, true>(p, pl, s) : launch_mode<MODE_WGRAD, false>(p, pl, s);
     if (rc) return rc;
+    if (pl.splits > 1 && defer_splits) { *defer_splits = pl.splits; return MI_OK; }
     if (pl.splits > 1) {
         long n4 = out_elems / 4;
         int blocks = (int)std::min<long>((n4 + 255) / 256, 2048);
@@ -1216,6 +1242,35 @@ extern "C" int mi_convnd_wgrad_f32(const float* x, const float* dy, float* dw, i
     Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
     if (!x || !dy || !dw || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
     return run_conv(MODE_WGRAD, g, x, dy, dw, nullptr, nullptr, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mi_convnd_wgrad_slabs_f32(const float* x, const float* dy, float* dw, int N, int Di, int Hi, int Wi, int Ci,
+                                         int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw, void* ws,
+                                         size_t ws_bytes, int* splits_out, mi_stream_t stream) {
+    Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
+    if (!x || !dy || !dw || !splits_out || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
+    return run_conv(MODE_WGRAD, g, x, dy, dw, nullptr, nullptr, 0, ws, ws_bytes, (hipStream_t)stream, splits_out);
+}
+
+extern "C" int mi_splitk_reduce_batch(const void* const* slabs, void* const* outs, const int* n_slabs, const long* out_elems,
+                                      int n, mi_stream_t stream) {
+    if (n <= 0) return MI_OK;
+    if (!slabs || !outs || !n_slabs || !out_elems) return MI_E_ARG;
+    for (int i0 = 0; i0 < n; i0 += MI_REDUCE_BATCH) {
+        SplitBatch bt = {};
+        const int m = std::min(MI_REDUCE_BATCH, n - i0);
+        long max4 = 1;
+        for (int i = 0; i < m; ++i) {
+            if (!slabs[i0 + i] || !outs[i0 + i] || n_slabs[i0 + i] < 1 || (out_elems[i0 + i] & 3)) return MI_E_ARG;
+            bt.d[i] = SplitDesc{(const float*)slabs[i0 + i], (float*)outs[i0 + i], out_elems[i0 + i], out_elems[i0 + i] / 4,
+                                n_slabs[i0 + i], 0};
+            max4 = std::max(max4, bt.d[i].n4);
+        }
+        const int bx = (int)std::min<long>((max4 + 255) / 256, 256);
+        hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(bx, m), dim3(256), 0, (hipStream_t)stream, bt);
+        MI_RETURN_IF_LAUNCH_FAILED();
+    }
+    return MI_OK;
 }
 
 // ---- dilated windows (stride 1): the 3-D head of the detector, unet_small.py:38-41 (kernel 3x3x3,

@@ -265,6 +265,30 @@ def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None, dil=None):
     return dx
 
 
+# Deferred split-K reduction of the weight gradients: while DEFERRED_WGRADS is a list (MocoStepEngine sets it around the
+# backward pass), every wgrad launch leaves its slabs in a slab buffer of its own and registers (slabs, target, splits,
+# elements) here; flush_wgrad_reduces() sums them all in one launch (one per gradient bucket under data parallelism)
+# instead of one small reduce launch behind each of the 18 weight-gradient kernels of a step.
+DEFERRED_WGRADS = None
+
+
+def flush_wgrad_reduces():
+    global DEFERRED_WGRADS
+    items = DEFERRED_WGRADS
+    if not items:
+        return
+    import ctypes
+    n = len(items)
+    slabs = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in items])
+    outs = (ctypes.c_void_p * n)(*[it[1].data_ptr() for it in items])
+    cnt = (ctypes.c_int * n)(*[it[2] for it in items])
+    elems = (ctypes.c_long * n)(*[it[3] for it in items])
+    L.check(L.lib().mi_splitk_reduce_batch(ctypes.cast(slabs, ctypes.c_void_p), ctypes.cast(outs, ctypes.c_void_p),
+                                           ctypes.cast(cnt, ctypes.c_void_p), ctypes.cast(elems, ctypes.c_void_p), n,
+                                           L.stream()), "mi_splitk_reduce_batch")
+    del items[:]
+
+
 def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
     """dW for `param`, written (or accumulated) into param.grad."""
     nd5 = x.dim() == 5
@@ -275,6 +299,20 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
     g, acc = _grad_target(param)
     tgt = torch.empty_like(g) if acc else g
     flops = 2.0 * dy.numel() * ci * k3[0] * k3[1] * k3[2]
+    if DEFERRED_WGRADS is not None and not acc and PROFILE is None and (dil is None or tuple(_k3(dil, nd5)) == (1, 1, 1)):
+        import ctypes
+        nbytes = lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3)
+        slab = getattr(param, "_mi_slabs", None)
+        if slab is None or slab.numel() < nbytes or slab.device != x.device:
+            slab = torch.empty(int(nbytes), dtype=torch.uint8, device=x.device)     # lives with the parameter
+            param._mi_slabs = slab
+        splits = ctypes.c_int(0)
+        L.check(lib.mi_convnd_wgrad_slabs_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, *k3, stride, *p3,
+                                              L.ptr(slab), slab.numel(), ctypes.addressof(splits), L.stream()),
+                "mi_convnd_wgrad_slabs_f32")
+        if splits.value > 1:
+            DEFERRED_WGRADS.append((slab, tgt, int(splits.value), tgt.numel()))
+        return
     if dil is not None and tuple(_k3(dil, nd5)) != (1, 1, 1):
         d3 = _k3(dil, nd5)
         ws = _ws(lib.mi_convnd_dil_workspace_bytes(n, d, h, wd, ci, co, *k3, *p3, *d3), x.device, "conv")
@@ -882,38 +920,25 @@ def moco_logits(q, k, queue, T):
 
 
 class _CELabel0Fn(torch.autograd.Function):
-    """Small batches (<= 256 rows, every MoCo configuration here): forward = one launch that also drops the mean loss into
-    `out` (the engine's loss buffer: no copy afterwards), backward = one launch that reads the upstream gradient on the
-    device.  Larger batches: the per-row kernel + mean, gradient scaled on the way back."""
+    """forward = one launch (a workgroup per row, the last one takes the mean) that also drops the loss into `out` (the
+    engine's loss buffer: no copy afterwards); backward = one launch that reads the upstream gradient on the device."""
 
     @staticmethod
     def forward(ctx, logits, out):
         b, n = logits.shape
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
-        row = torch.empty(b, dtype=torch.float32, device=logits.device)
-        ctx.small = b <= 256
-        if ctx.small:
-            L.check(L.lib().mi_ce_label0_fwd(L.ptr(logits), L.ptr(loss), L.ptr(out), L.ptr(row), b, n, L.stream()),
-                    "mi_ce_label0_fwd")
-            ctx.save_for_backward(logits, row)
-        else:
-            dl = torch.empty_like(logits)
-            L.check(L.lib().mi_ce_label0(L.ptr(logits), L.ptr(loss), L.ptr(row), L.ptr(dl), b, n, 1.0, L.stream()),
-                    "mi_ce_label0")
-            ctx.save_for_backward(dl)
-            if out is not None:
-                out.copy_(loss)
+        rows = torch.empty(2 * b, dtype=torch.float32, device=logits.device)          # row losses | row log-sum-exps
+        L.check(L.lib().mi_ce_label0_fwd(L.ptr(logits), L.ptr(loss), L.ptr(out), L.ptr(rows), L.ptr(rows[b:]), b, n,
+                                         L.stream()), "mi_ce_label0_fwd")
+        ctx.save_for_backward(logits, rows)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        if not ctx.small:
-            (dl,) = ctx.saved_tensors
-            return dl * g, None
-        logits, row = ctx.saved_tensors
+        logits, rows = ctx.saved_tensors
         b, n = logits.shape
         dl = torch.empty_like(logits)
-        L.check(L.lib().mi_ce_label0_bwd(L.ptr(logits), L.ptr(row), L.ptr(g.contiguous()), L.ptr(dl), b, n, L.stream()),
+        L.check(L.lib().mi_ce_label0_bwd(L.ptr(logits), L.ptr(rows[b:]), L.ptr(g.contiguous()), L.ptr(dl), b, n, L.stream()),
                 "mi_ce_label0_bwd")
         return dl, None
 

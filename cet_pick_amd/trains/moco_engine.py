@@ -64,6 +64,7 @@ class MocoStepEngine:
         the optimizer step.  The collective itself is issued synchronously - its internal wait only holds the exchange
         stream - because an async Work under hipGraph capture kills the process-group watchdog (hipops.dist_all_reduce)."""
         a, b = self._bucket[tag]
+        H.flush_wgrad_reduces()                       # the bucket's weight gradients still sit in split-K slabs
         if b > a and not self.arena_q.flat_grad.is_cuda:        # (CPU tensors over gloo: plumbing tests)
             H.dist_all_reduce(self.arena_q.flat_grad[a:b])
             self.buckets_sent.append(tag)
@@ -103,7 +104,12 @@ class MocoStepEngine:
         self.arena_q.zero_grad()
         logits, labels = moco(im_q, im_k)
         loss = H.cross_entropy_label0(logits, out=self._loss_buf)      # lands in the engine's loss buffer: no copy
-        loss.backward()
+        H.DEFERRED_WGRADS = [] if self.arena_q.flat_grad.is_cuda else None     # split-K slabs of the wgrads: one reduce
+        try:
+            loss.backward()
+            H.flush_wgrad_reduces()
+        finally:
+            H.DEFERRED_WGRADS = None
         if self.dist_on:
             # layer3+heads, layer2 and layer1 went out from the autograd hooks while the backward was still running
             # (RCCL over xGMI on its own stream); the stem's gradients are the last to exist

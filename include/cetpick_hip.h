@@ -192,6 +192,16 @@ int mi_convnd_dgrad_f32(const float* dy, const float* w, float* dx, const float*
 int mi_convnd_wgrad_f32(const float* x, const float* dy, float* dw, int N, int Di, int Hi, int Wi,
                         int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw,
                         void* ws, size_t ws_bytes, mi_stream_t stream);
+/* The weight gradient with its split-K reduction left to the caller: *splits_out = 1 -> dw is final; > 1 -> `ws` holds
+ * that many slabs of Co*Ci*kd*kh*kw floats (slab s at ws + s * that many floats) and dw is untouched.
+ * mi_splitk_reduce_batch sums the slabs of n such launches (outs[i] <- sum of n_slabs[i] slabs at slabs[i], out_elems[i]
+ * floats each, a multiple of 4) in one launch per 24 of them: one reduce for the weight gradients of a whole backward
+ * pass.  The pointer / count arrays are HOST arrays (read during the call). */
+int mi_convnd_wgrad_slabs_f32(const float* x, const float* dy, float* dw, int N, int Di, int Hi, int Wi, int Ci, int Co,
+                              int kd, int kh, int kw, int stride, int pd, int ph, int pw, void* ws, size_t ws_bytes,
+                              int* splits_out, mi_stream_t stream);
+int mi_splitk_reduce_batch(const void* const* slabs, void* const* outs, const int* n_slabs, const long* out_elems, int n,
+                           mi_stream_t stream);
 
 /* Dilated windows, stride 1 (kernel (3,3,3), dilation (1,4,4), padding (1,4,4): the 3-D head of the detector
  * network, models/networks/unet_small.py:38-41).  Same contract as mi_convnd_*; output extent per axis
@@ -328,11 +338,11 @@ int mi_column_std_mean(const float* x, float* out, int B, int C, mi_stream_t str
  * loss = mean_b(logsumexp(l_b) - l_b[0]); dlogits = grad_scale*(softmax - onehot0)/B (may be NULL). */
 int mi_ce_label0(const float* logits, float* loss, float* row_loss, float* dlogits, int B, int n,
                  float grad_scale, mi_stream_t stream);
-/* The same loss for B <= 256 rows in ONE launch (row maxima, log-sum-exp and the mean), row_lse[B] kept for the backward
- * pass; the backward reads the upstream gradient from the device (no host value, no extra scaling launch):
- * dlogits = grad_loss * (softmax - onehot0) / B. */
+/* The same loss in ONE launch (a workgroup per row; the last one to finish takes the mean, in row order), row_loss[B] and
+ * row_lse[B] scratch / kept for the backward pass; the backward reads the upstream gradient from the device (no host
+ * value, no extra scaling launch): dlogits = grad_loss * (softmax - onehot0) / B.  One call at a time per device. */
 int mi_ce_label0_fwd(const float* logits, float* loss, float* loss_copy /* may be NULL: a second place for the value */,
-                     float* row_lse, int B, int n, mi_stream_t stream);
+                     float* row_loss, float* row_lse, int B, int n, mi_stream_t stream);
 int mi_ce_label0_bwd(const float* logits, const float* row_lse, const float* grad_loss, float* dlogits, int B, int n,
                      mi_stream_t stream);
 
