@@ -170,9 +170,11 @@ struct SymTaps1 { float w[R + 1]; };         // w[t] = tap at distance t from th
 struct MarchGeom {
     int n_conv;            // extent of the filtered axis
     long conv_stride;      // elements between consecutive positions on it
-    long other_stride;     // column c -> base = (c / w_inner) * other_stride + c % w_inner
-    int w_inner;
+    long other_stride;     // column c -> base = (outer0 + c / w_inner) * other_stride + x0 + c % w_inner
+    int w_inner;           // columns per outer index (a box of the other two axes: the picker skips its zeroed border)
+    int outer0, x0;
     long n_cols;
+    int out_lo, out_hi;    // outputs [out_lo, out_hi) of the filtered axis are produced (the rest is never read)
 };
 
 // RB: radius of the ring (the larger sigma); RA: radius of the second output (DUAL), RA <= RB.
@@ -183,13 +185,13 @@ __device__ __forceinline__ void march_column(const float* __restrict__ in, float
     constexpr int PD = 2;
     constexpr int LEAD = 2 * RB + 4 + 4 * (PD - 1);        // rows resident ahead of output i: q in [i, i + LEAD)
     constexpr int RW = LEAD + 4;                           // ring registers
-    const long base = (c / p.w_inner) * p.other_stride + (c % p.w_inner);
+    const long base = (p.outer0 + c / p.w_inner) * p.other_stride + p.x0 + (c % p.w_inner);
     const float* src = in + base;
-    const int n = p.n_conv;
+    const int n = p.n_conv, n_out = p.out_hi;
     float win[RW];
 #pragma unroll
-    for (int q = 0; q < LEAD; ++q) win[q] = src[(long)reflect_idx(q - RB, n) * p.conv_stride];
-    for (int i0 = 0; i0 < n; i0 += RW) {
+    for (int q = 0; q < LEAD; ++q) win[q] = src[(long)reflect_idx(p.out_lo + q - RB, n) * p.conv_stride];
+    for (int i0 = p.out_lo; i0 < n_out; i0 += RW) {
 #pragma unroll
         for (int ph = 0; ph < RW / 4; ++ph) {
             const int i = i0 + 4 * ph;                     // slot of row q is (q - i0) mod RW: static per phase
@@ -214,10 +216,10 @@ __device__ __forceinline__ void march_column(const float* __restrict__ in, float
                     accb[u] = fmaf(wb.w[t], pair, accb[u]);
                     if (DUAL && t <= RA) acca[u] = fmaf(wa.w[t], pair, acca[u]);
                 }
-            if (i < n) {
+            if (i < n_out) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (i + u < n) {
+                    if (i + u < n_out) {
                         out_b[base + (long)(i + u) * p.conv_stride] = accb[u];
                         if (DUAL) out_a[base + (long)(i + u) * p.conv_stride] = acca[u];
                     }
@@ -405,8 +407,9 @@ int mi_gauss_radius(float sigma) { return (int)(4.0f * sigma + 0.5f); }
 // Marching variant: up to two jobs (in -> out with sigma), or one job producing two sigmas from one read
 // (out0b != null: out0a <- sig0a, out0b <- sig0b, sig0a <= sig0b).
 // Returns MI_E_UNSUPPORTED for radii it is not instantiated for (sigma > 5.1: callers fall back to the tiled kernels).
+// box (may be null = everything): {z0, z1, y0, y1, x0, x1}, the part of the OUTPUT volume that will be read later.
 int mi_launch_gauss_march(const float* in0, float* out0a, float* out0b, float sig0a, float sig0b, const float* in1,
-                          float* out1, float sig1, int D, int H, int W, int axis, hipStream_t s) {
+                          float* out1, float sig1, int D, int H, int W, int axis, hipStream_t s, const int* box) {
     if (axis != 0 && axis != 1) return MI_E_ARG;
     const bool dual = out0b != nullptr;
     float smax = sig0a;
@@ -414,10 +417,21 @@ int mi_launch_gauss_march(const float* in0, float* out0a, float* out0b, float si
     if (in1) smax = std::max(smax, sig1);
     if (mi_gauss_radius(smax) > 20 || getenv("MI_GAUSS_NO_REGMARCH")) return MI_E_UNSUPPORTED;
     MarchGeom g = {};
+    const int full[6] = {0, D, 0, H, 0, W};
+    const int* bx = box ? box : full;
+    if (bx[0] < 0 || bx[1] > D || bx[2] < 0 || bx[3] > H || bx[4] < 0 || bx[5] > W || bx[0] >= bx[1] || bx[2] >= bx[3] ||
+        bx[4] >= bx[5]) return MI_E_ARG;
     g.n_conv = axis == 0 ? D : H;
     g.conv_stride = axis == 0 ? (long)H * W : (long)W;
-    if (axis == 0) { g.other_stride = 0; g.w_inner = H * W; g.n_cols = (long)H * W; }
-    else { g.other_stride = (long)H * W; g.w_inner = W; g.n_cols = (long)D * W; }
+    g.w_inner = bx[5] - bx[4];
+    g.x0 = bx[4];
+    if (axis == 0) {             // columns = (y, x) of the box, outputs z in [z0, z1)
+        g.other_stride = W; g.outer0 = bx[2]; g.n_cols = (long)(bx[3] - bx[2]) * g.w_inner;
+        g.out_lo = bx[0]; g.out_hi = bx[1];
+    } else {                     // columns = (z, x) of the box, outputs y in [y0, y1)
+        g.other_stride = (long)H * W; g.outer0 = bx[0]; g.n_cols = (long)(bx[1] - bx[0]) * g.w_inner;
+        g.out_lo = bx[2]; g.out_hi = bx[3];
+    }
     if (g.n_conv < 1) return MI_E_ARG;
     const int ra = march_radius_class(mi_gauss_radius(sig0a));
 #define MI_R4(FN, R, ...)                                                       \
@@ -445,7 +459,7 @@ int mi_launch_gauss_march(const float* in0, float* out0a, float* out0b, float si
     if (!in1) { MI_R4(launch_march_single, ra, in0, out0a, g, sig0a, s) }
     const int r1 = march_radius_class(mi_gauss_radius(sig1));
     if (ra > r1)          // instantiated for R0 <= R1 only: the two jobs are independent, swap them
-        return mi_launch_gauss_march(in1, out1, nullptr, sig1, 0.f, in0, out0a, sig0a, D, H, W, axis, s);
+        return mi_launch_gauss_march(in1, out1, nullptr, sig1, 0.f, in0, out0a, sig0a, D, H, W, axis, s, box);
 #define MI_TWO(R0)                                                                                   \
     switch (r1) {                                                                                    \
         case 8: if (R0 <= 8) return launch_march_two<(R0 <= 8 ? R0 : 8), 8>(in0, out0a, sig0a, in1, out1, sig1, g, s);      \
@@ -509,7 +523,7 @@ extern "C" int mi_gauss3d_sep(const float* in, float* out, float* tmp, int D, in
         // z: in -> out, y: out -> tmp, x: tmp -> out   (one read + one write of the volume per pass; z and y
         // through the marching kernel when its radius fits)
         auto strided = [&](const float* a, float* b, int axis) -> int {
-            int r2 = mi_launch_gauss_march(a, b, nullptr, sigma, 0.f, nullptr, nullptr, 0.f, D, H, W, axis, s);
+            int r2 = mi_launch_gauss_march(a, b, nullptr, sigma, 0.f, nullptr, nullptr, 0.f, D, H, W, axis, s, nullptr);
             return r2 == MI_E_UNSUPPORTED ? mi_launch_gauss_axis(a, b, D, H, W, axis, sigma, s) : r2;
         };
         if ((rc = strided(in, out, 0))) return rc;

@@ -18,7 +18,7 @@
 int mi_launch_gauss_axis(const float* in, float* out, int D, int H, int W, int axis, float sigma,
                          hipStream_t s);
 int mi_launch_gauss_march(const float* in0, float* out0a, float* out0b, float sig0a, float sig0b, const float* in1,
-                          float* out1, float sig1, int D, int H, int W, int axis, hipStream_t s);
+                          float* out1, float sig1, int D, int H, int W, int axis, hipStream_t s, const int* box = nullptr);
 int mi_gauss_radius(float sigma);
 
 namespace {
@@ -370,7 +370,11 @@ __global__ __launch_bounds__(256) void neighbors_kernel(GreedyHeader* hdr,
                 }
             }
         }
-        if (lane == 0) { nbr[(size_t)i * CAPN] = count; state[i] = 0; }   // count > CAPN-1 -> overflow: re-probe in the rounds
+        if (lane == 0) {
+            nbr[(size_t)i * CAPN] = count; state[i] = 0;        // count > CAPN-1 -> overflow: re-probe in the rounds
+            if (count > CAPN - 1) atomicAdd(&hdr->trace[13], 1u);   // (diagnostics: lists that did not fit - rare.  An
+            // atomicMax of every count on one word here made this kernel 952 us instead of 60: ~11 ns per returning atomic)
+        }
     }
 }
 
@@ -386,10 +390,22 @@ __device__ __forceinline__ int decide(unsigned i, int4 r0, const unsigned long l
         const unsigned char s0 = cnt > 0 ? state[r0.y] : 2, s1 = cnt > 1 ? state[r0.z] : 2, s2 = cnt > 2 ? state[r0.w] : 2;
         if (s0 == 1 || s1 == 1 || s2 == 1) return 2;
         all_decided = s0 != 0 && s1 != 0 && s2 != 0;
-        for (int q = 3; q < cnt; ++q) {
-            unsigned char st = state[nbr[(size_t)i * CAPN + 1 + q]];
-            if (st == 1) return 2;
-            if (st == 0) all_decided = false;
+        // longer lists (up to 18 neighbours on the 256x512x512 benchmark volume): eight at a time, their ids with two
+        // 16-byte loads and their eight states in flight together - a wave waits for its longest list, and one id load
+        // plus one dependent state load per neighbour was most of a round's 38 us
+        const int4* row4 = reinterpret_cast<const int4*>(nbr + (size_t)i * CAPN);
+        for (int q0 = 3; q0 < cnt; q0 += 8) {
+            const int4 a = row4[(q0 + 1) >> 2];
+            const int4 b = (q0 + 4 < cnt) ? row4[((q0 + 1) >> 2) + 1] : make_int4(0, 0, 0, 0);     // (stays inside the row)
+            const int ids[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            unsigned char st[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) st[u] = (q0 + u < cnt) ? state[ids[u]] : (unsigned char)2;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (st[u] == 1) return 2;
+                if (st[u] == 0) all_decided = false;
+            }
         }
     } else {
         const unsigned long long ki = G[i];
@@ -426,15 +442,28 @@ __global__ __launch_bounds__(256) void round_step_kernel(GreedyHeader* hdr, cons
     // already written are seen within the launch and a dependency chain advances several links per launch - a launch
     // boundary costs ~7 us here, a pass over the few still-open candidates next to nothing
     for (int pass = 0; pass < GREEDY_INNER; ++pass) {
-        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-            if (state[i] != 0) continue;
-            const int4 r0 = *reinterpret_cast<const int4*>(nbr + (size_t)i * CAPN);
-            int d = decide(i, r0, G, map, bits, deltas, nd, n_vox, nbr, state);
-            if (d != 0) {
-                state[i] = (unsigned char)d;
-                ++decided_here;
+        // (wave-uniform trip count: the picks of a wave take their slots with ONE returning atomic - one per pick
+        // serialised ~8000 of them on a single word in the first launch)
+        for (unsigned i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+            const unsigned i = i0 + threadIdx.x;
+            int d = 0;
+            if (i < n && state[i] == 0) {
+                const int4 r0 = *reinterpret_cast<const int4*>(nbr + (size_t)i * CAPN);
+                d = decide(i, r0, G, map, bits, deltas, nd, n_vox, nbr, state);
+                if (d != 0) {
+                    state[i] = (unsigned char)d;
+                    ++decided_here;
+                }
+            }
+            const unsigned long long pm = __ballot(d == 1);
+            if (pm) {
+                const int lane = threadIdx.x & 63;
+                unsigned base = 0;
+                const int leader = __ffsll((long long)pm) - 1;
+                if (lane == leader) base = atomicAdd(&hdr->n_kept, (unsigned)__popcll(pm));
+                base = __shfl(base, leader, 64);
                 if (d == 1) {
-                    unsigned slot = atomicAdd(&hdr->n_kept, 1u);
+                    const unsigned slot = base + (unsigned)__popcll(pm & ((1ull << lane) - 1ull));
                     if (slot < kept_cap) kept[slot] = G[i];
                 }
             }
@@ -809,10 +838,23 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
         mi_dogx_usable(w.tmp, w.heat, heat_out, D, H, W, sigmas_host[0], sigmas_host[1], k) &&
         (bxy >= mi_gauss_radius(sigmas_host[1]) || W > 2 * mi_gauss_radius(sigmas_host[1]))) {
         const float sa = sigmas_host[0], sb = sigmas_host[1];
-        // z: ONE read of the tomogram feeds both sigmas; y: two jobs, each with its own radius
-        rc = sa <= sb ? mi_launch_gauss_march(rec, w.g[0], w.g[1], sa, sb, nullptr, nullptr, 0.f, D, H, W, 0, s)
-                      : mi_launch_gauss_march(rec, w.g[0], nullptr, sa, 0.f, rec, w.g[1], sb, D, H, W, 0, s);
-        if (rc == MI_OK) rc = mi_launch_gauss_march(w.g[0], w.tmp, nullptr, sa, 0.f, w.g[1], w.heat, sb, D, H, W, 1, s);
+        // z: ONE read of the tomogram feeds both sigmas; y: two jobs, each with its own radius.  The DoG is zeroed
+        // inside its border (z: border_z planes, x / y: bxy voxels), so only the part of each pass that the next one reads
+        // is produced: planes [bz, D - bz), and on y / x the live range widened by the larger radius (bxy >= radius: the
+        // fused kernel's windows of the live outputs stay inside it).  -11 % (z pass) / -19 % (y pass) of the writes.
+        const int rmax = std::max(mi_gauss_radius(sa), mi_gauss_radius(sb));
+        int boxz[6] = {0, D, 0, H, 0, W}, boxy[6] = {0, D, 0, H, 0, W};
+        if (bxy >= rmax && 2 * border_z < D && 2 * bxy < H && 2 * bxy < W) {
+            const int z0 = border_z, z1 = D - border_z;
+            const int ylo = std::max(0, bxy - rmax), yhi = std::min(H, H - bxy + rmax);
+            // (x stays whole: a box that starts at x = 10 and is 492 wide costs the marches more in split cache lines and
+            // rows straddled by a wave than its 8 % of columns saves - measured 269 us against 231 us for the y pass)
+            const int bz_[6] = {z0, z1, ylo, yhi, 0, W}, by_[6] = {z0, z1, bxy, H - bxy, 0, W};
+            for (int i = 0; i < 6; ++i) { boxz[i] = bz_[i]; boxy[i] = by_[i]; }
+        }
+        rc = sa <= sb ? mi_launch_gauss_march(rec, w.g[0], w.g[1], sa, sb, nullptr, nullptr, 0.f, D, H, W, 0, s, boxz)
+                      : mi_launch_gauss_march(rec, w.g[0], nullptr, sa, 0.f, rec, w.g[1], sb, D, H, W, 0, s, boxz);
+        if (rc == MI_OK) rc = mi_launch_gauss_march(w.g[0], w.tmp, nullptr, sa, 0.f, w.g[1], w.heat, sb, D, H, W, 1, s, boxy);
         if (rc == MI_OK) {
             DogxParams q = {};
             q.y1 = w.tmp; q.y2 = w.heat; q.nms_out = heat_out;

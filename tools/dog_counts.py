@@ -58,4 +58,6 @@ torch.cuda.synchronize()
 print("trivial kernel, 50 per hipGraph: %.2f us each" % (e0.elapsed_time(e1) / 200 * 1e3))
 # round trace (GreedyHeader.trace): candidates still open at the start of each chip-wide round launch; [14] = left for the finisher
 for h in hits[:1]:
-    print("undecided at the start of each round launch:", raw[h + 3:h + 3 + 16].tolist())
+    tr = raw[h + 3:h + 3 + 16].tolist()
+    print("undecided at the start of each round launch:", tr[:8], "| lists over capacity", tr[13],
+          "| left for the finisher", tr[14])
