@@ -1,0 +1,304 @@
+// Direct 3x3x3 / stride 1 / padding 1 convolution for 64 -> 64 channels on (N, D, 8, 8, 64) channels-last activations,
+// forward and data-gradient form, in the bf16x3 arithmetic of conv_igemm.hip (three-way exact bf16 cut of both operands,
+// six bf16 MFMA products per f32 product, f32 accumulate).  This is layer1 of the MoCo-3D encoder
+// (cet_pick/models/networks/moco_encoder_3d.py:55-84,170 - four such convolutions per encoder pass): 12 of the 75 conv
+// launches of a training step and the largest share of its time.
+//
+// Why not the implicit GEMM: with 64 output channels a 64 x 64 tile re-gathers, re-cuts and re-stores its im2col rows
+// for every one of the 27 taps (the matrix pipe is busy 14 % of the time, profiles/r02_mfma_busy.json: the waves
+// spend their issue slots on the cut, the gather addresses and LDS traffic).  Here the INPUT PATCH of a tile is cut once
+// and stays in LDS for all 27 taps:
+//   * one 256-thread workgroup owns two z-planes of one sample (128 output voxels x 64 channels); its patch is the four
+//     z-planes around them (256 voxels x 64 channels, three bf16 planes = 96 KB + zero regions = 109 KB of LDS), planes
+//     outside the volume zero-filled.  The 8 x 8 plane is the whole image, so the x / y halo is pure padding: a lane
+//     whose neighbour falls outside reads a zero record instead (one address select per tap and row block, no data
+//     select).
+//   * patch layout: per (k-step of 16 channels, bf16 plane, k-half) an array of 16-byte records, one per voxel - an
+//     MFMA A-fragment (row = voxel, 8 consecutive channels) is ONE ds_read_b128 at lane base + immediate; consecutive
+//     voxels are consecutive records, so the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots.
+//   * the weights never pass through LDS: a prep kernel cuts them once into an image in MFMA B-fragment order
+//     ([tap][k-step][column half][bf16 plane][lane] x 16 bytes), and every wave streams its 1-KB fragments straight
+//     from L2 into registers, six k-steps ahead of their use (the two waves that share a column half hit in the CU's L1).
+//   * the main loop therefore has no barrier, no LDS store, no gather and no cut: per k-step and wave 6 ds_read_b128,
+//     3 buffer loads and 12 MFMAs (wave tile 64 voxels x 32 channels).
+// DGRAD is the same kernel on dY with the weight image built transposed and tap-flipped:
+//   dX[i] = sum_t dY[i + 1 - t] W[t]^T = sum_t' dY[i + t' - 1] W[2 - t']^T.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int C = 64;                       // channels, in = out
+constexpr int PLANE = 64;                   // voxels of an 8 x 8 z-plane
+constexpr int TZ = 2;                       // output z-planes per workgroup
+constexpr int PZ = TZ + 2;                  // patch z-planes
+constexpr int NV = PZ * PLANE;              // 256 patch voxels
+constexpr int LEAD = 9;                     // records in front of voxel 0: lane bases carry the -9 of the tap offsets
+constexpr int ZREC = 19;                    // zero records behind the voxels: zero base + tap offset (0..18) stays inside
+constexpr int NREC = LEAD + NV + ZREC;      // 284
+constexpr int ARR = NREC * 16;              // bytes of one (k-step, plane, k-half) array
+constexpr int KS = C / 16;                  // bf16 MFMA k-steps per tap
+constexpr int PL_BYTES = 2 * ARR;
+constexpr int KS_BYTES = 3 * PL_BYTES;
+constexpr int LDS_BYTES = KS * KS_BYTES;    // 109,056
+constexpr int ZBASE = (LEAD + NV) * 16;     // byte offset of the zero region in an array
+constexpr int WBLK = 1024;                  // one B fragment: 64 lanes x 16 bytes
+constexpr int WSTEP = 2 * 3 * WBLK;         // bytes per (tap, k-step): [column half][plane]
+constexpr int NTAP = 27;
+constexpr int WIMG_BYTES = NTAP * KS * WSTEP;      // 663,552
+constexpr int RB = 6;                       // weight fragments in flight: k-steps ahead (36 k-steps per dz: 36 % RB == 0)
+static_assert(36 % RB == 0, "ring slots must line up across the dz loop");
+static_assert(LDS_BYTES <= 160 * 1024, "patch must fit the CU's LDS");
+
+struct Direct3Params {
+    const float* a;           // X (forward) or dY (data gradient): (N, D, 8, 8, 64)
+    const unsigned char* wimg;
+    float* out;
+    const float* res;         // out = act(acc + res)          (may be null)
+    const float* mask;        // out *= (mask > 0)             (may be null)
+    int relu;
+    int N, D;
+    unsigned a_bytes;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+
+// exact three-way bf16 cut of 8 consecutive f32 (truncation keeps every step exact, conv_igemm.hip): planes o[0..2],
+// element e in half (e & 1) of dword e / 2
+__device__ __forceinline__ void cut8(const float (&v)[8], u32x4 (&o)[3]) {
+    unsigned u0[8], u1[8], u2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        u0[t] = __float_as_uint(v[t]);
+        const float r1 = v[t] - __uint_as_float(u0[t] & 0xffff0000u);
+        u1[t] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1[t] & 0xffff0000u);
+        u2[t] = __float_as_uint(r2);
+    }
+    constexpr unsigned HI2 = 0x07060302u;   // v_perm_b32: high halves of two dwords -> one dword (first element low)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        o[0][d] = __builtin_amdgcn_perm(u0[2 * d + 1], u0[2 * d], HI2);
+        o[1][d] = __builtin_amdgcn_perm(u1[2 * d + 1], u1[2 * d], HI2);
+        o[2][d] = __builtin_amdgcn_perm(u2[2 * d + 1], u2[2 * d], HI2);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void direct3_kernel(Direct3Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned char patch[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    const int tz = wave >> 1, cw = wave & 1;             // wave tile: z-plane tz of the pair x column half cw
+    const int zb = blockIdx.x % (p.D / TZ), n = blockIdx.x / (p.D / TZ);
+    const int z0 = zb * TZ;
+
+    const __amdgpu_buffer_rsrc_t wrs = rsrc_of(p.wimg, WIMG_BYTES);
+    const int w_voff = cw * (3 * WBLK) + lane * 16;
+    // weight fragments of k-step g (tap * 4 + ks, 0..107; behind the image: zeros) -> ring slot g % RB
+    bf16x8 bfr[RB][3];
+    auto wload = [&](int g, auto SLOTc) {
+        constexpr int SLOT = decltype(SLOTc)::value;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, w_voff + pl * WBLK, g * WSTEP, 0));
+    };
+    // the first RB - 1 k-steps of weights go out before the patch is staged
+    wload(0, std::integral_constant<int, 0>{});
+    wload(1, std::integral_constant<int, 1>{});
+    wload(2, std::integral_constant<int, 2>{});
+    wload(3, std::integral_constant<int, 3>{});
+    wload(4, std::integral_constant<int, 4>{});
+
+    // ---- stage the patch: unit q = (voxel, group of 8 channels); 8 units per thread, all loads first ----
+    {
+        const __amdgpu_buffer_rsrc_t ars = rsrc_of(p.a, p.a_bytes);
+        constexpr int UNITS = NV * 8 / 256;
+        u32x4 ld[UNITS][2];
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int q = tid + 256 * u, vox = q >> 3, cig = q & 7;
+            const int z = z0 - 1 + (vox >> 6);
+            const bool ok = (unsigned)z < (unsigned)p.D;
+            const unsigned off = ok ? 4u * (unsigned)((((long)n * p.D + z) * PLANE + (vox & 63)) * C + cig * 8) : 0x80000000u;
+            ld[u][0] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)off, 0, 0);
+            ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(off + 16u), 0, 0);
+        }
+        // zero regions and the unused leading records of the 24 arrays
+        for (int i = tid; i < KS * 3 * 2 * (LEAD + ZREC); i += 256) {
+            const int arr = i / (LEAD + ZREC), r = i % (LEAD + ZREC);
+            const int rec = r < LEAD ? r : LEAD + NV + (r - LEAD);
+            *reinterpret_cast<u32x4*>(patch + arr * ARR + rec * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int q = tid + 256 * u, vox = q >> 3, cig = q & 7;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ld[u][0][e]); v[4 + e] = __uint_as_float(ld[u][1][e]); }
+            u32x4 o[3];
+            cut8(v, o);
+            unsigned char* dst = patch + (cig >> 1) * KS_BYTES + (cig & 1) * ARR + (LEAD + vox) * 16;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * PL_BYTES) = o[pl];
+        }
+    }
+
+    // ---- per-lane geometry: row block i (rows 32 i .. 32 i + 31 of the wave's z-plane), MFMA row l32 ----
+    int vbase[2], zaddr;
+    unsigned vmask[2];                  // bit dy * 3 + dx: the (dy, dx) neighbour is inside the 8 x 8 plane
+    zaddr = ZBASE + h * ARR;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int y = 4 * i + (l32 >> 3), x = l32 & 7;
+        vbase[i] = (tz * PLANE + y * 8 + x) * 16 + h * ARR;          // record (LEAD + voxel) - 9, k-half h
+        unsigned m = 0;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                if ((unsigned)(y + dy - 1) < 8u && (unsigned)(x + dx - 1) < 8u) m |= 1u << (dy * 3 + dx);
+        vmask[i] = m;
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // smallest products first
+
+    bf16x8 af[2][2][3];
+    __syncthreads();                    // the only barrier: patch complete
+
+    for (int dz = 0; dz < 3; ++dz) {
+        // address of the (dy, dx) neighbour's record for this dz, or the zero region
+        int sel[9][2];
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) sel[t9][i] = ((vmask[i] >> t9) & 1u) ? vbase[i] + dz * (PLANE * 16) : zaddr;
+        auto frags = [&](int j, auto SETc) {
+            constexpr int SET = decltype(SETc)::value;
+            const int t9 = j >> 2, ks = j & 3;
+            const int imm = ((t9 / 3) * 8 + (t9 % 3)) * 16 + ks * KS_BYTES;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    af[SET][i][pl] = *reinterpret_cast<const bf16x8*>(patch + sel[t9][i] + imm + pl * PL_BYTES);
+        };
+        frags(0, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 36; ++j) {
+            const int g = dz * 36 + j;
+            // weights of k-step g + RB - 1 into the slot k-step g - 1 used; A fragments of k-step j + 1 into the other set
+            switch ((j + RB - 1) % RB) {
+                case 0: wload(g + RB - 1, std::integral_constant<int, 0>{}); break;
+                case 1: wload(g + RB - 1, std::integral_constant<int, 1>{}); break;
+                case 2: wload(g + RB - 1, std::integral_constant<int, 2>{}); break;
+                case 3: wload(g + RB - 1, std::integral_constant<int, 3>{}); break;
+                case 4: wload(g + RB - 1, std::integral_constant<int, 4>{}); break;
+                default: wload(g + RB - 1, std::integral_constant<int, 5>{}); break;
+            }
+            if (j + 1 < 36) {
+                if ((j + 1) & 1) frags(j + 1, std::integral_constant<int, 1>{});
+                else frags(j + 1, std::integral_constant<int, 0>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j & 1][0][PA[pr]], bfr[j % RB][PB[pr]], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j & 1][1][PA[pr]], bfr[j % RB][PB[pr]], acc[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h ----
+    const long m0 = ((long)n * p.D + z0 + tz) * PLANE;
+    const int col = cw * 32 + l32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long o = (m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * C + col;
+            float v = acc[i][r];
+            if (p.res) v += p.res[o];
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.mask) v = (p.mask[o] > 0.f) ? v : 0.f;
+            p.out[o] = v;
+        }
+}
+
+// ---- weight image: W[tap][ci][co] f32 -> bf16x3 B fragments, [tap][k-step][column half][plane][lane] x 16 bytes ----
+constexpr int PREP_MAX = 16;
+struct PrepBatch {
+    const float* w[PREP_MAX];
+    unsigned char* img[PREP_MAX];
+    int dgrad[PREP_MAX];
+};
+__global__ __launch_bounds__(256) void direct3_prep_kernel(PrepBatch b) {
+    const float* w = b.w[blockIdx.y];
+    unsigned char* img = b.img[blockIdx.y];
+    const int dgrad = b.dgrad[blockIdx.y];
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // (tap, ks, cw, lane); 27 * 4 * 2 * 64 = 54 * 256
+    const int lane = idx & 63, cw = (idx >> 6) & 1, ks = (idx >> 7) & 3, tap = idx >> 9;
+    const int nn = cw * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+    float v[8];
+    if (dgrad) {        // B'[tap][k = co][n = ci] = W[26 - tap][ci = n][co = k]
+        const float* src = w + ((long)(NTAP - 1 - tap) * C + nn) * C + k0;
+        const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else {            // B[tap][k = ci][n = co] = W[tap][ci = k][co = n]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = w[((long)tap * C + k0 + e) * C + nn];
+    }
+    u32x4 o[3];
+    cut8(v, o);
+    unsigned char* dst = img + (long)((tap * KS + ks) * 2 + cw) * (3 * WBLK) + lane * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * WBLK) = o[pl];
+}
+
+}  // namespace
+
+// ---- host side (internal: conv_igemm.hip's run_conv dispatches here; extern "C" wrappers at the end) ----
+bool mi_direct3_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph,
+                       int pw, int dd, int dh, int dw) {
+    const char* off = getenv("MI_CONV_NO_DIRECT");      // A/B switch: keep the implicit GEMM
+    if (off && atoi(off) != 0) return false;
+    if (Ci != C || Co != C || Hi != 8 || Wi != 8 || Di < TZ || Di % TZ) return false;
+    if (kd != 3 || kh != 3 || kw != 3 || stride != 1 || pd != 1 || ph != 1 || pw != 1 || dd != 1 || dh != 1 || dw != 1) return false;
+    if (N < 1 || 4l * N * Di * PLANE * C >= 0x7fff0000l) return false;
+    return true;
+}
+
+size_t mi_direct3_wimg_bytes() { return (size_t)WIMG_BYTES; }
+
+int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += PREP_MAX) {
+        PrepBatch b = {};
+        const int m = n - i0 < PREP_MAX ? n - i0 : PREP_MAX;
+        for (int i = 0; i < m; ++i) {
+            if (!w[i0 + i] || !img[i0 + i]) return MI_E_ARG;
+            b.w[i] = w[i0 + i]; b.img[i] = (unsigned char*)img[i0 + i]; b.dgrad[i] = dgrad[i0 + i];
+        }
+        hipLaunchKernelGGL(direct3_prep_kernel, dim3(NTAP * KS * 2 * 64 / 256, m), dim3(256), 0, s, b);
+        MI_RETURN_IF_LAUNCH_FAILED();
+    }
+    return MI_OK;
+}
+
+// `a` = X (forward) / dY (data gradient); wimg from mi_direct3_prep with the matching `dgrad` flag
+int mi_direct3_launch(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
+                      int D, hipStream_t s) {
+    Direct3Params p = {a, (const unsigned char*)wimg, out, res, mask, relu, N, D, (unsigned)(4l * N * D * PLANE * C)};
+    hipLaunchKernelGGL(direct3_kernel, dim3((unsigned)(N * (D / TZ))), dim3(256), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}

@@ -43,6 +43,15 @@ size_t mi_stem7_wgrad_workspace_bytes(int N, int D, int H, int W, int Co);
 int mi_stem7_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Co, void* ws,
                    size_t ws_bytes, hipStream_t s);
 
+// conv_direct3.hip: direct kernel for 3^3 / stride 1 / 64 -> 64 channels on 8 x 8 planes (layer1 of the MoCo-3D encoder),
+// forward and data gradient, bf16x3 arithmetic only
+bool mi_direct3_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph,
+                       int pw, int dd, int dh, int dw);
+size_t mi_direct3_wimg_bytes();
+int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, int n, hipStream_t s);
+int mi_direct3_launch(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
+                      int D, hipStream_t s);
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -1103,6 +1112,10 @@ bool is_stem7(const Geom& g) {
            g.dd == 1 && g.dh == 1 && g.dw == 1;
 }
 
+bool is_direct3(const Geom& g) {
+    return mi_direct3_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw);
+}
+
 // defer_splits != null (weight gradients only): a split launch leaves its slabs in `ws` un-reduced and reports the split
 // count - the caller sums many layers' slabs in one mi_splitk_reduce_batch launch; an unsplit launch (or the stem,
 // which reduces by itself) reports 1 and `out` is final.
@@ -1133,6 +1146,16 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
                               ws_bytes, s);
         else if (mode == MODE_WGRAD) rc = mi_stem7_wgrad(a_src, b_src, out, g.N, g.Di, g.Hi, g.Wi, g.Co, ws, ws_bytes, s);
         if (rc != MI_E_UNSUPPORTED) return rc;
+    }
+    // layer1-shaped convolutions (3^3, stride 1, 64 -> 64 channels, 8 x 8 planes): patch-resident direct kernel; the
+    // weight image goes into `ws` (a short ws keeps the implicit GEMM)
+    if (mode != MODE_WGRAD && conv_arith_bf16x3() && is_direct3(g) && ws && ws_bytes >= mi_direct3_wimg_bytes()) {
+        const float* wl[1] = {b_src};
+        void* il[1] = {ws};
+        const int dg[1] = {mode == MODE_DGRAD ? 1 : 0};
+        int rc = mi_direct3_prep(wl, il, dg, 1, s);
+        if (rc) return rc;
+        return mi_direct3_launch(a_src, ws, out, res, mask, relu, g.N, g.Di, s);
     }
     Setup st;
     int rc = setup_conv(mode, g, &st);
@@ -1171,6 +1194,7 @@ extern "C" size_t mi_conv3d_workspace_bytes(int N, int Di, int Hi, int Wi, int C
     Geom g = make_geom(N, Di, Hi, Wi, Ci, Co, k, stride, pad);
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
+    if (is_direct3(g)) best = std::max(best, mi_direct3_wimg_bytes());
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;
@@ -1210,6 +1234,7 @@ extern "C" size_t mi_convnd_workspace_bytes(int N, int Di, int Hi, int Wi, int C
     Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
+    if (is_direct3(g)) best = std::max(best, mi_direct3_wimg_bytes());
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;
@@ -1280,6 +1305,7 @@ extern "C" size_t mi_convnd_dil_workspace_bytes(int N, int Di, int Hi, int Wi, i
     Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, 1, pd, ph, pw, dd, dh, dw);
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
+    if (is_direct3(g)) best = std::max(best, mi_direct3_wimg_bytes());
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;
