@@ -9,7 +9,7 @@
 // spend their issue slots on the cut, the gather addresses and LDS traffic).  Here the INPUT PATCH of a tile is cut once
 // and stays in LDS for all 27 taps:
 //   * one 256-thread workgroup owns two z-planes of one sample (128 output voxels x 64 channels); its patch is the four
-//     z-planes around them (256 voxels x 64 channels, three bf16 planes = 96 KB + zero regions = 109 KB of LDS), planes
+//     z-planes around them (256 voxels x 64 channels, three bf16 planes = 96 KB + zero regions = 115 KB of LDS), planes
 //     outside the volume zero-filled.  The 8 x 8 plane is the whole image, so the x / y halo is pure padding: a lane
 //     whose neighbour falls outside reads a zero record instead (one address select per tap and row block, no data
 //     select).
@@ -17,10 +17,12 @@
 //     MFMA A-fragment (row = voxel, 8 consecutive channels) is ONE ds_read_b128 at lane base + immediate; consecutive
 //     voxels are consecutive records, so the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots.
 //   * the weights never pass through LDS: a prep kernel cuts them once into an image in MFMA B-fragment order
-//     ([tap][k-step][column half][bf16 plane][lane] x 16 bytes), and every wave streams its 1-KB fragments straight
+//     ([channel chunk][tap][column half][bf16 plane][lane] x 16 bytes), and every wave streams its 1-KB fragments straight
 //     from L2 into registers, six k-steps ahead of their use (the two waves that share a column half hit in the CU's L1).
-//   * the main loop therefore has no barrier, no LDS store, no gather and no cut: per k-step and wave 6 ds_read_b128,
-//     3 buffer loads and 12 MFMAs (wave tile 64 voxels x 32 channels).
+//   * the reduction runs channel chunk (16 channels) outermost: chunk 0 of the patch is staged before the loop, chunk
+//     c + 1 is loaded, cut and stored in the shadow of chunk c's 27 x 12 MFMAs (three workgroup barriers in all).  Per
+//     k-step and wave: 6 ds_read_b128, 3 buffer loads and 12 MFMAs (wave tile 64 voxels x 32 channels) - no gather, and
+//     a cut of 4 elements per thread and k-step instead of 16.
 // DGRAD is the same kernel on dY with the weight image built transposed and tap-flipped:
 //   dX[i] = sum_t dY[i + 1 - t] W[t]^T = sum_t' dY[i + t' - 1] W[2 - t']^T.
 #include "common.h"
@@ -37,22 +39,24 @@ constexpr int PLANE = 64;                   // voxels of an 8 x 8 z-plane
 constexpr int TZ = 2;                       // output z-planes per workgroup
 constexpr int PZ = TZ + 2;                  // patch z-planes
 constexpr int NV = PZ * PLANE;              // 256 patch voxels
-constexpr int LEAD = 9;                     // records in front of voxel 0: lane bases carry the -9 of the tap offsets
-constexpr int ZREC = 19;                    // zero records behind the voxels: zero base + tap offset (0..18) stays inside
-constexpr int NREC = LEAD + NV + ZREC;      // 284
+constexpr int LEAD = 16;                    // records in front of voxel 0 (lane bases carry the -9 of the tap offsets)
+constexpr int ZREC = 34;                    // zero records behind the voxels: (record mod 16) + tap offset (0..18) stays inside
+constexpr int NREC = LEAD + NV + ZREC;      // 306
 constexpr int ARR = NREC * 16;              // bytes of one (k-step, plane, k-half) array
-constexpr int KS = C / 16;                  // bf16 MFMA k-steps per tap
+constexpr int KS = C / 16;                  // bf16 MFMA k-steps per tap = channel chunks of the patch
 constexpr int PL_BYTES = 2 * ARR;
 constexpr int KS_BYTES = 3 * PL_BYTES;
-constexpr int LDS_BYTES = KS * KS_BYTES;    // 109,056
-constexpr int ZBASE = (LEAD + NV) * 16;     // byte offset of the zero region in an array
+constexpr int LDS_BYTES = KS * KS_BYTES;    // 117,504
+constexpr int ZBASE = (LEAD + NV) * 16;     // byte offset of the zero region in an array: record 272 = 0 (mod 16)
 constexpr int WBLK = 1024;                  // one B fragment: 64 lanes x 16 bytes
-constexpr int WSTEP = 2 * 3 * WBLK;         // bytes per (tap, k-step): [column half][plane]
+constexpr int WSTEP = 2 * 3 * WBLK;         // bytes per k-step: [column half][plane]
 constexpr int NTAP = 27;
-constexpr int WIMG_BYTES = NTAP * KS * WSTEP;      // 663,552
-constexpr int RB = 6;                       // weight fragments in flight: k-steps ahead (36 k-steps per dz: 36 % RB == 0)
-static_assert(36 % RB == 0, "ring slots must line up across the dz loop");
+constexpr int NSTEP = KS * NTAP;            // 108 k-steps, chunk-major: g = chunk * 27 + tap
+constexpr int WIMG_BYTES = NSTEP * WSTEP;   // 663,552
+constexpr int RB = 6;                       // weight fragments in flight: k-steps ahead (9 and 12 measured: no faster)
+static_assert(NSTEP % RB == 0, "ring slots");
 static_assert(LDS_BYTES <= 160 * 1024, "patch must fit the CU's LDS");
+static_assert(((LEAD + NV) & 15) == 0, "zero region must start at a record = 0 (mod 16)");
 
 struct Direct3Params {
     const float* a;           // X (forward) or dY (data gradient): (N, D, 8, 8, 64)
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void direct3_kernel(Direct3Params p) {
 
     const __amdgpu_buffer_rsrc_t wrs = rsrc_of(p.wimg, WIMG_BYTES);
     const int w_voff = cw * (3 * WBLK) + lane * 16;
-    // weight fragments of k-step g (tap * 4 + ks, 0..107; behind the image: zeros) -> ring slot g % RB
+    // weight fragments of k-step g (0..107; behind the image: zeros) -> ring slot g % RB
     bf16x8 bfr[RB][3];
     auto wload = [&](int g, auto SLOTc) {
         constexpr int SLOT = decltype(SLOTc)::value;
@@ -108,55 +112,73 @@ __global__ __launch_bounds__(256, 1) void direct3_kernel(Direct3Params p) {
         for (int pl = 0; pl < 3; ++pl)
             bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, w_voff + pl * WBLK, g * WSTEP, 0));
     };
-    // the first RB - 1 k-steps of weights go out before the patch is staged
-    wload(0, std::integral_constant<int, 0>{});
-    wload(1, std::integral_constant<int, 1>{});
-    wload(2, std::integral_constant<int, 2>{});
-    wload(3, std::integral_constant<int, 3>{});
-    wload(4, std::integral_constant<int, 4>{});
+    auto wload_dyn = [&](int g) {                        // (g is a constant after unrolling)
+        switch (g % RB) {
+            case 0: wload(g, std::integral_constant<int, 0>{}); break;
+            case 1: wload(g, std::integral_constant<int, 1>{}); break;
+            case 2: wload(g, std::integral_constant<int, 2>{}); break;
+            case 3: wload(g, std::integral_constant<int, 3>{}); break;
+            case 4: wload(g, std::integral_constant<int, 4>{}); break;
+            default: wload(g, std::integral_constant<int, 5>{}); break;
+        }
+    };
+    // the first RB - 1 k-steps of weights go out before anything else
+#pragma unroll
+    for (int g = 0; g < RB - 1; ++g) wload_dyn(g);
 
-    // ---- stage the patch: unit q = (voxel, group of 8 channels); 8 units per thread, all loads first ----
-    {
-        const __amdgpu_buffer_rsrc_t ars = rsrc_of(p.a, p.a_bytes);
-        constexpr int UNITS = NV * 8 / 256;
-        u32x4 ld[UNITS][2];
+    // ---- patch staging, one 16-channel chunk at a time: unit q = (voxel, k-half); 2 units per thread and chunk.
+    // Chunk 0 is staged here; chunk c + 1 is loaded and cut in the shadow of chunk c's MFMAs.
+    const __amdgpu_buffer_rsrc_t ars = rsrc_of(p.a, p.a_bytes);
+    unsigned st_off[2];
+    int st_lds[2];
 #pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-            const int q = tid + 256 * u, vox = q >> 3, cig = q & 7;
-            const int z = z0 - 1 + (vox >> 6);
-            const bool ok = (unsigned)z < (unsigned)p.D;
-            const unsigned off = ok ? 4u * (unsigned)((((long)n * p.D + z) * PLANE + (vox & 63)) * C + cig * 8) : 0x80000000u;
-            ld[u][0] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)off, 0, 0);
-            ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(off + 16u), 0, 0);
-        }
-        // zero regions and the unused leading records of the 24 arrays
-        for (int i = tid; i < KS * 3 * 2 * (LEAD + ZREC); i += 256) {
-            const int arr = i / (LEAD + ZREC), r = i % (LEAD + ZREC);
-            const int rec = r < LEAD ? r : LEAD + NV + (r - LEAD);
-            *reinterpret_cast<u32x4*>(patch + arr * ARR + rec * 16) = u32x4{0u, 0u, 0u, 0u};
-        }
+    for (int u = 0; u < 2; ++u) {
+        const int q = tid + 256 * u, vox = q >> 1, hh = q & 1;
+        const int z = z0 - 1 + (vox >> 6);
+        const bool ok = (unsigned)z < (unsigned)p.D;      // planes outside the volume: zeros (offset out of range)
+        st_off[u] = ok ? 4u * (unsigned)((((long)n * p.D + z) * PLANE + (vox & 63)) * C + hh * 8) : 0x80000000u;
+        st_lds[u] = hh * ARR + (LEAD + vox) * 16;
+    }
+    u32x4 ld[2][2];
+    auto stage_load = [&](int c) {
 #pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-            const int q = tid + 256 * u, vox = q >> 3, cig = q & 7;
+        for (int u = 0; u < 2; ++u) {
+            ld[u][0] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(st_off[u] + 64u * c), 0, 0);
+            ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(st_off[u] + 64u * c + 16u), 0, 0);
+        }
+    };
+    auto stage_store = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ld[u][0][e]); v[4 + e] = __uint_as_float(ld[u][1][e]); }
             u32x4 o[3];
             cut8(v, o);
-            unsigned char* dst = patch + (cig >> 1) * KS_BYTES + (cig & 1) * ARR + (LEAD + vox) * 16;
+            unsigned char* dst = patch + c * KS_BYTES + st_lds[u];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * PL_BYTES) = o[pl];
         }
+    };
+    stage_load(0);
+    // zero regions of the 24 arrays (the leading records are never read)
+    for (int i = tid; i < KS * 3 * 2 * ZREC; i += 256) {
+        const int arr = i / ZREC, r = i % ZREC;
+        *reinterpret_cast<u32x4*>(patch + arr * ARR + ZBASE + r * 16) = u32x4{0u, 0u, 0u, 0u};
     }
 
     // ---- per-lane geometry: row block i (rows 32 i .. 32 i + 31 of the wave's z-plane), MFMA row l32 ----
-    int vbase[2], zaddr;
+    // vbase = record (LEAD + voxel - 9) of the lane's output voxel in patch plane tz; a tap adds (dz 64 + dy 8 + dx) records.
+    // zbase = the zero record with the same (record mod 16): a lane whose neighbour is padding keeps its LDS slot, so the
+    // 16 lanes of a ds_read_b128 group stay on 16 distinct slots (a shared zero record cost 46 % extra LDS cycles).
+    int vbase[2], zbase[2];
     unsigned vmask[2];                  // bit dy * 3 + dx: the (dy, dx) neighbour is inside the 8 x 8 plane
-    zaddr = ZBASE + h * ARR;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int y = 4 * i + (l32 >> 3), x = l32 & 7;
-        vbase[i] = (tz * PLANE + y * 8 + x) * 16 + h * ARR;          // record (LEAD + voxel) - 9, k-half h
+        const int rec = LEAD - 9 + tz * PLANE + y * 8 + x;
+        vbase[i] = rec * 16 + h * ARR;
+        zbase[i] = ZBASE + (rec & 15) * 16 + h * ARR;
         unsigned m = 0;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
@@ -166,76 +188,119 @@ __global__ __launch_bounds__(256, 1) void direct3_kernel(Direct3Params p) {
         vmask[i] = m;
     }
 
-    f32x16 acc[2];
+    f32x16 acc[2];                      // (two chains per row block measured: no faster)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // smallest products first
 
-    bf16x8 af[2][2][3];
-    __syncthreads();                    // the only barrier: patch complete
+    // epilogue operands (residual, mask), fetched during the last chunk; a null pointer reads zeros (empty descriptor)
+    const long m0 = ((long)n * p.D + z0 + tz) * PLANE;
+    const int col = cw * 32 + l32;
+    unsigned eoff[2][16];
+    float rv[2][16], mv[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) eoff[i][r] = 4u * (unsigned)((m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * C + col);
+    const __amdgpu_buffer_rsrc_t rrs = rsrc_of(p.res, p.res ? p.a_bytes : 0u), mrs = rsrc_of(p.mask, p.mask ? p.a_bytes : 0u);
 
-    for (int dz = 0; dz < 3; ++dz) {
-        // address of the (dy, dx) neighbour's record for this dz, or the zero region
-        int sel[9][2];
+    stage_store(0);
+    stage_load(1);
+    __syncthreads();                    // chunk 0 and the zero regions are in place
+
+    bf16x8 af[2][2][3];
+    int sel[9][2];
+    auto make_sel = [&](int dz) {       // address of the (dy, dx) neighbour's record for this dz, or the lane's zero record
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) sel[t9][i] = ((vmask[i] >> t9) & 1u) ? vbase[i] + dz * (PLANE * 16) : zaddr;
-        auto frags = [&](int j, auto SETc) {
-            constexpr int SET = decltype(SETc)::value;
-            const int t9 = j >> 2, ks = j & 3;
-            const int imm = ((t9 / 3) * 8 + (t9 % 3)) * 16 + ks * KS_BYTES;
+            for (int i = 0; i < 2; ++i) sel[t9][i] = ((vmask[i] >> t9) & 1u) ? vbase[i] + dz * (PLANE * 16) : zbase[i];
+    };
+    auto frags = [&](int c, int t9, auto SETc) {
+        constexpr int SET = decltype(SETc)::value;
+        const int imm = ((t9 / 3) * 8 + (t9 % 3)) * 16 + c * KS_BYTES;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    af[SET][i][pl] = *reinterpret_cast<const bf16x8*>(patch + sel[t9][i] + imm + pl * PL_BYTES);
-        };
-        frags(0, std::integral_constant<int, 0>{});
-        __builtin_amdgcn_sched_barrier(0);
+            for (int pl = 0; pl < 3; ++pl)
+                af[SET][i][pl] = *reinterpret_cast<const bf16x8*>(patch + sel[t9][i] + imm + pl * PL_BYTES);
+    };
+    auto frags_dyn = [&](int g, int c, int t9) {
+        if (g & 1) frags(c, t9, std::integral_constant<int, 1>{});
+        else frags(c, t9, std::integral_constant<int, 0>{});
+    };
+
+    make_sel(0);
+    frags_dyn(0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 36; ++j) {
-            const int g = dz * 36 + j;
-            // weights of k-step g + RB - 1 into the slot k-step g - 1 used; A fragments of k-step j + 1 into the other set
-            switch ((j + RB - 1) % RB) {
-                case 0: wload(g + RB - 1, std::integral_constant<int, 0>{}); break;
-                case 1: wload(g + RB - 1, std::integral_constant<int, 1>{}); break;
-                case 2: wload(g + RB - 1, std::integral_constant<int, 2>{}); break;
-                case 3: wload(g + RB - 1, std::integral_constant<int, 3>{}); break;
-                case 4: wload(g + RB - 1, std::integral_constant<int, 4>{}); break;
-                default: wload(g + RB - 1, std::integral_constant<int, 5>{}); break;
+    for (int c = 0; c < KS; ++c) {
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const int g = c * NTAP + dz * 9 + t9;
+                // weights of k-step g + RB - 1 go into the slot k-step g - 1 used
+                wload_dyn(g + RB - 1);
+                // the next chunk of the patch: cut + stored a third into this chunk's taps (its loads have been in flight
+                // since the previous chunk), the loads of the chunk after it right behind
+                if (dz == 1 && t9 == 0 && c + 1 < KS) {
+                    stage_store(c + 1);
+                    if (c + 2 < KS) stage_load(c + 2);
+                }
+                if (c == KS - 1 && dz == 0 && t9 == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            rv[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, (int)eoff[i][r], 0, 0));
+                            mv[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mrs, (int)eoff[i][r], 0, 0));
+                        }
+                }
+                // A fragments of the next k-step into the other register set
+                if (g + 1 < NSTEP) {
+                    const int c2 = (g + 1) / NTAP, r2 = (g + 1) % NTAP;
+                    if (r2 == 0) __syncthreads();            // next chunk of the patch visible (stored >= 17 k-steps ago)
+                    if (r2 % 9 == 0) make_sel(r2 / 9);
+                    frags_dyn(g + 1, c2, r2 % 9);
+                }
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][0][PA[pr]], bfr[g % RB][PB[pr]], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][1][PA[pr]], bfr[g % RB][PB[pr]], acc[1], 0, 0, 0);
+                }
+                // issue order inside the k-step: every load behind an MFMA (the matrix pipe keeps running while the
+                // LDS / buffer instructions issue); all nine in front of the first MFMA cost 3 us per launch
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one buffer load
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (j + 1 < 36) {
-                if ((j + 1) & 1) frags(j + 1, std::integral_constant<int, 1>{});
-                else frags(j + 1, std::integral_constant<int, 0>{});
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int pr = 0; pr < 6; ++pr) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j & 1][0][PA[pr]], bfr[j % RB][PB[pr]], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j & 1][1][PA[pr]], bfr[j % RB][PB[pr]], acc[1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h ----
-    const long m0 = ((long)n * p.D + z0 + tz) * PLANE;
-    const int col = cw * 32 + l32;
+    const bool has_mask = p.mask != nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long o = (m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * C + col;
-            float v = acc[i][r];
-            if (p.res) v += p.res[o];
+            float v = acc[i][r] + rv[i][r];
             if (p.relu) v = fmaxf(v, 0.f);
-            if (p.mask) v = (p.mask[o] > 0.f) ? v : 0.f;
-            p.out[o] = v;
+            if (has_mask) v = (mv[i][r] > 0.f) ? v : 0.f;
+            p.out[eoff[i][r] / 4] = v;
         }
 }
 
-// ---- weight image: W[tap][ci][co] f32 -> bf16x3 B fragments, [tap][k-step][column half][plane][lane] x 16 bytes ----
+// ---- weight image: W[tap][ci][co] f32 -> bf16x3 B fragments, [k-step (channel chunk)][tap][column half][plane][lane] x 16 bytes ----
 constexpr int PREP_MAX = 16;
 struct PrepBatch {
     const float* w[PREP_MAX];
@@ -247,7 +312,7 @@ __global__ __launch_bounds__(256) void direct3_prep_kernel(PrepBatch b) {
     unsigned char* img = b.img[blockIdx.y];
     const int dgrad = b.dgrad[blockIdx.y];
     const int idx = blockIdx.x * 256 + threadIdx.x;          // (tap, ks, cw, lane); 27 * 4 * 2 * 64 = 54 * 256
-    const int lane = idx & 63, cw = (idx >> 6) & 1, ks = (idx >> 7) & 3, tap = idx >> 9;
+    const int lane = idx & 63, cw = (idx >> 6) & 1, ks = (idx >> 7) & 3, tap = idx >> 9;      // image order: [ks][tap]
     const int nn = cw * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
     float v[8];
     if (dgrad) {        // B'[tap][k = co][n = ci] = W[26 - tap][ci = n][co = k]
@@ -260,7 +325,7 @@ __global__ __launch_bounds__(256) void direct3_prep_kernel(PrepBatch b) {
     }
     u32x4 o[3];
     cut8(v, o);
-    unsigned char* dst = img + (long)((tap * KS + ks) * 2 + cw) * (3 * WBLK) + lane * 16;
+    unsigned char* dst = img + (long)((ks * NTAP + tap) * 2 + cw) * (3 * WBLK) + lane * 16;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * WBLK) = o[pl];
 }
@@ -301,4 +366,24 @@ int mi_direct3_launch(const float* a, const void* wimg, float* out, const float*
     hipLaunchKernelGGL(direct3_kernel, dim3((unsigned)(N * (D / TZ))), dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
+}
+
+// ---- C-ABI (include/cetpick_hip.h): the image kept by the caller across calls ----
+extern "C" size_t mi_conv3d_direct_wimg_bytes(void) { return mi_direct3_wimg_bytes(); }
+
+extern "C" int mi_conv3d_direct_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
+    return mi_direct3_usable(N, Di, Hi, Wi, Ci, Co, k, k, k, stride, pad, pad, pad, 1, 1, 1) ? 1 : 0;
+}
+
+extern "C" int mi_conv3d_direct_prep(const void* const* w, void* const* img, const int* dgrad, int n, mi_stream_t stream) {
+    if (!w || !img || !dgrad || n < 0) return MI_E_ARG;
+    if (n == 0) return MI_OK;
+    return mi_direct3_prep(reinterpret_cast<const float* const*>(w), img, dgrad, n, (hipStream_t)stream);
+}
+
+extern "C" int mi_conv3d_direct_f32(const float* a, const void* wimg, float* out, const float* res, const float* mask,
+                                    int relu, int N, int D, mi_stream_t stream) {
+    if (!a || !wimg || !out) return MI_E_ARG;
+    if (!mi_direct3_usable(N, D, 8, 8, C, C, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1)) return MI_E_UNSUPPORTED;
+    return mi_direct3_launch(a, wimg, out, res, mask, relu, N, D, (hipStream_t)stream);
 }

@@ -205,6 +205,63 @@ def _out_dims(shape5, k3, stride, p3):
     return tuple((v + 2 * p - k) // stride + 1 for v, k, p in zip((d, h, w), k3, p3))
 
 
+# Pre-cut weight images of the layer1-shaped convolutions (conv_direct3.hip).  Without a cache the C side rebuilds the image
+# of a weight on every convolution call (one extra launch); an owner that knows when the weights change - MocoStepEngine:
+# after the EMA kernel and after the SGD kernel - keeps them here and re-cuts a whole group in ONE launch.  The cache is
+# only consulted while ACTIVE_IMAGES is set (the engine sets it around its step), so a stale image can never reach a
+# convolution issued from anywhere else.
+ACTIVE_IMAGES = None
+
+
+class WeightImages:
+    def __init__(self):
+        self._groups = {}            # group -> list of (weight, dgrad flag, image tensor)
+        self._by_weight = {}         # (weight storage address, dgrad) -> image tensor
+        self.launches = 0
+
+    @staticmethod
+    def eligible(w, k, stride, pad):
+        return (w.is_cuda and tuple(w.shape[:2]) == (64, 64) and _k3(k, True) == (3, 3, 3) and stride == 1
+                and _p3(pad, True) == (1, 1, 1) and _phys_ok(w))
+
+    def add(self, group, w, dgrad):
+        nb = L.lib().mi_conv3d_direct_wimg_bytes()
+        img = torch.empty(nb, dtype=torch.uint8, device=w.device)
+        self._groups.setdefault(group, []).append((w, int(bool(dgrad)), img))
+        self._by_weight[(w.data_ptr(), int(bool(dgrad)))] = img
+
+    def get(self, w, dgrad, n, d, h, wd):
+        img = self._by_weight.get((w.data_ptr(), int(bool(dgrad))))
+        if img is None or not L.lib().mi_conv3d_direct_usable(n, d, h, wd, 64, 64, 3, 1, 1):
+            return None
+        return img
+
+    def refresh(self, group):
+        """Re-cut every image of `group` from the current weights: one launch (per 16 images) on the current stream."""
+        items = self._groups.get(group)
+        if not items:
+            return
+        import ctypes
+        n = len(items)
+        ws = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in items])
+        imgs = (ctypes.c_void_p * n)(*[it[2].data_ptr() for it in items])
+        dg = (ctypes.c_int * n)(*[it[1] for it in items])
+        L.check(L.lib().mi_conv3d_direct_prep(ctypes.cast(ws, ctypes.c_void_p), ctypes.cast(imgs, ctypes.c_void_p),
+                                              ctypes.cast(dg, ctypes.c_void_p), n, L.stream()), "mi_conv3d_direct_prep")
+        self.launches += (n + 15) // 16
+
+    def versions(self):
+        """Sum of the torch version counters of the cached weights: changes when anything but the engine's own kernels
+        (which refresh by themselves) wrote a weight."""
+        return sum(it[0]._version for items in self._groups.values() for it in items)
+
+
+def _cached_image(w, dgrad, n, d, h, wd, k3, stride, p3):
+    if ACTIVE_IMAGES is None or PROFILE is not None or k3 != (3, 3, 3) or stride != 1 or p3 != (1, 1, 1):
+        return None
+    return ACTIVE_IMAGES.get(w, dgrad, n, d, h, wd)
+
+
 def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None):
     """y = act(conv(x, w) + res).  x: (N,D,H,W,Ci) or (N,H,W,Ci) channels-last; w in kernel layout.
     dil: per-axis dilation (stride 1 only)."""
@@ -231,6 +288,11 @@ def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None):
         return y
     do, ho, wo = _out_dims(x5.shape, k3, stride, p3)
     y = torch.empty((n, do, ho, wo, co) if nd5 else (n, ho, wo, co), dtype=torch.float32, device=x.device)
+    img = _cached_image(w, False, n, d, h, wd, k3, stride, p3) if nd5 else None
+    if img is not None:
+        L.check(lib.mi_conv3d_direct_f32(L.ptr(x), L.ptr(img), L.ptr(y), L.ptr(res), None, int(relu), n, d, L.stream()),
+                "mi_conv3d_direct_f32")
+        return y
     ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), x.device, "conv")
     def call():
         return L.check(lib.mi_convnd_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(res), int(relu), n, d, h, wd, ci,
@@ -256,6 +318,11 @@ def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None, dil=None):
             return L.check(lib.mi_convnd_dil_dgrad_f32(L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(res), L.ptr(mask), n, d,
                 h, wd, ci, co, *k3, *p3, *d3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_dil_dgrad_f32")
         _prof_run("dgrad", flops, call)
+        return dx
+    img = _cached_image(w, True, n, d, h, wd, k3, stride, p3) if (nd5 and dil is None) else None
+    if img is not None:
+        L.check(lib.mi_conv3d_direct_f32(L.ptr(dy), L.ptr(img), L.ptr(dx), L.ptr(res), L.ptr(mask), 0, n, d, L.stream()),
+                "mi_conv3d_direct_f32")
         return dx
     ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), dy.device, "conv")
     def call():

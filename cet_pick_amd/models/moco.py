@@ -41,6 +41,8 @@ class MoCo(nn.Module):
         """models/moco.py:31-39: k <- m*k + (1-m)*q over parameters (buffers untouched)."""
         if self._arena_q is not None:
             H.ema_update_(self._arena_k.flat, self._arena_q.flat, self.m)
+            if self.weight_images is not None and H.ACTIVE_IMAGES is self.weight_images:
+                self.weight_images.refresh("k")        # encoder_k's pre-cut conv weights follow the update (one launch)
             return
         for param_q, param_k in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
             # un-flattened model: one launch per tensor over its (dense) storage
@@ -64,6 +66,7 @@ class MoCo(nn.Module):
     # order, which is the order the process group's communicator stream runs them in.
     overlap_key_branch = True
     _side = None
+    weight_images = None           # hipops.WeightImages of a MocoStepEngine (conv_direct3.hip), else None
 
     def _zero_labels(self, logits):
         """labels = zeros(B) (models/moco.py:140-141), allocated once per batch size instead of filled every step"""

@@ -43,6 +43,33 @@ class MocoStepEngine:
         self.buckets_sent = []           # tags of the last step's exchanges, in issue order (tests / diagnostics)
         if self.dist_on:
             self._setup_buckets()
+        self._images = self._build_weight_images()
+        self._img_versions = None
+
+    # ---- pre-cut weight images of the layer1 convolutions (conv_direct3.hip) ---------------------------------
+    def _build_weight_images(self):
+        """Group "q": forward + data-gradient images of encoder_q's 64 -> 64 3^3 convolutions (re-cut behind the SGD
+        kernel), group "k": forward images of encoder_k's (re-cut behind the EMA kernel) - one launch each per step
+        instead of one image build in front of each of the 12 direct-kernel launches."""
+        if not self.arena_q.flat.is_cuda:
+            return None
+        imgs = H.WeightImages()
+        for enc, group in ((self.moco.encoder_q, "q"), (self.moco.encoder_k, "k")):
+            for m in enc.modules():
+                if isinstance(m, H.HipConv3d) and H.WeightImages.eligible(m.weight, m.k, m.stride, m.pad):
+                    imgs.add(group, m.weight, False)
+                    if group == "q":
+                        imgs.add(group, m.weight, True)
+        self.moco.weight_images = imgs                 # MoCo re-cuts group "k" right behind its momentum update
+        return imgs
+
+    def refresh_weight_images(self):
+        """Call after writing the encoders' weights from outside the step (checkpoint load, broadcast): the step itself
+        keeps the images current, and notices writes made through torch ops by their version counters."""
+        if self._images is not None:
+            self._images.refresh("q")
+            self._images.refresh("k")
+            self._img_versions = self._images.versions()
 
     # ---- data parallel: bucketed gradient all-reduce overlapped with the backward pass ---------------------
     def _setup_buckets(self):
@@ -91,6 +118,7 @@ class MocoStepEngine:
         d.broadcast(self.arena_k.flat, src)
         for b in self.moco.buffers():
             d.broadcast(b, src)
+        self.refresh_weight_images()
 
     def set_lr(self, lr):
         """utils/utils.py:58-70 `adjust_learning_rate` target: the schedule reaches a captured graph
@@ -102,14 +130,16 @@ class MocoStepEngine:
         moco = self.moco
         self.buckets_sent = []
         self.arena_q.zero_grad()
-        logits, labels = moco(im_q, im_k)
-        loss = H.cross_entropy_label0(logits, out=self._loss_buf)      # lands in the engine's loss buffer: no copy
-        H.DEFERRED_WGRADS = [] if self.arena_q.flat_grad.is_cuda else None     # split-K slabs of the wgrads: one reduce
+        H.ACTIVE_IMAGES = self._images                 # the cached weight images are valid inside the step only
         try:
+            logits, labels = moco(im_q, im_k)
+            loss = H.cross_entropy_label0(logits, out=self._loss_buf)      # lands in the engine's loss buffer: no copy
+            H.DEFERRED_WGRADS = [] if self.arena_q.flat_grad.is_cuda else None     # split-K slabs of the wgrads: one reduce
             loss.backward()
             H.flush_wgrad_reduces()
         finally:
             H.DEFERRED_WGRADS = None
+            H.ACTIVE_IMAGES = None
         if self.dist_on:
             # layer3+heads, layer2 and layer1 went out from the autograd hooks while the backward was still running
             # (RCCL over xGMI on its own stream); the stem's gradients are the last to exist
@@ -118,6 +148,8 @@ class MocoStepEngine:
                 torch.cuda.current_stream().wait_stream(self._xchg)
             self.arena_q.flat_grad.mul_(1.0 / self.world)
         H.sgd_step_(self.arena_q.flat, self.arena_q.flat_grad, self.lr, self.weight_decay, self.lr_dev)
+        if self._images is not None:
+            self._images.refresh("q")                  # next step's forward / data-gradient images of encoder_q
         return self.loss
 
     def _capture(self, im_q, im_k):
@@ -157,6 +189,8 @@ class MocoStepEngine:
         Graph mode: the first two calls run eagerly (they size every workspace), the third call
         captures the step into a hipGraph and from then on each call is one graph replay.  A batch whose
         shape differs from the captured one (a short last batch) runs eagerly."""
+        if self._images is not None and self._images.versions() != self._img_versions:
+            self.refresh_weight_images()               # first step, or the weights were written through torch ops
         if not self.use_graph:
             return self._step_eager(im_q, im_k)
         if self._graph is None:

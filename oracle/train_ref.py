@@ -32,7 +32,7 @@ def _block(sd, prefix, x, stride):
     return F.relu(out + res)
 
 
-def encoder_forward(sd, x, train=True, acts=None):
+def encoder_forward(sd, x, train=True, acts=None, pre=None):
     """moco_encoder_3d.py:353-404 (`forward`) / :326-351 (`forward_test` when train=False).
     sd: dict name -> tensor with the reference's logical shapes; running stats are updated in
     place when train.  Returns proj (B,128)."""
@@ -52,8 +52,12 @@ def encoder_forward(sd, x, train=True, acts=None):
     x = rec("feature_3d", F.relu(_bn(sd, "feature_3d.1", x, train, BN_MOMENTUM)))
     x = F.adaptive_avg_pool3d(x, 1).reshape(x.shape[0], -1)
     x = rec("fc", F.linear(x, sd["fc.weight"], sd["fc.bias"]))
-    x = F.relu(_bn(sd, "proj.1", F.linear(x, sd["proj.0.weight"]), train, 0.1))
-    x = F.relu(_bn(sd, "proj.4", F.linear(x, sd["proj.3.weight"]), train, 0.1))
+    def rec_pre(name, t):       # `pre`: the BatchNorm outputs in front of the head's ReLUs (a test reads their distance from zero)
+        if pre is not None:
+            pre[name] = t
+        return t
+    x = F.relu(rec_pre("proj.1.pre", _bn(sd, "proj.1", F.linear(x, sd["proj.0.weight"]), train, 0.1)))
+    x = F.relu(rec_pre("proj.4.pre", _bn(sd, "proj.4", F.linear(x, sd["proj.3.weight"]), train, 0.1)))
     x = _bn(sd, "proj.7", F.linear(x, sd["proj.6.weight"]), train, 0.1, affine=False)
     return x
 
@@ -85,11 +89,12 @@ class MocoRef:
         self.m, self.T, self.lr = m, T, lr
         self.names = param_names(self.q)
 
-    def step(self, im_q, im_k):
+    def step(self, im_q, im_k, pre=None):
+        """pre: optional dict that receives the query head's ReLU inputs (encoder_forward)."""
         for n in self.names:
             self.q[n] = self.q[n].detach().requires_grad_(True)
         self.q.update({("pred" + n[4:]): self.q[n] for n in self.names if n.startswith("proj.")})
-        qf = F.normalize(encoder_forward(self.q, im_q, True), dim=1)
+        qf = F.normalize(encoder_forward(self.q, im_q, True, None, pre), dim=1)
         with torch.no_grad():
             for n in self.names:                                    # moco.py:31-39
                 self.k[n] = self.k[n] * self.m + self.q[n].detach() * (1.0 - self.m)
