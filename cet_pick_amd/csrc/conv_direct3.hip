@@ -330,6 +330,211 @@ __global__ __launch_bounds__(256) void direct3_prep_kernel(PrepBatch b) {
     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * WBLK) = o[pl];
 }
 
+
+// ---- weight gradient of the same convolutions -----------------------------------------------------------------------
+//   dW[tap][ci][co] = sum over output voxels m of X[m + tap - 1][ci] * dY[m][co]
+// The reduction runs over voxels, so both operands are needed k-major (k = voxel) while memory is channel-major: both are
+// staged as [voxel][32 channels] bf16 rows of 64 bytes per channel half and bf16 plane, and the fragments come out of
+// LDS through the transposing read (ds_read_b64_tr_b16: a lane names its own row, so a tap's x shift and the padding -
+// a zero row - cost one address select, made once per kernel).
+// Work split: a workgroup owns ONE (dz, dy) pair - the three dx taps, all 64 x 64 channels: its four waves are the four
+// 32 x 32 (ci half, co half) blocks, three accumulators each - and every 28th z-plane of the batch (a plane of dY with
+// the plane of X that dz pairs it with; planes whose partner lies outside the volume are skipped).  9 x 28 = 252
+// workgroups; each writes its 3 taps of split-K slab s, 28 slabs in all (12 MB), summed by the caller's reduce launch.
+// A z-plane (64 voxels = 4 k-steps of 16) is the staging unit: plane t + 1 is cut and stored into the other LDS buffer
+// and plane t + 2 fetched in the shadow of plane t's 72 MFMAs per wave; one barrier per plane.
+constexpr int WG_SPLITS = 28;
+constexpr int WROW = 64;                    // bytes of a (voxel, 32 channels) row
+constexpr int WHALF = (PLANE + 1) * WROW;   // one channel half of a plane: 64 voxel rows + a zero row
+constexpr int WPL = 2 * WHALF;              // one bf16 plane
+constexpr int WOP = 3 * WPL;                // one operand (X or dY) of one z-plane
+constexpr int WBUF = 2 * WOP;               // one staging buffer
+constexpr int WZERO = PLANE * WROW;         // byte offset of the zero row in a half
+
+struct Direct3WgradParams {
+    const float* x;           // (N, D, 8, 8, 64)
+    const float* dy;          // (N, D, 8, 8, 64)
+    float* slabs;             // WG_SPLITS slabs of [27][64][64] floats
+    int N, D;
+    unsigned bytes;           // extent of x / dy
+};
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__global__ __launch_bounds__(256, 1) void direct3_wgrad_kernel(Direct3WgradParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WBUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31, i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int wm = wave >> 1, wn = wave & 1;             // wave block: ci half wm x co half wn
+    const int grp = blockIdx.x / WG_SPLITS, split = blockIdx.x % WG_SPLITS;
+    const int dz = grp / 3, dy = grp % 3;
+    const int n_planes = p.N * p.D;
+
+    // ---- staging: unit u of a thread = (operand, voxel, 8 channels): 2 units of X and 2 of dY per plane ----
+    const __amdgpu_buffer_rsrc_t xrs = rsrc_of(p.x, p.bytes), yrs = rsrc_of(p.dy, p.bytes);
+    int st_lds[2];
+    unsigned st_src[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = tid + 256 * u, vox = q >> 3, cg = q & 7;          // 64 voxels x 8 channel groups
+        st_src[u] = 4u * (unsigned)(vox * C + cg * 8);
+        st_lds[u] = (cg >> 2) * WHALF + vox * WROW + (cg & 3) * 16;
+    }
+    // plane index of this workgroup's i-th tile, or -1 behind the last: every WG_SPLITS-th (n, z) whose partner plane
+    // z + dz - 1 is inside the volume
+    auto next_plane = [&](int from) {
+        for (int pi = from; pi < n_planes; pi += WG_SPLITS) {
+            const int zi = pi % p.D + dz - 1;
+            if ((unsigned)zi < (unsigned)p.D) return pi;
+        }
+        return -1;
+    };
+    u32x4 ldx[2][2], ldy[2][2];
+    auto stage_load = [&](int pi) {                     // pi < 0: nothing to fetch (offsets out of range: zeros)
+        const unsigned ybase = pi >= 0 ? 4u * (unsigned)((long)pi * PLANE * C) : 0x80000000u;
+        const unsigned xbase = pi >= 0 ? 4u * (unsigned)((long)(pi + dz - 1) * PLANE * C) : 0x80000000u;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            ldx[u][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src[u]), 0, 0);
+            ldx[u][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src[u] + 16u), 0, 0);
+            ldy[u][0] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(ybase + st_src[u]), 0, 0);
+            ldy[u][1] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(ybase + st_src[u] + 16u), 0, 0);
+        }
+    };
+    auto stage_store_unit = [&](int buf, int op, int u) {          // op 0: X, 1: dY
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = __uint_as_float(op ? ldy[u][0][e] : ldx[u][0][e]);
+            v[4 + e] = __uint_as_float(op ? ldy[u][1][e] : ldx[u][1][e]);
+        }
+        u32x4 o[3];
+        cut8(v, o);
+        unsigned char* dst = lds + buf * WBUF + op * WOP + st_lds[u];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * WPL) = o[pl];
+    };
+
+    // ---- fragment addresses (transposing read: this lane names row q of its 16-lane group's 4-row block) ----
+    // k-step ks covers output voxels 16 ks .. 16 ks + 15; MFMA k = 8 h + e: the lane's "lo" read fetches rows
+    // 16 ks + 8 h + q (e = 0..3 after the transpose), the "hi" read rows + 4.  Output voxel v = (y, x) = (v >> 3, v & 7)
+    // pairs with input voxel (y + dy - 1, x + dx - 1) of the partner plane.
+    const int q4 = i16 >> 2;
+    const int coloff = (16 * g16 + 4 * (i16 & 3)) * 2;
+    const int b_base = wn * WHALF + (8 * h + q4) * WROW + coloff;         // + ks * 16 rows, + 4 rows for "hi"
+    int a_sel[4][3][2];               // byte offset inside an X plane-half image, or the zero row
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int v = 16 * ks + 8 * h + 4 * hi + q4;
+                const int yi = (v >> 3) + dy - 1, xi = (v & 7) + dx - 1;
+                const bool ok = (unsigned)yi < 8u && (unsigned)xi < 8u;
+                a_sel[ks][dx][hi] = wm * WHALF + (ok ? (yi * 8 + xi) * WROW : WZERO) + coloff;
+            }
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+
+    // zero rows of both buffers, both operands, all planes and halves
+    for (int i = tid; i < 2 * 2 * 3 * 2 * (WROW / 16); i += 256) {
+        const int img = i / (WROW / 16), c16 = i % (WROW / 16);
+        *reinterpret_cast<u32x4*>(lds + img * WHALF + WZERO + c16 * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    int cur = next_plane(split);
+    int nxt = cur >= 0 ? next_plane(cur + WG_SPLITS) : -1;
+    stage_load(cur);
+    if (cur >= 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { stage_store_unit(0, 0, u); stage_store_unit(0, 1, u); }
+    }
+    stage_load(nxt);
+    __syncthreads();
+
+    bf16x8 af[2][3][3], bfg[2][3];
+    auto frags = [&](int buf, int ks, auto SETc) {
+        constexpr int SET = decltype(SETc)::value;
+        const unsigned char* xb = lds + buf * WBUF;
+        const unsigned char* yb = xb + WOP + b_base + ks * 16 * WROW;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(yb + pl * WPL));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(yb + pl * WPL + 4 * WROW));
+            bfg[SET][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb + pl * WPL + a_sel[ks][dx][0]));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb + pl * WPL + a_sel[ks][dx][1]));
+                af[SET][dx][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+    };
+    auto frags_dyn = [&](int buf, int ks) {
+        if (ks & 1) frags(buf, ks, std::integral_constant<int, 1>{});
+        else frags(buf, ks, std::integral_constant<int, 0>{});
+    };
+
+    int buf = 0;
+    while (cur >= 0) {
+        const int nn = nxt >= 0 ? next_plane(nxt + WG_SPLITS) : -1;      // the plane after next: fetched during this one
+        frags_dyn(buf, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            // one quarter of the next plane's staging rides behind this k-step's MFMAs: cut + store of one unit of the
+            // plane fetched a whole plane ago, then (last k-step) the fetch of the plane after it
+            if (ks < 2) stage_store_unit(buf ^ 1, 0, ks);
+            else stage_store_unit(buf ^ 1, 1, ks - 2);
+            if (ks == 3) stage_load(nn);
+            if (ks + 1 < 4) frags_dyn(buf, ks + 1);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+                    acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][dx][PA[pr]], bfg[ks & 1][PB[pr]], acc[dx], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // two LDS reads
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // a slice of the cut
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // LDS store
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // buffer loads
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();               // next plane stored by every wave; this plane's reads are done
+        buf ^= 1;
+        cur = nxt;
+        nxt = nn;
+    }
+
+    // ---- slab: this workgroup's three taps of slab `split`; C/D layout col = lane & 31 (co), row = ci ----
+    float* out = p.slabs + (long)split * (NTAP * C * C);
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int tap = (dz * 3 + dy) * 3 + dx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+            out[((long)tap * C + ci) * C + 32 * wn + l32] = acc[dx][r];
+        }
+    }
+}
+
 }  // namespace
 
 // ---- host side (internal: conv_igemm.hip's run_conv dispatches here; extern "C" wrappers at the end) ----
@@ -364,6 +569,17 @@ int mi_direct3_launch(const float* a, const void* wimg, float* out, const float*
                       int D, hipStream_t s) {
     Direct3Params p = {a, (const unsigned char*)wimg, out, res, mask, relu, N, D, (unsigned)(4l * N * D * PLANE * C)};
     hipLaunchKernelGGL(direct3_kernel, dim3((unsigned)(N * (D / TZ))), dim3(256), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+size_t mi_direct3_wgrad_slab_bytes() { return sizeof(float) * (size_t)WG_SPLITS * NTAP * C * C; }
+int mi_direct3_wgrad_splits() { return WG_SPLITS; }
+
+// writes WG_SPLITS full-size slabs ([27][64][64] floats each) into `slabs`; the caller sums them
+int mi_direct3_wgrad_launch(const float* x, const float* dy, float* slabs, int N, int D, hipStream_t s) {
+    Direct3WgradParams p = {x, dy, slabs, N, D, (unsigned)(4l * N * D * PLANE * C)};
+    hipLaunchKernelGGL(direct3_wgrad_kernel, dim3(9 * WG_SPLITS), dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

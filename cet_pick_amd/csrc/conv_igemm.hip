@@ -51,6 +51,9 @@ size_t mi_direct3_wimg_bytes();
 int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, int n, hipStream_t s);
 int mi_direct3_launch(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
                       int D, hipStream_t s);
+size_t mi_direct3_wgrad_slab_bytes();
+int mi_direct3_wgrad_splits();
+int mi_direct3_wgrad_launch(const float* x, const float* dy, float* slabs, int N, int D, hipStream_t s);
 
 namespace {
 
@@ -1157,6 +1160,17 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         if (rc) return rc;
         return mi_direct3_launch(a_src, ws, out, res, mask, relu, g.N, g.Di, s);
     }
+    if (mode == MODE_WGRAD && conv_arith_bf16x3() && is_direct3(g) && ws && ws_bytes >= mi_direct3_wgrad_slab_bytes()) {
+        int rc = mi_direct3_wgrad_launch(a_src, b_src, (float*)ws, g.N, g.Di, s);
+        if (rc) return rc;
+        const int splits = mi_direct3_wgrad_splits();
+        if (defer_splits) { *defer_splits = splits; return MI_OK; }
+        const long out_elems = 27l * g.Ci * g.Co, n4 = out_elems / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 2048)), dim3(256), 0, s,
+                           (const float*)ws, splits, out_elems, out, (const float*)nullptr, (const float*)nullptr, 0, n4);
+        MI_RETURN_IF_LAUNCH_FAILED();
+        return MI_OK;
+    }
     Setup st;
     int rc = setup_conv(mode, g, &st);
     if (rc) return rc;
@@ -1194,7 +1208,7 @@ extern "C" size_t mi_conv3d_workspace_bytes(int N, int Di, int Hi, int Wi, int C
     Geom g = make_geom(N, Di, Hi, Wi, Ci, Co, k, stride, pad);
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
-    if (is_direct3(g)) best = std::max(best, mi_direct3_wimg_bytes());
+    if (is_direct3(g)) best = std::max(best, std::max(mi_direct3_wimg_bytes(), mi_direct3_wgrad_slab_bytes()));
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;
@@ -1234,7 +1248,7 @@ extern "C" size_t mi_convnd_workspace_bytes(int N, int Di, int Hi, int Wi, int C
     Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
-    if (is_direct3(g)) best = std::max(best, mi_direct3_wimg_bytes());
+    if (is_direct3(g)) best = std::max(best, std::max(mi_direct3_wimg_bytes(), mi_direct3_wgrad_slab_bytes()));
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;
@@ -1305,7 +1319,7 @@ extern "C" size_t mi_convnd_dil_workspace_bytes(int N, int Di, int Hi, int Wi, i
     Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, 1, pd, ph, pw, dd, dh, dw);
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
-    if (is_direct3(g)) best = std::max(best, mi_direct3_wimg_bytes());
+    if (is_direct3(g)) best = std::max(best, std::max(mi_direct3_wimg_bytes(), mi_direct3_wgrad_slab_bytes()));
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;

@@ -118,7 +118,7 @@ def test_conv_direct3_matches_igemm_and_float64(n, d, monkeypatch):
     """layer1-shaped convolutions (3^3, stride 1, 64 -> 64, 8 x 8 planes) take the patch-resident direct kernel
     (conv_direct3.hip); MI_CONV_NO_DIRECT=1 keeps the implicit GEMM.  Both are the bf16x3 arithmetic: equal up to the
     summation order, and both at f32 level against float64 - forward with residual + ReLU, data gradient with
-    residual + mask, every z tile position (first / interior / last plane pair)."""
+    residual + mask, weight gradient; every z tile position (first / interior / last plane pair)."""
     from cet_pick_amd import hipops as H
     from conftest import f32_equivalent
     g = torch.Generator().manual_seed(100 * n + d)
@@ -129,9 +129,10 @@ def test_conv_direct3_matches_igemm_and_float64(n, d, monkeypatch):
     dy = torch.randn(n, 64, d, 8, 8, generator=g)
     def chain(xx, ww, rr, mm, dd):
         xx = xx.clone().requires_grad_(True)
+        ww = ww.clone().requires_grad_(True)
         y = F.conv3d(xx, ww, padding=1)
-        gx, = torch.autograd.grad(y, xx, dd)
-        return (F.relu(y.detach() + rr).permute(0, 2, 3, 4, 1), ((gx + rr) * (mm > 0)).permute(0, 2, 3, 4, 1))
+        gx, gw = torch.autograd.grad(y, (xx, ww), dd)
+        return (F.relu(y.detach() + rr).permute(0, 2, 3, 4, 1), ((gx + rr) * (mm > 0)).permute(0, 2, 3, 4, 1), gw)
     ref64 = chain(x.double(), w.double(), res.double(), mask.double(), dy.double())
     cpu32 = chain(x, w, res, mask, dy)                   # the arbiter: the same chain in fp32 on the CPU
     out = {}
@@ -139,9 +140,11 @@ def test_conv_direct3_matches_igemm_and_float64(n, d, monkeypatch):
         monkeypatch.setenv("MI_CONV_NO_DIRECT", off)
         yf = H.conv_fwd(cl(x), param, 3, 1, 1, cl(res), True)
         yd = H.conv_dgrad(cl(dy), param, (n, d, 8, 8, 64), 3, 1, 1, cl(res), cl(mask))
-        out[tag] = (yf.cpu(), yd.cpu())
-    for i in range(2):
-        f32_equivalent(out["direct"][i].numpy(), cpu32[i].numpy(), ref64[i].numpy(), what="direct3 %s" % ("fwd", "dgrad")[i])
+        param.grad = None
+        H.conv_wgrad_into(cl(x), cl(dy), param, 3, 1, 1)
+        out[tag] = (yf.cpu(), yd.cpu(), param.grad.detach().cpu().clone())
+    for i in range(3):
+        f32_equivalent(out["direct"][i].numpy(), cpu32[i].numpy(), ref64[i].numpy(), what="direct3 %s" % ("fwd", "dgrad", "wgrad")[i])
         scale = float(ref64[i].abs().max())
         assert float((out["direct"][i] - out["igemm"][i]).abs().max()) / scale < 2e-6
 
