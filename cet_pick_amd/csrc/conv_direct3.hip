@@ -459,64 +459,91 @@ __global__ __launch_bounds__(256, 1) void direct3_wgrad_kernel(Direct3WgradParam
     stage_load(nxt);
     __syncthreads();
 
+    // Fragment reads and staging are cut into pieces, one behind each MFMA of a k-step (pinned by sched_barrier): left to
+    // the scheduler the 50 instructions of a unit's cut went out in one block in front of the MFMAs and the matrix pipe sat
+    // idle for a third of the k-step.
     bf16x8 af[2][3][3], bfg[2][3];
-    auto frags = [&](int buf, int ks, auto SETc) {
+    // piece j (0..11) of the 24 transposing reads of k-step ks: j < 3: dY plane j; else X tap (j - 3) / 3, plane (j - 3) % 3
+    auto read_piece = [&](int buf, int ks, int j, auto SETc) {
         constexpr int SET = decltype(SETc)::value;
         const unsigned char* xb = lds + buf * WBUF;
-        const unsigned char* yb = xb + WOP + b_base + ks * 16 * WROW;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(yb + pl * WPL));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(yb + pl * WPL + 4 * WROW));
-            bfg[SET][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (j < 3) {
+            const unsigned char* yb = xb + WOP + b_base + ks * 16 * WROW + j * WPL;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(yb));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(yb + 4 * WROW));
+            bfg[SET][j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+            const int dx = (j - 3) / 3, pl = (j - 3) % 3;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb + pl * WPL + a_sel[ks][dx][0]));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb + pl * WPL + a_sel[ks][dx][1]));
+            af[SET][dx][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb + pl * WPL + a_sel[ks][dx][0]));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb + pl * WPL + a_sel[ks][dx][1]));
-                af[SET][dx][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
     };
-    auto frags_dyn = [&](int buf, int ks) {
-        if (ks & 1) frags(buf, ks, std::integral_constant<int, 1>{});
-        else frags(buf, ks, std::integral_constant<int, 0>{});
+    auto read_piece_dyn = [&](int buf, int ks, int j) {
+        if (ks & 1) read_piece(buf, ks, j, std::integral_constant<int, 1>{});
+        else read_piece(buf, ks, j, std::integral_constant<int, 0>{});
+    };
+    // staging pieces of unit (op, u): element e of the cut (4 VALU), then pack + store of plane pl
+    unsigned cu[3][8];
+    auto cut_piece = [&](int op, int u, int e) {
+        const float x = __uint_as_float(op ? ldy[u][e >> 2][e & 3] : ldx[u][e >> 2][e & 3]);
+        cu[0][e] = __float_as_uint(x);
+        const float r1 = x - __uint_as_float(cu[0][e] & 0xffff0000u);
+        cu[1][e] = __float_as_uint(r1);
+        cu[2][e] = __float_as_uint(r1 - __uint_as_float(cu[1][e] & 0xffff0000u));
+    };
+    auto store_piece = [&](int buf, int op, int u, int pl) {
+        constexpr unsigned HI2 = 0x07060302u;
+        u32x4 o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_perm(cu[pl][2 * d + 1], cu[pl][2 * d], HI2);
+        *reinterpret_cast<u32x4*>(lds + buf * WBUF + op * WOP + st_lds[u] + pl * WPL) = o;
     };
 
     int buf = 0;
+    if (cur >= 0) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) read_piece_dyn(0, 0, j);
+    }
     while (cur >= 0) {
         const int nn = nxt >= 0 ? next_plane(nxt + WG_SPLITS) : -1;      // the plane after next: fetched during this one
-        frags_dyn(buf, 0);
+        const unsigned ybase = nn >= 0 ? 4u * (unsigned)((long)nn * PLANE * C) : 0x80000000u;
+        const unsigned xbase = nn >= 0 ? 4u * (unsigned)((long)(nn + dz - 1) * PLANE * C) : 0x80000000u;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            // one quarter of the next plane's staging rides behind this k-step's MFMAs: cut + store of one unit of the
-            // plane fetched a whole plane ago, then (last k-step) the fetch of the plane after it
-            if (ks < 2) stage_store_unit(buf ^ 1, 0, ks);
-            else stage_store_unit(buf ^ 1, 1, ks - 2);
-            if (ks == 3) stage_load(nn);
-            if (ks + 1 < 4) frags_dyn(buf, ks + 1);
+            const int op = ks >> 1, u = ks & 1;           // the unit of the NEXT plane that is cut + stored behind this k-step
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                for (int pr = 0; pr < 6; ++pr)
-                    acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][dx][PA[pr]], bfg[ks & 1][PB[pr]], acc[dx], 0, 0, 0);
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // two LDS reads
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // a slice of the cut
+            for (int m = 0; m < 18; ++m) {
+                acc[m / 6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][m / 6][PA[m % 6]], bfg[ks & 1][PB[m % 6]], acc[m / 6], 0, 0, 0);
+                // behind the MFMA: one piece of the staging (k-steps 0..2: behind the reads of the fragments that are
+                // needed first, so that every MFMA carries 4 - 5 other instructions) ...
+                const int c0 = ks < 3 ? 3 : 0;
+                if (m >= c0 && m < c0 + 8) cut_piece(op, u, m - c0);
+                else if (m >= c0 + 8 && m < c0 + 11) store_piece(buf ^ 1, op, u, m - c0 - 8);
+                // ... the fetch of the plane after next (its staging registers were consumed by the cuts above) ...
+                if (ks == 3 && m >= 9 && m < 17) {
+                    const int i = m - 9, uu = (i >> 1) & 1, hf = i & 1;
+                    if (i < 4) ldx[uu][hf] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src[uu] + 16u * hf), 0, 0);
+                    else ldy[uu][hf] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(ybase + st_src[uu] + 16u * hf), 0, 0);
+                }
+                // ... and the fragment reads of the next k-step.  The last k-step of a plane reads the NEXT plane's first
+                // k-step, which is complete once every wave has stored its last unit: the barrier sits behind MFMA 10
+                if (ks < 3) {
+                    // pieces 0..5 (dY and tap 0: used by the next k-step's first MFMAs) first, tap 1 / 2 at the end
+                    if (m < 3) { read_piece_dyn(buf, ks + 1, 2 * m); read_piece_dyn(buf, ks + 1, 2 * m + 1); }
+                    if (m >= 14 && m < 17) { read_piece_dyn(buf, ks + 1, 2 * (m - 11)); read_piece_dyn(buf, ks + 1, 2 * (m - 11) + 1); }
+                } else {
+                    if (m == 10) __syncthreads();
+                    if (m >= 11 && nxt >= 0) {
+                        const int j0 = 2 * (m - 11);
+                        if (j0 < 12) read_piece_dyn(buf ^ 1, 0, j0);
+                        if (j0 + 1 < 12) read_piece_dyn(buf ^ 1, 0, j0 + 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // LDS store
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // buffer loads
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();               // next plane stored by every wave; this plane's reads are done
         buf ^= 1;
         cur = nxt;
         nxt = nn;
