@@ -359,7 +359,9 @@ def test_moco_three_steps_match_reference(golden):
         # the outputs are cosines: logits * T.  1e-3 on them at every step (north_star), against float64
         np.testing.assert_allclose(0.1 * lg.numpy(), 0.1 * l64.numpy(), rtol=0, atol=1e-3)
         f32_equivalent(lg.numpy(), l_ref.numpy(), l64.numpy(), what="logits step %d" % step)
-        assert abs(float(loss.detach()) - loss64) <= 2 * abs(loss_ref - loss64) + 2e-5
+        # (a scalar: the ratio of two fp32 evaluations' errors is unbounded when the CPU's happens to be ~0, so behind the
+        # arbiter stands north_star's 1e-3 - in the exploding regime of steps 1-2 the logits above are the sharper check)
+        assert abs(float(loss.detach()) - loss64) <= max(2 * abs(loss_ref - loss64) + 2e-5, 1e-3 if step > 0 else 0.0)
         gscale = float(sum(float(v.norm()) ** 2 for v in grads64.values()) ** 0.5)   # whole-gradient norm
         for n, p in moco.encoder_q.named_parameters():
             if n == "fc.bias" or n not in grads or on_relu_edge:
