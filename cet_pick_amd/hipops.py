@@ -408,8 +408,8 @@ class _ConvFn(torch.autograd.Function):
     """y = act(conv(x, W)); W's gradient goes to mod.weight.grad directly."""
 
     @staticmethod
-    def forward(ctx, x, w, mod, relu):
-        ctx.mod, ctx.relu = mod, relu
+    def forward(ctx, x, w, mod, relu, mask_dx=False):
+        ctx.mod, ctx.relu, ctx.mask_dx = mod, relu, mask_dx
         y = conv_fwd(x, w, mod.k, mod.stride, mod.pad, None, relu, dil=getattr(mod, "dil", None))
         ctx.save_for_backward(x, y if relu else None)
         ctx.x_needs_grad = x.requires_grad
@@ -427,8 +427,9 @@ class _ConvFn(torch.autograd.Function):
             conv_wgrad_into(x, dy, mod.weight, mod.k, mod.stride, mod.pad, dil=dil)
         dx = None
         if ctx.x_needs_grad:
-            dx = conv_dgrad(dy, mod.weight, x.shape, mod.k, mod.stride, mod.pad, dil=dil)
-        return dx, None, None, None
+            # mask_dx: x is the output of a ReLU whose derivative the producer left to this layer (see basic_block)
+            dx = conv_dgrad(dy, mod.weight, x.shape, mod.k, mod.stride, mod.pad, None, x if ctx.mask_dx else None, dil=dil)
+        return dx, None, None, None, None
 
 
 def convnd_weight_param(co, ci, k3, device=None):
@@ -464,8 +465,8 @@ class HipConv3d(nn.Module):
             bound = 1.0 / (ci * k ** 3) ** 0.5
             self.weight.uniform_(-bound, bound)
 
-    def forward(self, x, relu=False):
-        return _ConvFn.apply(x, self.weight, self, relu)
+    def forward(self, x, relu=False, mask_dx=False):
+        return _ConvFn.apply(x, self.weight, self, relu, mask_dx)
 
 
 class HipConv2d(nn.Module):
@@ -891,12 +892,13 @@ def global_avgpool(x):
 # ------------------------------------------------------------------------------------------------
 class _BasicBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, w2, wds, blk):
+    def forward(ctx, x, w1, w2, wds, blk, mask_dx=False, dout_masked=False):
         s = blk.stride
         hmid = conv_fwd(x, w1, 3, s, 1, None, True)
         r = conv_fwd(x, wds, 1, s, 0) if wds is not None else x
         out = conv_fwd(hmid, w2, 3, 1, 1, r, True)
         ctx.blk = blk
+        ctx.mask_dx, ctx.dout_masked = mask_dx, dout_masked
         ctx.save_for_backward(x, hmid, out)
         ctx.x_needs_grad = x.requires_grad
         return out
@@ -906,7 +908,9 @@ class _BasicBlockFn(torch.autograd.Function):
         x, hmid, out = ctx.saved_tensors
         blk = ctx.blk
         s = blk.stride
-        d2 = relu_mask(dout.contiguous(), out)                       # through the block's last ReLU
+        # through the block's last ReLU - unless the consumer of `out` already did it in its data-gradient epilogue
+        d2 = dout.contiguous() if ctx.dout_masked else relu_mask(dout.contiguous(), out)
+        xmask = x if ctx.mask_dx else None                           # ... as this block does for ITS producer
         if blk.conv2.weight.requires_grad:
             conv_wgrad_into(hmid, d2, blk.conv2.weight, 3, 1, 1)
         dh = conv_dgrad(d2, blk.conv2.weight, hmid.shape, 3, 1, 1, None, hmid)   # * (hmid > 0) fused
@@ -919,15 +923,19 @@ class _BasicBlockFn(torch.autograd.Function):
                 conv_wgrad_into(x, d2, ds[0].weight, 1, s, 0)
             if ctx.x_needs_grad:
                 dres = conv_dgrad(d2, ds[0].weight, x.shape, 1, s, 0)
-                dx = conv_dgrad(dh, blk.conv1.weight, x.shape, 3, s, 1, dres, None)
+                dx = conv_dgrad(dh, blk.conv1.weight, x.shape, 3, s, 1, dres, xmask)
         elif ctx.x_needs_grad:
-            dx = conv_dgrad(dh, blk.conv1.weight, x.shape, 3, s, 1, d2, None)   # + identity branch fused
-        return dx, None, None, None, None
+            dx = conv_dgrad(dh, blk.conv1.weight, x.shape, 3, s, 1, d2, xmask)   # + identity branch fused
+        return dx, None, None, None, None, None, None
 
 
-def basic_block(x, blk):
+def basic_block(x, blk, mask_dx=False, dout_masked=False):
+    """mask_dx: x is the output of a ReLU whose derivative its producer leaves to this block - the returned gradient is
+    (dx) * (x > 0), applied in the data-gradient epilogue (x > 0 exactly where the producer's pre-activation was).
+    dout_masked: the ONE consumer of this block's output does the same for this block's last ReLU, so the backward skips
+    its own mask launch.  The caller (the encoder's trunk) pairs the two flags; defaults keep the block self-contained."""
     wds = blk.downsample[0].weight if blk.downsample is not None else None
-    return _BasicBlockFn.apply(_f32c(x, "x"), blk.conv1.weight, blk.conv2.weight, wds, blk)
+    return _BasicBlockFn.apply(_f32c(x, "x"), blk.conv1.weight, blk.conv2.weight, wds, blk, mask_dx, dout_masked)
 
 
 # ------------------------------------------------------------------------------------------------

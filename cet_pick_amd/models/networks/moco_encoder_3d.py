@@ -43,8 +43,8 @@ class BasicBlock(nn.Module):
         self.stride = stride
         self.dilation = dilation
 
-    def forward(self, x):
-        return H.basic_block(x, self)
+    def forward(self, x, mask_dx=False, dout_masked=False):
+        return H.basic_block(x, self, mask_dx, dout_masked)
 
 
 class TomoResClassifier3D(nn.Module):
@@ -107,15 +107,16 @@ class TomoResClassifier3D(nn.Module):
         x = self.conv1(x)
         # bn1 + ReLU + MaxPool3d(3, 2, 1) as one fused layer: relu(bn(x)), the largest activation, is never stored
         x = self._mark(H.bn_relu_maxpool3d(x, self.bn1, 3, 2, 1), "layer1")     # its gradient exists => layer1.. are done
-        for blk in self.layer1:
-            x = blk(x)
-        x = self._mark(x, "layer2")
-        for blk in self.layer2:
-            x = blk(x)
-        x = self._mark(x, "layer3")
-        for blk in self.layer3:
-            x = blk(x)
-        x = self.feature_3d[0](x)
+        # The ReLU at the end of a block is differentiated by the block's single consumer (the next block, then the
+        # feature_3d convolution) in its data-gradient epilogue: six mask launches fewer per backward pass.
+        first = True
+        for tag, layer in (("layer2", self.layer1), ("layer3", self.layer2), (None, self.layer3)):
+            for blk in layer:
+                x = blk(x, mask_dx=not first, dout_masked=True)
+                first = False
+            if tag is not None:
+                x = self._mark(x, tag)
+        x = self.feature_3d[0](x, mask_dx=True)
         x = self.feature_3d[1](x, relu=True)
         x = H.global_avgpool(x)
         return self.fc(x)
