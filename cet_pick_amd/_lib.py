@@ -82,6 +82,8 @@ SIGNATURES = {
     "mi_bn_relu_bwd_apply_x": (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _P, _D, _P, _P, _P]),
     "mi_bn_small_fwd": (_I, [_P, _P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P]),
     "mi_bn_small_bwd": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _P, _P]),
+    "mi_bn_small_pool_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "mi_bn_small_pool_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "mi_bn_eval_fwd": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "mi_bn_bwd_reduce": (_I, [_P, _P, _P, _L, _I, _P, _I, _P, _P, _Z, _P]),
     "mi_bn_bwd_apply": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _D, _I, _P, _P, _P]),

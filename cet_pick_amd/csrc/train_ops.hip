@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* x, float
                                                           const float* beta, float eps, float momentum,
                                                           float* running_mean, float* running_var,
                                                           long long* num_batches_tracked, float* save,
-                                                          const float* res, int relu) {
+                                                          const float* res, int relu, float* pooled, int V) {
     const int c = blockIdx.x * BNS_CH;
     __shared__ double red[4][8];
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -405,6 +405,31 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* x, float
     if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
     const float4 g = gamma ? ld4(gamma + c) : make_float4(1, 1, 1, 1);
     const float4 b = beta ? ld4(beta + c) : make_float4(0, 0, 0, 0);
+    if (pooled) {
+        // global average pool of the output over the V consecutive rows of a sample (V a power of two <= 64, M % V == 0):
+        // the first lane of each group of V sums its group's values in row order - the order of avgpool_fwd_kernel
+        const int lane = threadIdx.x & 63;
+        for (int r0 = 0; r0 < M; r0 += 256) {
+            const int r = r0 + threadIdx.x;
+            const bool ok = r < M;
+            const long o = (long)(ok ? r : 0) * C + c;
+            const float4 v = ld4(x + o);
+            float q[4];
+            q[0] = fmaf((v.x - m[0]) * iv[0], g.x, b.x); q[1] = fmaf((v.y - m[1]) * iv[1], g.y, b.y);
+            q[2] = fmaf((v.z - m[2]) * iv[2], g.z, b.z); q[3] = fmaf((v.w - m[3]) * iv[3], g.w, b.w);
+            if (relu) { q[0] = fmaxf(q[0], 0.f); q[1] = fmaxf(q[1], 0.f); q[2] = fmaxf(q[2], 0.f); q[3] = fmaxf(q[3], 0.f); }
+            if (ok) st4(y + o, make_float4(q[0], q[1], q[2], q[3]));
+            float acc[4] = {q[0], q[1], q[2], q[3]};
+            for (int k = 1; k < V; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += __shfl(q[e], (lane & ~(V - 1)) + k, 64);
+            if (ok && (lane & (V - 1)) == 0) {
+                const float rs = (float)V;
+                st4(pooled + (long)(r / V) * C + c, make_float4(acc[0] / rs, acc[1] / rs, acc[2] / rs, acc[3] / rs));
+            }
+        }
+        return;
+    }
 #pragma unroll 4
     for (int r = threadIdx.x; r < M; r += 256) {
         const long o = (long)r * C + c;
@@ -421,7 +446,8 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* x, float
 // backward in one launch: sums of dy' and dy'*xhat per channel, then dx, dgamma, dbeta
 __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* dy, const float* x, const float* y, float* dx,
                                                           int M, int C, const float* save, const float* gamma,
-                                                          int relu, float* dgamma, float* dbeta) {
+                                                          int relu, float* dgamma, float* dbeta, int V) {
+    // V > 0: dy is the gradient of the pooled output (M / V rows); the gradient of row r is dy[r / V] / V (avgpool_bwd_kernel)
     const int c = blockIdx.x * BNS_CH;
     __shared__ double red[4][8];
     const float4 ma = ld4(save + c), ia = ld4(save + C + c);
@@ -430,7 +456,9 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* dy, cons
 #pragma unroll 4
     for (int r = threadIdx.x; r < M; r += 256) {
         const long o = (long)r * C + c;
-        const float4 d4 = ld4(dy + o), x4 = ld4(x + o);
+        const float4 x4 = ld4(x + o);
+        float4 d4 = ld4(dy + (V > 0 ? (long)(r / V) * C + c : o));
+        if (V > 0) { const float rs = (float)V; d4.x /= rs; d4.y /= rs; d4.z /= rs; d4.w /= rs; }
         float d[4] = {d4.x, d4.y, d4.z, d4.w};
         const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
         if (relu) {
@@ -460,7 +488,9 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* dy, cons
 #pragma unroll 4
     for (int r = threadIdx.x; r < M; r += 256) {
         const long o = (long)r * C + c;
-        const float4 d4 = ld4(dy + o), x4 = ld4(x + o);
+        const float4 x4 = ld4(x + o);
+        float4 d4 = ld4(dy + (V > 0 ? (long)(r / V) * C + c : o));
+        if (V > 0) { const float rs = (float)V; d4.x /= rs; d4.y /= rs; d4.z /= rs; d4.w /= rs; }
         float d[4] = {d4.x, d4.y, d4.z, d4.w};
         const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
         if (relu) {
@@ -1016,7 +1046,23 @@ extern "C" int mi_bn_small_fwd(const float* x, float* y, long M, int C, const fl
     if ((running_mean == nullptr) != (running_var == nullptr)) return MI_E_ARG;
     hipLaunchKernelGGL(bn_small_fwd_kernel, dim3((C + BNS_CH - 1) / BNS_CH), dim3(256), 0, (hipStream_t)stream, x, y,
                        (int)M, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
-                       save_mean_invstd, res, relu);
+                       save_mean_invstd, res, relu, (float*)nullptr, 0);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+/* global_avgpool(relu(bn(x))) over the V rows of each sample in the same launch (feature_3d + avgpool of the MoCo-3D trunk,
+ * models/networks/moco_encoder_3d.py:385-388): y = relu(bn(x)) is still written (the backward reads its sign), pooled is
+ * (M / V, C).  V a power of two <= 64 dividing M. */
+extern "C" int mi_bn_small_pool_fwd(const float* x, float* y, float* pooled, long M, int C, int V, const float* gamma,
+                                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                    long long* num_batches_tracked, float* save_mean_invstd, mi_stream_t stream) {
+    if (!x || !y || !pooled || !save_mean_invstd || M <= 0 || M > MI_BN_SMALL_MAX_ROWS || C <= 0 || C % 4) return MI_E_ARG;
+    if (V < 1 || V > 64 || (V & (V - 1)) || M % V) return MI_E_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return MI_E_ARG;
+    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3((C + BNS_CH - 1) / BNS_CH), dim3(256), 0, (hipStream_t)stream, x, y,
+                       (int)M, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+                       save_mean_invstd, (const float*)nullptr, 1, pooled, V);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -1027,7 +1073,18 @@ extern "C" int mi_bn_small_bwd(const float* dy, const float* x, const float* y, 
     if (!dy || !x || !dx || !save_mean_invstd || (relu && !y) || M <= 0 || M > MI_BN_SMALL_MAX_ROWS || C <= 0 || C % 4)
         return MI_E_ARG;
     hipLaunchKernelGGL(bn_small_bwd_kernel, dim3((C + BNS_CH - 1) / BNS_CH), dim3(256), 0, (hipStream_t)stream, dy, x, y,
-                       dx, (int)M, C, save_mean_invstd, gamma, relu, dgamma, dbeta);
+                       dx, (int)M, C, save_mean_invstd, gamma, relu, dgamma, dbeta, 0);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_bn_small_pool_bwd(const float* dpooled, const float* x, const float* y, float* dx, long M, int C, int V,
+                                    const float* save_mean_invstd, const float* gamma, float* dgamma, float* dbeta,
+                                    mi_stream_t stream) {
+    if (!dpooled || !x || !y || !dx || !save_mean_invstd || M <= 0 || M > MI_BN_SMALL_MAX_ROWS || C <= 0 || C % 4) return MI_E_ARG;
+    if (V < 1 || V > 64 || (V & (V - 1)) || M % V) return MI_E_ARG;
+    hipLaunchKernelGGL(bn_small_bwd_kernel, dim3((C + BNS_CH - 1) / BNS_CH), dim3(256), 0, (hipStream_t)stream, dpooled, x, y,
+                       dx, (int)M, C, save_mean_invstd, gamma, 1, dgamma, dbeta, V);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

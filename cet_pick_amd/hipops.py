@@ -886,6 +886,65 @@ def global_avgpool(x):
     return _AvgPoolFn.apply(_f32c(x, "x"))
 
 
+class _BNReluAvgPoolFn(torch.autograd.Function):
+    """global_avgpool(relu(bn(x))) in the one launch of the small-M BatchNorm, forward and backward (the pooled sum runs in
+    row order, the gradient is dy / V: the values of the separate avgpool kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mod, v):
+        c = x.shape[-1]
+        m = x.numel() // c
+        lib = L.lib()
+        y = torch.empty_like(x)
+        pooled = torch.empty((x.shape[0], c), dtype=torch.float32, device=x.device)
+        save = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+        track = mod.track_running_stats and mod.training
+        L.check(lib.mi_bn_small_pool_fwd(L.ptr(x), L.ptr(y), L.ptr(pooled), m, c, v, L.ptr(gamma), L.ptr(beta), mod.eps,
+                                         mod.momentum, L.ptr(mod.running_mean if track else None),
+                                         L.ptr(mod.running_var if track else None),
+                                         L.ptr(mod.num_batches_tracked if track else None), L.ptr(save), L.stream()),
+                "mi_bn_small_pool_fwd")
+        ctx.mod, ctx.m, ctx.c, ctx.v = mod, m, c, v
+        ctx.save_for_backward(x, y, save)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, y, save = ctx.saved_tensors
+        mod, m, c, v = ctx.mod, ctx.m, ctx.c, ctx.v
+        gamma = mod.weight
+        dg = db = None
+        acc_g = acc_b = False
+        if gamma is not None and gamma.requires_grad:
+            gt, acc_g = _grad_target(gamma)
+            dg = torch.empty_like(gt) if acc_g else gt
+            bt, acc_b = _grad_target(mod.bias)
+            db = torch.empty_like(bt) if acc_b else bt
+        dx = torch.empty_like(x)
+        L.check(L.lib().mi_bn_small_pool_bwd(L.ptr(dp.contiguous()), L.ptr(x), L.ptr(y), L.ptr(dx), m, c, v, L.ptr(save),
+                                             L.ptr(gamma), L.ptr(dg), L.ptr(db), L.stream()), "mi_bn_small_pool_bwd")
+        if acc_g:
+            gamma.grad.add_(dg)
+        if acc_b:
+            mod.bias.grad.add_(db)
+        return dx, None, None, None, None
+
+
+def bn_relu_global_avgpool(x, bn):
+    """AdaptiveAvgPool3d(1)(relu(bn(x))) -> (N, C): one launch each way when the one-launch BatchNorm applies (training
+    statistics, <= BN_SMALL_MAX_ROWS rows, no SyncBN exchange, a power-of-two number of voxels per sample <= 64);
+    otherwise the separate kernels."""
+    _f32c(x, "x")
+    n, c = x.shape[0], x.shape[-1]
+    m = x.numel() // c
+    v = m // max(n, 1)
+    fused = (x.is_cuda and (bn.training or not bn.track_running_stats) and m <= BN_SMALL_MAX_ROWS and c % 4 == 0
+             and not (bn.sync and _distributed()) and 1 <= v <= 64 and (v & (v - 1)) == 0 and v * n == m)
+    if not fused:
+        return global_avgpool(bn(x, relu=True))
+    return _BNReluAvgPoolFn.apply(x, bn.weight, bn.bias, bn, v)
+
+
 # ------------------------------------------------------------------------------------------------
 # BasicBlock (moco_encoder_3d.py:55-84): conv-ReLU-conv (+residual) -ReLU, no BN, with the ReLU
 # derivatives fused into the data-gradient epilogues

@@ -117,8 +117,7 @@ class TomoResClassifier3D(nn.Module):
             if tag is not None:
                 x = self._mark(x, tag)
         x = self.feature_3d[0](x, mask_dx=True)
-        x = self.feature_3d[1](x, relu=True)
-        x = H.global_avgpool(x)
+        x = H.bn_relu_global_avgpool(x, self.feature_3d[1])      # BatchNorm + ReLU + global average pool: one launch
         return self.fc(x)
 
     def _head(self, head, x):

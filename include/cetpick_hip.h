@@ -302,6 +302,16 @@ int mi_bn_small_fwd(const float* x, float* y, long M, int C, const float* gamma,
 int mi_bn_small_bwd(const float* dy, const float* x, const float* y, float* dx, long M, int C,
                     const float* save_mean_invstd, const float* gamma, int relu, float* dgamma, float* dbeta,
                     mi_stream_t stream);
+/* global_avgpool(relu(bn(x))) in the launch of the small-M BatchNorm (nn.BatchNorm3d + ReLU + AdaptiveAvgPool3d(1) behind
+ * feature_3d, models/networks/moco_encoder_3d.py:178-181,385-388): `pooled` (M / V, C) is the mean over the V consecutive
+ * rows of each sample (V a power of two <= 64 dividing M); y = relu(bn(x)) is written as well - the backward reads its sign.
+ * mi_bn_small_pool_bwd takes the gradient of `pooled`. */
+int mi_bn_small_pool_fwd(const float* x, float* y, float* pooled, long M, int C, int V, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                         long long* num_batches_tracked, float* save_mean_invstd, mi_stream_t stream);
+int mi_bn_small_pool_bwd(const float* dpooled, const float* x, const float* y, float* dx, long M, int C, int V,
+                         const float* save_mean_invstd, const float* gamma, float* dgamma, float* dbeta,
+                         mi_stream_t stream);
 int mi_bn_eval_fwd(const float* x, float* y, long M, int C, const float* running_mean,
                    const float* running_var, const float* gamma, const float* beta, float eps,
                    float* save_mean_invstd, const float* res, int relu, mi_stream_t stream);

@@ -398,6 +398,31 @@ def test_moco_three_steps_match_reference(golden):
     print("ReLU-edge steps (gradient comparison skipped):", edges)
 
 
+@pytest.mark.parametrize("shape", [(64, 2, 2, 2, 256), (5, 4, 4, 4, 32), (7, 1, 1, 1, 64), (3, 3, 2, 2, 16)])
+def test_fused_bn_relu_avgpool_equals_separate_kernels(shape):
+    """feature_3d's BatchNorm + ReLU + global average pool in one launch each way: bit-identical to the separate
+    kernels (same summation orders); a voxel count that is not a power of two takes the separate kernels."""
+    from cet_pick_amd import hipops as H
+    g = torch.Generator().manual_seed(sum(shape))
+    c = shape[-1]
+    x0 = (torch.randn(shape, generator=g) * 2 + 0.3).cuda()
+    dp = torch.randn(shape[0], c, generator=g).cuda()
+    outs = []
+    for fused in (True, False):
+        bn = H.HipBatchNorm(c).cuda()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, c)); bn.bias.copy_(torch.linspace(-0.2, 0.2, c))
+        x = x0.clone().requires_grad_(True)
+        p = H.bn_relu_global_avgpool(x, bn) if fused else H.global_avgpool(bn(x, relu=True))
+        p.backward(dp)
+        outs.append((p.detach(), x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    ref = torch.nn.functional.relu(torch.nn.functional.batch_norm(
+        x0.cpu().permute(0, 4, 1, 2, 3), None, None, torch.linspace(0.5, 1.5, c), torch.linspace(-0.2, 0.2, c), True)).mean((2, 3, 4))
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("shape,train", [((3, 10, 12, 14, 16), True), ((2, 9, 7, 8, 64), True), ((2, 8, 8, 8, 16), False)])
 def test_fused_bn_relu_maxpool_matches_unfused(shape, train):
     """stem fusion: maxpool3d(relu(bn(x))) forward / backward against torch (BatchNorm3d + ReLU + MaxPool3d)."""
