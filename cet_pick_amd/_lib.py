@@ -48,6 +48,7 @@ SIGNATURES = {
     "mi_convnd_wgrad_f32": (_I, [_P, _P, _P] + [_I] * 13 + [_P, _Z, _P]),
     "mi_convnd_wgrad_slabs_f32": (_I, [_P, _P, _P] + [_I] * 13 + [_P, _Z, _P, _P]),
     "mi_splitk_reduce_batch": (_I, [_P, _P, _P, _P, _I, _P]),
+    "mi_linear_fwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
     "mi_conv3d_direct_wimg_bytes": (_Z, []),
     "mi_conv3d_direct_usable": (_I, [_I] * 9),
     "mi_conv3d_direct_prep": (_I, [_P, _P, _P, _I, _P]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "mi_l2norm_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "mi_l2norm_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "mi_moco_logits_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "mi_moco_logits_norm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "mi_moco_logits_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "mi_rowdot_mean_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "mi_rowdot_mean_bwd": (_I, [_P, _P, _P, _I, _I, _P]),

@@ -79,6 +79,7 @@ struct ConvParams {
     const float* b_src;   // W (FWD, DGRAD) or dY (WGRAD)
     float* out;           // Y / dX / dW, or the split-K slabs
     const float* res;     // epilogue: out = act(acc + res)         (may be null)
+    int res_bcast;        // 1: res is one row of Ncols values added to every output row (a Linear layer's bias)
     const float* mask;    // epilogue: out *= (mask > 0)            (may be null)
     int relu;
     int N, Dg, Hg, Wg, Cg;         // gathered tensor grid / channels
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(NTHREADS, BF3 ? 3 : 1) void conv_igemm_kernel(ConvP
                 const long o = row * p.Ncols + col;
                 float v = acc[i][j][r];
                 if (direct) {
-                    if (p.res) v += p.res[o];
+                    if (p.res) v += p.res[p.res_bcast ? (long)col : o];
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.mask) v = (p.mask[o] > 0.f) ? v : 0.f;
                 }
@@ -794,14 +795,15 @@ __global__ __launch_bounds__(NTHREADS, BF3 ? 3 : 1) void conv_igemm_kernel(ConvP
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int n_slabs,
                                                            long slab_stride, float* out,
                                                            const float* res, const float* mask,
-                                                           int relu, long n4) {
+                                                           int relu, long n4, int res_mod = 0) {
+    // res_mod > 0: res is one row of res_mod values (a bias), broadcast over the rows
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 s = ld4(slabs + 4 * i);
         for (int z = 1; z < n_slabs; ++z) {
             float4 v = ld4(slabs + (long)z * slab_stride + 4 * i);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        if (res) { float4 v = ld4(res + 4 * i); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        if (res) { float4 v = ld4(res + (res_mod ? (4 * i) % res_mod : 4 * i)); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
         if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
         if (mask) {
             float4 v = ld4(mask + 4 * i);
@@ -1124,7 +1126,7 @@ bool is_direct3(const Geom& g) {
 // which reduces by itself) reports 1 and `out` is final.
 int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, float* out,
              const float* res, const float* mask, int relu, void* ws, size_t ws_bytes, hipStream_t s,
-             int* defer_splits = nullptr) {
+             int* defer_splits = nullptr, int res_bcast = 0) {
     if (defer_splits) *defer_splits = 1;
     // A gathered operand of 2 GiB or more (32-bit buffer offsets): FWD / DGRAD rows are independent per sample,
     // so the batch is cut in halves until every piece fits
@@ -1134,11 +1136,11 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         if (4 * a_per * g.N >= 0x7fff0000l) {
             Geom lo = g, hi = g;
             lo.N = g.N / 2; hi.N = g.N - lo.N;
-            int rc = run_conv(mode, lo, a_src, b_src, out, res, mask, relu, ws, ws_bytes, s);
+            int rc = run_conv(mode, lo, a_src, b_src, out, res, mask, relu, ws, ws_bytes, s, nullptr, res_bcast);
             if (rc) return rc;
             const long ao = a_per * lo.N, oo = o_per * lo.N;
-            return run_conv(mode, hi, a_src + ao, b_src, out + oo, res ? res + oo : nullptr, mask ? mask + oo : nullptr,
-                            relu, ws, ws_bytes, s);
+            return run_conv(mode, hi, a_src + ao, b_src, out + oo, (res && !res_bcast) ? res + oo : res,
+                            mask ? mask + oo : nullptr, relu, ws, ws_bytes, s, nullptr, res_bcast);
         }
     }
     // the 7^3 stride-2 stem has its own direct kernels (conv_stem.hip); anything they decline runs below
@@ -1177,6 +1179,7 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
     ConvParams& p = st.p;
     Plan& pl = st.pl;
     p.a_src = a_src; p.b_src = b_src; p.res = res; p.mask = mask; p.relu = relu;
+    p.res_bcast = res_bcast;
     const bool stem = (g.Ci == 1);
     const long out_elems = p.M * p.Ncols;
     if (pl.splits > 1) {
@@ -1195,7 +1198,7 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         long n4 = out_elems / 4;
         int blocks = (int)std::min<long>((n4 + 255) / 256, 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws,
-                           pl.splits, out_elems, out, res, mask, relu, n4);
+                           pl.splits, out_elems, out, res, mask, relu, n4, res_bcast ? p.Ncols : 0);
         MI_RETURN_IF_LAUNCH_FAILED();
     }
     return MI_OK;
@@ -1223,6 +1226,15 @@ extern "C" int mi_conv3d_fwd_f32(const float* x, const float* w, float* y, const
     Geom g = make_geom(N, Di, Hi, Wi, Ci, Co, k, stride, pad);
     if (!x || !w || !y || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
     return run_conv(MODE_FWD, g, x, w, y, res, nullptr, relu, ws, ws_bytes, (hipStream_t)stream);
+}
+
+/* nn.Linear forward in one pass: y[M][Co] = x[M][Ci] . W + bias (W in kernel layout [Ci][Co], bias may be NULL) - the
+ * 1 x 1 x 1 convolution with the bias added in the epilogue of the kernel (or of its split-K reduce). */
+extern "C" int mi_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, int M, int Ci, int Co,
+                                 void* ws, size_t ws_bytes, mi_stream_t stream) {
+    Geom g = make_geom(M, 1, 1, 1, Ci, Co, 1, 1, 0);
+    if (!x || !w || !y || !geom_ok(g)) return MI_E_ARG;
+    return run_conv(MODE_FWD, g, x, w, y, bias, nullptr, 0, ws, ws_bytes, (hipStream_t)stream, nullptr, bias ? 1 : 0);
 }
 
 extern "C" int mi_conv3d_dgrad_f32(const float* dy, const float* w, float* dx, const float* res,

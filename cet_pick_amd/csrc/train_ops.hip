@@ -796,6 +796,51 @@ __global__ __launch_bounds__(256) void moco_logits_fwd_kernel(const float* q, co
         if (tid == 0) out[0] = s * invT;
     }
 }
+// The same logits from the UN-normalised projections: every workgroup normalises its q row on the way into LDS (same
+// summation pattern and same multiply as l2norm_fwd_kernel: bit-identical rows), the first workgroup of a row also
+// writes q_hat / 1/|q| (the backward's inputs) and the normalised key row k_hat (the enqueue's input) - two l2norm
+// launches fewer per step.  C <= 1024.
+__global__ __launch_bounds__(256) void moco_logits_norm_fwd_kernel(const float* q_raw, const float* k_raw,
+                                                                  const float* queue, float* logits, float* q_hat,
+                                                                  float* q_inv, float* k_hat, int C, int R, float invT) {
+    extern __shared__ float qs[];
+    __shared__ float s_inv[2];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool first = blockIdx.y == 0;
+    if (wave < 2 && (wave == 0 || first)) {            // wave 0: |q|, wave 1 (first workgroup of the row): |k|
+        const float* src = (wave == 0 ? q_raw : k_raw) + (long)b * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) { const float v = src[c]; s = fmaf(v, v, s); }
+        s = wave_sum(s);
+        if (lane == 0) s_inv[wave] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    }
+    __syncthreads();
+    const float qi = s_inv[0];
+    for (int c = tid; c < C; c += 256) qs[c] = q_raw[(long)b * C + c] * qi;
+    __syncthreads();
+    float* out = logits + (long)b * (R + 1);
+    const int j = blockIdx.y * 256 + tid;
+    if (j < R) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) s = fmaf(qs[c], queue[(long)c * R + j], s);
+        out[1 + j] = s * invT;
+    }
+    if (first) {
+        const float ki = s_inv[1];
+        for (int c = tid; c < C; c += 256) {
+            q_hat[(long)b * C + c] = qs[c];
+            k_hat[(long)b * C + c] = k_raw[(long)b * C + c] * ki;
+        }
+        if (tid == 0) q_inv[b] = qi;
+        if (tid < 64) {
+            float s = 0.f;
+            for (int c = tid; c < C; c += 64) s = fmaf(qs[c], k_raw[(long)b * C + c] * ki, s);
+            s = wave_sum(s);
+            if (tid == 0) out[0] = s * invT;
+        }
+    }
+}
 // dq[b][c] = (dl[b][0]*k[b][c] + sum_j dl[b][1+j]*queue[c][j]) / T
 // grid (B, ceil(C/4)): one wave per (b, c), the row of queue is read contiguously
 __global__ __launch_bounds__(256) void moco_logits_bwd_kernel(const float* dlogits, const float* k,
@@ -1241,6 +1286,17 @@ extern "C" int mi_moco_logits_fwd(const float* q, const float* k, const float* q
     if (!q || !k || !queue || !logits || B <= 0 || C <= 0 || R <= 0 || !(T > 0.f) || C > 8192) return MI_E_ARG;
     hipLaunchKernelGGL(moco_logits_fwd_kernel, dim3(B, (R + 255) / 256), dim3(256), sizeof(float) * C,
                        (hipStream_t)stream, q, k, queue, logits, C, R, 1.0f / T);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+extern "C" int mi_moco_logits_norm_fwd(const float* q_raw, const float* k_raw, const float* queue, float* logits,
+                                       float* q_hat, float* q_inv, float* k_hat, int B, int C, int R, float T,
+                                       mi_stream_t stream) {
+    if (!q_raw || !k_raw || !queue || !logits || !q_hat || !q_inv || !k_hat || B <= 0 || C <= 0 || R <= 0 || !(T > 0.f) ||
+        C > 1024)
+        return MI_E_ARG;
+    hipLaunchKernelGGL(moco_logits_norm_fwd_kernel, dim3(B, (R + 255) / 256), dim3(256), sizeof(float) * C,
+                       (hipStream_t)stream, q_raw, k_raw, queue, logits, q_hat, q_inv, k_hat, C, R, 1.0f / T);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

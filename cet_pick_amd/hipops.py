@@ -488,10 +488,20 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, mod):
         m, ci = x.shape
-        y = conv_fwd(x.view(m, 1, 1, 1, ci), w.view(w.shape[0], ci, 1, 1, 1) if w.dim() == 5 else _as5(w),
-                     1, 1, 0).view(m, -1)
-        if b is not None:
-            L.check(L.lib().mi_bias_add(L.ptr(y), L.ptr(b), m, y.shape[1], L.stream()), "mi_bias_add")
+        w5 = w.view(w.shape[0], ci, 1, 1, 1) if w.dim() == 5 else _as5(w)
+        if b is not None and PROFILE is None and _phys_ok(w5):
+            # the bias rides in the epilogue of the GEMM launch (or of its split-K reduce)
+            _f32c(x, "x")
+            lib = L.lib()
+            co = w5.shape[0]
+            y = torch.empty((m, co), dtype=torch.float32, device=x.device)
+            ws = _ws(lib.mi_conv3d_workspace_bytes(m, 1, 1, 1, ci, co, 1, 1, 0), x.device, "conv")
+            L.check(lib.mi_linear_fwd_f32(L.ptr(x), L.ptr(w5), L.ptr(b), L.ptr(y), m, ci, co, L.ptr(ws), ws.numel(),
+                                          L.stream()), "mi_linear_fwd_f32")
+        else:
+            y = conv_fwd(x.view(m, 1, 1, 1, ci), w5, 1, 1, 0).view(m, -1)
+            if b is not None:
+                L.check(L.lib().mi_bias_add(L.ptr(y), L.ptr(b), m, y.shape[1], L.stream()), "mi_bias_add")
         ctx.mod = mod
         ctx.save_for_backward(x)
         ctx.x_needs_grad = x.requires_grad
@@ -1051,6 +1061,47 @@ class _MocoLogitsFn(torch.autograd.Function):
 
 def moco_logits(q, k, queue, T):
     return _MocoLogitsFn.apply(_f32c(q, "q"), _f32c(k, "k"), _f32c(queue, "queue"), T)
+
+
+class _MocoLogitsNormFn(torch.autograd.Function):
+    """(logits, k_hat) from the un-normalised projections: normalize(q), normalize(k) and the logits in one launch; the
+    backward is logits_bwd + l2norm_bwd on the saved q_hat / 1/|q| (gradient w.r.t. q_raw only).
+    queue_stable: the caller enqueues only after the backward pass, so the queue needs no copy."""
+
+    @staticmethod
+    def forward(ctx, q_raw, k_raw, queue, T, queue_stable):
+        b, c = q_raw.shape
+        r = queue.shape[1]
+        dev = q_raw.device
+        logits = torch.empty((b, r + 1), dtype=torch.float32, device=dev)
+        q_hat = torch.empty_like(q_raw)
+        k_hat = torch.empty_like(q_raw)
+        q_inv = torch.empty(b, dtype=torch.float32, device=dev)
+        L.check(L.lib().mi_moco_logits_norm_fwd(L.ptr(q_raw), L.ptr(k_raw), L.ptr(queue), L.ptr(logits), L.ptr(q_hat),
+                                                L.ptr(q_inv), L.ptr(k_hat), b, c, r, float(T), L.stream()),
+                "mi_moco_logits_norm_fwd")
+        ctx.save_for_backward(k_hat, queue if queue_stable else queue.clone(), q_hat, q_inv)
+        ctx.T = float(T)
+        ctx.mark_non_differentiable(k_hat)
+        return logits, k_hat
+
+    @staticmethod
+    def backward(ctx, dl, _dk):
+        k_hat, queue, q_hat, q_inv = ctx.saved_tensors
+        b, c = k_hat.shape
+        r = queue.shape[1]
+        lib = L.lib()
+        dq = torch.empty_like(k_hat)
+        L.check(lib.mi_moco_logits_bwd(L.ptr(dl.contiguous()), L.ptr(k_hat), L.ptr(queue), L.ptr(dq), b, c, r, ctx.T,
+                                       L.stream()), "mi_moco_logits_bwd")
+        dx = torch.empty_like(dq)
+        L.check(lib.mi_l2norm_bwd(L.ptr(dq), L.ptr(q_hat), L.ptr(q_inv), L.ptr(dx), b, c, L.stream()), "mi_l2norm_bwd")
+        return dx, None, None, None, None
+
+
+def moco_logits_normalized(q_raw, k_raw, queue, T, queue_stable=False):
+    """models/moco.py:113-138 from the encoders' raw outputs; returns (logits, normalize(k))."""
+    return _MocoLogitsNormFn.apply(_f32c(q_raw, "q"), _f32c(k_raw, "k"), _f32c(queue, "queue"), T, bool(queue_stable))
 
 
 class _CELabel0Fn(torch.autograd.Function):

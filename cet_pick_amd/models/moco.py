@@ -80,7 +80,17 @@ class MoCo(nn.Module):
         with torch.no_grad():
             self._momentum_update_key_encoder()
             k = self.encoder_k(im_k)[0]["proj"]
-            return H.l2_normalize(k)
+            return k                                       # un-normalised: the logits kernel normalises both branches
+
+    # MocoStepEngine sets this: the keys are enqueued by flush_enqueue() AFTER the backward pass, so the backward reads the
+    # queue in place (no 8 MB copy per step).  The state after the step is the same: the enqueue only writes the queue.
+    defer_enqueue = False
+    _pending_keys = None
+
+    def flush_enqueue(self):
+        if self._pending_keys is not None:
+            self._dequeue_and_enqueue(self._pending_keys)
+            self._pending_keys = None
 
     def forward(self, im_q, im_k):
         if self.overlap_key_branch and im_q.is_cuda:
@@ -89,17 +99,21 @@ class MoCo(nn.Module):
             cur = torch.cuda.current_stream()
             self._side.wait_stream(cur)                    # inputs and last step's SGD are ordered before it
             with torch.cuda.stream(self._side):
-                k = self._key_branch(im_k)
-            q = H.l2_normalize(self.encoder_q(im_q)[0]["proj"])
+                k_raw = self._key_branch(im_k)
+            q_raw = self.encoder_q(im_q)[0]["proj"]
             cur.wait_stream(self._side)
-            k.record_stream(cur)
+            k_raw.record_stream(cur)
         else:
-            q = H.l2_normalize(self.encoder_q(im_q)[0]["proj"])
-            k = self._key_branch(im_k)
-        logits = H.moco_logits(q, k, self.queue, self.T)
+            q_raw = self.encoder_q(im_q)[0]["proj"]
+            k_raw = self._key_branch(im_k)
+        # normalize(q), normalize(k) and the logits in one launch; k comes back normalised for the queue
+        logits, k = H.moco_logits_normalized(q_raw, k_raw, self.queue, self.T, queue_stable=self.defer_enqueue)
         labels = self._zero_labels(logits)
         keys = concat_all_gather(k) if H._distributed() else k
-        self._dequeue_and_enqueue(keys)
+        if self.defer_enqueue:
+            self._pending_keys = keys
+        else:
+            self._dequeue_and_enqueue(keys)
         return logits, labels
 
 

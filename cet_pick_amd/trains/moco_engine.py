@@ -131,15 +131,19 @@ class MocoStepEngine:
         self.buckets_sent = []
         self.arena_q.zero_grad()
         H.ACTIVE_IMAGES = self._images                 # the cached weight images are valid inside the step only
+        moco.defer_enqueue = True                      # the backward reads the queue in place; keys go in behind it
         try:
             logits, labels = moco(im_q, im_k)
             loss = H.cross_entropy_label0(logits, out=self._loss_buf)      # lands in the engine's loss buffer: no copy
             H.DEFERRED_WGRADS = [] if self.arena_q.flat_grad.is_cuda else None     # split-K slabs of the wgrads: one reduce
             loss.backward()
             H.flush_wgrad_reduces()
+            moco.flush_enqueue()
         finally:
             H.DEFERRED_WGRADS = None
             H.ACTIVE_IMAGES = None
+            moco.defer_enqueue = False
+            moco._pending_keys = None
         if self.dist_on:
             # layer3+heads, layer2 and layer1 went out from the autograd hooks while the backward was still running
             # (RCCL over xGMI on its own stream); the stem's gradients are the last to exist

@@ -177,6 +177,12 @@ int mi_conv3d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int D
                         int Ci, int Co, int k, int stride, int pad, void* ws, size_t ws_bytes,
                         mi_stream_t stream);
 
+/* nn.Linear (models/networks/moco_encoder_3d.py:183-236: fc and the projection head): y[M][Co] = x[M][Ci] . W + bias with
+ * W in kernel layout [Ci][Co]; bias (Co values, may be NULL) is added in the epilogue of the 1x1x1 convolution launch.
+ * Workspace as mi_conv3d_workspace_bytes(M, 1, 1, 1, Ci, Co, 1, 1, 0). */
+int mi_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, int M, int Ci, int Co, void* ws,
+                      size_t ws_bytes, mi_stream_t stream);
+
 /* Same kernels with a per-axis window (kd,kh,kw) and zero padding (pd,ph,pw); weights
  * [kd][kh][kw][Cin][Cout].  nn.Conv2d of the 2-D encoder (models/networks/simsiam_model_2d.py:25-28,
  * 473-502, 617-661) is the D = 1, kd = 1, pd = 0 case on (N,1,H,W,C) activations. */
@@ -352,6 +358,11 @@ int mi_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float*
                   mi_stream_t stream);
 int mi_moco_logits_fwd(const float* q, const float* k, const float* queue, float* logits, int B,
                        int C, int R, float T, mi_stream_t stream);
+/* The same logits from the un-normalised projections (models/moco.py:113-138: q = normalize(encoder_q(im_q)), k =
+ * normalize(encoder_k(im_k)), logits): q_hat (B, C), q_inv (B) = 1/|q| and k_hat (B, C) leave as by-products - the inputs
+ * of mi_l2norm_bwd / mi_moco_logits_bwd and of the enqueue.  Rows bit-identical to mi_l2norm_fwd + mi_moco_logits_fwd. */
+int mi_moco_logits_norm_fwd(const float* q_raw, const float* k_raw, const float* queue, float* logits, float* q_hat,
+                            float* q_inv, float* k_hat, int B, int C, int R, float T, mi_stream_t stream);
 int mi_moco_logits_bwd(const float* dlogits, const float* k, const float* queue, float* dq, int B,
                        int C, int R, float T, mi_stream_t stream);
 /* SimSiam loss pieces (trains/tomo_simsiam_trainer.py:28-40) on L2-normalised rows:

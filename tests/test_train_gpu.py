@@ -398,6 +398,34 @@ def test_moco_three_steps_match_reference(golden):
     print("ReLU-edge steps (gradient comparison skipped):", edges)
 
 
+@pytest.mark.parametrize("m,ci,co,bias", [(64, 256, 128, True), (64, 128, 128, False), (5, 48, 32, True), (2048, 256, 128, True)])
+def test_linear_fwd_bwd(m, ci, co, bias):
+    """nn.Linear (fc / projection head): the bias is added in the epilogue of the GEMM launch (or of its split-K reduce)."""
+    from cet_pick_amd import hipops as H
+    g = torch.Generator().manual_seed(m + ci + co)
+    lin = H.HipLinear(ci, co, bias=bias).cuda()
+    ref = torch.nn.Linear(ci, co, bias=bias)
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(co, ci, generator=g) * 0.1)
+        lin.weight.copy_(ref.weight.cuda())
+        if bias:
+            ref.bias.copy_(torch.randn(co, generator=g))
+            lin.bias.copy_(ref.bias.cuda())
+    x = torch.randn(m, ci, generator=g)
+    dy = torch.randn(m, co, generator=g)
+    xg = x.cuda().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y = lin(xg)
+    yr = ref(xr)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-4)
+    y.backward(dy.cuda())
+    yr.backward(dy)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(lin.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), rtol=1e-4, atol=1e-3)
+    if bias:
+        np.testing.assert_allclose(lin.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), rtol=1e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize("shape", [(64, 2, 2, 2, 256), (5, 4, 4, 4, 32), (7, 1, 1, 1, 64), (3, 3, 2, 2, 16)])
 def test_fused_bn_relu_avgpool_equals_separate_kernels(shape):
     """feature_3d's BatchNorm + ReLU + global average pool in one launch each way: bit-identical to the separate
