@@ -562,31 +562,257 @@ __global__ __launch_bounds__(256, 1) void direct3_wgrad_kernel(Direct3WgradParam
     }
 }
 
+
+// ---- layer2-shaped convolutions: 3^3 / stride 1 / padding 1, 128 -> 128 channels on 4 x 4 x 4 volumes --------------------
+// (moco_encoder_3d.py:55-84,171: three of them per encoder pass, 9 forward / data-gradient launches per step.)  M is small
+// (64 voxels per sample), so the parallelism comes from the reduction: a workgroup owns TWO samples (128 rows) x 64
+// output channels x ONE chunk of 32 input channels - 32 sample pairs x 2 column tiles x 4 chunks = 256 workgroups - and
+// writes its partial tile into split-K slab `chunk`; the caller's reduce launch sums the four slabs and applies the
+// epilogue.  Same structure as direct3_kernel otherwise: the 128 x 32 patch is cut once into LDS (43 KB), a wave owns
+// one sample x 32 columns (two row blocks), weight fragments stream from the pre-cut image, every halo voxel is padding
+// (the volume IS the tile) and reads the lane's zero record.
+constexpr int CS = 128;                     // channels, in = out
+constexpr int VS = 64;                      // voxels of a 4 x 4 x 4 sample
+constexpr int S_LEAD = 32;                  // records in front of voxel 0 (>= 21, the -21 of the tap offsets; 32 + 128 = 0 mod 16)
+constexpr int S_NV = 2 * VS;                // two samples
+constexpr int S_ZREC = 64;                  // (record mod 16) + tap offset (0..42) stays inside
+constexpr int S_NREC = S_LEAD + S_NV + S_ZREC;
+constexpr int S_ARR = S_NREC * 16;          // 3,584
+constexpr int S_PL = 2 * S_ARR;
+constexpr int S_KS = 3 * S_PL;
+constexpr int S_LDS = 2 * S_KS;             // 43,008
+constexpr int S_ZBASE = (S_LEAD + S_NV) * 16;
+constexpr int S_CHUNKS = 4;                 // split-K over 32-channel chunks
+constexpr int S_STEPS = 2 * NTAP;           // k-steps per chunk: g = tap * 2 + ks
+constexpr int S_WSTEP = 4 * 3 * WBLK;       // bytes per k-step of the image: [column block 0..3][plane]
+constexpr int S_WIMG_BYTES = S_CHUNKS * S_STEPS * S_WSTEP;       // 2,654,208
+static_assert(S_STEPS % RB == 0, "ring slots");
+static_assert(((S_LEAD + S_NV) & 15) == 0, "zero region must start at a record = 0 (mod 16)");
+
+struct Direct3sParams {
+    const float* a;           // X or dY: (N, 4, 4, 4, 128)
+    const unsigned char* wimg;
+    float* slabs;             // S_CHUNKS slabs of (N * 64, 128) floats
+    int N;
+    unsigned a_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void direct3s_kernel(Direct3sParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char patch[S_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    const int wsm = wave >> 1, cw = wave & 1;            // wave tile: sample wsm of the pair x column half cw
+    const int cc = blockIdx.x % S_CHUNKS, ct = (blockIdx.x / S_CHUNKS) & 1, sp = blockIdx.x / (2 * S_CHUNKS);
+    const int n0 = 2 * sp;
+
+    const __amdgpu_buffer_rsrc_t wrs = rsrc_of(p.wimg, S_WIMG_BYTES);
+    const int w_voff = (ct * 2 + cw) * (3 * WBLK) + lane * 16;
+    const int w_soff = cc * (S_STEPS * S_WSTEP);
+    bf16x8 bfr[RB][3];
+    auto wload = [&](int g, auto SLOTc) {
+        constexpr int SLOT = decltype(SLOTc)::value;
+        const int so = g < S_STEPS ? w_soff + g * S_WSTEP : S_WIMG_BYTES;       // behind the chunk: zeros (out of range)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, w_voff + pl * WBLK, so, 0));
+    };
+    auto wload_dyn = [&](int g) {
+        switch (g % RB) {
+            case 0: wload(g, std::integral_constant<int, 0>{}); break;
+            case 1: wload(g, std::integral_constant<int, 1>{}); break;
+            case 2: wload(g, std::integral_constant<int, 2>{}); break;
+            case 3: wload(g, std::integral_constant<int, 3>{}); break;
+            case 4: wload(g, std::integral_constant<int, 4>{}); break;
+            default: wload(g, std::integral_constant<int, 5>{}); break;
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < RB - 1; ++g) wload_dyn(g);
+
+    // ---- stage the patch: unit q = (voxel of the pair, group of 8 of the chunk's 32 channels); 2 units per thread ----
+    {
+        const __amdgpu_buffer_rsrc_t ars = rsrc_of(p.a, p.a_bytes);
+        u32x4 ld[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = tid + 256 * u, vox = q >> 2, cg = q & 3;
+            const bool ok = n0 + (vox >> 6) < p.N;
+            const unsigned off = ok ? 4u * (unsigned)(((long)n0 * VS + vox) * CS + cc * 32 + cg * 8) : 0x80000000u;
+            ld[u][0] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)off, 0, 0);
+            ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(off + 16u), 0, 0);
+        }
+        for (int i = tid; i < 12 * S_ZREC; i += 256) {
+            const int arr = i / S_ZREC, r = i % S_ZREC;
+            *reinterpret_cast<u32x4*>(patch + arr * S_ARR + S_ZBASE + r * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = tid + 256 * u, vox = q >> 2, cg = q & 3;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ld[u][0][e]); v[4 + e] = __uint_as_float(ld[u][1][e]); }
+            u32x4 o[3];
+            cut8(v, o);
+            unsigned char* dst = patch + (cg >> 1) * S_KS + (cg & 1) * S_ARR + (S_LEAD + vox) * 16;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * S_PL) = o[pl];
+        }
+    }
+
+    // ---- per-lane geometry: row block i = voxels 32 i .. 32 i + 31 of the wave's sample ----
+    int vbase[2], zbase[2];
+    unsigned vmask[2];                  // bit tap: the tap's neighbour is inside the 4 x 4 x 4 volume
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = 32 * i + l32, z = v >> 4, y = (v >> 2) & 3, x = v & 3;
+        const int rec = S_LEAD - 21 + wsm * VS + v;
+        vbase[i] = rec * 16 + h * S_ARR;
+        zbase[i] = S_ZBASE + (rec & 15) * 16 + h * S_ARR;
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+            if ((unsigned)(z + dz - 1) < 4u && (unsigned)(y + dy - 1) < 4u && (unsigned)(x + dx - 1) < 4u) m |= 1u << t;
+        }
+        vmask[i] = m;
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+
+    bf16x8 af[2][2][3];
+    auto frags = [&](int g, auto SETc) {
+        constexpr int SET = decltype(SETc)::value;
+        const int tap = g >> 1, ksx = g & 1;
+        const int imm = ((tap / 9) * 16 + ((tap / 3) % 3) * 4 + tap % 3) * 16 + ksx * S_KS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sel = ((vmask[i] >> tap) & 1u) ? vbase[i] : zbase[i];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                af[SET][i][pl] = *reinterpret_cast<const bf16x8*>(patch + sel + imm + pl * S_PL);
+        }
+    };
+    auto frags_dyn = [&](int g) {
+        if (g & 1) frags(g, std::integral_constant<int, 1>{});
+        else frags(g, std::integral_constant<int, 0>{});
+    };
+
+    __syncthreads();
+    frags_dyn(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < S_STEPS; ++g) {
+        wload_dyn(g + RB - 1);
+        if (g + 1 < S_STEPS) frags_dyn(g + 1);
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][0][PA[pr]], bfr[g % RB][PB[pr]], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][1][PA[pr]], bfr[g % RB][PB[pr]], acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- partial tile into slab cc; C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h ----
+    if (n0 + wsm < p.N) {
+        float* out = p.slabs + (long)cc * ((long)p.N * VS * CS);
+        const long m0 = (long)(n0 + wsm) * VS;
+        const int col = ct * 64 + cw * 32 + l32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[(m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * CS + col] = acc[i][r];
+    }
+}
+
+// weight image of the 128-channel kernel: [chunk 4][tap 27][ks 2][column block 4][plane 3][lane 64] x 16 bytes
+__global__ __launch_bounds__(256) void direct3s_prep_kernel(PrepBatch b) {
+    const float* w = b.w[blockIdx.y];
+    unsigned char* img = b.img[blockIdx.y];
+    const int dgrad = b.dgrad[blockIdx.y];
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // (chunk, tap, ks, cb, lane): 4 * 27 * 2 * 4 * 64 = 216 * 256
+    const int lane = idx & 63, cb = (idx >> 6) & 3, ksx = (idx >> 8) & 1, rest = idx >> 9, tap = rest % NTAP, cc = rest / NTAP;
+    const int nn = cb * 32 + (lane & 31), k0 = cc * 32 + ksx * 16 + 8 * (lane >> 5);
+    float v[8];
+    if (dgrad) {
+        const float* src = w + ((long)(NTAP - 1 - tap) * CS + nn) * CS + k0;
+        const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = w[((long)tap * CS + k0 + e) * CS + nn];
+    }
+    u32x4 o[3];
+    cut8(v, o);
+    unsigned char* dst = img + (long)(((cc * NTAP + tap) * 2 + ksx) * 4 + cb) * (3 * WBLK) + lane * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * WBLK) = o[pl];
+}
+
 }  // namespace
 
 // ---- host side (internal: conv_igemm.hip's run_conv dispatches here; extern "C" wrappers at the end) ----
+// 0: not a direct shape; 1: 64 -> 64 channels on 8 x 8 planes (direct3_kernel); 2: 128 -> 128 on 4 x 4 x 4 (direct3s_kernel)
+int mi_direct3_kind(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph,
+                    int pw, int dd, int dh, int dw) {
+    const char* off = getenv("MI_CONV_NO_DIRECT");      // A/B switch: keep the implicit GEMM
+    if (off && atoi(off) != 0) return 0;
+    if (kd != 3 || kh != 3 || kw != 3 || stride != 1 || pd != 1 || ph != 1 || pw != 1 || dd != 1 || dh != 1 || dw != 1) return 0;
+    if (N < 1 || 4l * N * Di * Hi * Wi * Ci >= 0x7fff0000l) return 0;
+    if (Ci == C && Co == C && Hi == 8 && Wi == 8 && Di >= TZ && Di % TZ == 0) return 1;
+    if (Ci == CS && Co == CS && Di == 4 && Hi == 4 && Wi == 4) return 2;
+    return 0;
+}
 bool mi_direct3_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph,
                        int pw, int dd, int dh, int dw) {
-    const char* off = getenv("MI_CONV_NO_DIRECT");      // A/B switch: keep the implicit GEMM
-    if (off && atoi(off) != 0) return false;
-    if (Ci != C || Co != C || Hi != 8 || Wi != 8 || Di < TZ || Di % TZ) return false;
-    if (kd != 3 || kh != 3 || kw != 3 || stride != 1 || pd != 1 || ph != 1 || pw != 1 || dd != 1 || dh != 1 || dw != 1) return false;
-    if (N < 1 || 4l * N * Di * PLANE * C >= 0x7fff0000l) return false;
-    return true;
+    return mi_direct3_kind(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw, dd, dh, dw) != 0;
 }
 
-size_t mi_direct3_wimg_bytes() { return (size_t)WIMG_BYTES; }
+size_t mi_direct3_wimg_bytes(int channels) {
+    return channels == C ? (size_t)WIMG_BYTES : channels == CS ? (size_t)S_WIMG_BYTES : 0;
+}
+// split-K slabs the 128-channel kernel writes (the caller reduces them); 0 for the 64-channel kernel
+size_t mi_direct3_slab_bytes(int N, int channels) {
+    return channels == CS ? sizeof(float) * (size_t)S_CHUNKS * N * VS * CS : 0;
+}
+int mi_direct3_splits(int channels) { return channels == CS ? S_CHUNKS : 1; }
 
-int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, int n, hipStream_t s) {
-    for (int i0 = 0; i0 < n; i0 += PREP_MAX) {
+// channels[i] = 64 or 128 selects the image format of weight i
+int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, const int* channels, int n, hipStream_t s) {
+    for (int kind = 0; kind < 2; ++kind) {
+        const int want = kind == 0 ? C : CS;
         PrepBatch b = {};
-        const int m = n - i0 < PREP_MAX ? n - i0 : PREP_MAX;
-        for (int i = 0; i < m; ++i) {
-            if (!w[i0 + i] || !img[i0 + i]) return MI_E_ARG;
-            b.w[i] = w[i0 + i]; b.img[i] = (unsigned char*)img[i0 + i]; b.dgrad[i] = dgrad[i0 + i];
+        int m = 0;
+        auto flush = [&]() -> int {
+            if (m == 0) return MI_OK;
+            if (kind == 0) hipLaunchKernelGGL(direct3_prep_kernel, dim3(NTAP * KS * 2 * 64 / 256, m), dim3(256), 0, s, b);
+            else hipLaunchKernelGGL(direct3s_prep_kernel, dim3(S_CHUNKS * NTAP * 2 * 4 * 64 / 256, m), dim3(256), 0, s, b);
+            MI_RETURN_IF_LAUNCH_FAILED();
+            m = 0;
+            return MI_OK;
+        };
+        for (int i = 0; i < n; ++i) {
+            if (channels[i] != C && channels[i] != CS) return MI_E_ARG;
+            if (channels[i] != want) continue;
+            if (!w[i] || !img[i]) return MI_E_ARG;
+            b.w[m] = w[i]; b.img[m] = (unsigned char*)img[i]; b.dgrad[m] = dgrad[i];
+            if (++m == PREP_MAX) { int rc = flush(); if (rc) return rc; }
         }
-        hipLaunchKernelGGL(direct3_prep_kernel, dim3(NTAP * KS * 2 * 64 / 256, m), dim3(256), 0, s, b);
-        MI_RETURN_IF_LAUNCH_FAILED();
+        int rc = flush();
+        if (rc) return rc;
     }
     return MI_OK;
 }
@@ -596,6 +822,14 @@ int mi_direct3_launch(const float* a, const void* wimg, float* out, const float*
                       int D, hipStream_t s) {
     Direct3Params p = {a, (const unsigned char*)wimg, out, res, mask, relu, N, D, (unsigned)(4l * N * D * PLANE * C)};
     hipLaunchKernelGGL(direct3_kernel, dim3((unsigned)(N * (D / TZ))), dim3(256), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+// 128-channel kernel: S_CHUNKS partial slabs of (N * 64, 128) floats into `slabs`; the caller sums them (+ epilogue)
+int mi_direct3s_launch(const float* a, const void* wimg, float* slabs, int N, hipStream_t s) {
+    Direct3sParams p = {a, (const unsigned char*)wimg, slabs, N, (unsigned)(4l * N * VS * CS)};
+    hipLaunchKernelGGL(direct3s_kernel, dim3((unsigned)(((N + 1) / 2) * 2 * S_CHUNKS)), dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -612,21 +846,34 @@ int mi_direct3_wgrad_launch(const float* x, const float* dy, float* slabs, int N
 }
 
 // ---- C-ABI (include/cetpick_hip.h): the image kept by the caller across calls ----
-extern "C" size_t mi_conv3d_direct_wimg_bytes(void) { return mi_direct3_wimg_bytes(); }
+int mi_direct3_finish_slabs(const float* slabs, int n_slabs, long out_elems, float* out, const float* res, const float* mask,
+                            int relu, hipStream_t s);       // conv_igemm.hip: split-K reduce + epilogue
+
+extern "C" size_t mi_conv3d_direct_wimg_bytes(int channels) { return mi_direct3_wimg_bytes(channels); }
+extern "C" size_t mi_conv3d_direct_workspace_bytes(int N, int channels) { return mi_direct3_slab_bytes(N, channels); }
 
 extern "C" int mi_conv3d_direct_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
-    return mi_direct3_usable(N, Di, Hi, Wi, Ci, Co, k, k, k, stride, pad, pad, pad, 1, 1, 1) ? 1 : 0;
+    return mi_direct3_kind(N, Di, Hi, Wi, Ci, Co, k, k, k, stride, pad, pad, pad, 1, 1, 1);
 }
 
-extern "C" int mi_conv3d_direct_prep(const void* const* w, void* const* img, const int* dgrad, int n, mi_stream_t stream) {
-    if (!w || !img || !dgrad || n < 0) return MI_E_ARG;
+extern "C" int mi_conv3d_direct_prep(const void* const* w, void* const* img, const int* dgrad, const int* channels, int n,
+                                     mi_stream_t stream) {
+    if (!w || !img || !dgrad || !channels || n < 0) return MI_E_ARG;
     if (n == 0) return MI_OK;
-    return mi_direct3_prep(reinterpret_cast<const float* const*>(w), img, dgrad, n, (hipStream_t)stream);
+    return mi_direct3_prep(reinterpret_cast<const float* const*>(w), img, dgrad, channels, n, (hipStream_t)stream);
 }
 
 extern "C" int mi_conv3d_direct_f32(const float* a, const void* wimg, float* out, const float* res, const float* mask,
-                                    int relu, int N, int D, mi_stream_t stream) {
+                                    int relu, int N, int Di, int Hi, int Wi, int channels, void* ws, size_t ws_bytes,
+                                    mi_stream_t stream) {
     if (!a || !wimg || !out) return MI_E_ARG;
-    if (!mi_direct3_usable(N, D, 8, 8, C, C, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1)) return MI_E_UNSUPPORTED;
-    return mi_direct3_launch(a, wimg, out, res, mask, relu, N, D, (hipStream_t)stream);
+    const int kind = mi_direct3_kind(N, Di, Hi, Wi, channels, channels, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1);
+    if (kind == 1) return mi_direct3_launch(a, wimg, out, res, mask, relu, N, Di, (hipStream_t)stream);
+    if (kind == 2) {
+        if (!ws || ws_bytes < mi_direct3_slab_bytes(N, channels)) return MI_E_WORKSPACE;
+        int rc = mi_direct3s_launch(a, wimg, (float*)ws, N, (hipStream_t)stream);
+        if (rc) return rc;
+        return mi_direct3_finish_slabs((const float*)ws, S_CHUNKS, (long)N * VS * CS, out, res, mask, relu, (hipStream_t)stream);
+    }
+    return MI_E_UNSUPPORTED;
 }

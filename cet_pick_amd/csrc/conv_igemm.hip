@@ -43,14 +43,20 @@ size_t mi_stem7_wgrad_workspace_bytes(int N, int D, int H, int W, int Co);
 int mi_stem7_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Co, void* ws,
                    size_t ws_bytes, hipStream_t s);
 
-// conv_direct3.hip: direct kernel for 3^3 / stride 1 / 64 -> 64 channels on 8 x 8 planes (layer1 of the MoCo-3D encoder),
-// forward and data gradient, bf16x3 arithmetic only
-bool mi_direct3_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph,
-                       int pw, int dd, int dh, int dw);
-size_t mi_direct3_wimg_bytes();
-int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, int n, hipStream_t s);
+// conv_direct3.hip: patch-resident direct kernels for the 3^3 / stride 1 convolutions of layer1 (64 -> 64 channels on 8 x 8
+// planes: forward, data and weight gradient) and layer2 (128 -> 128 on 4 x 4 x 4: forward, data gradient) of the MoCo-3D
+// encoder, bf16x3 arithmetic only
+int mi_direct3_kind(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph,
+                    int pw, int dd, int dh, int dw);
+size_t mi_direct3_wimg_bytes(int channels);
+size_t mi_direct3_slab_bytes(int N, int channels);
+int mi_direct3_splits(int channels);
+int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, const int* channels, int n, hipStream_t s);
 int mi_direct3_launch(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
                       int D, hipStream_t s);
+int mi_direct3s_launch(const float* a, const void* wimg, float* slabs, int N, hipStream_t s);
+int mi_direct3_finish_slabs(const float* slabs, int n_slabs, long out_elems, float* out, const float* res, const float* mask,
+                            int relu, hipStream_t s);
 size_t mi_direct3_wgrad_slab_bytes();
 int mi_direct3_wgrad_splits();
 int mi_direct3_wgrad_launch(const float* x, const float* dy, float* slabs, int N, int D, hipStream_t s);
@@ -1117,8 +1123,16 @@ bool is_stem7(const Geom& g) {
            g.dd == 1 && g.dh == 1 && g.dw == 1;
 }
 
-bool is_direct3(const Geom& g) {
-    return mi_direct3_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw);
+int direct3_kind(const Geom& g) {
+    return mi_direct3_kind(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw);
+}
+// workspace of the direct kernels for this geometry: weight image (+ split-K slabs), or the weight-gradient slabs
+size_t direct3_ws_bytes(const Geom& g) {
+    const int kind = direct3_kind(g);
+    if (!kind) return 0;
+    size_t b = mi_align_up(mi_direct3_wimg_bytes(g.Ci), 256) + mi_direct3_slab_bytes(g.N, g.Ci);
+    if (kind == 1) b = std::max(b, mi_direct3_wgrad_slab_bytes());
+    return b;
 }
 
 // defer_splits != null (weight gradients only): a split launch leaves its slabs in `ws` un-reduced and reports the split
@@ -1154,15 +1168,22 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
     }
     // layer1-shaped convolutions (3^3, stride 1, 64 -> 64 channels, 8 x 8 planes): patch-resident direct kernel; the
     // weight image goes into `ws` (a short ws keeps the implicit GEMM)
-    if (mode != MODE_WGRAD && conv_arith_bf16x3() && is_direct3(g) && ws && ws_bytes >= mi_direct3_wimg_bytes()) {
+    const int dkind = conv_arith_bf16x3() ? direct3_kind(g) : 0;
+    const size_t dimg = mi_align_up(mi_direct3_wimg_bytes(g.Ci), 256);
+    if (mode != MODE_WGRAD && dkind && ws && ws_bytes >= dimg + mi_direct3_slab_bytes(g.N, g.Ci)) {
         const float* wl[1] = {b_src};
         void* il[1] = {ws};
-        const int dg[1] = {mode == MODE_DGRAD ? 1 : 0};
-        int rc = mi_direct3_prep(wl, il, dg, 1, s);
+        const int dg[1] = {mode == MODE_DGRAD ? 1 : 0}, ch[1] = {g.Ci};
+        int rc = mi_direct3_prep(wl, il, dg, ch, 1, s);
         if (rc) return rc;
-        return mi_direct3_launch(a_src, ws, out, res, mask, relu, g.N, g.Di, s);
+        if (dkind == 1) return mi_direct3_launch(a_src, ws, out, res, mask, relu, g.N, g.Di, s);
+        float* slabs = (float*)((char*)ws + dimg);               // 128-channel kernel: split-K slabs behind the image
+        rc = mi_direct3s_launch(a_src, ws, slabs, g.N, s);
+        if (rc) return rc;
+        return mi_direct3_finish_slabs(slabs, mi_direct3_splits(g.Ci), (long)g.N * g.Di * g.Hi * g.Wi * g.Ci, out, res, mask,
+                                       relu, s);
     }
-    if (mode == MODE_WGRAD && conv_arith_bf16x3() && is_direct3(g) && ws && ws_bytes >= mi_direct3_wgrad_slab_bytes()) {
+    if (mode == MODE_WGRAD && dkind == 1 && ws && ws_bytes >= mi_direct3_wgrad_slab_bytes()) {
         int rc = mi_direct3_wgrad_launch(a_src, b_src, (float*)ws, g.N, g.Di, s);
         if (rc) return rc;
         const int splits = mi_direct3_wgrad_splits();
@@ -1206,12 +1227,22 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
 
 }  // namespace
 
+// split-K slabs of a direct kernel -> out, with the convolution epilogue (conv_direct3.hip)
+int mi_direct3_finish_slabs(const float* slabs, int n_slabs, long out_elems, float* out, const float* res, const float* mask,
+                            int relu, hipStream_t s) {
+    const long n4 = out_elems / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 2048)), dim3(256), 0, s, slabs,
+                       n_slabs, out_elems, out, res, mask, relu, n4, 0);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
 extern "C" size_t mi_conv3d_workspace_bytes(int N, int Di, int Hi, int Wi, int Ci, int Co, int k,
                                             int stride, int pad) {
     Geom g = make_geom(N, Di, Hi, Wi, Ci, Co, k, stride, pad);
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
-    if (is_direct3(g)) best = std::max(best, std::max(mi_direct3_wimg_bytes(), mi_direct3_wgrad_slab_bytes()));
+    best = std::max(best, direct3_ws_bytes(g));
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;
@@ -1260,7 +1291,7 @@ extern "C" size_t mi_convnd_workspace_bytes(int N, int Di, int Hi, int Wi, int C
     Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
-    if (is_direct3(g)) best = std::max(best, std::max(mi_direct3_wimg_bytes(), mi_direct3_wgrad_slab_bytes()));
+    best = std::max(best, direct3_ws_bytes(g));
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;
@@ -1331,7 +1362,7 @@ extern "C" size_t mi_convnd_dil_workspace_bytes(int N, int Di, int Hi, int Wi, i
     Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, 1, pd, ph, pw, dd, dh, dw);
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
-    if (is_direct3(g)) best = std::max(best, std::max(mi_direct3_wimg_bytes(), mi_direct3_wgrad_slab_bytes()));
+    best = std::max(best, direct3_ws_bytes(g));
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;

@@ -217,22 +217,22 @@ class WeightImages:
     def __init__(self):
         self._groups = {}            # group -> list of (weight, dgrad flag, image tensor)
         self._by_weight = {}         # (weight storage address, dgrad) -> image tensor
-        self.launches = 0
 
     @staticmethod
     def eligible(w, k, stride, pad):
-        return (w.is_cuda and tuple(w.shape[:2]) == (64, 64) and _k3(k, True) == (3, 3, 3) and stride == 1
+        return (w.is_cuda and tuple(w.shape[:2]) in ((64, 64), (128, 128)) and _k3(k, True) == (3, 3, 3) and stride == 1
                 and _p3(pad, True) == (1, 1, 1) and _phys_ok(w))
 
     def add(self, group, w, dgrad):
-        nb = L.lib().mi_conv3d_direct_wimg_bytes()
+        nb = L.lib().mi_conv3d_direct_wimg_bytes(int(w.shape[0]))
         img = torch.empty(nb, dtype=torch.uint8, device=w.device)
         self._groups.setdefault(group, []).append((w, int(bool(dgrad)), img))
         self._by_weight[(w.data_ptr(), int(bool(dgrad)))] = img
 
     def get(self, w, dgrad, n, d, h, wd):
         img = self._by_weight.get((w.data_ptr(), int(bool(dgrad))))
-        if img is None or not L.lib().mi_conv3d_direct_usable(n, d, h, wd, 64, 64, 3, 1, 1):
+        c = int(w.shape[0])
+        if img is None or not L.lib().mi_conv3d_direct_usable(n, d, h, wd, c, c, 3, 1, 1):
             return None
         return img
 
@@ -246,9 +246,10 @@ class WeightImages:
         ws = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in items])
         imgs = (ctypes.c_void_p * n)(*[it[2].data_ptr() for it in items])
         dg = (ctypes.c_int * n)(*[it[1] for it in items])
+        ch = (ctypes.c_int * n)(*[int(it[0].shape[0]) for it in items])
         L.check(L.lib().mi_conv3d_direct_prep(ctypes.cast(ws, ctypes.c_void_p), ctypes.cast(imgs, ctypes.c_void_p),
-                                              ctypes.cast(dg, ctypes.c_void_p), n, L.stream()), "mi_conv3d_direct_prep")
-        self.launches += (n + 15) // 16
+                                              ctypes.cast(dg, ctypes.c_void_p), ctypes.cast(ch, ctypes.c_void_p), n,
+                                              L.stream()), "mi_conv3d_direct_prep")
 
     def versions(self):
         """Sum of the torch version counters of the cached weights: changes when anything but the engine's own kernels
@@ -290,8 +291,9 @@ def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None):
     y = torch.empty((n, do, ho, wo, co) if nd5 else (n, ho, wo, co), dtype=torch.float32, device=x.device)
     img = _cached_image(w, False, n, d, h, wd, k3, stride, p3) if nd5 else None
     if img is not None:
-        L.check(lib.mi_conv3d_direct_f32(L.ptr(x), L.ptr(img), L.ptr(y), L.ptr(res), None, int(relu), n, d, L.stream()),
-                "mi_conv3d_direct_f32")
+        ws = _ws(lib.mi_conv3d_direct_workspace_bytes(n, ci), x.device, "conv")
+        L.check(lib.mi_conv3d_direct_f32(L.ptr(x), L.ptr(img), L.ptr(y), L.ptr(res), None, int(relu), n, d, h, wd, ci,
+                                         L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_direct_f32")
         return y
     ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), x.device, "conv")
     def call():
@@ -321,8 +323,9 @@ def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None, dil=None):
         return dx
     img = _cached_image(w, True, n, d, h, wd, k3, stride, p3) if (nd5 and dil is None) else None
     if img is not None:
-        L.check(lib.mi_conv3d_direct_f32(L.ptr(dy), L.ptr(img), L.ptr(dx), L.ptr(res), L.ptr(mask), 0, n, d, L.stream()),
-                "mi_conv3d_direct_f32")
+        ws = _ws(lib.mi_conv3d_direct_workspace_bytes(n, ci), dy.device, "conv")
+        L.check(lib.mi_conv3d_direct_f32(L.ptr(dy), L.ptr(img), L.ptr(dx), L.ptr(res), L.ptr(mask), 0, n, d, h, wd, ci,
+                                         L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_direct_f32")
         return dx
     ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), dy.device, "conv")
     def call():

@@ -209,21 +209,27 @@ int mi_convnd_wgrad_slabs_f32(const float* x, const float* dy, float* dw, int N,
 int mi_splitk_reduce_batch(const void* const* slabs, void* const* outs, const int* n_slabs, const long* out_elems, int n,
                            mi_stream_t stream);
 
-/* Patch-resident direct kernel for the layer1 convolutions of the MoCo-3D encoder (models/networks/moco_encoder_3d.py:55-84,
- * 170: nn.Conv3d(64, 64, 3, stride 1, padding 1) on 8 x 8 planes; D even), forward and data gradient, bf16x3 arithmetic.
- * mi_conv3d_fwd_f32 / mi_conv3d_dgrad_f32 (and the mi_convnd_* forms) take it by themselves for such shapes and build the
- * weight image in `ws` on every call (MI_CONV_NO_DIRECT=1 keeps the implicit GEMM).  A caller that knows when the weights
- * change keeps the images instead: mi_conv3d_direct_prep cuts n weight tensors ([tap][Cin][Cout] f32) into n images of
- * mi_conv3d_direct_wimg_bytes() bytes in ONE launch (dgrad[i] != 0: the transposed, tap-flipped image the data gradient
- * needs; the three arrays are HOST arrays), and mi_conv3d_direct_f32 runs
- *   forward  (image with dgrad = 0): out = act(conv(a, w) + res)              a = x,  relu as given, mask NULL
+/* Patch-resident direct kernels for the 3^3 / stride 1 / padding 1 convolutions of the MoCo-3D encoder's residual layers
+ * (models/networks/moco_encoder_3d.py:55-84,170-171), forward and data gradient, bf16x3 arithmetic:
+ *   channels 64 : nn.Conv3d(64, 64, 3, 1, 1) on (N, D, 8, 8, 64), D even                  (layer1)
+ *   channels 128: nn.Conv3d(128, 128, 3, 1, 1) on (N, 4, 4, 4, 128)                        (layer2)
+ * mi_conv3d_fwd_f32 / mi_conv3d_dgrad_f32 (and the mi_convnd_* forms) take them by themselves for such shapes and build
+ * the weight image in `ws` on every call (MI_CONV_NO_DIRECT=1 keeps the implicit GEMM).  A caller that knows when the
+ * weights change keeps the images instead: mi_conv3d_direct_prep cuts n weight tensors ([tap][Cin][Cout] f32, channels[i]
+ * = 64 or 128) into n images of mi_conv3d_direct_wimg_bytes(channels[i]) bytes in one launch per channel count (dgrad[i]
+ * != 0: the transposed, tap-flipped image the data gradient needs; the four arrays are HOST arrays), and
+ * mi_conv3d_direct_f32 runs
+ *   forward  (image with dgrad = 0): out = act(conv(a, w) + res)                       a = x,  relu as given, mask NULL
  *   dgrad    (image with dgrad = 1): out = (conv_transpose(a, w) + res) * (mask > 0)   a = dy, relu 0
- * on (N, D, 8, 8, 64) tensors.  MI_E_UNSUPPORTED for any other shape (mi_conv3d_direct_usable tells). */
-size_t mi_conv3d_direct_wimg_bytes(void);
+ * `ws`: mi_conv3d_direct_workspace_bytes(N, channels) bytes (split-K slabs of the 128-channel kernel; 0 for 64).
+ * MI_E_UNSUPPORTED for any other shape (mi_conv3d_direct_usable: 0 / 1 (64 channels) / 2 (128 channels)). */
+size_t mi_conv3d_direct_wimg_bytes(int channels);
+size_t mi_conv3d_direct_workspace_bytes(int N, int channels);
 int mi_conv3d_direct_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad);
-int mi_conv3d_direct_prep(const void* const* w, void* const* img, const int* dgrad, int n, mi_stream_t stream);
+int mi_conv3d_direct_prep(const void* const* w, void* const* img, const int* dgrad, const int* channels, int n,
+                          mi_stream_t stream);
 int mi_conv3d_direct_f32(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu,
-                         int N, int D, mi_stream_t stream);
+                         int N, int Di, int Hi, int Wi, int channels, void* ws, size_t ws_bytes, mi_stream_t stream);
 
 /* Dilated windows, stride 1 (kernel (3,3,3), dilation (1,4,4), padding (1,4,4): the 3-D head of the detector
  * network, models/networks/unet_small.py:38-41).  Same contract as mi_convnd_*; output extent per axis

@@ -113,20 +113,22 @@ def test_conv_bf16x3_is_f32_equivalent(case, monkeypatch):
         assert e3 <= 2.0 * e32 + 2e-7, errs     # ... and no worse than the f32 matrix instruction
 
 
-@pytest.mark.parametrize("n,d", [(3, 8), (5, 2), (2, 6), (64, 8)])
-def test_conv_direct3_matches_igemm_and_float64(n, d, monkeypatch):
-    """layer1-shaped convolutions (3^3, stride 1, 64 -> 64, 8 x 8 planes) take the patch-resident direct kernel
-    (conv_direct3.hip); MI_CONV_NO_DIRECT=1 keeps the implicit GEMM.  Both are the bf16x3 arithmetic: equal up to the
+@pytest.mark.parametrize("n,d,hw,c", [(3, 8, 8, 64), (5, 2, 8, 64), (2, 6, 8, 64), (64, 8, 8, 64),
+                                      (5, 4, 4, 128), (2, 4, 4, 128), (64, 4, 4, 128)])
+def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
+    """layer1- (3^3, stride 1, 64 -> 64, 8 x 8 planes) and layer2-shaped (128 -> 128, 4 x 4 x 4; odd batch: a half-empty
+    sample pair) convolutions take the patch-resident direct kernels (conv_direct3.hip); MI_CONV_NO_DIRECT=1 keeps the
+    implicit GEMM.  Both are the bf16x3 arithmetic: equal up to the
     summation order, and both at f32 level against float64 - forward with residual + ReLU, data gradient with
     residual + mask, weight gradient; every z tile position (first / interior / last plane pair)."""
     from cet_pick_amd import hipops as H
     from conftest import f32_equivalent
-    g = torch.Generator().manual_seed(100 * n + d)
-    x = torch.randn(n, 64, d, 8, 8, generator=g) * torch.exp(2 * torch.randn(n, 64, d, 8, 8, generator=g))
-    param, w = make_w(64, 64, 3, g)
-    res = torch.randn(n, 64, d, 8, 8, generator=g)
-    mask = torch.randn(n, 64, d, 8, 8, generator=g)
-    dy = torch.randn(n, 64, d, 8, 8, generator=g)
+    g = torch.Generator().manual_seed(100 * n + d + c)
+    x = torch.randn(n, c, d, hw, hw, generator=g) * torch.exp(2 * torch.randn(n, c, d, hw, hw, generator=g))
+    param, w = make_w(c, c, 3, g)
+    res = torch.randn(n, c, d, hw, hw, generator=g)
+    mask = torch.randn(n, c, d, hw, hw, generator=g)
+    dy = torch.randn(n, c, d, hw, hw, generator=g)
     def chain(xx, ww, rr, mm, dd):
         xx = xx.clone().requires_grad_(True)
         ww = ww.clone().requires_grad_(True)
@@ -139,7 +141,7 @@ def test_conv_direct3_matches_igemm_and_float64(n, d, monkeypatch):
     for tag, off in (("direct", "0"), ("igemm", "1")):
         monkeypatch.setenv("MI_CONV_NO_DIRECT", off)
         yf = H.conv_fwd(cl(x), param, 3, 1, 1, cl(res), True)
-        yd = H.conv_dgrad(cl(dy), param, (n, d, 8, 8, 64), 3, 1, 1, cl(res), cl(mask))
+        yd = H.conv_dgrad(cl(dy), param, (n, d, hw, hw, c), 3, 1, 1, cl(res), cl(mask))
         param.grad = None
         H.conv_wgrad_into(cl(x), cl(dy), param, 3, 1, 1)
         out[tag] = (yf.cpu(), yd.cpu(), param.grad.detach().cpu().clone())
