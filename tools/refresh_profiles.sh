@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round-end collection of everything under profiles/ that is measured (run on the GPU box through gpurun):
+#   tools/refresh_profiles.sh <round tag, e.g. r02>
+# leaves raw rocprofv3 output under gpurun_out/<tag>_final/; tools/refresh_profiles_local.sh turns it into profiles/<tag>_*.
+set -e
+R=${GRAFT_REPO_ROOT:-/root/repo}
+T=${1:-r02}
+O=$T"_final"
+mkdir -p $R/gpurun_out/$O
+cd $R
+# 1. kernel traces (rocprofv3 --kernel-trace --stats, program directly behind `--`)
+tools/gprof.sh $O/train $R/bench.py --no-graph --no-conv-profile --no-secondary --no-cpu-baseline --steps 100 --warmup 10 > gpurun_out/$O/train.txt 2>&1
+tools/gprof.sh $O/infer $R/tools/prof_infer.py both 10 > gpurun_out/$O/infer.txt 2>&1
+echo "traces done"
+# 2. PMC passes (counters only, one pass per group)
+tools/pmc_run.sh $O/pmc_infer FETCH_SIZE:WRITE_SIZE $R/tools/prof_infer.py both 5
+tools/pmc_run.sh $O/pmc_train FETCH_SIZE:WRITE_SIZE:SQ_VALU_MFMA_BUSY_CYCLES,GRBM_GUI_ACTIVE $R/bench.py --no-graph --no-conv-profile --no-secondary --no-cpu-baseline --steps 6 --warmup 3
+echo "pmc done"

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Summaries of tools/refresh_profiles.sh's raw output -> profiles/<tag>_* (stamped with the kernel-source hashes).
+set -e
+cd "$(dirname "$0")/.."
+T=${1:-r02}
+O=gpurun_out/$T"_final"
+cp $O/train/out_kernel_stats.csv profiles/${T}_train_kernel_stats.csv
+cp $O/infer/out_kernel_stats.csv profiles/${T}_infer_kernel_stats.csv
+python tools/pmc_summary.py $O/pmc_infer profiles/${T}_infer_traffic.json --sources infer_,common --per-step 5 \
+  --note "tools/prof_infer.py both 5: 5 fused decodes (logits 128x256x256, K=900) + 5 DoG picks (256x512x512, sigma 3/5); per-launch averages" > /dev/null
+mkdir -p $O/pmc_traffic $O/pmc_busy
+rm -rf $O/pmc_traffic/* $O/pmc_busy/*
+cp -r $O/pmc_train/FETCH_SIZE $O/pmc_train/WRITE_SIZE $O/pmc_traffic/
+cp -r "$O/pmc_train/SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE" $O/pmc_busy/
+python tools/pmc_summary.py $O/pmc_traffic profiles/${T}_conv_traffic.json --sources conv_ --per-step 9 --kernels conv_igemm,stem_,direct3,splitk \
+  --note "bench.py --no-secondary --no-cpu-baseline --no-conv-profile --no-graph --steps 6 --warmup 3 (9 eager steps): the conv family of the MoCo-3D step" > /dev/null
+python tools/pmc_summary.py $O/pmc_busy profiles/${T}_mfma_busy.json --sources conv_,loss_ --per-step 9 --kernels conv_igemm,stem_,direct3 \
+  --note "same run; SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE in one pass" > /dev/null
+python - <<PY
+import json
+for f in ("conv_traffic", "mfma_busy", "infer_traffic"):
+    d = json.load(open("profiles/${T}_%s.json" % f))
+    print(f, d["source_sha16"], len(d["kernels"]), "kernels", d.get("hbm_bytes_per_step"))
+PY
