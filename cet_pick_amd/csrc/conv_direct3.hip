@@ -94,6 +94,8 @@ __device__ __forceinline__ void cut8(const float (&v)[8], u32x4 (&o)[3]) {
     }
 }
 
+// (Measured and rejected: eight waves per workgroup - two quartets splitting the reduction over the same tile, two waves
+// per SIMD, partial sums exchanged through LDS at the end - 36.9 us against 32.3 us for this form.)
 __global__ __launch_bounds__(256, 1) void direct3_kernel(Direct3Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char patch[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
