@@ -308,8 +308,19 @@ struct PrepBatch {
     const float* w[PREP_MAX];
     unsigned char* img[PREP_MAX];
     int dgrad[PREP_MAX];
+    int wide[PREP_MAX];       // 0: 64-channel image (this kernel's), 1: 128-channel image (direct3s_prep_body)
 };
+__device__ void direct3s_prep_body(const float* w, unsigned char* img, int dgrad, int idx);
+constexpr int PREP_BLOCKS = NTAP * KS * 2 * 64 / 256;                     // 54
+constexpr int PREP_BLOCKS_WIDE = 4 * NTAP * 2 * 4 * 64 / 256;             // 216
+// one launch cuts every image of a batch, both formats: blockIdx.y = image, blockIdx.x = its blocks (the narrow format
+// uses the first 54 of them)
 __global__ __launch_bounds__(256) void direct3_prep_kernel(PrepBatch b) {
+    if (b.wide[blockIdx.y]) {
+        direct3s_prep_body(b.w[blockIdx.y], b.img[blockIdx.y], b.dgrad[blockIdx.y], blockIdx.x * 256 + threadIdx.x);
+        return;
+    }
+    if (blockIdx.x >= PREP_BLOCKS) return;
     const float* w = b.w[blockIdx.y];
     unsigned char* img = b.img[blockIdx.y];
     const int dgrad = b.dgrad[blockIdx.y];
@@ -741,11 +752,8 @@ __global__ __launch_bounds__(256, 2) void direct3s_kernel(Direct3sParams p) {
 }
 
 // weight image of the 128-channel kernel: [chunk 4][tap 27][ks 2][column block 4][plane 3][lane 64] x 16 bytes
-__global__ __launch_bounds__(256) void direct3s_prep_kernel(PrepBatch b) {
-    const float* w = b.w[blockIdx.y];
-    unsigned char* img = b.img[blockIdx.y];
-    const int dgrad = b.dgrad[blockIdx.y];
-    const int idx = blockIdx.x * 256 + threadIdx.x;          // (chunk, tap, ks, cb, lane): 4 * 27 * 2 * 4 * 64 = 216 * 256
+__device__ void direct3s_prep_body(const float* w, unsigned char* img, int dgrad, int idx) {
+    // idx = (chunk, tap, ks, cb, lane): 4 * 27 * 2 * 4 * 64 = 216 * 256
     const int lane = idx & 63, cb = (idx >> 6) & 3, ksx = (idx >> 8) & 1, rest = idx >> 9, tap = rest % NTAP, cc = rest / NTAP;
     const int nn = cb * 32 + (lane & 31), k0 = cc * 32 + ksx * 16 + 8 * (lane >> 5);
     float v[8];
@@ -794,27 +802,19 @@ int mi_direct3_splits(int channels) { return channels == CS ? S_CHUNKS : 1; }
 
 // channels[i] = 64 or 128 selects the image format of weight i
 int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, const int* channels, int n, hipStream_t s) {
-    for (int kind = 0; kind < 2; ++kind) {
-        const int want = kind == 0 ? C : CS;
+    for (int i0 = 0; i0 < n; i0 += PREP_MAX) {
         PrepBatch b = {};
-        int m = 0;
-        auto flush = [&]() -> int {
-            if (m == 0) return MI_OK;
-            if (kind == 0) hipLaunchKernelGGL(direct3_prep_kernel, dim3(NTAP * KS * 2 * 64 / 256, m), dim3(256), 0, s, b);
-            else hipLaunchKernelGGL(direct3s_prep_kernel, dim3(S_CHUNKS * NTAP * 2 * 4 * 64 / 256, m), dim3(256), 0, s, b);
-            MI_RETURN_IF_LAUNCH_FAILED();
-            m = 0;
-            return MI_OK;
-        };
-        for (int i = 0; i < n; ++i) {
-            if (channels[i] != C && channels[i] != CS) return MI_E_ARG;
-            if (channels[i] != want) continue;
-            if (!w[i] || !img[i]) return MI_E_ARG;
-            b.w[m] = w[i]; b.img[m] = (unsigned char*)img[i]; b.dgrad[m] = dgrad[i];
-            if (++m == PREP_MAX) { int rc = flush(); if (rc) return rc; }
+        const int m = n - i0 < PREP_MAX ? n - i0 : PREP_MAX;
+        bool any_wide = false;
+        for (int i = 0; i < m; ++i) {
+            const int ch = channels[i0 + i];
+            if ((ch != C && ch != CS) || !w[i0 + i] || !img[i0 + i]) return MI_E_ARG;
+            b.w[i] = w[i0 + i]; b.img[i] = (unsigned char*)img[i0 + i]; b.dgrad[i] = dgrad[i0 + i];
+            b.wide[i] = ch == CS;
+            any_wide |= ch == CS;
         }
-        int rc = flush();
-        if (rc) return rc;
+        hipLaunchKernelGGL(direct3_prep_kernel, dim3(any_wide ? PREP_BLOCKS_WIDE : PREP_BLOCKS, m), dim3(256), 0, s, b);
+        MI_RETURN_IF_LAUNCH_FAILED();
     }
     return MI_OK;
 }

@@ -33,6 +33,10 @@ struct ColReduceParams {
     // BNBWD_X: the ReLU mask is recomputed from x (y = relu(bn(x)) was never stored): y > 0 <=> xhat*gamma + beta > 0
     const float* gamma;
     const float* beta;
+    // a launch of ONE workgroup writes the final sums itself (no finalize launch): sums_direct[2][C], f32_direct[n_f32]
+    double* sums_direct;
+    float* f32_direct;
+    int n_f32;
 };
 
 template <int MODE>
@@ -96,9 +100,15 @@ __global__ __launch_bounds__(256) void colreduce_kernel(ColReduceParams p) {
         for (int rr = 0; rr < RS; ++rr)
 #pragma unroll
             for (int i = 0; i < 4; ++i) { a0[i] += red[0][rr * CV + tcol][i]; a1[i] += red[1][rr * CV + tcol][i]; }
-        double* dst = p.partials + (long)blockIdx.x * 2 * p.C;
+        double* dst = p.sums_direct ? p.sums_direct : p.partials + (long)blockIdx.x * 2 * p.C;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { dst[4 * tcol + i] = a0[i]; dst[p.C + 4 * tcol + i] = a1[i]; }
+        for (int i = 0; i < 4; ++i) {
+            dst[4 * tcol + i] = a0[i]; dst[p.C + 4 * tcol + i] = a1[i];
+            if (p.f32_direct) {
+                if (4 * tcol + i < p.n_f32) p.f32_direct[4 * tcol + i] = (float)a0[i];
+                if (p.C + 4 * tcol + i < p.n_f32) p.f32_direct[p.C + 4 * tcol + i] = (float)a1[i];
+            }
+        }
     }
 }
 
@@ -131,6 +141,12 @@ int run_colreduce(ColReduceParams p, double* sums, void* ws, size_t ws_bytes, hi
     int blocks = colreduce_blocks(p.M, p.C);
     if (!ws || ws_bytes < sizeof(double) * 2 * p.C * (size_t)blocks) return MI_E_WORKSPACE;
     p.partials = (double*)ws;
+    if (blocks == 1) {       // few rows: the one workgroup's partial sums ARE the sums (the finalize would add zeros to them)
+        p.sums_direct = sums; p.f32_direct = sums_f32; p.n_f32 = n_f32;
+        hipLaunchKernelGGL((colreduce_kernel<MODE>), dim3(1), dim3(256), 0, s, p);
+        MI_RETURN_IF_LAUNCH_FAILED();
+        return MI_OK;
+    }
     hipLaunchKernelGGL((colreduce_kernel<MODE>), dim3(blocks), dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((2 * p.C + 7) / 8), dim3(256), 0, s,
