@@ -1,0 +1,201 @@
+// 3x3x3 / stride 1 / padding 1 convolutions on 2 x 2 x 2 volumes (layer3 and feature_3d of the MoCo-3D encoder,
+// cet_pick/models/networks/moco_encoder_3d.py:55-84,172,178: 256 -> 256 channels, four per encoder pass), forward and data
+// gradient, bf16x3 arithmetic.
+//
+// On a 2^3 volume every (input voxel i, output voxel o) pair is connected by exactly ONE tap (per axis t = i - o + 1 is
+// 0, 1 or 2), so the convolution of a sample is a dense product with no padding at all:
+//   Y[n][(o, co)] = sum over (i, ci) of X[n][(i, ci)] * W[tap(i, o)][ci][co]          - a (N x 8C) . (8C x 8C) GEMM
+// whose A operand is the activation tensor as it lies in memory.  N is the batch (64 rows): far too few rows for the
+// implicit GEMM's tile pipeline (12 - 19 us per launch + a 4 us split-K reduce for 0.5 GFLOP: launch, prologue and
+// per-slice barrier latency).  Here nothing is staged: a wave owns 64 rows x 32 columns x a sixteenth of the reduction,
+// loads its A fragments (8 consecutive channels of a row: two 16-byte loads) and B fragments (forward: 8 strided dwords;
+// data gradient: the same 8 values are contiguous in W) straight from L2 into registers, one k-step ahead, cuts them there
+// (three bf16 planes) and issues the six products.  The four waves of a workgroup split a quarter of the reduction and
+// add their tiles through LDS; 8C/32 column blocks x 4 quarters = 256 workgroups write four slabs that the caller's reduce
+// launch sums (with the convolution's epilogue).  No weight image, no LDS tile, one barrier.  (Sixteen waves per workgroup
+// reducing a whole tile in one launch - no slabs, epilogue in the kernel - were measured: 64 workgroups on 64 CUs take
+// 20.7 / 24.5 us against 10.5 + 4.2 us for this form.)
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KQ = 4;                       // reduction quarters (split-K slabs); x 4 waves = 16 parts
+
+struct Cube2Params {
+    const float* a;           // X (forward) or dY (data gradient): (N, 2, 2, 2, C) = N rows of 8 C
+    const float* w;           // [27][C][C] f32, kernel layout [tap][ci][co]
+    float* slabs;             // KQ slabs of (N * 8, C) floats
+    int N, C;
+    unsigned a_bytes, w_bytes;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of2(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+
+// exact three-way bf16 cut of 8 f32 (truncation, as conv_igemm.hip / conv_direct3.hip)
+__device__ __forceinline__ void cut8r(const float (&v)[8], bf16x8 (&o)[3]) {
+    unsigned u0[8], u1[8], u2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        u0[t] = __float_as_uint(v[t]);
+        const float r1 = v[t] - __uint_as_float(u0[t] & 0xffff0000u);
+        u1[t] = __float_as_uint(r1);
+        u2[t] = __float_as_uint(r1 - __uint_as_float(u1[t] & 0xffff0000u));
+    }
+    constexpr unsigned HI2 = 0x07060302u;
+    u32x4 p0, p1, p2;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        p0[d] = __builtin_amdgcn_perm(u0[2 * d + 1], u0[2 * d], HI2);
+        p1[d] = __builtin_amdgcn_perm(u1[2 * d + 1], u1[2 * d], HI2);
+        p2[d] = __builtin_amdgcn_perm(u2[2 * d + 1], u2[2 * d], HI2);
+    }
+    o[0] = __builtin_bit_cast(bf16x8, p0); o[1] = __builtin_bit_cast(bf16x8, p1); o[2] = __builtin_bit_cast(bf16x8, p2);
+}
+
+// tap index of the pair (voxel on the reduction side kv, voxel on the column side cv): per axis t = in - out + 1
+__device__ __forceinline__ int pair_tap(int in_v, int out_v) {
+    const int tz = ((in_v >> 2) & 1) - ((out_v >> 2) & 1) + 1, ty = ((in_v >> 1) & 1) - ((out_v >> 1) & 1) + 1,
+              tx = (in_v & 1) - (out_v & 1) + 1;
+    return (tz * 3 + ty) * 3 + tx;
+}
+
+template <bool DGRAD, int NS>               // NS = k-steps per wave = (8 C / 16) / (4 quarters x 4 waves) = C / 32
+__global__ __launch_bounds__(256, 2) void cube2_kernel(Cube2Params p) {
+    __shared__ float red[4][32][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    const int C = p.C, cpb = C >> 5;                     // column blocks per voxel
+    const int cbi = blockIdx.x, q = blockIdx.y, mt = blockIdx.z;
+    const int cv = cbi / cpb, cc0 = (cbi % cpb) * 32;    // column side: voxel cv, channels cc0 .. cc0 + 31
+    const int n0 = mt * 64;
+    const __amdgpu_buffer_rsrc_t ars = rsrc_of2(p.a, p.a_bytes), wrs = rsrc_of2(p.w, p.w_bytes);
+
+    // k-steps of this wave: global k-step g = (q * 4 + wave) * NS + s covers reduction voxel kv = g / (C / 16), channels
+    // kc0 = (g % (C / 16)) * 16 .. + 15; this lane's 8 are kc0 + 8 h ..
+    const int g0 = (q * 4 + wave) * NS;
+    unsigned a_row[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int n = n0 + rb * 32 + l32;
+        a_row[rb] = n < p.N ? 4u * (unsigned)((long)n * 8 * C) : 0x80000000u;
+    }
+    constexpr int PD = NS < 4 ? NS : 4;   // k-steps in flight: the loop is a chain of L2 round trips, so the fetches run
+                                          // four k-steps ahead of the MFMAs (one ahead: 12.3 us per launch)
+    u32x4 araw[PD][2][2];              // [set][row block][16-byte half]
+    unsigned braw[PD][8];              // [set][k]
+    auto fetch = [&](int s, auto SETc) {
+        constexpr int SET = decltype(SETc)::value;
+        const int g = g0 + s, kv = g / (C >> 4), kc = (g % (C >> 4)) * 16 + 8 * h;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const unsigned off = a_row[rb] + 4u * (unsigned)(kv * C + kc);
+            araw[SET][rb][0] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)off, 0, 0);
+            araw[SET][rb][1] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(off + 16u), 0, 0);
+        }
+        if (DGRAD) {
+            // reduction side = output voxel kv, channels co; column side = input voxel cv, channel ci = cc0 + l32:
+            // B[k][col] = W[tap(cv, kv)][ci][co]: the lane's 8 k's are contiguous
+            const int tap = pair_tap(cv, kv);
+            const unsigned off = 4u * (unsigned)(((long)tap * C + cc0 + l32) * C + kc);
+            const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)off, 0, 0);
+            const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(off + 16u), 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { braw[SET][e] = lo[e]; braw[SET][4 + e] = hi[e]; }
+        } else {
+            // reduction side = input voxel kv, channels ci; column side = output voxel cv, channel co = cc0 + l32:
+            // B[k][col] = W[tap(kv, cv)][ci][co]: the lane's 8 k's are C floats apart
+            const int tap = pair_tap(kv, cv);
+            const unsigned off = 4u * (unsigned)(((long)tap * C + kc) * C + cc0 + l32);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                braw[SET][e] = __builtin_amdgcn_raw_buffer_load_b32(wrs, (int)(off + 4u * (unsigned)(e * C)), 0, 0);
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+
+    auto fetch_dyn = [&](int s) {
+        switch (s % PD) {
+            case 0: fetch(s, std::integral_constant<int, 0>{}); break;
+            case 1: fetch(s, std::integral_constant<int, 1 % PD>{}); break;
+            case 2: fetch(s, std::integral_constant<int, 2 % PD>{}); break;
+            default: fetch(s, std::integral_constant<int, 3 % PD>{}); break;
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < PD - 1; ++s) fetch_dyn(s);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + PD - 1 < NS) fetch_dyn(s + PD - 1);
+        bf16x8 af[2][3], bf[3];
+        float v[8];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(araw[s % PD][rb][0][e]); v[4 + e] = __uint_as_float(araw[s % PD][rb][1][e]); }
+            cut8r(v, af[rb]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = __uint_as_float(braw[s % PD][e]);
+        cut8r(v, bf);
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][PA[pr]], bf[PB[pr]], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][PA[pr]], bf[PB[pr]], acc[1], 0, 0, 0);
+        }
+    }
+
+    // ---- the four waves' tiles added through LDS (fixed order: wave 0 + 1 + 2 + 3), wave w finishing a quarter ----
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][rb * 16 + r][lane] = acc[rb][r];
+    __syncthreads();
+    float* out = p.slabs + (long)q * ((long)p.N * 8 * C);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = wave * 8 + j, rb = idx >> 4, r = idx & 15;
+        const float t = ((red[0][idx][lane] + red[1][idx][lane]) + red[2][idx][lane]) + red[3][idx][lane];
+        const int n = n0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;          // C/D layout: row of the 32 x 32 block
+        if (n < p.N) out[((long)n * 8 + cv) * C + cc0 + l32] = t;
+    }
+}
+
+}  // namespace
+
+bool mi_cube2_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw,
+                     int dd, int dh, int dw) {
+    const char* off = getenv("MI_CONV_NO_DIRECT");
+    if (off && atoi(off) != 0) return false;
+    if (kd != 3 || kh != 3 || kw != 3 || stride != 1 || pd != 1 || ph != 1 || pw != 1 || dd != 1 || dh != 1 || dw != 1) return false;
+    if (Di != 2 || Hi != 2 || Wi != 2 || Ci != Co) return false;
+    if (Ci != 128 && Ci != 256 && Ci != 512) return false;                    // k-steps per wave = C / 32: 4, 8, 16
+    return N >= 1 && 4l * N * 8 * Ci < 0x7fff0000l;
+}
+
+size_t mi_cube2_slab_bytes(int N, int C) { return sizeof(float) * (size_t)KQ * N * 8 * C; }
+int mi_cube2_splits() { return KQ; }
+
+// KQ partial slabs of (N * 8, C) floats into `slabs`; the caller sums them (+ epilogue)
+int mi_cube2_launch(int dgrad, const float* a, const float* w, float* slabs, int N, int C, hipStream_t s) {
+    Cube2Params p = {a, w, slabs, N, C, (unsigned)(4l * N * 8 * C), (unsigned)(4l * 27 * C * C)};
+    const dim3 grid((unsigned)(8 * C / 32), KQ, (unsigned)((N + 63) / 64));
+#define CUBE2_LAUNCH(D, NSV) hipLaunchKernelGGL((cube2_kernel<D, NSV>), grid, dim3(256), 0, s, p)
+    if (C == 128) { if (dgrad) CUBE2_LAUNCH(true, 4); else CUBE2_LAUNCH(false, 4); }
+    else if (C == 256) { if (dgrad) CUBE2_LAUNCH(true, 8); else CUBE2_LAUNCH(false, 8); }
+    else if (C == 512) { if (dgrad) CUBE2_LAUNCH(true, 16); else CUBE2_LAUNCH(false, 16); }
+    else return MI_E_UNSUPPORTED;
+#undef CUBE2_LAUNCH
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}

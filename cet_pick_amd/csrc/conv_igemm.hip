@@ -60,6 +60,12 @@ int mi_direct3_finish_slabs(const float* slabs, int n_slabs, long out_elems, flo
 size_t mi_direct3_wgrad_slab_bytes();
 int mi_direct3_wgrad_splits();
 int mi_direct3_wgrad_launch(const float* x, const float* dy, float* slabs, int N, int D, hipStream_t s);
+// conv_cube2.hip: 3^3 convolutions on 2 x 2 x 2 volumes (layer3 / feature_3d) as a dense GEMM with register-staged operands
+bool mi_cube2_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw,
+                     int dd, int dh, int dw);
+size_t mi_cube2_slab_bytes(int N, int C);
+int mi_cube2_splits();
+int mi_cube2_launch(int dgrad, const float* a, const float* w, float* slabs, int N, int C, hipStream_t s);
 
 namespace {
 
@@ -1126,8 +1132,12 @@ bool is_stem7(const Geom& g) {
 int direct3_kind(const Geom& g) {
     return mi_direct3_kind(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw);
 }
+bool is_cube2(const Geom& g) {
+    return mi_cube2_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw);
+}
 // workspace of the direct kernels for this geometry: weight image (+ split-K slabs), or the weight-gradient slabs
 size_t direct3_ws_bytes(const Geom& g) {
+    if (is_cube2(g)) return mi_cube2_slab_bytes(g.N, g.Ci);
     const int kind = direct3_kind(g);
     if (!kind) return 0;
     size_t b = mi_align_up(mi_direct3_wimg_bytes(g.Ci), 256) + mi_direct3_slab_bytes(g.N, g.Ci);
@@ -1182,6 +1192,11 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         if (rc) return rc;
         return mi_direct3_finish_slabs(slabs, mi_direct3_splits(g.Ci), (long)g.N * g.Di * g.Hi * g.Wi * g.Ci, out, res, mask,
                                        relu, s);
+    }
+    if (mode != MODE_WGRAD && conv_arith_bf16x3() && is_cube2(g) && ws && ws_bytes >= mi_cube2_slab_bytes(g.N, g.Ci)) {
+        int rc = mi_cube2_launch(mode == MODE_DGRAD ? 1 : 0, a_src, b_src, (float*)ws, g.N, g.Ci, s);
+        if (rc) return rc;
+        return mi_direct3_finish_slabs((const float*)ws, mi_cube2_splits(), (long)g.N * 8 * g.Ci, out, res, mask, relu, s);
     }
     if (mode == MODE_WGRAD && dkind == 1 && ws && ws_bytes >= mi_direct3_wgrad_slab_bytes()) {
         int rc = mi_direct3_wgrad_launch(a_src, b_src, (float*)ws, g.N, g.Di, s);

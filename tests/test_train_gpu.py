@@ -114,11 +114,12 @@ def test_conv_bf16x3_is_f32_equivalent(case, monkeypatch):
 
 
 @pytest.mark.parametrize("n,d,hw,c", [(3, 8, 8, 64), (5, 2, 8, 64), (2, 6, 8, 64), (64, 8, 8, 64),
-                                      (5, 4, 4, 128), (2, 4, 4, 128), (64, 4, 4, 128)])
+                                      (5, 4, 4, 128), (2, 4, 4, 128), (64, 4, 4, 128),
+                                      (64, 2, 2, 256), (5, 2, 2, 256), (70, 2, 2, 128)])
 def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
     """layer1- (3^3, stride 1, 64 -> 64, 8 x 8 planes) and layer2-shaped (128 -> 128, 4 x 4 x 4; odd batch: a half-empty
-    sample pair) convolutions take the patch-resident direct kernels (conv_direct3.hip); MI_CONV_NO_DIRECT=1 keeps the
-    implicit GEMM.  Both are the bf16x3 arithmetic: equal up to the
+    sample pair) convolutions take the patch-resident direct kernels (conv_direct3.hip), 2 x 2 x 2 volumes (layer3,
+    feature_3d) the register-staged dense GEMM (conv_cube2.hip); MI_CONV_NO_DIRECT=1 keeps the implicit GEMM.  Both are the bf16x3 arithmetic: equal up to the
     summation order, and both at f32 level against float64 - forward with residual + ReLU, data gradient with
     residual + mask, weight gradient; every z tile position (first / interior / last plane pair)."""
     from cet_pick_amd import hipops as H
