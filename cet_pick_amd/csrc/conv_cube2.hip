@@ -12,7 +12,10 @@
 // data gradient: the same 8 values are contiguous in W) straight from L2 into registers, one k-step ahead, cuts them there
 // (three bf16 planes) and issues the six products.  The four waves of a workgroup split a quarter of the reduction and
 // add their tiles through LDS; 8C/32 column blocks x 4 quarters = 256 workgroups write four slabs that the caller's reduce
-// launch sums (with the convolution's epilogue).  No weight image, no LDS tile, one barrier.  (Sixteen waves per workgroup
+// launch sums (with the convolution's epilogue).  No weight image, no LDS tile, one barrier.
+// (The weight gradient in the same style - a workgroup per (tap, 64 x 32 tile), the batch as the reduction, every fragment 8
+// dwords 32 KB apart - was built and measured: 17.1 us against 19.0 us for the implicit GEMM + its share of the batch
+// reduce; it is bound by the number of 4-byte load instructions and was not kept.)  (Sixteen waves per workgroup
 // reducing a whole tile in one launch - no slabs, epilogue in the kernel - were measured: 64 workgroups on 64 CUs take
 // 20.7 / 24.5 us against 10.5 + 4.2 us for this form.)
 #include "common.h"
