@@ -174,6 +174,128 @@ __global__ __launch_bounds__(256, 2) void cube2_kernel(Cube2Params p) {
     }
 }
 
+
+// ---- small dense products: the Linear layers of the encoder head (fc, projection MLP: 64 rows) ---------------------------
+//   C[m][n] = sum_k A(m, k) * B(k, n) (+ bias[n]),   A(m, k) = a[m * lda_m + k * lda_k],  B(k, n) = b[k * ldb_k + n * ldb_n]
+// covers y = x W + b (A k-contiguous, B strided), dx = dy W^T (both k-contiguous) and dW = x^T dy (both strided: the batch
+// is the reduction).  Same register-staged form as cube2_kernel: a workgroup owns a 64 x 32 tile, its four waves take the
+// k-steps round-robin and add their tiles through LDS; the launch is final (bias included): no split-K slabs, no reduce
+// launch.  The implicit GEMM spends 8 - 14 us + a reduce launch on each of these 16 calls per step.
+struct SmallGemmParams {
+    const float* a;
+    const float* b;
+    const float* bias;        // may be null
+    float* c;
+    int M, N, K;
+    long lda_m, lda_k, ldb_k, ldb_n;
+    unsigned a_bytes, b_bytes;
+};
+
+template <bool A_KC, bool B_KC, int NS>     // operand is k-contiguous (16-byte loads) or strided (8 dwords); NS k-steps per wave
+__global__ __launch_bounds__(256, 2) void small_gemm_kernel(SmallGemmParams p) {
+    __shared__ float red[4][32][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 64;
+    const int KT = (p.K + 15) >> 4;
+    const __amdgpu_buffer_rsrc_t ars = rsrc_of2(p.a, p.a_bytes), brs = rsrc_of2(p.b, p.b_bytes);
+    constexpr int PD = NS < 4 ? NS : 4;
+    unsigned araw[PD][2][8], braw[PD][8];
+    const bool col_ok = n0 + l32 < p.N;
+    auto fetch = [&](auto Uc) {
+        constexpr int U = decltype(Uc)::value, SET = U % PD;
+        if constexpr (U < NS) {
+            const int ks = wave + 4 * U;
+            const int k0 = ks * 16 + 8 * h;
+            const bool live = ks < KT;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int m = m0 + rb * 32 + l32;
+                const bool ok = live && m < p.M;
+                if (A_KC) {
+                    const unsigned off = (ok && k0 + 8 <= p.K) ? 4u * (unsigned)(m * p.lda_m + k0) : 0x80000000u;
+                    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)off, 0, 0);
+                    const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(off + 16u), 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { araw[SET][rb][e] = lo[e]; araw[SET][rb][4 + e] = hi[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned off = (ok && k0 + e < p.K) ? 4u * (unsigned)(m * p.lda_m + (long)(k0 + e) * p.lda_k) : 0x80000000u;
+                        araw[SET][rb][e] = __builtin_amdgcn_raw_buffer_load_b32(ars, (int)off, 0, 0);
+                    }
+                }
+            }
+            const bool okb = live && col_ok;
+            if (B_KC) {
+                const unsigned off = (okb && k0 + 8 <= p.K) ? 4u * (unsigned)((long)(n0 + l32) * p.ldb_n + k0) : 0x80000000u;
+                const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(brs, (int)off, 0, 0);
+                const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(brs, (int)(off + 16u), 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { braw[SET][e] = lo[e]; braw[SET][4 + e] = hi[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned off = (okb && k0 + e < p.K) ? 4u * (unsigned)((long)(k0 + e) * p.ldb_k + (long)(n0 + l32) * p.ldb_n) : 0x80000000u;
+                    braw[SET][e] = __builtin_amdgcn_raw_buffer_load_b32(brs, (int)off, 0, 0);
+                }
+            }
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    auto step = [&](auto Uc) {
+        constexpr int U = decltype(Uc)::value, SET = U % PD;
+        if constexpr (U < NS) {
+            fetch(std::integral_constant<int, U + PD - 1>{});
+            if (wave + 4 * U < KT) {                               // (wave-uniform)
+                bf16x8 af[2][3], bf[3];
+                float v[8];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = __uint_as_float(araw[SET][rb][e]);
+                    cut8r(v, af[rb]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = __uint_as_float(braw[SET][e]);
+                cut8r(v, bf);
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][PA[pr]], bf[PB[pr]], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][PA[pr]], bf[PB[pr]], acc[1], 0, 0, 0);
+                }
+            }
+        }
+    };
+    if constexpr (PD > 1) fetch(std::integral_constant<int, 0>{});
+    if constexpr (PD > 2) fetch(std::integral_constant<int, 1>{});
+    if constexpr (PD > 3) fetch(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 9>{});
+    step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+    step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{});
+    step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][rb * 16 + r][lane] = acc[rb][r];
+    __syncthreads();
+    const float bv = (p.bias && col_ok) ? p.bias[n0 + l32] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = wave * 8 + j, rb = idx >> 4, r = idx & 15;
+        const float t = ((red[0][idx][lane] + red[1][idx][lane]) + red[2][idx][lane]) + red[3][idx][lane];
+        const int m = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < p.M && col_ok) p.c[(long)m * p.N + n0 + l32] = t + bv;
+    }
+}
+
 }  // namespace
 
 bool mi_cube2_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw,
@@ -199,6 +321,39 @@ int mi_cube2_launch(int dgrad, const float* a, const float* w, float* slabs, int
     else if (C == 512) { if (dgrad) CUBE2_LAUNCH(true, 16); else CUBE2_LAUNCH(false, 16); }
     else return MI_E_UNSUPPORTED;
 #undef CUBE2_LAUNCH
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+// C[M][N] = A . B (+ bias) with strided operand views (see small_gemm_kernel); K <= 1024, tensors < 2 GiB
+bool mi_small_gemm_usable(long M, long N, long K) {
+    const char* off = getenv("MI_CONV_NO_DIRECT");
+    if (off && atoi(off) != 0) return false;
+    return M >= 1 && M <= 1024 && N >= 1 && N <= 4096 && K >= 1 && K <= 1024;
+}
+int mi_small_gemm_launch(const float* a, long lda_m, long lda_k, long a_elems, const float* b, long ldb_k, long ldb_n,
+                         long b_elems, const float* bias, float* c, int M, int N, int K, hipStream_t s) {
+    if (4 * a_elems >= 0x7fff0000l || 4 * b_elems >= 0x7fff0000l) return MI_E_UNSUPPORTED;
+    SmallGemmParams p = {a, b, bias, c, M, N, K, lda_m, lda_k, ldb_k, ldb_n, (unsigned)(4 * a_elems), (unsigned)(4 * b_elems)};
+    const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 63) / 64));
+    const int kt = (K + 15) / 16, per = (kt + 3) / 4;
+    const int ns = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 16;
+    const bool akc = lda_k == 1 && (lda_m % 4) == 0 && (K % 8) == 0, bkc = ldb_k == 1 && (ldb_n % 4) == 0 && (K % 8) == 0;
+#define SG_LAUNCH(AK, BK, NSV) hipLaunchKernelGGL((small_gemm_kernel<AK, BK, NSV>), grid, dim3(256), 0, s, p)
+#define SG_NS(AK, BK)                                                                                   \
+    switch (ns) {                                                                                       \
+        case 1: SG_LAUNCH(AK, BK, 1); break;                                                            \
+        case 2: SG_LAUNCH(AK, BK, 2); break;                                                            \
+        case 4: SG_LAUNCH(AK, BK, 4); break;                                                            \
+        case 8: SG_LAUNCH(AK, BK, 8); break;                                                            \
+        default: SG_LAUNCH(AK, BK, 16); break;                                                          \
+    }
+    if (akc && bkc) { SG_NS(true, true) }
+    else if (akc) { SG_NS(true, false) }
+    else if (bkc) { SG_NS(false, true) }
+    else { SG_NS(false, false) }
+#undef SG_NS
+#undef SG_LAUNCH
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

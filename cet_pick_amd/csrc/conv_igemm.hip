@@ -66,6 +66,10 @@ bool mi_cube2_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int 
 size_t mi_cube2_slab_bytes(int N, int C);
 int mi_cube2_splits();
 int mi_cube2_launch(int dgrad, const float* a, const float* w, float* slabs, int N, int C, hipStream_t s);
+// ... and the small dense products of the Linear layers (register-staged, final in one launch)
+bool mi_small_gemm_usable(long M, long N, long K);
+int mi_small_gemm_launch(const float* a, long lda_m, long lda_k, long a_elems, const float* b, long ldb_k, long ldb_n,
+                         long b_elems, const float* bias, float* c, int M, int N, int K, hipStream_t s);
 
 namespace {
 
@@ -1178,6 +1182,17 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
     }
     // layer1-shaped convolutions (3^3, stride 1, 64 -> 64 channels, 8 x 8 planes): patch-resident direct kernel; the
     // weight image goes into `ws` (a short ws keeps the implicit GEMM)
+    // Linear layers (1x1x1 window on 1x1x1 "volumes", few rows): one register-staged launch, bias included
+    if (conv_arith_bf16x3() && g.Di == 1 && g.Hi == 1 && g.Wi == 1 && g.kd == 1 && g.kh == 1 && g.kw == 1 && g.stride == 1 &&
+        g.pd == 0 && g.ph == 0 && g.pw == 0 && !mask && !relu && (!res || res_bcast)) {
+        const long xe = (long)g.N * g.Ci, ye = (long)g.N * g.Co, we = (long)g.Ci * g.Co;
+        if (mode == MODE_FWD && mi_small_gemm_usable(g.N, g.Co, g.Ci))
+            return mi_small_gemm_launch(a_src, g.Ci, 1, xe, b_src, g.Co, 1, we, res, out, g.N, g.Co, g.Ci, s);
+        if (mode == MODE_DGRAD && !res && mi_small_gemm_usable(g.N, g.Ci, g.Co))
+            return mi_small_gemm_launch(a_src, g.Co, 1, ye, b_src, 1, g.Co, we, nullptr, out, g.N, g.Ci, g.Co, s);
+        if (mode == MODE_WGRAD && mi_small_gemm_usable(g.Ci, g.Co, g.N))
+            return mi_small_gemm_launch(a_src, 1, g.Ci, xe, b_src, g.Co, 1, ye, nullptr, out, g.Ci, g.Co, g.N, s);
+    }
     const int dkind = conv_arith_bf16x3() ? direct3_kind(g) : 0;
     const size_t dimg = mi_align_up(mi_direct3_wimg_bytes(g.Ci), 256);
     if (mode != MODE_WGRAD && dkind && ws && ws_bytes >= dimg + mi_direct3_slab_bytes(g.N, g.Ci)) {
