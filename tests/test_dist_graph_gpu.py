@@ -50,7 +50,16 @@ print("TEARDOWN ok", flush=True)
 '''
 
 
-def run(mode, port):
+def free_port():
+    """A port nobody listens on right now (a fixed number can still be in TIME_WAIT from an earlier run on the same box)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def run(mode, port=None):
+    port = port or free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if mode == "eager":
         env["CETPICK_DIST_GRAPH"] = "0"
@@ -64,9 +73,9 @@ def run(mode, port):
 
 
 def test_data_parallel_step_is_captured_with_its_collectives():
-    graph = run("graph", 29631)
-    eager = run("eager", 29632)
-    single = run("single", 29633)
+    graph = run("graph")
+    eager = run("eager")
+    single = run("single")
     assert graph["graph"], "the data-parallel step did not end up in a hipGraph"
     assert not eager["graph"] and single["graph"]
     assert graph["buckets"] == ["layer3", "layer2", "layer1", "stem"] == eager["buckets"]
@@ -84,7 +93,7 @@ def test_bench_n_gt_1_path_on_one_rank_rccl_group_tears_down():
     """bench.py's N>1 code path (captured collectives, rccl_ranks, ordered tear-down with destroy_process_group) on the
     one GPU of a test box: a 1-rank RCCL group with every collective forced on.  A failed tear-down is a non-zero exit."""
     import json
-    env = dict(os.environ, CETPICK_BENCH_REHEARSE_RCCL="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29634",
+    env = dict(os.environ, CETPICK_BENCH_REHEARSE_RCCL="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "10", "--warmup", "4", "--no-secondary",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
