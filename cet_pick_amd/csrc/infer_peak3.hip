@@ -21,7 +21,7 @@
 
 namespace {
 
-constexpr int RY = 4, WX = 256, WPB = 4, NT3 = 64 * WPB;
+constexpr int RY = 4, WX = 256, WPB = 8, NT3 = 64 * WPB;      // (8 waves per workgroup: half the histogram merges of 4; 16: 3x slower)
 constexpr int NROW = RY + 2;
 constexpr int RING = 512;          // candidate ring per wave: < 64 pending + one row of the strip (<= 256 new entries)
 
