@@ -401,9 +401,12 @@ def test_moco_three_steps_match_reference(golden):
     print("ReLU-edge steps (gradient comparison skipped):", edges)
 
 
-@pytest.mark.parametrize("m,ci,co,bias", [(64, 256, 128, True), (64, 128, 128, False), (5, 48, 32, True), (2048, 256, 128, True)])
+@pytest.mark.parametrize("m,ci,co,bias", [(64, 256, 128, True), (64, 128, 128, False), (5, 48, 32, True), (2048, 256, 128, True),
+                                          (3, 48, 16, False), (70, 16, 16, True), (1, 1008, 64, True)])
 def test_linear_fwd_bwd(m, ci, co, bias):
-    """nn.Linear (fc / projection head): the bias is added in the epilogue of the GEMM launch (or of its split-K reduce)."""
+    """nn.Linear (fc / projection head): one register-staged launch each for forward (bias in the epilogue), data gradient
+    and weight gradient (conv_cube2.hip small_gemm_kernel) - ragged sizes exercise its row / column / k masks; 2048 rows
+    take the implicit GEMM with the bias in its epilogue."""
     from cet_pick_amd import hipops as H
     g = torch.Generator().manual_seed(m + ci + co)
     lin = H.HipLinear(ci, co, bias=bias).cuda()
