@@ -117,3 +117,31 @@ def confident_pred(gt, seed=37):
     g = torch.Generator().manual_seed(seed)
     r = torch.rand(gt.shape, generator=g)
     return torch.where(gt == 1, 0.90 + 0.09 * r, 0.02 + 0.05 * r)
+
+
+def semi_loss_inputs(flip_prob, shape=(2, 1, 3, 12, 16), dim=32):
+    """Seeded inputs of the `TomoCRSemiLoss` fixture (tests/golden/semi_loss.npz): label volume with unlabeled (-1),
+    labelled-negative (0), soft (0.6) and positive (1) voxels, heat-map logits and L2-normalised projections of both
+    views.  Returns (gt, hm_logits, hm_logits_cr, proj, proj_cr)."""
+    import torch
+    g = torch.Generator().manual_seed(int(flip_prob * 10))
+    gt = torch.full(shape, -1.0)
+    r = torch.rand(shape, generator=g)
+    gt[r < 0.3] = 0.0
+    gt[(r >= 0.3) & (r < 0.4)] = 0.6
+    gt[r > 0.96] = 1.0
+    hm, hm_cr = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    pshape = (shape[0], dim) + tuple(shape[2:])
+    pj = torch.nn.functional.normalize(torch.randn(pshape, generator=g), dim=1)
+    pj_cr = torch.nn.functional.normalize(torch.randn(pshape, generator=g), dim=1)
+    return gt, hm, hm_cr, pj, pj_cr
+
+
+def moco_small_inputs(batch=8, dim=128, K=64):
+    """Seeded inputs of the symmetric-MoCo fixture (tests/golden/moco_small.npz): two views and the initial queue."""
+    import torch
+    g = torch.Generator().manual_seed(12)
+    im1 = torch.randn(batch, 1, 32, 32, 32, generator=g)
+    im2 = torch.randn(batch, 1, 32, 32, 32, generator=g)
+    queue0 = torch.nn.functional.normalize(torch.randn(dim, K, generator=g), dim=0)
+    return im1, im2, queue0

@@ -87,8 +87,9 @@ def unbiased_con_loss(labels, out_labels, out_labels_cr, f, f_cr, T, tau_plus, t
 
 
 def tomo_cr_semi_loss(hm_logits, hm_logits_cr, proj, proj_cr, gt, flip_prob, tau, temp, thresh, cr_weight):
-    """trains/tomo_cr_semi_trainer.py:43-112, train phase with --contrastive (restated: that module does not import
-    here - `progress`, `cv2`, `sknetwork` are absent)."""
+    """trains/tomo_cr_semi_trainer.py:43-112, train phase with --contrastive.  Pinned since round 3 by
+    tests/golden/semi_loss.npz (the reference's own TomoCRSemiLoss.forward, both flip branches, values and gradients;
+    gen_golden.py::gen_semi_loss stubs the module's unused load-time imports)."""
     sig = lambda x: torch.clamp(torch.sigmoid(x), min=1e-4, max=1 - 1e-4)
     hm, hm_cr = sig(hm_logits), sig(hm_logits_cr)
     hm_loss = pu_neg_loss(hm, gt, tau)

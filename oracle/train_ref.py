@@ -249,11 +249,13 @@ def simsiam2d3d_forward(sd, x1_2d, x1_3d, x2_2d, x2_3d, train=True):
 
 
 # ------------------------------------------------------------------------------------------------
-# symmetric MoCo (trains/tomo_moco_small_trainer.py:24-161).  That module needs `progress`, `cv2` and
-# `pytorch_metric_learning` (absent): restated from source, PARITY UNPINNED.
+# symmetric MoCo (trains/tomo_moco_small_trainer.py:24-161).  Pinned since round 3 by
+# tests/golden/moco_small.npz: the reference's own MoCoModel.forward run on the CPU (its load-time imports of `progress`,
+# `cv2`, `sknetwork`, `pytorch_metric_learning` are inert stubs in tests/golden/gen_golden.py::gen_moco_small).
 # ------------------------------------------------------------------------------------------------
-def symmetric_moco_step(sd_q, sd_k, queue, ptr, im1, im2, m, T):
-    """One forward of MoCoModel(symmetric=True) with moco3d encoders: returns loss, new key state dict, queue, ptr."""
+def symmetric_moco_step(sd_q, sd_k, queue, ptr, im1, im2, m, T, symmetric=True):
+    """One forward of MoCoModel (tomo_moco_small_trainer.py:136-161) with moco3d encoders: returns loss, new key state
+    dict, queue, ptr.  symmetric=False: the one-directional loss of :153-154 (only k(im2) is enqueued)."""
     names = param_names(sd_q)
     sd_k = dict(sd_k)
     for n in names:
@@ -266,8 +268,11 @@ def symmetric_moco_step(sd_q, sd_k, queue, ptr, im1, im2, m, T):
         logits = moco_logits(q, k, queue, T)
         return F.cross_entropy(logits, torch.zeros(logits.shape[0], dtype=torch.long)), k
     l12, k2 = side(im1, im2)
-    l21, k1 = side(im2, im1)
-    keys = torch.cat([k1, k2], 0)
+    if symmetric:
+        l21, k1 = side(im2, im1)
+        keys = torch.cat([k1, k2], 0)
+    else:
+        l21, keys = 0.0, k2
     queue = queue.clone()
     n = keys.shape[0]
     queue[:, ptr:ptr + n] = keys.t()

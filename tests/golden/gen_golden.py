@@ -468,6 +468,119 @@ def gen_crops():
     save("crops.npz", **out)
 
 
+def _stub_tree(*names):
+    """inert, attribute-permissive stand-ins for absent packages whose names a reference module imports at load time
+    but whose code the arithmetic under test never reaches (progress.bar, sknetwork.topology, pytorch_metric_learning)"""
+    class _Any(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return None
+    for name in names:
+        parts = name.split(".")
+        for i in range(1, len(parts) + 1):
+            n = ".".join(parts[:i])
+            if n not in sys.modules:
+                m = _Any(n)
+                m.__path__ = []
+                sys.modules[n] = m
+
+
+def gen_semi_loss():
+    """a23 glue: the reference's own `TomoCRSemiLoss.forward` (trains/tomo_cr_semi_trainer.py:43-112), train phase with
+    --contrastive, both `flip_prob` branches, values and gradients w.r.t. both views' heat-map logits and projections;
+    plus the 'val' phase.  The module's load-time imports of progress / sknetwork / cv2 / utils.debugger are inert
+    stubs: the loss arithmetic never touches them.  -> semi_loss.npz"""
+    from types import SimpleNamespace
+    _stub_tree("progress.bar", "sknetwork.topology", "pytorch_metric_learning")
+    sys.modules["progress.bar"].Bar = object
+    from cet_pick.trains import tomo_cr_semi_trainer as RT
+    from cet_pick_amd.synthetic import semi_loss_inputs
+    opt = SimpleNamespace(pn=False, ge=False, tau=0.1, temp=0.07, thresh=0.5, cr_weight=0.1, num_stacks=1,
+                          contrastive=True, device=torch.device("cpu"))
+    out = {}
+    for fp in (0.2, 0.8):
+        gt, hm, hm_cr, pj, pj_cr = semi_loss_inputs(fp)
+        leaves = [t.clone().requires_grad_() for t in (hm, hm_cr, pj, pj_cr)]
+        # `_sigmoid` works in place: hand it non-leaf tensors, as the network's outputs are
+        o = [{"hm": leaves[0] * 1.0, "proj": leaves[2]}]
+        o_cr = [{"hm": leaves[1] * 1.0, "proj": leaves[3]}]
+        loss, stats = RT.TomoCRSemiLoss(opt)(o, {"hm": gt, "flip_prob": fp}, 1, "train", o_cr)
+        loss.backward()
+        tag = "%.1f" % fp
+        for k in ("loss", "hm_loss", "cr_loss", "consis_loss"):
+            out[f"{k}_{tag}"] = np.asarray(float(stats[k].detach()))
+        for name, t in zip(("g_hm", "g_hm_cr", "g_proj", "g_proj_cr"), leaves):
+            g = t.grad.numpy()
+            out[f"{name}_{tag}"] = g.copy() if g.size < 4096 else g.reshape(-1)[::5].copy()     # projections: every 5th element
+    gt, hm, _, _, _ = semi_loss_inputs(0.2)
+    vloss, vstats = RT.TomoCRSemiLoss(opt)([{"hm": hm.clone(), "proj": None}], {"hm": gt}, 1, "val")
+    out["val_loss"] = np.asarray(float(vloss))
+    out["val_cr_loss"] = np.asarray(float(vstats["cr_loss"]))
+    save("semi_loss.npz", **out)
+
+
+def gen_moco_small():
+    """f4: the reference's own `MoCoModel.forward` (trains/tomo_moco_small_trainer.py:24-161), symmetric and asymmetric,
+    on the CPU.  The class hard-codes `.cuda()` on the shuffle index and the labels (:82,128): `torch.Tensor.cuda` is
+    an identity for the duration of the call, nothing else is touched.  The encoders are the reference's
+    TomoResClassifier3D behind a two-line adapter that returns the 'proj' tensor (MoCoModel expects an encoder that
+    returns the embedding itself).  -> moco_small.npz"""
+    import contextlib
+    import io
+    _stub_tree("progress.bar", "sknetwork.topology", "pytorch_metric_learning")
+    sys.modules["progress.bar"].Bar = object
+    from cet_pick.trains import tomo_moco_small_trainer as RM
+    from cet_pick_amd.synthetic import moco_small_inputs
+
+    class Proj(torch.nn.Module):
+        def __init__(self, enc):
+            super().__init__()
+            self.enc = enc
+
+        def forward(self, x):
+            return self.enc(x)[0]["proj"]
+
+    def enc330():
+        enc = R_enc3d.TomoResClassifier3D(R_enc3d.BasicBlock, [2, 2, 2, 2], HEADS, 0)
+        sd0 = seeded_state_dict(enc, seed=330)
+        for kk in [k for k in sd0 if k.startswith("pred.")]:    # 'pred' re-registers the 'proj' module: one set of weights
+            sd0["proj." + kk[5:]] = sd0[kk]
+        enc.load_state_dict(sd0)
+        return enc
+
+    im1, im2, queue0 = moco_small_inputs()
+    res = {}
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for tag, symmetric in (("sym", True), ("asym", False)):
+            torch.manual_seed(5)                                  # the shuffle permutation
+            model = RM.MoCoModel(Proj(enc330()), Proj(enc330()), None, dim=128, K=64, m=0.99, T=0.1, symmetric=symmetric)
+            model.queue.copy_(queue0)
+            model.train()
+            with contextlib.redirect_stdout(io.StringIO()):
+                loss, stats = model(im1, im2)
+            loss.backward()
+            res[f"loss_{tag}"] = np.asarray(float(loss))
+            res[f"ptr_{tag}"] = np.asarray(int(model.queue_ptr))
+            res[f"queue_{tag}"] = model.queue.numpy().copy()
+            idx = np.random.default_rng(8).integers(0, 2 ** 31, size=64)
+            for k, prm in model.encoder_q.enc.named_parameters():
+                if prm.grad is None or k.startswith("pred."):
+                    continue
+                gf = prm.grad.reshape(-1).numpy()
+                res[f"grad_{tag}_{k}_norm"] = np.asarray(np.linalg.norm(gf.astype(np.float64)))
+                res[f"grad_{tag}_{k}_sample"] = gf[idx % gf.size]
+            res["sample_idx"] = idx
+            res[f"k_fc_weight_{tag}"] = model.encoder_k.enc.fc.weight.detach().reshape(-1)[::7].numpy().copy()
+            res[f"k_l1c1_sample_{tag}"] = model.encoder_k.enc.layer1[0].conv1.weight.detach().reshape(-1)[::997].numpy().copy()
+            res[f"k_bn1_running_mean_{tag}"] = model.encoder_k.enc.bn1.running_mean.numpy().copy()
+    finally:
+        torch.Tensor.cuda = real_cuda
+    save("moco_small.npz", **res)
+
+
 def gen_lr():
     class A:
         pass
@@ -483,6 +596,6 @@ def gen_lr():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader", "unet", "losses", "simsiam", "simsiam2d3d", "crops"]
+    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader", "unet", "losses", "simsiam", "simsiam2d3d", "crops", "semi_loss", "moco_small"]
     for w in which:
         globals()["gen_" + w]()

@@ -103,16 +103,8 @@ def test_ucl_full_size_rowsums_properties():
 def test_tomo_cr_semi_loss_vs_oracle(flip_prob):
     from oracle import loss_ref as O
     from cet_pick_amd.trains.tomo_cr_semi_trainer import TomoCRSemiLoss
-    g = torch.Generator().manual_seed(int(flip_prob * 10))
-    shape = (2, 1, 3, 12, 16)
-    gt = torch.full(shape, -1.0)
-    r = torch.rand(shape, generator=g)
-    gt[r < 0.3] = 0.0
-    gt[(r >= 0.3) & (r < 0.4)] = 0.6
-    gt[r > 0.96] = 1.0
-    hm, hm_cr = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
-    pj = torch.nn.functional.normalize(torch.randn(2, 32, 3, 12, 16, generator=g), dim=1)
-    pj_cr = torch.nn.functional.normalize(torch.randn(2, 32, 3, 12, 16, generator=g), dim=1)
+    from cet_pick_amd.synthetic import semi_loss_inputs
+    gt, hm, hm_cr, pj, pj_cr = semi_loss_inputs(flip_prob)
     ref_in = [t.clone().requires_grad_() for t in (hm, hm_cr, pj, pj_cr)]
     ref = O.tomo_cr_semi_loss(*ref_in, gt, flip_prob, 0.1, 0.07, 0.5, 0.1)
     ref[0].backward()
@@ -129,5 +121,15 @@ def test_tomo_cr_semi_loss_vs_oracle(flip_prob):
     for a, b in zip(dev_in, ref_in):
         rr = b.grad.numpy()
         np.testing.assert_allclose(a.grad.cpu().numpy(), rr, rtol=0, atol=5e-4 * np.abs(rr).max() + 1e-9)
+    # ... and against the reference's own TomoCRSemiLoss.forward (tests/golden/semi_loss.npz, gen_golden.py::gen_semi_loss)
+    S = np.load(os.path.join(os.path.dirname(__file__), "golden", "semi_loss.npz"))
+    tag = "%.1f" % flip_prob
+    for k in ("loss", "hm_loss", "cr_loss", "consis_loss"):
+        np.testing.assert_allclose(float(stats[k]), S[f"{k}_{tag}"], rtol=2e-4, err_msg=k)
+    for name, a in zip(("g_hm", "g_hm_cr", "g_proj", "g_proj_cr"), dev_in):
+        got = a.grad.cpu().numpy()
+        got = got if got.size < 4096 else got.reshape(-1)[::5]
+        want = S[f"{name}_{tag}"]
+        np.testing.assert_allclose(got, want, rtol=0, atol=5e-4 * np.abs(want).max() + 1e-9, err_msg=name)
     val_loss, _ = TomoCRSemiLoss(opt)([{"hm": hm.cuda().clone(), "proj": None}], {"hm": gt.cuda()}, 1, "val")
     np.testing.assert_allclose(val_loss.item(), O.neg_loss(torch.clamp(torch.sigmoid(hm), 1e-4, 1 - 1e-4).squeeze(), gt.squeeze()).item(), rtol=1e-4)

@@ -47,3 +47,26 @@ def test_unbiased_con_loss(thresh):
     np.testing.assert_allclose(fa.grad.numpy(), G[f"ucl_gf_{thresh}"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(fb.grad.numpy(), G[f"ucl_gfcr_{thresh}"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(pa.grad.numpy(), G[f"ucl_gp_{thresh}"], rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("flip_prob", [0.2, 0.8])
+def test_tomo_cr_semi_loss_matches_reference(flip_prob):
+    """oracle == the reference's own TomoCRSemiLoss.forward (trains/tomo_cr_semi_trainer.py:43-112; semi_loss.npz)."""
+    from cet_pick_amd.synthetic import semi_loss_inputs
+    S = np.load(os.path.join(os.path.dirname(__file__), "golden", "semi_loss.npz"))
+    gt, hm, hm_cr, pj, pj_cr = semi_loss_inputs(flip_prob)
+    leaves = [t.clone().requires_grad_() for t in (hm, hm_cr, pj, pj_cr)]
+    ref = O.tomo_cr_semi_loss(*leaves, gt, flip_prob, 0.1, 0.07, 0.5, 0.1)
+    ref[0].backward()
+    tag = "%.1f" % flip_prob
+    for k, v in zip(("loss", "hm_loss", "cr_loss", "consis_loss"), ref):
+        np.testing.assert_allclose(v.item(), S[f"{k}_{tag}"], rtol=2e-6)
+    for name, t in zip(("g_hm", "g_hm_cr", "g_proj", "g_proj_cr"), leaves):
+        g = t.grad.numpy()
+        want = S[f"{name}_{tag}"]
+        got = g if g.size < 4096 else g.reshape(-1)[::5]
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6 * np.abs(want).max())
+    # validation phase: the plain focal loss, no contrastive term
+    sig = torch.clamp(torch.sigmoid(semi_loss_inputs(0.2)[1]), 1e-4, 1 - 1e-4)
+    np.testing.assert_allclose(O.neg_loss(sig, semi_loss_inputs(0.2)[0]).item(), S["val_loss"], rtol=2e-6)
+    assert S["val_cr_loss"] == 0

@@ -1,6 +1,7 @@
 """The training oracle (plain torch CPU) pinned against vectors produced by the reference's own
 modules (tests/golden/gen_golden.py).  CPU only."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import train_ref as T
@@ -168,3 +169,38 @@ def test_simsiam2d3d_oracle_and_keys_match_reference():
     p1, z1, p2, z2 = O.simsiam2d3d_forward({k: v.clone() for k, v in sd.items()}, *xs, True)
     for got, key in ((p1, "p1"), (z1, "z1"), (p2, "p2"), (z2, "z2")):
         np.testing.assert_allclose(got.numpy(), g[key], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,symmetric", [("sym", True), ("asym", False)])
+def test_symmetric_moco_matches_reference(golden, tag, symmetric):
+    """oracle.symmetric_moco_step == the reference's own MoCoModel.forward (trains/tomo_moco_small_trainer.py:24-161;
+    moco_small.npz): loss, queue, pointer, EMA'd key weights, BatchNorm running statistics of the key encoder and the
+    query-encoder gradients."""
+    from cet_pick_amd.synthetic import moco_small_inputs
+    g = golden("moco_small.npz")
+    sd0 = seeded_sd(330)
+    for kk in [k for k in sd0 if k.startswith("pred.")]:
+        sd0["proj." + kk[5:]] = sd0[kk]
+    im1, im2, queue0 = moco_small_inputs()
+    sd_q = {k: v.clone().requires_grad_(k.endswith(T.PARAM_SUFFIX)) for k, v in sd0.items()}
+    sd_k = {k: v.clone() for k, v in sd0.items()}
+    loss, new_k, queue, ptr = T.symmetric_moco_step(sd_q, sd_k, queue0, 0, im1, im2, 0.99, 0.1, symmetric=symmetric)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[f"loss_{tag}"], rtol=2e-5)
+    assert ptr == int(g[f"ptr_{tag}"]) == (16 if symmetric else 8)
+    np.testing.assert_allclose(queue.numpy(), g[f"queue_{tag}"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(new_k["fc.weight"].detach().reshape(-1)[::7].numpy(), g[f"k_fc_weight_{tag}"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(new_k["layer1.0.conv1.weight"].detach().reshape(-1)[::997].numpy(), g[f"k_l1c1_sample_{tag}"],
+                               rtol=0, atol=1e-7)
+    idx = g["sample_idx"]
+    for name in T.param_names(sd_q):
+        if name.startswith("pred.") or f"grad_{tag}_{name}_norm" not in g.files:
+            continue
+        gf = sd_q[name].grad.reshape(-1).numpy()
+        want = float(g[f"grad_{tag}_{name}_norm"])
+        if want < 1e-5:
+            assert np.linalg.norm(gf) < 1e-4, name
+            continue
+        np.testing.assert_allclose(np.linalg.norm(gf.astype(np.float64)), want, rtol=2e-3, err_msg=name)
+        np.testing.assert_allclose(gf[idx % gf.size], g[f"grad_{tag}_{name}_sample"], rtol=0,
+                                   atol=2e-3 * np.abs(g[f"grad_{tag}_{name}_sample"]).max() + 1e-7, err_msg=name)

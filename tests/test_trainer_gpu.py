@@ -174,10 +174,11 @@ def test_symmetric_moco_variant_vs_oracle():
     for kk in [k for k in sd0 if k.startswith("pred.")]:      # 'pred' re-registers the 'proj' module: one set of weights
         sd0["proj." + kk[5:]] = sd0[kk]
     eq.load_state_dict(sd0)
-    model = MoCoModel(eq, ek, dim=128, K=64, m=0.99, T=0.1, symmetric=True, shuffle=False).cuda().train()
-    g = torch.Generator().manual_seed(12)
-    im1, im2 = torch.randn(8, 1, 32, 32, 32, generator=g), torch.randn(8, 1, 32, 32, 32, generator=g)
-    queue0 = model.queue.cpu().clone()
+    from cet_pick_amd.synthetic import moco_small_inputs
+    im1, im2, queue0 = moco_small_inputs()
+    model = MoCoModel(eq, ek, dim=128, K=64, m=0.99, T=0.1, symmetric=True, shuffle=False)
+    model.queue.copy_(queue0)
+    model = model.cuda().train()
     sd_q = {k: v.clone().requires_grad_(k.endswith(O.PARAM_SUFFIX)) for k, v in sd0.items()}
     sd_k = {k: v.clone() for k, v in sd0.items()}
     ref_loss, ref_k, ref_queue, ref_ptr = O.symmetric_moco_step(sd_q, sd_k, queue0, 0, im1, im2, 0.99, 0.1)
@@ -205,6 +206,38 @@ def test_symmetric_moco_variant_vs_oracle():
         f32_equivalent(prm.grad.cpu().numpy(), rg.numpy(), sd_q64[name].grad.numpy(), floor=2e-5, what=name)
     for name, prm in model.encoder_k.named_parameters():
         np.testing.assert_allclose(prm.detach().cpu().numpy(), ref_k[name].numpy(), rtol=0, atol=1e-6)
+    # ... and against the reference's own MoCoModel.forward (tests/golden/moco_small.npz, gen_golden.py::gen_moco_small)
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "moco_small.npz"))
+    assert abs(float(loss) - float(G["loss_sym"])) < 2e-4 * float(G["loss_sym"])
+    assert int(model.queue_ptr) == int(G["ptr_sym"])
+    np.testing.assert_allclose(model.queue.cpu().numpy(), G["queue_sym"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(model.encoder_k.fc.weight.detach().cpu().reshape(-1)[::7].numpy(), G["k_fc_weight_sym"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(model.encoder_k.bn1.running_mean.cpu().numpy(), G["k_bn1_running_mean_sym"], rtol=0, atol=1e-5)
+    idx = G["sample_idx"]
+    for name, prm in model.encoder_q.named_parameters():
+        if name.startswith("pred.") or f"grad_sym_{name}_norm" not in G.files:
+            continue
+        want = float(G[f"grad_sym_{name}_norm"])
+        gf = prm.grad.detach().cpu().reshape(-1).numpy()            # logical (co, ci, kd, kh, kw) order, as the reference
+        if want < 1e-5:
+            continue
+        # the reference ran in fp32 on the CPU: its own distance from float64 bounds what "equal" can mean (the stem-level
+        # gradients pass through two forward passes); 1e-3 (north_star) + that distance
+        r64 = np.linalg.norm(sd_q64[name].grad.reshape(-1).numpy())
+        slack = abs(want - r64) / r64
+        assert abs(np.linalg.norm(gf.astype(np.float64)) - want) <= (1e-3 + 2 * slack) * want, name
+        ws = G[f"grad_sym_{name}_sample"]
+        np.testing.assert_allclose(gf[idx % gf.size], ws, rtol=0, atol=(1e-3 + 2 * slack) * np.abs(ws).max() * 3 + 1e-7, err_msg=name)
+    # the one-directional variant (symmetric=False, :153-154): loss and the 8 enqueued keys
+    ma = MoCoModel(get_moco_net_small_3d(18, heads, 0), get_moco_net_small_3d(18, heads, 0), dim=128, K=64, m=0.99, T=0.1,
+                   symmetric=False, shuffle=False)
+    ma.encoder_q.load_state_dict(sd0); ma.encoder_k.load_state_dict(sd0)
+    ma.queue.copy_(queue0)
+    ma = ma.cuda().train()
+    la, _ = ma(im1.cuda(), im2.cuda())
+    assert abs(float(la) - float(G["loss_asym"])) < 2e-4 * float(G["loss_asym"]) and int(ma.queue_ptr) == int(G["ptr_asym"]) == 8
+    np.testing.assert_allclose(ma.queue.cpu().numpy(), G["queue_asym"], rtol=0, atol=3e-5)
     # shuffle on: same loss up to summation order (BatchNorm statistics do not depend on the row order)
     model2 = MoCoModel(get_moco_net_small_3d(18, heads, 0), get_moco_net_small_3d(18, heads, 0), dim=128, K=64, m=0.99,
                        T=0.1, symmetric=True, shuffle=True)
