@@ -121,12 +121,22 @@ def _traffic(fname, kernels):
     return tot, "PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch, profiles/%s" % fname
 
 
-def inference_secondary(dev, with_cpu=True):
-    """voxels/s of the inference half on BASELINE configs[2] sizes (one rank, after the timed region).
-    Each entry carries its own HBM roofline (8 B per voxel algorithmic) and CPU baseline(s)."""
+def inference_secondary(dev, with_cpu=True, rank=0, world=1):
+    """voxels/s of the inference half on BASELINE configs[2] sizes, after the timed region.
+    Each entry carries its own HBM roofline (8 B per voxel algorithmic) and CPU baseline(s).
+    world > 1 (inference does not exchange - one tomogram per GPU): EVERY rank runs the chains on a
+    tomogram of its own (seed 317 + rank) at the same time - the timed replays sit between two barriers - and the entry
+    holds the SUM of the ranks' voxels/s, the slowest rank's ms and the aggregate rate over the wall clock of the
+    concurrent region (which would show host-side launch or PCIe serialisation between the ranks)."""
     from cet_pick_amd.synthetic import make_tomo, make_logits
     from cet_pick_amd.models import decode as Dm
     from cet_pick_amd.utils import image as Im
+    import torch.distributed as dist
+
+    def barrier():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
 
     def timeit(fn, n, warm=3):
         """(eager ms, hipGraph-replay ms): the chain is a handful of short launches, so the product call is also timed
@@ -145,40 +155,57 @@ def inference_secondary(dev, with_cpu=True):
         with torch.cuda.graph(g):
             fn()
         g.replay()
+        barrier()                              # N > 1: every rank replays its chain in the same window
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
         e0.record()
         for _ in range(n):
             g.replay()
         e1.record()
         torch.cuda.synchronize()
-        return eager, e0.elapsed_time(e1) / n
+        barrier()
+        wall = (time.perf_counter() - t0) * 1e3 / n
+        return eager, e0.elapsed_time(e1) / n, wall
 
-    def entry(workload, n_vox, eager, graph, kernels, traffic_file):
+    def entry(workload, n_vox, timing, kernels, traffic_file):
+        eager, graph, wall = timing
         ms = min(eager, graph)
-        achieved = n_vox * 8 / (ms * 1e-3) / 1e9
+        rate, slow_ms, wall_ms = n_vox / ms * 1e3, ms, wall
+        if world > 1:
+            t = torch.tensor([rate, 0.0, 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t)                                   # sum of the ranks' voxels/s
+            m = torch.tensor([ms, wall], dtype=torch.float64, device=dev)
+            dist.all_reduce(m, op=dist.ReduceOp.MAX)             # slowest rank; longest concurrent window
+            rate, slow_ms, wall_ms = float(t[0]), float(m[0]), float(m[1])
+        achieved = rate / world * 8 / 1e9                        # per GPU, against one GPU's HBM peak
         traffic, tnote = _traffic(traffic_file, kernels)
-        return {"workload": workload, "ms": round(ms, 4), "ms_eager": round(eager, 4), "ms_hipgraph": round(graph, 4),
-                "voxels_per_sec": n_vox / ms * 1e3,
-                "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_note": tnote,
-                             "algorithmic_bytes": n_vox * 8,
-                             "measured": "whole chain (every launch of the call) between two HIP events on the launch "
-                                         "stream, per call; algorithmic 8 B per voxel (SURVEY.md 8d)"}}
+        e = {"workload": workload, "ms": round(slow_ms, 4), "ms_eager": round(eager, 4), "ms_hipgraph": round(graph, 4),
+             "voxels_per_sec": rate, "ranks": world,
+             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_note": tnote,
+                          "algorithmic_bytes": n_vox * 8,
+                          "measured": "whole chain (every launch of the call) between two HIP events on the launch "
+                                      "stream, per call; algorithmic 8 B per voxel (SURVEY.md 8d)"}}
+        if world > 1:
+            e["voxels_per_sec_wall"] = world * n_vox / wall_ms * 1e3
+            e["note"] = ("one tomogram per rank (seed 317 + rank), the ranks' replays between two barriers: voxels_per_sec = sum "
+                         "of the ranks' rates, ms = slowest rank, voxels_per_sec_wall = all ranks' voxels over the wall clock of "
+                         "the concurrent window (barrier skew included); roofline per GPU")
+        return e
 
-    logits_np = make_logits((128, 256, 256), seed=317)
+    logits_np = make_logits((128, 256, 256), seed=317 + rank)
     logits = torch.as_tensor(logits_np).to(dev)[None, None]
-    e_dec, g_dec = timeit(lambda: Dm.sigmoid_tomo_decode(logits, kernel=3, K=900), 30)
-    vol, _ = make_tomo((256, 512, 512), seed=317)
+    t_dec = timeit(lambda: Dm.sigmoid_tomo_decode(logits, kernel=3, K=900), 30)
+    vol, _ = make_tomo((256, 512, 512), seed=317 + rank)
     v = torch.as_tensor(vol).to(dev)
-    e_dog, g_dog = timeit(lambda: Im.dog_pick(v, [3, 5]), 8)
+    t_dog = timeit(lambda: Im.dog_pick(v, [3, 5]), 8)
     out = {
         "metric": "voxels/sec (heatmap+NMS)",
         "decode_sigmoid_nms_topk": entry("logits 1x1x128x256x256, k=3, K=900: sigmoid+clamp -> (3,3,3) NMS -> top-K", logits.numel(),
-                                         e_dec, g_dec, {"peak3_march_kernel": 1, "topk_filter_seg_kernel": 1, "topk_final_kernel": 1},
-                                         "r02_infer_traffic.json"),
-        "dog_pick": entry("tomogram 256x512x512, sigma=(3,5), nms_xy k=3, greedy d=14", v.numel(), e_dog, g_dog,
-                          {"gauss_march_dual_kernel": 1, "gauss_march_two_kernel": 1, "dogx_nms_kernel": 1},
-                          "r02_infer_traffic.json"),
+                                         t_dec, {"peak3_march_kernel": 1, "topk_filter_seg_kernel": 1, "topk_final_kernel": 1},
+                                         INFER_TRAFFIC),
+        "dog_pick": entry("tomogram 256x512x512, sigma=(3,5), nms_xy k=3, greedy d=14", v.numel(), t_dog,
+                          DOG_KERNELS, INFER_TRAFFIC),
     }
     if with_cpu:
         # CPU baselines on a bounded sample: the oracle (numpy / C port), and for the picker also the reference's own
@@ -215,6 +242,11 @@ def inference_secondary(dev, with_cpu=True):
             pass
     return out
 
+
+# PMC traffic summary of the inference chains (tools/pmc_run.sh + tools/pmc_summary.py) and the kernels of the picker's
+# chain that it is summed over - EVERY launch of the call, not only the Gaussians
+INFER_TRAFFIC = "r02_infer_traffic.json"
+DOG_KERNELS = {"gauss_march_dual_kernel": 1, "gauss_march_two_kernel": 1, "dogx_nms_kernel": 1}
 
 T_START = time.perf_counter()
 
@@ -454,9 +486,14 @@ def main():
             out["f32_mfma_step"] = {"ms_per_step": f32_ms, "value": B / (f32_ms * 1e-3),
                                     "note": "the same step with MI_CONV_ARITH=f32 (v_mfma_f32_32x32x2_f32 in the generic kernel)"}
         log("conv roofline pass done")
-        if not args.no_secondary:
-            out["secondary"] = inference_secondary(dev, with_cpu=not args.no_cpu_baseline)
+    # the voxels/s half of the metric: N = 1 on the one rank; N > 1 on EVERY rank at once (one tomogram per GPU, no exchange)
+    if not args.no_secondary and (world > 1 or rank == 0):
+        sec = inference_secondary(dev, with_cpu=(not args.no_cpu_baseline) and world == 1, rank=rank, world=world)
+        if rank == 0:
+            out["secondary"] = sec
             log("inference secondary done")
+    if rank == 0:
+        if not args.no_secondary and world == 1:
             # detector-side rows (loader a12, unet_4 forward a22, debiased contrastive loss a23, C5 train step)
             from tools.bench_detector import run as detector_secondary
             out["secondary"]["detector"] = detector_secondary()

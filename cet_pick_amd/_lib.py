@@ -106,10 +106,10 @@ SIGNATURES = {
     "mi_rowdot_mean_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "mi_column_std_mean": (_I, [_P, _P, _I, _I, _P]),
     "mi_ce_label0": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
-    "mi_ce_label0_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "mi_ce_label0_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "mi_ce_label0_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "mi_ema_update": (_I, [_P, _P, _F, _L, _P]),
-    "mi_sgd_step": (_I, [_P, _P, _P, _F, _F, _L, _P]),
+    "mi_sgd_step": (_I, [_P, _P, _P, _F, _F, _F, _L, _P]),
     "mi_queue_enqueue": (_I, [_P, _P, _P, _I, _I, _I, _P]),
 }
 

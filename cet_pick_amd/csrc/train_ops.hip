@@ -905,10 +905,12 @@ __global__ __launch_bounds__(256) void ce0_kernel(const float* logits, float* ro
 }
 // One workgroup per row (as ce0_kernel); the workgroup that finishes LAST sums the row losses in row order and writes the
 // mean - one launch, deterministic.  (A single 16-wave workgroup for all rows was measured at 29 us on the step's critical
-// path against 5 us here.)  The arrival counter resets itself; one cross-entropy runs at a time per device.
+// path against 5 us here.)  The arrival counter is the caller's (one word per stream, zero before the first call): it resets
+// itself, so launches on different streams - the key branch's side stream, a second model, an eager step beside a graph
+// replay - never share tickets.  A null counter falls back to one process-wide word (one call at a time per device).
 __device__ unsigned g_ce0_arrivals = 0;
 __global__ __launch_bounds__(256) void ce0_rows_kernel(const float* logits, float* loss, float* loss_copy, float* row_loss,
-                                                      float* row_lse, int B, int n) {
+                                                      float* row_lse, int B, int n, unsigned* counter) {
     __shared__ float red[4];
     __shared__ unsigned s_ticket;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -931,7 +933,7 @@ __global__ __launch_bounds__(256) void ce0_rows_kernel(const float* logits, floa
         __hip_atomic_store(&row_loss[b], lse - l[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_ticket = atomicAdd(&g_ce0_arrivals, 1u);
+        s_ticket = atomicAdd(counter ? counter : &g_ce0_arrivals, 1u);
     }
     __syncthreads();
     if (s_ticket == (unsigned)B - 1 && tid == 0) {
@@ -940,7 +942,7 @@ __global__ __launch_bounds__(256) void ce0_rows_kernel(const float* logits, floa
         for (int r = 0; r < B; ++r) t += __hip_atomic_load(&row_loss[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *loss = t / (float)B;
         if (loss_copy) *loss_copy = t / (float)B;
-        g_ce0_arrivals = 0;
+        __hip_atomic_store(counter ? counter : &g_ce0_arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // dlogits = g * (softmax - onehot0) / B with the upstream gradient g read on the device
@@ -975,18 +977,20 @@ __global__ __launch_bounds__(256) void ema_kernel(float* k, const float* q, floa
         for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) k[i] = k[i] * m + q[i] * om;
 }
 // p <- p - lr * (g + wd * p)   (torch.optim.SGD without momentum)
+// gs: scale of the gradient (1 / world size when g holds the SUM over the data-parallel ranks: the averaging rides here
+// instead of in a pass of its own over the 40 MB arena)
 __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, const float* lr_dev,
-                                                 float lr_host, float wd, long n) {
+                                                 float lr_host, float wd, float gs, long n) {
     const float lr = lr_dev ? *lr_dev : lr_host;
     long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 a = ld4(p + 4 * i), b = ld4(g + 4 * i);
-        a.x -= lr * (b.x + wd * a.x); a.y -= lr * (b.y + wd * a.y);
-        a.z -= lr * (b.z + wd * a.z); a.w -= lr * (b.w + wd * a.w);
+        a.x -= lr * (gs * b.x + wd * a.x); a.y -= lr * (gs * b.y + wd * a.y);
+        a.z -= lr * (gs * b.z + wd * a.z); a.w -= lr * (gs * b.w + wd * a.w);
         st4(p + 4 * i, a);
     }
     if (blockIdx.x == 0)
-        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) p[i] -= lr * (g[i] + wd * p[i]);
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) p[i] -= lr * (gs * g[i] + wd * p[i]);
 }
 
 // queue[:, ptr:ptr+B] = keys.T ; ptr = (ptr + B) % R      (queue is [C][R], ptr is int64 on device)
@@ -1337,10 +1341,10 @@ extern "C" int mi_ce_label0(const float* logits, float* loss, float* row_loss, f
 }
 
 extern "C" int mi_ce_label0_fwd(const float* logits, float* loss, float* loss_copy, float* row_loss, float* row_lse, int B,
-                                int n, mi_stream_t stream) {
+                                int n, unsigned* counter, mi_stream_t stream) {
     if (!logits || !loss || !row_loss || !row_lse || B <= 0 || n <= 0) return MI_E_ARG;
     hipLaunchKernelGGL(ce0_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, loss, loss_copy, row_loss, row_lse,
-                       B, n);
+                       B, n, counter);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -1360,9 +1364,10 @@ extern "C" int mi_ema_update(float* k, const float* q, float m, long n, mi_strea
 }
 
 extern "C" int mi_sgd_step(float* p, const float* g, const float* lr_dev, float lr, float weight_decay,
-                           long n, mi_stream_t stream) {
+                           float grad_scale, long n, mi_stream_t stream) {
     if (!p || !g || n <= 0 || ((uintptr_t)p & 15) || ((uintptr_t)g & 15)) return MI_E_ARG;
-    hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, lr_dev, lr, weight_decay, n);
+    hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, lr_dev, lr, weight_decay,
+                       grad_scale, n);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

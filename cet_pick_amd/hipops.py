@@ -257,8 +257,16 @@ class WeightImages:
         return sum(it[0]._version for items in self._groups.values() for it in items)
 
 
+def _arith_bf16x3():
+    """MI_CONV_ARITH (conv_igemm.hip conv_arith_bf16x3): anything starting with 'f' selects the f32 MFMA path."""
+    import os
+    return not os.environ.get("MI_CONV_ARITH", "").startswith("f")
+
+
 def _cached_image(w, dgrad, n, d, h, wd, k3, stride, p3):
     if ACTIVE_IMAGES is None or PROFILE is not None or k3 != (3, 3, 3) or stride != 1 or p3 != (1, 1, 1):
+        return None
+    if not _arith_bf16x3():          # the direct kernels are bf16x3 only: an f32 A/B run keeps every conv on the f32 MFMA
         return None
     return ACTIVE_IMAGES.get(w, dgrad, n, d, h, wd)
 
@@ -375,7 +383,10 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
         slab = getattr(param, "_mi_slabs", None)
         if slab is None or slab.numel() < nbytes or slab.device != x.device:
             slab = torch.empty(int(nbytes), dtype=torch.uint8, device=x.device)     # lives with the parameter
-            param._mi_slabs = slab
+            if not getattr(param, "_mi_slabs_pinned", False):
+                param._mi_slabs = slab
+            # (pinned: a captured hipGraph writes and reads the old buffer on every replay - MocoStepEngine pins the slabs
+            # when it captures; an eager call that needs more space gets a buffer of its own and the graph's stays alive)
         splits = ctypes.c_int(0)
         L.check(lib.mi_convnd_wgrad_slabs_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, *k3, stride, *p3,
                                               L.ptr(slab), slab.numel(), ctypes.addressof(splits), L.stream()),
@@ -582,7 +593,8 @@ FORCE_COLLECTIVES = False     # tests: issue every collective on a 1-rank group 
 # async_op=True while its stream is being captured ends up polled by the process group's watchdog thread, whose
 # hipEventQuery on the Work's end event - last recorded in a capturing stream - raises hipErrorCapturedEvent and
 # terminates the process ("operation not permitted on an event last recorded in a capturing stream"; measured with
-# tools/diag_watchdog.sh: 4 of 4 captured runs die with async works, 0 of 4 without).  That was the intermittent abort of
+# tools/diag_captured_event.py / tools/diag_teardown.py, profiles/r02_teardown_diag.txt: 4 of 4 captured runs die with async
+# works, 0 of 4 without).  That was the intermittent abort of
 # the N > 1 captured step that round 1 hid behind os._exit: the engine's four bucket all-reduces were async.  Overlap
 # with the backward pass comes from issuing the (synchronous) collective on a side stream instead - see
 # MocoStepEngine._reduce_bucket.
@@ -1116,8 +1128,10 @@ class _CELabel0Fn(torch.autograd.Function):
         b, n = logits.shape
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
         rows = torch.empty(2 * b, dtype=torch.float32, device=logits.device)          # row losses | row log-sum-exps
+        # arrival counter of the launch's last workgroup: one self-resetting word per (device, stream)
+        ctr = L.workspace(256, logits.device, "ce0_counter", init=lambda buf: buf.zero_())
         L.check(L.lib().mi_ce_label0_fwd(L.ptr(logits), L.ptr(loss), L.ptr(out), L.ptr(rows), L.ptr(rows[b:]), b, n,
-                                         L.stream()), "mi_ce_label0_fwd")
+                                         L.ptr(ctr), L.stream()), "mi_ce_label0_fwd")
         ctx.save_for_backward(logits, rows)
         return loss
 
@@ -1177,9 +1191,10 @@ def ema_update_(k_flat, q_flat, m):
             "mi_ema_update")
 
 
-def sgd_step_(p_flat, g_flat, lr, weight_decay=0.0, lr_dev=None):
+def sgd_step_(p_flat, g_flat, lr, weight_decay=0.0, lr_dev=None, grad_scale=1.0):
+    """p -= lr * (grad_scale * g + wd * p); grad_scale = 1 / world when g is the SUM of the ranks' gradients."""
     L.check(L.lib().mi_sgd_step(L.ptr(p_flat), L.ptr(g_flat), L.ptr(lr_dev), float(lr), float(weight_decay),
-                                p_flat.numel(), L.stream()), "mi_sgd_step")
+                                float(grad_scale), p_flat.numel(), L.stream()), "mi_sgd_step")
 
 
 def queue_enqueue_(queue, queue_ptr, keys):

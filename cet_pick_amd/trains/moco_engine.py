@@ -28,6 +28,7 @@ class MocoStepEngine:
         self.arena_q, self.arena_k = moco.flatten_parameters()
         dev = self.arena_q.flat.device
         self.lr_dev = torch.full((1,), self.lr, dtype=torch.float32, device=dev)
+        self.logits = None
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self._loss_buf = self.loss
         d = _dist()
@@ -69,7 +70,12 @@ class MocoStepEngine:
         if self._images is not None:
             self._images.refresh("q")
             self._images.refresh("k")
-            self._img_versions = self._images.versions()
+            self._img_versions = self._weight_versions()
+
+    def _weight_versions(self):
+        """Changes whenever a torch op wrote a cached weight OR either flat arena (dist.broadcast, arena.flat.copy_, a
+        checkpoint load): the engine's own SGD / EMA kernels go through the C-ABI, bump nothing, and refresh by themselves."""
+        return self._images.versions() + self.arena_q.flat._version + self.arena_k.flat._version
 
     # ---- data parallel: bucketed gradient all-reduce overlapped with the backward pass ---------------------
     def _setup_buckets(self):
@@ -134,6 +140,7 @@ class MocoStepEngine:
         moco.defer_enqueue = True                      # the backward reads the queue in place; keys go in behind it
         try:
             logits, labels = moco(im_q, im_k)
+            self.logits = logits.detach()              # (B, 1 + r) of the last step; under graph replay a static buffer
             loss = H.cross_entropy_label0(logits, out=self._loss_buf)      # lands in the engine's loss buffer: no copy
             H.DEFERRED_WGRADS = [] if self.arena_q.flat_grad.is_cuda else None     # split-K slabs of the wgrads: one reduce
             loss.backward()
@@ -150,8 +157,10 @@ class MocoStepEngine:
             self._reduce_bucket("stem")
             if self._xchg is not None:
                 torch.cuda.current_stream().wait_stream(self._xchg)
-            self.arena_q.flat_grad.mul_(1.0 / self.world)
-        H.sgd_step_(self.arena_q.flat, self.arena_q.flat_grad, self.lr, self.weight_decay, self.lr_dev)
+        # (flat_grad holds the SUM over the ranks; the 1 / world of DistributedDataParallel's averaging rides in the SGD
+        # kernel instead of a pass of its own over the arena)
+        H.sgd_step_(self.arena_q.flat, self.arena_q.flat_grad, self.lr, self.weight_decay, self.lr_dev,
+                    grad_scale=1.0 / self.world)
         if self._images is not None:
             self._images.refresh("q")                  # next step's forward / data-gradient images of encoder_q
         return self.loss
@@ -172,6 +181,10 @@ class MocoStepEngine:
             if not self.dist_on:
                 raise
             err = e
+        # the graph bakes in the addresses of the weight-gradient slab buffers: they must never be reallocated from now on
+        for prm in self.arena_q.params:
+            if getattr(prm, "_mi_slabs", None) is not None:
+                prm._mi_slabs_pinned = True
         if self.dist_on:
             # the outcome is agreed on eagerly (outside any capture); a stream or communicator left in an error
             # state by the aborted capture surfaces here instead of being swallowed
@@ -193,8 +206,8 @@ class MocoStepEngine:
         Graph mode: the first two calls run eagerly (they size every workspace), the third call
         captures the step into a hipGraph and from then on each call is one graph replay.  A batch whose
         shape differs from the captured one (a short last batch) runs eagerly."""
-        if self._images is not None and self._images.versions() != self._img_versions:
-            self.refresh_weight_images()               # first step, or the weights were written through torch ops
+        if self._images is not None and self._weight_versions() != self._img_versions:
+            self.refresh_weight_images()               # first step, or the weights / arenas were written through torch ops
         if not self.use_graph:
             return self._step_eager(im_q, im_k)
         if self._graph is None:

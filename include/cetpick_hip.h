@@ -383,17 +383,20 @@ int mi_ce_label0(const float* logits, float* loss, float* row_loss, float* dlogi
                  float grad_scale, mi_stream_t stream);
 /* The same loss in ONE launch (a workgroup per row; the last one to finish takes the mean, in row order), row_loss[B] and
  * row_lse[B] scratch / kept for the backward pass; the backward reads the upstream gradient from the device (no host
- * value, no extra scaling launch): dlogits = grad_loss * (softmax - onehot0) / B.  One call at a time per device. */
+ * value, no extra scaling launch): dlogits = grad_loss * (softmax - onehot0) / B.
+ * counter: the arrival counter of the "last workgroup" - ONE 4-byte word owned by the caller, zero before the first call and
+ * left zero by every call; give each stream (and each model) its own.  NULL: a process-wide word - one call at a time per device. */
 int mi_ce_label0_fwd(const float* logits, float* loss, float* loss_copy /* may be NULL: a second place for the value */,
-                     float* row_loss, float* row_lse, int B, int n, mi_stream_t stream);
+                     float* row_loss, float* row_lse, int B, int n, unsigned* counter, mi_stream_t stream);
 int mi_ce_label0_bwd(const float* logits, const float* row_lse, const float* grad_loss, float* dlogits, int B, int n,
                      mi_stream_t stream);
 
 /* models/moco.py:31-39: k <- m*k + (1-m)*q over a flat parameter arena (16-B aligned). */
 int mi_ema_update(float* k, const float* q, float m, long n, mi_stream_t stream);
-/* torch.optim.SGD (moco_main.py:79, no momentum): p <- p - lr*(g + wd*p).  lr_dev (device float,
- * may be NULL -> lr) lets a captured graph follow the schedule. */
-int mi_sgd_step(float* p, const float* g, const float* lr_dev, float lr, float weight_decay, long n,
+/* torch.optim.SGD (moco_main.py:79, no momentum): p <- p - lr*(grad_scale*g + wd*p).  lr_dev (device float,
+ * may be NULL -> lr) lets a captured graph follow the schedule; grad_scale = 1 / world size when g holds the sum of the
+ * data-parallel ranks' gradients (DistributedDataParallel's averaging, moco_main.py:44-66), 1 otherwise. */
+int mi_sgd_step(float* p, const float* g, const float* lr_dev, float lr, float weight_decay, float grad_scale, long n,
                 mi_stream_t stream);
 /* models/moco.py:41-52: queue[:, ptr:ptr+B] = keys.T; ptr = (ptr+B) % R, ptr read and advanced on
  * the device (no host sync).  R % B == 0 as the reference asserts. */

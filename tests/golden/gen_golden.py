@@ -385,6 +385,67 @@ def gen_moco():
     save("moco_3steps.npz", **res)
 
 
+def gen_moco_wc():
+    """The same 3 MoCo steps as gen_moco at a WELL-CONDITIONED learning rate, so that gradients are comparable on every
+    step.  Measured on the CPU oracle, fp32 against float64 of the same arithmetic (relative L2 of the
+    stem / layer1 gradients at steps 0, 1, 2): lr 1e-3: 2e-5, 5e-3, 3e-1 (batch 8 and batch 32 alike: the step map
+    amplifies a perturbation about 100x per step - 0.4 % weight change per step through the batch-statistics BatchNorms of
+    the head and the un-normalised residual trunk); lr 1e-4: 2e-5, 1e-5, 2e-3; lr 1e-5: 2e-5, 1e-5, 1e-5.  Hence 1e-5.
+    Per step: logits, loss, pointer, the norm of every parameter gradient and a sample of nine of them; at the end the
+    weight DELTAS of three tensors (the update is ~1e-6 of a weight: deltas, not weights, show that SGD ran).
+    -> moco_3steps_wc.npz"""
+    import contextlib
+    import io
+    torch.manual_seed(7)
+    q, k = _enc(), _enc()
+    moco = R_moco.MoCo(q, k, dim=128, r=64, m=0.99, T=0.1)
+    g = torch.Generator().manual_seed(123)
+    moco.queue.copy_(torch.nn.functional.normalize(torch.randn(128, 64, generator=g), dim=0))
+    opt = torch.optim.SGD(moco.parameters(), lr=1e-5)
+    crit = torch.nn.CrossEntropyLoss()
+    res = {"queue0": moco.queue.numpy().copy(), "lr": np.asarray(1e-5)}
+    w0 = {n: prm.detach().clone() for n, prm in moco.encoder_q.named_parameters()}
+    k0 = {n: prm.detach().clone() for n, prm in moco.encoder_k.named_parameters()}
+    idx = np.random.default_rng(11).integers(0, 2 ** 31, size=32)
+    res["sample_idx"] = idx
+    sampled = ("conv1.weight", "layer1.0.conv1.weight", "layer2.0.conv1.weight", "layer2.0.downsample.0.weight",
+               "layer3.0.conv1.weight", "layer3.1.conv2.weight", "feature_3d.0.weight", "fc.weight", "proj.0.weight")
+    B = 8
+    for step in range(3):
+        im_q = torch.randn(B, 1, 32, 32, 32, generator=g)
+        im_k = im_q.flip(4) + 0.1 * torch.randn(B, 1, 32, 32, 32, generator=g)
+        with contextlib.redirect_stdout(io.StringIO()):
+            qf = torch.nn.functional.normalize(moco.encoder_q(im_q)[0]["proj"], dim=1)
+            with torch.no_grad():
+                moco._momentum_update_key_encoder()
+                kf = torch.nn.functional.normalize(moco.encoder_k(im_k)[0]["proj"], dim=1)
+        l_pos = torch.einsum("nc,nc->n", [qf, kf]).unsqueeze(-1)
+        l_neg = torch.einsum("nc,ck->nk", [qf, moco.queue.clone().detach()])
+        logits = torch.cat([l_pos, l_neg], dim=1) / moco.T
+        labels = torch.zeros(B, dtype=torch.long)
+        moco._dequeue_and_enqueue(kf)
+        loss = crit(logits, labels)
+        opt.zero_grad()
+        loss.backward()
+        for n, prm in moco.encoder_q.named_parameters():
+            if prm.grad is None or n.startswith("pred."):
+                continue
+            gf = prm.grad.reshape(-1).numpy()
+            res[f"gnorm_{step}_{n}"] = np.asarray(np.linalg.norm(gf.astype(np.float64)))
+            if n in sampled:
+                res[f"gsample_{step}_{n}"] = gf[idx % gf.size].copy()
+        opt.step()
+        res[f"logits_{step}"] = logits.detach().numpy()
+        res[f"loss_{step}"] = np.asarray(loss.item())
+        res[f"ptr_{step}"] = np.asarray(int(moco.queue_ptr))
+    res["queue_final"] = moco.queue.numpy().copy()
+    qp, kp = dict(moco.encoder_q.named_parameters()), dict(moco.encoder_k.named_parameters())
+    for n, stride in (("fc.weight", 7), ("layer1.0.conv1.weight", 997), ("layer3.0.downsample.0.weight", 101)):
+        res[f"q_delta_{n}"] = (qp[n].detach().double() - w0[n].double()).reshape(-1)[::stride].numpy().copy()
+        res[f"k_delta_{n}"] = (kp[n].detach().double() - k0[n].double()).reshape(-1)[::stride].numpy().copy()
+    save("moco_3steps_wc.npz", **res)
+
+
 def gen_simsiam2d():
     """a2 + a9: TomoResClassifier2D (simsiam_model_2d.py:617-819) two-view forward/backward under
     TomoSimSiamLoss's arithmetic (trains/tomo_simsiam_trainer.py:28-40; that module itself imports
@@ -596,6 +657,6 @@ def gen_lr():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader", "unet", "losses", "simsiam", "simsiam2d3d", "crops", "semi_loss", "moco_small"]
+    which = sys.argv[1:] or ["decode", "greedy", "dog", "enc3d", "moco", "lr", "simsiam2d", "loader", "unet", "losses", "simsiam", "simsiam2d3d", "crops", "semi_loss", "moco_small", "moco_wc"]
     for w in which:
         globals()["gen_" + w]()

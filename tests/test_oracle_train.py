@@ -204,3 +204,35 @@ def test_symmetric_moco_matches_reference(golden, tag, symmetric):
         np.testing.assert_allclose(np.linalg.norm(gf.astype(np.float64)), want, rtol=2e-3, err_msg=name)
         np.testing.assert_allclose(gf[idx % gf.size], g[f"grad_{tag}_{name}_sample"], rtol=0,
                                    atol=2e-3 * np.abs(g[f"grad_{tag}_{name}_sample"]).max() + 1e-7, err_msg=name)
+
+
+def test_moco_three_wellconditioned_steps_match_reference(golden):
+    """moco_3steps_wc.npz: the reference's three MoCo steps at lr 1e-5 - logits, loss, pointer and EVERY parameter
+    gradient's norm on every step (the lr-0.05 fixture above is chaotic from step 1 on, and so is lr 1e-3: fp32 and
+    float64 runs of this oracle are 5e-3 apart at step 1 and 3e-1 at step 2; at 1e-5 they stay 2e-5 apart)."""
+    g = golden("moco_3steps_wc.npz")
+    ref = T.MocoRef(seeded_sd(), torch.from_numpy(g["queue0"]), m=0.99, T=0.1, lr=float(g["lr"]))
+    q0 = {k: v.clone() for k, v in ref.q.items()}
+    gen = torch.Generator().manual_seed(123)
+    torch.randn(128, 64, generator=gen)
+    idx = g["sample_idx"]
+    for step in range(3):
+        im_q = torch.randn(8, 1, 32, 32, 32, generator=gen)
+        im_k = im_q.flip(4) + 0.1 * torch.randn(8, 1, 32, 32, 32, generator=gen)
+        lg, loss, grads = ref.step(im_q, im_k)
+        np.testing.assert_allclose(lg.numpy(), g[f"logits_{step}"], rtol=0, atol=1e-3)
+        assert abs(loss - float(g[f"loss_{step}"])) < 1e-4
+        assert ref.ptr == int(g[f"ptr_{step}"])
+        for n, gr in grads.items():
+            want = float(g[f"gnorm_{step}_{n}"])
+            if want > 1e-4:
+                assert abs(float(gr.double().norm()) - want) <= 1e-3 * want, (step, n)
+            if f"gsample_{step}_{n}" in g.files:
+                ws = g[f"gsample_{step}_{n}"]
+                gf = gr.reshape(-1).numpy()
+                np.testing.assert_allclose(gf[idx % gf.size], ws, rtol=0, atol=1e-3 * np.abs(ws).max() + 1e-7)
+    for n, stride in (("fc.weight", 7), ("layer1.0.conv1.weight", 997), ("layer3.0.downsample.0.weight", 101)):
+        want = g[f"q_delta_{n}"]
+        got = (ref.q[n].double() - q0[n].double()).reshape(-1)[::stride].numpy()
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-2 * np.abs(want).max())   # (an update is ~1e-6 of a weight: ulps)
+    np.testing.assert_allclose(ref.queue.numpy(), g["queue_final"], rtol=0, atol=1e-4)

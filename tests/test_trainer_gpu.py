@@ -174,6 +174,7 @@ def test_symmetric_moco_variant_vs_oracle():
     for kk in [k for k in sd0 if k.startswith("pred.")]:      # 'pred' re-registers the 'proj' module: one set of weights
         sd0["proj." + kk[5:]] = sd0[kk]
     eq.load_state_dict(sd0)
+    ek.load_state_dict(sd0)                  # (MoCoModel copies parameters q -> k, not buffers: the fixture seeded both)
     from cet_pick_amd.synthetic import moco_small_inputs
     im1, im2, queue0 = moco_small_inputs()
     model = MoCoModel(eq, ek, dim=128, K=64, m=0.99, T=0.1, symmetric=True, shuffle=False)
@@ -252,3 +253,131 @@ def test_symmetric_moco_variant_vs_oracle():
     tr.set_device([0], None, "cuda")
     ret, _ = tr.train(1, [{"input": im1, "input_aug": im2}])
     assert set(ret) == {"loss", "moco_loss", "time"} and np.isfinite(ret["loss"])
+
+
+def _moco_pair(batch_seed, r):
+    """MoCo over two seeded moco3d encoders + its state as oracle dictionaries."""
+    from cet_pick_amd.models.networks.moco_encoder_3d import get_moco_net_small_3d
+    from cet_pick_amd.models.moco import MoCo
+    from cet_pick_amd.synthetic import seeded_state_dict
+    heads = {"proj": 256, "pred": 256}
+    eq, ek = get_moco_net_small_3d(18, heads, 0), get_moco_net_small_3d(18, heads, 0)
+    sd0 = seeded_state_dict(eq, seed=317)
+    for kk in [k for k in sd0 if k.startswith("pred.")]:
+        sd0["proj." + kk[5:]] = sd0[kk]
+    eq.load_state_dict(sd0)
+    moco = MoCo(eq, ek, dim=128, r=r, m=0.999, T=0.1)
+    g = torch.Generator().manual_seed(batch_seed)
+    moco.queue.copy_(torch.nn.functional.normalize(torch.randn(128, r, generator=g), dim=0))
+    return moco.cuda().train(), g
+
+
+def _oracle_state(enc):
+    return {n: t.detach().cpu().contiguous().clone() for n, t in list(enc.named_parameters()) + list(enc.named_buffers())}
+
+
+def test_engine_graph_replayed_batch64_step_matches_oracle():
+    """The step bench.py times - batch 64, r = 1024, lr 1e-3, replayed from the captured hipGraph, i.e. cached weight
+    images + direct kernels + deferred weight-gradient reduce + deferred enqueue + side-stream key branch - against
+    oracle/train_ref.MocoRef started from the engine's own state (float64 evaluation of the same oracle as arbiter):
+    logits, loss, every parameter gradient, the SGD'd query weights, the EMA'd key weights, queue and pointer
+    (models/moco.py:101-146)."""
+    import numpy as np
+    from conftest import f32_equivalent
+    from oracle import train_ref as T
+    from cet_pick_amd.trains.moco_engine import MocoStepEngine
+    moco, g = _moco_pair(5, 1024)
+    eng = MocoStepEngine(moco, lr=1e-3, use_graph=True)
+    B = 64
+    def batch():
+        a = torch.randn(B, 1, 32, 32, 32, generator=g)
+        return a, a.flip(4) + 0.1 * torch.randn(B, 1, 32, 32, 32, generator=g)
+    for _ in range(3):                                        # eager, eager, capture + first replay
+        a, b = batch()
+        eng.step(a.cuda(), b.cuda())
+    assert eng._graph is not None and eng.node_counts()["kernel"] > 50
+    torch.cuda.synchronize()
+    sd_q, sd_k = _oracle_state(moco.encoder_q), _oracle_state(moco.encoder_k)
+    queue0, ptr0 = moco.queue.cpu().clone(), int(moco.queue_ptr)
+    q_before = eng.arena_q.flat.clone()
+    im_q, im_k = batch()
+    loss = eng.step(im_q.cuda(), im_k.cuda())                 # ONE graph replay
+    torch.cuda.synchronize()
+
+    def run_ref(dt):
+        cv = lambda t: t.to(dt) if t.is_floating_point() else t.clone()
+        ref = T.MocoRef({k: cv(v) for k, v in sd_q.items()}, cv(queue0), m=0.999, T=0.1, lr=1e-3)
+        ref.k = {k: cv(v) for k, v in sd_k.items()}
+        ref.ptr = ptr0
+        out = ref.step(cv(im_q), cv(im_k))
+        return ref, out
+    ref, (lg32, loss32, g32) = run_ref(torch.float32)
+    ref64, (lg64, loss64, g64) = run_ref(torch.float64)
+    lg = eng.logits.cpu().numpy()
+    assert lg.shape == (B, 1025)
+    np.testing.assert_allclose(0.1 * lg, 0.1 * lg64.numpy(), rtol=0, atol=1e-3)          # cosines: north_star's 1e-3
+    f32_equivalent(lg, lg32.numpy(), lg64.numpy(), what="logits")
+    assert abs(float(loss) - loss64) <= max(2 * abs(loss32 - loss64) + 2e-5, 2e-4)
+    gscale = float(sum(float(v.norm()) ** 2 for v in g64.values()) ** 0.5)
+    checked = 0
+    for n, p in moco.encoder_q.named_parameters():
+        if n == "fc.bias" or n not in g32:
+            continue
+        a = p._mi_grad_view.detach().cpu().contiguous().numpy()          # the arena the graph wrote (and SGD consumed)
+        floor = 5e-5 * gscale / (float(g64[n].norm()) + 1e-30) + 2e-6
+        f32_equivalent(a, g32[n].numpy(), g64[n].numpy(), floor=floor, what="grad " + n)
+        assert float(np.linalg.norm(a - g32[n].numpy())) <= 1e-3 * float(g32[n].norm()) + 5e-5 * gscale, n
+        checked += 1
+    assert checked >= 28
+    # SGD applied exactly the arena's gradient; EMA, queue and pointer follow the oracle
+    want_q = q_before - 1e-3 * eng.arena_q.flat_grad
+    assert float((eng.arena_q.flat - want_q).abs().max()) <= 2e-7 * float(q_before.abs().max())
+    for n, p in moco.encoder_k.named_parameters():
+        np.testing.assert_allclose(p.detach().cpu().contiguous().numpy(), ref.k[n].numpy(), rtol=0, atol=2e-6, err_msg=n)
+    np.testing.assert_allclose(moco.queue.cpu().numpy(), ref.queue.numpy(), rtol=0, atol=2e-4)
+    assert int(moco.queue_ptr) == ref.ptr == (ptr0 + B) % 1024
+    np.testing.assert_allclose(moco.encoder_q.bn1.running_var.cpu().numpy(), ref.q["bn1.running_var"].numpy(), rtol=1e-4, atol=1e-6)
+    eng.close()
+
+
+def test_engine_step_equals_plain_sequence_bitwise():
+    """the fast paths that exist only inside MocoStepEngine - cached pre-cut weight images, the deferred
+    split-K weight-gradient reduce, the deferred enqueue on a stable queue, the loss buffer - against the plain sequence
+    moco(); cross_entropy_label0; backward; sgd_step_ from the same state.  Both run the same kernels in the same
+    order of summation: gradients, both arenas, queue and pointer must be EQUAL BIT FOR BIT on every step - also after
+    the weights were written through the flat arena between two steps (a stale image would show here)."""
+    from cet_pick_amd import hipops as H
+    from cet_pick_amd.trains.moco_engine import MocoStepEngine
+    mA, g = _moco_pair(9, 64)
+    mB, _ = _moco_pair(9, 64)
+    eng = MocoStepEngine(mA, lr=1e-3, use_graph=False)
+    aq, ak = mB.flatten_parameters()
+    assert torch.equal(eng.arena_q.flat, aq.flat) and torch.equal(mA.queue, mB.queue)
+    B = 16
+    for step in range(4):
+        x = torch.randn(B, 1, 32, 32, 32, generator=g).cuda()
+        y = (x.flip(4) + 0.1 * torch.randn(B, 1, 32, 32, 32, generator=g).cuda())
+        if step == 2:
+            # a write from outside the step, through the ARENA (what dist.broadcast / a checkpoint load do): the engine
+            # has to notice and re-cut its images
+            with torch.no_grad():
+                eng.arena_q.flat.mul_(1.001); aq.flat.mul_(1.001)
+                eng.arena_k.flat.mul_(0.999); ak.flat.mul_(0.999)
+        la = eng.step(x, y)
+        aq.zero_grad()
+        logits, _ = mB(x, y)
+        lb = H.cross_entropy_label0(logits)
+        lb.backward()
+        H.sgd_step_(aq.flat, aq.flat_grad, 1e-3)
+        torch.cuda.synchronize()
+        assert torch.equal(eng.logits, logits.detach()), step
+        assert float(la) == float(lb), step
+        assert torch.equal(eng.arena_q.flat_grad, aq.flat_grad), step
+        assert torch.equal(eng.arena_q.flat, aq.flat) and torch.equal(eng.arena_k.flat, ak.flat), step
+        assert torch.equal(mA.queue, mB.queue) and int(mA.queue_ptr) == int(mB.queue_ptr) == ((step + 1) * B) % 64, step
+    # and a fresh engine started from the plain model's state takes the same next step
+    eng2 = MocoStepEngine(mB, lr=1e-3, use_graph=False)
+    x = torch.randn(B, 1, 32, 32, 32, generator=g).cuda()
+    eng.step(x, x.flip(3)); eng2.step(x, x.flip(3))
+    torch.cuda.synchronize()
+    assert torch.equal(eng.arena_q.flat, eng2.arena_q.flat) and torch.equal(eng.arena_q.flat_grad, eng2.arena_q.flat_grad)
