@@ -1098,10 +1098,13 @@ class _MocoLogitsNormFn(torch.autograd.Function):
         ctx.save_for_backward(k_hat, queue if queue_stable else queue.clone(), q_hat, q_inv)
         ctx.T = float(T)
         ctx.mark_non_differentiable(k_hat)
+        ctx.set_materialize_grads(False)        # (no zeros(B, C) launch for the key output's absent gradient)
         return logits, k_hat
 
     @staticmethod
     def backward(ctx, dl, _dk):
+        if dl is None:
+            return None, None, None, None, None
         k_hat, queue, q_hat, q_inv = ctx.saved_tensors
         b, c = k_hat.shape
         r = queue.shape[1]
@@ -1119,6 +1122,28 @@ def moco_logits_normalized(q_raw, k_raw, queue, T, queue_stable=False):
     return _MocoLogitsNormFn.apply(_f32c(q_raw, "q"), _f32c(k_raw, "k"), _f32c(queue, "queue"), T, bool(queue_stable))
 
 
+_CE0_COUNTERS = {}       # device -> (int32 tensor of 64 self-resetting arrival counters, {stream id: slot})
+
+
+def _ce0_counter(device):
+    """The arrival counter of this stream's cross-entropy launches: one 4-byte word per stream out of a per-device table that
+    is zeroed ONCE, when it is created (a per-stream workspace would be created - and its clearing pass captured - inside a
+    hipGraph capture, whose capture stream is a new one: a fill launch in every replay).  Launches on different streams never
+    share a word; the kernel leaves its word zero."""
+    key = (device.type, device.index)
+    ent = _CE0_COUNTERS.get(key)
+    if ent is None:
+        ent = (torch.zeros(64 * 64, dtype=torch.int32, device=device), {})      # 64 words, 256 bytes apart
+        _CE0_COUNTERS[key] = ent
+    table, slots = ent
+    sid = torch.cuda.current_stream(device).cuda_stream
+    slot = slots.get(sid)
+    if slot is None:
+        slot = len(slots) % 64
+        slots[sid] = slot
+    return table[slot * 64:]
+
+
 class _CELabel0Fn(torch.autograd.Function):
     """forward = one launch (a workgroup per row, the last one takes the mean) that also drops the loss into `out` (the
     engine's loss buffer: no copy afterwards); backward = one launch that reads the upstream gradient on the device."""
@@ -1128,10 +1153,8 @@ class _CELabel0Fn(torch.autograd.Function):
         b, n = logits.shape
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
         rows = torch.empty(2 * b, dtype=torch.float32, device=logits.device)          # row losses | row log-sum-exps
-        # arrival counter of the launch's last workgroup: one self-resetting word per (device, stream)
-        ctr = L.workspace(256, logits.device, "ce0_counter", init=lambda buf: buf.zero_())
         L.check(L.lib().mi_ce_label0_fwd(L.ptr(logits), L.ptr(loss), L.ptr(out), L.ptr(rows), L.ptr(rows[b:]), b, n,
-                                         L.ptr(ctr), L.stream()), "mi_ce_label0_fwd")
+                                         L.ptr(_ce0_counter(logits.device)), L.stream()), "mi_ce_label0_fwd")
         ctx.save_for_backward(logits, rows)
         return loss
 

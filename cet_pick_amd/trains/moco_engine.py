@@ -29,6 +29,7 @@ class MocoStepEngine:
         dev = self.arena_q.flat.device
         self.lr_dev = torch.full((1,), self.lr, dtype=torch.float32, device=dev)
         self.logits = None
+        self._one = torch.ones((), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self._loss_buf = self.loss
         d = _dist()
@@ -143,7 +144,7 @@ class MocoStepEngine:
             self.logits = logits.detach()              # (B, 1 + r) of the last step; under graph replay a static buffer
             loss = H.cross_entropy_label0(logits, out=self._loss_buf)      # lands in the engine's loss buffer: no copy
             H.DEFERRED_WGRADS = [] if self.arena_q.flat_grad.is_cuda else None     # split-K slabs of the wgrads: one reduce
-            loss.backward()
+            loss.backward(self._one)                   # (a kept seed: autograd's ones_like(loss) is a fill launch per step)
             H.flush_wgrad_reduces()
             moco.flush_enqueue()
         finally:

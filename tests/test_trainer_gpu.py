@@ -223,13 +223,16 @@ def test_symmetric_moco_variant_vs_oracle():
         gf = prm.grad.detach().cpu().reshape(-1).numpy()            # logical (co, ci, kd, kh, kw) order, as the reference
         if want < 1e-5:
             continue
-        # the reference ran in fp32 on the CPU: its own distance from float64 bounds what "equal" can mean (the stem-level
-        # gradients pass through two forward passes); 1e-3 (north_star) + that distance
-        r64 = np.linalg.norm(sd_q64[name].grad.reshape(-1).numpy())
+        # the reference ran in fp32 on the CPU: ITS distance from the float64 evaluation is the resolution of the comparison
+        # (the stem-level gradients pass through two forward passes: 0.3 % of the largest sample); the GPU may be twice as
+        # far from float64 (f32_equivalent above), i.e. three such distances from the reference, + north_star's 1e-3
+        g64 = sd_q64[name].grad.reshape(-1).numpy()
+        r64 = np.linalg.norm(g64)
         slack = abs(want - r64) / r64
-        assert abs(np.linalg.norm(gf.astype(np.float64)) - want) <= (1e-3 + 2 * slack) * want, name
+        assert abs(np.linalg.norm(gf.astype(np.float64)) - want) <= (1e-3 + 3 * slack) * want, name
         ws = G[f"grad_sym_{name}_sample"]
-        np.testing.assert_allclose(gf[idx % gf.size], ws, rtol=0, atol=(1e-3 + 2 * slack) * np.abs(ws).max() * 3 + 1e-7, err_msg=name)
+        e_ref = float(np.abs(ws - g64[idx % g64.size]).max())
+        np.testing.assert_allclose(gf[idx % gf.size], ws, rtol=0, atol=3 * e_ref + 1e-3 * float(np.abs(ws).max()) + 1e-7, err_msg=name)
     # the one-directional variant (symmetric=False, :153-154): loss and the 8 enqueued keys
     ma = MoCoModel(get_moco_net_small_3d(18, heads, 0), get_moco_net_small_3d(18, heads, 0), dim=128, K=64, m=0.99, T=0.1,
                    symmetric=False, shuffle=False)
