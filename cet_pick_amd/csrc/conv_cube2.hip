@@ -175,6 +175,145 @@ __global__ __launch_bounds__(256, 2) void cube2_kernel(Cube2Params p) {
 }
 
 
+
+// ---- weight gradient of the convolutions whose OUTPUT is a 2 x 2 x 2 volume (round 3) -----------------------------------------
+// layer3 / feature_3d (256 -> 256 on 2^3, stride 1: four launches per step) and layer3.0.conv1 (128 -> 256, 4^3 -> 2^3, stride 2)
+// of the MoCo-3D encoder (moco_encoder_3d.py:55-84,172,178).  dW[tap][ci][co] = sum over samples n and over the (input voxel vi,
+// output voxel vo) PAIRS the tap connects - at most 8, one per output voxel, 64 / 27 = 2.4 on average on a stride-1 2^3 volume -
+// of X[n][vi][ci] dY[n][vo][co]: per tap a few (ci x n) . (n x co) products whose reduction is the BATCH.  The implicit GEMM
+// walks 16 slices per 64 x 64 tile behind a per-slice gather (19 - 20 us per launch for 0.5 GFLOP of real work).  Here a
+// workgroup owns one (tap, 64 ci, 64 co) tile and loops over the tap's pairs: the two 64-sample x 64-channel blocks of a pair
+// are fetched with 16-byte loads along the channels (their memory order), cut ONCE into bf16x3 rows [sample][32 channels] in
+// LDS, and the fragments - which need the sample axis contiguous - come out through the transposing LDS read
+// (ds_read_b64_tr_b16), as in direct3_wgrad_kernel.  The next pair's loads are in flight during the MFMAs of the current one;
+// eight waves (four 32 x 32 sub-tiles x two halves of a block's k-steps, summed through LDS at the end: a workgroup's time is
+// its chain of pair iterations); 48 KB of LDS, two workgroups per CU.  Output tiles are final: no split-K slabs,
+// no reduce launch.  Taps are launched heaviest first (the centre tap has 8 pairs, a corner tap 1).
+constexpr int PW_ROW = 64;                      // bytes of a (sample, 32 channels) row of one bf16 plane
+constexpr int PW_HALF = 64 * PW_ROW;            // 64 samples: one 32-channel half
+constexpr int PW_PLANE = 2 * PW_HALF;
+constexpr int PW_OP = 3 * PW_PLANE;             // one operand block (64 samples x 64 channels x 3 planes): 24,576 bytes
+constexpr int PW_MAXTAP = 27;
+
+struct PairWgradParams {
+    const float* x;           // (N, VI voxels, CI)
+    const float* dy;          // (N, VO voxels, CO)
+    float* dw;                // [ntaps][CI][CO]
+    int N, VI, VO, CI, CO, ntaps;
+    unsigned x_bytes, dy_bytes;
+    unsigned char order[PW_MAXTAP];       // taps, heaviest first
+    unsigned char cnt[PW_MAXTAP];         // pairs of a tap
+    unsigned char vi[PW_MAXTAP][8], vo[PW_MAXTAP][8];
+};
+
+typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4w lds_bf16x4w;
+
+__global__ __launch_bounds__(512, 2) void pair_wgrad_kernel(PairWgradParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PW_OP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31, i16 = lane & 15, g16 = (lane >> 4) & 1;
+    // eight waves: wave & 3 = the 32 x 32 sub-tile (ci half wm x co half wn), wave >> 2 = the half of a block's four k-steps it
+    // takes - a workgroup's time is its chain of pair iterations (the centre tap has 8), so an iteration is cut in two
+    const int wm = (wave >> 1) & 1, wn = wave & 1, kh = wave >> 2;
+    const int ncb = p.CO >> 6, nib = p.CI >> 6;
+    const int tap = p.order[blockIdx.x / (nib * ncb)];
+    const int rem = blockIdx.x % (nib * ncb), ib = rem / ncb, cb = rem % ncb;
+    const int npairs = p.cnt[tap], nchunks = (p.N + 63) >> 6, total = npairs * nchunks;
+
+    // staging: thread = (sample row, 8 channels): one unit of X and one of dY per block
+    const __amdgpu_buffer_rsrc_t xrs = rsrc_of2(p.x, p.x_bytes), yrs = rsrc_of2(p.dy, p.dy_bytes);
+    const int srow = tid >> 3, cg = tid & 7;
+    const int st_lds = (cg >> 2) * PW_HALF + srow * PW_ROW + (cg & 3) * 16;
+    // three blocks in flight: an iteration (12 MFMAs per wave) is far shorter than an L2 / HBM round trip
+    u32x4 ldx[3][2], ldy[3][2];
+    auto fetch = [&](auto Sc, int it) {
+        constexpr int S = decltype(Sc)::value;
+        const int pr = it / nchunks, n = (it % nchunks) * 64 + srow;
+        const bool ok = it < total && n < p.N;
+        const unsigned xo = ok ? 4u * (unsigned)(((long)n * p.VI + p.vi[tap][pr]) * p.CI + ib * 64 + cg * 8) : 0x80000000u;
+        const unsigned yo = ok ? 4u * (unsigned)(((long)n * p.VO + p.vo[tap][pr]) * p.CO + cb * 64 + cg * 8) : 0x80000000u;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            ldx[S][q] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo + 16u * q), 0, 0);
+            ldy[S][q] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(yo + 16u * q), 0, 0);
+        }
+    };
+    auto store = [&](auto Sc) {
+        constexpr int S = decltype(Sc)::value;
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = __uint_as_float(op ? ldy[S][0][e] : ldx[S][0][e]);
+                v[4 + e] = __uint_as_float(op ? ldy[S][1][e] : ldx[S][1][e]);
+            }
+            bf16x8 o[3];
+            cut8r(v, o);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<u32x4*>(lds + op * PW_OP + pl * PW_PLANE + st_lds) = __builtin_bit_cast(u32x4, o[pl]);
+        }
+    };
+    // fragment addresses (transposing read: this lane names row q4 of its 16-lane group's 4-row block; see
+    // direct3_wgrad_kernel): k-step ks covers samples 16 ks .. 16 ks + 15, MFMA k = 8 h + e
+    const int q4 = i16 >> 2;
+    const int coloff = (16 * g16 + 4 * (i16 & 3)) * 2;
+    const int a_base = wm * PW_HALF + (8 * h + q4 + 32 * kh) * PW_ROW + coloff;
+    const int b_base = PW_OP + wn * PW_HALF + (8 * h + q4 + 32 * kh) * PW_ROW + coloff;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+
+    auto body = [&](auto Sc, int it) {
+        store(Sc);
+        __syncthreads();
+        fetch(Sc, it + 3);                               // (behind the last block: out of range, zeros, never stored)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[3], bf[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const unsigned char* ap = lds + a_base + pl * PW_PLANE + ks * 16 * PW_ROW;
+                const unsigned char* bp = lds + b_base + pl * PW_PLANE + ks * 16 * PW_ROW;
+                const bf16x4w alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4w*)(ap));
+                const bf16x4w ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4w*)(ap + 4 * PW_ROW));
+                const bf16x4w blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4w*)(bp));
+                const bf16x4w bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4w*)(bp + 4 * PW_ROW));
+                af[pl] = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+                bf[pl] = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pr]], bf[PB[pr]], acc, 0, 0, 0);
+        }
+        __syncthreads();                                 // every wave has read this block before the next one is stored
+    };
+    fetch(std::integral_constant<int, 0>{}, 0);
+    fetch(std::integral_constant<int, 1>{}, 1);
+    fetch(std::integral_constant<int, 2>{}, 2);
+    for (int it = 0; it < total; it += 3) {
+        body(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < total) body(std::integral_constant<int, 1>{}, it + 1);
+        if (it + 2 < total) body(std::integral_constant<int, 2>{}, it + 2);
+    }
+    // the two k-halves meet in LDS (staging is over): waves 4..7 publish, waves 0..3 add (first half + second half) and store
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(lds);
+    if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave & 3][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+        // final tile: C/D layout col = lane & 31 (co), row = ci
+        float* out = p.dw + ((long)tap * p.CI + ib * 64 + 32 * wm) * p.CO + cb * 64 + 32 * wn + l32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(long)((r & 3) + 8 * (r >> 2) + 4 * h) * p.CO] = acc[r] + red[wave][r][lane];
+    }
+}
+
 // ---- small dense products: the Linear layers of the encoder head (fc, projection MLP: 64 rows) ---------------------------
 //   C[m][n] = sum_k A(m, k) * B(k, n) (+ bias[n]),   A(m, k) = a[m * lda_m + k * lda_k],  B(k, n) = b[k * ldb_k + n * ldb_n]
 // covers y = x W + b (A k-contiguous, B strided), dx = dy W^T (both k-contiguous) and dW = x^T dy (both strided: the batch
@@ -306,6 +445,45 @@ bool mi_cube2_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int 
     if (Di != 2 || Hi != 2 || Wi != 2 || Ci != Co) return false;
     if (Ci != 128 && Ci != 256 && Ci != 512) return false;                    // k-steps per wave = C / 32: 4, 8, 16
     return N >= 1 && 4l * N * 8 * Ci < 0x7fff0000l;
+}
+
+
+// weight gradient through pair_wgrad_kernel: k^3 window (k = 3, pad 1 or k = 1, pad 0), output volume 2 x 2 x 2, stride 1
+// (input 2^3) or 2 (input 4^3), channels multiples of 64
+bool mi_pair_wgrad_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw,
+                          int dd, int dh, int dw) {
+    const char* off = getenv("MI_CONV_NO_DIRECT");
+    if (off && atoi(off) != 0) return false;
+    if (kd != 3 || kh != 3 || kw != 3 || pd != 1 || ph != 1 || pw != 1 || dd != 1 || dh != 1 || dw != 1) return false;
+    if (!((stride == 1 && Di == 2) || (stride == 2 && Di == 4)) || Hi != Di || Wi != Di) return false;
+    if (Ci < 64 || Co < 64 || (Ci & 63) || (Co & 63)) return false;
+    return N >= 1 && 4l * N * Di * Hi * Wi * Ci < 0x7fff0000l && 4l * N * 8 * Co < 0x7fff0000l;
+}
+
+int mi_pair_wgrad_launch(const float* x, const float* dy, float* dwt, int N, int Di, int Ci, int Co, int stride, hipStream_t s) {
+    PairWgradParams p = {};
+    p.x = x; p.dy = dy; p.dw = dwt; p.N = N; p.VI = Di * Di * Di; p.VO = 8; p.CI = Ci; p.CO = Co; p.ntaps = 27;
+    p.x_bytes = (unsigned)(4l * N * p.VI * Ci); p.dy_bytes = (unsigned)(4l * N * 8 * Co);
+    for (int t = 0; t < 27; ++t) {
+        const int tz = t / 9, ty = (t / 3) % 3, tx = t % 3;
+        int c = 0;
+        for (int vo = 0; vo < 8; ++vo) {
+            const int iz = stride * ((vo >> 2) & 1) + tz - 1, iy = stride * ((vo >> 1) & 1) + ty - 1, ix = stride * (vo & 1) + tx - 1;
+            if (iz < 0 || iz >= Di || iy < 0 || iy >= Di || ix < 0 || ix >= Di) continue;
+            p.vi[t][c] = (unsigned char)((iz * Di + iy) * Di + ix);
+            p.vo[t][c] = (unsigned char)vo;
+            ++c;
+        }
+        p.cnt[t] = (unsigned char)c;
+    }
+    // heaviest taps first (stable); a tap without a pair (none with these geometries) would write zeros
+    int n = 0;
+    for (int want = 8; want >= 0; --want)
+        for (int t = 0; t < 27; ++t)
+            if (p.cnt[t] == want) p.order[n++] = (unsigned char)t;
+    hipLaunchKernelGGL(pair_wgrad_kernel, dim3((unsigned)(27 * (Ci / 64) * (Co / 64))), dim3(512), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
 }
 
 size_t mi_cube2_slab_bytes(int N, int C) { return sizeof(float) * (size_t)KQ * N * 8 * C; }

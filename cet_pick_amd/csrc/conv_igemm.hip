@@ -67,6 +67,9 @@ size_t mi_cube2_slab_bytes(int N, int C);
 int mi_cube2_splits();
 int mi_cube2_launch(int dgrad, const float* a, const float* w, float* slabs, int N, int C, hipStream_t s);
 // ... and the small dense products of the Linear layers (register-staged, final in one launch)
+bool mi_pair_wgrad_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw,
+                          int dd, int dh, int dw);
+int mi_pair_wgrad_launch(const float* x, const float* dy, float* dwt, int N, int Di, int Ci, int Co, int stride, hipStream_t s);
 bool mi_small_gemm_usable(long M, long N, long K);
 int mi_small_gemm_launch(const float* a, long lda_m, long lda_k, long a_elems, const float* b, long ldb_k, long ldb_n,
                          long b_elems, const float* bias, float* c, int M, int N, int K, hipStream_t s);
@@ -1213,6 +1216,10 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         if (rc) return rc;
         return mi_direct3_finish_slabs((const float*)ws, mi_cube2_splits(), (long)g.N * 8 * g.Ci, out, res, mask, relu, s);
     }
+    // weight gradients of the convolutions with a 2 x 2 x 2 output (layer3, feature_3d, layer3.0.conv1): final in one launch
+    if (mode == MODE_WGRAD && conv_arith_bf16x3() &&
+        mi_pair_wgrad_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw))
+        return mi_pair_wgrad_launch(a_src, b_src, out, g.N, g.Di, g.Ci, g.Co, g.stride, s);
     if (mode == MODE_WGRAD && dkind == 1 && ws && ws_bytes >= mi_direct3_wgrad_slab_bytes()) {
         int rc = mi_direct3_wgrad_launch(a_src, b_src, (float*)ws, g.N, g.Di, s);
         if (rc) return rc;

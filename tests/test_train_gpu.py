@@ -42,6 +42,8 @@ CASES = [
     (2, 7, 5, 6, 32, 16, 3, 2, 1),
     (2, 16, 16, 16, 1, 64, 7, 2, 3),     # stem
     (64, 1, 1, 1, 256, 128, 1, 1, 0),    # linear
+    (70, 4, 4, 4, 64, 128, 3, 2, 1),     # 2^3 output, stride 2, two sample chunks: pair_wgrad_kernel
+    (5, 2, 2, 2, 128, 64, 3, 1, 1),
 ]
 
 
