@@ -4,8 +4,9 @@ reference's cet_pick/moco_main.py (:27-207), with the defects listed in SURVEY.m
 reference's flag surface (cet_pick_amd/opts.py).  One process per GPU; under torch.distributed.run
 the ranks exchange gradients / keys / SyncBN sums over RCCL.
 
-The reference datasets are out of scope; `--dataset synthetic` (default here) trains on a synthetic
-tomogram with the same batch contract.
+Data: `--dataset synthetic` trains on a synthetic tomogram; any other `--dataset` value reads the reference's
+`<cwd>/data/<--train_img_txt>` list of MRC reconstructions (datasets/tomo_files.py: device loader -> DoG picks -> crop
+kernel, same batch contract; the random augmentations of the reference's datasets are out of scope).
 """
 import os
 import random
@@ -62,8 +63,13 @@ def main(opt):
         trainer.engine.broadcast_state(0)
     else:
         trainer.set_device(opt.gpus, opt.chunk_sizes, opt.device)
-    loader = SyntheticMocoLoader(batch_size=opt.batch_size, seed=opt.seed, device=opt.device, rank=rank, world=world,
-                                 n_crops=max(opt.batch_size * 8, 256))
+    from .datasets.tomo_files import use_files
+    if not use_files(opt):
+        loader = SyntheticMocoLoader(batch_size=opt.batch_size, seed=opt.seed, device=opt.device, rank=rank, world=world,
+                                     n_crops=max(opt.batch_size * 8, 256))
+    else:
+        from .datasets.tomo_files import TomoFileMocoLoader
+        loader = TomoFileMocoLoader(opt, crop=opt.bbox, device=opt.device, rank=rank, world=world)
     log = open(os.path.join(opt.save_dir, "log.txt"), "a") if rank == 0 else None
     for epoch in range(start_epoch + 1, opt.num_epochs + 1):
         np.random.seed(epoch)

@@ -69,6 +69,9 @@ def main(opt):
         trainer.set_device(opt.gpus, opt.chunk_sizes, opt.device)
 
     print("Setting up data...")
+    from .datasets.tomo_files import use_files
+    if use_files(opt):
+        from .datasets.tomo_files import TomoFileSimSiamDataset as Dataset
     dataset = Dataset(opt, "train", (3, opt.bbox, opt.bbox), sigma1=opt.dog, device=opt.device, rank=rank, world=world)
     print("Starting training...")
     for epoch in range(start_epoch + 1, opt.num_epochs + 1):

@@ -27,6 +27,9 @@ def test(opt):
         model = load_model(model, opt.load_model)
     model = model.to(opt.device)
     model.eval()
+    from .datasets.tomo_files import use_files
+    if use_files(opt, "test"):
+        from .datasets.tomo_files import TomoFileSimSiamDataset as Dataset
     dataset = Dataset(opt, "test", (3, opt.bbox, opt.bbox), sigma1=opt.dog, device=opt.device)
     normed = S.to_uint8_normalize(dataset.sub_vols_3d, dataset.mean_subvols3d, dataset.std_subvols3d)
     all_proj, all_pred, all_sub = [], [], []

@@ -101,6 +101,15 @@ def preprocess(mrc, denoise=0, is_tilt=False):
     return out
 
 
+def load_tomos_from_list(names, paths, order="xzy", compress=False, denoise=0, tilt=False):
+    """loader.py:165-173: {name: preprocess(load_rec(path))} - device tensors in [0, 1]."""
+    images = {}
+    for name, path in zip(names, paths):
+        im = load_rec(path, order=order, compress=compress, is_tilt=tilt)
+        images[name] = preprocess(im, denoise=denoise, is_tilt=tilt)
+    return images
+
+
 def cutup(data, blck, strd):
     """loader.py:124-132: sliding windows (a strided view, no copy).  Device tensors and numpy arrays."""
     if isinstance(data, torch.Tensor):

@@ -71,3 +71,70 @@ def test_detector_main_then_test(tmp_path, monkeypatch):
         assert hm.shape == (128, 32, 128) and np.isfinite(hm).all()                 # (H', D, W') as tomo_det.py:60 writes it
         rows = [ln.split("\t") for ln in open(os.path.join(out, name + ".txt")).read().splitlines()]
         assert all(len(r) == 4 for r in rows)
+
+
+def _write_listed_tomograms(tmp_path, shape=(48, 160, 176), n=2):
+    """Two synthetic tomograms as MRC files + the reference's tab-separated image list under <cwd>/data."""
+    from cet_pick_amd.synthetic import make_tomo
+    from cet_pick_amd.utils import mrc
+    data = tmp_path / "data"
+    data.mkdir()
+    lines = ["image_name\trec_path"]
+    vols = {}
+    for i in range(n):
+        vol, _ = make_tomo(shape, seed=500 + i, margin_xy=40, margin_z=12)
+        name = "tomo%d" % i
+        mrc.write(str(data / (name + ".rec")), vol)
+        lines.append("%s\t%s.rec" % (name, name))                  # relative to the list
+        vols[name] = vol
+    (data / "train_images.txt").write_text("\n".join(lines) + "\n")
+    (data / "test_images.txt").write_text("\n".join(lines) + "\n")
+    return vols
+
+
+def test_moco_main_trains_on_mrc_files(tmp_path, monkeypatch):
+    """`--train_img_txt` list of MRC files -> device load_rec / preprocess -> DoG picks -> crop kernel ->
+    the batch contract of the step engine (datasets/tomo_pre_proj_angle_select_new3d_vol.py:29-93,181-239 semantics)."""
+    from cet_pick_amd import moco_main
+    from cet_pick_amd.datasets.tomo_files import TomoFileMocoLoader, read_image_list
+    from cet_pick_amd.opts import opts
+    monkeypatch.chdir(tmp_path)
+    vols = _write_listed_tomograms(tmp_path)
+    args = ["moco", "--arch", "moco3d_18", "--dataset", "simsiam3d", "--order", "zxy", "--batch_size", "8", "--num_epochs", "1",
+            "--lr", "0.01", "--exp_id", "f", "--debug", "0", "--dog", "2.5,5", "--num_iters", "4"]
+    o = opts().parse(args)
+    assert [n for n, _ in read_image_list(os.path.join(o.data_dir, o.train_img_txt))] == ["tomo0", "tomo1"]
+    loader = TomoFileMocoLoader(o, crop=32, device="cuda")
+    assert len(loader.vols) == 2 and tuple(loader.vols[0].shape) == (48, 160, 176) and len(loader) >= 2
+    c = loader.centres
+    assert (c[:, 0] >= 17).all() and (c[:, 0] < 176 - 17).all() and (c[:, 2] >= 17).all() and (c[:, 2] < 48 - 17).all()
+    batch = next(iter(loader))
+    assert batch["input"].shape == batch["input_aug"].shape == (8, 1, 32, 32, 32)
+    x = batch["input"]
+    assert abs(float(x.mean())) < 1e-3 and abs(float(x.flatten(1).std(1).mean()) - 1.0) < 1e-3           # z-normalised crops
+    # the loaded volume is the reference's preprocess() of the file: values on the 8-bit grid in [0, 1]
+    v = loader.vols[0]
+    assert float(v.min()) == 0.0 and float(v.max()) == 1.0
+    moco_main.main(o)
+    save_dir = os.path.join(str(tmp_path), "exp", "moco", "f")
+    line = open(os.path.join(save_dir, "log.txt")).read().strip().split("\n")[-1]
+    assert line.startswith("epoch: 1 |loss ") and np.isfinite(float(line.split("|")[1].split()[1]))
+    assert os.path.exists(os.path.join(save_dir, "model_last_contrastive.pth"))
+
+
+def test_simsiam_main_and_exploration_on_mrc_files(tmp_path, monkeypatch):
+    from cet_pick_amd import simsiam_main, simsiam_test_hm_3d
+    from cet_pick_amd.opts import opts
+    monkeypatch.chdir(tmp_path)
+    _write_listed_tomograms(tmp_path, shape=(40, 200, 200))
+    common = ["simsiam3d", "--arch", "simsiam2d_18", "--dataset", "simsiam3d", "--order", "zxy", "--bbox", "36", "--exp_id", "sf",
+              "--debug", "0", "--dog", "2.5,5"]
+    simsiam_main.main(opts().parse(common + ["--batch_size", "8", "--num_epochs", "1", "--num_iters", "4", "--lr", "0.01"]))
+    save_dir = os.path.join(str(tmp_path), "exp", "simsiam3d", "sf")
+    assert open(os.path.join(save_dir, "log.txt")).read().startswith("epoch: 1 |loss ")
+    out = simsiam_test_hm_3d.test(opts().parse(common + ["--load_model", os.path.join(save_dir, "model_last_contrastive.pth")]))
+    z = np.load(out)
+    n = z["proj"].shape[0]
+    assert n > 8 and set(np.unique(z["name"])) <= {"tomo0", "tomo1"} and z["subvol"].shape == (n, 1, 36, 36)
+    # every pick respects the border rule of load_data (:196): crop // 1.8 = 20 voxels from the x / y edges
+    assert (z["coords"][:, 0] > 20).all() and (z["coords"][:, 0] < 200 - 20).all()
