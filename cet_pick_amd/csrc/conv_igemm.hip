@@ -40,7 +40,7 @@ int mi_stem7_fwd(const float* x, const float* w, float* y, const float* res, int
                  int Co, int bf16x3, void* ws, size_t ws_bytes, hipStream_t s);
 size_t mi_stem7_fwd_workspace_bytes();
 size_t mi_stem7_wgrad_workspace_bytes(int N, int D, int H, int W, int Co);
-int mi_stem7_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Co, void* ws,
+int mi_stem7_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Co, int bf16x3, void* ws,
                    size_t ws_bytes, hipStream_t s);
 
 // conv_direct3.hip: patch-resident direct kernels for the 3^3 / stride 1 convolutions of layer1 (64 -> 64 channels on 8 x 8
@@ -1180,7 +1180,8 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         if (mode == MODE_FWD)
             rc = mi_stem7_fwd(a_src, b_src, out, res, relu, g.N, g.Di, g.Hi, g.Wi, g.Co, conv_arith_bf16x3() ? 1 : 0, ws,
                               ws_bytes, s);
-        else if (mode == MODE_WGRAD) rc = mi_stem7_wgrad(a_src, b_src, out, g.N, g.Di, g.Hi, g.Wi, g.Co, ws, ws_bytes, s);
+        else if (mode == MODE_WGRAD) rc = mi_stem7_wgrad(a_src, b_src, out, g.N, g.Di, g.Hi, g.Wi, g.Co,
+                                                         (conv_arith_bf16x3() && !env_int("MI_STEM_WGRAD_F32")) ? 1 : 0, ws, ws_bytes, s);
         if (rc != MI_E_UNSUPPORTED) return rc;
     }
     // layer1-shaped convolutions (3^3, stride 1, 64 -> 64 channels, 8 x 8 planes): patch-resident direct kernel; the

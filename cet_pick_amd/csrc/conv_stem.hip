@@ -478,6 +478,223 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// WGRAD on the bf16 matrix pipe (round 3), f32-equivalent arithmetic as everywhere (three-way exact bf16 cut of both
+// operands, six products, f32 accumulate).  Same decomposition as stem_wgrad_kernel - rows = taps, columns = channels,
+// reduction = the 128 output voxels of a tile, three tap tiles x two column tiles per wave - but one
+// v_mfma_f32_32x32x16_bf16 contracts 16 voxels: k-step ks = the 8 x-neighbours of the two output rows oy = 2 (ks & 1) + h.
+//   * A fragment (lane = tap, 8 voxels along x): x[2 ox + kx], ox = 0..7 - a stride-2 run of the patch row.  The patch rows
+//     are stored DE-INTERLEAVED (12 even-x entries, then 12 odd-x entries, bf16), so the run is 8 consecutive entries
+//     starting at kx >> 1 of the half kx & 1: five dword reads at lane base + immediate and, for odd starts, four
+//     v_alignbit shifts by 16 (the start differs per lane: the lane IS the tap).
+//   * B fragment (lane = channel, 8 voxels): dy is staged [voxel][32 channels] in bf16 rows and read through the transposing
+//     LDS read, as in direct3_wgrad_kernel.
+// Both operands are cut once per tile while they are staged (the patch by x quads: an even and an odd pair per thread).
+// 288 MFMAs of 32 cycles per tile and wave against 384 of 64 cycles; 72 KB of LDS (two workgroups per CU).
+constexpr int WG_PPLANE = PZ * PY * PROW;                // 8112 bytes: one bf16 plane of the de-interleaved patch
+constexpr int WG_QROW = PW / 4;                          // 6 x-quads per patch row
+constexpr int WG_NQ = PZ * PY * WG_QROW;                 // 1014 quads
+constexpr int WG_NQT = (WG_NQ + 255) / 256;              // 4 per thread
+constexpr int WG_DROW = 64;                              // bytes of a (voxel, 32 channels) bf16 row
+constexpr int WG_DHALF = VOX * WG_DROW;                  // 8192
+constexpr int WG_DPLANE = 2 * WG_DHALF;                  // 16384
+typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4s lds_bf16x4s;
+
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void stem_wgrad_bf3_kernel(StemWgradParams p) {
+    constexpr int ND = VOX * (CO / 8) / 256;             // 4 (voxel, 8 channels) units of dy per thread
+    __shared__ __attribute__((aligned(16))) unsigned char patchb[3 * WG_PPLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char dyb[3 * WG_DPLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31, i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const __amdgpu_buffer_rsrc_t xr = rsrc(p.x, p.x_bytes), dr = rsrc(p.dy, p.dy_bytes);
+    const int txn = p.Wo / TX, tyn = p.Ho / TY, tzn = p.Do / TZ;
+
+    float pv[WG_NQT][4];
+    u32x4 dv[ND][2];
+    // (the patch of the next tile is fetched in front of the current tile's MFMAs, its dy rows behind them: with both in
+    // registers across the k-steps the 256-register budget of two workgroups per CU spills)
+    auto gload_patch = [&](int tile) {                    // tile >= n_tiles: everything reads as zero
+        int b = tile;
+        const bool live = tile < p.n_tiles;
+        const int bx = b % txn; b /= txn;
+        const int by = b % tyn; b /= tyn;
+        const int bz = b % tzn;
+        const int n = b / tzn;
+        const int ox0 = bx * TX, oy0 = by * TY, oz0 = bz * TZ;
+        const int iz0 = oz0 * S2 - P3, iy0 = oy0 * S2 - P3, ix0 = ox0 * S2 - P3;
+#pragma unroll
+        for (int u = 0; u < WG_NQT; ++u) {
+            const int q = tid + u * 256;
+            const int qx = q % WG_QROW, t = q / WG_QROW, py = t % PY, pz = t / PY;
+            const int iz = iz0 + pz, iy = iy0 + py;
+            const bool rok = live & (pz < PZ) & ((unsigned)iz < (unsigned)p.D) & ((unsigned)iy < (unsigned)p.H);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int px = 4 * qx + e, ix = ix0 + px;
+                const bool ok = rok & (px < PX) & ((unsigned)ix < (unsigned)p.W);
+                const unsigned off = ok ? 4u * (unsigned)((((long)n * p.D + iz) * p.H + iy) * p.W + ix) : 0x80000000u;
+                pv[u][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)off, 0, 0));
+            }
+        }
+    };
+    auto gload_dy = [&](int tile) {
+        int b = tile;
+        const bool live = tile < p.n_tiles;
+        const int bx = b % txn; b /= txn;
+        const int by = b % tyn; b /= tyn;
+        const int bz = b % tzn;
+        const int n = b / tzn;
+        const int ox0 = bx * TX, oy0 = by * TY, oz0 = bz * TZ;
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int q = tid + u * 256;
+            const int v = q >> 3, c = (q & 7) * 8;
+            const int ox = ox0 + (v & 7), oy = oy0 + ((v >> 3) & 3), oz = oz0 + (v >> 5);
+            const unsigned off = live ? 4u * (unsigned)(((((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * CO + c)
+                                      : 0x80000000u;
+            dv[u][0] = __builtin_amdgcn_raw_buffer_load_b128(dr, (int)off, 0, 0);
+            dv[u][1] = __builtin_amdgcn_raw_buffer_load_b128(dr, (int)(off + 16u), 0, 0);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int u = 0; u < WG_NQT; ++u) {
+            const int q = tid + u * 256;
+            if (q < WG_NQ) {
+                unsigned c0[4], c1[4], c2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cut3(pv[u][e], c0[e], c1[e], c2[e]);
+                // quad q of its row: even pair -> entries 2 qx, 2 qx + 1 of the even half, odd pair -> of the odd half
+                unsigned char* d = patchb + (q / WG_QROW) * PROW + 4 * (q % WG_QROW);
+                *reinterpret_cast<unsigned*>(d) = c0[0] | (c0[2] << 16);
+                *reinterpret_cast<unsigned*>(d + 24) = c0[1] | (c0[3] << 16);
+                *reinterpret_cast<unsigned*>(d + WG_PPLANE) = c1[0] | (c1[2] << 16);
+                *reinterpret_cast<unsigned*>(d + WG_PPLANE + 24) = c1[1] | (c1[3] << 16);
+                *reinterpret_cast<unsigned*>(d + 2 * WG_PPLANE) = c2[0] | (c2[2] << 16);
+                *reinterpret_cast<unsigned*>(d + 2 * WG_PPLANE + 24) = c2[1] | (c2[3] << 16);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int q = tid + u * 256;
+            const int v = q >> 3, cg = q & 7;
+            unsigned o0[4], o1[4], o2[4];
+            unsigned a0[8], a1[8], a2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cut3(__uint_as_float(dv[u][e >> 2][e & 3]), a0[e], a1[e], a2[e]);
+#pragma unroll
+            for (int d2 = 0; d2 < 4; ++d2) {
+                o0[d2] = a0[2 * d2] | (a0[2 * d2 + 1] << 16);
+                o1[d2] = a1[2 * d2] | (a1[2 * d2 + 1] << 16);
+                o2[d2] = a2[2 * d2] | (a2[2 * d2 + 1] << 16);
+            }
+            unsigned char* d = dyb + (cg >> 2) * WG_DHALF + v * WG_DROW + (cg & 3) * 16;
+            *reinterpret_cast<u32x4*>(d) = u32x4{o0[0], o0[1], o0[2], o0[3]};
+            *reinterpret_cast<u32x4*>(d + WG_DPLANE) = u32x4{o1[0], o1[1], o1[2], o1[3]};
+            *reinterpret_cast<u32x4*>(d + 2 * WG_DPLANE) = u32x4{o2[0], o2[1], o2[2], o2[3]};
+        }
+    };
+
+    // lane constants of this wave's tap tiles: dword-aligned start of the 8-entry run of output row oy = h, and its shift
+    constexpr int MYT = 3;
+    int abase[MYT];
+    unsigned ash[MYT];
+    bool avalid[MYT];
+#pragma unroll
+    for (int i = 0; i < MYT; ++i) {
+        const int tt = wave + 4 * i;
+        const int tap = tt * 32 + l32;
+        avalid[i] = (tt < TAPT) && (tap < NTAP);
+        const int tc = avalid[i] ? tap : 0;
+        const int kz = tc / (K7 * K7), ky = (tc / K7) % K7, kx = tc % K7;
+        const int st = kx >> 1;
+        abase[i] = (kz * PY + ky + S2 * h) * PROW + (kx & 1) * 24 + (st >> 1) * 4;
+        ash[i] = (unsigned)(st & 1) * 16u;
+    }
+    // B fragments: transposing read (this lane names row q4 of its 16-lane group's 4-row block; direct3_wgrad_kernel)
+    const int q4 = i16 >> 2;
+    const int b_base = (8 * h + q4) * WG_DROW + (16 * g16 + 4 * (i16 & 3)) * 2;
+
+    f32x16 acc[MYT][2];
+#pragma unroll
+    for (int i = 0; i < MYT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+
+    const int tile0 = blockIdx.x * p.tiles_per_block;
+    gload_patch(tile0);
+    gload_dy(tile0);
+    for (int it = 0; it < p.tiles_per_block; ++it) {
+        __syncthreads();                                  // every wave is done with the previous tile's LDS
+        lstore();
+        __syncthreads();
+        const int nxt = it + 1 < p.tiles_per_block ? tile0 + it + 1 : p.n_tiles;     // (zeros past the end)
+        gload_patch(nxt);
+        // software pipeline: the fragments of k-step ks + 1 are read (and shifted) while the MFMAs of k-step ks run
+        bf16x8 bf[2][2][3], af[2][MYT][3];
+        auto frags = [&](int ks, int SET) {
+            const int imm = ((S2 * (ks >> 1)) * PY + 2 * S2 * (ks & 1)) * PROW;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const unsigned char* bp = dyb + pl * WG_DPLANE + j * WG_DHALF + b_base + ks * 16 * WG_DROW;
+                    const bf16x4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4s*)(bp));
+                    const bf16x4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4s*)(bp + 4 * WG_DROW));
+                    bf[SET][j][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+            for (int i = 0; i < MYT; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const unsigned char* ap = patchb + pl * WG_PPLANE + abase[i] + imm;
+                    unsigned d[5];
+#pragma unroll
+                    for (int e = 0; e < 5; ++e) d[e] = *reinterpret_cast<const unsigned*>(ap + 4 * e);
+                    u32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_alignbit(d[e + 1], d[e], ash[i]);
+                    // third tap tile: taps 343.. of tile 10 (and wave 3's tile 11) are padding
+                    if (i == MYT - 1 && !avalid[i]) v = u32x4{0u, 0u, 0u, 0u};
+                    af[SET][i][pl] = __builtin_bit_cast(bf16x8, v);
+                }
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < VOX / 16; ++ks) {
+            if (ks + 1 < VOX / 16) frags(ks + 1, (ks + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < MYT; ++i)
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i][PA[pr]], bf[ks & 1][0][PB[pr]], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i][PA[pr]], bf[ks & 1][1][PB[pr]], acc[i][1], 0, 0, 0);
+                }
+        }
+        gload_dy(nxt);
+    }
+    // ---- slab: rows = taps (C/D layout row = (r&3) + 8*(r>>2) + 4*h), cols = channels ----
+    float* slab = p.slabs + (long)blockIdx.x * (TAPT * 32) * CO;
+#pragma unroll
+    for (int i = 0; i < MYT; ++i) {
+        const int tt = wave + 4 * i;
+        if (tt >= TAPT) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tap = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[(long)tap * CO + j * 32 + l32] = acc[i][j][r];
+            }
+    }
+}
+
 // out[g] = sum of slabs [g*group, (g+1)*group) (slab order); two levels keep every pass wide:
 // level 1: grid (22, G) over the workgroup slabs -> G partial slabs, level 2: grid (22, 1) over those -> dW
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* slabs, int n_slabs, int group, float* out,
@@ -539,7 +756,7 @@ size_t mi_stem7_wgrad_workspace_bytes(int N, int D, int H, int W, int Co) {
     return sizeof(float) * (size_t)(stem7_wgrad_blocks(tiles) + RED_GROUPS) * (TAPT * 32) * CO;
 }
 
-int mi_stem7_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Co, void* ws,
+int mi_stem7_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Co, int bf16x3, void* ws,
                    size_t ws_bytes, hipStream_t s) {
     if (Co != CO) return MI_E_UNSUPPORTED;
     const int Do = (D + 2 * P3 - K7) / S2 + 1, Ho = (H + 2 * P3 - K7) / S2 + 1, Wo = (W + 2 * P3 - K7) / S2 + 1;
@@ -552,7 +769,10 @@ int mi_stem7_wgrad(const float* x, const float* dy, float* dw, int N, int D, int
     if (!ws || ws_bytes < mi_stem7_wgrad_workspace_bytes(N, D, H, W, Co)) return MI_E_UNSUPPORTED;   // generic path
     StemWgradParams p = {x, dy, (float*)ws, N, D, H, W, Do, Ho, Wo, (int)tiles, (int)((tiles + blocks - 1) / blocks),
                          (unsigned)xb, (unsigned)yb};
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(blocks), dim3(256), 0, s, p);
+    const char* occ = getenv("MI_STEM_WGRAD_OCC");
+    if (bf16x3 && occ && atoi(occ) == 1) hipLaunchKernelGGL(stem_wgrad_bf3_kernel<1>, dim3(blocks), dim3(256), 0, s, p);
+    else if (bf16x3) hipLaunchKernelGGL(stem_wgrad_bf3_kernel<2>, dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(stem_wgrad_kernel, dim3(blocks), dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     const int rb = (NTAP * CO / 4 + 255) / 256;
     const long slab = (long)(TAPT * 32) * CO;
