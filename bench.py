@@ -151,21 +151,27 @@ def inference_secondary(dev, with_cpu=True, rank=0, world=1):
         e1.record()
         torch.cuda.synchronize()
         eager = e0.elapsed_time(e1) / n
+        # captured: GREPS calls per graph - a replay has a fixed cost of its own (10 - 16 us on this part,
+        # MI355X_MICROARCH.md "graph-replay-floor"), which a 50 us chain replayed one call at a time pays in full (round 2's
+        # "ms_hipgraph > ms_eager" for the decode: eager launches are queued ahead of the GPU, single replays are not)
+        GREPS = 8
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            fn()
+            for _ in range(GREPS):
+                fn()
         g.replay()
         barrier()                              # N > 1: every rank replays its chain in the same window
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         e0.record()
-        for _ in range(n):
+        for _ in range(max(1, n // GREPS)):
             g.replay()
         e1.record()
         torch.cuda.synchronize()
         barrier()
-        wall = (time.perf_counter() - t0) * 1e3 / n
-        return eager, e0.elapsed_time(e1) / n, wall
+        calls = max(1, n // GREPS) * GREPS
+        wall = (time.perf_counter() - t0) * 1e3 / calls
+        return eager, e0.elapsed_time(e1) / calls, wall
 
     def entry(workload, n_vox, timing, kernels, traffic_file):
         eager, graph, wall = timing

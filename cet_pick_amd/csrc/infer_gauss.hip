@@ -175,7 +175,18 @@ struct MarchGeom {
     int outer0, x0;
     long n_cols;
     int out_lo, out_hi;    // outputs [out_lo, out_hi) of the filtered axis are produced (the rest is never read)
+    // up to two word ranges that the launch zeroes on the side (the picker's header and candidate bitmap: the chain then
+    // needs no clearing pass of its own - two fill launches fewer per pick); spread over all threads of the launch
+    unsigned* clr[2];
+    unsigned clr_n[2];
 };
+
+__device__ __forceinline__ void march_clear(const MarchGeom& p, long tid_linear, long n_threads) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (p.clr[k])
+            for (long i = tid_linear; i < (long)p.clr_n[k]; i += n_threads) p.clr[k][i] = 0u;
+}
 
 // RB: radius of the ring (the larger sigma); RA: radius of the second output (DUAL), RA <= RB.
 template <int RB, int RA, bool DUAL>
@@ -238,6 +249,7 @@ template <int RB, int RA>
 __global__ __launch_bounds__(GT) void gauss_march_dual_kernel(const float* in, float* out_a, float* out_b, MarchGeom p,
                                                              SymTaps1<RA> wa, SymTaps1<RB> wb) {
     const long c = (long)blockIdx.x * GT + threadIdx.x;
+    march_clear(p, c, (long)gridDim.x * GT);
     if (c >= p.n_cols) return;
     march_column<RB, RA, true>(in, out_b, out_a, wb, wa, p, c);
 }
@@ -409,14 +421,17 @@ int mi_gauss_radius(float sigma) { return (int)(4.0f * sigma + 0.5f); }
 // Returns MI_E_UNSUPPORTED for radii it is not instantiated for (sigma > 5.1: callers fall back to the tiled kernels).
 // box (may be null = everything): {z0, z1, y0, y1, x0, x1}, the part of the OUTPUT volume that will be read later.
 int mi_launch_gauss_march(const float* in0, float* out0a, float* out0b, float sig0a, float sig0b, const float* in1,
-                          float* out1, float sig1, int D, int H, int W, int axis, hipStream_t s, const int* box) {
+                          float* out1, float sig1, int D, int H, int W, int axis, hipStream_t s, const int* box,
+                          unsigned* clr0, unsigned clr0_n, unsigned* clr1, unsigned clr1_n) {
     if (axis != 0 && axis != 1) return MI_E_ARG;
+    if ((clr0 || clr1) && !out0b) return MI_E_ARG;          // only the dual (one read, two sigmas) launch clears
     const bool dual = out0b != nullptr;
     float smax = sig0a;
     if (dual) smax = std::max(smax, sig0b);
     if (in1) smax = std::max(smax, sig1);
     if (mi_gauss_radius(smax) > 20 || getenv("MI_GAUSS_NO_REGMARCH")) return MI_E_UNSUPPORTED;
     MarchGeom g = {};
+    g.clr[0] = clr0; g.clr_n[0] = clr0_n; g.clr[1] = clr1; g.clr_n[1] = clr1_n;
     const int full[6] = {0, D, 0, H, 0, W};
     const int* bx = box ? box : full;
     if (bx[0] < 0 || bx[1] > D || bx[2] < 0 || bx[3] > H || bx[4] < 0 || bx[5] > W || bx[0] >= bx[1] || bx[2] >= bx[3] ||
@@ -459,7 +474,7 @@ int mi_launch_gauss_march(const float* in0, float* out0a, float* out0b, float si
     if (!in1) { MI_R4(launch_march_single, ra, in0, out0a, g, sig0a, s) }
     const int r1 = march_radius_class(mi_gauss_radius(sig1));
     if (ra > r1)          // instantiated for R0 <= R1 only: the two jobs are independent, swap them
-        return mi_launch_gauss_march(in1, out1, nullptr, sig1, 0.f, in0, out0a, sig0a, D, H, W, axis, s, box);
+        return mi_launch_gauss_march(in1, out1, nullptr, sig1, 0.f, in0, out0a, sig0a, D, H, W, axis, s, box, nullptr, 0, nullptr, 0);
 #define MI_TWO(R0)                                                                                   \
     switch (r1) {                                                                                    \
         case 8: if (R0 <= 8) return launch_march_two<(R0 <= 8 ? R0 : 8), 8>(in0, out0a, sig0a, in1, out1, sig1, g, s);      \
@@ -523,7 +538,7 @@ extern "C" int mi_gauss3d_sep(const float* in, float* out, float* tmp, int D, in
         // z: in -> out, y: out -> tmp, x: tmp -> out   (one read + one write of the volume per pass; z and y
         // through the marching kernel when its radius fits)
         auto strided = [&](const float* a, float* b, int axis) -> int {
-            int r2 = mi_launch_gauss_march(a, b, nullptr, sigma, 0.f, nullptr, nullptr, 0.f, D, H, W, axis, s, nullptr);
+            int r2 = mi_launch_gauss_march(a, b, nullptr, sigma, 0.f, nullptr, nullptr, 0.f, D, H, W, axis, s, nullptr, nullptr, 0, nullptr, 0);
             return r2 == MI_E_UNSUPPORTED ? mi_launch_gauss_axis(a, b, D, H, W, axis, sigma, s) : r2;
         };
         if ((rc = strided(in, out, 0))) return rc;

@@ -18,7 +18,8 @@
 int mi_launch_gauss_axis(const float* in, float* out, int D, int H, int W, int axis, float sigma,
                          hipStream_t s);
 int mi_launch_gauss_march(const float* in0, float* out0a, float* out0b, float sig0a, float sig0b, const float* in1,
-                          float* out1, float sig1, int D, int H, int W, int axis, hipStream_t s, const int* box = nullptr);
+                          float* out1, float sig1, int D, int H, int W, int axis, hipStream_t s, const int* box = nullptr,
+                          unsigned* clr0 = nullptr, unsigned clr0_n = 0, unsigned* clr1 = nullptr, unsigned clr1_n = 0);
 int mi_gauss_radius(float sigma);
 
 namespace {
@@ -795,7 +796,16 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
     DogWs w;
     dog_ws_layout(D, H, W, &w, (char*)workspace);
     GreedyWs& gw = w.gw;
-    MI_HIP(hipMemsetAsync(gw.hdr, 0, sizeof(GreedyHeader), s));
+    // The fused two-sigma chain clears the header and the candidate bitmap inside its first launch (the z pass: a few words
+    // per thread next to 0.8 GB of traffic); every other chain clears them with two fill passes here.
+    const unsigned bits_words = (unsigned)((n_vox + 31) / 32 + 2);
+    const bool no_march0 = getenv("MI_GAUSS_NO_MARCH") != nullptr;
+    const int bxy0 = (H > 512 && W > 512) ? 60 : 30;
+    const bool fused_chain = n_sigmas == 2 && !no_march0 && sigmas_host[0] <= sigmas_host[1] &&
+                             mi_dogx_usable(w.tmp, w.heat, heat_out, D, H, W, sigmas_host[0], sigmas_host[1], k) &&
+                             (bxy0 >= mi_gauss_radius(sigmas_host[1]) || W > 2 * mi_gauss_radius(sigmas_host[1])) &&
+                             mi_gauss_radius(sigmas_host[1]) <= 20 && !getenv("MI_GAUSS_NO_REGMARCH");
+    if (!fused_chain) MI_HIP(hipMemsetAsync(gw.hdr, 0, sizeof(GreedyHeader), s));
 
     // utils/image.py:141-143: 30-voxel xy border, doubled when both H and W exceed 512
     int bxy = (H > 512 && W > 512) ? 60 : 30;
@@ -854,8 +864,11 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
             const int bz_[6] = {z0, z1, ylo, yhi, 0, W}, by_[6] = {z0, z1, bxy, H - bxy, 0, W};
             for (int i = 0; i < 6; ++i) { boxz[i] = bz_[i]; boxy[i] = by_[i]; }
         }
-        rc = sa <= sb ? mi_launch_gauss_march(rec, w.g[0], w.g[1], sa, sb, nullptr, nullptr, 0.f, D, H, W, 0, s, boxz)
+        rc = sa <= sb ? mi_launch_gauss_march(rec, w.g[0], w.g[1], sa, sb, nullptr, nullptr, 0.f, D, H, W, 0, s, boxz,
+                                              fused_chain ? reinterpret_cast<unsigned*>(gw.hdr) : nullptr,
+                                              (unsigned)(sizeof(GreedyHeader) / 4), fused_chain ? gw.bits : nullptr, bits_words)
                       : mi_launch_gauss_march(rec, w.g[0], nullptr, sa, 0.f, rec, w.g[1], sb, D, H, W, 0, s, boxz);
+        if (rc == MI_E_UNSUPPORTED && fused_chain) return MI_E_ARG;          // (fused_chain implies the dual launch exists)
         if (rc == MI_OK) rc = mi_launch_gauss_march(w.g[0], w.tmp, nullptr, sa, 0.f, w.g[1], w.heat, sb, D, H, W, 1, s, boxy);
         if (rc == MI_OK) {
             DogxParams q = {};
@@ -867,7 +880,7 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
             MI_RETURN_IF_LAUNCH_FAILED();
             gw.map = reinterpret_cast<int*>(w.g[0]);              // both z-pass outputs are consumed
             gw.vmap = reinterpret_cast<unsigned*>(w.g[1]); gw.vol = nullptr;
-            MI_HIP(hipMemsetAsync(gw.bits, 0, sizeof(unsigned) * ((n_vox + 31) / 32 + 2), s));
+            if (!fused_chain) MI_HIP(hipMemsetAsync(gw.bits, 0, sizeof(unsigned) * bits_words, s));
             const unsigned fb = std::min<unsigned>((w.xg.n_seg + 7) / 8, 1024u);
             hipLaunchKernelGGL(cand_filter_seg_kernel, dim3(fb), dim3(256), 0, s, w.cands, w.seg_count, w.xg.n_seg,
                                w.xg.seg_cap, gw.hdr, gw.G, gw.map, gw.vmap, gw.bits, gw.cap);

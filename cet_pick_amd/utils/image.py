@@ -99,8 +99,8 @@ def dog_pick(rec, sigmas, kernel=3, border_z=10, nms_d=14, max_out=None, return_
         max_out = min(D * H * W // 4 + 1024, 1 << 17)   # picks are >= d apart: 128 Ki covers a 512x512x512 volume at d=14
     scores = torch.empty((max_out,), dtype=torch.float32, device=v.device)
     coords = torch.empty((max_out, 3), dtype=torch.int32, device=v.device)
-    n = torch.zeros((1,), dtype=torch.int32, device=v.device)
-    cutoff = torch.zeros((1,), dtype=torch.float32, device=v.device)
+    n = torch.empty((1,), dtype=torch.int32, device=v.device)          # (both written by the chain on every path: the pick
+    cutoff = torch.empty((1,), dtype=torch.float32, device=v.device)   # count / overflow code and the threshold)
     heat = torch.empty_like(v) if return_heat else None
     sig = (ctypes.c_float * len(sigmas))(*[float(s) for s in sigmas])
     L.check(lib.mi_dog_pick(L.ptr(v), D, H, W, ctypes.cast(sig, ctypes.c_void_p), len(sigmas),
