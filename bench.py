@@ -113,6 +113,13 @@ def _traffic(fname, kernels):
     if d.get("source_sha16") != source_sha16(d.get("source_prefixes")):
         return None, "stale: %s was measured on sources %s" % (fname, d.get("source_sha16"))
     tot = 0.0
+    if isinstance(kernels, tuple):
+        # ("not", prefix, ...): EVERY kernel of the profiled run whose name starts with none of the prefixes, each with the
+        # launches per call the summary recorded - the whole chain, fills and tail included
+        for name, v in d["kernels"].items():
+            if not name.startswith(kernels[1:]) and "hbm_bytes_per_launch" in v:
+                tot += v["hbm_bytes_per_launch"] * v.get("launches_per_step", 1.0)
+        return tot, "PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, every launch of the chain, profiles/%s" % fname
     for k in kernels:
         hit = [v for name, v in d["kernels"].items() if name.startswith(k) and "hbm_bytes_per_launch" in v]
         if not hit:
@@ -251,8 +258,8 @@ def inference_secondary(dev, with_cpu=True, rank=0, world=1):
 
 # PMC traffic summary of the inference chains (tools/pmc_run.sh + tools/pmc_summary.py) and the kernels of the picker's
 # chain that it is summed over - EVERY launch of the call, not only the Gaussians
-INFER_TRAFFIC = "r02_infer_traffic.json"
-DOG_KERNELS = {"gauss_march_dual_kernel": 1, "gauss_march_two_kernel": 1, "dogx_nms_kernel": 1}
+INFER_TRAFFIC = "r03_infer_traffic.json"
+DOG_KERNELS = ("not", "peak3_", "topk_", "zero_header", "nms_march")      # = everything the picker launches
 
 T_START = time.perf_counter()
 
@@ -458,7 +465,7 @@ def main():
                        "hipgraph": bool(engine.use_graph), "final_loss": final_loss},
             "step_graph_nodes": step_nodes,
             "step_mfma_frac_of_peak": value / world * FLOP_PER_SUBTOMO / 1e12 / peak,
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel + stem_fwd/stem_wgrad_kernel (fwd/dgrad/wgrad, all 75 conv launches of a step)",
+            "roofline": {"bound": "mfma", "kernel": "the conv family: direct3 / direct3s / direct3_wgrad / cube2 / pair_wgrad / stem_fwd_bf3 / stem_wgrad_bf3 / conv_igemm (+ split-K reduces): all 75 conv calls of a step, forward / data gradient / weight gradient",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
                          "peak_note": ("peak = the pipe the kernel runs on: the bf16x3 arithmetic executes 6 bf16 MFMA "
@@ -473,21 +480,21 @@ def main():
                                      for t, v in sorted(by.items())},
                          "measured": "per conv call of 3 eager steps after the timed region: 8 back-to-back launches of the "
                                      "call (kernel + its split-K reduce) between two HIP events on the launch stream; "
-                                     "compare profiles/r02_train_kernel_stats.csv"},
+                                     "compare profiles/r03_train_kernel_stats.csv"},
         }
         # HBM traffic of the conv kernels from PMC counters (tools/pmc_run.sh + tools/pmc_summary.py: separate rocprofv3
         # --pmc passes of this workload; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), per conv call.
         # The summary carries the hash of the kernel sources it was measured on: a stale one is not quoted.
-        tpath = os.path.join(REPO, "profiles", "r02_conv_traffic.json")
+        tpath = os.path.join(REPO, "profiles", "r03_conv_traffic.json")
         if os.path.exists(tpath):
             from cet_pick_amd.build import source_sha16
             tj = json.load(open(tpath))
             if tj.get("source_sha16") == source_sha16(tj.get("source_prefixes")):
                 out["roofline"]["traffic"] = tj["hbm_bytes_per_step"] / (n_launch // 3)
-                out["roofline"]["traffic_note"] = ("bytes per conv call (%d per step), profiles/r02_conv_traffic.json"
+                out["roofline"]["traffic_note"] = ("bytes per conv call (%d per step), profiles/r03_conv_traffic.json"
                                                    % (n_launch // 3))
             else:
-                out["roofline"]["traffic_note"] = "stale: profiles/r02_conv_traffic.json was measured on other kernel sources"
+                out["roofline"]["traffic_note"] = "stale: profiles/r03_conv_traffic.json was measured on other kernel sources"
         if f32_ms is not None:
             out["f32_mfma_step"] = {"ms_per_step": f32_ms, "value": B / (f32_ms * 1e-3),
                                     "note": "the same step with MI_CONV_ARITH=f32 (v_mfma_f32_32x32x2_f32 in the generic kernel)"}
