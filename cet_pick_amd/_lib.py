@@ -108,6 +108,9 @@ SIGNATURES = {
     "mi_ce_label0": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "mi_ce_label0_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "mi_ce_label0_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "mi_conv3d_s2_dgrad_usable": (_I, [_I, _I, _I, _I]),
+    "mi_conv3d_s2_dgrad_workspace_bytes": (_Z, [_I, _I]),
+    "mi_conv3d_s2_dgrad_f32": (_I, [_P] * 7 + [_I, _I, _I, _I, _P, _Z, _P]),
     "mi_ema_update": (_I, [_P, _P, _F, _L, _P]),
     "mi_sgd_step": (_I, [_P, _P, _P, _F, _F, _F, _L, _P]),
     "mi_queue_enqueue": (_I, [_P, _P, _P, _I, _I, _I, _P]),

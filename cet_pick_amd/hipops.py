@@ -343,6 +343,27 @@ def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None, dil=None):
     return dx
 
 
+def conv_dgrad_s2_block(dh, d2, w, w_ds, in_shape, res=None, mask=None):
+    """Data gradient of a BasicBlock's stride-2 front in ONE launch (csrc/conv_s2.hip): conv_dgrad(dh; w, 3x3x3 stride 2 pad 1)
+    + conv_dgrad(d2; w_ds, 1x1 stride 2) (+ res), times (mask > 0).  Returns None when the shape is not one of the encoder's two
+    (the caller then runs the two generic launches)."""
+    n, g, _, _, ci = in_shape
+    co = w.shape[0]
+    lib = L.lib()
+    if PROFILE is not None or not dh.is_cuda or not lib.mi_conv3d_s2_dgrad_usable(n, g, ci, co):
+        return None
+    if in_shape[1] != in_shape[2] or in_shape[2] != in_shape[3] or not (_phys_ok(w) and (w_ds is None or _phys_ok(w_ds))):
+        return None
+    _f32c(dh, "dh")
+    if d2 is not None:
+        _f32c(d2, "d2")
+    dx = torch.empty(tuple(in_shape), dtype=torch.float32, device=dh.device)
+    ws = _ws(lib.mi_conv3d_s2_dgrad_workspace_bytes(ci, co), dh.device, "conv_s2")
+    L.check(lib.mi_conv3d_s2_dgrad_f32(L.ptr(dh), L.ptr(d2), L.ptr(w), L.ptr(w_ds), L.ptr(dx), L.ptr(res), L.ptr(mask), n, g, ci, co,
+                                       L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_s2_dgrad_f32")
+    return dx
+
+
 # Deferred split-K reduction of the weight gradients: while DEFERRED_WGRADS is a list (MocoStepEngine sets it around the
 # backward pass), every wgrad launch leaves its slabs in a slab buffer of its own and registers (slabs, target, splits,
 # elements) here; flush_wgrad_reduces() sums them all in one launch (one per gradient bucket under data parallelism)
@@ -1006,8 +1027,11 @@ class _BasicBlockFn(torch.autograd.Function):
             if ds[0].weight.requires_grad:
                 conv_wgrad_into(x, d2, ds[0].weight, 1, s, 0)
             if ctx.x_needs_grad:
-                dres = conv_dgrad(d2, ds[0].weight, x.shape, 1, s, 0)
-                dx = conv_dgrad(dh, blk.conv1.weight, x.shape, 3, s, 1, dres, xmask)
+                # stride-2 block front: both data gradients (+ the ReLU mask) in one launch where the shape is the encoder's
+                dx = conv_dgrad_s2_block(dh, d2, blk.conv1.weight, ds[0].weight, x.shape, None, xmask) if s == 2 else None
+                if dx is None:
+                    dres = conv_dgrad(d2, ds[0].weight, x.shape, 1, s, 0)
+                    dx = conv_dgrad(dh, blk.conv1.weight, x.shape, 3, s, 1, dres, xmask)
         elif ctx.x_needs_grad:
             dx = conv_dgrad(dh, blk.conv1.weight, x.shape, 3, s, 1, d2, xmask)   # + identity branch fused
         return dx, None, None, None, None, None, None

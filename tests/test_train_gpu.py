@@ -154,6 +154,40 @@ def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
         assert float((out["direct"][i] - out["igemm"][i]).abs().max()) / scale < 2e-6
 
 
+@pytest.mark.parametrize("n,gi,ci,co,with_ds", [(3, 8, 64, 128, True), (64, 8, 64, 128, True), (2, 8, 64, 128, False),
+                                                  (5, 4, 128, 256, True), (70, 4, 128, 256, True), (4, 4, 128, 256, False)])
+def test_s2_block_dgrad_matches_generic_and_float64(n, gi, ci, co, with_ds):
+    """csrc/conv_s2.hip: the data gradient of a BasicBlock's stride-2 front (3^3 stride-2 convolution + 1x1 stride-2 shortcut,
+    ReLU mask of the input) in one launch, against the two generic launches and against torch in float64; ragged batches
+    (layer3's workgroups hold four samples) and the variant without a shortcut."""
+    from cet_pick_amd import hipops as H
+    from conftest import f32_equivalent
+    g = torch.Generator().manual_seed(n + gi + co)
+    go = gi // 2
+    param, w = make_w(co, ci, 3, g)
+    pds, wds = make_w(co, ci, 1, g)
+    dh = torch.randn(n, co, go, go, go, generator=g) * torch.exp(torch.randn(n, co, go, go, go, generator=g))
+    d2 = torch.randn(n, co, go, go, go, generator=g)
+    mask = torch.randn(n, ci, gi, gi, gi, generator=g)
+    res = torch.randn(n, ci, gi, gi, gi, generator=g)
+    def ref(dt):
+        x = torch.zeros(n, ci, gi, gi, gi, dtype=dt, requires_grad=True)
+        y = F.conv3d(x, w.to(dt), stride=2, padding=1)
+        gx = torch.autograd.grad(y, x, dh.to(dt))[0]
+        if with_ds:
+            x2 = torch.zeros(n, ci, gi, gi, gi, dtype=dt, requires_grad=True)
+            gx = gx + torch.autograd.grad(F.conv3d(x2, wds.to(dt), stride=2), x2, d2.to(dt))[0]
+        return ((gx + res.to(dt)) * (mask > 0)).permute(0, 2, 3, 4, 1)
+    r64, r32 = ref(torch.float64), ref(torch.float32)
+    got = H.conv_dgrad_s2_block(cl(dh), cl(d2) if with_ds else None, param, pds if with_ds else None, (n, gi, gi, gi, ci), cl(res), cl(mask))
+    assert got is not None
+    f32_equivalent(got.cpu().numpy(), r32.numpy(), r64.numpy(), what="s2 block dgrad")
+    # the two generic launches
+    dres = H.conv_dgrad(cl(d2), pds, (n, gi, gi, gi, ci), 1, 2, 0, cl(res)) if with_ds else cl(res)
+    gen = H.conv_dgrad(cl(dh), param, (n, gi, gi, gi, ci), 3, 2, 1, dres, cl(mask))
+    assert float((got - gen).abs().max()) / float(r64.abs().max()) < 2e-6
+
+
 @pytest.mark.parametrize("shape", [(4, 16, 16, 16, 64), (8, 2, 2, 2, 256), (64, 128), (6, 3, 5, 7, 32)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_batchnorm_train_fwd_bwd(shape, relu):
