@@ -350,7 +350,7 @@ def conv_dgrad_s2_block(dh, d2, w, w_ds, in_shape, res=None, mask=None):
     n, g, _, _, ci = in_shape
     co = w.shape[0]
     lib = L.lib()
-    if PROFILE is not None or not dh.is_cuda or not lib.mi_conv3d_s2_dgrad_usable(n, g, ci, co):
+    if not dh.is_cuda or not lib.mi_conv3d_s2_dgrad_usable(n, g, ci, co):
         return None
     if in_shape[1] != in_shape[2] or in_shape[2] != in_shape[3] or not (_phys_ok(w) and (w_ds is None or _phys_ok(w_ds))):
         return None
@@ -359,8 +359,11 @@ def conv_dgrad_s2_block(dh, d2, w, w_ds, in_shape, res=None, mask=None):
         _f32c(d2, "d2")
     dx = torch.empty(tuple(in_shape), dtype=torch.float32, device=dh.device)
     ws = _ws(lib.mi_conv3d_s2_dgrad_workspace_bytes(ci, co), dh.device, "conv_s2")
-    L.check(lib.mi_conv3d_s2_dgrad_f32(L.ptr(dh), L.ptr(d2), L.ptr(w), L.ptr(w_ds), L.ptr(dx), L.ptr(res), L.ptr(mask), n, g, ci, co,
-                                       L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_s2_dgrad_f32")
+    def call():
+        return L.check(lib.mi_conv3d_s2_dgrad_f32(L.ptr(dh), L.ptr(d2), L.ptr(w), L.ptr(w_ds), L.ptr(dx), L.ptr(res), L.ptr(mask), n, g,
+                                                  ci, co, L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_s2_dgrad_f32")
+    # algorithmic FLOPs of both convolutions the launch replaces (27 taps + the 1x1 shortcut)
+    _prof_run("dgrad", 2.0 * dh.numel() * ci * (27 + (1 if d2 is not None else 0)), call)
     return dx
 
 
