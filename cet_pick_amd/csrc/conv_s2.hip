@@ -85,8 +85,8 @@ struct S2DgradParams {
 // Eight waves: RBK row blocks x CBW column blocks x KW parts of a tap's k-steps (k-step ks belongs to part ks % KW; the parts
 // meet in LDS at the end).  A workgroup's time is its chain of MFMAs - the all-odd class has 8 taps - so the chain is cut KW
 // ways, and layer3 (32 rows per workgroup) spreads its 128 output channels over two workgroups to reach 256 of them.
-template <int G, int CR, int CN, int CBW, int KW>
-__global__ __launch_bounds__(512, 2) void s2_dgrad_kernel(S2DgradParams p) {
+template <int G, int CR, int CN, int CBW, int KW, int RING, int OCC>
+__global__ __launch_bounds__(512, OCC) void s2_dgrad_kernel(S2DgradParams p) {
     constexpr int VO = G * G * G;                       // voxels of a dH sample
     constexpr int RBK = VO >= 32 ? VO / 32 : 1;         // row blocks of a workgroup
     constexpr int NV = 32 * RBK;                        // patch records: one sample (layer2) / 32 / VO samples (layer3)
@@ -95,8 +95,8 @@ __global__ __launch_bounds__(512, 2) void s2_dgrad_kernel(S2DgradParams p) {
     static_assert(RBK * CBW * KW == 8, "eight waves");
     constexpr int KS = CR / 16;                         // k-steps per tap
     constexpr int SPT = KS / KW;                        // ... of one wave
-    static_assert(SPT == 4, "two taps per ring round");
-    constexpr int RING = 8;                             // weight fragments in flight per wave: two taps' worth
+    static_assert(SPT == 4 && (RING == 4 || RING == 8), "one or two taps per ring round");
+    constexpr int TPR = RING / SPT;                     // taps per ring round (RING weight fragments in flight per wave)
     constexpr int ARR = (NV + 16) * 16;                 // one (k-step, plane, k-half) array: records + 16 zero records
     constexpr int LDS_BYTES = KS * 6 * ARR;
     constexpr int WSTEP = CB * 3 * S2_WBLK;             // bytes per k-step of the image
@@ -165,11 +165,11 @@ __global__ __launch_bounds__(512, 2) void s2_dgrad_kernel(S2DgradParams p) {
             case 0: wload(rs, so, std::integral_constant<int, 0>{}); break;
             case 1: wload(rs, so, std::integral_constant<int, 1>{}); break;
             case 2: wload(rs, so, std::integral_constant<int, 2>{}); break;
-            case 3: wload(rs, so, std::integral_constant<int, 3>{}); break;
-            case 4: wload(rs, so, std::integral_constant<int, 4>{}); break;
-            case 5: wload(rs, so, std::integral_constant<int, 5>{}); break;
-            case 6: wload(rs, so, std::integral_constant<int, 6>{}); break;
-            default: wload(rs, so, std::integral_constant<int, 7>{}); break;
+            case 3: wload(rs, so, std::integral_constant<int, 3 % RING>{}); break;
+            case 4: wload(rs, so, std::integral_constant<int, 4 % RING>{}); break;
+            case 5: wload(rs, so, std::integral_constant<int, 5 % RING>{}); break;
+            case 6: wload(rs, so, std::integral_constant<int, 6 % RING>{}); break;
+            default: wload(rs, so, std::integral_constant<int, 7 % RING>{}); break;
         }
     };
     const unsigned tap_bytes = (unsigned)KS * WSTEP;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void s2_dgrad_kernel(S2DgradParams p) {
         for (int g = 0; g < RING - 1; ++g) wload_dyn(rs, woff(base, g, n_t), g);
         for (int s0 = 0; s0 < n_t * SPT; s0 += RING) {
             const int j0 = s0 / SPT;
-            const int sel0 = plain ? vaddr : sel_of(j0, n_t), sel1 = plain ? zaddr : sel_of(j0 + 1, n_t);
+            const int sel0 = plain ? vaddr : sel_of(j0, n_t), sel1 = (plain || TPR == 1) ? zaddr : sel_of(j0 + 1, n_t);
 #pragma unroll
             for (int u = 0; u < RING; ++u) {
                 wload_dyn(rs, woff(base, s0 + u + RING - 1, n_t), (u + RING - 1) % RING);
@@ -342,10 +342,14 @@ extern "C" int mi_conv3d_s2_dgrad_f32(const float* dh, const float* dout, const 
     MI_RETURN_IF_LAUNCH_FAILED();
     if (G == 4) {
         p.n_groups = N;
-        hipLaunchKernelGGL((s2_dgrad_kernel<4, 128, 64, 2, 2>), dim3((unsigned)(N * 8), 1), dim3(512), 0, s, p);
+        const char* rg = getenv("MI_S2_RING");
+        if (rg && atoi(rg) == 8) hipLaunchKernelGGL((s2_dgrad_kernel<4, 128, 64, 2, 2, 8, 2>), dim3((unsigned)(N * 8), 1), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((s2_dgrad_kernel<4, 128, 64, 2, 2, 4, 4>), dim3((unsigned)(N * 8), 1), dim3(512), 0, s, p);
     } else {
         p.n_groups = (N + 3) / 4;
-        hipLaunchKernelGGL((s2_dgrad_kernel<2, 256, 128, 2, 4>), dim3((unsigned)(p.n_groups * 8), 2), dim3(512), 0, s, p);
+        const char* rg = getenv("MI_S2_RING");
+        if (rg && atoi(rg) == 4) hipLaunchKernelGGL((s2_dgrad_kernel<2, 256, 128, 2, 4, 4, 4>), dim3((unsigned)(p.n_groups * 8), 2), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((s2_dgrad_kernel<2, 256, 128, 2, 4, 8, 2>), dim3((unsigned)(p.n_groups * 8), 2), dim3(512), 0, s, p);
     }
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
