@@ -2,7 +2,7 @@
 #include "common.h"
 #include <cstdlib>
 
-extern "C" int mi_abi_version(void) { return 2; }
+extern "C" int mi_abi_version(void) { return 3; }
 extern "C" const char* mi_build_arch(void) { return "gfx950"; }
 
 // Nodes of a captured hipGraph by type (measurement aid: launches per replayed step).  counts[0..3] = kernel, memcpy,
