@@ -18,6 +18,7 @@ _P, _I, _F, _Z, _D, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_do
 SIGNATURES = {
     "mi_abi_version": (_I, []),
     "mi_graph_node_counts": (_I, [_P, _P]),
+    "mi_debug_stamp": (_I, [_P, _P]),
     "mi_build_arch": (_c.c_char_p, []),
     "mi_sigmoid_clamp": (_I, [_P, _P, _Z, _P]),
     "mi_nms3d": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

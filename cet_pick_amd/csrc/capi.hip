@@ -28,3 +28,13 @@ extern "C" int mi_graph_node_counts(void* graph, int* counts) {
     free(nodes);
     return e == hipSuccess ? MI_OK : (int)e;
 }
+
+// Measurement aid: one thread writes the constant-rate (100 MHz) wall clock into *slot.  A launch of its own, so that it
+// can be recorded into a captured step at the points whose time is asked for (tools/stamp_step.py).
+__global__ void debug_stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+
+extern "C" int mi_debug_stamp(void* slot, mi_stream_t stream) {
+    if (!slot) return MI_E_ARG;
+    hipLaunchKernelGGL(debug_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)slot);
+    return (int)hipGetLastError();
+}

@@ -9,6 +9,7 @@ the model was flattened by :class:`ParamArena`): a parameter whose ``.grad`` is 
 gradient assigned, otherwise it is accumulated - the same contract as torch's AccumulateGrad.
 PyTorch is the allocator / stream owner; all arithmetic happens in the HIP kernels.
 """
+import os
 import torch
 import torch.nn as nn
 
@@ -31,6 +32,21 @@ def _prof_run(tag, flops, fn):
             fn()
         e1.record()
         PROFILE.append((tag, flops, e0, e1, PROFILE_REPEAT))
+
+
+STAMPS = None           # tools/stamp_step.py: (device int64 buffer, [names]) - wall-clock stamps recorded into the step
+
+
+def stamp(name):
+    """Measurement aid: a one-thread launch on the current stream that writes the 100 MHz wall clock; a no-op unless
+    tools/stamp_step.py armed it.  Recorded into a captured step it times the step's phases WITHOUT a profiler attached."""
+    if STAMPS is None:
+        return
+    buf, names = STAMPS
+    if len(names) >= buf.numel():
+        raise L.HipExtensionError("stamp buffer full")
+    L.check(L.lib().mi_debug_stamp(buf.data_ptr() + 8 * len(names), L.stream()), "mi_debug_stamp")
+    names.append(name)
 
 
 def _ws(nbytes, device, tag):
@@ -391,6 +407,23 @@ def flush_wgrad_reduces():
     del items[:]
 
 
+# Weight gradients of the small layers on a side stream: while SIDE_WGRADS is a list (MocoStepEngine sets it around the
+# backward pass), the weight-gradient launches of layers with at most SIDE_ROWS_MAX output rows (everything but the stem at
+# the encoder's shapes) are not issued where autograd reaches them but collected here; the engine issues a whole stage's worth
+# on ONE fork of a side stream when the data-gradient chain leaves the stage: layer3's and the head's next to layer2's
+# data gradients, layer2's next to layer1's, layer1's next to the HBM-bound stem chain.  One cross-stream edge per stage - an
+# edge per launch costs more than it returns (r03_experiments.txt items 6 and 9).
+SIDE_WGRADS = None
+SIDE_ROWS_MAX = int(os.environ.get("CETPICK_SIDE_ROWS", "32768"))
+
+
+def _side_or_now(fn, rows):
+    if SIDE_WGRADS is not None and rows <= SIDE_ROWS_MAX and PROFILE is None:
+        SIDE_WGRADS.append(fn)
+    else:
+        fn()
+
+
 def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
     """dW for `param`, written (or accumulated) into param.grad."""
     nd5 = x.dim() == 5
@@ -411,12 +444,14 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
                 param._mi_slabs = slab
             # (pinned: a captured hipGraph writes and reads the old buffer on every replay - MocoStepEngine pins the slabs
             # when it captures; an eager call that needs more space gets a buffer of its own and the graph's stays alive)
-        splits = ctypes.c_int(0)
-        L.check(lib.mi_convnd_wgrad_slabs_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, *k3, stride, *p3,
-                                              L.ptr(slab), slab.numel(), ctypes.addressof(splits), L.stream()),
-                "mi_convnd_wgrad_slabs_f32")
-        if splits.value > 1:
-            DEFERRED_WGRADS.append((slab, tgt, int(splits.value), tgt.numel()))
+        def launch():
+            splits = ctypes.c_int(0)
+            L.check(lib.mi_convnd_wgrad_slabs_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, *k3, stride, *p3,
+                                                  L.ptr(slab), slab.numel(), ctypes.addressof(splits), L.stream()),
+                    "mi_convnd_wgrad_slabs_f32")
+            if splits.value > 1:
+                DEFERRED_WGRADS.append((slab, tgt, int(splits.value), tgt.numel()))
+        _side_or_now(launch, dy.numel() // co)
         return
     if dil is not None and tuple(_k3(dil, nd5)) != (1, 1, 1):
         d3 = _k3(dil, nd5)
@@ -556,11 +591,13 @@ class _LinearFn(torch.autograd.Function):
         if mod.weight.requires_grad:
             g, acc = _grad_target(mod.weight)
             tgt = torch.empty_like(g) if acc else g
-            ws = _ws(lib.mi_conv3d_workspace_bytes(m, 1, 1, 1, ci, co, 1, 1, 0), x.device, "conv")
-            L.check(lib.mi_conv3d_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), m, 1, 1, 1, ci, co, 1, 1, 0,
-                                            L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_wgrad_f32")
-            if acc:
-                g.add_(tgt)
+            def launch(g=g, acc=acc, tgt=tgt):          # (bound now: the names are reused for the bias below)
+                ws = _ws(lib.mi_conv3d_workspace_bytes(m, 1, 1, 1, ci, co, 1, 1, 0), x.device, "conv")
+                L.check(lib.mi_conv3d_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), m, 1, 1, 1, ci, co, 1, 1, 0,
+                                                L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_wgrad_f32")
+                if acc:
+                    g.add_(tgt)
+            _side_or_now(launch, m)
         if mod.bias is not None and mod.bias.requires_grad:
             g, acc = _grad_target(mod.bias)
             tgt = torch.empty_like(g) if acc else g

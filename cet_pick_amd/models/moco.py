@@ -99,9 +99,13 @@ class MoCo(nn.Module):
             cur = torch.cuda.current_stream()
             self._side.wait_stream(cur)                    # inputs and last step's SGD are ordered before it
             with torch.cuda.stream(self._side):
+                H.stamp("k:start")
                 k_raw = self._key_branch(im_k)
+                H.stamp("k:end")
             q_raw = self.encoder_q(im_q)[0]["proj"]
+            H.stamp("q:end")
             cur.wait_stream(self._side)
+            H.stamp("joined")
             k_raw.record_stream(cur)
         else:
             q_raw = self.encoder_q(im_q)[0]["proj"]

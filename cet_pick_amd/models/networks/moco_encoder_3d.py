@@ -106,7 +106,9 @@ class TomoResClassifier3D(nn.Module):
         x = x1.contiguous().float().view(b, d, h, w, 1)      # C == 1: NCDHW is already channels-last
         x = self.conv1(x)
         # bn1 + ReLU + MaxPool3d(3, 2, 1) as one fused layer: relu(bn(x)), the largest activation, is never stored
+        H.stamp("stem")
         x = self._mark(H.bn_relu_maxpool3d(x, self.bn1, 3, 2, 1), "layer1")     # its gradient exists => layer1.. are done
+        H.stamp("pool")
         # The ReLU at the end of a block is differentiated by the block's single consumer (the next block, then the
         # feature_3d convolution) in its data-gradient epilogue: six mask launches fewer per backward pass.
         first = True
@@ -116,12 +118,14 @@ class TomoResClassifier3D(nn.Module):
                 first = False
             if tag is not None:
                 x = self._mark(x, tag)
+            H.stamp("layer")
         x = self.feature_3d[0](x, mask_dx=True)
         x = H.bn_relu_global_avgpool(x, self.feature_3d[1])      # BatchNorm + ReLU + global average pool: one launch
         return self.fc(x)
 
     def _head(self, head, x):
         seq = self.__getattr__(head)
+        H.stamp("trunk")
         x = seq[1](seq[0](x), relu=True)
         x = seq[4](seq[3](x), relu=True)
         return seq[7](seq[6](x))

@@ -45,6 +45,13 @@ class MocoStepEngine:
         self.buckets_sent = []           # tags of the last step's exchanges, in issue order (tests / diagnostics)
         if self.dist_on:
             self._setup_buckets()
+        # weight gradients of layer1-3 and the head on a side stream, one fork per stage (hipops.SIDE_WGRADS)
+        self.side_wgrads = dev.type == "cuda" and os.environ.get("CETPICK_SIDE_WGRADS", "1") != "0"
+        self._wside = None
+        self._wside_used = False
+        self._wside_keep = []
+        if self.side_wgrads:
+            moco.encoder_q.grad_marker = self._on_marker
         self._images = self._build_weight_images()
         self._img_versions = None
 
@@ -99,6 +106,8 @@ class MocoStepEngine:
         stream - because an async Work under hipGraph capture kills the process-group watchdog (hipops.dist_all_reduce)."""
         a, b = self._bucket[tag]
         H.flush_wgrad_reduces()                       # the bucket's weight gradients still sit in split-K slabs
+        # (with the weight gradients on their side stream the slabs of the stage were reduced there, behind the launches
+        # that wrote them: the exchange stream then waits for both)
         if b > a and not self.arena_q.flat_grad.is_cuda:        # (CPU tensors over gloo: plumbing tests)
             H.dist_all_reduce(self.arena_q.flat_grad[a:b])
             self.buckets_sent.append(tag)
@@ -107,12 +116,41 @@ class MocoStepEngine:
             if self._xchg is None:
                 self._xchg = torch.cuda.Stream(device=self.arena_q.flat_grad.device)
             self._xchg.wait_stream(cur)
+            if self._wside_used:
+                self._xchg.wait_stream(self._wside)
             with torch.cuda.stream(self._xchg):
                 H.dist_all_reduce(self.arena_q.flat_grad[a:b])
             self.buckets_sent.append(tag)
 
     def _on_marker(self, tag):
-        self._reduce_bucket(tag)
+        if self.side_wgrads and tag in ("layer3", "layer2", "layer1"):
+            self._issue_side_wgrads(enqueue=(tag == "layer3"))
+        if self.dist_on:
+            self._reduce_bucket(tag)
+
+    def _issue_side_wgrads(self, enqueue=False):
+        """The data-gradient chain has left a stage: its collected weight-gradient launches go out on the side stream (one
+        fork), next to the following stage's kernels on the main stream.  The deferred key enqueue rides along behind
+        layer3's: the backward pass read the queue for the last time in the logits' gradient, long before."""
+        items = H.SIDE_WGRADS
+        if not items:
+            return
+        cur = torch.cuda.current_stream()
+        if self._wside is None:
+            self._wside = torch.cuda.Stream(device=self.arena_q.flat_grad.device)
+        self._wside.wait_stream(cur)
+        with torch.cuda.stream(self._wside):
+            for fn in items:
+                fn()
+            H.flush_wgrad_reduces()                   # the stage's split-K slabs, behind the launches that wrote them
+            if enqueue:
+                self._wside_keep.append(self.moco._pending_keys)
+                self.moco.flush_enqueue()
+        # the launches read activations / gradients allocated on the main stream: they stay referenced until the join, so
+        # that the allocator cannot hand their memory to the main stream's next kernels while the side stream reads it
+        self._wside_keep.extend(items)
+        del items[:]
+        self._wside_used = True
 
     def broadcast_state(self, src=0):
         """Identical replicas before the first step (what DistributedDataParallel does at construction): the two flat
@@ -140,15 +178,27 @@ class MocoStepEngine:
         H.ACTIVE_IMAGES = self._images                 # the cached weight images are valid inside the step only
         moco.defer_enqueue = True                      # the backward reads the queue in place; keys go in behind it
         try:
+            H.stamp("step:start")
             logits, labels = moco(im_q, im_k)
             self.logits = logits.detach()              # (B, 1 + r) of the last step; under graph replay a static buffer
             loss = H.cross_entropy_label0(logits, out=self._loss_buf)      # lands in the engine's loss buffer: no copy
             H.DEFERRED_WGRADS = [] if self.arena_q.flat_grad.is_cuda else None     # split-K slabs of the wgrads: one reduce
+            H.SIDE_WGRADS = [] if self.side_wgrads else None
+            self._wside_used = False
             loss.backward(self._one)                   # (a kept seed: autograd's ones_like(loss) is a fill launch per step)
+            if H.SIDE_WGRADS:                          # collected behind the last stage boundary: in line
+                for fn in H.SIDE_WGRADS:
+                    fn()
+            H.SIDE_WGRADS = None
+            if self._wside_used:
+                torch.cuda.current_stream().wait_stream(self._wside)
+            del self._wside_keep[:]
+            H.stamp("backward:end")
             H.flush_wgrad_reduces()
             moco.flush_enqueue()
         finally:
             H.DEFERRED_WGRADS = None
+            H.SIDE_WGRADS = None
             H.ACTIVE_IMAGES = None
             moco.defer_enqueue = False
             moco._pending_keys = None
@@ -164,6 +214,7 @@ class MocoStepEngine:
                     grad_scale=1.0 / self.world)
         if self._images is not None:
             self._images.refresh("q")                  # next step's forward / data-gradient images of encoder_q
+        H.stamp("step:end")
         return self.loss
 
     def _capture(self, im_q, im_k):

@@ -38,6 +38,8 @@ typedef void* mi_stream_t; /* hipStream_t */
 int mi_abi_version(void);
 /* measurement aid: nodes of a captured hipGraph (hipGraph_t) by type: counts[4] = kernel, memcpy, memset, other */
 int mi_graph_node_counts(void* graph, int* counts);
+/* measurement aid: a one-thread launch that writes the 100 MHz wall clock into *slot (device uint64) */
+int mi_debug_stamp(void* slot, mi_stream_t stream);
 /* gfx target the code objects were built for, e.g. "gfx950". */
 const char* mi_build_arch(void);
 
