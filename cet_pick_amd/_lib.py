@@ -19,6 +19,8 @@ SIGNATURES = {
     "mi_abi_version": (_I, []),
     "mi_graph_node_counts": (_I, [_P, _P]),
     "mi_debug_stamp": (_I, [_P, _P]),
+    "mi_conv3d_stem_stats_workspace_bytes": (_Z, [_I] * 5),
+    "mi_conv3d_stem_stats_f32": (_I, [_P, _P, _P] + [_I] * 5 + [_P, _P, _Z, _P]),
     "mi_build_arch": (_c.c_char_p, []),
     "mi_sigmoid_clamp": (_I, [_P, _P, _Z, _P]),
     "mi_nms3d": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -37,8 +37,9 @@
 
 // conv_stem.hip: direct kernels for the 7^3 stride-2 stem; MI_E_UNSUPPORTED = shape declined, take the generic path
 int mi_stem7_fwd(const float* x, const float* w, float* y, const float* res, int relu, int N, int D, int H, int W,
-                 int Co, int bf16x3, void* ws, size_t ws_bytes, hipStream_t s);
+                 int Co, int bf16x3, void* ws, size_t ws_bytes, hipStream_t s, double* sums = nullptr);
 size_t mi_stem7_fwd_workspace_bytes();
+size_t mi_stem7_fwd_stats_workspace_bytes(int N, int D, int H, int W);
 size_t mi_stem7_wgrad_workspace_bytes(int N, int D, int H, int W, int Co);
 int mi_stem7_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Co, int bf16x3, void* ws,
                    size_t ws_bytes, hipStream_t s);
@@ -1295,6 +1296,25 @@ extern "C" int mi_conv3d_fwd_f32(const float* x, const float* w, float* y, const
     Geom g = make_geom(N, Di, Hi, Wi, Ci, Co, k, stride, pad);
     if (!x || !w || !y || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
     return run_conv(MODE_FWD, g, x, w, y, res, nullptr, relu, ws, ws_bytes, (hipStream_t)stream);
+}
+
+/* The 7^3 stride-2 single-channel stem convolution (models/networks/moco_encoder_3d.py:170-176 `conv1`) together with
+ * the batch statistics its BatchNorm3d needs (`bn1`, :326-328): sums[0..Co) = column sums of y, sums[Co..2Co) = column sums
+ * of y^2 (doubles, what mi_bn_stats would produce from y), taken from the output tiles while they are still in registers.
+ * MI_E_UNSUPPORTED where the stem kernel does not apply (shape, Co != 64, MI_CONV_ARITH=f32): the caller then runs
+ * mi_conv3d_fwd_f32 + mi_bn_stats. */
+extern "C" size_t mi_conv3d_stem_stats_workspace_bytes(int N, int Di, int Hi, int Wi, int Co) {
+    Geom g = make_geom(N, Di, Hi, Wi, 1, Co, 7, 2, 3);
+    if (!geom_ok(g) || !is_stem7(g) || Co != 64) return 0;
+    return mi_stem7_fwd_stats_workspace_bytes(N, Di, Hi, Wi);
+}
+
+extern "C" int mi_conv3d_stem_stats_f32(const float* x, const float* w, float* y, int N, int Di, int Hi, int Wi, int Co,
+                                        double* sums, void* ws, size_t ws_bytes, mi_stream_t stream) {
+    Geom g = make_geom(N, Di, Hi, Wi, 1, Co, 7, 2, 3);
+    if (!x || !w || !y || !sums || !geom_ok(g)) return MI_E_ARG;
+    if (!is_stem7(g) || !conv_arith_bf16x3() || env_int("MI_CONV_NO_STEM") || env_int("MI_STEM_NO_STATS")) return MI_E_UNSUPPORTED;
+    return mi_stem7_fwd(x, w, y, nullptr, 0, N, Di, Hi, Wi, Co, 1, ws, ws_bytes, (hipStream_t)stream, sums);
 }
 
 /* nn.Linear forward in one pass: y[M][Co] = x[M][Ci] . W + bias (W in kernel layout [Ci][Co], bias may be NULL) - the

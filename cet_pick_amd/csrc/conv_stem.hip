@@ -41,6 +41,7 @@ struct StemParams {
     int relu;
     int N, D, H, W, Do, Ho, Wo;
     unsigned x_bytes;
+    double* stats;       // bf16x3 kernel only, may be null: per-workgroup column sums of y and y^2, [2][64][gridDim.x]
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const float* base, unsigned bytes) {
@@ -325,9 +326,11 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_bf3_kernel(StemParams p, cons
 
     // ---- epilogue: C/D layout col = lane & 31 (channel), row = (r&3) + 8*(r>>2) + 4*h (output voxel) ----
     const int oz = oz0 + wave;
+    float cs[2][2];                                      // [column tile][sum, sum of squares] of what is stored
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int co = j * 32 + l32;
+        float t0 = 0.f, t1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -337,8 +340,48 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_bf3_kernel(StemParams p, cons
             if (p.res) v += p.res[o];
             if (p.relu) v = fmaxf(v, 0.f);
             p.y[o] = v;
+            t0 += v; t1 = fmaf(v, v, t1);
+        }
+        cs[j][0] = t0; cs[j][1] = t1;
+    }
+    // BatchNorm statistics of the following layer from the tile that is still in registers: the 128 voxels of the
+    // workgroup per channel (16 per lane in f32, then doubles in a fixed order), one partial per workgroup stored
+    // [stat][channel][workgroup] so that the finalize reads a channel's partials as one contiguous run
+    if (p.stats) {
+        float* red = reinterpret_cast<float*>(patchb);   // (no LDS read is left behind the loop's last barrier)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float o = cs[j][q] + __shfl_xor(cs[j][q], 32);
+                if (h == 0) red[(wave * 2 + q) * CO + j * 32 + l32] = o;
+            }
+        __syncthreads();
+        if (tid < 2 * CO) {
+            const int q = tid >> 6, c = tid & (CO - 1);
+            double a = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += (double)red[(w * 2 + q) * CO + c];
+            p.stats[(long)(q * CO + c) * gridDim.x + blockIdx.x] = a;
         }
     }
+}
+
+// per-channel sums from the per-workgroup partials of stem_fwd_bf3_kernel ([2*64][n_part], one workgroup per entry):
+// every thread a fixed stride of the run, then a fixed-shape tree - deterministic
+__global__ __launch_bounds__(256) void stem_stats_finalize_kernel(const double* part, int n_part, double* sums) {
+    __shared__ double red[256];
+    const double* src = part + (long)blockIdx.x * n_part;
+    double a = 0;
+    for (int i = threadIdx.x; i < n_part; i += 256) a += src[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+#pragma unroll
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -715,24 +758,39 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* sla
 // Called by conv_igemm.hip's dispatcher.  Returns MI_E_UNSUPPORTED when the shape is not the stem this kernel is
 // specialised for (the caller then takes the generic path).
 size_t mi_stem7_fwd_workspace_bytes() { return WPREP_BYTES; }
+// with the BatchNorm statistics of the output from the epilogue: + one partial per workgroup and statistic
+size_t mi_stem7_fwd_stats_workspace_bytes(int N, int D, int H, int W) {
+    const int Do = (D + 2 * P3 - K7) / S2 + 1, Ho = (H + 2 * P3 - K7) / S2 + 1, Wo = (W + 2 * P3 - K7) / S2 + 1;
+    if (Do <= 0 || Ho <= 0 || Wo <= 0 || Do % TZ || Ho % TY || Wo % TX) return 0;
+    const size_t blocks = (size_t)N * (Do / TZ) * (Ho / TY) * (Wo / TX);
+    return ((WPREP_BYTES + 255) & ~(size_t)255) + sizeof(double) * 2 * CO * blocks;
+}
 
 // bf16x3 != 0 with a workspace of mi_stem7_fwd_workspace_bytes(): the bf16-pipe kernel (f32-equivalent); otherwise the
 // f32 MFMA kernel
 int mi_stem7_fwd(const float* x, const float* w, float* y, const float* res, int relu, int N, int D, int H, int W,
-                 int Co, int bf16x3, void* ws, size_t ws_bytes, hipStream_t s) {
+                 int Co, int bf16x3, void* ws, size_t ws_bytes, hipStream_t s, double* sums) {
     if (Co != CO) return MI_E_UNSUPPORTED;
+    if (sums && (!bf16x3 || !ws || ws_bytes < mi_stem7_fwd_stats_workspace_bytes(N, D, H, W) || ws_bytes == 0))
+        return MI_E_UNSUPPORTED;                       // (statistics: the bf16-pipe kernel's epilogue only)
     const int Do = (D + 2 * P3 - K7) / S2 + 1, Ho = (H + 2 * P3 - K7) / S2 + 1, Wo = (W + 2 * P3 - K7) / S2 + 1;
     if (Do <= 0 || Ho <= 0 || Wo <= 0 || Do % TZ || Ho % TY || Wo % TX) return MI_E_UNSUPPORTED;
     const long xb = 4l * N * D * H * W;
     if (xb >= 0x7fff0000l) return MI_E_UNSUPPORTED;
     const long blocks = (long)N * (Do / TZ) * (Ho / TY) * (Wo / TX);
     if (blocks > 0x7fffffffl) return MI_E_UNSUPPORTED;
-    StemParams p = {x, w, y, res, relu, N, D, H, W, Do, Ho, Wo, (unsigned)xb};
+    StemParams p = {x, w, y, res, relu, N, D, H, W, Do, Ho, Wo, (unsigned)xb, nullptr};
     if (bf16x3 && ws && ws_bytes >= WPREP_BYTES) {
+        if (sums) p.stats = reinterpret_cast<double*>((unsigned char*)ws + ((WPREP_BYTES + 255) & ~(size_t)255));
         hipLaunchKernelGGL(stem_wprep_kernel, dim3((K7 * 8 * CO * 8 + 255) / 256), dim3(256), 0, s, w, (unsigned short*)ws);
         MI_RETURN_IF_LAUNCH_FAILED();
         hipLaunchKernelGGL(stem_fwd_bf3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, (const unsigned char*)ws);
         MI_RETURN_IF_LAUNCH_FAILED();
+        if (sums) {
+            hipLaunchKernelGGL(stem_stats_finalize_kernel, dim3(2 * CO), dim3(256), 0, s, (const double*)p.stats, (int)blocks,
+                               sums);
+            MI_RETURN_IF_LAUNCH_FAILED();
+        }
         return MI_OK;
     }
     hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);

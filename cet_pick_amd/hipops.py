@@ -477,13 +477,41 @@ def relu_mask(dy, y, add=None):
     return out
 
 
+def _stem_fwd_with_stats(x, w, mod):
+    """The stem convolution with the batch statistics of the BatchNorm behind it from its epilogue (mi_conv3d_stem_stats_f32:
+    no statistics pass over the 67 MB output).  Leaves them in mod.bn_sums for bn_relu_maxpool3d(..., sums=...); None where
+    the stem kernel does not apply (the caller then takes the plain convolution and the BatchNorm its own statistics)."""
+    mod.bn_sums = None
+    if PROFILE is not None or x.dim() != 5 or x.shape[-1] != 1 or (mod.k, mod.stride, mod.pad) != (7, 2, 3) or not _phys_ok(w):
+        return None
+    lib = L.lib()
+    n, d, h, wd, _ = x.shape
+    co = w.shape[0]
+    nbytes = lib.mi_conv3d_stem_stats_workspace_bytes(n, d, h, wd, co)
+    if nbytes == 0:
+        return None
+    do, ho, wo = [(v + 6 - 7) // 2 + 1 for v in (d, h, wd)]
+    y = torch.empty((n, do, ho, wo, co), dtype=torch.float32, device=x.device)
+    sums = torch.empty(2 * co, dtype=torch.float64, device=x.device)
+    ws = _ws(nbytes, x.device, "stem_stats")
+    rc = lib.mi_conv3d_stem_stats_f32(L.ptr(x), L.ptr(w), L.ptr(y), n, d, h, wd, co, L.ptr(sums), L.ptr(ws), ws.numel(),
+                                      L.stream())
+    if rc == -3:
+        return None
+    L.check(rc, "mi_conv3d_stem_stats_f32")
+    mod.bn_sums = sums
+    return y
+
+
 class _ConvFn(torch.autograd.Function):
     """y = act(conv(x, W)); W's gradient goes to mod.weight.grad directly."""
 
     @staticmethod
     def forward(ctx, x, w, mod, relu, mask_dx=False):
         ctx.mod, ctx.relu, ctx.mask_dx = mod, relu, mask_dx
-        y = conv_fwd(x, w, mod.k, mod.stride, mod.pad, None, relu, dil=getattr(mod, "dil", None))
+        y = _stem_fwd_with_stats(x, w, mod) if (getattr(mod, "stats_for_bn", False) and not relu) else None
+        if y is None:
+            y = conv_fwd(x, w, mod.k, mod.stride, mod.pad, None, relu, dil=getattr(mod, "dil", None))
         ctx.save_for_backward(x, y if relu else None)
         ctx.x_needs_grad = x.requires_grad
         return y
@@ -802,7 +830,7 @@ class _BNReluPoolFn(torch.autograd.Function):
     """MaxPool3d(k, s, p)(relu(bn(x))) without materialising relu(bn(x)): the stem of the 3-D encoder."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mod, k, stride, pad):
+    def forward(ctx, x, gamma, beta, mod, k, stride, pad, given_sums=None):
         n, d, h, w, c = x.shape
         lib = L.lib()
         dev = x.device
@@ -815,9 +843,12 @@ class _BNReluPoolFn(torch.autograd.Function):
         count = float(m)
         sums = None
         if train:
-            ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
-            sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
-            L.check(lib.mi_bn_stats(L.ptr(x), m, c, L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()), "mi_bn_stats")
+            if given_sums is not None:
+                sums = given_sums
+            else:
+                ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
+                sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+                L.check(lib.mi_bn_stats(L.ptr(x), m, c, L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()), "mi_bn_stats")
             if mod.sync and _distributed():
                 import torch.distributed as dist
                 dist_all_reduce(sums)
@@ -875,12 +906,13 @@ class _BNReluPoolFn(torch.autograd.Function):
             gamma.grad.add_(dg)
         if acc_b:
             beta.grad.add_(db)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
-def bn_relu_maxpool3d(x, bn, k, stride, pad):
-    """maxpool3d(bn(x, relu=True), k, stride, pad) as one fused layer (bn: HipBatchNorm)."""
-    return _BNReluPoolFn.apply(_f32c(x, "x"), bn.weight, bn.bias, bn, k, stride, pad)
+def bn_relu_maxpool3d(x, bn, k, stride, pad, sums=None):
+    """maxpool3d(bn(x, relu=True), k, stride, pad) as one fused layer (bn: HipBatchNorm).  sums: the column sums of x and
+    x^2 (2C doubles) where the producer of x already has them (the stem's epilogue) - the statistics pass is skipped."""
+    return _BNReluPoolFn.apply(_f32c(x, "x"), bn.weight, bn.bias, bn, k, stride, pad, sums)
 
 
 class HipBatchNorm(nn.Module):

@@ -104,10 +104,14 @@ class TomoResClassifier3D(nn.Module):
         if c != 1:
             raise ValueError("the moco3d encoder takes single-channel sub-tomograms (B,1,D,H,W)")
         x = x1.contiguous().float().view(b, d, h, w, 1)      # C == 1: NCDHW is already channels-last
+        # bn1's batch statistics come out of conv1's epilogue where the stem kernel runs (no pass over the 67 MB output)
+        self.conv1.stats_for_bn = self.bn1.training or not self.bn1.track_running_stats
         x = self.conv1(x)
+        sums = getattr(self.conv1, "bn_sums", None) if self.conv1.stats_for_bn else None
+        self.conv1.bn_sums = None
         # bn1 + ReLU + MaxPool3d(3, 2, 1) as one fused layer: relu(bn(x)), the largest activation, is never stored
         H.stamp("stem")
-        x = self._mark(H.bn_relu_maxpool3d(x, self.bn1, 3, 2, 1), "layer1")     # its gradient exists => layer1.. are done
+        x = self._mark(H.bn_relu_maxpool3d(x, self.bn1, 3, 2, 1, sums=sums), "layer1")     # its gradient exists => layer1.. are done
         H.stamp("pool")
         # The ReLU at the end of a block is differentiated by the block's single consumer (the next block, then the
         # feature_3d convolution) in its data-gradient epilogue: six mask launches fewer per backward pass.

@@ -179,6 +179,15 @@ int mi_conv3d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int D
                         int Ci, int Co, int k, int stride, int pad, void* ws, size_t ws_bytes,
                         mi_stream_t stream);
 
+/* conv1 + the batch statistics of bn1 in one pass (models/networks/moco_encoder_3d.py:170-176, 326-328): the 7^3
+ * stride-2 single-channel stem convolution, with sums[0..Co) = column sums of y and sums[Co..2Co) = column sums of y^2
+ * (device doubles; what mi_bn_stats(y) would produce) taken from the output tiles while they are in registers.
+ * MI_E_UNSUPPORTED where the stem kernel does not apply (shape, Co != 64, MI_CONV_ARITH=f32): run mi_conv3d_fwd_f32 and
+ * mi_bn_stats instead.  Workspace: mi_conv3d_stem_stats_workspace_bytes (0 = unsupported shape). */
+size_t mi_conv3d_stem_stats_workspace_bytes(int N, int Di, int Hi, int Wi, int Co);
+int mi_conv3d_stem_stats_f32(const float* x, const float* w, float* y, int N, int Di, int Hi, int Wi, int Co,
+                             double* sums, void* ws, size_t ws_bytes, mi_stream_t stream);
+
 /* nn.Linear (models/networks/moco_encoder_3d.py:183-236: fc and the projection head): y[M][Co] = x[M][Ci] . W + bias with
  * W in kernel layout [Ci][Co]; bias (Co values, may be NULL) is added in the epilogue of the 1x1x1 convolution launch.
  * Workspace as mi_conv3d_workspace_bytes(M, 1, 1, 1, Ci, Co, 1, 1, 0). */

@@ -594,3 +594,35 @@ def test_fused_bn_relu_maxpool_matches_unfused(shape, train):
         np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), bn_ref.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(bn.running_var.cpu().numpy(), bn_ref.running_var.numpy(), rtol=1e-5, atol=1e-6)
         assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,size", [(3, 32), (2, 48), (64, 32)])
+def test_stem_epilogue_statistics_match_statistics_pass(n, size):
+    """mi_conv3d_stem_stats_f32: the output equals the plain stem convolution's bit for bit and the BatchNorm sums from
+    its epilogue equal float64 column sums of that output (to float32 rounding of the 16-voxel partial sums); the encoder's
+    trunk produces the same activations with and without them (MI_STEM_NO_STATS=1)."""
+    import ctypes
+    import numpy as np
+    from cet_pick_amd import hipops as H, _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(n * 100 + size)
+    x = (torch.randn(n, size, size, size, 1, generator=g) * 1.5 + 0.2).cuda()
+    conv = H.HipConv3d(1, 64, 7, 2, 3).cuda()
+    y_plain = conv(x)
+    nbytes = lib.mi_conv3d_stem_stats_workspace_bytes(n, size, size, size, 64)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    y = torch.empty_like(y_plain)
+    sums = torch.zeros(128, dtype=torch.float64, device="cuda")
+    rc = lib.mi_conv3d_stem_stats_f32(L.ptr(x), L.ptr(conv.weight), L.ptr(y), n, size, size, size, 64, L.ptr(sums), L.ptr(ws),
+                                      ws.numel(), L.stream())
+    assert rc == 0
+    assert torch.equal(y, y_plain.detach())
+    y64 = y.double().reshape(-1, 64)
+    want = torch.cat([y64.sum(0), (y64 * y64).sum(0)]).cpu().numpy()
+    got = sums.cpu().numpy()
+    scale = np.concatenate([y64.abs().sum(0).cpu().numpy(), want[64:]])
+    assert np.max(np.abs(got - want) / scale) < 2e-6          # fp32 partial sums over 16 voxels, doubles from there
+    # an unsupported geometry is declined, not mis-run
+    assert lib.mi_conv3d_stem_stats_workspace_bytes(n, size + 2, size, size, 64) == 0
