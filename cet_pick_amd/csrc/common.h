@@ -17,6 +17,19 @@
     } while (0)
 
 static inline size_t mi_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// BatchNorm1d (training mode) + optional ReLU in the epilogue of a small dense product (conv_cube2.hip small_gemm_kernel)
+struct MiSmallGemmBN {
+    float* y;                 // act(bn(C))
+    const float* gamma;       // may be null
+    const float* beta;
+    float eps, momentum;
+    float* running_mean;      // may be null (with running_var)
+    float* running_var;
+    long long* num_batches_tracked;     // may be null
+    float* save;              // mean[N], invstd[N]
+    int relu;
+};
 static inline int mi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -328,6 +328,17 @@ struct SmallGemmParams {
     int M, N, K;
     long lda_m, lda_k, ldb_k, ldb_n;
     unsigned a_bytes, b_bytes;
+    // training-mode BatchNorm1d (+ ReLU) of C in the same launch (M <= 64: the workgroup's tile holds every row of its 32
+    // columns, so the batch statistics are its own): bn_y = act(bn(C)); C itself is still written (the backward reads it)
+    float* bn_y;              // null: plain product
+    const float* gamma;       // may be null
+    const float* beta;
+    float eps, momentum;
+    float* running_mean;      // may be null (with running_var)
+    float* running_var;
+    long long* num_batches_tracked;     // may be null
+    float* save;              // mean[N], invstd[N]
+    int relu;
 };
 
 template <bool A_KC, bool B_KC, int NS>     // operand is k-contiguous (16-byte loads) or strided (8 dwords); NS k-steps per wave
@@ -426,12 +437,49 @@ __global__ __launch_bounds__(256, 2) void small_gemm_kernel(SmallGemmParams p) {
         for (int r = 0; r < 16; ++r) red[wave][rb * 16 + r][lane] = acc[rb][r];
     __syncthreads();
     const float bv = (p.bias && col_ok) ? p.bias[n0 + l32] : 0.f;
+    float tv[8];
+    double cs = 0, css = 0;                              // column sums over this thread's rows (BatchNorm: doubles, as bn_small_fwd)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int idx = wave * 8 + j, rb = idx >> 4, r = idx & 15;
         const float t = ((red[0][idx][lane] + red[1][idx][lane]) + red[2][idx][lane]) + red[3][idx][lane];
         const int m = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < p.M && col_ok) p.c[(long)m * p.N + n0 + l32] = t + bv;
+        tv[j] = t + bv;
+        if (m < p.M && col_ok) {
+            p.c[(long)m * p.N + n0 + l32] = tv[j];
+            cs += (double)tv[j]; css += (double)tv[j] * (double)tv[j];
+        }
+    }
+    if (p.bn_y) {                                        // (uniform: a launch argument)
+        __shared__ double bred[4][2][32];
+        cs += __shfl_xor(cs, 32, 64); css += __shfl_xor(css, 32, 64);
+        if (h == 0) { bred[wave][0][l32] = cs; bred[wave][1][l32] = css; }
+        __syncthreads();
+        const double S = (bred[0][0][l32] + bred[1][0][l32]) + (bred[2][0][l32] + bred[3][0][l32]);
+        const double SS = (bred[0][1][l32] + bred[1][1][l32]) + (bred[2][1][l32] + bred[3][1][l32]);
+        const double mean = S / p.M;
+        double var = SS / p.M - mean * mean;
+        if (var < 0) var = 0;
+        const float mf = (float)mean, iv = (float)(1.0 / sqrt(var + (double)p.eps));
+        const int col = n0 + l32;
+        if (wave == 0 && h == 0 && col_ok) {
+            p.save[col] = mf; p.save[p.N + col] = iv;
+            if (p.running_mean) {
+                const double unbiased = p.M > 1 ? var * p.M / (p.M - 1.0) : var;
+                p.running_mean[col] = (1.f - p.momentum) * p.running_mean[col] + p.momentum * mf;
+                p.running_var[col] = (1.f - p.momentum) * p.running_var[col] + p.momentum * (float)unbiased;
+            }
+        }
+        if (blockIdx.x == 0 && tid == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
+        const float g = (p.gamma && col_ok) ? p.gamma[col] : 1.f, b = (p.beta && col_ok) ? p.beta[col] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = wave * 8 + j, rb = idx >> 4, r = idx & 15;
+            const int m = m0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float q = fmaf((tv[j] - mf) * iv, g, b);
+            if (p.relu) q = fmaxf(q, 0.f);
+            if (m < p.M && col_ok) p.bn_y[(long)m * p.N + col] = q;
+        }
     }
 }
 
@@ -510,9 +558,16 @@ bool mi_small_gemm_usable(long M, long N, long K) {
     return M >= 1 && M <= 1024 && N >= 1 && N <= 4096 && K >= 1 && K <= 1024;
 }
 int mi_small_gemm_launch(const float* a, long lda_m, long lda_k, long a_elems, const float* b, long ldb_k, long ldb_n,
-                         long b_elems, const float* bias, float* c, int M, int N, int K, hipStream_t s) {
+                         long b_elems, const float* bias, float* c, int M, int N, int K, hipStream_t s, const MiSmallGemmBN* bn) {
     if (4 * a_elems >= 0x7fff0000l || 4 * b_elems >= 0x7fff0000l) return MI_E_UNSUPPORTED;
+    if (bn && (M > 64 || !bn->y || !bn->save || (bn->running_mean == nullptr) != (bn->running_var == nullptr))) return MI_E_UNSUPPORTED;
     SmallGemmParams p = {a, b, bias, c, M, N, K, lda_m, lda_k, ldb_k, ldb_n, (unsigned)(4 * a_elems), (unsigned)(4 * b_elems)};
+    p.bn_y = nullptr;
+    if (bn) {
+        p.bn_y = bn->y; p.gamma = bn->gamma; p.beta = bn->beta; p.eps = bn->eps; p.momentum = bn->momentum;
+        p.running_mean = bn->running_mean; p.running_var = bn->running_var; p.num_batches_tracked = bn->num_batches_tracked;
+        p.save = bn->save; p.relu = bn->relu;
+    }
     const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 63) / 64));
     const int kt = (K + 15) / 16, per = (kt + 3) / 4;
     const int ns = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 16;

@@ -73,7 +73,8 @@ bool mi_pair_wgrad_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd,
 int mi_pair_wgrad_launch(const float* x, const float* dy, float* dwt, int N, int Di, int Ci, int Co, int stride, hipStream_t s);
 bool mi_small_gemm_usable(long M, long N, long K);
 int mi_small_gemm_launch(const float* a, long lda_m, long lda_k, long a_elems, const float* b, long ldb_k, long ldb_n,
-                         long b_elems, const float* bias, float* c, int M, int N, int K, hipStream_t s);
+                         long b_elems, const float* bias, float* c, int M, int N, int K, hipStream_t s,
+                         const MiSmallGemmBN* bn = nullptr);
 
 namespace {
 
@@ -1296,6 +1297,22 @@ extern "C" int mi_conv3d_fwd_f32(const float* x, const float* w, float* y, const
     Geom g = make_geom(N, Di, Hi, Wi, Ci, Co, k, stride, pad);
     if (!x || !w || !y || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
     return run_conv(MODE_FWD, g, x, w, y, res, nullptr, relu, ws, ws_bytes, (hipStream_t)stream);
+}
+
+/* nn.Linear (+ bias) followed by training-mode nn.BatchNorm1d (+ ReLU) in ONE launch - the projection MLP of the MoCo-3D
+ * encoder (models/networks/moco_encoder_3d.py:238-255: Linear, BatchNorm1d, ReLU three times over a batch of <= 64 rows).
+ * xlin = x W + bias is written as well (the BatchNorm backward reads it); y = act(bn(xlin)); save = mean[Co], invstd[Co];
+ * running statistics / num_batches_tracked updated when given.  Same arithmetic as mi_linear_fwd_f32 + mi_bn_small_fwd.
+ * MI_E_UNSUPPORTED for M > 64 (a workgroup's tile must hold every row) or shapes the small product declines. */
+extern "C" int mi_linear_bn_fwd_f32(const float* x, const float* w, const float* bias, float* xlin, float* y, int M, int Ci,
+                                    int Co, const float* gamma, const float* beta, float eps, float momentum,
+                                    float* running_mean, float* running_var, long long* num_batches_tracked,
+                                    float* save_mean_invstd, int relu, mi_stream_t stream) {
+    if (!x || !w || !xlin || !y || !save_mean_invstd || M <= 0 || Ci <= 0 || Co <= 0) return MI_E_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return MI_E_ARG;
+    if (M > 64 || !conv_arith_bf16x3() || !mi_small_gemm_usable(M, Co, Ci) || env_int("MI_NO_LINEAR_BN")) return MI_E_UNSUPPORTED;
+    MiSmallGemmBN bn = {y, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean_invstd, relu};
+    return mi_small_gemm_launch(x, Ci, 1, (long)M * Ci, w, Co, 1, (long)Ci * Co, bias, xlin, M, Co, Ci, (hipStream_t)stream, &bn);
 }
 
 /* The 7^3 stride-2 single-channel stem convolution (models/networks/moco_encoder_3d.py:170-176 `conv1`) together with

@@ -590,7 +590,34 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b, mod):
         m, ci = x.shape
         w5 = w.view(w.shape[0], ci, 1, 1, 1) if w.dim() == 5 else _as5(w)
-        if b is not None and PROFILE is None and _phys_ok(w5):
+        y = None
+        fuse = getattr(mod, "_fuse_bn", None)
+        if fuse is not None:
+            mod._bn_pre = None
+        if fuse is not None and PROFILE is None and _phys_ok(w5):
+            # Linear + BatchNorm1d (+ ReLU) in one launch (linear_bn): the BatchNorm's output and saved statistics wait in
+            # mod._bn_pre for the BatchNorm node; this node's own output is the Linear's, as always
+            bn, bn_relu = fuse
+            _f32c(x, "x")
+            lib = L.lib()
+            co = w5.shape[0]
+            y = torch.empty((m, co), dtype=torch.float32, device=x.device)
+            yb = torch.empty((m, co), dtype=torch.float32, device=x.device)
+            save = torch.empty(2 * co, dtype=torch.float32, device=x.device)
+            track = bn.track_running_stats and bn.training
+            rc = lib.mi_linear_bn_fwd_f32(L.ptr(x), L.ptr(w5), L.ptr(b), L.ptr(y), L.ptr(yb), m, ci, co, L.ptr(bn.weight),
+                                          L.ptr(bn.bias), bn.eps, bn.momentum, L.ptr(bn.running_mean if track else None),
+                                          L.ptr(bn.running_var if track else None),
+                                          L.ptr(bn.num_batches_tracked if track else None), L.ptr(save), int(bn_relu),
+                                          L.stream())
+            if rc == -3:
+                y = None                                  # declined (rows, arithmetic switch): the two launches
+            else:
+                L.check(rc, "mi_linear_bn_fwd_f32")
+                mod._bn_pre = (yb, save)
+        if y is not None:
+            pass
+        elif b is not None and PROFILE is None and _phys_ok(w5):
             # the bias rides in the epilogue of the GEMM launch (or of its split-K reduce)
             _f32c(x, "x")
             lib = L.lib()
@@ -712,17 +739,27 @@ class _BNFn(torch.autograd.Function):
     """y = act(bn(x) + res); res (optional) is a residual branch added before the activation."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mod, relu, res=None):
+    def forward(ctx, x, gamma, beta, mod, relu, res=None, pre=None):
         shape = x.shape
         c = shape[-1]
         m = x.numel() // c
         lib = L.lib()
         dev = x.device
-        y = torch.empty_like(x)
-        save = torch.empty(2 * c, dtype=torch.float32, device=dev)
         distributed = mod.sync and _distributed()
         ctx.small = (mod.training or not mod.track_running_stats) and m <= BN_SMALL_MAX_ROWS and not distributed
-        if ctx.small:
+        if pre is not None:
+            # (y, save) came out of the producing Linear's launch (linear_bn): nothing to run here
+            if not ctx.small or res is not None:
+                raise L.HipExtensionError("fused Linear+BatchNorm output handed to a BatchNorm that would not take the small path")
+            y, save = pre
+            ctx.count = float(m)
+            ctx.train_stats = True
+        else:
+            y = torch.empty_like(x)
+            save = torch.empty(2 * c, dtype=torch.float32, device=dev)
+        if pre is not None:
+            pass
+        elif ctx.small:
             # one launch: statistics, running statistics, affine (+res, ReLU)
             track = mod.track_running_stats and mod.training
             L.check(lib.mi_bn_small_fwd(L.ptr(x), L.ptr(y), m, c, L.ptr(gamma), L.ptr(beta), mod.eps, mod.momentum,
@@ -792,7 +829,7 @@ class _BNFn(torch.autograd.Function):
                 gamma.grad.add_(dg)
             if acc_b:
                 mod.bias.grad.add_(db)
-            return dx, None, None, None, None, dres
+            return dx, None, None, None, None, dres, None
         ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         L.check(lib.mi_bn_bwd_reduce(L.ptr(dy), L.ptr(x), L.ptr(y), m, c, L.ptr(save), int(relu), L.ptr(sums),
@@ -823,7 +860,7 @@ class _BNFn(torch.autograd.Function):
             gamma.grad.add_(dg)
         if acc_b:
             mod.bias.grad.add_(db)
-        return dx, None, None, None, None, dres
+        return dx, None, None, None, None, dres, None
 
 
 class _BNReluPoolFn(torch.autograd.Function):
@@ -915,6 +952,24 @@ def bn_relu_maxpool3d(x, bn, k, stride, pad, sums=None):
     return _BNReluPoolFn.apply(_f32c(x, "x"), bn.weight, bn.bias, bn, k, stride, pad, sums)
 
 
+def linear_bn(x, lin, bn, relu=False):
+    """bn(lin(x), relu) for a HipLinear followed by a HipBatchNorm over a batch of at most 64 rows in ONE launch
+    (mi_linear_bn_fwd_f32: the product's tile holds every row of its columns, so the batch statistics are the workgroup's
+    own); both autograd nodes stay, with their backward passes.  Anything else (more rows, eval mode, SyncBN across ranks)
+    runs the two launches."""
+    train = bn.training or not bn.track_running_stats
+    if not (x.is_cuda and x.dim() == 2 and x.shape[0] <= 64 and train and not (bn.sync and _distributed()) and PROFILE is None):
+        return bn(lin(x), relu=relu)
+    lin._fuse_bn = (bn, relu)
+    try:
+        xl = lin(x)
+        pre = getattr(lin, "_bn_pre", None)
+    finally:
+        lin._fuse_bn = None
+        lin._bn_pre = None
+    return bn(xl, relu=relu, pre=pre)                 # (through the module: forward hooks keep firing)
+
+
 class HipBatchNorm(nn.Module):
     """nn.BatchNorm3d / nn.BatchNorm1d over the last (channel) axis, optional fused ReLU."""
 
@@ -933,8 +988,8 @@ class HipBatchNorm(nn.Module):
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, relu=False, res=None):
-        return _BNFn.apply(_f32c(x, "x"), self.weight, self.bias, self, relu, res)
+    def forward(self, x, relu=False, res=None, pre=None):
+        return _BNFn.apply(_f32c(x, "x"), self.weight, self.bias, self, relu, res, pre)
 
 
 def convert_sync_batchnorm(module):

@@ -130,9 +130,9 @@ class TomoResClassifier3D(nn.Module):
     def _head(self, head, x):
         seq = self.__getattr__(head)
         H.stamp("trunk")
-        x = seq[1](seq[0](x), relu=True)
-        x = seq[4](seq[3](x), relu=True)
-        return seq[7](seq[6](x))
+        x = H.linear_bn(x, seq[0], seq[1], relu=True)          # Linear + BatchNorm1d + ReLU: one launch each
+        x = H.linear_bn(x, seq[3], seq[4], relu=True)
+        return H.linear_bn(x, seq[6], seq[7])
 
     def forward_test(self, x1):
         """moco_encoder_3d.py:326-351: {'proj': z.detach()}."""

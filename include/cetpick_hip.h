@@ -179,6 +179,15 @@ int mi_conv3d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int D
                         int Ci, int Co, int k, int stride, int pad, void* ws, size_t ws_bytes,
                         mi_stream_t stream);
 
+/* nn.Linear (+ bias) followed by training-mode nn.BatchNorm1d (+ ReLU) in one launch (the projection MLP,
+ * models/networks/moco_encoder_3d.py:238-255): xlin (M, Co) = x W + bias (kept for the backward), y = act(bn(xlin)),
+ * save = mean[Co], invstd[Co]; running statistics and num_batches_tracked (int64) are updated when given.  Arithmetic of
+ * mi_linear_fwd_f32 followed by mi_bn_small_fwd.  MI_E_UNSUPPORTED for M > 64 or MI_CONV_ARITH=f32: run those two. */
+int mi_linear_bn_fwd_f32(const float* x, const float* w, const float* bias, float* xlin, float* y, int M, int Ci, int Co,
+                         const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, float* save_mean_invstd, int relu,
+                         mi_stream_t stream);
+
 /* conv1 + the batch statistics of bn1 in one pass (models/networks/moco_encoder_3d.py:170-176, 326-328): the 7^3
  * stride-2 single-channel stem convolution, with sums[0..Co) = column sums of y and sums[Co..2Co) = column sums of y^2
  * (device doubles; what mi_bn_stats(y) would produce) taken from the output tiles while they are in registers.

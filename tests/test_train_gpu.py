@@ -626,3 +626,58 @@ def test_stem_epilogue_statistics_match_statistics_pass(n, size):
     assert np.max(np.abs(got - want) / scale) < 2e-6          # fp32 partial sums over 16 voxels, doubles from there
     # an unsupported geometry is declined, not mis-run
     assert lib.mi_conv3d_stem_stats_workspace_bytes(n, size + 2, size, size, 64) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,ci,co,relu,bias", [(64, 128, 128, True, False), (16, 128, 256, False, False), (37, 256, 128, True, True)])
+def test_linear_bn_one_launch_matches_two_launches_and_torch(m, ci, co, relu, bias, monkeypatch):
+    """hipops.linear_bn (mi_linear_bn_fwd_f32: Linear + BatchNorm1d (+ ReLU) in the product's epilogue) against the two
+    separate launches (MI_NO_LINEAR_BN=1) and against torch in float64: outputs, running statistics, every gradient."""
+    import numpy as np
+    from cet_pick_amd import hipops as H
+    g = torch.Generator().manual_seed(m + ci + co)
+    x0 = torch.randn(m, ci, generator=g)
+    dy = torch.randn(m, co, generator=g)
+    w0 = torch.randn(co, ci, generator=g) * 0.1
+    b0 = torch.randn(co, generator=g) * 0.1
+    gam, bet = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.2
+
+    def run(fused):
+        monkeypatch.setenv("MI_NO_LINEAR_BN", "0" if fused else "1")
+        lin = H.HipLinear(ci, co, bias=bias).cuda()
+        bn = H.HipBatchNorm(co).cuda()
+        with torch.no_grad():
+            lin.weight.copy_(w0.cuda())
+            if bias:
+                lin.bias.copy_(b0.cuda())
+            bn.weight.copy_(gam.cuda()); bn.bias.copy_(bet.cuda())
+        x = x0.cuda().requires_grad_(True)
+        y = H.linear_bn(x, lin, bn, relu=relu)
+        y.backward(dy.cuda())
+        out = [y.detach(), x.grad, lin.weight.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var]
+        if bias:
+            out.append(lin.bias.grad)
+        assert int(bn.num_batches_tracked) == 1
+        return [t.detach().cpu().double().numpy() for t in out]
+
+    one, two = run(True), run(False)
+    # float64 reference
+    lin_r = torch.nn.Linear(ci, co, bias=bias).double()
+    bn_r = torch.nn.BatchNorm1d(co).double()
+    with torch.no_grad():
+        lin_r.weight.copy_(w0.double())
+        if bias:
+            lin_r.bias.copy_(b0.double())
+        bn_r.weight.copy_(gam.double()); bn_r.bias.copy_(bet.double())
+    xr = x0.double().requires_grad_(True)
+    yr = bn_r(lin_r(xr))
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(dy.double())
+    ref = [yr.detach(), xr.grad, lin_r.weight.grad, bn_r.weight.grad, bn_r.bias.grad, bn_r.running_mean, bn_r.running_var]
+    if bias:
+        ref.append(lin_r.bias.grad)
+    ref = [t.detach().numpy() for t in ref]
+    for a, b, r in zip(one, two, ref):
+        scale = max(np.abs(r).max(), 0.05)                   # (a Linear bias in front of a BatchNorm has a zero gradient)
+        assert np.abs(a - b).max() <= 2e-6 * scale           # same arithmetic, another summation order of the statistics
+        assert np.abs(a - r).max() <= 2e-5 * scale
