@@ -115,6 +115,12 @@ SIGNATURES = {
     "mi_conv3d_s2_dgrad_usable": (_I, [_I, _I, _I, _I]),
     "mi_conv3d_s2_dgrad_workspace_bytes": (_Z, [_I, _I]),
     "mi_conv3d_s2_dgrad_f32": (_I, [_P] * 7 + [_I, _I, _I, _I, _P, _Z, _P]),
+    "mi_conv3d_s2_fwd_usable": (_I, [_I, _I, _I, _I]),
+    "mi_conv3d_s2_fwd_workspace_bytes": (_Z, [_I, _I]),
+    "mi_conv3d_s2_fwd_f32": (_I, [_P] * 5 + [_I, _I, _I, _I, _P, _Z, _P]),
+    "mi_conv3d_s2_prep": (_I, [_P] * 6 + [_I, _P]),
+    "mi_conv3d_s2_fwd_img_f32": (_I, [_P] * 4 + [_I] * 4 + [_P]),
+    "mi_conv3d_s2_dgrad_img_f32": (_I, [_P] * 6 + [_I] * 4 + [_P]),
     "mi_ema_update": (_I, [_P, _P, _F, _L, _P]),
     "mi_sgd_step": (_I, [_P, _P, _P, _F, _F, _F, _L, _P]),
     "mi_queue_enqueue": (_I, [_P, _P, _P, _I, _I, _I, _P]),

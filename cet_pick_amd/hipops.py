@@ -232,7 +232,8 @@ ACTIVE_IMAGES = None
 class WeightImages:
     def __init__(self):
         self._groups = {}            # group -> list of (weight, dgrad flag, image tensor)
-        self._by_weight = {}         # (weight storage address, dgrad) -> image tensor
+        self._s2_groups = {}         # group -> list of (weight, shortcut weight, dgrad flag, image tensor)
+        self._by_weight = {}         # (weight storage address, dgrad [+ 2: stride-2 front]) -> image tensor
 
     @staticmethod
     def eligible(w, k, stride, pad):
@@ -252,8 +253,38 @@ class WeightImages:
             return None
         return img
 
+    # ---- the stride-2 block fronts (csrc/conv_s2.hip): image of (conv1.weight, downsample weight), forward or data gradient ----
+    def add_s2(self, group, w, w_ds, dgrad):
+        lib = L.lib()
+        co, ci = int(w.shape[0]), int(w.shape[1])
+        nb = lib.mi_conv3d_s2_dgrad_workspace_bytes(ci, co) if dgrad else lib.mi_conv3d_s2_fwd_workspace_bytes(ci, co)
+        img = torch.empty(int(nb), dtype=torch.uint8, device=w.device)
+        self._s2_groups.setdefault(group, []).append((w, w_ds, int(bool(dgrad)), img))
+        self._by_weight[(w.data_ptr(), 2 + int(bool(dgrad)))] = img
+
+    def get_s2(self, w, dgrad):
+        return self._by_weight.get((w.data_ptr(), 2 + int(bool(dgrad))))
+
+    def _refresh_s2(self, group):
+        items = self._s2_groups.get(group)
+        if not items:
+            return
+        import ctypes
+        n = len(items)
+        ws = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in items])
+        wd = (ctypes.c_void_p * n)(*[(it[1].data_ptr() if it[1] is not None else None) for it in items])
+        imgs = (ctypes.c_void_p * n)(*[it[3].data_ptr() for it in items])
+        ci = (ctypes.c_int * n)(*[int(it[0].shape[1]) for it in items])
+        co = (ctypes.c_int * n)(*[int(it[0].shape[0]) for it in items])
+        dg = (ctypes.c_int * n)(*[it[2] for it in items])
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        L.check(L.lib().mi_conv3d_s2_prep(cast(ws), cast(wd), cast(imgs), cast(ci), cast(co), cast(dg), n, L.stream()),
+                "mi_conv3d_s2_prep")
+
     def refresh(self, group):
-        """Re-cut every image of `group` from the current weights: one launch (per 16 images) on the current stream."""
+        """Re-cut every image of `group` from the current weights: one launch (per 16 images) on the current stream, and one
+        for the group's stride-2 fronts."""
+        self._refresh_s2(group)
         items = self._groups.get(group)
         if not items:
             return
@@ -270,7 +301,8 @@ class WeightImages:
     def versions(self):
         """Sum of the torch version counters of the cached weights: changes when anything but the engine's own kernels
         (which refresh by themselves) wrote a weight."""
-        return sum(it[0]._version for items in self._groups.values() for it in items)
+        return (sum(it[0]._version for items in self._groups.values() for it in items) +
+                sum(it[0]._version + (it[1]._version if it[1] is not None else 0) for items in self._s2_groups.values() for it in items))
 
 
 def _arith_bf16x3():
@@ -359,6 +391,33 @@ def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None, dil=None):
     return dx
 
 
+def conv_fwd_s2_block(x, w, w_ds):
+    """Forward of a BasicBlock's stride-2 front in ONE launch (csrc/conv_s2.hip): (relu(conv(x; w, 3x3x3 stride 2 pad 1)),
+    conv(x; w_ds, 1x1 stride 2)).  None when the shape is not one of the encoder's two (the caller runs the generic launches)."""
+    if x.dim() != 5 or w_ds is None:
+        return None
+    n, g, g2, g3, ci = x.shape
+    co = w.shape[0]
+    lib = L.lib()
+    if not x.is_cuda or g != g2 or g != g3 or not lib.mi_conv3d_s2_fwd_usable(n, g, ci, co) or not (_phys_ok(w) and _phys_ok(w_ds)):
+        return None
+    _f32c(x, "x")
+    hmid = torch.empty((n, g // 2, g // 2, g // 2, co), dtype=torch.float32, device=x.device)
+    r = torch.empty_like(hmid)
+    img = ACTIVE_IMAGES.get_s2(w, False) if (ACTIVE_IMAGES is not None and PROFILE is None) else None
+    if img is not None:                                   # the engine keeps the image current: no image build here
+        L.check(lib.mi_conv3d_s2_fwd_img_f32(L.ptr(x), L.ptr(img), L.ptr(hmid), L.ptr(r), n, g, ci, co, L.stream()),
+                "mi_conv3d_s2_fwd_img_f32")
+        return hmid, r
+    ws = _ws(lib.mi_conv3d_s2_fwd_workspace_bytes(ci, co), x.device, "conv_s2f")
+    def call():
+        return L.check(lib.mi_conv3d_s2_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(w_ds), L.ptr(hmid), L.ptr(r), n, g, ci, co, L.ptr(ws),
+                                                ws.numel(), L.stream()), "mi_conv3d_s2_fwd_f32")
+    # algorithmic FLOPs of both convolutions the launch replaces (27 taps + the 1x1 shortcut)
+    _prof_run("fwd", 2.0 * hmid.numel() * ci * 28, call)
+    return hmid, r
+
+
 def conv_dgrad_s2_block(dh, d2, w, w_ds, in_shape, res=None, mask=None):
     """Data gradient of a BasicBlock's stride-2 front in ONE launch (csrc/conv_s2.hip): conv_dgrad(dh; w, 3x3x3 stride 2 pad 1)
     + conv_dgrad(d2; w_ds, 1x1 stride 2) (+ res), times (mask > 0).  Returns None when the shape is not one of the encoder's two
@@ -374,6 +433,11 @@ def conv_dgrad_s2_block(dh, d2, w, w_ds, in_shape, res=None, mask=None):
     if d2 is not None:
         _f32c(d2, "d2")
     dx = torch.empty(tuple(in_shape), dtype=torch.float32, device=dh.device)
+    img = ACTIVE_IMAGES.get_s2(w, True) if (ACTIVE_IMAGES is not None and PROFILE is None and d2 is not None) else None
+    if img is not None:                                   # the engine keeps the images current: no image build here
+        L.check(lib.mi_conv3d_s2_dgrad_img_f32(L.ptr(dh), L.ptr(d2), L.ptr(img), L.ptr(dx), L.ptr(res), L.ptr(mask), n, g, ci, co,
+                                               L.stream()), "mi_conv3d_s2_dgrad_img_f32")
+        return dx
     ws = _ws(lib.mi_conv3d_s2_dgrad_workspace_bytes(ci, co), dh.device, "conv_s2")
     def call():
         return L.check(lib.mi_conv3d_s2_dgrad_f32(L.ptr(dh), L.ptr(d2), L.ptr(w), L.ptr(w_ds), L.ptr(dx), L.ptr(res), L.ptr(mask), n, g,
@@ -1126,8 +1190,12 @@ class _BasicBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, w2, wds, blk, mask_dx=False, dout_masked=False):
         s = blk.stride
-        hmid = conv_fwd(x, w1, 3, s, 1, None, True)
-        r = conv_fwd(x, wds, 1, s, 0) if wds is not None else x
+        front = conv_fwd_s2_block(x, w1, wds) if (s == 2 and wds is not None) else None
+        if front is not None:
+            hmid, r = front                                  # stride-2 front: conv1 + ReLU and the shortcut in one launch
+        else:
+            hmid = conv_fwd(x, w1, 3, s, 1, None, True)
+            r = conv_fwd(x, wds, 1, s, 0) if wds is not None else x
         out = conv_fwd(hmid, w2, 3, 1, 1, r, True)
         ctx.blk = blk
         ctx.mask_dx, ctx.dout_masked = mask_dx, dout_masked

@@ -69,6 +69,18 @@ class MocoStepEngine:
                     imgs.add(group, m.weight, False)
                     if group == "q":
                         imgs.add(group, m.weight, True)
+            # the stride-2 block fronts (conv_s2.hip): forward image per encoder, data-gradient image for encoder_q
+            for blk in enc.modules():
+                ds = getattr(blk, "downsample", None)
+                if ds is None or getattr(blk, "stride", 1) != 2 or not hasattr(blk, "conv1"):
+                    continue
+                w, wds = blk.conv1.weight, ds[0].weight
+                co, ci = int(w.shape[0]), int(w.shape[1])
+                if (co, ci) not in ((128, 64), (256, 128)) or not (H._phys_ok(w) and H._phys_ok(wds)):
+                    continue
+                imgs.add_s2(group, w, wds, False)
+                if group == "q":
+                    imgs.add_s2(group, w, wds, True)
         self.moco.weight_images = imgs                 # MoCo re-cuts group "k" right behind its momentum update
         return imgs
 

@@ -424,6 +424,27 @@ size_t mi_conv3d_s2_dgrad_workspace_bytes(int Ci, int Co);
 int mi_conv3d_s2_dgrad_f32(const float* dh, const float* dout, const float* w, const float* w_ds, float* dx, const float* res,
                            const float* mask, int N, int Gi, int Ci, int Co, void* ws, size_t ws_bytes, mi_stream_t stream);
 
+/* Forward of the same block front in one launch (csrc/conv_s2.hip): hmid (N, Gi/2.., Co) = relu(conv3d(x; w [27][Ci][Co], k 3,
+ * stride 2, pad 1)) and the 1x1 stride-2 shortcut r (N, Gi/2.., Co) = conv3d(x; w_ds [Ci][Co]) - replaces two mi_conv3d_fwd_f32
+ * calls (models/networks/moco_encoder_3d.py:66-69,78-79: conv1 + relu, downsample).  `ws`: mi_conv3d_s2_fwd_workspace_bytes(Ci, Co)
+ * bytes - the call cuts the weight image into it.  mi_conv3d_s2_fwd_usable: 1 for the two encoder shapes, else 0. */
+int mi_conv3d_s2_fwd_usable(int N, int Gi, int Ci, int Co);
+size_t mi_conv3d_s2_fwd_workspace_bytes(int Ci, int Co);
+int mi_conv3d_s2_fwd_f32(const float* x, const float* w, const float* w_ds, float* hmid, float* r, int N, int Gi, int Ci, int Co,
+                         void* ws, size_t ws_bytes, mi_stream_t stream);
+
+/* Caller-kept images of the stride-2 fronts: mi_conv3d_s2_prep cuts the images of n fronts in one launch per 8 (host arrays of
+ * device pointers; w[i] [27][Ci][Co], w_ds[i] [Ci][Co] - may be NULL only for a data-gradient image of a block without
+ * shortcut -, img[i] of mi_conv3d_s2_fwd_workspace_bytes / mi_conv3d_s2_dgrad_workspace_bytes bytes, dgrad[i] 0 / 1); the _img_
+ * calls are mi_conv3d_s2_fwd_f32 / mi_conv3d_s2_dgrad_f32 without the image build (a training loop cuts the images once per
+ * weight update, behind its SGD / momentum kernel, instead of in front of every call). */
+int mi_conv3d_s2_prep(const float* const* w, const float* const* w_ds, void* const* img, const int* ci, const int* co,
+                      const int* dgrad, int n, mi_stream_t stream);
+int mi_conv3d_s2_fwd_img_f32(const float* x, const void* img, float* hmid, float* r, int N, int Gi, int Ci, int Co,
+                             mi_stream_t stream);
+int mi_conv3d_s2_dgrad_img_f32(const float* dh, const float* dout, const void* img, float* dx, const float* res,
+                               const float* mask, int N, int Gi, int Ci, int Co, mi_stream_t stream);
+
 /* models/moco.py:31-39: k <- m*k + (1-m)*q over a flat parameter arena (16-B aligned). */
 int mi_ema_update(float* k, const float* q, float m, long n, mi_stream_t stream);
 /* torch.optim.SGD (moco_main.py:79, no momentum): p <- p - lr*(grad_scale*g + wd*p).  lr_dev (device float,

@@ -29,3 +29,10 @@ for (gi, ci, co) in ((8, 64, 128), (4, 128, 256)):
         dres = H.conv_dgrad(d2, wd, shape, 1, 2, 0)
         return H.conv_dgrad(dh, w, shape, 3, 2, 1, dres, mask)
     print("grid %d  %d -> %d:  one launch %.1f us   generic %.1f us" % (gi, ci, co, timeit(fused), timeit(generic)))
+    # forward of the same front: relu(conv) + shortcut
+    x = torch.randn(n, gi, gi, gi, ci, device="cuda")
+    def generic_f():
+        return H.conv_fwd(x, w, 3, 2, 1, None, True), H.conv_fwd(x, wd, 1, 2, 0)
+    for narrow in ("0", "1"):
+        os.environ["MI_S2FWD_NARROW"] = narrow
+        print("   forward (narrow=%s): one launch %.1f us   generic %.1f us" % (narrow, timeit(lambda: H.conv_fwd_s2_block(x, w, wd)), timeit(generic_f)))
