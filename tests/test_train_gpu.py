@@ -354,6 +354,46 @@ def test_encoder_matches_reference_golden(golden):
     np.testing.assert_allclose(ev.cpu().numpy(), g["proj_eval"], rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("crop,batch", [(48, 3), (64, 2), (40, 2)])
+def test_encoder_other_crop_sizes_match_oracle(crop, batch):
+    """The reference encoder is shape-agnostic (moco_encoder_3d.py:156-236); the patch-resident kernels are built for the 32^3
+    crops of the benchmark.  Other crop sizes take the stem kernel where its tiling divides the volume and the implicit GEMM
+    elsewhere: forward and every parameter gradient against the CPU oracle, float64-arbitrated (VERDICT r2 item 8's test half)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle import train_ref as T
+    from conftest import f32_equivalent
+    enc = _seeded_encoder()
+    enc.train()
+    sd = {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}
+    gen = torch.Generator().manual_seed(crop)
+    x = torch.randn(batch, 1, crop, crop, crop, generator=gen)
+    wv = torch.linspace(-1, 1, 128)
+    def run_ref(dt):
+        sdr = {k: (v.to(dt).clone().requires_grad_(k.endswith((".weight", ".bias"))) if v.is_floating_point() else v.clone())
+               for k, v in sd.items()}
+        out = T.encoder_forward(sdr, x.to(dt), train=True)
+        loss = (out * wv.to(dt)[None]).sum() + (out ** 2).sum() * 0.1
+        loss.backward()
+        return out.detach(), {k: v.grad for k, v in sdr.items() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None}
+    o32, g32 = run_ref(torch.float32)
+    o64, g64 = run_ref(torch.float64)
+    out = enc(x.cuda())[0]["proj"]
+    loss = (out * wv.cuda()[None]).sum() + (out ** 2).sum() * 0.1
+    loss.backward()
+    f32_equivalent(out.detach().cpu().numpy(), o32.numpy(), o64.numpy(), floor=2e-5, what="proj at crop %d" % crop)
+    gscale = float(sum(float(v.norm()) ** 2 for v in g64.values()) ** 0.5)
+    checked = 0
+    for n, p in enc.named_parameters():
+        if n not in g64 or n == "fc.bias" or n.startswith("pred."):
+            continue
+        floor = 5e-5 * gscale / (float(g64[n].norm()) + 1e-30) + 2e-5
+        f32_equivalent(p.grad.detach().cpu().contiguous().numpy(), g32[n].numpy(), g64[n].numpy(), floor=floor, factor=3.0,
+                       what="crop %d grad %s" % (crop, n))
+        checked += 1
+    assert checked >= 25
+
+
 def test_state_dict_roundtrip_with_reference_layout(tmp_path):
     """Checkpoints keep the reference's keys and logical shapes; values survive save -> load."""
     enc = _seeded_encoder()
