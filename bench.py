@@ -319,6 +319,16 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 
+    # The one JSON line is the only thing this process writes to its stdout: RCCL prints a version banner to fd 1 at
+    # communicator setup (and any other native library might), so fd 1 is pointed at stderr and the line goes out through a
+    # saved duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -420,10 +430,10 @@ def main():
     step_nodes = engine.node_counts() if engine.use_graph else None
     if args.no_conv_profile:
         if rank == 0:
-            print(json.dumps({"metric": "subtomograms/sec (MoCo-3D train) + voxels/sec (heatmap+NMS) at 1/2/4/8 GPU",
-                              "value": B * world * args.steps / dt, "unit": "subtomograms/sec", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                              "step_graph_nodes": step_nodes, "note": "--no-conv-profile: no roofline pass"}), flush=True)
+            emit({"metric": "subtomograms/sec (MoCo-3D train) + voxels/sec (heatmap+NMS) at 1/2/4/8 GPU",
+                  "value": B * world * args.steps / dt, "unit": "subtomograms/sec", "n_gpus": world,
+                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                  "step_graph_nodes": step_nodes, "note": "--no-conv-profile: no roofline pass"})
         if dist_active:
             dist.barrier()
             engine.close()
@@ -517,7 +527,7 @@ def main():
                                    "sample": "4 MoCo steps of batch 64 (after 1 warm-up) of the same workload "
                                              "with oracle/train_ref.py (torch fp32, all host cores)"}
     if rank == 0:
-        print(json.dumps(out), flush=True)           # the line is out before any tear-down
+        emit(out)                                    # the line is out before any tear-down
     if dist_active:
         # tear-down in dependency order: the captured hipGraph (it holds the RCCL kernels and the events of the async
         # work handles recorded during capture) goes before the communicator it refers to
