@@ -12,9 +12,9 @@ mkdir -p $O/pmc_traffic $O/pmc_busy
 rm -rf $O/pmc_traffic/* $O/pmc_busy/*
 cp -r $O/pmc_train/FETCH_SIZE $O/pmc_train/WRITE_SIZE $O/pmc_traffic/
 cp -r "$O/pmc_train/SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE" $O/pmc_busy/
-python tools/pmc_summary.py $O/pmc_traffic profiles/${T}_conv_traffic.json --sources conv_ --per-step 9 --kernels conv_igemm,stem_,direct3,splitk,cube2,pair_wgrad,s2_dgrad,small_gemm \
+python tools/pmc_summary.py $O/pmc_traffic profiles/${T}_conv_traffic.json --sources conv_ --per-step 9 --kernels conv_igemm,stem_,direct3,splitk,cube2,pair_wgrad,s2_,small_gemm \
   --note "bench.py --no-secondary --no-cpu-baseline --no-conv-profile --no-graph --steps 6 --warmup 3 (9 eager steps): the conv family of the MoCo-3D step" > /dev/null
-python tools/pmc_summary.py $O/pmc_busy profiles/${T}_mfma_busy.json --sources conv_,loss_ --per-step 9 --kernels conv_igemm,stem_,direct3,cube2,pair_wgrad,s2_dgrad \
+python tools/pmc_summary.py $O/pmc_busy profiles/${T}_mfma_busy.json --sources conv_,loss_ --per-step 9 --kernels conv_igemm,stem_,direct3,cube2,pair_wgrad,s2_,small_gemm \
   --note "same run; SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE in one pass" > /dev/null
 if [ -f $O/graph/out_kernel_trace.csv ]; then python tools/trace_timeline.py $O/graph/out_kernel_trace.csv 2 > profiles/${T}_step_timeline.txt; fi
 python - <<PY
