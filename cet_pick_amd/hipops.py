@@ -720,12 +720,14 @@ class _LinearFn(torch.autograd.Function):
         if mod.bias is not None and mod.bias.requires_grad:
             g, acc = _grad_target(mod.bias)
             tgt = torch.empty_like(g) if acc else g
-            ws = _ws(lib.mi_colreduce_workspace_bytes(m, co), x.device, "colreduce")
-            sums = torch.empty(2 * co, dtype=torch.float64, device=x.device)
-            L.check(lib.mi_colsum(L.ptr(dy), m, co, L.ptr(tgt), L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()),
-                    "mi_colsum")
-            if acc:
-                g.add_(tgt)
+            def launch_b(g=g, acc=acc, tgt=tgt):       # the bias gradient is a parameter gradient too: same side-stream batch
+                ws = _ws(lib.mi_colreduce_workspace_bytes(m, co), x.device, "colreduce")
+                sums = torch.empty(2 * co, dtype=torch.float64, device=x.device)
+                L.check(lib.mi_colsum(L.ptr(dy), m, co, L.ptr(tgt), L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()),
+                        "mi_colsum")
+                if acc:
+                    g.add_(tgt)
+            _side_or_now(launch_b, m)
         dx = None
         if ctx.x_needs_grad:
             dx = conv_dgrad(dy.view(m, 1, 1, 1, co), _as5(mod.weight), (m, 1, 1, 1, ci), 1, 1, 0).view(m, ci)
