@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512, OCC) void s2_dgrad_kernel(S2DgradParams p) {
     constexpr int SPT = KS / KW;                        // ... of one wave
     static_assert(SPT == 4 && (RING == 4 || RING == 8), "one or two taps per ring round");
     constexpr int TPR = RING / SPT;                     // taps per ring round (RING weight fragments in flight per wave)
-    constexpr int ARR = (NV + 16) * 16;                 // one (k-step, plane, k-half) array: records + 16 zero records
+    constexpr int ARR = (NV + 18) * 16;                 // one (k-step, plane, k-half) array: records + 16 zero records (+ 2: the k-half arrays 32 bytes apart mod 128, no bank shared by the two lane halves)
     constexpr int LDS_BYTES = KS * 6 * ARR;
     constexpr int WSTEP = CB * 3 * S2_WBLK;             // bytes per k-step of the image
     static_assert(LDS_BYTES >= 4 * 16 * 64 * 4 * (KW - 1), "the reduction buffer fits the patch");
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512, OCC) void s2_fwd_kernel(S2FwdParams p) {
     constexpr int SPW = RBK * 32 / VO;                  // samples per workgroup
     static_assert(SPW >= 1 && SPW * VO == RBK * 32 && RBK * CBW * KW == 8, "rows of whole samples, eight waves");
     constexpr int NV = SPW * VI;                        // patch records per array
-    constexpr int ARR = (NV + 16) * 16;                 // + 16 zero records
+    constexpr int ARR = (NV + 18) * 16;                 // + 16 zero records (+ 2: the two k-half arrays 32 bytes apart mod 128)
     constexpr int SLOT = 6 * ARR;                       // one k-step of the patch: (plane, k-half) arrays
     constexpr int KS = CI / 16, CB = CO / 32;
     // 28 entries (27 taps + the shortcut) in equal ranges over the KW wave groups; KW = 8 pads to 32 (four idle steps)
