@@ -9,7 +9,8 @@
 // spend their issue slots on the cut, the gather addresses and LDS traffic).  Here the INPUT PATCH of a tile is cut once
 // and stays in LDS for all 27 taps:
 //   * one 256-thread workgroup owns two z-planes of one sample (128 output voxels x 64 channels); its patch is the four
-//     z-planes around them (256 voxels x 64 channels, three bf16 planes = 96 KB + zero regions = 115 KB of LDS), planes
+//     z-planes around them (256 voxels x 64 channels, three bf16 planes = 96 KB + zero regions = 115 KB of LDS with every
+//     16-channel chunk resident; round 3: a ring of TWO chunks, 59 KB, so that two workgroups share a CU), planes
 //     outside the volume zero-filled.  The 8 x 8 plane is the whole image, so the x / y halo is pure padding: a lane
 //     whose neighbour falls outside reads a zero record instead (one address select per tap and row block, no data
 //     select).
@@ -96,8 +97,13 @@ __device__ __forceinline__ void cut8(const float (&v)[8], u32x4 (&o)[3]) {
 
 // (Measured and rejected: eight waves per workgroup - two quartets splitting the reduction over the same tile, two waves
 // per SIMD, partial sums exchanged through LDS at the end - 36.9 us against 32.3 us for this form.)
-__global__ __launch_bounds__(256, 1) void direct3_kernel(Direct3Params p) {
-    __shared__ __attribute__((aligned(16))) unsigned char patch[LDS_BYTES];
+// TWO: only two channel chunks of the patch are resident (a ring of two slots: 59 KB), the residual / mask operands of the
+// epilogue are fetched IN the epilogue instead of during the last chunk (64 registers less), so that two workgroups share a CU
+// (256 registers each) and one's prologue / epilogue runs under the other's MFMA loop.
+template <bool TWO>
+__global__ __launch_bounds__(256, TWO ? 2 : 1) void direct3_kernel(Direct3Params p) {
+    constexpr int NSLOT = TWO ? 2 : KS;
+    __shared__ __attribute__((aligned(16))) unsigned char patch[NSLOT * KS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l32 = lane & 31;
     const int tz = wave >> 1, cw = wave & 1;             // wave tile: z-plane tz of the pair x column half cw
@@ -157,14 +163,14 @@ __global__ __launch_bounds__(256, 1) void direct3_kernel(Direct3Params p) {
             for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ld[u][0][e]); v[4 + e] = __uint_as_float(ld[u][1][e]); }
             u32x4 o[3];
             cut8(v, o);
-            unsigned char* dst = patch + c * KS_BYTES + st_lds[u];
+            unsigned char* dst = patch + (c % NSLOT) * KS_BYTES + st_lds[u];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * PL_BYTES) = o[pl];
         }
     };
     stage_load(0);
     // zero regions of the 24 arrays (the leading records are never read)
-    for (int i = tid; i < KS * 3 * 2 * ZREC; i += 256) {
+    for (int i = tid; i < NSLOT * 3 * 2 * ZREC; i += 256) {
         const int arr = i / ZREC, r = i % ZREC;
         *reinterpret_cast<u32x4*>(patch + arr * ARR + ZBASE + r * 16) = u32x4{0u, 0u, 0u, 0u};
     }
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void direct3_kernel(Direct3Params p) {
     };
     auto frags = [&](int c, int t9, auto SETc) {
         constexpr int SET = decltype(SETc)::value;
-        const int imm = ((t9 / 3) * 8 + (t9 % 3)) * 16 + c * KS_BYTES;
+        const int imm = ((t9 / 3) * 8 + (t9 % 3)) * 16 + (c % NSLOT) * KS_BYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void direct3_kernel(Direct3Params p) {
                     stage_store(c + 1);
                     if (c + 2 < KS) stage_load(c + 2);
                 }
-                if (c == KS - 1 && dz == 0 && t9 == 0) {
+                if (!TWO && c == KS - 1 && dz == 0 && t9 == 0) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -291,6 +297,27 @@ __global__ __launch_bounds__(256, 1) void direct3_kernel(Direct3Params p) {
 
     // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h ----
     const bool has_mask = p.mask != nullptr;
+    if constexpr (TWO) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float rr[16], mm[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned eo = 4u * (unsigned)((m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * C + col);
+                rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, (int)eo, 0, 0));
+                mm[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mrs, (int)eo, 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned eo = 4u * (unsigned)((m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * C + col);
+                float v = acc[i][r] + rr[r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (has_mask) v = (mm[r] > 0.f) ? v : 0.f;
+                p.out[eo / 4] = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -823,7 +850,10 @@ int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, c
 int mi_direct3_launch(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
                       int D, hipStream_t s) {
     Direct3Params p = {a, (const unsigned char*)wimg, out, res, mask, relu, N, D, (unsigned)(4l * N * D * PLANE * C)};
-    hipLaunchKernelGGL(direct3_kernel, dim3((unsigned)(N * (D / TZ))), dim3(256), 0, s, p);
+    // two resident chunks / two workgroups per CU by default (captured step 1.628 against 1.649 ms, r03_experiments.txt item 20);
+    // MI_DIRECT3_FOUR_SLOTS=1: the whole patch resident, one workgroup per CU
+    if (getenv("MI_DIRECT3_FOUR_SLOTS")) hipLaunchKernelGGL(direct3_kernel<false>, dim3((unsigned)(N * (D / TZ))), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(direct3_kernel<true>, dim3((unsigned)(N * (D / TZ))), dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
