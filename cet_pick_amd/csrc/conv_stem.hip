@@ -195,9 +195,12 @@ __global__ __launch_bounds__(256) void stem_wprep_kernel(const float* w, unsigne
     out[o] = (unsigned short)h0; out[o + WPL / 2] = (unsigned short)h1; out[o + WPL] = (unsigned short)h2;
 }
 
-__global__ __launch_bounds__(256, 2) void stem_fwd_bf3_kernel(StemParams p, const unsigned char* wprep) {
+// NBUF = 2: the kz slabs of the weights alternate between two LDS buffers (75 KB, two workgroups per CU); NBUF = 1: one buffer
+// (51 KB, THREE workgroups per CU), the next slab stored between two barriers under the last k-step's MFMAs.
+template <int NBUF>
+__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void stem_fwd_bf3_kernel(StemParams p, const unsigned char* wprep) {
     __shared__ __attribute__((aligned(16))) unsigned char patchb[3 * PPLANE];
-    __shared__ __attribute__((aligned(16))) unsigned char wl[2][WSLAB];
+    __shared__ __attribute__((aligned(16))) unsigned char wl[NBUF][WSLAB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l32 = lane & 31;
     const int txn = p.Wo / TX, tyn = p.Ho / TY, tzn = p.Do / TZ;
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_bf3_kernel(StemParams p, cons
     bf16x8 af[2][3], bf0[2][3], bf1[2][3];
     auto frags = [&](int kz, int u, auto SETc) {
         constexpr int SET = decltype(SETc)::value;
-        const unsigned char* wb = wl[kz & 1] + b_base + u * (2 * CO * 16);
+        const unsigned char* wb = wl[kz % NBUF] + b_base + u * (2 * CO * 16);
         const unsigned char* ab = patchb + a_base + (kz * PYP + 2 * u) * PROW;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
@@ -302,10 +305,12 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_bf3_kernel(StemParams p, cons
     __syncthreads();
     frags(0, 0, S0{});
     for (int kz = 0; kz < K7; ++kz) {
-        // slab kz+1 (in registers since the previous iteration) -> the other buffer (last read during kz-1, before the
-        // barrier that ended it); then fetch slab kz+2
-        if (kz + 1 < K7) wstore((kz + 1) & 1);
-        wload(kz + 2);
+        if constexpr (NBUF == 2) {
+            // slab kz+1 (in registers since the previous iteration) -> the other buffer (last read during kz-1, before the
+            // barrier that ended it); then fetch slab kz+2
+            if (kz + 1 < K7) wstore((kz + 1) & 1);
+            wload(kz + 2);
+        }
         __builtin_amdgcn_sched_barrier(0);
         frags(kz, 1, S1{});
         __builtin_amdgcn_sched_barrier(0);
@@ -318,10 +323,20 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_bf3_kernel(StemParams p, cons
         frags(kz, 3, S1{});
         __builtin_amdgcn_sched_barrier(0);
         mfmas(S0{});
-        __syncthreads();                                   // slab kz+1 visible; slab kz fully read
-        if (kz + 1 < K7) frags(kz + 1, 0, S0{});
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(S1{});
+        __syncthreads();                                   // NBUF 2: slab kz+1 visible; both: slab kz fully read
+        if constexpr (NBUF == 1) {
+            // slab kz+1 (in registers) over slab kz, under the last k-step's MFMAs; then fetch slab kz+2
+            if (kz + 1 < K7) wstore(0);
+            wload(kz + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(S1{});
+            __syncthreads();                               // slab kz+1 visible
+            if (kz + 1 < K7) frags(kz + 1, 0, S0{});
+        } else {
+            if (kz + 1 < K7) frags(kz + 1, 0, S0{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(S1{});
+        }
     }
 
     // ---- epilogue: C/D layout col = lane & 31 (channel), row = (r&3) + 8*(r>>2) + 4*h (output voxel) ----
@@ -784,7 +799,9 @@ int mi_stem7_fwd(const float* x, const float* w, float* y, const float* res, int
         if (sums) p.stats = reinterpret_cast<double*>((unsigned char*)ws + ((WPREP_BYTES + 255) & ~(size_t)255));
         hipLaunchKernelGGL(stem_wprep_kernel, dim3((K7 * 8 * CO * 8 + 255) / 256), dim3(256), 0, s, w, (unsigned short*)ws);
         MI_RETURN_IF_LAUNCH_FAILED();
-        hipLaunchKernelGGL(stem_fwd_bf3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, (const unsigned char*)ws);
+        // one weight buffer / three workgroups per CU by default (captured step 1.632 against 1.646 ms, r03_experiments.txt item 23)
+        if (getenv("MI_STEM_FWD_NBUF2")) hipLaunchKernelGGL(stem_fwd_bf3_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, p, (const unsigned char*)ws);
+        else hipLaunchKernelGGL(stem_fwd_bf3_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, p, (const unsigned char*)ws);
         MI_RETURN_IF_LAUNCH_FAILED();
         if (sums) {
             hipLaunchKernelGGL(stem_stats_finalize_kernel, dim3(2 * CO), dim3(256), 0, s, (const double*)p.stats, (int)blocks,
