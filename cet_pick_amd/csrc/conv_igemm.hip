@@ -1157,6 +1157,9 @@ size_t direct3_ws_bytes(const Geom& g) {
 // defer_splits != null (weight gradients only): a split launch leaves its slabs in `ws` un-reduced and reports the split
 // count - the caller sums many layers' slabs in one mi_splitk_reduce_batch launch; an unsplit launch (or the stem,
 // which reduces by itself) reports 1 and `out` is final.
+// measurement aid (tools/bench_conv.py --kernels): the kernel family the last convolution call of this thread dispatched to
+thread_local const char* g_last_conv_kernel = "none";
+
 int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, float* out,
              const float* res, const float* mask, int relu, void* ws, size_t ws_bytes, hipStream_t s,
              int* defer_splits = nullptr, int res_bcast = 0) {
@@ -1184,7 +1187,7 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
                               ws_bytes, s);
         else if (mode == MODE_WGRAD) rc = mi_stem7_wgrad(a_src, b_src, out, g.N, g.Di, g.Hi, g.Wi, g.Co,
                                                          (conv_arith_bf16x3() && !env_int("MI_STEM_WGRAD_F32")) ? 1 : 0, ws, ws_bytes, s);
-        if (rc != MI_E_UNSUPPORTED) return rc;
+        if (rc != MI_E_UNSUPPORTED) { g_last_conv_kernel = mode == MODE_FWD ? "stem_fwd" : "stem_wgrad"; return rc; }
     }
     // layer1-shaped convolutions (3^3, stride 1, 64 -> 64 channels, 8 x 8 planes): patch-resident direct kernel; the
     // weight image goes into `ws` (a short ws keeps the implicit GEMM)
@@ -1192,6 +1195,7 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
     if (conv_arith_bf16x3() && g.Di == 1 && g.Hi == 1 && g.Wi == 1 && g.kd == 1 && g.kh == 1 && g.kw == 1 && g.stride == 1 &&
         g.pd == 0 && g.ph == 0 && g.pw == 0 && !mask && !relu && (!res || res_bcast)) {
         const long xe = (long)g.N * g.Ci, ye = (long)g.N * g.Co, we = (long)g.Ci * g.Co;
+        g_last_conv_kernel = "small_gemm";
         if (mode == MODE_FWD && mi_small_gemm_usable(g.N, g.Co, g.Ci))
             return mi_small_gemm_launch(a_src, g.Ci, 1, xe, b_src, g.Co, 1, we, res, out, g.N, g.Co, g.Ci, s);
         if (mode == MODE_DGRAD && !res && mi_small_gemm_usable(g.N, g.Ci, g.Co))
@@ -1207,6 +1211,7 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         const int dg[1] = {mode == MODE_DGRAD ? 1 : 0}, ch[1] = {g.Ci};
         int rc = mi_direct3_prep(wl, il, dg, ch, 1, s);
         if (rc) return rc;
+        g_last_conv_kernel = dkind == 1 ? "direct3" : "direct3s + reduce";
         if (dkind == 1) return mi_direct3_launch(a_src, ws, out, res, mask, relu, g.N, g.Di, s);
         float* slabs = (float*)((char*)ws + dimg);               // 128-channel kernel: split-K slabs behind the image
         rc = mi_direct3s_launch(a_src, ws, slabs, g.N, s);
@@ -1215,6 +1220,7 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
                                        relu, s);
     }
     if (mode != MODE_WGRAD && conv_arith_bf16x3() && is_cube2(g) && ws && ws_bytes >= mi_cube2_slab_bytes(g.N, g.Ci)) {
+        g_last_conv_kernel = "cube2 + reduce";
         int rc = mi_cube2_launch(mode == MODE_DGRAD ? 1 : 0, a_src, b_src, (float*)ws, g.N, g.Ci, s);
         if (rc) return rc;
         return mi_direct3_finish_slabs((const float*)ws, mi_cube2_splits(), (long)g.N * 8 * g.Ci, out, res, mask, relu, s);
@@ -1222,8 +1228,12 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
     // weight gradients of the convolutions with a 2 x 2 x 2 output (layer3, feature_3d, layer3.0.conv1): final in one launch
     if (mode == MODE_WGRAD && conv_arith_bf16x3() &&
         mi_pair_wgrad_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw))
+    {
+        g_last_conv_kernel = "pair_wgrad";
         return mi_pair_wgrad_launch(a_src, b_src, out, g.N, g.Di, g.Ci, g.Co, g.stride, s);
+    }
     if (mode == MODE_WGRAD && dkind == 1 && ws && ws_bytes >= mi_direct3_wgrad_slab_bytes()) {
+        g_last_conv_kernel = "direct3_wgrad + reduce";
         int rc = mi_direct3_wgrad_launch(a_src, b_src, (float*)ws, g.N, g.Di, s);
         if (rc) return rc;
         const int splits = mi_direct3_wgrad_splits();
@@ -1237,6 +1247,7 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
     Setup st;
     int rc = setup_conv(mode, g, &st);
     if (rc) return rc;
+    g_last_conv_kernel = st.pl.splits > 1 ? "implicit GEMM + reduce" : "implicit GEMM";
     ConvParams& p = st.p;
     Plan& pl = st.pl;
     p.a_src = a_src; p.b_src = b_src; p.res = res; p.mask = mask; p.relu = relu;
@@ -1298,6 +1309,9 @@ extern "C" int mi_conv3d_fwd_f32(const float* x, const float* w, float* y, const
     if (!x || !w || !y || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
     return run_conv(MODE_FWD, g, x, w, y, res, nullptr, relu, ws, ws_bytes, (hipStream_t)stream);
 }
+
+/* measurement aid: the kernel family the last mi_conv* call of the calling thread ran ("direct3", "cube2 + reduce", ...) */
+extern "C" const char* mi_debug_last_conv_kernel(void) { return g_last_conv_kernel; }
 
 /* nn.Linear (+ bias) followed by training-mode nn.BatchNorm1d (+ ReLU) in ONE launch - the projection MLP of the MoCo-3D
  * encoder (models/networks/moco_encoder_3d.py:238-255: Linear, BatchNorm1d, ReLU three times over a batch of <= 64 rows).

@@ -40,6 +40,8 @@ int mi_abi_version(void);
 int mi_graph_node_counts(void* graph, int* counts);
 /* measurement aid: a one-thread launch that writes the 100 MHz wall clock into *slot (device uint64) */
 int mi_debug_stamp(void* slot, mi_stream_t stream);
+/* measurement aid: the kernel family the last mi_conv* call of the calling thread dispatched to (tools/bench_conv.py) */
+const char* mi_debug_last_conv_kernel(void);
 /* gfx target the code objects were built for, e.g. "gfx950". */
 const char* mi_build_arch(void);
 
