@@ -760,3 +760,25 @@ def test_linear_bn_one_launch_matches_two_launches_and_torch(m, ci, co, relu, bi
         scale = max(np.abs(r).max(), 0.05)                   # (a Linear bias in front of a BatchNorm has a zero gradient)
         assert np.abs(a - b).max() <= 2e-6 * scale           # same arithmetic, another summation order of the statistics
         assert np.abs(a - r).max() <= 2e-5 * scale
+
+
+@pytest.mark.gpu
+def test_conv_dispatch_by_shape(monkeypatch):
+    """Which kernel family a convolution call takes (mi_debug_last_conv_kernel; tools/bench_conv.py --kernels prints the table):
+    the encoder's shapes at the benchmark's crop size take the patch-resident kernels, other shapes the implicit GEMM, and the
+    A/B switches move them."""
+    from cet_pick_amd import hipops as H, _lib as L
+    lib = L.lib()
+    def fwd(n, d, ci, co, k=3, s=1, p=1):
+        x = torch.randn(n, d, d, d, ci, device="cuda")
+        w = H.conv_weight_param(co, ci, k); w.data = w.data.cuda(); w.data.normal_()
+        H.conv_fwd(x, w, k, s, p)
+        return lib.mi_debug_last_conv_kernel().decode()
+    monkeypatch.delenv("MI_CONV_NO_DIRECT", raising=False)
+    assert fwd(4, 32, 1, 64, 7, 2, 3) == "stem_fwd"
+    assert fwd(4, 8, 64, 64) == "direct3"
+    assert fwd(4, 4, 128, 128).startswith("direct3s")
+    assert fwd(4, 2, 256, 256).startswith("cube2")
+    assert fwd(2, 16, 64, 64).startswith("implicit GEMM")          # layer1 of a 64^3 crop
+    monkeypatch.setenv("MI_CONV_NO_DIRECT", "1")
+    assert fwd(4, 8, 64, 64).startswith("implicit GEMM")
