@@ -239,7 +239,16 @@ class MocoStepEngine:
         graph = torch.cuda.CUDAGraph(keep_graph=True)      # the hipGraph_t stays queryable (node_counts)
         err = None
         try:
-            with torch.cuda.graph(graph):             # records, does not execute
+            # Data parallel: the process group's watchdog THREAD polls (hipEventQuery) the works of the eager warm-up steps
+            # at its own pace; under the default "global" capture mode such a call from another thread while this one is
+            # capturing is an error that terminates the process (hipErrorStreamCaptureUnsupported: seen once in ~20 runs of
+            # the one-rank rehearsal).  "thread_local" restricts only the capturing thread - which issues everything the
+            # step needs - and the short drain lets the watchdog retire the finished works first.
+            mode = "thread_local" if self.dist_on else "global"
+            if self.dist_on:
+                import time
+                time.sleep(0.25)
+            with torch.cuda.graph(graph, capture_error_mode=mode):       # records, does not execute
                 self._step_eager(self._static_q, self._static_k)
         except Exception as e:                        # e.g. a collective that cannot be captured
             if not self.dist_on:
