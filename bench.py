@@ -163,7 +163,14 @@ def inference_secondary(dev, with_cpu=True, rank=0, world=1):
         # "ms_hipgraph > ms_eager" for the decode: eager launches are queued ahead of the GPU, single replays are not)
         GREPS = 8
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # N > 1: the process group's watchdog thread polls its finished works with hipEventQuery at its own pace; inside a
+        # "global" mode capture that call from another thread is fatal (MocoStepEngine._capture) - thread_local mode, and a
+        # short drain so that the barrier's works are retired first
+        import torch.distributed as _dist
+        pg = _dist.is_available() and _dist.is_initialized()
+        if pg:
+            time.sleep(0.25)
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if pg else "global"):
             for _ in range(GREPS):
                 fn()
         g.replay()
