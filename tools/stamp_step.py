@@ -12,14 +12,25 @@ from cet_pick_amd.models.networks.moco_encoder_3d import get_moco_net_small_3d
 from cet_pick_amd.models.moco import MoCo
 from cet_pick_amd.trains.moco_engine import MocoStepEngine
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-R = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+ARGS = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(ARGS[0]) if len(ARGS) > 0 else 64
+R = int(ARGS[1]) if len(ARGS) > 1 else 50
+DIST = "--dist" in sys.argv          # the N>1 code path on a 1-rank RCCL group (every collective issued and captured)
+if DIST:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29657")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    H.FORCE_COLLECTIVES = True
 
 
 def build(stamps):
     torch.manual_seed(5)
     heads = {"proj": 256, "pred": 256}
     moco = MoCo(get_moco_net_small_3d(18, heads, 0), get_moco_net_small_3d(18, heads, 0), dim=128, r=1024, m=0.99, T=0.1).cuda()
+    if DIST:
+        H.convert_sync_batchnorm(moco)
     moco.train()
     eng = MocoStepEngine(moco, lr=1e-3, use_graph=True)
     if stamps:
@@ -84,3 +95,6 @@ print("   t_us   stamp")
 for i in order:
     print("%8.1f  %s" % (acc[i], names[base + i]))
 eng.close()
+if DIST:
+    dist.barrier()
+    dist.destroy_process_group()
