@@ -19,6 +19,7 @@ SIGNATURES = {
     "mi_abi_version": (_I, []),
     "mi_graph_node_counts": (_I, [_P, _P]),
     "mi_debug_stamp": (_I, [_P, _P]),
+    "mi_linear_stats_fwd_f32": (_I, [_P] * 5 + [_I] * 3 + [_P]),
     "mi_debug_last_conv_kernel": (_c.c_char_p, []),
     "mi_linear_bn_fwd_f32": (_I, [_P] * 5 + [_I] * 3 + [_P, _P, _F, _F] + [_P] * 4 + [_I, _P]),
     "mi_conv3d_stem_stats_workspace_bytes": (_Z, [_I] * 5),

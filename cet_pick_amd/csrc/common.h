@@ -29,6 +29,8 @@ struct MiSmallGemmBN {
     long long* num_batches_tracked;     // may be null
     float* save;              // mean[N], invstd[N]
     int relu;
+    double* sums_only;        // not null: ONLY the column sums of C (sum[N], sum of squares[N], doubles) are produced - the
+                              // statistics pass of a SyncBN whose all-reduce and apply follow as launches of their own
 };
 static inline int mi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -339,6 +339,7 @@ struct SmallGemmParams {
     long long* num_batches_tracked;     // may be null
     float* save;              // mean[N], invstd[N]
     int relu;
+    double* sums_only;        // not null (with bn_y null): write the column sums of C instead (SyncBN's statistics pass)
 };
 
 template <bool A_KC, bool B_KC, int NS>     // operand is k-contiguous (16-byte loads) or strided (8 dwords); NS k-steps per wave
@@ -450,13 +451,17 @@ __global__ __launch_bounds__(256, 2) void small_gemm_kernel(SmallGemmParams p) {
             cs += (double)tv[j]; css += (double)tv[j] * (double)tv[j];
         }
     }
-    if (p.bn_y) {                                        // (uniform: a launch argument)
+    if (p.bn_y || p.sums_only) {                         // (uniform: launch arguments)
         __shared__ double bred[4][2][32];
         cs += __shfl_xor(cs, 32, 64); css += __shfl_xor(css, 32, 64);
         if (h == 0) { bred[wave][0][l32] = cs; bred[wave][1][l32] = css; }
         __syncthreads();
         const double S = (bred[0][0][l32] + bred[1][0][l32]) + (bred[2][0][l32] + bred[3][0][l32]);
         const double SS = (bred[0][1][l32] + bred[1][1][l32]) + (bred[2][1][l32] + bred[3][1][l32]);
+        if (p.sums_only) {                               // SyncBN: this rank's sums; the all-reduce and the apply follow
+            if (wave == 0 && h == 0 && col_ok) { p.sums_only[n0 + l32] = S; p.sums_only[p.N + n0 + l32] = SS; }
+            return;
+        }
         const double mean = S / p.M;
         double var = SS / p.M - mean * mean;
         if (var < 0) var = 0;
@@ -560,10 +565,12 @@ bool mi_small_gemm_usable(long M, long N, long K) {
 int mi_small_gemm_launch(const float* a, long lda_m, long lda_k, long a_elems, const float* b, long ldb_k, long ldb_n,
                          long b_elems, const float* bias, float* c, int M, int N, int K, hipStream_t s, const MiSmallGemmBN* bn) {
     if (4 * a_elems >= 0x7fff0000l || 4 * b_elems >= 0x7fff0000l) return MI_E_UNSUPPORTED;
-    if (bn && (M > 64 || !bn->y || !bn->save || (bn->running_mean == nullptr) != (bn->running_var == nullptr))) return MI_E_UNSUPPORTED;
+    if (bn && M > 64) return MI_E_UNSUPPORTED;
+    if (bn && !bn->sums_only && (!bn->y || !bn->save || (bn->running_mean == nullptr) != (bn->running_var == nullptr))) return MI_E_UNSUPPORTED;
     SmallGemmParams p = {a, b, bias, c, M, N, K, lda_m, lda_k, ldb_k, ldb_n, (unsigned)(4 * a_elems), (unsigned)(4 * b_elems)};
-    p.bn_y = nullptr;
-    if (bn) {
+    p.bn_y = nullptr; p.sums_only = nullptr;
+    if (bn && bn->sums_only) p.sums_only = bn->sums_only;
+    else if (bn) {
         p.bn_y = bn->y; p.gamma = bn->gamma; p.beta = bn->beta; p.eps = bn->eps; p.momentum = bn->momentum;
         p.running_mean = bn->running_mean; p.running_var = bn->running_var; p.num_batches_tracked = bn->num_batches_tracked;
         p.save = bn->save; p.relu = bn->relu;

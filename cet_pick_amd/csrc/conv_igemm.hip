@@ -1325,7 +1325,21 @@ extern "C" int mi_linear_bn_fwd_f32(const float* x, const float* w, const float*
     if (!x || !w || !xlin || !y || !save_mean_invstd || M <= 0 || Ci <= 0 || Co <= 0) return MI_E_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MI_E_ARG;
     if (M > 64 || !conv_arith_bf16x3() || !mi_small_gemm_usable(M, Co, Ci) || env_int("MI_NO_LINEAR_BN")) return MI_E_UNSUPPORTED;
-    MiSmallGemmBN bn = {y, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean_invstd, relu};
+    MiSmallGemmBN bn = {y, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean_invstd, relu,
+                        nullptr};
+    return mi_small_gemm_launch(x, Ci, 1, (long)M * Ci, w, Co, 1, (long)Ci * Co, bias, xlin, M, Co, Ci, (hipStream_t)stream, &bn);
+}
+
+/* nn.Linear (+ bias) with the column sums a SyncBatchNorm behind it needs (sums[0..Co) = sum of xlin, sums[Co..2Co) = sum of
+ * xlin^2 over this rank's M <= 64 rows, doubles: what mi_bn_stats(xlin) would produce) from the product's epilogue - the
+ * all-reduce of `sums` and mi_bn_apply_fwd follow (models/networks/moco_encoder_3d.py:238-255 under
+ * SyncBatchNorm.convert_sync_batchnorm, moco_main.py:65-66). */
+extern "C" int mi_linear_stats_fwd_f32(const float* x, const float* w, const float* bias, float* xlin, double* sums, int M, int Ci,
+                                       int Co, mi_stream_t stream) {
+    if (!x || !w || !xlin || !sums || M <= 0 || Ci <= 0 || Co <= 0) return MI_E_ARG;
+    if (M > 64 || !conv_arith_bf16x3() || !mi_small_gemm_usable(M, Co, Ci) || env_int("MI_NO_LINEAR_BN")) return MI_E_UNSUPPORTED;
+    MiSmallGemmBN bn = {};
+    bn.sums_only = sums;
     return mi_small_gemm_launch(x, Ci, 1, (long)M * Ci, w, Co, 1, (long)Ci * Co, bias, xlin, M, Co, Ci, (hipStream_t)stream, &bn);
 }
 

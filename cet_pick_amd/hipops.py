@@ -658,10 +658,24 @@ class _LinearFn(torch.autograd.Function):
         fuse = getattr(mod, "_fuse_bn", None)
         if fuse is not None:
             mod._bn_pre = None
-        if fuse is not None and PROFILE is None and _phys_ok(w5):
+        if fuse is not None and fuse[2] and PROFILE is None and _phys_ok(w5):
+            # SyncBN across ranks (linear_bn): this rank's column sums come out of the product's epilogue and wait in
+            # mod._bn_pre for the BatchNorm node, which all-reduces them and applies
+            _f32c(x, "x")
+            lib = L.lib()
+            co = w5.shape[0]
+            y = torch.empty((m, co), dtype=torch.float32, device=x.device)
+            sums = torch.empty(2 * co, dtype=torch.float64, device=x.device)
+            rc = lib.mi_linear_stats_fwd_f32(L.ptr(x), L.ptr(w5), L.ptr(b), L.ptr(y), L.ptr(sums), m, ci, co, L.stream())
+            if rc == -3:
+                y = None
+            else:
+                L.check(rc, "mi_linear_stats_fwd_f32")
+                mod._bn_pre = ("sums", sums)
+        elif fuse is not None and PROFILE is None and _phys_ok(w5):
             # Linear + BatchNorm1d (+ ReLU) in one launch (linear_bn): the BatchNorm's output and saved statistics wait in
             # mod._bn_pre for the BatchNorm node; this node's own output is the Linear's, as always
-            bn, bn_relu = fuse
+            bn, bn_relu, _ = fuse
             _f32c(x, "x")
             lib = L.lib()
             co = w5.shape[0]
@@ -813,6 +827,10 @@ class _BNFn(torch.autograd.Function):
         dev = x.device
         distributed = mod.sync and _distributed()
         ctx.small = (mod.training or not mod.track_running_stats) and m <= BN_SMALL_MAX_ROWS and not distributed
+        given_sums = None
+        if pre is not None and isinstance(pre[0], str):
+            given_sums = pre[1]                           # this rank's column sums from the producing Linear's epilogue (SyncBN)
+            pre = None
         if pre is not None:
             # (y, save) came out of the producing Linear's launch (linear_bn): nothing to run here
             if not ctx.small or res is not None:
@@ -836,9 +854,12 @@ class _BNFn(torch.autograd.Function):
             ctx.count = float(m)
             ctx.train_stats = True
         elif mod.training or not mod.track_running_stats:
-            ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
-            sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
-            L.check(lib.mi_bn_stats(L.ptr(x), m, c, L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()), "mi_bn_stats")
+            if given_sums is not None:
+                sums = given_sums
+            else:
+                ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
+                sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+                L.check(lib.mi_bn_stats(L.ptr(x), m, c, L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()), "mi_bn_stats")
             count = float(m)
             if mod.sync and _distributed():
                 import torch.distributed as dist
@@ -1024,9 +1045,11 @@ def linear_bn(x, lin, bn, relu=False):
     own); both autograd nodes stay, with their backward passes.  Anything else (more rows, eval mode, SyncBN across ranks)
     runs the two launches."""
     train = bn.training or not bn.track_running_stats
-    if not (x.is_cuda and x.dim() == 2 and x.shape[0] <= 64 and train and not (bn.sync and _distributed()) and PROFILE is None):
+    if not (x.is_cuda and x.dim() == 2 and x.shape[0] <= 64 and train and PROFILE is None):
         return bn(lin(x), relu=relu)
-    lin._fuse_bn = (bn, relu)
+    # SyncBN across ranks: only the statistics come out of the product's epilogue (this rank's column sums); the all-reduce and
+    # the apply stay launches of their own
+    lin._fuse_bn = (bn, relu, bool(bn.sync and _distributed()))
     try:
         xl = lin(x)
         pre = getattr(lin, "_bn_pre", None)

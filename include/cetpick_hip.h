@@ -190,6 +190,12 @@ int mi_linear_bn_fwd_f32(const float* x, const float* w, const float* bias, floa
                          float* running_var, long long* num_batches_tracked, float* save_mean_invstd, int relu,
                          mi_stream_t stream);
 
+/* The SyncBatchNorm form of the same fusion (moco_main.py:65-66 converts the encoders): xlin = x W + bias and this rank's column
+ * sums of xlin and xlin^2 (2 Co doubles, as mi_bn_stats) from the product's epilogue; the all-reduce of `sums` and
+ * mi_bn_apply_fwd follow.  M <= 64 rows. */
+int mi_linear_stats_fwd_f32(const float* x, const float* w, const float* bias, float* xlin, double* sums, int M, int Ci, int Co,
+                            mi_stream_t stream);
+
 /* conv1 + the batch statistics of bn1 in one pass (models/networks/moco_encoder_3d.py:170-176, 326-328): the 7^3
  * stride-2 single-channel stem convolution, with sums[0..Co) = column sums of y and sums[Co..2Co) = column sums of y^2
  * (device doubles; what mi_bn_stats(y) would produce) taken from the output tiles while they are in registers.

@@ -782,3 +782,26 @@ def test_conv_dispatch_by_shape(monkeypatch):
     assert fwd(2, 16, 64, 64).startswith("implicit GEMM")          # layer1 of a 64^3 crop
     monkeypatch.setenv("MI_CONV_NO_DIRECT", "1")
     assert fwd(4, 8, 64, 64).startswith("implicit GEMM")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,ci,co,bias", [(64, 128, 128, False), (37, 256, 128, True)])
+def test_linear_stats_epilogue_matches_statistics_pass(m, ci, co, bias):
+    """mi_linear_stats_fwd_f32 (the SyncBN form of the Linear + BatchNorm fusion): the product equals the plain Linear's bit
+    for bit and the column sums from its epilogue equal mi_bn_stats of that product (doubles over <= 64 rows: to rounding)."""
+    import numpy as np
+    from cet_pick_amd import hipops as H, _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(m + ci)
+    lin = H.HipLinear(ci, co, bias=bias).cuda()
+    x = torch.randn(m, ci, generator=g).cuda()
+    y_plain = lin(x).detach()
+    y = torch.empty_like(y_plain)
+    sums = torch.zeros(2 * co, dtype=torch.float64, device="cuda")
+    w5 = H._as5(lin.weight)
+    rc = lib.mi_linear_stats_fwd_f32(L.ptr(x), L.ptr(w5), L.ptr(lin.bias), L.ptr(y), L.ptr(sums), m, ci, co, L.stream())
+    assert rc == 0
+    assert torch.equal(y, y_plain)
+    want = torch.cat([y.double().sum(0), (y.double() ** 2).sum(0)])
+    scale = torch.cat([y.double().abs().sum(0), (y.double() ** 2).sum(0)])
+    assert float(((sums - want).abs() / scale).max()) < 1e-12
