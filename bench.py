@@ -164,12 +164,10 @@ def inference_secondary(dev, with_cpu=True, rank=0, world=1):
         GREPS = 8
         g = torch.cuda.CUDAGraph()
         # N > 1: the process group's watchdog thread polls its finished works with hipEventQuery at its own pace; inside a
-        # "global" mode capture that call from another thread is fatal (MocoStepEngine._capture) - thread_local mode, and a
-        # short drain so that the barrier's works are retired first
+        # "global" mode capture that call from another thread is fatal (MocoStepEngine._capture): thread_local mode is the
+        # cure (HIP then checks only the capturing thread's own captures); nothing is drained
         import torch.distributed as _dist
         pg = _dist.is_available() and _dist.is_initialized()
-        if pg:
-            time.sleep(0.25)
         with torch.cuda.graph(g, capture_error_mode="thread_local" if pg else "global"):
             for _ in range(GREPS):
                 fn()
@@ -199,7 +197,8 @@ def inference_secondary(dev, with_cpu=True, rank=0, world=1):
             rate, slow_ms, wall_ms = float(t[0]), float(m[0]), float(m[1])
         achieved = rate / world * 8 / 1e9                        # per GPU, against one GPU's HBM peak
         traffic, tnote = _traffic(traffic_file, kernels)
-        e = {"workload": workload, "ms": round(slow_ms, 4), "ms_eager": round(eager, 4), "ms_hipgraph": round(graph, 4),
+        e = {"workload": workload, "ms": round(slow_ms, 4), "ms_source": "eager" if eager <= graph else "hipgraph",
+             "ms_eager": round(eager, 4), "ms_hipgraph": round(graph, 4),
              "voxels_per_sec": rate, "ranks": world,
              "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_note": tnote,

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(512, OCC) void s2_dgrad_kernel(S2DgradParams p) {
         constexpr int SLOT = decltype(SLOTc)::value;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-            bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, w_voff + pl * S2_WBLK, (int)so, 0));
+            // the offset (and its out-of-range sentinel) rides in the CHECKED voffset: soffset is not part of the range check
+            bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(so + (unsigned)(w_voff + pl * S2_WBLK)), 0, 0));
     };
     auto wload_dyn = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned so, int slot) {
         switch (slot) {

@@ -72,5 +72,34 @@ DogxGrid mi_dogx_grid(int D, int H, int W);
 bool mi_dogx_usable(const float* y1, const float* y2, const float* nms_out, int D, int H, int W, float s1, float s2, int k);
 int mi_launch_dogx(DogxParams p, const DogxGrid& g, float s1, float s2, hipStream_t st);
 
+// z + x passes | y pass + DoG + 3x3 xy-NMS + statistics + candidates: the picker's filter stage in two launches (infer_dogf.hip)
+struct DogfParams {
+    const float* rec;       // tomogram (D, H, W)
+    float* g1;              // smaller sigma after the z and x passes (planes [bz, D - bz), rows [ylo, yhi) are written)
+    float* g2;              // larger sigma, likewise
+    float* nms_out;         // dense NMS'd DoG volume (the live box is written; the caller zeroes the rest) or null
+    int D, H, W;
+    int bz, by, bx;         // zeroed border
+    int ylo, yhi;           // rows the y pass reads
+    unsigned vol_bytes;     // D * H * W * 4 (< 2 GiB)
+    int ychunk, n_ychunks, n_strips;
+    unsigned n_seg, n_wg;   // waves / workgroups of the y march
+    uint2* cands;           // segment of wave g = cands + g * seg_cap
+    unsigned* seg_count;
+    unsigned seg_cap;
+    unsigned* overflow;     // bit 0 set when a segment overflowed
+    double* stats;          // {count, sum, sumsq} of the positive survivors, per workgroup of the y march
+    unsigned* clr[2];       // word ranges the first launch zeroes on the side (header, candidate bitmap) or null
+    unsigned clr_n[2];
+};
+struct DogfGrid {
+    int ychunk, n_ychunks, n_strips;
+    unsigned n_seg, n_wg, seg_cap;
+};
+DogfGrid mi_dogf_grid(int D, int H, int W, int bz, int bxy);
+bool mi_dogf_usable(const float* rec, const float* g1, const float* g2, const float* nms_out, int D, int H, int W,
+                    float s1, float s2, int k, int bz, int bxy);
+int mi_launch_dogf(DogfParams p, const DogfGrid& g, float s1, float s2, hipStream_t st);
+
 dim3 mi_march_grid(int D, int H, int W, int* zchunk_out);
 int mi_launch_march(MarchParams p, int kz, int kxy, hipStream_t s);

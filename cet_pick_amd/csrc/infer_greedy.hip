@@ -25,22 +25,17 @@ int mi_gauss_radius(float sigma);
 namespace {
 
 constexpr int CAPN = 32;          // stored higher-priority neighbours per candidate
-constexpr int GREEDY_WIDE_ROUNDS = 3;    // chip-wide launches (GREEDY_INNER passes each) before the single-workgroup finisher
-                                        // (83 k candidates: 6.9 k, 0.4 k, 23 still open after rounds 1-3; rounds 4-5 were two
-                                        // 5 us launches for what the finisher does in passing)
-constexpr int GREEDY_INNER = 3;
-constexpr int MAX_DELTAS = 36000; // (2*16+1)^3
 constexpr int MAX_RUNS = 33 * 33; // (dz, dy) rows of the ball
 
 struct GreedyHeader {
     unsigned cand_count;     // positive NMS survivors (march kernel)
     unsigned n;              // candidates above the cutoff
     unsigned n_kept;
-    unsigned n_deltas;
+    unsigned n_left;         // candidates the chip-wide passes left open (rounds_all_kernel -> its last workgroup)
     unsigned overflow;       // bit0: candidate buffer overflow, bit1: too many picks for max_out
     float cutoff;
     unsigned n_runs;         // rows of the ball: runs of consecutive flat offsets
-    unsigned pad[1];
+    unsigned ticket;         // workgroups of rounds_all_kernel that have finished their passes
     unsigned trace[16];      // candidates still undecided at the start of each chip-wide round launch (diagnostics)
 };
 
@@ -86,70 +81,52 @@ __global__ void stats_finalize_kernel(const double* partials, int n_part, Greedy
 __global__ void set_cutoff_kernel(GreedyHeader* hdr, float v) { hdr->cutoff = v; }
 
 // ---- ball offsets (decode.py:43-54) ------------------------------------------------------------
-__global__ void build_deltas_kernel(GreedyHeader* hdr, long* deltas, BallRun* runs, double r, int width, long zs,
-                                    long ys) {
-    __shared__ unsigned cnt, rcnt;
-    if (threadIdx.x == 0) { cnt = 0; rcnt = 0; }
+// The ball of radius r as rows: row (dz, dy) is the run of consecutive flat offsets dz * zs + dy * ys + [-cm, cm] (the
+// reference's ball lives in flat index space, no bounds check).  Every workgroup that needs the rows builds them in its own
+// LDS (side^2 <= 1089 square roots) - round 3 spent a launch of one workgroup on a global copy.  Rows come out in (dz, dy)
+// order: consecutive lanes of the neighbour search then read adjacent rows of the bitmap.  Returns the number of rows.
+__device__ int ball_rows_lds(BallRun* s_runs, int* s_scan, double r, int width, long zs, long ys) {
+    const int side = 2 * width + 1, total = side * side;
+    const double r2 = r * r;
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const int per = (total + nt - 1) / nt;                 // consecutive entries per thread
+    int cm[5];                                             // (total <= 1089, nt >= 256: per <= 5)
+    int mine = 0;
+    for (int k = 0; k < per && k < 5; ++k) {
+        const int t = tid * per + k;
+        int c = -1;
+        if (t < total) {
+            const int a = t / side - width, b = t % side - width;
+            const double rest = r2 - (double)(a * a + b * b);
+            if (rest >= 0.0) {
+                c = (int)sqrt(rest);
+                while ((double)((c + 1) * (c + 1)) <= rest) ++c;         // exact integer bound of c^2 <= rest
+                while ((double)(c * c) > rest) --c;
+                if (c > width) c = width;
+            }
+        }
+        cm[k] = c;
+        mine += c >= 0;
+    }
+    s_scan[tid] = mine;
     __syncthreads();
-    int side = 2 * width + 1;
-    int total = side * side * side;
-    double r2 = r * r;
-    for (int t = threadIdx.x; t < total; t += blockDim.x) {
-        int a = t / (side * side) - width, b = (t / side) % side - width, c = t % side - width;
-        if ((double)(a * a + b * b + c * c) <= r2) {
-            unsigned slot = atomicAdd(&cnt, 1u);
-            if (slot < MAX_DELTAS) deltas[slot] = (long)a * zs + (long)b * ys + (long)c;
+    for (int o = 1; o < nt; o <<= 1) {                     // inclusive scan (nt <= 1024 entries)
+        const int v = tid >= o ? s_scan[tid - o] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    int pos = s_scan[tid] - mine;
+    for (int k = 0; k < per && k < 5; ++k) {
+        const int t = tid * per + k;
+        if (cm[k] >= 0) {
+            const int a = t / side - width, b = t % side - width;
+            s_runs[pos++] = BallRun{(long)a * zs + (long)b * ys - (long)cm[k], 2 * cm[k] + 1, 0};
         }
     }
-    // rows in (dz, dy) order - consecutive lanes of the neighbour search then read adjacent rows of the bitmap (64 bytes
-    // apart at W = 512: two rows per cache line) instead of rows scattered by an atomic slot counter
-    __shared__ int s_cm[MAX_RUNS];
-    for (int t = threadIdx.x; t < side * side; t += blockDim.x) {
-        const int a = t / side - width, b = t % side - width;
-        const double rest = r2 - (double)(a * a + b * b);
-        int cm = -1;
-        if (rest >= 0.0) {
-            cm = (int)sqrt(rest);
-            while ((double)((cm + 1) * (cm + 1)) <= rest) ++cm;          // exact integer bound of c^2 <= rest
-            while ((double)(cm * cm) > rest) --cm;
-            if (cm > width) cm = width;
-        }
-        s_cm[t] = cm;
-    }
+    const int n = s_scan[nt - 1];
     __syncthreads();
-    // order-preserving compaction: ballot prefix inside a wave, wave totals through LDS (side^2 <= 1089 entries; the
-    // block has 1024 threads: at most two entries per thread)
-    __shared__ unsigned s_wtot[2][16];
-    const int lane_ = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
-    unsigned pre[2];
-    bool valid[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int t = h * 1024 + (int)threadIdx.x;
-        valid[h] = t < side * side && s_cm[t] >= 0;
-        const unsigned long long m = __ballot(valid[h]);
-        pre[h] = (unsigned)__popcll(m & ((1ull << lane_) - 1ull));
-        if (lane_ == 0) s_wtot[h][wv_] = (unsigned)__popcll(m);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        unsigned off = 0;
-        if (h == 1) for (int w2 = 0; w2 < 16; ++w2) off += s_wtot[0][w2];
-        for (int w2 = 0; w2 < wv_; ++w2) off += s_wtot[h][w2];
-        const int t = h * 1024 + (int)threadIdx.x;
-        if (valid[h]) {
-            const int a = t / side - width, b = t % side - width, cm = s_cm[t];
-            runs[off + pre[h]] = BallRun{(long)a * zs + (long)b * ys - (long)cm, 2 * cm + 1, 0};
-        }
-    }
-    if (threadIdx.x == 0) {
-        unsigned tot = 0;
-        for (int w2 = 0; w2 < 16; ++w2) tot += s_wtot[0][w2] + s_wtot[1][w2];
-        rcnt = tot;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { hdr->n_deltas = min(cnt, (unsigned)MAX_DELTAS); hdr->n_runs = rcnt; }
+    return n;
 }
 
 // ---- dense volume -> candidate list (values > cutoff) ------------------------------------------
@@ -223,16 +200,43 @@ __global__ __launch_bounds__(256) void cand_filter_kernel(const uint2* cands, un
 // returning atomic on a single word costs ~11 ns, and one per wave and 64-candidate step (~10^4 of them for 83 k
 // survivors) made the linear-list kernel above 58 us for 2.4 MB of candidates.
 constexpr int CF_STAGE = 3072;
+// FIN: the cutoff (mean + 0.5 std of the positive survivors, stats_finalize_kernel's arithmetic) is computed by EVERY
+// workgroup from the partial sums in one fixed order - the same bits everywhere - instead of by a launch of its own in
+// front of this one; workgroup 0 publishes it.
+template <bool FIN>
 __global__ __launch_bounds__(256) void cand_filter_seg_kernel(const uint2* cands, const unsigned* seg_count,
                                                              unsigned n_seg, unsigned seg_cap, GreedyHeader* hdr,
                                                              unsigned long long* G, int* map, unsigned* vmap,
-                                                             unsigned* bits, unsigned cap) {
+                                                             unsigned* bits, unsigned cap, const double* partials,
+                                                             int n_part, float* cutoff_out) {
     __shared__ uint2 stage[CF_STAGE];
     __shared__ unsigned s_n, s_base;
+    __shared__ float s_cut;
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) s_n = 0;
+    if (FIN) {
+        double* r = reinterpret_cast<double*>(stage);      // 3 x 256 doubles, before the stage is used
+        double a = 0, s = 0, ss = 0;
+        for (int i = tid; i < n_part; i += 256) { a += partials[3 * i]; s += partials[3 * i + 1]; ss += partials[3 * i + 2]; }
+        r[tid] = a; r[256 + tid] = s; r[512 + tid] = ss;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) { r[tid] += r[tid + o]; r[256 + tid] += r[256 + tid + o]; r[512 + tid] += r[512 + tid + o]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double n = r[0], mean = n > 0 ? r[256] / n : 0.0;
+            double var = n > 1 ? (r[512] - n * mean * mean) / (n - 1.0) : 0.0;
+            if (var < 0) var = 0;
+            float c = (float)(mean + 0.5 * sqrt(var));
+            if (!(n > 0)) c = INFINITY;
+            s_cut = c;
+            if (blockIdx.x == 0) { hdr->cutoff = c; if (cutoff_out) *cutoff_out = c; }
+        }
+    }
     __syncthreads();
-    const float cut = hdr->cutoff;
+    const float cut = FIN ? s_cut : hdr->cutoff;
+    __syncthreads();                                       // (FIN: the reduction scratch becomes the stage)
     auto place = [&](uint2 c, unsigned slot) {
         if (slot < cap) {
             G[slot] = ((unsigned long long)order_bits(__uint_as_float(c.x)) << 32) | (unsigned long long)c.y;
@@ -299,24 +303,30 @@ __global__ __launch_bounds__(256) void cand_filter_seg_kernel(const uint2* cands
 __global__ __launch_bounds__(256) void neighbors_kernel(GreedyHeader* hdr,
                                                        const unsigned long long* G, const int* map,
                                                        const unsigned* vmap, const float* vol,
-                                                       const unsigned* bits, const BallRun* runs, long n_vox,
-                                                       unsigned cap, int* nbr, unsigned char* state, unsigned* undecided) {
+                                                       const unsigned* bits, BallRun* runs, long n_vox,
+                                                       unsigned cap, int* nbr, unsigned char* state, double ball_r,
+                                                       int ball_width, long zs, long ys) {
     const unsigned n = min(hdr->n, cap);
-    const int nr = (int)hdr->n_runs;
     const int lane = threadIdx.x & 63;
     // Candidates are dealt round-robin to the waves: the list is filled roughly plane by plane, so at any moment the whole
     // chip works on one slab of the volume and that slab of the 8 MB bitmap is hot in every XCD's L2.  (Contiguous ranges
     // per wave with one z-slab per XCD were measured slower: 85 us against 59 us.)
     const unsigned wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const unsigned n_waves = (gridDim.x * 256) >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *undecided = n; hdr->n_kept = 0; }
-    // the ball's rows in LDS (one dependent global load less per candidate)
+    // the ball's rows, built by every workgroup in its own LDS; workgroup 0 publishes them for the rounds' re-probe of the
+    // (rare) candidates whose neighbour list overflowed
     __shared__ BallRun s_runs[MAX_RUNS];
-    for (int q = threadIdx.x; q < nr; q += 256) s_runs[q] = runs[q];
-    __syncthreads();
+    __shared__ int s_scan[256];
+    const int nr = ball_rows_lds(s_runs, s_scan, ball_r, ball_width, zs, ys);
+    if (blockIdx.x == 0) {
+        for (int q = threadIdx.x; q < nr; q += 256) runs[q] = s_runs[q];
+        if (threadIdx.x == 0) { hdr->n_runs = (unsigned)nr; hdr->n_kept = 0; hdr->n_left = 0; hdr->ticket = 0; }
+    }
     constexpr int QB = 4;                         // row groups whose bitmap words are fetched together
+    unsigned long long k_next = wave < n ? G[wave] : 0ull;
     for (unsigned i = wave; i < n; i += n_waves) {
-        const unsigned long long ki = G[i];
+        const unsigned long long ki = k_next;              // (the next candidate's key is in flight during this one's search)
+        if (i + n_waves < n) k_next = G[i + n_waves];
         const long idx = (long)(ki & 0xffffffffull);
         const unsigned vi = (unsigned)(ki >> 32);
         int count = 0;
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(256) void neighbors_kernel(GreedyHeader* hdr,
 // ---- rounds: single workgroup, all candidates --------------------------------------------------
 // state: 0 undecided, 1 pick, 2 suppressed
 __device__ __forceinline__ int decide(unsigned i, int4 r0, const unsigned long long* G, const int* map, const unsigned* bits,
-                                      const long* deltas, int nd, long n_vox, const int* nbr,
+                                      const BallRun* runs, int nr, long n_vox, const int* nbr,
                                       const volatile unsigned char* state) {
     const int cnt = r0.x;                                  // r0 = the first 16 bytes of row i: count + three neighbours
     bool all_decided = true;
@@ -413,123 +423,128 @@ __device__ __forceinline__ int decide(unsigned i, int4 r0, const unsigned long l
     } else {
         const unsigned long long ki = G[i];
         const long idx = (long)(ki & 0xffffffffull);
-        for (int q = 0; q < nd; ++q) {
-            long j = idx + deltas[q];
-            if (j < 0 || j >= n_vox) continue;
-            if (!((bits[j >> 5] >> (j & 31)) & 1u)) continue;       // (the id map is only valid where a bit is set)
-            int mm = map[j];
-            if ((unsigned)mm == i || !(G[mm] > ki)) continue;
-            unsigned char st = state[mm];
-            if (st == 1) return 2;
-            if (st == 0) all_decided = false;
+        for (int q = 0; q < nr; ++q) {
+            const BallRun rn = runs[q];
+            for (int c = 0; c < rn.len; ++c) {
+                const long j = idx + rn.start + c;
+                if (j < 0 || j >= n_vox) continue;
+                if (!((bits[j >> 5] >> (j & 31)) & 1u)) continue;   // (the id map is only valid where a bit is set)
+                const int mm = map[j];
+                if ((unsigned)mm == i || !(G[mm] > ki)) continue;
+                const unsigned char st = state[mm];
+                if (st == 1) return 2;
+                if (st == 0) all_decided = false;
+            }
         }
     }
     return all_decided ? 1 : 0;
 }
 
-// Chip-wide rounds: every launch decides whatever can be decided from the states left by the
-// previous launches (reads of states written in the same launch may be stale: that only defers a
-// decision).  `undecided` counts candidates still open; a launch that finds 0 returns at once.
-__global__ __launch_bounds__(256) void round_step_kernel(GreedyHeader* hdr, const unsigned long long* G,
-                                                        const int* map, const unsigned* bits, const long* deltas,
-                                                        long n_vox, unsigned cap, const int* nbr,
-                                                        volatile unsigned char* state, unsigned* undecided,
-                                                        unsigned long long* kept, unsigned kept_cap, int round) {
-    const unsigned open_now = *reinterpret_cast<volatile unsigned*>(undecided);
-    if (blockIdx.x == 0 && threadIdx.x == 0) hdr->trace[round & 15] = open_now;
-    if (open_now == 0) return;
-    const unsigned n = min(hdr->n, cap);
-    const int nd = (int)hdr->n_deltas;
-    unsigned decided_here = 0;
-    // GREEDY_INNER passes per launch: the states are read past the L1 (volatile), so decisions other workgroups have
-    // already written are seen within the launch and a dependency chain advances several links per launch - a launch
-    // boundary costs ~7 us here, a pass over the few still-open candidates next to nothing
-    for (int pass = 0; pass < GREEDY_INNER; ++pass) {
-        // (wave-uniform trip count: the picks of a wave take their slots with ONE returning atomic - one per pick
-        // serialised ~8000 of them on a single word in the first launch)
-        for (unsigned i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
-            const unsigned i = i0 + threadIdx.x;
-            int d = 0;
-            if (i < n && state[i] == 0) {
-                const int4 r0 = *reinterpret_cast<const int4*>(nbr + (size_t)i * CAPN);
-                d = decide(i, r0, G, map, bits, deltas, nd, n_vox, nbr, state);
-                if (d != 0) {
-                    state[i] = (unsigned char)d;
-                    ++decided_here;
-                }
-            }
-            const unsigned long long pm = __ballot(d == 1);
-            if (pm) {
-                const int lane = threadIdx.x & 63;
-                unsigned base = 0;
-                const int leader = __ffsll((long long)pm) - 1;
-                if (lane == leader) base = atomicAdd(&hdr->n_kept, (unsigned)__popcll(pm));
-                base = __shfl(base, leader, 64);
-                if (d == 1) {
-                    const unsigned slot = base + (unsigned)__popcll(pm & ((1ull << lane) - 1ull));
-                    if (slot < kept_cap) kept[slot] = G[i];
-                }
-            }
-        }
-    }
-    // one atomic per wave
-    unsigned tot = decided_here;
+// ---- rounds: ONE launch ------------------------------------------------------------------------------------------
+// Round 3 resolved the fixed point in three chip-wide launches + a one-workgroup finisher, every wave taking its picks'
+// slots and its share of an `undecided` counter with returning atomics on two words (~11 ns each, serialised: 25 of the
+// first launch's 42 us).  Here a workgroup owns a contiguous chunk of the candidate list and makes RA_PASSES passes over it
+// (states are read past the L1 - volatile - so decisions of other workgroups are seen as they land; a stale read only
+// defers a decision), compacts its picks with ONE returning atomic per workgroup, hands what is still open (a few dozen
+// candidates chip-wide) to a list, and the workgroup that finishes last resolves that list alone.
+constexpr int RA_T = 256, RA_PASSES = 12, RA_REG = 11;   // RA_REG neighbour ids of a candidate live in registers
+
+// one pass over a candidate whose list (<= RA_REG entries) sits in registers: ONE round trip (the neighbours' states)
+__device__ __forceinline__ int decide_reg(const int (&ids)[RA_REG], int cnt, const volatile unsigned char* state) {
+    unsigned char st[RA_REG];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-    if ((threadIdx.x & 63) == 0 && tot) atomicSub(undecided, tot);
+    for (int u = 0; u < RA_REG; ++u) st[u] = u < cnt ? state[ids[u]] : (unsigned char)2;
+    bool all_decided = true, pick_near = false;
+#pragma unroll
+    for (int u = 0; u < RA_REG; ++u) { pick_near |= st[u] == 1; all_decided &= st[u] != 0; }
+    return pick_near ? 2 : (all_decided ? 1 : 0);
 }
 
-__global__ __launch_bounds__(1024) void rounds_kernel(GreedyHeader* hdr, const unsigned long long* G,
-                                                      const int* map, const unsigned* bits, const long* deltas, long n_vox,
-                                                      unsigned cap, const int* nbr,
-                                                      volatile unsigned char* state,
-                                                      unsigned* act_a, unsigned* act_b,
-                                                      unsigned long long* kept, unsigned kept_cap) {
-    __shared__ unsigned s_next, s_kept;
-    const int tid = threadIdx.x;
+__global__ __launch_bounds__(RA_T) void rounds_all_kernel(GreedyHeader* hdr, const unsigned long long* G, const int* map,
+                                                         const unsigned* bits, const BallRun* runs, long n_vox,
+                                                         unsigned cap, const int* nbr, volatile unsigned char* state,
+                                                         unsigned* left, unsigned* act_b, unsigned long long* kept,
+                                                         unsigned kept_cap) {
+    __shared__ unsigned s_wcnt[2][RA_T / 64], s_base[2], s_last, s_next, s_kept;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const unsigned n = min(hdr->n, cap);
-    const int nd = (int)hdr->n_deltas;
-    // finisher: picks up whatever the chip-wide rounds left undecided (usually nothing)
-    if (tid == 0) { s_next = 0; s_kept = hdr->n_kept; }
-    __syncthreads();
-    // (16 states per load: the byte-at-a-time volatile scan of all n candidates was most of this kernel's 24 us)
-    {
-        const uint4* sv = reinterpret_cast<const uint4*>(const_cast<const unsigned char*>(state));
-        const unsigned n16 = n >> 4;
-        for (unsigned q = tid; q < n16; q += 1024) {
-            const uint4 v = sv[q];
-            const unsigned w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    if (((w4[c] >> (8 * b)) & 0xffu) == 0u) act_a[atomicAdd(&s_next, 1u)] = 16 * q + 4 * c + b;
+    const int nr = (int)hdr->n_runs;
+    const unsigned chunk = (n + gridDim.x - 1) / gridDim.x;
+    const unsigned lo = min(blockIdx.x * chunk, n), hi = min(lo + chunk, n);
+    volatile unsigned* vleft = left;
+    auto load_list = [&](unsigned i, int (&ids)[RA_REG], int& cnt) {
+        const int4* row4 = reinterpret_cast<const int4*>(nbr + (size_t)i * CAPN);
+        const int4 a = row4[0];
+        cnt = a.x;
+        ids[0] = a.y; ids[1] = a.z; ids[2] = a.w;
+        if (cnt > 3 && cnt <= RA_REG) {
+            const int4 b = row4[1], c = row4[2];
+            ids[3] = b.x; ids[4] = b.y; ids[5] = b.z; ids[6] = b.w; ids[7] = c.x; ids[8] = c.y; ids[9] = c.z; ids[10] = c.w;
         }
-        for (unsigned i = (n16 << 4) + tid; i < n; i += 1024)
-            if (state[i] == 0) act_a[atomicAdd(&s_next, 1u)] = i;
+    };
+    for (unsigned i0 = lo; i0 < hi; i0 += RA_T) {           // (a chunk is 162 candidates at 83 k: one trip)
+        const unsigned i = i0 + tid;
+        int ids[RA_REG], cnt = 0, my = 2;
+        if (i < hi) { load_list(i, ids, cnt); my = 0; }
+        for (int pass = 0; pass < RA_PASSES; ++pass) {
+            if (my == 0) {
+                const int4 r0 = make_int4(cnt, ids[0], ids[1], ids[2]);
+                my = cnt <= RA_REG ? decide_reg(ids, cnt, state) : decide(i, r0, G, map, bits, runs, nr, n_vox, nbr, state);
+                if (my != 0) state[i] = (unsigned char)my;
+            }
+            if (!__syncthreads_or(my == 0 ? 1 : 0)) break;  // this trip is resolved
+        }
+        // picks -> kept, still open -> left: ballot prefix in the wave, wave totals through LDS, one atomic per list
+        const unsigned long long mk = __ballot(my == 1), ml = __ballot(my == 0);
+        if (lane == 0) { s_wcnt[0][wv] = (unsigned)__popcll(mk); s_wcnt[1][wv] = (unsigned)__popcll(ml); }
+        __syncthreads();
+        if (tid < 2) {
+            unsigned tot = 0;
+            for (int w2 = 0; w2 < RA_T / 64; ++w2) tot += s_wcnt[tid][w2];
+            s_base[tid] = tot ? atomicAdd(tid == 0 ? &hdr->n_kept : &hdr->n_left, tot) : 0u;
+        }
+        __syncthreads();
+        unsigned offk = s_base[0], offl = s_base[1];
+        for (int w2 = 0; w2 < wv; ++w2) { offk += s_wcnt[0][w2]; offl += s_wcnt[1][w2]; }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (my == 1) { const unsigned slot = offk + (unsigned)__popcll(mk & below); if (slot < kept_cap) kept[slot] = G[i]; }
+        if (my == 0) vleft[offl + (unsigned)__popcll(ml & below)] = i;          // (left holds `cap` entries)
+        __syncthreads();
     }
+    // The last workgroup to get here resolves the leftovers (its own included).  What it reads from the others - their
+    // states and list entries - was stored past the caches (volatile = sc0 sc1 accesses), drained by the barrier's
+    // vmcnt(0) before the owner's ticket (an agent-scope atomic), and is loaded the same way: no device-scope fence (the
+    // L2 write-back / invalidate pair costs tens of microseconds on this part - MI355X_MICROARCH.md, inter-workgroup
+    // visibility, the sc1 form).
     __syncthreads();
-    if (tid == 0) hdr->trace[14] = s_next;
-    unsigned n_act = s_next;
+    if (tid == 0) s_last = (atomicAdd(&hdr->ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
     __syncthreads();
-    if (tid == 0) s_next = 0;
+    if (!s_last) return;
+    unsigned n_act = *reinterpret_cast<volatile unsigned*>(&hdr->n_left);
+    if (tid == 0) { s_next = 0; s_kept = *reinterpret_cast<volatile unsigned*>(&hdr->n_kept); hdr->trace[14] = n_act; }
     __syncthreads();
-    unsigned* cur = act_a;
+    const volatile unsigned* cur = left;
     unsigned* nxt = act_b;
-    bool first = false;
     while (n_act > 0) {
-        for (unsigned t = tid; t < n_act; t += 1024) {
-            unsigned i = first ? t : cur[t];
-            const int4 r0 = *reinterpret_cast<const int4*>(nbr + (size_t)i * CAPN);
-            int d = decide(i, r0, G, map, bits, deltas, nd, n_vox, nbr, state);
-            if (d == 0) {
-                nxt[atomicAdd(&s_next, 1u)] = i;
-            } else {
-                state[i] = (unsigned char)d;
-                if (d == 1) {
-                    unsigned slot = atomicAdd(&s_kept, 1u);
-                    if (slot < kept_cap) kept[slot] = G[i];
+        // every open candidate keeps its list in registers while the passes of this trip run (a few dozen candidates)
+        for (unsigned t0 = 0; t0 < n_act; t0 += RA_T) {
+            const unsigned t = t0 + tid;
+            int ids[RA_REG], cnt = 0, my = 2;
+            unsigned i = 0;
+            if (t < n_act) { i = cur[t]; load_list(i, ids, cnt); my = 0; }
+            for (int pass = 0; pass < 64; ++pass) {
+                int before = my;
+                if (my == 0) {
+                    const int4 r0 = make_int4(cnt, ids[0], ids[1], ids[2]);
+                    my = cnt <= RA_REG ? decide_reg(ids, cnt, state) : decide(i, r0, G, map, bits, runs, nr, n_vox, nbr, state);
+                    if (my != 0) state[i] = (unsigned char)my;
                 }
+                // go on while somebody of this trip made progress (an open candidate may wait for one of another trip)
+                if (!__syncthreads_or((before == 0 && my != 0) ? 1 : 0)) break;
+            }
+            if (t < n_act) {
+                if (my == 0) nxt[atomicAdd(&s_next, 1u)] = i;
+                else if (my == 1) { const unsigned slot = atomicAdd(&s_kept, 1u); if (slot < kept_cap) kept[slot] = G[i]; }
             }
         }
         __threadfence_block();
@@ -537,8 +552,7 @@ __global__ __launch_bounds__(1024) void rounds_kernel(GreedyHeader* hdr, const u
         n_act = s_next;
         __syncthreads();
         if (tid == 0) s_next = 0;
-        unsigned* tmp = cur; cur = nxt; nxt = tmp;
-        first = false;
+        const volatile unsigned* tmp = cur; cur = nxt; nxt = const_cast<unsigned*>(tmp);
         __syncthreads();
     }
     if (tid == 0) {
@@ -548,73 +562,57 @@ __global__ __launch_bounds__(1024) void rounds_kernel(GreedyHeader* hdr, const u
     }
 }
 
-// ---- sort picks (descending priority) and write outputs ----------------------------------------
-// Two launches whatever the number of picks (the bitonic network over the padded array was 1 + 5 + 10 + 1 launches for
-// max_out = 2^17, most of them leaving at once): every tile of SORT_TILE picks is sorted in LDS, then each pick finds its
-// final row by itself - its position in its own tile plus, by binary search, the number of greater keys in every other
-// tile (keys are unique) - and writes score and coordinates there.
-// An in-LDS bitonic sort is bound by LDS store bandwidth (~85 B/clk/CU: 91 steps x 128 KB for 8192 keys = 67 us in one
-// workgroup, 18 us for 2048 keys): small tiles on many CUs, and the rank pass pays for it with more - but independent,
-// interleaved - binary searches.
-constexpr int SORT_TILE = 2048;   // keys per workgroup
-constexpr int SORT_TILE_LOG2 = 11;
+// ---- picks in descending priority: rank by counting ----------------------------------------------------------------
+// Keys are unique (score bits, flat index), so a pick's output row is the number of greater keys.  Round 3 sorted
+// 2048-key tiles in LDS and merged by binary searches (two launches, 56 us for 16 k picks).  Here a WAVE owns ER_PPW picks
+// (their keys in registers) and its lanes scan ALL keys, 64 at a time out of an LDS chunk the workgroup staged once for
+// its 16 waves: one 8-byte LDS read feeds ER_PPW compares, the lanes' counts are summed by shuffles at the end.  n^2
+// compares spread over the chip, no sort, one launch.
+constexpr int ER_T = 1024, ER_CHUNK = 4096, ER_PPW = 4, ER_PPG = ER_PPW * (ER_T / 64);   // 64 picks per workgroup
 
-__global__ __launch_bounds__(1024) void sort_tiles_kernel(const GreedyHeader* hdr, unsigned long long* kept, unsigned cap) {
-    __shared__ unsigned long long keys[SORT_TILE];
-    const unsigned n = min(hdr->n_kept, cap);
-    const unsigned tile0 = blockIdx.x * SORT_TILE;
-    if (tile0 >= n) return;
-    const int tid = threadIdx.x;
-    const unsigned m = min(n - tile0, (unsigned)SORT_TILE);
-    unsigned P = 1024;                                   // sort only what the tile holds
-    while (P < m) P <<= 1;
-    for (unsigned i = tid; i < P; i += 1024) keys[i] = i < m ? kept[tile0 + i] : 0ull;     // zero keys sink to the end
-    block_sort_desc_fast(keys, (int)P, tid, 1024);
-    for (unsigned i = tid; i < m; i += 1024) kept[tile0 + i] = keys[i];
-}
-
-__global__ __launch_bounds__(256) void merge_emit_kernel(GreedyHeader* hdr, const unsigned long long* kept, unsigned cap,
+__global__ __launch_bounds__(ER_T) void emit_rank_kernel(GreedyHeader* hdr, const unsigned long long* kept, unsigned cap,
                                                         int H, int W, float* scores, int32_t* coords, int32_t* n_out,
                                                         int max_out) {
+    __shared__ unsigned long long keys[ER_CHUNK];
     const unsigned n = min(hdr->n_kept, cap);
-    const unsigned n_tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long hw = (long)H * W;
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const unsigned long long key = kept[i];
-        const unsigned my_tile = i / SORT_TILE;
-        unsigned rank = i - my_tile * SORT_TILE;
-        // the searches in the other tiles are independent: eight of them advance in lockstep, their loads in flight together
-        constexpr int TG = 8;
-        for (unsigned t0 = 0; t0 < n_tiles; t0 += TG) {
-            unsigned lo[TG], hi[TG];
+    for (unsigned g0 = blockIdx.x * ER_PPG; g0 < n; g0 += gridDim.x * ER_PPG) {      // (workgroup-uniform trip count)
+        unsigned long long key[ER_PPW];
+        unsigned rank[ER_PPW];
 #pragma unroll
-            for (int u = 0; u < TG; ++u) {
-                const unsigned t = t0 + u;
-                lo[u] = 0;
-                hi[u] = (t < n_tiles && t != my_tile) ? min(n - t * SORT_TILE, (unsigned)SORT_TILE) : 0u;   // keys in [0, lo) are > key
-            }
-            for (int step = 0; step <= SORT_TILE_LOG2; ++step) {
-                unsigned long long v[TG];
-                unsigned mid[TG];
-#pragma unroll
-                for (int u = 0; u < TG; ++u) {
-                    mid[u] = (lo[u] + hi[u]) >> 1;
-                    v[u] = lo[u] < hi[u] ? kept[(size_t)(t0 + u) * SORT_TILE + mid[u]] : 0ull;
-                }
-#pragma unroll
-                for (int u = 0; u < TG; ++u)
-                    if (lo[u] < hi[u]) { if (v[u] > key) lo[u] = mid[u] + 1; else hi[u] = mid[u]; }
-            }
-#pragma unroll
-            for (int u = 0; u < TG; ++u) rank += lo[u];
+        for (int u = 0; u < ER_PPW; ++u) {
+            const unsigned i = g0 + wv * ER_PPW + u;
+            key[u] = i < n ? kept[i] : ~0ull;
+            rank[u] = 0;
         }
-        if (rank < (unsigned)max_out) {
-            const long idx = (long)(key & 0xffffffffull);
-            scores[rank] = unorder_bits((unsigned)(key >> 32));
-            const long z = idx / hw, t2 = idx - z * hw;
-            coords[3 * rank + 0] = (int)(t2 % W);
-            coords[3 * rank + 1] = (int)(t2 / W);
-            coords[3 * rank + 2] = (int)z;
+        for (unsigned c0 = 0; c0 < n; c0 += ER_CHUNK) {
+            const unsigned m = min((unsigned)ER_CHUNK, n - c0);
+            __syncthreads();
+#pragma unroll
+            for (int q = tid; q < ER_CHUNK; q += ER_T) keys[q] = (unsigned)q < m ? kept[c0 + q] : 0ull;   // zero keys count for nobody
+            __syncthreads();
+            const unsigned m64 = (m + 63) & ~63u;
+#pragma unroll 4
+            for (unsigned q = lane; q < m64; q += 64) {
+                const unsigned long long kj = keys[q];
+#pragma unroll
+                for (int u = 0; u < ER_PPW; ++u) rank[u] += kj > key[u] ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < ER_PPW; ++u) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rank[u] += __shfl_xor(rank[u], o, 64);
+            const unsigned i = g0 + wv * ER_PPW + u;
+            if (lane == 0 && i < n && rank[u] < (unsigned)max_out) {
+                const long idx = (long)(key[u] & 0xffffffffull);
+                scores[rank[u]] = unorder_bits((unsigned)(key[u] >> 32));
+                const long z = idx / hw, t2 = idx - z * hw;
+                coords[3 * rank[u] + 0] = (int)(t2 % W);
+                coords[3 * rank[u] + 1] = (int)(t2 / W);
+                coords[3 * rank[u] + 2] = (int)z;
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -628,14 +626,12 @@ __global__ __launch_bounds__(256) void merge_emit_kernel(GreedyHeader* hdr, cons
 
 struct GreedyWs {
     GreedyHeader* hdr;
-    long* deltas;
     unsigned long long* G;
     unsigned long long* kept;
     int* nbr;
     unsigned char* state;
     unsigned* act_a;
     unsigned* act_b;
-    unsigned* undecided;
     int* map;          // dense, n_vox ints; valid only where `bits` is set (never cleared)
     unsigned* vmap;    // dense order_bits(value) of the candidates (valid where `bits` is set), or null when
     const float* vol;  // ... the dense value volume itself is at hand (mi_greedy_nms3d)
@@ -652,20 +648,18 @@ size_t greedy_default_cap(size_t n_vox, bool dense_api) {
 }
 
 size_t greedy_ws_layout(size_t n_vox, size_t cap, GreedyWs* w, char* base, bool with_map) {
-    size_t kept_cap = SORT_TILE;
+    size_t kept_cap = 2048;
     while (kept_cap < cap) kept_cap <<= 1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += mi_align_up(bytes, 256); return base ? base + o : nullptr; };
     char* p;
     p = take(sizeof(GreedyHeader)); if (w) w->hdr = (GreedyHeader*)p;
-    p = take(sizeof(long) * MAX_DELTAS); if (w) w->deltas = (long*)p;
     p = take(sizeof(unsigned long long) * cap); if (w) w->G = (unsigned long long*)p;
     p = take(sizeof(unsigned long long) * kept_cap); if (w) w->kept = (unsigned long long*)p;
     p = take(sizeof(int) * cap * CAPN); if (w) w->nbr = (int*)p;
     p = take(cap); if (w) w->state = (unsigned char*)p;
     p = take(sizeof(unsigned) * cap); if (w) w->act_a = (unsigned*)p;
     p = take(sizeof(unsigned) * cap); if (w) w->act_b = (unsigned*)p;
-    p = take(256); if (w) w->undecided = (unsigned*)p;
     p = take(sizeof(BallRun) * MAX_RUNS); if (w) w->runs = (BallRun*)p;
     p = take(sizeof(unsigned) * ((n_vox + 31) / 32 + 2)); if (w) w->bits = (unsigned*)p;
     if (with_map) { p = take(sizeof(int) * n_vox); if (w) w->map = (int*)p; }
@@ -673,33 +667,21 @@ size_t greedy_ws_layout(size_t n_vox, size_t cap, GreedyWs* w, char* base, bool 
     return off;
 }
 
-// everything after the candidate list G (and map) is filled: neighbours, rounds, sort, emit
+// everything after the candidate list G (and map) is filled: neighbours, rounds, ranked output - three launches
 int greedy_tail(const GreedyWs& w, int D, int H, int W, float d, float scale, float* scores,
                 int32_t* coords, int32_t* n_out, int max_out, hipStream_t s) {
     const long n_vox = (long)D * H * W;
     double r = (double)scale * (double)d / 2.0;
     int width = (int)ceil(r);
     if (width > 16 || width < 0) return MI_E_UNSUPPORTED;
-    hipLaunchKernelGGL(build_deltas_kernel, dim3(1), dim3(1024), 0, s, w.hdr, w.deltas, w.runs, r, width,
-                       (long)H * W, (long)W);
-    MI_RETURN_IF_LAUNCH_FAILED();
     hipLaunchKernelGGL(neighbors_kernel, dim3(2048), dim3(256), 0, s, w.hdr, w.G, w.map, w.vmap, w.vol, w.bits, w.runs,
-                       n_vox, w.cap, w.nbr, w.state, w.undecided);
+                       n_vox, w.cap, w.nbr, w.state, r, width, (long)H * W, (long)W);
     MI_RETURN_IF_LAUNCH_FAILED();
-    for (int r = 0; r < GREEDY_WIDE_ROUNDS; ++r) {
-        hipLaunchKernelGGL(round_step_kernel, dim3(1024), dim3(256), 0, s, w.hdr, w.G, w.map, w.bits, w.deltas, n_vox,
-                           w.cap, w.nbr, w.state, w.undecided, w.kept, w.kept_cap, r);
-        MI_RETURN_IF_LAUNCH_FAILED();
-    }
-    hipLaunchKernelGGL(rounds_kernel, dim3(1), dim3(1024), 0, s, w.hdr, w.G, w.map, w.bits, w.deltas, n_vox,
-                       w.cap, w.nbr, w.state, w.act_a, w.act_b, w.kept, w.kept_cap);
+    hipLaunchKernelGGL(rounds_all_kernel, dim3(512), dim3(RA_T), 0, s, w.hdr, w.G, w.map, w.bits, w.runs, n_vox, w.cap,
+                       w.nbr, w.state, w.act_a, w.act_b, w.kept, w.kept_cap);
     MI_RETURN_IF_LAUNCH_FAILED();
-    // sort + emit: two launches (tiles beyond the picks leave at once)
-    unsigned tiles = (unsigned)mi_cdiv((long)std::min<size_t>((size_t)max_out, w.kept_cap), SORT_TILE);
-    hipLaunchKernelGGL(sort_tiles_kernel, dim3(tiles), dim3(1024), 0, s, w.hdr, w.kept, w.kept_cap);
-    MI_RETURN_IF_LAUNCH_FAILED();
-    hipLaunchKernelGGL(merge_emit_kernel, dim3(std::min(tiles * 32u, 1024u)), dim3(256), 0, s, w.hdr, w.kept, w.kept_cap, H, W,
-                       scores, coords, n_out, max_out);
+    hipLaunchKernelGGL(emit_rank_kernel, dim3(256), dim3(ER_T), 0, s, w.hdr, w.kept, w.kept_cap, H, W, scores, coords,
+                       n_out, max_out);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -747,7 +729,7 @@ struct DogWs {
     double* stats;
     unsigned* seg_count;
     unsigned cand_cap;
-    size_t n_stats;
+    size_t n_stats, cand_room, seg_room;
     DogxGrid xg;
     GreedyWs gw;
 };
@@ -761,16 +743,26 @@ size_t dog_ws_layout(int D, int H, int W, DogWs* w, char* base) {
     p = take(sizeof(float) * n_vox); if (w) w->g[1] = (float*)p;
     p = take(sizeof(float) * n_vox); if (w) w->tmp = (float*)p;
     p = take(sizeof(float) * n_vox); if (w) w->heat = (float*)p;
-    // candidates: the linear list of the generic march, or one segment per wave of the fused x-pass kernel
+    // candidates: the linear list of the generic march, or one segment per wave of the fused kernels (infer_dogx.hip: x pass;
+    // infer_dogf.hip: y march - its grid depends on the z border, unknown here: bounds over every border)
     const DogxGrid xg = mi_dogx_grid(D, H, W);
     size_t cand_cap = n_vox / 4 + 1024;
-    p = take(sizeof(uint2) * std::max(cand_cap, (size_t)xg.n_seg * xg.seg_cap));
-    if (w) { w->cands = (uint2*)p; w->cand_cap = (unsigned)cand_cap; w->xg = xg; }
+    const int bxy_l = (H > 512 && W > 512) ? 60 : 30;
+    size_t f_seg = 0, f_ent = 0;
+    if (2 * bxy_l < H && 2 * bxy_l < W) {
+        const DogfGrid fg0 = mi_dogf_grid(D, H, W, 0, bxy_l);
+        f_seg = std::max<size_t>(4 * 12288, (size_t)D * fg0.n_strips) + 64;      // (mi_dogf_grid: chunks double while waves < 6144; x4 for the MI_DOGF_NYC knob)
+        f_ent = (size_t)D * fg0.n_strips * (size_t)(H - 2 * bxy_l) * 16 + 96 * f_seg;
+    }
+    const size_t cand_room = std::max(std::max(cand_cap, (size_t)xg.n_seg * xg.seg_cap), f_ent);
+    p = take(sizeof(uint2) * cand_room);
+    if (w) { w->cands = (uint2*)p; w->cand_cap = (unsigned)cand_cap; w->xg = xg; w->cand_room = cand_room; }
     int zc;
     dim3 grid = mi_march_grid(D, H, W, &zc);
     size_t n_stats = (size_t)grid.x * grid.y * grid.z;
-    p = take(sizeof(double) * 3 * std::max(n_stats, (size_t)xg.n_seg)); if (w) { w->stats = (double*)p; w->n_stats = n_stats; }
-    p = take(sizeof(unsigned) * xg.n_seg); if (w) w->seg_count = (unsigned*)p;
+    const size_t seg_room = std::max((size_t)xg.n_seg, f_seg);
+    p = take(sizeof(double) * 3 * std::max(n_stats, seg_room)); if (w) { w->stats = (double*)p; w->n_stats = n_stats; }
+    p = take(sizeof(unsigned) * seg_room); if (w) { w->seg_count = (unsigned*)p; w->seg_room = seg_room; }
     // the dense candidate map reuses a Gaussian buffer (free once the last DoG level is consumed)
     off += greedy_ws_layout(n_vox, greedy_default_cap(n_vox, false), w ? &w->gw : nullptr, base ? base + off : nullptr, false);
     return off;
@@ -796,9 +788,37 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
     DogWs w;
     dog_ws_layout(D, H, W, &w, (char*)workspace);
     GreedyWs& gw = w.gw;
-    // The fused two-sigma chain clears the header and the candidate bitmap inside its first launch (the z pass: a few words
-    // per thread next to 0.8 GB of traffic); every other chain clears them with two fill passes here.
     const unsigned bits_words = (unsigned)((n_vox + 31) / 32 + 2);
+    // Round 4: z + x passes | y pass + DoG + NMS (infer_dogf.hip) - two launches, no y-pass intermediates; the first launch
+    // also zeroes the header and the candidate bitmap, the candidate filter computes the cutoff in its prologue.
+    {
+        const int bxy_f = (H > 512 && W > 512) ? 60 : 30;
+        if (n_sigmas == 2 && mi_dogf_usable(rec, w.g[0], w.g[1], heat_out, D, H, W, sigmas_host[0], sigmas_host[1], k,
+                                            border_z, bxy_f)) {
+            const DogfGrid fg = mi_dogf_grid(D, H, W, border_z, bxy_f);
+            if (fg.n_seg > 0 && (size_t)fg.n_seg * fg.seg_cap <= w.cand_room && fg.n_seg <= w.seg_room) {
+                DogfParams q = {};
+                q.rec = rec; q.g1 = w.g[0]; q.g2 = w.g[1]; q.nms_out = heat_out;
+                q.D = D; q.H = H; q.W = W; q.bz = border_z; q.by = bxy_f; q.bx = bxy_f;
+                q.cands = w.cands; q.seg_count = w.seg_count; q.overflow = &gw.hdr->overflow; q.stats = w.stats;
+                q.clr[0] = reinterpret_cast<unsigned*>(gw.hdr); q.clr_n[0] = (unsigned)(sizeof(GreedyHeader) / 4);
+                q.clr[1] = gw.bits; q.clr_n[1] = bits_words;
+                if (heat_out) MI_HIP(hipMemsetAsync(heat_out, 0, sizeof(float) * n_vox, s));      // the zeroed border
+                int rcf = mi_launch_dogf(q, fg, sigmas_host[0], sigmas_host[1], s);
+                if (rcf) return rcf;
+                gw.map = reinterpret_cast<int*>(w.tmp);               // (g[0] / g[1] are read by the y march only: free as
+                gw.vmap = reinterpret_cast<unsigned*>(w.heat); gw.vol = nullptr;    // well, but these two are never touched)
+                const unsigned fb = std::min<unsigned>((fg.n_seg + 7) / 8, 1024u);
+                hipLaunchKernelGGL(cand_filter_seg_kernel<true>, dim3(fb), dim3(256), 0, s, w.cands, w.seg_count, fg.n_seg,
+                                   fg.seg_cap, gw.hdr, gw.G, gw.map, gw.vmap, gw.bits, gw.cap, (const double*)w.stats,
+                                   (int)fg.n_wg, cutoff_out);
+                MI_RETURN_IF_LAUNCH_FAILED();
+                return greedy_tail(gw, D, H, W, (float)nms_d, 1.0f, scores, coords, n_out, max_out, s);
+            }
+        }
+    }
+    // The round-3 two-sigma chain clears the header and the candidate bitmap inside its first launch (the z pass: a few words
+    // per thread next to 0.8 GB of traffic); every other chain clears them with two fill passes here.
     const bool no_march0 = getenv("MI_GAUSS_NO_MARCH") != nullptr;
     const int bxy0 = (H > 512 && W > 512) ? 60 : 30;
     const bool fused_chain = n_sigmas == 2 && !no_march0 && sigmas_host[0] <= sigmas_host[1] &&
@@ -882,8 +902,9 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
             gw.vmap = reinterpret_cast<unsigned*>(w.g[1]); gw.vol = nullptr;
             if (!fused_chain) MI_HIP(hipMemsetAsync(gw.bits, 0, sizeof(unsigned) * bits_words, s));
             const unsigned fb = std::min<unsigned>((w.xg.n_seg + 7) / 8, 1024u);
-            hipLaunchKernelGGL(cand_filter_seg_kernel, dim3(fb), dim3(256), 0, s, w.cands, w.seg_count, w.xg.n_seg,
-                               w.xg.seg_cap, gw.hdr, gw.G, gw.map, gw.vmap, gw.bits, gw.cap);
+            hipLaunchKernelGGL(cand_filter_seg_kernel<false>, dim3(fb), dim3(256), 0, s, w.cands, w.seg_count, w.xg.n_seg,
+                               w.xg.seg_cap, gw.hdr, gw.G, gw.map, gw.vmap, gw.bits, gw.cap, (const double*)nullptr, 0,
+                               (float*)nullptr);
             MI_RETURN_IF_LAUNCH_FAILED();
             return greedy_tail(gw, D, H, W, (float)nms_d, 1.0f, scores, coords, n_out, max_out, s);
         }

@@ -1383,9 +1383,21 @@ def _ce0_counter(device):
     sid = torch.cuda.current_stream(device).cuda_stream
     slot = slots.get(sid)
     if slot is None:
-        slot = len(slots) % 64
+        if len(slots) >= 64:
+            # never alias: two live streams on one arrival word mix their tickets (a wrong or missing loss write)
+            raise L.HipExtensionError("cross_entropy_label0 has been launched on 64 distinct HIP streams of %s; "
+                                    "hipops.reset_ce0_counters() releases the words of streams that no longer exist" % (device,))
+        slot = len(slots)
         slots[sid] = slot
     return table[slot * 64:]
+
+
+def reset_ce0_counters(device=None):
+    """Forget the stream -> arrival-word table (all devices, or one).  Call it only with no cross-entropy launch in flight
+    and outside a hipGraph capture; graphs captured before keep the addresses of the old table alive through their tensors."""
+    for key in list(_CE0_COUNTERS):
+        if device is None or key == (device.type, device.index):
+            del _CE0_COUNTERS[key]
 
 
 class _CELabel0Fn(torch.autograd.Function):
@@ -1397,8 +1409,12 @@ class _CELabel0Fn(torch.autograd.Function):
         b, n = logits.shape
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
         rows = torch.empty(2 * b, dtype=torch.float32, device=logits.device)          # row losses | row log-sum-exps
-        L.check(L.lib().mi_ce_label0_fwd(L.ptr(logits), L.ptr(loss), L.ptr(out), L.ptr(rows), L.ptr(rows[b:]), b, n,
-                                         L.ptr(_ce0_counter(logits.device)), L.stream()), "mi_ce_label0_fwd")
+        word = _ce0_counter(logits.device)
+        rc = L.lib().mi_ce_label0_fwd(L.ptr(logits), L.ptr(loss), L.ptr(out), L.ptr(rows), L.ptr(rows[b:]), b, n,
+                                      L.ptr(word), L.stream())
+        if rc != 0 and not torch.cuda.is_current_stream_capturing():
+            word[:1].zero_()                           # a launch that failed midway must not leave its tickets behind
+        L.check(rc, "mi_ce_label0_fwd")
         ctx.save_for_backward(logits, rows)
         return loss
 

@@ -243,11 +243,9 @@ class MocoStepEngine:
             # at its own pace; under the default "global" capture mode such a call from another thread while this one is
             # capturing is an error that terminates the process (hipErrorStreamCaptureUnsupported: seen once in ~20 runs of
             # the one-rank rehearsal).  "thread_local" restricts only the capturing thread - which issues everything the
-            # step needs - and the short drain lets the watchdog retire the finished works first.
+            # step needs; HIP then checks only this thread's own capture list, so no drain of the watchdog is needed (the
+            # device was synchronised above: every warm-up work has finished, whenever the watchdog gets to see it).
             mode = "thread_local" if self.dist_on else "global"
-            if self.dist_on:
-                import time
-                time.sleep(0.25)
             with torch.cuda.graph(graph, capture_error_mode=mode):       # records, does not execute
                 self._step_eager(self._static_q, self._static_k)
         except Exception as e:                        # e.g. a collective that cannot be captured
