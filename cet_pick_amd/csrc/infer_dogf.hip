@@ -374,6 +374,8 @@ bool mi_dogf_usable(const float* rec, const float* g1, const float* g2, const fl
            bxy >= r2 && bxy >= 1 && 2 * bxy < H && 2 * bxy < W && bz >= 0 && 2 * bz < D && al(rec) && al(g1) && al(g2) && al(nms_out);
 }
 
+int mi_dogf_own() { return FY_OWN; }
+
 DogfGrid mi_dogf_grid(int D, int H, int W, int bz, int bxy) {
     DogfGrid g = {};
     if (2 * bxy >= H || 2 * bxy >= W || 2 * bz >= D) return g;

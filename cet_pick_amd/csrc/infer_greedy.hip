@@ -26,6 +26,7 @@ namespace {
 
 constexpr int CAPN = 32;          // stored higher-priority neighbours per candidate
 constexpr int MAX_RUNS = 33 * 33; // (dz, dy) rows of the ball
+constexpr int NB_MAX_RANGES = 1024;   // workgroups of cand_filter_seg_kernel (one list range each)
 
 struct GreedyHeader {
     unsigned cand_count;     // positive NMS survivors (march kernel)
@@ -41,7 +42,7 @@ struct GreedyHeader {
 
 // A row (dz, dy) of the ball is a run of consecutive flat offsets (the reference's ball lives in flat index space, no
 // bounds check): first offset and length.
-struct BallRun { long start; int len; int pad; };
+struct BallRun { int start; int len; };       // (|start| < 2^31: the volume has fewer voxels than that)
 
 __device__ __forceinline__ unsigned order_bits(float v) {
     unsigned b = __float_as_uint(v);
@@ -121,7 +122,7 @@ __device__ int ball_rows_lds(BallRun* s_runs, int* s_scan, double r, int width, 
         const int t = tid * per + k;
         if (cm[k] >= 0) {
             const int a = t / side - width, b = t % side - width;
-            s_runs[pos++] = BallRun{(long)a * zs + (long)b * ys - (long)cm[k], 2 * cm[k] + 1, 0};
+            s_runs[pos++] = BallRun{(int)((long)a * zs + (long)b * ys - (long)cm[k]), 2 * cm[k] + 1};
         }
     }
     const int n = s_scan[nt - 1];
@@ -199,7 +200,6 @@ __global__ __launch_bounds__(256) void cand_filter_kernel(const uint2* cands, un
 // The survivors of a workgroup are staged in LDS and take their slots in G with ONE returning atomic per workgroup: a
 // returning atomic on a single word costs ~11 ns, and one per wave and 64-candidate step (~10^4 of them for 83 k
 // survivors) made the linear-list kernel above 58 us for 2.4 MB of candidates.
-constexpr int CF_STAGE = 3072;
 // FIN: the cutoff (mean + 0.5 std of the positive survivors, stats_finalize_kernel's arithmetic) is computed by EVERY
 // workgroup from the partial sums in one fixed order - the same bits everywhere - instead of by a launch of its own in
 // front of this one; workgroup 0 publishes it.
@@ -208,14 +208,14 @@ __global__ __launch_bounds__(256) void cand_filter_seg_kernel(const uint2* cands
                                                              unsigned n_seg, unsigned seg_cap, GreedyHeader* hdr,
                                                              unsigned long long* G, int* map, unsigned* vmap,
                                                              unsigned* bits, unsigned cap, const double* partials,
-                                                             int n_part, float* cutoff_out) {
-    __shared__ uint2 stage[CF_STAGE];
+                                                             int n_part, float* cutoff_out, uint2* ranges) {
+    __shared__ double s_red[3 * 256];
     __shared__ unsigned s_n, s_base;
     __shared__ float s_cut;
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) s_n = 0;
     if (FIN) {
-        double* r = reinterpret_cast<double*>(stage);      // 3 x 256 doubles, before the stage is used
+        double* r = s_red;
         double a = 0, s = 0, ss = 0;
         for (int i = tid; i < n_part; i += 256) { a += partials[3 * i]; s += partials[3 * i + 1]; ss += partials[3 * i + 2]; }
         r[tid] = a; r[256 + tid] = s; r[512 + tid] = ss;
@@ -236,7 +236,6 @@ __global__ __launch_bounds__(256) void cand_filter_seg_kernel(const uint2* cands
     }
     __syncthreads();
     const float cut = FIN ? s_cut : hdr->cutoff;
-    __syncthreads();                                       // (FIN: the reduction scratch becomes the stage)
     auto place = [&](uint2 c, unsigned slot) {
         if (slot < cap) {
             G[slot] = ((unsigned long long)order_bits(__uint_as_float(c.x)) << 32) | (unsigned long long)c.y;
@@ -247,11 +246,15 @@ __global__ __launch_bounds__(256) void cand_filter_seg_kernel(const uint2* cands
             atomicOr(&hdr->overflow, 1u);
         }
     };
-    // a workgroup takes CONSECUTIVE segments (= neighbouring y chunks / z planes): the list comes out roughly plane by
-    // plane, which gives the neighbour search its cache locality
+    // A workgroup takes CONSECUTIVE segments (= neighbouring strips / row chunks / z planes) and its survivors ONE contiguous
+    // range of the list, recorded in `ranges[workgroup]`: walked range by range the list is in plane order whatever order
+    // the workgroups finished in - the neighbour search then works on one slab of the volume at a time (its bitmap lines stay
+    // in L2; in completion order the whole 8 MB bitmap was the working set: 0.32 GB of fetches).  Two passes over the
+    // segments: count, take the range with one atomic, place (the second read comes from L2).
     const unsigned per_wg = (n_seg + gridDim.x - 1) / gridDim.x;
     const unsigned sg_end = min((blockIdx.x + 1) * per_wg, n_seg);
     constexpr int PF = 4;
+    unsigned mine = 0;
     for (unsigned sg = blockIdx.x * per_wg + (tid >> 6); sg < sg_end; sg += 4) {
         const unsigned cnt = min(seg_count[sg], seg_cap);
         const uint2* base = cands + (size_t)sg * seg_cap;
@@ -259,6 +262,31 @@ __global__ __launch_bounds__(256) void cand_filter_seg_kernel(const uint2* cands
             uint2 c[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {                        // all loads of the step in flight together
+                const unsigned i = i0 + 64 * u + lane;
+                c[u] = i < cnt ? base[i] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) mine += (i0 + 64 * u + lane < cnt && __uint_as_float(c[u].x) > cut) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (lane == 0 && mine) atomicAdd(&s_n, mine);               // LDS
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned n = s_n;
+        s_base = n ? atomicAdd(&hdr->n, n) : 0u;                // ONE returning atomic per workgroup (~11 ns each on one word)
+        if (ranges) ranges[blockIdx.x] = make_uint2(s_base, n);
+        s_n = s_base;                                            // becomes the placement cursor
+    }
+    __syncthreads();
+    for (unsigned sg = blockIdx.x * per_wg + (tid >> 6); sg < sg_end; sg += 4) {
+        const unsigned cnt = min(seg_count[sg], seg_cap);
+        const uint2* base = cands + (size_t)sg * seg_cap;
+        for (unsigned i0 = 0; i0 < cnt; i0 += 64 * PF) {
+            uint2 c[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
                 const unsigned i = i0 + 64 * u + lane;
                 c[u] = i < cnt ? base[i] : make_uint2(0u, 0u);
             }
@@ -273,21 +301,267 @@ __global__ __launch_bounds__(256) void cand_filter_seg_kernel(const uint2* cands
                 const int leader = __ffsll((long long)km) - 1;
                 if (lane == leader) b0 = atomicAdd(&s_n, (unsigned)__popcll(km));     // LDS
                 b0 = __shfl(b0, leader, 64);
-                if (keep) {
-                    const unsigned slot = b0 + (unsigned)__popcll(km & ((1ull << lane) - 1ull));
-                    if (slot < CF_STAGE) stage[slot] = c[u];
-                    else place(c[u], atomicAdd(&hdr->n, 1u));     // stage full: straight to the list
-                }
+                if (keep) place(c[u], b0 + (unsigned)__popcll(km & ((1ull << lane) - 1ull)));
             }
         }
     }
+}
+
+// ---- the fused picker's candidates as a SPATIAL INDEX (round 4) ------------------------------------------------------
+// The y march (infer_dogf.hip) leaves its survivors in segments: one per (plane, chunk of rows, strip of 62 columns), in
+// row order.  Filtered by the cutoff IN that order, every segment becomes a contiguous, row-sorted run of the candidate
+// list, and (start, count) per segment is a grid index of the candidates: the ball of a candidate (15 planes, radius 7)
+// overlaps ~40 segments and a binary search on the row finds the one or two entries of each that can matter.  The bitmap
+// search of round 3 probed every row of the ball - 149 scattered 8-byte loads per candidate, 97 % of them empty - through
+// an 8 MB bitmap, a dense id map and a dense value map (60 - 70 us, 0.33 GB of fetches, all three cleared / scattered per
+// call); none of the three exists on this path.  Exactness: the reference's ball lives in flat index space; with the picker's
+// zeroed border (>= 30 voxels in x / y) wider than the ball no row of it wraps, so the coordinate test is the same set.
+struct SegIndex {
+    const uint2* seg_range;      // per segment: (first slot, count) in the candidate list; null = no index (bitmap search)
+    const unsigned* coord;       // per slot: (y << 16) | x
+    const unsigned* coordz;      // per slot: z
+    const unsigned* sub;         // per segment nb + 1 slots: sub[r] = first entry of the segment in row block r or later (8 rows
+    int nb;                      // per block; sub[nb] = end of the segment): a row window is two loads, not a binary search
+    int D, H, W, bz, by, bx;
+    int ychunk, n_ychunks, n_strips, own;
+    int width;
+    double r2;
+};
+
+// calls fn(slot) for every candidate of HIGHER priority inside the ball of candidate (ki, z, y, x)
+template <typename F>
+__device__ __forceinline__ void seg_for_each_higher(const SegIndex& sx, const unsigned long long* G, unsigned long long ki,
+                                                    int z, int y, int x, F&& fn) {
+    const int w = sx.width;
+    const int z_lo = max(z - w, sx.bz), z_hi = min(z + w, sx.D - sx.bz - 1);
+    const int y_lo = max(y - w, sx.by), y_hi = min(y + w, sx.H - sx.by - 1);
+    const int x_lo = max(x - w, sx.bx), x_hi = min(x + w, sx.W - sx.bx - 1);
+    const int c_lo = (y_lo - sx.by) / sx.ychunk, c_hi = (y_hi - sx.by) / sx.ychunk;
+    const int s_lo = (x_lo - sx.bx) / sx.own, s_hi = (x_hi - sx.bx) / sx.own;
+    for (int zz = z_lo; zz <= z_hi; ++zz) {
+        const int dz = zz - z;
+        const double rest = sx.r2 - (double)(dz * dz);
+        if (rest < 0.0) continue;
+        for (int c = c_lo; c <= c_hi; ++c)
+            for (int st = s_lo; st <= s_hi; ++st) {
+                const uint2 rg = sx.seg_range[((size_t)(zz - sx.bz) * sx.n_ychunks + c) * sx.n_strips + st];
+                if (rg.y == 0) continue;
+                // first entry with row >= y_lo (entries are in row order)
+                unsigned lo = 0, hi = rg.y;
+                while (lo < hi) {
+                    const unsigned mid = (lo + hi) >> 1;
+                    if ((int)(sx.coord[rg.x + mid] >> 16) < y_lo) lo = mid + 1; else hi = mid;
+                }
+                for (unsigned e = lo; e < rg.y; ++e) {
+                    const unsigned cj = sx.coord[rg.x + e];
+                    const int yj = (int)(cj >> 16), xj = (int)(cj & 0xffffu);
+                    if (yj > y_hi) break;
+                    const int dy = yj - y, dx = xj - x;
+                    if ((double)(dy * dy + dx * dx) > rest) continue;
+                    if (G[rg.x + e] > ki) fn((int)(rg.x + e));
+                }
+            }
+    }
+}
+
+// ---- segmented candidates -> row-sorted runs of the list + the index ------------------------------------------------------
+// As cand_filter_seg_kernel<true> (cutoff in the prologue, one list range per workgroup), but a SEGMENT's survivors stay
+// together and in order, and nothing else is written: no bitmap, no id map, no value map.
+constexpr int CI_MAXSEG = 64;        // segments per workgroup (the host sizes the grid accordingly)
+__global__ __launch_bounds__(256) void cand_index_kernel(const uint2* cands, const unsigned* seg_count, unsigned n_seg,
+                                                        unsigned seg_cap, GreedyHeader* hdr, unsigned long long* G,
+                                                        unsigned* coord, unsigned* coordz, uint2* seg_range, unsigned cap,
+                                                        const double* partials, int n_part, float* cutoff_out,
+                                                        uint2* ranges, int H, int W, unsigned* sub, int nb, int by,
+                                                        int ychunk, int n_ychunks, int n_strips) {
+    __shared__ double s_red[3 * 256];
+    __shared__ unsigned s_cnt[CI_MAXSEG], s_start[CI_MAXSEG];
+    __shared__ float s_cut;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    {
+        double a = 0, s = 0, ss = 0;
+        for (int i = tid; i < n_part; i += 256) { a += partials[3 * i]; s += partials[3 * i + 1]; ss += partials[3 * i + 2]; }
+        s_red[tid] = a; s_red[256 + tid] = s; s_red[512 + tid] = ss;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) { s_red[tid] += s_red[tid + o]; s_red[256 + tid] += s_red[256 + tid + o]; s_red[512 + tid] += s_red[512 + tid + o]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double n = s_red[0], mean = n > 0 ? s_red[256] / n : 0.0;
+            double var = n > 1 ? (s_red[512] - n * mean * mean) / (n - 1.0) : 0.0;
+            if (var < 0) var = 0;
+            float c = (float)(mean + 0.5 * sqrt(var));
+            if (!(n > 0)) c = INFINITY;
+            s_cut = c;
+            if (blockIdx.x == 0) { hdr->cutoff = c; if (cutoff_out) *cutoff_out = c; }
+        }
+        __syncthreads();
+    }
+    const float cut = s_cut;
+    const unsigned per_wg = (n_seg + gridDim.x - 1) / gridDim.x;            // <= CI_MAXSEG
+    const unsigned sg0 = blockIdx.x * per_wg, sg_end = min(sg0 + per_wg, n_seg);
+    constexpr int PF = 4;
+    // pass 1: survivors per segment (a wave per segment)
+    for (unsigned sg = sg0 + wv; sg < sg_end; sg += 4) {
+        const unsigned cnt = min(seg_count[sg], seg_cap);
+        const uint2* base = cands + (size_t)sg * seg_cap;
+        unsigned mine = 0;
+        for (unsigned i0 = 0; i0 < cnt; i0 += 64 * PF) {
+            uint2 c[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {                        // all loads of the step in flight together
+                const unsigned i = i0 + 64 * u + lane;
+                c[u] = i < cnt ? base[i] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) mine += (i0 + 64 * u + lane < cnt && __uint_as_float(c[u].x) > cut) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+        if (lane == 0) s_cnt[sg - sg0] = mine;
+    }
     __syncthreads();
-    const unsigned n = min(s_n, (unsigned)CF_STAGE);
-    if (n == 0) return;
-    if (tid == 0) s_base = atomicAdd(&hdr->n, n);
+    if (tid == 0) {
+        unsigned tot = 0;
+        for (unsigned q = 0; q < sg_end - sg0 && sg0 < sg_end; ++q) tot += s_cnt[q];
+        unsigned base = tot ? atomicAdd(&hdr->n, tot) : 0u;     // ONE returning atomic per workgroup
+        if (base + tot > cap) { atomicOr(&hdr->overflow, 1u); }
+        if (ranges) ranges[blockIdx.x] = make_uint2(base, tot);
+        for (unsigned q = 0; sg0 + q < sg_end; ++q) { s_start[q] = base; base += s_cnt[q]; }
+    }
     __syncthreads();
-    const unsigned gb = s_base;
-    for (unsigned i = tid; i < n; i += 256) place(stage[i], gb + i);
+    if (tid < (int)(sg_end > sg0 ? sg_end - sg0 : 0u)) {
+        const unsigned st = s_start[tid], ct = s_cnt[tid];
+        seg_range[sg0 + tid] = (st + ct <= cap) ? make_uint2(st, ct) : make_uint2(0u, 0u);
+    }
+    // pass 2: place, in order (the second read comes from L2)
+    const long hw = (long)H * W;
+    for (unsigned sg = sg0 + wv; sg < sg_end; sg += 4) {
+        const unsigned cnt = min(seg_count[sg], seg_cap);
+        const uint2* base = cands + (size_t)sg * seg_cap;
+        unsigned pos = s_start[sg - sg0];
+        unsigned* sb = sub + (size_t)sg * (nb + 1);
+        if (pos + s_cnt[sg - sg0] > cap) {                      // (overflow: flagged above, the segment is dropped)
+            for (int r = lane; r <= nb; r += 64) sb[r] = 0u;
+            continue;
+        }
+        const int ya = by + (int)((sg / n_strips) % n_ychunks) * ychunk;      // first row of the segment's chunk
+        int rb_last = -1;                                       // row block of the last entry placed so far (wave-uniform)
+        for (unsigned i0 = 0; i0 < cnt; i0 += 64 * PF) {
+            uint2 c[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const unsigned i = i0 + 64 * u + lane;
+                c[u] = i < cnt ? base[i] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (i0 + 64 * u >= cnt) break;                    // (wave-uniform)
+                const unsigned i = i0 + 64 * u + lane;
+                const bool keep = i < cnt && __uint_as_float(c[u].x) > cut;
+                const unsigned long long km = __ballot(keep);
+                if (!km) continue;
+                const unsigned long long below = km & ((1ull << lane) - 1ull);
+                const long rem = (long)c[u].y % hw;
+                const int yy = (int)(rem / W);
+                int rb = keep ? min(max((yy - ya) >> 3, 0), nb - 1) : 0;
+                // the row block of the previous survivor: the nearest kept lane below, or the last one of the step before
+                const int prev_lane = below ? 63 - __builtin_clzll(below) : 0;
+                const int rb_from = __shfl(rb, prev_lane, 64);
+                const int rb_prev = below ? rb_from : rb_last;
+                if (keep) {
+                    const unsigned slot = pos + (unsigned)__popcll(below);
+                    G[slot] = ((unsigned long long)order_bits(__uint_as_float(c[u].x)) << 32) | (unsigned long long)c[u].y;
+                    coord[slot] = ((unsigned)yy << 16) | (unsigned)(rem % W);
+                    coordz[slot] = (unsigned)((long)c[u].y / hw);
+                    for (int r = rb_prev + 1; r <= rb; ++r) sb[r] = slot;       // blocks that start at this entry
+                }
+                rb_last = __shfl(rb, 63 - __builtin_clzll(km), 64);
+                pos += (unsigned)__popcll(km);
+            }
+        }
+        for (int r = rb_last + 1 + lane; r <= nb; r += 64) sb[r] = pos;        // the blocks behind the last entry, and the end
+    }
+}
+
+// ---- neighbour lists from the index: a WAVE per candidate, a LANE per segment of its ball --------------------------------
+// The ball of a candidate overlaps (2 w + 1) planes x <= 2 chunks x <= 2 strips = at most 60 segments at w = 7: lane v takes
+// segment v, finds the candidate's row window in it with two loads of the sub-index, and the lanes then walk their windows
+// in lockstep - entry t of every lane in one step, coordinate and key loaded together - compacting the hits into the row of
+// `nbr` by ballot.  A candidate costs 1 + (longest window, ~4) memory round trips, its successor's key and coordinates are
+// in flight meanwhile.  (A thread per candidate walking its ~40 segments by itself: 129 us - 280 dependent loads in a row.)
+__global__ __launch_bounds__(256) void neighbors_seg_kernel(GreedyHeader* hdr, const unsigned long long* G, SegIndex sx,
+                                                           unsigned cap, int* nbr, unsigned char* state) {
+    const unsigned n = min(hdr->n, cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { hdr->n_runs = 0; hdr->n_kept = 0; hdr->n_left = 0; hdr->ticket = 0; }
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), n_waves = (gridDim.x * 256) >> 6;
+    const int w = sx.width;
+    // (no integer division in the loop: the kernel was bound by its own instruction stream - ~8 emulated divisions per
+    // candidate; rows and columns are < 2^16, so n / d = (n * ceil(2^32 / d)) >> 32 exactly)
+    const unsigned m_chunk = (unsigned)((0x100000000ull + (unsigned)sx.ychunk - 1) / (unsigned)sx.ychunk);
+    const unsigned m_own = (unsigned)((0x100000000ull + (unsigned)sx.own - 1) / (unsigned)sx.own);
+    unsigned long long k_next = wave < n ? G[wave] : 0ull;
+    unsigned c_next = wave < n ? sx.coord[wave] : 0u, z_next = wave < n ? sx.coordz[wave] : 0u;
+    for (unsigned i = wave; i < n; i += n_waves) {
+        // the candidate is the same for the whole wave: scalar registers
+        const unsigned kilo = __builtin_amdgcn_readfirstlane((unsigned)k_next), kihi = __builtin_amdgcn_readfirstlane((unsigned)(k_next >> 32));
+        const unsigned long long ki = ((unsigned long long)kihi << 32) | kilo;
+        const unsigned ci = __builtin_amdgcn_readfirstlane(c_next);
+        const int z = (int)__builtin_amdgcn_readfirstlane(z_next);
+        if (i + n_waves < n) { k_next = G[i + n_waves]; c_next = sx.coord[i + n_waves]; z_next = sx.coordz[i + n_waves]; }
+        const int y = (int)(ci >> 16), x = (int)(ci & 0xffffu);
+        const int z_lo = max(z - w, sx.bz), z_hi = min(z + w, sx.D - sx.bz - 1);
+        const int y_lo = max(y - w, sx.by), y_hi = min(y + w, sx.H - sx.by - 1);
+        const int x_lo = max(x - w, sx.bx), x_hi = min(x + w, sx.W - sx.bx - 1);
+        const int c_lo = (int)__umulhi((unsigned)(y_lo - sx.by), m_chunk), nc = (int)__umulhi((unsigned)(y_hi - sx.by), m_chunk) - c_lo + 1;
+        const int s_lo = (int)__umulhi((unsigned)(x_lo - sx.bx), m_own), ns = (int)__umulhi((unsigned)(x_hi - sx.bx), m_own) - s_lo + 1;
+        // nc, ns are 1 or 2 (a chunk is >= 48 rows, a strip 62 columns, the window <= 33)
+        const int sh_s = ns - 1, sh_c = nc - 1;
+        const int n_visits = ((z_hi - z_lo + 1) << sh_c) << sh_s;
+        int count = 0;
+        int* row = nbr + (size_t)i * CAPN;
+        for (int v0 = 0; v0 < n_visits; v0 += 64) {
+            const int v = v0 + lane;
+            unsigned e0 = 0, e1 = 0;
+            int rest = -1;                                   // floor(r^2 - dz^2): dy^2 + dx^2 is an integer
+            if (v < n_visits) {
+                const int st = s_lo + (v & sh_s), c = c_lo + ((v >> sh_s) & sh_c), zz = z_lo + (v >> (sh_s + sh_c));
+                const int dz = zz - z;
+                const double rd = sx.r2 - (double)(dz * dz);
+                if (rd >= 0.0) {
+                    rest = (int)rd;
+                    const unsigned sg = (unsigned)((zz - sx.bz) * sx.n_ychunks + c) * (unsigned)sx.n_strips + (unsigned)st;
+                    const int ya = sx.by + c * sx.ychunk;
+                    const int rb0 = min(max((y_lo - ya) >> 3, 0), sx.nb - 1), rb1 = min(max((y_hi - ya) >> 3, 0), sx.nb - 1);
+                    const unsigned* sb = sx.sub + (size_t)sg * (unsigned)(sx.nb + 1);
+                    e0 = sb[rb0]; e1 = sb[rb1 + 1];
+                }
+            }
+            for (unsigned t = 0; __ballot(e0 + t < e1); ++t) {
+                int m = -1;
+                const unsigned slot = e0 + t;
+                bool near = false;
+                if (slot < e1) {
+                    const unsigned cj = sx.coord[slot];
+                    const int dy = (int)(cj >> 16) - y, dx = (int)(cj & 0xffffu) - x;
+                    near = dy * dy + dx * dx <= rest;
+                }
+                if (!__ballot(near)) continue;               // (nine entries of ten lie outside the ball: no key is fetched for them)
+                if (near && G[slot] > ki) m = (int)slot;
+                const unsigned long long ball = __ballot(m >= 0);
+                if (ball) {
+                    if (m >= 0) {
+                        const int pos = count + __popcll(ball & ((1ull << lane) - 1ull));
+                        if (pos < CAPN - 1) row[1 + pos] = m;
+                    }
+                    count += __popcll(ball);
+                }
+            }
+        }
+        if (lane == 0) { row[0] = count; state[i] = 0; }       // count > CAPN-1 -> overflow: re-probe in the rounds
+    }
 }
 
 // ---- higher-priority ball neighbours of every candidate (one wave per candidate) ---------------
@@ -305,9 +579,34 @@ __global__ __launch_bounds__(256) void neighbors_kernel(GreedyHeader* hdr,
                                                        const unsigned* vmap, const float* vol,
                                                        const unsigned* bits, BallRun* runs, long n_vox,
                                                        unsigned cap, int* nbr, unsigned char* state, double ball_r,
-                                                       int ball_width, long zs, long ys) {
+                                                       int ball_width, long zs, long ys, const uint2* ranges, int n_ranges) {
     const unsigned n = min(hdr->n, cap);
     const int lane = threadIdx.x & 63;
+    // the list range by range (cand_filter_seg_kernel: plane order); s_pref[b] = candidates in the ranges before b
+    __shared__ unsigned s_pref[NB_MAX_RANGES + 1], s_rbase[NB_MAX_RANGES];
+    if (n_ranges > 0) {
+        for (int b = threadIdx.x; b < n_ranges; b += 256) { const uint2 rg = ranges[b]; s_rbase[b] = rg.x; s_pref[b + 1] = rg.y; }
+        if (threadIdx.x == 0) s_pref[0] = 0;
+        __syncthreads();
+        if (threadIdx.x < 64) {                             // inclusive scan of <= 1024 counts by one wave
+            unsigned carry = 0;
+            for (int b0 = 0; b0 < n_ranges; b0 += 64) {
+                const int b = b0 + lane;
+                unsigned v = b < n_ranges ? s_pref[b + 1] : 0u;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+                if (b < n_ranges) s_pref[b + 1] = v + carry;
+                carry += __shfl(v, 63, 64);
+            }
+        }
+        __syncthreads();
+    }
+    auto list_index = [&](unsigned k) -> unsigned {         // k-th candidate in range order -> its slot in G
+        if (n_ranges <= 0) return k;
+        int lo = 0, hi = n_ranges;                          // last b with s_pref[b] <= k
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pref[mid] <= k) lo = mid; else hi = mid; }
+        return s_rbase[lo] + (k - s_pref[lo]);
+    };
     // Candidates are dealt round-robin to the waves: the list is filled roughly plane by plane, so at any moment the whole
     // chip works on one slab of the volume and that slab of the 8 MB bitmap is hot in every XCD's L2.  (Contiguous ranges
     // per wave with one z-slab per XCD were measured slower: 85 us against 59 us.)
@@ -323,10 +622,12 @@ __global__ __launch_bounds__(256) void neighbors_kernel(GreedyHeader* hdr,
         if (threadIdx.x == 0) { hdr->n_runs = (unsigned)nr; hdr->n_kept = 0; hdr->n_left = 0; hdr->ticket = 0; }
     }
     constexpr int QB = 4;                         // row groups whose bitmap words are fetched together
-    unsigned long long k_next = wave < n ? G[wave] : 0ull;
-    for (unsigned i = wave; i < n; i += n_waves) {
+    unsigned i_next = wave < n ? list_index(wave) : 0u;
+    unsigned long long k_next = wave < n ? G[i_next] : 0ull;
+    for (unsigned kk = wave; kk < n; kk += n_waves) {
+        const unsigned i = i_next;
         const unsigned long long ki = k_next;              // (the next candidate's key is in flight during this one's search)
-        if (i + n_waves < n) k_next = G[i + n_waves];
+        if (kk + n_waves < n) { i_next = list_index(kk + n_waves); k_next = G[i_next]; }
         const long idx = (long)(ki & 0xffffffffull);
         const unsigned vi = (unsigned)(ki >> 32);
         int count = 0;
@@ -361,19 +662,30 @@ __global__ __launch_bounds__(256) void neighbors_kernel(GreedyHeader* hdr,
                 pend[u] = len[u] > 0 ? (win & ((1ull << len[u]) - 1ull)) : 0ull;     // len <= 33 <= 64 - sh
                 if (idx >= lo[u] && idx < lo[u] + len[u]) pend[u] &= ~(1ull << (idx - lo[u]));   // not its own neighbour
             }
-            // pop the set bits (rare) in wave-uniform steps, compacting the hits into the neighbour list
+            // pop the set bits in wave-uniform steps, compacting the hits into the neighbour list.  A step takes up to TWO
+            // hits per lane out of ANY of its rows and has all four loads (id, priority) in flight together: the steps of a
+            // candidate are its longest lane's hits / 2 - round 3 ran one loop per row group with one hit per trip, each
+            // trip a memory round trip of its own (3 - 6 per candidate)
+            while (true) {
+                long j[2] = {-1, -1};
 #pragma unroll
-            for (int u = 0; u < QB; ++u) {
-                while (__ballot(pend[u] != 0ull)) {
-                    int m = -1;
-                    if (pend[u]) {
-                        const int b = __ffsll((long long)pend[u]) - 1;
-                        pend[u] &= pend[u] - 1ull;
-                        const long j = lo[u] + b;
-                        const int mm = map[j];                                          // two independent loads
-                        const unsigned vj = vol ? order_bits(vol[j]) : vmap[j];
-                        if (vj > vi || (vj == vi && j > idx)) m = mm;                   // (value, index) both descending
-                    }
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < QB; ++u)
+                        if (j[t] < 0 && pend[u]) {
+                            const int b = __ffsll((long long)pend[u]) - 1;
+                            pend[u] &= pend[u] - 1ull;
+                            j[t] = lo[u] + b;
+                        }
+                if (!__ballot(j[0] >= 0)) break;
+                int mm[2] = {-1, -1};
+                unsigned vj[2] = {0u, 0u};
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (j[t] >= 0) { mm[t] = map[j[t]]; vj[t] = vol ? order_bits(vol[j[t]]) : vmap[j[t]]; }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int m = (j[t] >= 0 && (vj[t] > vi || (vj[t] == vi && j[t] > idx))) ? mm[t] : -1;   // (value, index) both descending
                     const unsigned long long ball = __ballot(m >= 0);
                     if (m >= 0) {
                         const int pos = count + __popcll(ball & ((1ull << lane) - 1ull));
@@ -395,7 +707,7 @@ __global__ __launch_bounds__(256) void neighbors_kernel(GreedyHeader* hdr,
 // state: 0 undecided, 1 pick, 2 suppressed
 __device__ __forceinline__ int decide(unsigned i, int4 r0, const unsigned long long* G, const int* map, const unsigned* bits,
                                       const BallRun* runs, int nr, long n_vox, const int* nbr,
-                                      const volatile unsigned char* state) {
+                                      const volatile unsigned char* state, const SegIndex& sx) {
     const int cnt = r0.x;                                  // r0 = the first 16 bytes of row i: count + three neighbours
     bool all_decided = true;
     if (cnt <= CAPN - 1) {
@@ -420,6 +732,18 @@ __device__ __forceinline__ int decide(unsigned i, int4 r0, const unsigned long l
                 if (st[u] == 0) all_decided = false;
             }
         }
+    } else if (sx.seg_range) {
+        const unsigned long long ki = G[i];
+        const long idx = (long)(ki & 0xffffffffull);
+        const unsigned cj = sx.coord[i];
+        bool pick_near = false;
+        (void)idx;
+        seg_for_each_higher(sx, G, ki, (int)sx.coordz[i], (int)(cj >> 16), (int)(cj & 0xffffu), [&](int slot) {
+            const unsigned char st = state[slot];
+            if (st == 1) pick_near = true;
+            if (st == 0) all_decided = false;
+        });
+        if (pick_near) return 2;
     } else {
         const unsigned long long ki = G[i];
         const long idx = (long)(ki & 0xffffffffull);
@@ -447,7 +771,7 @@ __device__ __forceinline__ int decide(unsigned i, int4 r0, const unsigned long l
 // (states are read past the L1 - volatile - so decisions of other workgroups are seen as they land; a stale read only
 // defers a decision), compacts its picks with ONE returning atomic per workgroup, hands what is still open (a few dozen
 // candidates chip-wide) to a list, and the workgroup that finishes last resolves that list alone.
-constexpr int RA_T = 256, RA_PASSES = 12, RA_REG = 11;   // RA_REG neighbour ids of a candidate live in registers
+constexpr int RA_T = 256, RA_PASSES = 16, RA_LBITS = 8, RA_LMAX = 1 << RA_LBITS, RA_REG = 11;   // RA_REG neighbour ids of a candidate live in registers
 
 // one pass over a candidate whose list (<= RA_REG entries) sits in registers: ONE round trip (the neighbours' states)
 __device__ __forceinline__ int decide_reg(const int (&ids)[RA_REG], int cnt, const volatile unsigned char* state) {
@@ -464,7 +788,7 @@ __global__ __launch_bounds__(RA_T) void rounds_all_kernel(GreedyHeader* hdr, con
                                                          const unsigned* bits, const BallRun* runs, long n_vox,
                                                          unsigned cap, const int* nbr, volatile unsigned char* state,
                                                          unsigned* left, unsigned* act_b, unsigned long long* kept,
-                                                         unsigned kept_cap) {
+                                                         unsigned kept_cap, SegIndex sx) {
     __shared__ unsigned s_wcnt[2][RA_T / 64], s_base[2], s_last, s_next, s_kept;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const unsigned n = min(hdr->n, cap);
@@ -486,13 +810,13 @@ __global__ __launch_bounds__(RA_T) void rounds_all_kernel(GreedyHeader* hdr, con
         const unsigned i = i0 + tid;
         int ids[RA_REG], cnt = 0, my = 2;
         if (i < hi) { load_list(i, ids, cnt); my = 0; }
-        for (int pass = 0; pass < RA_PASSES; ++pass) {
-            if (my == 0) {
-                const int4 r0 = make_int4(cnt, ids[0], ids[1], ids[2]);
-                my = cnt <= RA_REG ? decide_reg(ids, cnt, state) : decide(i, r0, G, map, bits, runs, nr, n_vox, nbr, state);
-                if (my != 0) state[i] = (unsigned char)my;
-            }
-            if (!__syncthreads_or(my == 0 ? 1 : 0)) break;  // this trip is resolved
+        // every thread polls for itself: a pass is ONE memory round trip (the neighbours' states, read past the caches),
+        // its own state goes out as a store nobody waits for - with a workgroup barrier between the passes every pass also
+        // paid the store's way to memory (59 us for 12 passes)
+        for (int pass = 0; pass < RA_PASSES && my == 0; ++pass) {
+            const int4 r0 = make_int4(cnt, ids[0], ids[1], ids[2]);
+            my = cnt <= RA_REG ? decide_reg(ids, cnt, state) : decide(i, r0, G, map, bits, runs, nr, n_vox, nbr, state, sx);
+            if (my != 0) state[i] = (unsigned char)my;
         }
         // picks -> kept, still open -> left: ballot prefix in the wave, wave totals through LDS, one atomic per list
         const unsigned long long mk = __ballot(my == 1), ml = __ballot(my == 0);
@@ -523,10 +847,80 @@ __global__ __launch_bounds__(RA_T) void rounds_all_kernel(GreedyHeader* hdr, con
     unsigned n_act = *reinterpret_cast<volatile unsigned*>(&hdr->n_left);
     if (tid == 0) { s_next = 0; s_kept = *reinterpret_cast<volatile unsigned*>(&hdr->n_kept); hdr->trace[14] = n_act; }
     __syncthreads();
+    // Up to RA_LMAX leftovers with register-sized lists are resolved INSIDE LDS: an open candidate only waits for open
+    // candidates, and every open candidate is in this list - so after ONE look at the global states (decided neighbours
+    // drop out or suppress at once) the rest of the fixed point needs no memory round trips, only LDS passes.
+    __shared__ unsigned s_id[RA_LMAX];
+    __shared__ short s_nb[RA_LMAX][RA_REG];
+    __shared__ unsigned char s_cnt[RA_LMAX], s_st[RA_LMAX];
+    __shared__ unsigned s_hash[2 * RA_LMAX], s_big;
+    bool local_ok = n_act <= RA_LMAX;
+    if (local_ok) {
+        if (tid == 0) s_big = 0;
+        for (unsigned q = tid; q < 2 * RA_LMAX; q += RA_T) s_hash[q] = 0xffffffffu;
+        __syncthreads();
+        for (unsigned t = tid; t < n_act; t += RA_T) {
+            const unsigned i = vleft[t];
+            s_id[t] = i; s_st[t] = 0;
+            unsigned h = (i * 2654435761u) >> (31 - RA_LBITS);         // table of 2 RA_LMAX slots
+            while (atomicCAS(&s_hash[h], 0xffffffffu, t) != 0xffffffffu) h = (h + 1) & (2 * RA_LMAX - 1);
+        }
+        __syncthreads();
+        for (unsigned t = tid; t < n_act; t += RA_T) {
+            const unsigned i = s_id[t];
+            int ids[RA_REG], cnt = 0;
+            load_list(i, ids, cnt);
+            if (cnt > RA_REG) { s_big = 1; continue; }
+            int m = 0, st0 = 0;
+            for (int u = 0; u < cnt; ++u) {
+                const unsigned char sg = state[ids[u]];
+                if (sg == 1) st0 = 2;
+                if (sg == 0) {                              // open: one of the leftovers - its local slot
+                    unsigned h = ((unsigned)ids[u] * 2654435761u) >> (31 - RA_LBITS);
+                    int slot = -1;
+                    for (int probe = 0; probe < 2 * RA_LMAX; ++probe) {
+                        const unsigned e = s_hash[h];
+                        if (e == 0xffffffffu) break;
+                        if (s_id[e] == (unsigned)ids[u]) { slot = (int)e; break; }
+                        h = (h + 1) & (2 * RA_LMAX - 1);
+                    }
+                    if (slot < 0) { s_big = 1; }            // (cannot happen: every open candidate is a leftover)
+                    else s_nb[t][m++] = (short)slot;
+                }
+            }
+            s_cnt[t] = (unsigned char)m;
+            if (st0 == 2) s_st[t] = 2;
+        }
+        __syncthreads();
+        local_ok = s_big == 0;
+    }
+    if (local_ok) {
+        for (int pass = 0; pass < 4 * RA_LMAX; ++pass) {
+            int progress = 0;
+            for (unsigned t = tid; t < n_act; t += RA_T) {
+                if (s_st[t] != 0) continue;
+                bool pick_near = false, all_dec = true;
+                for (int u = 0; u < (int)s_cnt[t]; ++u) {
+                    const unsigned char sg = s_st[s_nb[t][u]];
+                    pick_near |= sg == 1; all_dec &= sg != 0;
+                }
+                const int d = pick_near ? 2 : (all_dec ? 1 : 0);
+                if (d) { s_st[t] = (unsigned char)d; progress = 1; }
+            }
+            if (!__syncthreads_or(progress)) break;
+        }
+        for (unsigned t = tid; t < n_act; t += RA_T) {
+            const unsigned i = s_id[t];
+            state[i] = s_st[t];
+            if (s_st[t] == 1) { const unsigned slot = atomicAdd(&s_kept, 1u); if (slot < kept_cap) kept[slot] = G[i]; }
+        }
+        __syncthreads();
+        n_act = 0;
+    }
     const volatile unsigned* cur = left;
     unsigned* nxt = act_b;
     while (n_act > 0) {
-        // every open candidate keeps its list in registers while the passes of this trip run (a few dozen candidates)
+        // (more leftovers than the LDS tables hold, or an overflowed list among them: passes through memory)
         for (unsigned t0 = 0; t0 < n_act; t0 += RA_T) {
             const unsigned t = t0 + tid;
             int ids[RA_REG], cnt = 0, my = 2;
@@ -536,7 +930,7 @@ __global__ __launch_bounds__(RA_T) void rounds_all_kernel(GreedyHeader* hdr, con
                 int before = my;
                 if (my == 0) {
                     const int4 r0 = make_int4(cnt, ids[0], ids[1], ids[2]);
-                    my = cnt <= RA_REG ? decide_reg(ids, cnt, state) : decide(i, r0, G, map, bits, runs, nr, n_vox, nbr, state);
+                    my = cnt <= RA_REG ? decide_reg(ids, cnt, state) : decide(i, r0, G, map, bits, runs, nr, n_vox, nbr, state, sx);
                     if (my != 0) state[i] = (unsigned char)my;
                 }
                 // go on while somebody of this trip made progress (an open candidate may wait for one of another trip)
@@ -592,12 +986,18 @@ __global__ __launch_bounds__(ER_T) void emit_rank_kernel(GreedyHeader* hdr, cons
 #pragma unroll
             for (int q = tid; q < ER_CHUNK; q += ER_T) keys[q] = (unsigned)q < m ? kept[c0 + q] : 0ull;   // zero keys count for nobody
             __syncthreads();
-            const unsigned m64 = (m + 63) & ~63u;
-#pragma unroll 4
-            for (unsigned q = lane; q < m64; q += 64) {
-                const unsigned long long kj = keys[q];
+            // eight keys per lane and step, all eight LDS reads in flight before the first compare (left to the compiler the
+            // loop waited for every read by itself: 30 us); the chunk's tail is zero keys
+            for (unsigned q0 = 0; q0 < m; q0 += 512) {
+                unsigned long long kj[8];
 #pragma unroll
-                for (int u = 0; u < ER_PPW; ++u) rank[u] += kj > key[u] ? 1u : 0u;
+                for (int e = 0; e < 8; ++e) kj[e] = keys[q0 + 64 * e + lane];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int u = 0; u < ER_PPW; ++u) rank[u] += kj[e] > key[u] ? 1u : 0u;
+                    // (measured and rejected: the borrow of key - kj as v_sub_co / v_subb_co / v_addc_co in inline assembly -
+                    // every chain goes through vcc, nothing overlaps: 38 us against 28)
             }
         }
 #pragma unroll
@@ -637,6 +1037,9 @@ struct GreedyWs {
     const float* vol;  // ... the dense value volume itself is at hand (mi_greedy_nms3d)
     unsigned* bits;    // candidate bitmap of the volume, (n_vox + 31) / 32 words (+2 words of slack)
     BallRun* runs;
+    uint2* ranges;     // list range of every workgroup of cand_filter_seg_kernel
+    int n_ranges;      // 0: the list is walked in slot order
+    SegIndex sx;       // seg_range != null: the list is indexed by segment (fused picker) - no bitmap / id map / value map
     unsigned cap, kept_cap;
 };
 
@@ -661,6 +1064,7 @@ size_t greedy_ws_layout(size_t n_vox, size_t cap, GreedyWs* w, char* base, bool 
     p = take(sizeof(unsigned) * cap); if (w) w->act_a = (unsigned*)p;
     p = take(sizeof(unsigned) * cap); if (w) w->act_b = (unsigned*)p;
     p = take(sizeof(BallRun) * MAX_RUNS); if (w) w->runs = (BallRun*)p;
+    p = take(sizeof(uint2) * NB_MAX_RANGES); if (w) { w->ranges = (uint2*)p; w->n_ranges = 0; w->sx = SegIndex{}; }
     p = take(sizeof(unsigned) * ((n_vox + 31) / 32 + 2)); if (w) w->bits = (unsigned*)p;
     if (with_map) { p = take(sizeof(int) * n_vox); if (w) w->map = (int*)p; }
     if (w) { w->cap = (unsigned)cap; w->kept_cap = (unsigned)kept_cap; }
@@ -674,11 +1078,17 @@ int greedy_tail(const GreedyWs& w, int D, int H, int W, float d, float scale, fl
     double r = (double)scale * (double)d / 2.0;
     int width = (int)ceil(r);
     if (width > 16 || width < 0) return MI_E_UNSUPPORTED;
-    hipLaunchKernelGGL(neighbors_kernel, dim3(2048), dim3(256), 0, s, w.hdr, w.G, w.map, w.vmap, w.vol, w.bits, w.runs,
-                       n_vox, w.cap, w.nbr, w.state, r, width, (long)H * W, (long)W);
+    SegIndex sx = w.sx;
+    if (sx.seg_range) {
+        sx.width = width; sx.r2 = r * r;
+        hipLaunchKernelGGL(neighbors_seg_kernel, dim3(2048), dim3(256), 0, s, w.hdr, w.G, sx, w.cap, w.nbr, w.state);
+    } else {
+        hipLaunchKernelGGL(neighbors_kernel, dim3(2048), dim3(256), 0, s, w.hdr, w.G, w.map, w.vmap, w.vol, w.bits, w.runs,
+                           n_vox, w.cap, w.nbr, w.state, r, width, (long)H * W, (long)W, w.ranges, w.n_ranges);
+    }
     MI_RETURN_IF_LAUNCH_FAILED();
     hipLaunchKernelGGL(rounds_all_kernel, dim3(512), dim3(RA_T), 0, s, w.hdr, w.G, w.map, w.bits, w.runs, n_vox, w.cap,
-                       w.nbr, w.state, w.act_a, w.act_b, w.kept, w.kept_cap);
+                       w.nbr, w.state, w.act_a, w.act_b, w.kept, w.kept_cap, sx);
     MI_RETURN_IF_LAUNCH_FAILED();
     hipLaunchKernelGGL(emit_rank_kernel, dim3(256), dim3(ER_T), 0, s, w.hdr, w.kept, w.kept_cap, H, W, scores, coords,
                        n_out, max_out);
@@ -728,6 +1138,9 @@ struct DogWs {
     uint2* cands;
     double* stats;
     unsigned* seg_count;
+    uint2* seg_range;
+    unsigned* sub;
+    size_t sub_room;
     unsigned cand_cap;
     size_t n_stats, cand_room, seg_room;
     DogxGrid xg;
@@ -763,6 +1176,11 @@ size_t dog_ws_layout(int D, int H, int W, DogWs* w, char* base) {
     const size_t seg_room = std::max((size_t)xg.n_seg, f_seg);
     p = take(sizeof(double) * 3 * std::max(n_stats, seg_room)); if (w) { w->stats = (double*)p; w->n_stats = n_stats; }
     p = take(sizeof(unsigned) * seg_room); if (w) { w->seg_count = (unsigned*)p; w->seg_room = seg_room; }
+    p = take(sizeof(uint2) * seg_room); if (w) w->seg_range = (uint2*)p;
+    // sub-index of the fused picker's segments: (rows of a chunk / 8 + 1) slots per segment
+    const size_t sub_room = 3 * seg_room + (2 * bxy_l < H && 2 * bxy_l < W
+                                            ? (size_t)D * mi_dogf_grid(D, H, W, 0, bxy_l).n_strips * (size_t)((H - 2 * bxy_l) / 8 + 1) : 0);
+    p = take(sizeof(unsigned) * sub_room); if (w) { w->sub = (unsigned*)p; w->sub_room = sub_room; }
     // the dense candidate map reuses a Gaussian buffer (free once the last DoG level is consumed)
     off += greedy_ws_layout(n_vox, greedy_default_cap(n_vox, false), w ? &w->gw : nullptr, base ? base + off : nullptr, false);
     return off;
@@ -802,30 +1220,49 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
                 q.D = D; q.H = H; q.W = W; q.bz = border_z; q.by = bxy_f; q.bx = bxy_f;
                 q.cands = w.cands; q.seg_count = w.seg_count; q.overflow = &gw.hdr->overflow; q.stats = w.stats;
                 q.clr[0] = reinterpret_cast<unsigned*>(gw.hdr); q.clr_n[0] = (unsigned)(sizeof(GreedyHeader) / 4);
-                q.clr[1] = gw.bits; q.clr_n[1] = bits_words;
+                const int nb = (fg.ychunk + 7) / 8;
+                const bool use_index = !getenv("MI_DOG_NO_INDEX") &&
+                                       (fg.n_seg + CI_MAXSEG - 1) / CI_MAXSEG <= (unsigned)NB_MAX_RANGES && H < 65536 && W < 65536 &&
+                                       (size_t)fg.n_seg * (nb + 1) <= w.sub_room;
+                if (!use_index) { q.clr[1] = gw.bits; q.clr_n[1] = bits_words; }     // (the bitmap search: A/B and fallback)
                 if (heat_out) MI_HIP(hipMemsetAsync(heat_out, 0, sizeof(float) * n_vox, s));      // the zeroed border
                 int rcf = mi_launch_dogf(q, fg, sigmas_host[0], sigmas_host[1], s);
                 if (rcf) return rcf;
                 gw.map = reinterpret_cast<int*>(w.tmp);               // (g[0] / g[1] are read by the y march only: free as
                 gw.vmap = reinterpret_cast<unsigned*>(w.heat); gw.vol = nullptr;    // well, but these two are never touched)
-                const unsigned fb = std::min<unsigned>((fg.n_seg + 7) / 8, 1024u);
-                hipLaunchKernelGGL(cand_filter_seg_kernel<true>, dim3(fb), dim3(256), 0, s, w.cands, w.seg_count, fg.n_seg,
-                                   fg.seg_cap, gw.hdr, gw.G, gw.map, gw.vmap, gw.bits, gw.cap, (const double*)w.stats,
-                                   (int)fg.n_wg, cutoff_out);
-                MI_RETURN_IF_LAUNCH_FAILED();
+                if (use_index) {
+                    // survivors above the cutoff, segment by segment and in row order: the list IS a grid index
+                    const unsigned fb = std::max<unsigned>(std::min<unsigned>((fg.n_seg + 7) / 8, (unsigned)NB_MAX_RANGES),
+                                                           (fg.n_seg + CI_MAXSEG - 1) / CI_MAXSEG);
+                    unsigned* coord = reinterpret_cast<unsigned*>(w.tmp);       // (free volumes of the workspace:
+                    unsigned* coordz = reinterpret_cast<unsigned*>(w.heat);     // `cap` entries each fit four times)
+                    hipLaunchKernelGGL(cand_index_kernel, dim3(fb), dim3(256), 0, s, w.cands, w.seg_count, fg.n_seg, fg.seg_cap,
+                                       gw.hdr, gw.G, coord, coordz, w.seg_range, gw.cap, (const double*)w.stats, (int)fg.n_wg,
+                                       cutoff_out, gw.ranges, H, W, w.sub, nb, bxy_f, fg.ychunk, fg.n_ychunks, fg.n_strips);
+                    MI_RETURN_IF_LAUNCH_FAILED();
+                    gw.n_ranges = (int)fb;
+                    SegIndex sx = {};
+                    sx.seg_range = w.seg_range; sx.coord = coord; sx.coordz = coordz; sx.sub = w.sub; sx.nb = nb;
+                    sx.D = D; sx.H = H; sx.W = W; sx.bz = border_z; sx.by = bxy_f; sx.bx = bxy_f;
+                    sx.ychunk = fg.ychunk; sx.n_ychunks = fg.n_ychunks; sx.n_strips = fg.n_strips; sx.own = mi_dogf_own();
+                    gw.sx = sx;
+                } else {
+                    const unsigned fb = std::min<unsigned>((fg.n_seg + 7) / 8, 1024u);
+                    hipLaunchKernelGGL(cand_filter_seg_kernel<true>, dim3(fb), dim3(256), 0, s, w.cands, w.seg_count, fg.n_seg,
+                                       fg.seg_cap, gw.hdr, gw.G, gw.map, gw.vmap, gw.bits, gw.cap, (const double*)w.stats,
+                                       (int)fg.n_wg, cutoff_out, gw.ranges);
+                    MI_RETURN_IF_LAUNCH_FAILED();
+                    gw.n_ranges = (int)fb;
+                }
                 return greedy_tail(gw, D, H, W, (float)nms_d, 1.0f, scores, coords, n_out, max_out, s);
             }
         }
     }
-    // The round-3 two-sigma chain clears the header and the candidate bitmap inside its first launch (the z pass: a few words
-    // per thread next to 0.8 GB of traffic); every other chain clears them with two fill passes here.
-    const bool no_march0 = getenv("MI_GAUSS_NO_MARCH") != nullptr;
-    const int bxy0 = (H > 512 && W > 512) ? 60 : 30;
-    const bool fused_chain = n_sigmas == 2 && !no_march0 && sigmas_host[0] <= sigmas_host[1] &&
-                             mi_dogx_usable(w.tmp, w.heat, heat_out, D, H, W, sigmas_host[0], sigmas_host[1], k) &&
-                             (bxy0 >= mi_gauss_radius(sigmas_host[1]) || W > 2 * mi_gauss_radius(sigmas_host[1])) &&
-                             mi_gauss_radius(sigmas_host[1]) <= 20 && !getenv("MI_GAUSS_NO_REGMARCH");
-    if (!fused_chain) MI_HIP(hipMemsetAsync(gw.hdr, 0, sizeof(GreedyHeader), s));
+    // Every other chain (volumes the fused kernels do not take: fewer planes than a ring, rows wider than 512, more than two
+    // sigmas, other windows) clears the header and the candidate bitmap with two fill passes here - ONE place, whatever branch
+    // runs below (round 3 skipped them for its fused chain by re-deriving that chain's own launch condition by hand).
+    MI_HIP(hipMemsetAsync(gw.hdr, 0, sizeof(GreedyHeader), s));
+    MI_HIP(hipMemsetAsync(gw.bits, 0, sizeof(unsigned) * bits_words, s));
 
     // utils/image.py:141-143: 30-voxel xy border, doubled when both H and W exceed 512
     int bxy = (H > 512 && W > 512) ? 60 : 30;
@@ -884,11 +1321,8 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
             const int bz_[6] = {z0, z1, ylo, yhi, 0, W}, by_[6] = {z0, z1, bxy, H - bxy, 0, W};
             for (int i = 0; i < 6; ++i) { boxz[i] = bz_[i]; boxy[i] = by_[i]; }
         }
-        rc = sa <= sb ? mi_launch_gauss_march(rec, w.g[0], w.g[1], sa, sb, nullptr, nullptr, 0.f, D, H, W, 0, s, boxz,
-                                              fused_chain ? reinterpret_cast<unsigned*>(gw.hdr) : nullptr,
-                                              (unsigned)(sizeof(GreedyHeader) / 4), fused_chain ? gw.bits : nullptr, bits_words)
+        rc = sa <= sb ? mi_launch_gauss_march(rec, w.g[0], w.g[1], sa, sb, nullptr, nullptr, 0.f, D, H, W, 0, s, boxz)
                       : mi_launch_gauss_march(rec, w.g[0], nullptr, sa, 0.f, rec, w.g[1], sb, D, H, W, 0, s, boxz);
-        if (rc == MI_E_UNSUPPORTED && fused_chain) return MI_E_ARG;          // (fused_chain implies the dual launch exists)
         if (rc == MI_OK) rc = mi_launch_gauss_march(w.g[0], w.tmp, nullptr, sa, 0.f, w.g[1], w.heat, sb, D, H, W, 1, s, boxy);
         if (rc == MI_OK) {
             DogxParams q = {};
@@ -900,11 +1334,11 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
             MI_RETURN_IF_LAUNCH_FAILED();
             gw.map = reinterpret_cast<int*>(w.g[0]);              // both z-pass outputs are consumed
             gw.vmap = reinterpret_cast<unsigned*>(w.g[1]); gw.vol = nullptr;
-            if (!fused_chain) MI_HIP(hipMemsetAsync(gw.bits, 0, sizeof(unsigned) * bits_words, s));
             const unsigned fb = std::min<unsigned>((w.xg.n_seg + 7) / 8, 1024u);
             hipLaunchKernelGGL(cand_filter_seg_kernel<false>, dim3(fb), dim3(256), 0, s, w.cands, w.seg_count, w.xg.n_seg,
                                w.xg.seg_cap, gw.hdr, gw.G, gw.map, gw.vmap, gw.bits, gw.cap, (const double*)nullptr, 0,
-                               (float*)nullptr);
+                               (float*)nullptr, gw.ranges);
+            gw.n_ranges = (int)fb;
             MI_RETURN_IF_LAUNCH_FAILED();
             return greedy_tail(gw, D, H, W, (float)nms_d, 1.0f, scores, coords, n_out, max_out, s);
         }
@@ -934,7 +1368,6 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
     // dense candidate-id map in the Gaussian buffer that is no longer needed
     gw.map = reinterpret_cast<int*>(w.g[cur ^ 1]);
     gw.vmap = reinterpret_cast<unsigned*>(w.tmp); gw.vol = nullptr;      // the x-pass scratch volume is free by now
-    MI_HIP(hipMemsetAsync(gw.bits, 0, sizeof(unsigned) * ((n_vox + 31) / 32 + 2), s));
     // (many short workgroups: the loop is one dependent load per trip)
     hipLaunchKernelGGL(cand_filter_kernel, dim3(4096), dim3(256), 0, s, w.cands, w.cand_cap, gw.hdr,
                        gw.G, gw.map, gw.vmap, gw.bits, gw.cap);

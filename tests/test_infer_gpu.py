@@ -188,6 +188,48 @@ def test_dog_pick_vs_oracle_larger():
     assert abs(len(s) - len(so)) <= max(2, len(so) // 100)
 
 
+@pytest.mark.parametrize("shape,sigmas,nms_d", [((48, 200, 264), (3, 5), 14), ((40, 160, 512), (2, 4), 14),
+                                                ((64, 256, 256), (3, 5), 30), ((44, 130, 96), (2.5, 4.5), 9)])
+def test_dog_pick_chains_agree(shape, sigmas, nms_d, monkeypatch):
+    """The picker's three implementations of one algorithm on the same tomogram: the round-4 chain (z + x | y + DoG + NMS,
+    candidates as a grid index), the same filters with round 3's bitmap neighbour search, and round 3's chain (z | y | x +
+    DoG + NMS).  Index against bitmap: the same candidates go through two neighbour searches - picks and scores must be
+    IDENTICAL (nms_d = 30: balls of 33 planes, neighbour lists longer than a row of `nbr` - the rounds' re-probe runs on
+    both).  Against round 3's chain the filter passes run in another order (rounding-order differences in the DoG): the
+    strong picks agree exactly, scores to 1e-5."""
+    from cet_pick_amd.utils import image as Im
+    vol, _ = make_tomo(shape, seed=321)
+    v = dev(vol)
+
+    def run():
+        s, c, n, cut, heat = Im.dog_pick(v, list(sigmas), nms_d=nms_d, return_heat=True)
+        k = int(n.item())
+        assert k > 0
+        return s[:k].cpu().numpy(), c[:k].cpu().numpy(), float(cut.item()), heat.cpu().numpy()
+
+    s0, c0, cut0, h0 = run()
+    monkeypatch.setenv("MI_DOG_NO_INDEX", "1")
+    s1, c1, cut1, h1 = run()
+    monkeypatch.delenv("MI_DOG_NO_INDEX")
+    assert cut0 == cut1
+    np.testing.assert_array_equal(h0, h1)
+    np.testing.assert_array_equal(c0, c1)
+    np.testing.assert_array_equal(s0, s1)
+    monkeypatch.setenv("MI_NO_DOGF", "1")
+    s2, c2, cut2, h2 = run()
+    monkeypatch.delenv("MI_NO_DOGF")
+    assert abs(cut2 - cut0) <= 1e-5 * abs(cut0)
+    np.testing.assert_allclose(h2, h0, rtol=0, atol=2e-6)
+    strong0 = {tuple(r) for r, sc in zip(c0, s0) if sc > cut0 * 1.01}
+    strong2 = {tuple(r) for r, sc in zip(c2, s2) if sc > cut0 * 1.01}
+    assert strong0 == strong2
+    # the picks are the greedy NMS of the heat-map this chain produced: the oracle's sequential loop on it
+    from oracle import infer_ref as O
+    so, co = O.non_maximum_suppression_3d(h0, nms_d, threshold=cut0)
+    np.testing.assert_array_equal(c0, co)
+    np.testing.assert_array_equal(s0, so)
+
+
 def test_get_potential_coords(golden):
     from cet_pick_amd.utils import image as Im
     g = golden("dog_small.npz")
