@@ -86,7 +86,69 @@ def unbiased_con_loss(labels, out_labels, out_labels_cr, f, f_cr, T, tau_plus, t
     return sup, unsup
 
 
-def tomo_cr_semi_loss(hm_logits, hm_logits_cr, proj, proj_cr, gt, flip_prob, tau, temp, thresh, cr_weight):
+def unbiased_con_loss_streamed(labels, out_labels, out_labels_cr, f, f_cr, T, tau_plus, thresh, block=2048, device=None,
+                               dtype=None):
+    """`unbiased_con_loss` (models/loss.py:571-699) without the (2N)^2 matrix in memory: the same rows, `block` of them at
+    a time, reduced to the row sums the loss is a function of.  Forward values only (no autograd graph is kept).  It exists
+    so that the batch-16 step of BASELINE config C5 (2N = 196,608: a 154 GB matrix) has an oracle at all;
+    tests/test_oracle_losses.py pins it to the dense form above on sizes where both run."""
+    device = device or f.device
+    dtype = dtype or f.dtype
+    n = f.shape[0]
+    to = lambda t: t.detach().to(device=device, dtype=dtype)
+    labels, out_labels, out_labels_cr, f, f_cr = (to(t) for t in (labels, out_labels, out_labels_cr, f, f_cr))
+    tot = torch.cat([f, f_cr], 0)
+    all_labels = torch.cat([labels, labels], 0)
+    preds = torch.cat([out_labels, out_labels_cr], 0)
+    pos = all_labels.gt(thresh) if thresh < 1 else all_labels.eq(1)
+    un = all_labels.lt(0)
+    other = all_labels.lt(thresh).to(dtype)
+    posf = pos.to(dtype)
+    n_pos1 = (labels.gt(thresh) if thresh < 1 else labels.eq(1)).to(dtype).sum()
+    n_neg = 2 * (n - n_pos1)
+    sum_all = torch.empty(2 * n, device=device, dtype=dtype)
+    sum_pos = torch.empty_like(sum_all)
+    sum_oth = torch.empty_like(sum_all)
+    e_pair = torch.empty_like(sum_all)
+    idx = torch.arange(2 * n, device=device)
+    for r0 in range(0, 2 * n, block):
+        rows = idx[r0:r0 + block]
+        s_ = tot[rows] @ tot.t() / T
+        s_ = s_ - s_.max(dim=1, keepdim=True)[0]
+        s_[torch.arange(rows.numel(), device=device), rows] = 0          # sims * (1 - eye) before the exp: the diagonal is exp(0)
+        e = torch.exp(s_)
+        sum_all[rows] = e.sum(1)
+        sum_pos[rows] = (e * posf).sum(1)
+        sum_oth[rows] = (e * other).sum(1)
+        e_pair[rows] = e[torch.arange(rows.numel(), device=device), (rows + n) % (2 * n)]
+
+    def calc_g(p, q, c):
+        return torch.clamp((q - c * p) / (1 - c), min=np.e ** (-1 / T))
+
+    pos_mean = sum_pos[pos] / (posf.sum() - 1)
+    rem_mean = sum_oth[pos] / other.sum()
+    sup = (-torch.log(pos_mean / (pos_mean + calc_g(pos_mean, rem_mean, tau_plus)))).mean()
+    up = e_pair[un]
+    urem = (sum_all[un] - up) / n_neg
+    gp, gn = calc_g(up, urem, tau_plus), calc_g(up, urem, 1 - tau_plus)
+    pr = preds[un]
+    lpos = -torch.log(up / (up + gp)) * pr
+    lneg = -torch.log(up / (up + gn)) * (1 - pr)
+    unsup = torch.zeros((), device=device, dtype=dtype)
+    hi, lo = pr.gt(0.99), pr.lt(0.01)
+    mid = pr.gt(0.01) & pr.lt(0.99)
+    if hi.any():
+        unsup = unsup + lpos[hi].mean()
+    if lo.any():
+        unsup = unsup + lneg[lo].mean()
+    if mid.any():
+        unsup = unsup + lpos[mid].mean() + lneg[mid].mean()
+    return sup.cpu(), unsup.cpu()
+
+
+def tomo_cr_semi_loss(hm_logits, hm_logits_cr, proj, proj_cr, gt, flip_prob, tau, temp, thresh, cr_weight, streamed=None):
+    """`streamed`: None = the dense contrastive term (autograd works), or a dict of keyword arguments for
+    `unbiased_con_loss_streamed` (values only)."""
     """trains/tomo_cr_semi_trainer.py:43-112, train phase with --contrastive.  Pinned since round 3 by
     tests/golden/semi_loss.npz (the reference's own TomoCRSemiLoss.forward, both flip branches, values and gradients;
     gen_golden.py::gen_semi_loss stubs the module's unused load-time imports)."""
@@ -98,7 +160,11 @@ def tomo_cr_semi_loss(hm_logits, hm_logits_cr, proj, proj_cr, gt, flip_prob, tau
     pc, hc = proj_cr.flip(fd), hm_cr.flip(fd)
     f = proj.reshape(b, ch, -1).permute(1, 0, 2).reshape(ch, -1).T
     fc = pc.reshape(b, ch, -1).permute(1, 0, 2).reshape(ch, -1).T
-    sup, unsup = unbiased_con_loss(gt.reshape(-1), hm.reshape(-1), hc.reshape(-1), f, fc, temp, tau, thresh)
+    if streamed is not None:
+        sup, unsup = unbiased_con_loss_streamed(gt.reshape(-1), hm.reshape(-1), hc.reshape(-1), f, fc, temp, tau, thresh, **streamed)
+        sup, unsup = sup.to(hm.dtype), unsup.to(hm.dtype)
+    else:
+        sup, unsup = unbiased_con_loss(gt.reshape(-1), hm.reshape(-1), hc.reshape(-1), f, fc, temp, tau, thresh)
     cr = sup + 0.1 * unsup
     cons = mse(hm.reshape(-1), hc.reshape(-1))
     return hm_loss + cr * cr_weight + cons, hm_loss, cr, cons

@@ -70,3 +70,27 @@ def test_tomo_cr_semi_loss_matches_reference(flip_prob):
     sig = torch.clamp(torch.sigmoid(semi_loss_inputs(0.2)[1]), 1e-4, 1 - 1e-4)
     np.testing.assert_allclose(O.neg_loss(sig, semi_loss_inputs(0.2)[0]).item(), S["val_loss"], rtol=2e-6)
     assert S["val_cr_loss"] == 0
+
+
+@pytest.mark.parametrize("thresh", [1.0, 0.4])
+def test_streamed_contrastive_loss_equals_the_dense_form(thresh):
+    """The row-blocked restatement (no (2N)^2 matrix; the oracle of the batch-16 step of C5) gives the dense oracle's
+    values - itself pinned to the reference's UnbiasedConLoss two tests up - with ragged blocks, and in float64."""
+    pred, gt, f, f_cr, lab, o1, o2 = losses_inputs()
+    sup, unsup = O.unbiased_con_loss(lab, o1, o2, f, f_cr, 0.07, 0.03, thresh)
+    for block in (37, 4096):
+        s2, u2 = O.unbiased_con_loss_streamed(lab, o1, o2, f, f_cr, 0.07, 0.03, thresh, block=block)
+        np.testing.assert_allclose(s2.item(), sup.item(), rtol=2e-6)
+        np.testing.assert_allclose(u2.item(), unsup.item(), rtol=2e-6)
+    d = lambda t: t.double()
+    s64, u64 = O.unbiased_con_loss(d(lab), d(o1), d(o2), d(f), d(f_cr), 0.07, 0.03, thresh)
+    s3, u3 = O.unbiased_con_loss_streamed(lab, o1, o2, f, f_cr, 0.07, 0.03, thresh, block=100, dtype=torch.float64)
+    np.testing.assert_allclose(s3.item(), s64.item(), rtol=1e-10)
+    np.testing.assert_allclose(u3.item(), u64.item(), rtol=1e-10)
+    # through the step's loss: flags and flips as in tomo_cr_semi_loss
+    from cet_pick_amd.synthetic import semi_loss_inputs
+    gt4, hm, hm_cr, pj, pj_cr = semi_loss_inputs(0.8)
+    a = O.tomo_cr_semi_loss(hm, hm_cr, pj, pj_cr, gt4, 0.8, 0.1, 0.07, 0.5, 0.1)
+    b = O.tomo_cr_semi_loss(hm, hm_cr, pj, pj_cr, gt4, 0.8, 0.1, 0.07, 0.5, 0.1, streamed={"block": 500})
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(y.item(), x.item(), rtol=2e-6)

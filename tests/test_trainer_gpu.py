@@ -160,6 +160,97 @@ def test_semi_detector_trainer_two_steps_vs_oracle(tmp_path):
     assert np.isfinite(val["loss"]) and val["cr_loss"] == 0
 
 
+def _semi_trainer(lr=1e-3, seed=323):
+    from types import SimpleNamespace
+    from cet_pick_amd.models.model import create_model
+    from cet_pick_amd.synthetic import seeded_state_dict
+    from cet_pick_amd.trains.train_factory import train_factory
+    heads = {"hm": 1, "proj": 32}
+    opt = SimpleNamespace(task="semi", arch="unet_4", pn=False, ge=False, tau=0.1, temp=0.07, thresh=0.5, cr_weight=0.1,
+                          num_stacks=1, contrastive=True, device=torch.device("cuda"), num_iters=-1, print_iter=0,
+                          hide_data_time=True, exp_id="t", lr=lr, hipgraph=False)
+    model = create_model(opt.arch, heads, 32)
+    sd0 = seeded_state_dict(model, seed=seed)
+    for k in ("hm.weight", "proj.weight"):
+        sd0[k] = sd0[k] * 0.3
+    model.load_state_dict(sd0)
+    trainer = train_factory["semi"](opt, model, torch.optim.SGD(model.parameters(), lr=opt.lr))
+    trainer.set_device([0], None, "cuda")
+    return opt, heads, model, sd0, trainer
+
+
+def _semi_batch(b, d, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(b, d, h, w, generator=g)
+    x_aug = x.flip(-1) + 0.05 * torch.randn(b, d, h, w, generator=g)
+    gt = torch.full((b, 1, d, h // 2, w // 2), -1.0)
+    r = torch.rand(gt.shape, generator=g)
+    gt[r < 0.3] = 0.0
+    gt[(r >= 0.3) & (r < 0.4)] = 0.6
+    gt[r > 0.96] = 1.0
+    return x, x_aug, gt
+
+
+@pytest.mark.parametrize("pairs", [1, 16])
+def test_semi_detector_step_at_c5_size_vs_oracle(pairs):
+    """BASELINE config C5 AS STATED: one TomoCRSemiTrainer step (unet_4, --contrastive) on `pairs` pairs of 6 x 64 x 64
+    crops - 16 per GPU is the configuration, and what tools/bench_detector.py times.  N = pairs * 6 * 32 * 32 voxels per
+    view; at 16 pairs the reference's (2N)^2 similarity matrix would be 154 GB.
+      pairs = 1  (2N = 12,288): every loss term against the DENSE oracle (the reference's own arithmetic, 0.6 GB), fp32 and -
+                 the arbiter - float64.
+      pairs = 16 (2N = 196,608): hm_loss, consis_loss against the oracle as they are; the contrastive term against the
+                 oracle's row-blocked form (oracle/loss_ref.py::unbiased_con_loss_streamed, pinned to the dense form in
+                 tests/test_oracle_losses.py) evaluated in float64 - plain torch matmul / exp blocks on the device the test runs
+                 on, no kernel of this repository - plus the row-sum identities of the streaming kernel on sampled rows of
+                 THIS batch's features against dense float64 rows."""
+    from oracle import loss_ref as OL, unet_ref as OU
+    opt, heads, model, sd0, trainer = _semi_trainer()
+    x, x_aug, gt = _semi_batch(pairs, 6, 64, 64, seed=40 + pairs)
+    batch = {"input": x, "input_aug": x_aug, "hm": gt, "flip_prob": 0.2, "meta": {}}
+    with torch.no_grad():
+        def oracle(dt, streamed):
+            rsd = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+            o1 = OU.tomo_conv_unet_forward(rsd, x.to(dt), 4, heads, training=True)
+            o2 = OU.tomo_conv_unet_forward(rsd, x_aug.to(dt), 4, heads, training=True)
+            return o1, o2, OL.tomo_cr_semi_loss(o1["hm"], o2["hm"], o1["proj"], o2["proj"], gt.to(dt), 0.2, opt.tau, opt.temp,
+                                                opt.thresh, opt.cr_weight, streamed=streamed)
+        if pairs == 1:
+            _, _, ref = oracle(torch.float32, None)
+            o1_64, o2_64, ref64 = oracle(torch.float64, None)
+        else:
+            _, _, ref = oracle(torch.float32, {"block": 4096, "device": "cuda"})
+            o1_64, o2_64, ref64 = oracle(torch.float64, {"block": 2048, "device": "cuda", "dtype": torch.float64})
+    stats, _ = trainer.train(1, [dict(batch)])
+    assert set(stats) == {"loss", "hm_loss", "cr_loss", "consis_loss", "time"}
+    for k, v, v64 in zip(("loss", "hm_loss", "cr_loss", "consis_loss"), ref, ref64):
+        # as far from float64 as twice the fp32 oracle, or 1e-4 (the network's outputs differ by fp32 rounding order)
+        assert abs(stats[k] - v64.item()) <= 2 * abs(v.item() - v64.item()) + 1e-4 * abs(v64.item()) + 1e-7, (k, stats[k], v.item(), v64.item())
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+    if pairs == 16:
+        # the streaming kernel's row sums on THIS batch's features (float64 oracle features, rounded to fp32): sampled rows
+        from cet_pick_amd.models.loss import _UclRowSumsFn
+        ch = o1_64["proj"].shape[1]
+        flat = lambda p: p.reshape(pairs, ch, -1).permute(1, 0, 2).reshape(ch, -1).T
+        f = torch.cat([flat(o1_64["proj"]), flat(o2_64["proj"].flip(-1))], 0)
+        f32 = f.float().cuda().contiguous()
+        n2 = f32.shape[0]
+        assert n2 == 2 * pairs * 6 * 32 * 32
+        cls = torch.randint(0, 4, (n2,), generator=torch.Generator().manual_seed(5)).to(torch.uint8).cuda()
+        m, sa, sp, so, ep = _UclRowSumsFn.apply(f32, cls, 1.0 / opt.temp)
+        rows = torch.arange(7, n2, 769, device="cuda")
+        fd = f32.double()
+        S = (fd[rows] @ fd.t()) / opt.temp
+        mx = S.max(1, keepdim=True)[0]
+        np.testing.assert_allclose(m[rows].cpu().numpy(), mx[:, 0].cpu().numpy(), rtol=1e-5)
+        E = torch.exp(S - mx)
+        E[torch.arange(rows.numel()), rows] = 1.0
+        np.testing.assert_allclose(sa[rows].cpu().numpy(), E.sum(1).cpu().numpy(), rtol=2e-4)
+        np.testing.assert_allclose(sp[rows].cpu().numpy(), (E * (cls & 1).double()).sum(1).cpu().numpy(), rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(so[rows].cpu().numpy(), (E * ((cls >> 1) & 1).double()).sum(1).cpu().numpy(), rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(ep[rows].cpu().numpy(), E[torch.arange(rows.numel()), (rows + n2 // 2) % n2].cpu().numpy(),
+                                   rtol=2e-4, atol=1e-7)
+
+
 def test_symmetric_moco_variant_vs_oracle():
     """MoCoModel(symmetric=True) - EMA first, loss in both directions, one enqueue of both key sets."""
     import numpy as np
