@@ -1211,6 +1211,11 @@ def bn_relu_global_avgpool(x, bn):
 # BasicBlock (moco_encoder_3d.py:55-84): conv-ReLU-conv (+residual) -ReLU, no BN, with the ReLU
 # derivatives fused into the data-gradient epilogues
 # ------------------------------------------------------------------------------------------------
+RELU_TAP = None      # tests set a dict: post-ReLU activations of a forward pass (block: id(module) -> (mid, out); the encoder
+                     # adds "feature_3d", "proj.1", "proj.4"), copies - so that a float64 oracle can take the SAME branch of the
+                     # piecewise-linear network the GPU took where a unit sits within rounding of zero
+
+
 class _BasicBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, w2, wds, blk, mask_dx=False, dout_masked=False):
@@ -1222,6 +1227,8 @@ class _BasicBlockFn(torch.autograd.Function):
             hmid = conv_fwd(x, w1, 3, s, 1, None, True)
             r = conv_fwd(x, wds, 1, s, 0) if wds is not None else x
         out = conv_fwd(hmid, w2, 3, 1, 1, r, True)
+        if RELU_TAP is not None:                             # (tests: the ReLU decisions of this forward pass)
+            RELU_TAP[id(blk)] = (hmid.detach().clone(), out.detach().clone())
         ctx.blk = blk
         ctx.mask_dx, ctx.dout_masked = mask_dx, dout_masked
         ctx.save_for_backward(x, hmid, out)

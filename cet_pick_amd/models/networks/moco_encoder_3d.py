@@ -124,6 +124,12 @@ class TomoResClassifier3D(nn.Module):
                 x = self._mark(x, tag)
             H.stamp("layer")
         x = self.feature_3d[0](x, mask_dx=True)
+        if H.RELU_TAP is not None:
+            # (the fused launch below never stores relu(bn(x)); the separate kernels give the same bits - on a copy of the
+            # module, whose running statistics may move)
+            import copy
+            with torch.no_grad():
+                H.RELU_TAP["feature_3d"] = copy.deepcopy(self.feature_3d[1])(x.detach(), relu=True).clone()
         x = H.bn_relu_global_avgpool(x, self.feature_3d[1])      # BatchNorm + ReLU + global average pool: one launch
         return self.fc(x)
 
@@ -131,7 +137,11 @@ class TomoResClassifier3D(nn.Module):
         seq = self.__getattr__(head)
         H.stamp("trunk")
         x = H.linear_bn(x, seq[0], seq[1], relu=True)          # Linear + BatchNorm1d + ReLU: one launch each
+        if H.RELU_TAP is not None:
+            H.RELU_TAP[head + ".1"] = x.detach().clone()
         x = H.linear_bn(x, seq[3], seq[4], relu=True)
+        if H.RELU_TAP is not None:
+            H.RELU_TAP[head + ".4"] = x.detach().clone()
         return H.linear_bn(x, seq[6], seq[7])
 
     def forward_test(self, x1):

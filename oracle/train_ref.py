@@ -22,20 +22,33 @@ def _bn(sd, prefix, x, train, momentum, affine=True):
                         training=train, momentum=momentum, eps=1e-5)
 
 
-def _block(sd, prefix, x, stride):
+def _relu(name, t, pre, masks):
+    """ReLU `name`.  pre: optional dict that receives its input as name + ".pre".  masks: optional dict of boolean tensors -
+    where `name` is in it the unit fires where the MASK says so (t * mask) instead of where t > 0: the same function wherever
+    the two agree, and a chosen branch of the piecewise-linear network where a unit sits within rounding of zero (a test
+    passes the decisions the GPU took, tests/test_trainer_gpu.py)."""
+    if pre is not None:
+        pre[name + ".pre"] = t
+    if masks is not None and name in masks:
+        return t * masks[name].to(t.dtype)
+    return F.relu(t)
+
+
+def _block(sd, prefix, x, stride, pre=None, masks=None):
     """moco_encoder_3d.py:55-84 BasicBlock (no BN)."""
-    out = F.relu(F.conv3d(x, sd[prefix + ".conv1.weight"], stride=stride, padding=1))
+    out = _relu(prefix + ".mid", F.conv3d(x, sd[prefix + ".conv1.weight"], stride=stride, padding=1), pre, masks)
     out = F.conv3d(out, sd[prefix + ".conv2.weight"], padding=1)
     res = x
     if prefix + ".downsample.0.weight" in sd:
         res = F.conv3d(x, sd[prefix + ".downsample.0.weight"], stride=stride)
-    return F.relu(out + res)
+    return _relu(prefix + ".out", out + res, pre, masks)
 
 
-def encoder_forward(sd, x, train=True, acts=None, pre=None):
+def encoder_forward(sd, x, train=True, acts=None, pre=None, relu_masks=None):
     """moco_encoder_3d.py:353-404 (`forward`) / :326-351 (`forward_test` when train=False).
     sd: dict name -> tensor with the reference's logical shapes; running stats are updated in
-    place when train.  Returns proj (B,128)."""
+    place when train.  Returns proj (B,128).  pre / relu_masks: see `_relu` (names: layerL.B.mid, layerL.B.out, feature_3d,
+    proj.1, proj.4; the stem's ReLU always takes its own decision)."""
     def rec(name, t):
         if acts is not None:
             acts[name] = t
@@ -46,18 +59,15 @@ def encoder_forward(sd, x, train=True, acts=None, pre=None):
     x = rec("maxpool", F.max_pool3d(x, 3, stride=2, padding=1))
     for li, stride in ((1, 1), (2, 2), (3, 2)):
         for bi in range(2):
-            x = _block(sd, "layer%d.%d" % (li, bi), x, stride if bi == 0 else 1)
+            x = _block(sd, "layer%d.%d" % (li, bi), x, stride if bi == 0 else 1, pre, relu_masks)
         rec("layer%d" % li, x)
     x = F.conv3d(x, sd["feature_3d.0.weight"], padding=1)
-    x = rec("feature_3d", F.relu(_bn(sd, "feature_3d.1", x, train, BN_MOMENTUM)))
+    x = rec("feature_3d", _relu("feature_3d", _bn(sd, "feature_3d.1", x, train, BN_MOMENTUM), pre, relu_masks))
     x = F.adaptive_avg_pool3d(x, 1).reshape(x.shape[0], -1)
     x = rec("fc", F.linear(x, sd["fc.weight"], sd["fc.bias"]))
-    def rec_pre(name, t):       # `pre`: the BatchNorm outputs in front of the head's ReLUs (a test reads their distance from zero)
-        if pre is not None:
-            pre[name] = t
-        return t
-    x = F.relu(rec_pre("proj.1.pre", _bn(sd, "proj.1", F.linear(x, sd["proj.0.weight"]), train, 0.1)))
-    x = F.relu(rec_pre("proj.4.pre", _bn(sd, "proj.4", F.linear(x, sd["proj.3.weight"]), train, 0.1)))
+    # (`pre`: e.g. the BatchNorm outputs in front of the head's ReLUs - a test reads their distance from zero)
+    x = _relu("proj.1", _bn(sd, "proj.1", F.linear(x, sd["proj.0.weight"]), train, 0.1), pre, relu_masks)
+    x = _relu("proj.4", _bn(sd, "proj.4", F.linear(x, sd["proj.3.weight"]), train, 0.1), pre, relu_masks)
     x = _bn(sd, "proj.7", F.linear(x, sd["proj.6.weight"]), train, 0.1, affine=False)
     return x
 
@@ -89,12 +99,13 @@ class MocoRef:
         self.m, self.T, self.lr = m, T, lr
         self.names = param_names(self.q)
 
-    def step(self, im_q, im_k, pre=None):
-        """pre: optional dict that receives the query head's ReLU inputs (encoder_forward)."""
+    def step(self, im_q, im_k, pre=None, relu_masks=None):
+        """pre: optional dict that receives the query encoder's ReLU inputs; relu_masks: the query encoder's ReLU decisions
+        (encoder_forward).  The key encoder carries no gradient: a ReLU is continuous, its decisions do not matter there."""
         for n in self.names:
             self.q[n] = self.q[n].detach().requires_grad_(True)
         self.q.update({("pred" + n[4:]): self.q[n] for n in self.names if n.startswith("proj.")})
-        qf = F.normalize(encoder_forward(self.q, im_q, True, None, pre), dim=1)
+        qf = F.normalize(encoder_forward(self.q, im_q, True, None, pre, relu_masks), dim=1)
         with torch.no_grad():
             for n in self.names:                                    # moco.py:31-39
                 self.k[n] = self.k[n] * self.m + self.q[n].detach() * (1.0 - self.m)

@@ -49,3 +49,49 @@ def f32_equivalent(got, cpu32, ref64, factor=2.0, floor=2e-6, what="", more_cpu3
         e_c = max(e_c, float(np.linalg.norm(np.asarray(m, np.float64).ravel() - r)) / scale)
     assert e_g <= factor * e_c + floor, "%s: GPU %.3e from float64, CPU fp32 %.3e" % (what, e_g, e_c)
     return e_g, e_c
+
+
+def gpu_relu_decisions(enc, x):
+    """The ReLU decisions of one training-mode forward pass of `enc` on x: {oracle name: bool (N, C, ...)}.  The pass runs
+    without autograd and leaves the module's BatchNorm buffers as they were."""
+    import torch
+    from cet_pick_amd import hipops as H
+    saved = {k: v.clone() for k, v in enc.state_dict().items()}
+    H.RELU_TAP = {}
+    try:
+        with torch.no_grad():
+            enc(x)
+        tap = H.RELU_TAP
+    finally:
+        H.RELU_TAP = None
+    enc.load_state_dict(saved)
+    names = {id(m): n for n, m in enc.named_modules()}
+    cl = lambda t: (t > 0).permute(0, 4, 1, 2, 3).contiguous().cpu() if t.dim() == 5 else (t > 0).cpu()
+    masks = {}
+    for k, v in tap.items():
+        if isinstance(k, int):
+            masks[names[k] + ".mid"], masks[names[k] + ".out"] = cl(v[0]), cl(v[1])
+        else:
+            masks[k] = cl(v)
+    return masks
+
+
+def assert_relu_flips_on_edge(masks, pre64, pre32=None, max_units=8, rel=1e-4):
+    """masks: the GPU's ReLU decisions (gpu_relu_decisions); pre64: the float64 oracle's ReLU inputs (encoder_forward's
+    `pre`).  Where the two disagree the unit must be ON THE EDGE: |float64 input| <= rel x the layer's rms - or, where the
+    forward pass itself is ill-conditioned (pre32: the CPU fp32 oracle's inputs of the same pass), <= 4 x the largest
+    fp32-vs-float64 difference in that layer: a decision is only the GPU's to take where fp32 cannot resolve it.  At most
+    `max_units` per layer.  Returns {layer: number of units that differ}."""
+    flips = {}
+    for name, m in masks.items():
+        p64 = pre64[name + ".pre"].detach()
+        assert p64.shape == m.shape, name
+        diff = m != (p64 > 0)
+        flips[name] = int(diff.sum())
+        if flips[name]:
+            edge = rel * float(p64.pow(2).mean().sqrt())
+            if pre32 is not None:
+                edge = max(edge, 4.0 * float((pre32[name + ".pre"].detach().double() - p64).abs().max()))
+            assert flips[name] <= max_units, (name, flips[name])
+            assert float(p64[diff].abs().max()) <= edge, (name, float(p64[diff].abs().max()), edge)
+    return flips
