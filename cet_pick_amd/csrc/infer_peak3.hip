@@ -23,6 +23,10 @@ namespace {
 
 constexpr int RY = 4, WX = 256, WPB = 8, NT3 = 64 * WPB;      // (8 waves per workgroup: half the histogram merges of 4; 16: 3x slower)
 constexpr int NROW = RY + 2;
+#ifndef MI_PEAK3_NB
+#define MI_PEAK3_NB 3
+#endif
+constexpr int NB = MI_PEAK3_NB;   // planes in flight per wave
 constexpr int RING = 512;          // candidate ring per wave: < 64 pending + one row of the strip (<= 256 new entries)
 
 __device__ __forceinline__ float dpp_from_lower(float v, float edge) {     // lane i <- lane i-1; lane 0 <- edge
@@ -192,16 +196,19 @@ __global__ __launch_bounds__(NT3) void peak3_march_kernel(Peak3Params p) {
     };
 
     if (strip_ok) {
-        RawPlane rawA, rawB;
-        fetch(rawA, z0 - 1);
-        fetch(rawB, z0);
-        for (int zz = z0 - 1; zz <= zend; zz += 2) {
-            process(rawA, zz);
-            fetch(rawA, zz + 2);
-            if (zz + 1 <= zend) {
-                process(rawB, zz + 1);
-                fetch(rawB, zz + 3);
-            }
+        // NB planes in flight (a ring of statically indexed register buffers): a wave lives for zchunk + 2 planes only, so
+        // with two planes ahead the pipeline's fill - one memory latency with nothing to do - was most of its life
+        // (SQ counters: 59 % of the wave cycles waiting, the vector unit 20 - 35 % busy)
+        RawPlane raw[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) fetch(raw[b], z0 - 1 + b);
+        for (int zz = z0 - 1; zz <= zend; zz += NB) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if (zz + b <= zend) {                       // (wave-uniform)
+                    process(raw[b], zz + b);
+                    fetch(raw[b], zz + b + NB);
+                }
         }
     }
     if (emit) {
