@@ -804,6 +804,12 @@ def dist_all_gather(tensor_list, tensor):
     dist.all_gather(tensor_list, tensor)
 
 
+def dist_all_gather_into(out, tensor):
+    """all_gather along dim 0 into ONE contiguous tensor (synchronous, like the others: see above)."""
+    import torch.distributed as dist
+    dist.all_gather_into_tensor(out, tensor)
+
+
 def _distributed():
     """True when the data-parallel exchanges (SyncBN sums, key all-gather, gradient all-reduce) have to be issued."""
     import torch.distributed as dist

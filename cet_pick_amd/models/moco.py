@@ -130,8 +130,16 @@ def _world_size():
 def concat_all_gather(tensor):
     """models/moco.py:149-162: all_gather (RCCL) + cat along the batch; no gradient."""
     import torch.distributed as dist
-    tensors_gather = [torch.empty_like(tensor) for _ in range(dist.get_world_size())]
-    H.dist_all_gather(tensors_gather, tensor.contiguous())
+    world = dist.get_world_size()
+    t = tensor.contiguous()
+    if t.is_cuda and dist.get_backend() == "nccl":
+        # ONE collective straight into the concatenated result: the list form leaves RCCL's flat receive buffer through one
+        # device copy per rank and a cat - three memcpy nodes in the captured N > 1 step (VERDICT r3 item 10)
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        H.dist_all_gather_into(out, t)
+        return out
+    tensors_gather = [torch.empty_like(t) for _ in range(world)]
+    H.dist_all_gather(tensors_gather, t)
     return torch.cat(tensors_gather, dim=0)
 
 
