@@ -163,14 +163,15 @@ __global__ __launch_bounds__(FZ_T, 4) void dogf_zx_kernel(DogfParams p, FTaps<RA
                         const float4 t4 = rp[q < 0 ? 0 : (q >= NQ ? NQ - 1 : q)];
                         if (q >= 0 && q < NQ) { val[4 * q] = t4.x; val[4 * q + 1] = t4.y; val[4 * q + 2] = t4.z; val[4 * q + 3] = t4.w; }
                     }
+                    // (distance outermost, the four outputs innermost: four independent multiply-add chains in flight - with the
+                    // output outermost the compiler emitted ONE dependent add -> fma chain of 4 x 41 links per window)
                     float g[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float acc = wb.w[0] * val[e + RB];
+                    for (int e = 0; e < 4; ++e) g[e] = wb.w[0] * val[e + RB];
 #pragma unroll
-                        for (int d = 1; d <= RB; ++d) acc = fmaf(wb.w[d], val[e + RB - d] + val[e + RB + d], acc);
-                        g[e] = acc;
-                    }
+                    for (int d = 1; d <= RB; ++d)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = fmaf(wb.w[d], val[e + RB - d] + val[e + RB + d], g[e]);
                     f_st4(g2rs, dst_off, so, g);
                 }
                 __builtin_amdgcn_sched_barrier(0);         // one window at a time (register pressure)
@@ -186,12 +187,11 @@ __global__ __launch_bounds__(FZ_T, 4) void dogf_zx_kernel(DogfParams p, FTaps<RA
                     }
                     float g[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float acc = wa.w[0] * val[e + RA];
+                    for (int e = 0; e < 4; ++e) g[e] = wa.w[0] * val[e + RA];
 #pragma unroll
-                        for (int d = 1; d <= RA; ++d) acc = fmaf(wa.w[d], val[e + RA - d] + val[e + RA + d], acc);
-                        g[e] = acc;
-                    }
+                    for (int d = 1; d <= RA; ++d)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] = fmaf(wa.w[d], val[e + RA - d] + val[e + RA + d], g[e]);
                     f_st4(g1rs, dst_off, so, g);
                 }
             }
