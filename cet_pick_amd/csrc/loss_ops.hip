@@ -7,7 +7,7 @@
 // one-thread finalize that also takes the data-dependent branch of the PU risk on the device, and an
 // elementwise backward.  The contrastive loss never materialises the (2N)^2 matrix (2.4 GB at N = 12,288):
 // a row block keeps its features in registers, walks the column tiles through LDS, forms each 32x32 tile of
-// similarities on the matrix cores (v_mfma_f32_32x32x2_f32, K = feature dim) and folds exp() of it straight
+// similarities on the matrix cores (round 4: f32-equivalent products as six bf16 MFMAs of a 3-way cut, UclS) and folds exp() of it straight
 // into the four row sums the loss needs (online max, flash-attention style).  The backward recomputes the
 // tiles and contracts them with the features again on the matrix cores.
 #include "common.h"
@@ -16,7 +16,84 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4w lds_bf16x4w;
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Exact 3-way bf16 cut of eight f32 values (a = a0 + a1 + a2, truncation: every subtraction is exact), packed as the three
+// MFMA operand planes - the arithmetic of the convolution kernels (conv_cube2.hip cut8r): six bf16 products of
+// weight <= 2 accumulated in f32 are an f32-equivalent product on the bf16 matrix pipe (16x the f32 MFMA rate).
+__device__ __forceinline__ void ucl_cut8(const float (&v)[8], bf16x8 (&o)[3]) {
+    unsigned u0[8], u1[8], u2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        u0[t] = __float_as_uint(v[t]);
+        const float r1 = v[t] - __uint_as_float(u0[t] & 0xffff0000u);
+        u1[t] = __float_as_uint(r1);
+        u2[t] = __float_as_uint(r1 - __uint_as_float(u1[t] & 0xffff0000u));
+    }
+    constexpr unsigned HI2 = 0x07060302u;
+    u32x4 p0, p1, p2;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        p0[d] = __builtin_amdgcn_perm(u0[2 * d + 1], u0[2 * d], HI2);
+        p1[d] = __builtin_amdgcn_perm(u1[2 * d + 1], u1[2 * d], HI2);
+        p2[d] = __builtin_amdgcn_perm(u2[2 * d + 1], u2[2 * d], HI2);
+    }
+    o[0] = __builtin_bit_cast(bf16x8, p0); o[1] = __builtin_bit_cast(bf16x8, p1); o[2] = __builtin_bit_cast(bf16x8, p2);
+}
+
+// The similarity tile S = F_rows . F_cols^T of the contrastive loss on the bf16 pipe.  A (this wave's 32 rows, constant over
+// the column walk): lane = (row l32, features 16 ks + 8 h .. + 7), cut once into registers.  B (the 64 columns of a tile):
+// cut once per tile while it is staged, three planes of [column][DIM] bf16 rows in LDS (row pitch DIM * 2 + 16 bytes: the
+// 16-byte fragment reads of eight consecutive lanes fall on disjoint banks).
+template <int DIM> struct UclS {
+    static constexpr int KS = DIM / 16;                  // k-steps of v_mfma_f32_32x32x16_bf16
+    static constexpr int PITCH = DIM * 2 + 16;           // bytes per column row of a plane
+    static constexpr int PLANE = 64 * PITCH;
+    static constexpr int BYTES = 3 * PLANE;
+    // rows [row0, row0 + 32) of feat -> A fragments
+    static __device__ __forceinline__ void load_a(const float* feat, int row, bool ok, int h, bf16x8 (&af)[KS][3]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float v[8];
+            const float4 a = ok ? ld4(feat + (long)row * DIM + 16 * ks + 8 * h) : make_float4(0, 0, 0, 0);
+            const float4 b = ok ? ld4(feat + (long)row * DIM + 16 * ks + 8 * h + 4) : make_float4(0, 0, 0, 0);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            ucl_cut8(v, af[ks]);
+        }
+    }
+    // one unit of the tile (column c, features k8 .. k8 + 7) -> the three planes
+    static __device__ __forceinline__ void stage(unsigned char* planes, int c, int k8, const float (&v)[8]) {
+        bf16x8 o[3];
+        ucl_cut8(v, o);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<u32x4*>(planes + pl * PLANE + c * PITCH + k8 * 2) = __builtin_bit_cast(u32x4, o[pl]);
+    }
+    // acc += A . B^T for the 32 columns [cb, cb + 32) of the tile
+    static __device__ __forceinline__ f32x16 product(const unsigned char* planes, const bf16x8 (&af)[KS][3], int cb, int l32,
+                                                     int h) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 bf[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bf[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(planes + pl * PLANE + (cb + l32) * PITCH +
+                                                                                     (16 * ks + 8 * h) * 2));
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][PA[pr]], bf[PB[pr]], acc, 0, 0, 0);
+        }
+        return acc;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // voxel losses
@@ -146,53 +223,52 @@ constexpr int UB = 64;            // rows per workgroup and columns per tile (2 
 constexpr int MAXDIM = 64;
 
 // per-lane online state of one row
-struct RowAcc { float m, sa, sp, so, spair; };
+struct RowAcc { float m, sa, sp, so; };
 
 template <int DIM>
-__global__ __launch_bounds__(256) void ucl_fwd_kernel(const float* feat, const uint8_t* cls, int n2, int n_half,
+// (three waves per SIMD: 168 registers, seven dwords of scratch outside the column walk - 118 ms against 127 for the C5 step)
+__global__ __launch_bounds__(256, 3) void ucl_fwd_kernel(const float* feat, const uint8_t* cls, int n2, int n_half,
                                                      float inv_T, float* rowmax, float* s_all, float* s_pos,
                                                      float* s_other, float* e_pair) {
-    constexpr int LD = DIM + 1;                           // conflict-free fragment reads
-    __shared__ float colf[UB * LD];
+    typedef UclS<DIM> SP;
+    __shared__ __attribute__((aligned(16))) unsigned char colb[SP::BYTES];
     __shared__ uint8_t colc[UB];
-    __shared__ float mrg[2][UB][5];                       // merge of the two column halves (wn)
+    __shared__ float mrg[2][UB][4];                       // merge of the two column halves (wn)
+    __shared__ float s_pair[UB];                          // S[row][pair(row)]: one writer per row in the whole walk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l32 = lane & 31;
     const int row0 = blockIdx.x * UB;
 
-    // A fragments: this wave's 32 rows, constant over the column walk
-    float af[DIM / 2];
-    {
-        const int r = row0 + wm * 32 + l32;
-#pragma unroll
-        for (int t = 0; t < DIM / 2; ++t) af[t] = r < n2 ? feat[(long)r * DIM + 2 * t + h] : 0.f;
-    }
+    // A fragments: this wave's 32 rows, constant over the column walk (bf16x3 cut, once)
+    bf16x8 af[SP::KS][3];
+    SP::load_a(feat, row0 + wm * 32 + l32, row0 + wm * 32 + l32 < n2, h, af);
     RowAcc st[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = {-INFINITY, 0.f, 0.f, 0.f, -INFINITY};
+    for (int r = 0; r < 16; ++r) st[r] = {-INFINITY, 0.f, 0.f, 0.f};
+    if (tid < UB) s_pair[tid] = -INFINITY;
 
     for (int col0 = 0; col0 < n2; col0 += UB) {
         __syncthreads();
-        for (int q = tid; q < UB * (DIM / 4); q += 256) {
-            const int c = q / (DIM / 4), k4 = (q % (DIM / 4)) * 4;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (col0 + c < n2) v = ld4(feat + (long)(col0 + c) * DIM + k4);
-            float* d = colf + c * LD + k4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        for (int q = tid; q < UB * (DIM / 8); q += 256) {
+            const int c = q / (DIM / 8), k8 = (q % (DIM / 8)) * 8;
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (col0 + c < n2) {
+                const float4 a = ld4(feat + (long)(col0 + c) * DIM + k8), b = ld4(feat + (long)(col0 + c) * DIM + k8 + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            }
+            SP::stage(colb, c, k8, v);
         }
         if (tid < UB) colc[tid] = col0 + tid < n2 ? cls[col0 + tid] : 0;
         __syncthreads();
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* bsrc = colf + (wn * 32 + l32) * LD + h;
-#pragma unroll
-        for (int t = 0; t < DIM / 2; ++t)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bsrc[2 * t], acc, 0, 0, 0);
+        const f32x16 acc = SP::product(colb, af, wn * 32, l32, h);
         const int col = col0 + wn * 32 + l32;
         const bool colok = col < n2;
         const uint8_t cc = colc[wn * 32 + l32];
         const float fp = (cc & 1) ? 1.f : 0.f, fo = (cc & 2) ? 1.f : 0.f;
+        // (the pair element (row, pair(row)) exists in ONE lane of the whole walk: it goes to LDS, not into per-row registers)
+        const int rlo = row0 + wm * 32, clo = col0 + wn * 32;
+        const bool pair_tile = !((clo + 32 <= rlo + n_half || clo >= rlo + 32 + n_half) &&
+                                 (clo + 32 <= rlo - n_half || clo >= rlo + 32 - n_half));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -207,24 +283,26 @@ __global__ __launch_bounds__(256) void ucl_fwd_kernel(const float* feat, const u
                 const float e = __expf(s - a.m);
                 a.sa += e; a.sp += e * fp; a.so += e * fo;
             }
-            const int pr = row < n_half ? row + n_half : row - n_half;
-            if (col == pr) a.spair = s;
+            if (pair_tile) {                              // (wave-uniform)
+                const int pr = row < n_half ? row + n_half : row - n_half;
+                if (col == pr) s_pair[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = s;
+            }
         }
     }
     // merge the 32 lanes that share a row (same h), then the two column halves
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         RowAcc a = st[r];
-        float m = a.m, sp_raw = a.spair;
+        float m = a.m;
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); sp_raw = fmaxf(sp_raw, __shfl_xor(sp_raw, o, 64)); }
+        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         const float sc = __expf(a.m - m);
         float sa = a.sa * sc, sp = a.sp * sc, so = a.so * sc;
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sp += __shfl_xor(sp, o, 64); so += __shfl_xor(so, o, 64); }
         if (l32 == 0) {
             const int tr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            mrg[wn][tr][0] = m; mrg[wn][tr][1] = sa; mrg[wn][tr][2] = sp; mrg[wn][tr][3] = so; mrg[wn][tr][4] = sp_raw;
+            mrg[wn][tr][0] = m; mrg[wn][tr][1] = sa; mrg[wn][tr][2] = sp; mrg[wn][tr][3] = so;
         }
     }
     __syncthreads();
@@ -238,7 +316,7 @@ __global__ __launch_bounds__(256) void ucl_fwd_kernel(const float* feat, const u
         s_all[row] = mrg[0][tid][1] * c0 + mrg[1][tid][1] * c1 + 1.f;
         s_pos[row] = mrg[0][tid][2] * c0 + mrg[1][tid][2] * c1 + ((rc & 1) ? 1.f : 0.f);
         s_other[row] = mrg[0][tid][3] * c0 + mrg[1][tid][3] * c1 + ((rc & 2) ? 1.f : 0.f);
-        e_pair[row] = __expf(fmaxf(mrg[0][tid][4], mrg[1][tid][4]) - m);
+        e_pair[row] = __expf(s_pair[tid] - m);
     }
 }
 
@@ -248,7 +326,7 @@ __global__ __launch_bounds__(256) void ucl_fwd_kernel(const float* feat, const u
 // with c(i; j) = g_all[i] + g_pos[i] [pos j] + g_other[i] [other j] + g_pair[i] [j == pair(i)], zero on the diagonal.
 // The W tile goes through LDS to become the A operand of the second product.
 template <int DIM, int TRANS>
-__global__ __launch_bounds__(256) void ucl_bwd_kernel(const float* feat, const uint8_t* cls, int n2, int n_half,
+__global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, const uint8_t* cls, int n2, int n_half,
                                                      float inv_T, const float* rowmax, const float* g_all,
                                                      const float* g_pos, const float* g_other, const float* g_pair,
                                                      float* dfeat, int accumulate) {
@@ -258,10 +336,14 @@ __global__ __launch_bounds__(256) void ucl_bwd_kernel(const float* feat, const u
     static_assert(DIM % 32 == 0, "feature dim");
     // one LDS arena: [column-tile features UB x LD][4 waves x (32 x 33) W tiles]; after the walk the same
     // memory holds the two column halves' partial dF (2 x UB x LD)
-    __shared__ float arena[UB * LD + 4 * 32 * 33];
-    static_assert(2 * UB * LD <= UB * LD + 4 * 32 * 33, "epilogue does not fit the arena");
+    typedef UclS<DIM> SP;
+    constexpr int WP = 36;                                // W tile row pitch (floats): 16-byte rows, bank-disjoint b128 reads
+    constexpr int COLF = (UB * LD + 3) & ~3;              // (the W tiles start 16-byte aligned)
+    __shared__ __attribute__((aligned(16))) float arena[COLF + 4 * 32 * WP];
+    static_assert(2 * UB * LD <= COLF + 4 * 32 * WP, "epilogue does not fit the arena");
     float* const colf = arena;
-    float (*const wt)[32 * 33] = reinterpret_cast<float (*)[32 * 33]>(arena + UB * LD);
+    float (*const wt)[32 * WP] = reinterpret_cast<float (*)[32 * WP]>(arena + COLF);
+    __shared__ __attribute__((aligned(16))) unsigned char colb[SP::BYTES];      // the tile's bf16x3 planes (first product)
     __shared__ float cmeta[UB][5];                        // TRANS: rowmax, g_* of the tile's columns
     __shared__ uint8_t colc[UB];
     (void)WL;
@@ -269,22 +351,27 @@ __global__ __launch_bounds__(256) void ucl_bwd_kernel(const float* feat, const u
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l32 = lane & 31;
     const int row0 = blockIdx.x * UB;
 
-    float af[DIM / 2];
-    {
-        const int r = row0 + wm * 32 + l32;
-#pragma unroll
-        for (int t = 0; t < DIM / 2; ++t) af[t] = r < n2 ? feat[(long)r * DIM + 2 * t + h] : 0.f;
-    }
+    bf16x8 af[SP::KS][3];
+    SP::load_a(feat, row0 + wm * 32 + l32, row0 + wm * 32 + l32 < n2, h, af);
     // per-row metadata of the 16 rows this lane sees in the C layout
-    float rm[16], ra[16], rp[16], ro[16], rq[16];
+    // TRANS == 0 needs five numbers per row and element: rowmax and g_all stay in registers, (g_pos, g_other, g_pair) of the
+    // workgroup's 64 rows sit in LDS and come as ONE 16-byte broadcast read per row (all five in registers: 198 VGPRs, two
+    // waves per SIMD - the kernel's vector work hides behind a third wave's MFMAs)
+    __shared__ __attribute__((aligned(16))) float rmeta[UB][4];
+    if (!TRANS && tid < UB) {
+        const int row = row0 + tid;
+        const bool ok = row < n2;
+        rmeta[tid][0] = ok ? g_pos[row] : 0.f; rmeta[tid][1] = ok ? g_other[row] : 0.f;
+        rmeta[tid][2] = ok ? g_pair[row] : 0.f; rmeta[tid][3] = 0.f;
+    }
+    float rm[16], ra[16];
     uint8_t rcl[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool ok = row < n2;
-        rm[r] = ok ? rowmax[row] : 0.f;
-        ra[r] = ok ? g_all[row] : 0.f; rp[r] = ok ? g_pos[row] : 0.f;
-        ro[r] = ok ? g_other[row] : 0.f; rq[r] = ok ? g_pair[row] : 0.f;
+        rm[r] = (!TRANS && ok) ? rowmax[row] : 0.f;
+        ra[r] = (!TRANS && ok) ? g_all[row] : 0.f;
         rcl[r] = ok ? cls[row] : 0;
     }
     f32x16 out[NT];
@@ -295,12 +382,14 @@ __global__ __launch_bounds__(256) void ucl_bwd_kernel(const float* feat, const u
 
     for (int col0 = 0; col0 < n2; col0 += UB) {
         __syncthreads();
-        for (int q = tid; q < UB * (DIM / 4); q += 256) {
-            const int c = q / (DIM / 4), k4 = (q % (DIM / 4)) * 4;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (col0 + c < n2) v = ld4(feat + (long)(col0 + c) * DIM + k4);
-            float* d = colf + c * LD + k4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        for (int q = tid; q < UB * (DIM / 8); q += 256) {
+            const int c = q / (DIM / 8), k8 = (q % (DIM / 8)) * 8;
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (col0 + c < n2) {
+                const float4 a = ld4(feat + (long)(col0 + c) * DIM + k8), b = ld4(feat + (long)(col0 + c) * DIM + k8 + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            }
+            SP::stage(colb, c, k8, v);                     // (both products read the planes)
         }
         if (tid < UB) {
             const int c = col0 + tid;
@@ -313,17 +402,36 @@ __global__ __launch_bounds__(256) void ucl_bwd_kernel(const float* feat, const u
             }
         }
         __syncthreads();
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* bsrc = colf + (wn * 32 + l32) * LD + h;
-#pragma unroll
-        for (int t = 0; t < DIM / 2; ++t)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bsrc[2 * t], acc, 0, 0, 0);
+        const f32x16 acc = SP::product(colb, af, wn * 32, l32, h);
         const int lc = wn * 32 + l32, col = col0 + lc;
         const bool colok = col < n2;
         const uint8_t cc = colc[lc];
         float* wrow = wt[wave];
+        const int rlo = row0 + wm * 32, clo = col0 + wn * 32;
+        const bool plain = clo + 32 <= n2 && rlo + 32 <= n2 && (clo + 32 <= rlo || clo >= rlo + 32) &&
+                           (clo + 32 <= rlo + n_half || clo >= rlo + 32 + n_half) &&
+                           (clo + 32 <= rlo - n_half || clo >= rlo + 32 - n_half);
+        if (plain) {                                       // (wave-uniform) no diagonal, no pair element, nothing ragged
+            float c0, c1, c2, cmx;
+            if (TRANS) {
+                const float* cm = cmeta[lc];
+                cmx = cm[0]; c0 = cm[1]; c1 = cm[2]; c2 = cm[3];
+            } else {
+                c0 = (cc & 1) ? 1.f : 0.f; c1 = (cc & 2) ? 1.f : 0.f; c2 = 0.f; cmx = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tr = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float s = acc[r] * inv_T;
+                float w;
+                if (!TRANS) {
+                    const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
+                    w = __expf(s - rm[r]) * fmaf(c1, mq.y, fmaf(c0, mq.x, ra[r]));
+                }
+                else w = __expf(s - cmx) * (c0 + ((rcl[r] & 1) ? c1 : 0.f) + ((rcl[r] & 2) ? c2 : 0.f));
+                wrow[tr * WP + l32] = w;
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int tr = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -333,25 +441,49 @@ __global__ __launch_bounds__(256) void ucl_bwd_kernel(const float* feat, const u
                 const float s = acc[r] * inv_T;
                 const int pr = row < n_half ? row + n_half : row - n_half;
                 if (!TRANS) {
-                    w = __expf(s - rm[r]) * (ra[r] + ((cc & 1) ? rp[r] : 0.f) + ((cc & 2) ? ro[r] : 0.f) +
-                                             (col == pr ? rq[r] : 0.f));
+                    const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
+                    w = __expf(s - rm[r]) * (ra[r] + ((cc & 1) ? mq.x : 0.f) + ((cc & 2) ? mq.y : 0.f) +
+                                             (col == pr ? mq.z : 0.f));
                 } else {
                     const float* cm = cmeta[lc];
                     w = __expf(s - cm[0]) * (cm[1] + ((rcl[r] & 1) ? cm[2] : 0.f) + ((rcl[r] & 2) ? cm[3] : 0.f) +
                                              (col == pr ? cm[4] : 0.f));
                 }
             }
-            wrow[tr * 33 + l32] = w;
+            wrow[tr * WP + l32] = w;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes are visible to it
-        // second product: out[32 rows][DIM] += W[32 x 32] * Fcol[32 x DIM]; A = W (rows x k = tile cols)
+        // second product: out[32 rows][DIM] += W[32 x 32] * Fcol[32 x DIM]; A = W (rows x k = tile cols), on the bf16 pipe as
+        // well (round 4): the lane's eight W values of a k-step are cut here (they exist only now), the tile's features are the
+        // planes staged for the first product - read through the TRANSPOSING LDS read (ds_read_b64_tr_b16: the planes are
+        // [column = k][feature = n] rows, the fragment wants n per lane and k along its registers; a lane names row q4 of its
+        // 16-lane group's 4 x 16 block and gets the block's column i16 - conv_cube2.hip pair_wgrad_kernel has the same read)
+        {
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            const int i16 = lane & 15, g16 = (lane >> 4) & 1, q4 = i16 >> 2;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float a = wrow[l32 * 33 + 2 * t + h];
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+                const float4 a0 = *reinterpret_cast<const float4*>(wrow + l32 * WP + 16 * ks + 8 * h);
+                const float4 a1 = *reinterpret_cast<const float4*>(wrow + l32 * WP + 16 * ks + 8 * h + 4);
+                v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+                bf16x8 aw[3];
+                ucl_cut8(v, aw);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float b = colf[(wn * 32 + 2 * t + h) * LD + j * 32 + l32];
-                out[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, out[j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) {
+                    bf16x8 bf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const unsigned char* bp = colb + pl * SP::PLANE + (wn * 32 + 16 * ks + 8 * h + q4) * SP::PITCH +
+                                                  (32 * j + 16 * g16 + 4 * (i16 & 3)) * 2;
+                        const bf16x4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4w*)(bp));
+                        const bf16x4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4w*)(bp + 4 * SP::PITCH));
+                        bf[pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+                        out[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[PA[pr]], bf[PB[pr]], out[j], 0, 0, 0);
+                }
             }
         }
     }

@@ -104,12 +104,15 @@ def run(small=False):
     ucl_flop = 2 * 5 * 2.0 * (2 * n_vox) ** 2 * 32
     out["semi_train_step"] = {"pairs": b, "crop": [6, 64, 64], "ms": t * 1e3, "crops_per_sec": 2 * b / t,
                               "voxels_per_view": n_vox, "ucl_gflop": ucl_flop / 1e9,
-                              "roofline": {"bound": "mfma", "kernel": "ucl_fwd_kernel + ucl_bwd_kernel<.,0/1> (v_mfma_f32_32x32x2_f32)",
-                                           "achieved": ucl_flop / t / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                                           "frac": ucl_flop / t / 1e12 / 157.3, "traffic": None,
-                                           "note": "whole step time against the loss kernels' FLOPs (they are 97 % of it, "
-                                                   "profiles/r02_detector_kernel_stats.csv); not launch-bound: a hipGraph "
-                                                   "of the step would not change it"}}
+                              "roofline": {"bound": "mfma", "kernel": "ucl_fwd_kernel + ucl_bwd_kernel<.,0/1> (round 4: both products of a "
+                                                                      "tile as six bf16 MFMAs of a 3-way cut, f32-equivalent)",
+                                           "achieved": ucl_flop / t / 1e12, "peak": 2500.0 / 6, "unit": "TFLOP/s",
+                                           "frac": ucl_flop / t / 1e12 / (2500.0 / 6), "traffic": None,
+                                           "frac_f32_mfma_peak": ucl_flop / t / 1e12 / 157.3,
+                                           "note": "whole step time against the loss kernels' FLOPs (they are ~95 % of it); with the "
+                                                   "products on the bf16 pipe the kernels are bound by their vector work (one exp and "
+                                                   "~10 instructions per similarity), not by the matrix cores; not launch-bound: a "
+                                                   "hipGraph of the step would not change it"}}
     return out
 
 
