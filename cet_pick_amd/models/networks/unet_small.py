@@ -123,8 +123,20 @@ class TomoConvUNet(nn.Module):
             raise ValueError("expected (b, d, h, w) after squeeze, got %s" % (tuple(x.shape),))
         b, d, h, w = x.shape
         x = L.require_cuda(x, "x").contiguous().view(b * d, h, w, 1)              # one image per slice
-        y = self.bn1(self.conv1(x), relu=True)
-        y = self.unet(y)
+        chunk = int(getattr(self, "slice_chunk", 16))
+        if not self.training and not torch.is_grad_enabled() and chunk > 0 and b * d > chunk:
+            # inference on a whole tomogram: the per-slice 2-D U-Net runs `slice_chunk` slices at a time (evaluation-mode
+            # BatchNorm: slices are independent), so its activations - the skip connections of every level, 17.7 GB for a
+            # 128 x 512 x 512 volume - exist for one chunk only; what stays is the 32-channel feature volume the 3-D head reads
+            y = None
+            for c0 in range(0, b * d, chunk):
+                yc = self.unet(self.bn1(self.conv1(x[c0:c0 + chunk]), relu=True))
+                if y is None:
+                    y = torch.empty((b * d,) + tuple(yc.shape[1:]), dtype=yc.dtype, device=yc.device)
+                y[c0:c0 + chunk].copy_(yc)
+                del yc
+        else:
+            y = self.unet(self.bn1(self.conv1(x), relu=True))
         _, hh, ww, ch = y.shape
         v = y.view(b, d, hh, ww, ch)                                              # slices are the z axis again
         v = self.feature_head[0](v, relu=True)

@@ -149,6 +149,40 @@ def test_unet_forward_vs_oracle_larger():
         np.testing.assert_allclose(out[h].cpu().numpy(), r, rtol=0, atol=3e-4 * max(1.0, np.abs(r).max()))
 
 
+def test_unet_inference_in_slice_chunks_matches_whole_volume_and_oracle():
+    """Round 4: the evaluation-mode forward runs the per-slice 2-D U-Net `slice_chunk` slices at a time (ragged last chunk
+    included) - same outputs as the whole volume at once (the only difference a split-K choice can make is rounding order),
+    the oracle's values, and a peak of activations that no longer grows with the number of slices of the 2-D part."""
+    from oracle import unet_ref as O
+    net = _net()
+    x = torch.randn(1, 37, 72, 88, generator=torch.Generator().manual_seed(14))
+    xc = x.cuda()
+    with torch.no_grad():
+        net.slice_chunk = 0
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        whole = {k: v.clone() for k, v in net(xc)[0].items()}
+        peak_whole = torch.cuda.max_memory_allocated() - base
+        net.slice_chunk = 8
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        chunked = net(xc)[0]
+        peak_chunk = torch.cuda.max_memory_allocated() - base
+    ref = O.tomo_conv_unet_forward({k: v.cpu() for k, v in net.state_dict().items()}, x, 4, HEADS)
+    for h in HEADS:
+        np.testing.assert_allclose(chunked[h].cpu().numpy(), whole[h].cpu().numpy(), rtol=0, atol=2e-6 * max(1.0, float(whole[h].abs().max())))
+        r = ref[h].numpy()
+        np.testing.assert_allclose(chunked[h].cpu().numpy(), r, rtol=0, atol=3e-4 * max(1.0, np.abs(r).max()))
+    assert peak_chunk < 0.6 * peak_whole, (peak_chunk, peak_whole)
+    # training mode keeps the whole batch in one pass (batch-statistics BatchNorm)
+    net.train()
+    try:
+        y = net(xc[:, :4])[0]["hm"]
+        assert y.requires_grad
+    finally:
+        net.eval()
+
+
 def test_unet_weight_cache_follows_parameter_updates():
     net = _net()
     x = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
