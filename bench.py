@@ -307,7 +307,7 @@ def inference_secondary(dev, with_cpu=True, rank=0, world=1):
 
 # PMC traffic summary of the inference chains (tools/pmc_run.sh + tools/pmc_summary.py) and the kernels of the picker's
 # chain that it is summed over - EVERY launch of the call, not only the Gaussians
-INFER_TRAFFIC = "r03_infer_traffic.json"
+INFER_TRAFFIC = "r04_infer_traffic.json"
 DOG_KERNELS = ("not", "peak3_", "topk_", "zero_header", "nms_march")      # = everything the picker launches
 
 T_START = time.perf_counter()

@@ -4,7 +4,7 @@
 # leaves raw rocprofv3 output under gpurun_out/<tag>_final/; tools/refresh_profiles_local.sh turns it into profiles/<tag>_*.
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
-T=${1:-r03}
+T=${1:-r04}
 O=$T"_final"
 mkdir -p $R/gpurun_out/$O
 cd $R

@@ -2,7 +2,7 @@
 # Summaries of tools/refresh_profiles.sh's raw output -> profiles/<tag>_* (stamped with the kernel-source hashes).
 set -e
 cd "$(dirname "$0")/.."
-T=${1:-r03}
+T=${1:-r04}
 O=gpurun_out/$T"_final"
 cp $O/train/out_kernel_stats.csv profiles/${T}_train_kernel_stats.csv
 cp $O/infer/out_kernel_stats.csv profiles/${T}_infer_kernel_stats.csv
