@@ -34,6 +34,16 @@ struct MiSmallGemmBN {
 };
 static inline int mi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// conv_cube2.hip, final form: the epilogue operands and the per-tile arrival counters of a launch that needs no reduce
+struct Cube2Final {
+    unsigned* tickets;        // MI_CUBE2_TICKET_BYTES, zero between launches
+    float* out;
+    const float* res;
+    const float* mask;
+    int relu;
+};
+constexpr size_t MI_CUBE2_TICKET_BYTES = 16384;      // 4,096 output tiles (64 samples x 32 columns each)
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -35,6 +35,12 @@ struct Cube2Params {
     float* slabs;             // KQ slabs of (N * 8, C) floats
     int N, C;
     unsigned a_bytes, w_bytes;
+    // FINAL form (round 4): the last of a tile's KQ workgroups sums the slabs and applies the epilogue
+    unsigned* tickets;        // one arrival counter per output tile, zero between launches
+    float* out;               // (N * 8, C)
+    const float* res;         // out = act(sum + res)          (may be null)
+    const float* mask;        // out *= (mask > 0)             (may be null)
+    int relu;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of2(const void* base, unsigned bytes) {
@@ -69,9 +75,16 @@ __device__ __forceinline__ int pair_tap(int in_v, int out_v) {
     return (tz * 3 + ty) * 3 + tx;
 }
 
-template <bool DGRAD, int NS>               // NS = k-steps per wave = (8 C / 16) / (4 quarters x 4 waves) = C / 32
+// FINAL: no reduce launch behind the kernel.  Each workgroup stores its quarter's tile into its slab PAST the caches
+// (agent-scope stores: the four quarters of a tile run on different XCDs, whose L2s do not see each other's dirty lines),
+// drains them (vmcnt(0) + barrier) and takes a ticket of the tile (agent-scope atomic); the workgroup that draws the last
+// one loads the other three quarters the same way, adds the four in slab order ((0 + 1) + 2) + 3 - what the reduce launch
+// computed, so the values do not depend on who arrives last -, applies the epilogue and re-arms the ticket.  No workgroup
+// waits for another; no device-scope fence (its L2 write-back costs tens of microseconds, MI355X_MICROARCH.md).
+template <bool DGRAD, int NS, bool FINAL>   // NS = k-steps per wave = (8 C / 16) / (4 quarters x 4 waves) = C / 32
 __global__ __launch_bounds__(256, 2) void cube2_kernel(Cube2Params p) {
     __shared__ float red[4][32][64];
+    __shared__ unsigned s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l32 = lane & 31;
     const int C = p.C, cpb = C >> 5;                     // column blocks per voxel
@@ -164,13 +177,41 @@ __global__ __launch_bounds__(256, 2) void cube2_kernel(Cube2Params p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave][rb * 16 + r][lane] = acc[rb][r];
     __syncthreads();
-    float* out = p.slabs + (long)q * ((long)p.N * 8 * C);
+    const long slab = (long)p.N * 8 * C;
+    float* out = p.slabs + (long)q * slab;
+    float tv[8];
+    long o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int idx = wave * 8 + j, rb = idx >> 4, r = idx & 15;
-        const float t = ((red[0][idx][lane] + red[1][idx][lane]) + red[2][idx][lane]) + red[3][idx][lane];
+        tv[j] = ((red[0][idx][lane] + red[1][idx][lane]) + red[2][idx][lane]) + red[3][idx][lane];
         const int n = n0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;          // C/D layout: row of the 32 x 32 block
-        if (n < p.N) out[((long)n * 8 + cv) * C + cc0 + l32] = t;
+        o[j] = n < p.N ? ((long)n * 8 + cv) * C + cc0 + l32 : -1;
+        if (!FINAL) { if (o[j] >= 0) out[o[j]] = tv[j]; }
+        else if (o[j] >= 0) __hip_atomic_store(out + o[j], tv[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!FINAL) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the slab stores have left the workgroup
+    __syncthreads();
+    unsigned* ticket = p.tickets + (mt * gridDim.x + cbi);
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == KQ - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // armed for the next launch
+    float part[KQ][8];
+#pragma unroll
+    for (int z = 0; z < KQ; ++z)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            part[z][j] = (z == q || o[j] < 0) ? tv[j] : __hip_atomic_load(p.slabs + (long)z * slab + o[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (o[j] < 0) continue;
+        float t = ((part[0][j] + part[1][j]) + part[2][j]) + part[3][j];
+        if (p.res) t += p.res[o[j]];
+        if (p.relu) t = fmaxf(t, 0.f);
+        if (p.mask) t = (p.mask[o[j]] > 0.f) ? t : 0.f;
+        p.out[o[j]] = t;
     }
 }
 
@@ -542,11 +583,15 @@ int mi_pair_wgrad_launch(const float* x, const float* dy, float* dwt, int N, int
 size_t mi_cube2_slab_bytes(int N, int C) { return sizeof(float) * (size_t)KQ * N * 8 * C; }
 int mi_cube2_splits() { return KQ; }
 
-// KQ partial slabs of (N * 8, C) floats into `slabs`; the caller sums them (+ epilogue)
-int mi_cube2_launch(int dgrad, const float* a, const float* w, float* slabs, int N, int C, hipStream_t s) {
-    Cube2Params p = {a, w, slabs, N, C, (unsigned)(4l * N * 8 * C), (unsigned)(4l * 27 * C * C)};
+// KQ partial slabs of (N * 8, C) floats into `slabs`; the caller sums them (+ epilogue) - or, with `fin`, the launch is
+// final: tickets (MI_CUBE2_TICKET_BYTES, zero between launches; mi_cube2_final_usable) + out / res / mask / relu of the epilogue
+bool mi_cube2_final_usable(int N, int C) { return sizeof(unsigned) * (size_t)(8 * C / 32) * ((N + 63) / 64) <= MI_CUBE2_TICKET_BYTES; }
+int mi_cube2_launch(int dgrad, const float* a, const float* w, float* slabs, int N, int C, hipStream_t s, const Cube2Final* fin) {
+    Cube2Params p = {a, w, slabs, N, C, (unsigned)(4l * N * 8 * C), (unsigned)(4l * 27 * C * C), nullptr, nullptr, nullptr, nullptr, 0};
+    if (fin) { p.tickets = fin->tickets; p.out = fin->out; p.res = fin->res; p.mask = fin->mask; p.relu = fin->relu; }
     const dim3 grid((unsigned)(8 * C / 32), KQ, (unsigned)((N + 63) / 64));
-#define CUBE2_LAUNCH(D, NSV) hipLaunchKernelGGL((cube2_kernel<D, NSV>), grid, dim3(256), 0, s, p)
+#define CUBE2_LAUNCH(D, NSV) do { if (fin) hipLaunchKernelGGL((cube2_kernel<D, NSV, true>), grid, dim3(256), 0, s, p); \
+                                  else hipLaunchKernelGGL((cube2_kernel<D, NSV, false>), grid, dim3(256), 0, s, p); } while (0)
     if (C == 128) { if (dgrad) CUBE2_LAUNCH(true, 4); else CUBE2_LAUNCH(false, 4); }
     else if (C == 256) { if (dgrad) CUBE2_LAUNCH(true, 8); else CUBE2_LAUNCH(false, 8); }
     else if (C == 512) { if (dgrad) CUBE2_LAUNCH(true, 16); else CUBE2_LAUNCH(false, 16); }
@@ -596,4 +641,22 @@ int mi_small_gemm_launch(const float* a, long lda_m, long lda_k, long a_elems, c
 #undef SG_LAUNCH
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
+}
+
+// ---- C-ABI (include/cetpick_hip.h): the 2 x 2 x 2 convolutions, final in one launch ----
+void mi_note_conv_kernel(const char* name);          // conv_igemm.hip: mi_debug_last_conv_kernel
+extern "C" size_t mi_conv3d_cube2_workspace_bytes(int N, int C) { return MI_CUBE2_TICKET_BYTES + mi_cube2_slab_bytes(N, C); }
+
+extern "C" int mi_conv3d_cube2_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
+    return mi_cube2_usable(N, Di, Hi, Wi, Ci, Co, k, k, k, stride, pad, pad, pad, 1, 1, 1) && mi_cube2_final_usable(N, Ci) ? 1 : 0;
+}
+
+extern "C" int mi_conv3d_cube2_f32(const float* a, const float* w, float* out, const float* res, const float* mask, int relu,
+                                   int dgrad, int N, int C, void* ws, size_t ws_bytes, mi_stream_t stream) {
+    if (!a || !w || !out) return MI_E_ARG;
+    if (!mi_conv3d_cube2_usable(N, 2, 2, 2, C, C, 3, 1, 1)) return MI_E_UNSUPPORTED;
+    if (!ws || ws_bytes < mi_conv3d_cube2_workspace_bytes(N, C)) return MI_E_WORKSPACE;
+    Cube2Final fin = {(unsigned*)ws, out, res, mask, relu};
+    mi_note_conv_kernel("cube2");
+    return mi_cube2_launch(dgrad ? 1 : 0, a, w, (float*)((char*)ws + MI_CUBE2_TICKET_BYTES), N, C, (hipStream_t)stream, &fin);
 }

@@ -402,25 +402,26 @@ struct Direct3WgradParams {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-__global__ __launch_bounds__(256, 1) void direct3_wgrad_kernel(Direct3WgradParams p) {
+// Round 4: EIGHT waves per workgroup, two per SIMD: waves 0-3 take k-steps 0-1 of every plane and waves 4-7 k-steps 2-3 (same
+// four 32 x 32 blocks, same three taps); the staging of a plane is shared by 512 threads (one unit of X and one of dY each), and
+// the two halves of the reduction are added through LDS once, before the slab is written.  Measured (profiles/r04_experiments.txt
+// item 12): 40.0 -> 38.7 us; of those 8.8 us are launch + prologue + the 12 MB of slabs, and 19 planes x 72 MFMAs per SIMD at the
+// 2.05 GHz the chip sustains under MFMA load are 21.4 us - the loop runs at 0.72 of the matrix pipe.
+__global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WBUF];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l32 = lane & 31, i16 = lane & 15, g16 = (lane >> 4) & 1;
-    const int wm = wave >> 1, wn = wave & 1;             // wave block: ci half wm x co half wn
+    const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;      // k-half of the plane; wave block: ci half wm x co half wn
     const int grp = blockIdx.x / WG_SPLITS, split = blockIdx.x % WG_SPLITS;
     const int dz = grp / 3, dy = grp % 3;
     const int n_planes = p.N * p.D;
 
-    // ---- staging: unit u of a thread = (operand, voxel, 8 channels): 2 units of X and 2 of dY per plane ----
+    // ---- staging: a thread's unit = (voxel, 8 channels) of X and the same unit of dY: 64 voxels x 8 channel groups ----
     const __amdgpu_buffer_rsrc_t xrs = rsrc_of(p.x, p.bytes), yrs = rsrc_of(p.dy, p.bytes);
-    int st_lds[2];
-    unsigned st_src[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int q = tid + 256 * u, vox = q >> 3, cg = q & 7;          // 64 voxels x 8 channel groups
-        st_src[u] = 4u * (unsigned)(vox * C + cg * 8);
-        st_lds[u] = (cg >> 2) * WHALF + vox * WROW + (cg & 3) * 16;
-    }
+    const int st_vox = tid >> 3, st_cg = tid & 7;
+    const unsigned st_src = 4u * (unsigned)(st_vox * C + st_cg * 8);
+    const int st_lds = (st_cg >> 2) * WHALF + st_vox * WROW + (st_cg & 3) * 16;
     // plane index of this workgroup's i-th tile, or -1 behind the last: every WG_SPLITS-th (n, z) whose partner plane
     // z + dz - 1 is inside the volume
     auto next_plane = [&](int from) {
@@ -430,28 +431,25 @@ __global__ __launch_bounds__(256, 1) void direct3_wgrad_kernel(Direct3WgradParam
         }
         return -1;
     };
-    u32x4 ldx[2][2], ldy[2][2];
+    u32x4 ldx[2], ldy[2];
     auto stage_load = [&](int pi) {                     // pi < 0: nothing to fetch (offsets out of range: zeros)
         const unsigned ybase = pi >= 0 ? 4u * (unsigned)((long)pi * PLANE * C) : 0x80000000u;
         const unsigned xbase = pi >= 0 ? 4u * (unsigned)((long)(pi + dz - 1) * PLANE * C) : 0x80000000u;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            ldx[u][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src[u]), 0, 0);
-            ldx[u][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src[u] + 16u), 0, 0);
-            ldy[u][0] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(ybase + st_src[u]), 0, 0);
-            ldy[u][1] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(ybase + st_src[u] + 16u), 0, 0);
-        }
+        ldx[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src), 0, 0);
+        ldx[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src + 16u), 0, 0);
+        ldy[0] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(ybase + st_src), 0, 0);
+        ldy[1] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(ybase + st_src + 16u), 0, 0);
     };
-    auto stage_store_unit = [&](int buf, int op, int u) {          // op 0: X, 1: dY
+    auto stage_store_unit = [&](int buf, int op) {          // op 0: X, 1: dY
         float v[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[e] = __uint_as_float(op ? ldy[u][0][e] : ldx[u][0][e]);
-            v[4 + e] = __uint_as_float(op ? ldy[u][1][e] : ldx[u][1][e]);
+            v[e] = __uint_as_float(op ? ldy[0][e] : ldx[0][e]);
+            v[4 + e] = __uint_as_float(op ? ldy[1][e] : ldx[1][e]);
         }
         u32x4 o[3];
         cut8(v, o);
-        unsigned char* dst = lds + buf * WBUF + op * WOP + st_lds[u];
+        unsigned char* dst = lds + buf * WBUF + op * WOP + st_lds;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * WPL) = o[pl];
     };
@@ -459,22 +457,22 @@ __global__ __launch_bounds__(256, 1) void direct3_wgrad_kernel(Direct3WgradParam
     // ---- fragment addresses (transposing read: this lane names row q of its 16-lane group's 4-row block) ----
     // k-step ks covers output voxels 16 ks .. 16 ks + 15; MFMA k = 8 h + e: the lane's "lo" read fetches rows
     // 16 ks + 8 h + q (e = 0..3 after the transpose), the "hi" read rows + 4.  Output voxel v = (y, x) = (v >> 3, v & 7)
-    // pairs with input voxel (y + dy - 1, x + dx - 1) of the partner plane.
+    // pairs with input voxel (y + dy - 1, x + dx - 1) of the partner plane.  This wave's k-steps: 2 kh + lk, lk = 0, 1.
     const int q4 = i16 >> 2;
     const int coloff = (16 * g16 + 4 * (i16 & 3)) * 2;
-    const int b_base = wn * WHALF + (8 * h + q4) * WROW + coloff;         // + ks * 16 rows, + 4 rows for "hi"
-    int a_sel[4][3][2];               // byte offset inside an X plane-half image, or the zero row
+    const int b_base = wn * WHALF + (2 * kh * 16 + 8 * h + q4) * WROW + coloff;         // + lk * 16 rows, + 4 rows for "hi"
+    // Only the dx = 1 tap is READ: a lane's eight k values are the eight x positions of ONE image row (y = 2 ks + h), so the
+    // fragments of dx = 0 / 2 are the same registers moved by one bf16 element with a zero shifted in at the row's edge
+    // (4 v_alignbit per fragment instead of 2 transposing reads: the LDS pipe, not the matrix pipe, was the busy one).
+    int a_sel[2][2];                  // byte offset inside an X plane-half image, or the zero row
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int lk = 0; lk < 2; ++lk)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-            for (int hi = 0; hi < 2; ++hi) {
-                const int v = 16 * ks + 8 * h + 4 * hi + q4;
-                const int yi = (v >> 3) + dy - 1, xi = (v & 7) + dx - 1;
-                const bool ok = (unsigned)yi < 8u && (unsigned)xi < 8u;
-                a_sel[ks][dx][hi] = wm * WHALF + (ok ? (yi * 8 + xi) * WROW : WZERO) + coloff;
-            }
+        for (int hi = 0; hi < 2; ++hi) {
+            const int v = 16 * (2 * kh + lk) + 8 * h + 4 * hi + q4;
+            const int yi = (v >> 3) + dy - 1;
+            a_sel[lk][hi] = wm * WHALF + ((unsigned)yi < 8u ? (yi * 8 + (v & 7)) * WROW : WZERO) + coloff;
+        }
 
     f32x16 acc[3];
 #pragma unroll
@@ -484,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void direct3_wgrad_kernel(Direct3WgradParam
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 
     // zero rows of both buffers, both operands, all planes and halves
-    for (int i = tid; i < 2 * 2 * 3 * 2 * (WROW / 16); i += 256) {
+    for (int i = tid; i < 2 * 2 * 3 * 2 * (WROW / 16); i += 512) {
         const int img = i / (WROW / 16), c16 = i % (WROW / 16);
         *reinterpret_cast<u32x4*>(lds + img * WHALF + WZERO + c16 * 16) = u32x4{0u, 0u, 0u, 0u};
     }
@@ -492,10 +490,7 @@ __global__ __launch_bounds__(256, 1) void direct3_wgrad_kernel(Direct3WgradParam
     int cur = next_plane(split);
     int nxt = cur >= 0 ? next_plane(cur + WG_SPLITS) : -1;
     stage_load(cur);
-    if (cur >= 0) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { stage_store_unit(0, 0, u); stage_store_unit(0, 1, u); }
-    }
+    if (cur >= 0) { stage_store_unit(0, 0); stage_store_unit(0, 1); }
     stage_load(nxt);
     __syncthreads();
 
@@ -503,83 +498,106 @@ __global__ __launch_bounds__(256, 1) void direct3_wgrad_kernel(Direct3WgradParam
     // the scheduler the 50 instructions of a unit's cut went out in one block in front of the MFMAs and the matrix pipe sat
     // idle for a third of the k-step.
     bf16x8 af[2][3][3], bfg[2][3];
-    // piece j (0..11) of the 24 transposing reads of k-step ks: j < 3: dY plane j; else X tap (j - 3) / 3, plane (j - 3) % 3
-    auto read_piece = [&](int buf, int ks, int j, auto SETc) {
+    // piece j (0..5) of the 12 transposing reads of local k-step lk: j < 3: dY plane j; else the dx = 1 tap of X, plane j - 3
+    auto read_piece = [&](int buf, int lk, int j, auto SETc) {
         constexpr int SET = decltype(SETc)::value;
         const unsigned char* xb = lds + buf * WBUF;
         if (j < 3) {
-            const unsigned char* yb = xb + WOP + b_base + ks * 16 * WROW + j * WPL;
+            const unsigned char* yb = xb + WOP + b_base + lk * 16 * WROW + j * WPL;
             const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(yb));
             const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(yb + 4 * WROW));
             bfg[SET][j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         } else {
-            const int dx = (j - 3) / 3, pl = (j - 3) % 3;
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb + pl * WPL + a_sel[ks][dx][0]));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb + pl * WPL + a_sel[ks][dx][1]));
-            af[SET][dx][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            const int pl = j - 3;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb + pl * WPL + a_sel[lk][0]));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb + pl * WPL + a_sel[lk][1]));
+            af[SET][1][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
     };
-    auto read_piece_dyn = [&](int buf, int ks, int j) {
-        if (ks & 1) read_piece(buf, ks, j, std::integral_constant<int, 1>{});
-        else read_piece(buf, ks, j, std::integral_constant<int, 0>{});
+    auto read_piece_dyn = [&](int buf, int lk, int j) {
+        if (lk & 1) read_piece(buf, lk, j, std::integral_constant<int, 1>{});
+        else read_piece(buf, lk, j, std::integral_constant<int, 0>{});
     };
-    // staging pieces of unit (op, u): element e of the cut (4 VALU), then pack + store of plane pl
+    // the order the first MFMAs of a k-step want their operands in: (dY 0, X 2), (dY 2, X 0), (dY 1, X 1)
+    auto read_pair = [&](int buf, int lk, int i) {
+        constexpr int BP[3] = {0, 2, 1}, AP[3] = {2, 0, 1};
+        read_piece_dyn(buf, lk, BP[i]);
+        read_piece_dyn(buf, lk, 3 + AP[i]);
+    };
+    // fragment of tap dxv (0 or 2), plane pl, from the dx = 1 fragment: element e <- element e + dxv - 1, zero at the edge
+    auto derive = [&](int set, int dxv, int pl) {
+        const u32x4 c = __builtin_bit_cast(u32x4, af[set][1][pl]);
+        u32x4 o;
+        if (dxv == 0) {
+            o[0] = c[0] << 16;
+#pragma unroll
+            for (int j = 1; j < 4; ++j) o[j] = __builtin_amdgcn_alignbit(c[j], c[j - 1], 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) o[j] = __builtin_amdgcn_alignbit(c[j + 1], c[j], 16);
+            o[3] = c[3] >> 16;
+        }
+        af[set][dxv][pl] = __builtin_bit_cast(bf16x8, o);
+    };
+    // staging pieces of operand op: the cut of element e in two halves, one MFMA slot apart (first residual, then second:
+    // the four instructions of an element depend on each other, and a chain of four dependent VALU operations behind
+    // every MFMA held the next MFMA back - the two halves of neighbouring elements in one slot are independent);
+    // then pack + store of plane pl
     unsigned cu[3][8];
-    auto cut_piece = [&](int op, int u, int e) {
-        const float x = __uint_as_float(op ? ldy[u][e >> 2][e & 3] : ldx[u][e >> 2][e & 3]);
+    auto cut_a = [&](int op, int e) {
+        const float x = __uint_as_float(op ? ldy[e >> 2][e & 3] : ldx[e >> 2][e & 3]);
         cu[0][e] = __float_as_uint(x);
-        const float r1 = x - __uint_as_float(cu[0][e] & 0xffff0000u);
-        cu[1][e] = __float_as_uint(r1);
+        cu[1][e] = __float_as_uint(x - __uint_as_float(cu[0][e] & 0xffff0000u));
+    };
+    auto cut_b = [&](int e) {
+        const float r1 = __uint_as_float(cu[1][e]);
         cu[2][e] = __float_as_uint(r1 - __uint_as_float(cu[1][e] & 0xffff0000u));
     };
-    auto store_piece = [&](int buf, int op, int u, int pl) {
+    auto store_piece = [&](int buf, int op, int pl) {
         constexpr unsigned HI2 = 0x07060302u;
         u32x4 o;
 #pragma unroll
         for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_perm(cu[pl][2 * d + 1], cu[pl][2 * d], HI2);
-        *reinterpret_cast<u32x4*>(lds + buf * WBUF + op * WOP + st_lds[u] + pl * WPL) = o;
+        *reinterpret_cast<u32x4*>(lds + buf * WBUF + op * WOP + st_lds + pl * WPL) = o;
     };
 
     int buf = 0;
     if (cur >= 0) {
 #pragma unroll
-        for (int j = 0; j < 12; ++j) read_piece_dyn(0, 0, j);
+        for (int i = 0; i < 3; ++i) read_pair(0, 0, i);
     }
+    constexpr int DXO[3] = {1, 0, 2};                     // MFMA order of the taps: the one that was read, then the derived ones
     while (cur >= 0) {
         const int nn = nxt >= 0 ? next_plane(nxt + WG_SPLITS) : -1;      // the plane after next: fetched during this one
         const unsigned ybase = nn >= 0 ? 4u * (unsigned)((long)nn * PLANE * C) : 0x80000000u;
         const unsigned xbase = nn >= 0 ? 4u * (unsigned)((long)(nn + dz - 1) * PLANE * C) : 0x80000000u;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int op = ks >> 1, u = ks & 1;           // the unit of the NEXT plane that is cut + stored behind this k-step
+        for (int lk = 0; lk < 2; ++lk) {
+            const int op = lk;                            // the unit of the NEXT plane that is cut + stored behind this k-step
 #pragma unroll
             for (int m = 0; m < 18; ++m) {
-                acc[m / 6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][m / 6][PA[m % 6]], bfg[ks & 1][PB[m % 6]], acc[m / 6], 0, 0, 0);
-                // behind the MFMA: one piece of the staging (k-steps 0..2: behind the reads of the fragments that are
-                // needed first, so that every MFMA carries 4 - 5 other instructions) ...
-                const int c0 = ks < 3 ? 3 : 0;
-                if (m >= c0 && m < c0 + 8) cut_piece(op, u, m - c0);
-                else if (m >= c0 + 8 && m < c0 + 11) store_piece(buf ^ 1, op, u, m - c0 - 8);
-                // ... the fetch of the plane after next (its staging registers were consumed by the cuts above) ...
-                if (ks == 3 && m >= 9 && m < 17) {
-                    const int i = m - 9, uu = (i >> 1) & 1, hf = i & 1;
-                    if (i < 4) ldx[uu][hf] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src[uu] + 16u * hf), 0, 0);
-                    else ldy[uu][hf] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(ybase + st_src[uu] + 16u * hf), 0, 0);
+                const int dxm = DXO[m / 6];
+                acc[dxm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[lk][dxm][PA[m % 6]], bfg[lk][PB[m % 6]], acc[dxm], 0, 0, 0);
+                // behind the MFMA: the derived fragments (tap 0 behind MFMAs 0-2, tap 2 behind 6-8), one piece of the staging,
+                if (m < 3) derive(lk, 0, m);
+                if (m >= 6 && m < 9) derive(lk, 2, m - 6);
+                if (m >= 2 && m < 10) cut_a(op, m - 2);
+                if (m >= 3 && m < 11) cut_b(m - 3);
+                if (m >= 11 && m < 14) store_piece(buf ^ 1, op, m - 11);
+                // the fetch of the plane after next (its staging registers were consumed by the cuts above) ...
+                if (lk == 1 && m >= 14) {
+                    const int i = m - 14, hf = i & 1;
+                    if (i < 2) ldx[hf] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src + 16u * hf), 0, 0);
+                    else ldy[hf] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(ybase + st_src + 16u * hf), 0, 0);
                 }
                 // ... and the fragment reads of the next k-step.  The last k-step of a plane reads the NEXT plane's first
-                // k-step, which is complete once every wave has stored its last unit: the barrier sits behind MFMA 10
-                if (ks < 3) {
-                    // pieces 0..5 (dY and tap 0: used by the next k-step's first MFMAs) first, tap 1 / 2 at the end
-                    if (m < 3) { read_piece_dyn(buf, ks + 1, 2 * m); read_piece_dyn(buf, ks + 1, 2 * m + 1); }
-                    if (m >= 14 && m < 17) { read_piece_dyn(buf, ks + 1, 2 * (m - 11)); read_piece_dyn(buf, ks + 1, 2 * (m - 11) + 1); }
+                // k-step, which is complete once every wave has stored its last unit: the barrier sits behind MFMA 13
+                if (lk == 0) {
+                    if (m < 3) read_pair(buf, 1, m);
                 } else {
-                    if (m == 10) __syncthreads();
-                    if (m >= 11 && nxt >= 0) {
-                        const int j0 = 2 * (m - 11);
-                        if (j0 < 12) read_piece_dyn(buf ^ 1, 0, j0);
-                        if (j0 + 1 < 12) read_piece_dyn(buf ^ 1, 0, j0 + 1);
-                    }
+                    if (m == 13) __syncthreads();
+                    if (m >= 14 && m < 17 && nxt >= 0) read_pair(buf ^ 1, 0, m - 14);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -589,7 +607,18 @@ __global__ __launch_bounds__(256, 1) void direct3_wgrad_kernel(Direct3WgradParam
         nxt = nn;
     }
 
-    // ---- slab: this workgroup's three taps of slab `split`; C/D layout col = lane & 31 (co), row = ci ----
+    // ---- the two k-halves added through LDS (waves 4-7 hand their tiles to waves 0-3), then the slab: this workgroup's
+    //      three taps of slab `split`; C/D layout col = lane & 31 (co), row = ci ----
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);          // [block 4][48 registers][64 lanes]: 48 KB
+    if (kh == 1) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((wave & 3) * 3 + dx) * 16 + r) * 64 + lane] = acc[dx][r];
+    }
+    __syncthreads();
+    if (kh == 1) return;
     float* out = p.slabs + (long)split * (NTAP * C * C);
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
@@ -597,7 +626,7 @@ __global__ __launch_bounds__(256, 1) void direct3_wgrad_kernel(Direct3WgradParam
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
-            out[((long)tap * C + ci) * C + 32 * wn + l32] = acc[dx][r];
+            out[((long)tap * C + ci) * C + 32 * wn + l32] = acc[dx][r] + red[((wave * 3 + dx) * 16 + r) * 64 + lane];
         }
     }
 }
@@ -605,56 +634,65 @@ __global__ __launch_bounds__(256, 1) void direct3_wgrad_kernel(Direct3WgradParam
 
 // ---- layer2-shaped convolutions: 3^3 / stride 1 / padding 1, 128 -> 128 channels on 4 x 4 x 4 volumes --------------------
 // (moco_encoder_3d.py:55-84,171: three of them per encoder pass, 9 forward / data-gradient launches per step.)  M is small
-// (64 voxels per sample), so the parallelism comes from the reduction: a workgroup owns TWO samples (128 rows) x 64
-// output channels x ONE chunk of 32 input channels - 32 sample pairs x 2 column tiles x 4 chunks = 256 workgroups - and
-// writes its partial tile into split-K slab `chunk`; the caller's reduce launch sums the four slabs and applies the
-// epilogue.  Same structure as direct3_kernel otherwise: the 128 x 32 patch is cut once into LDS (43 KB), a wave owns
-// one sample x 32 columns (two row blocks), weight fragments stream from the pre-cut image, every halo voxel is padding
-// (the volume IS the tile) and reads the lane's zero record.
+// (64 voxels per sample), so the parallelism comes from the reduction - and since round 4 the reduction is split INSIDE the
+// workgroup: a workgroup owns ONE sample (64 rows) x 32 output channels, its four waves take one chunk of 32 input
+// channels each (64 samples x 4 column blocks = 256 workgroups), the four partial tiles are added through LDS in chunk
+// order and the convolution's epilogue (residual, ReLU, mask) runs on the sum: the launch is final - no split-K slabs, no
+// reduce launch behind it (rounds 2-3: 4 slabs of 2 MB and a 4.9-us launch per convolution, nine per step), and the values
+// are the ones the slab form produced (same products, same order of the four partial sums).
+// Same structure as direct3_kernel otherwise: the sample's 64 x 128 patch is cut once into LDS (4 chunks x 30 KB), weight
+// fragments stream from the pre-cut image (a wave reads its chunk's stream), every halo voxel is padding (the volume IS
+// the tile) and reads the lane's zero record.
 constexpr int CS = 128;                     // channels, in = out
 constexpr int VS = 64;                      // voxels of a 4 x 4 x 4 sample
-constexpr int S_LEAD = 32;                  // records in front of voxel 0 (>= 21, the -21 of the tap offsets; 32 + 128 = 0 mod 16)
-constexpr int S_NV = 2 * VS;                // two samples
+constexpr int S_LEAD = 32;                  // records in front of voxel 0 (>= 21, the -21 of the tap offsets; 32 + 64 = 0 mod 16)
+constexpr int S_NV = VS;                    // one sample
 constexpr int S_ZREC = 64;                  // (record mod 16) + tap offset (0..42) stays inside
 constexpr int S_NREC = S_LEAD + S_NV + S_ZREC;
-constexpr int S_ARR = S_NREC * 16;          // 3,584
+constexpr int S_ARR = S_NREC * 16;          // 2,560
 constexpr int S_PL = 2 * S_ARR;
 constexpr int S_KS = 3 * S_PL;
-constexpr int S_LDS = 2 * S_KS;             // 43,008
+constexpr int S_CH = 2 * S_KS;              // one 32-channel chunk of the patch: 30,720
 constexpr int S_ZBASE = (S_LEAD + S_NV) * 16;
-constexpr int S_CHUNKS = 4;                 // split-K over 32-channel chunks
+constexpr int S_CHUNKS = 4;                 // 32-channel chunks = waves of the workgroup
+constexpr int S_LDS = S_CHUNKS * S_CH;      // 122,880
 constexpr int S_STEPS = 2 * NTAP;           // k-steps per chunk: g = tap * 2 + ks
 constexpr int S_WSTEP = 4 * 3 * WBLK;       // bytes per k-step of the image: [column block 0..3][plane]
 constexpr int S_WIMG_BYTES = S_CHUNKS * S_STEPS * S_WSTEP;       // 2,654,208
 static_assert(S_STEPS % RB == 0, "ring slots");
 static_assert(((S_LEAD + S_NV) & 15) == 0, "zero region must start at a record = 0 (mod 16)");
+static_assert(S_LDS <= 160 * 1024 && 4 * 32 * 64 * 4 <= S_LDS, "patch (and the four partial tiles behind it) fit the LDS");
 
 struct Direct3sParams {
     const float* a;           // X or dY: (N, 4, 4, 4, 128)
     const unsigned char* wimg;
-    float* slabs;             // S_CHUNKS slabs of (N * 64, 128) floats
+    float* out;               // (N, 4, 4, 4, 128), final
+    const float* res;         // out = act(acc + res)          (may be null)
+    const float* mask;        // out *= (mask > 0)             (may be null)
+    int relu;
     int N;
     unsigned a_bytes;
 };
 
-__global__ __launch_bounds__(256, 2) void direct3s_kernel(Direct3sParams p) {
+__global__ __launch_bounds__(256, 1) void direct3s_kernel(Direct3sParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char patch[S_LDS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int cc = __builtin_amdgcn_readfirstlane(tid >> 6);          // the wave's chunk of 32 input channels
     const int h = lane >> 5, l32 = lane & 31;
-    const int wsm = wave >> 1, cw = wave & 1;            // wave tile: sample wsm of the pair x column half cw
-    const int cc = blockIdx.x % S_CHUNKS, ct = (blockIdx.x / S_CHUNKS) & 1, sp = blockIdx.x / (2 * S_CHUNKS);
-    const int n0 = 2 * sp;
+    const int ct = blockIdx.x & 3, n0 = blockIdx.x >> 2;              // column block of 32 output channels, sample
 
     const __amdgpu_buffer_rsrc_t wrs = rsrc_of(p.wimg, S_WIMG_BYTES);
-    const int w_voff = (ct * 2 + cw) * (3 * WBLK) + lane * 16;
+    const int w_voff = ct * (3 * WBLK) + lane * 16;
     const int w_soff = cc * (S_STEPS * S_WSTEP);
     bf16x8 bfr[RB][3];
     auto wload = [&](int g, auto SLOTc) {
         constexpr int SLOT = decltype(SLOTc)::value;
-        const int so = g < S_STEPS ? w_soff + g * S_WSTEP : S_WIMG_BYTES;       // behind the chunk: zeros (out of range)
+        // behind the chunk: zeros - the out-of-range offset goes into the CHECKED voffset (soffset is not range-checked)
+        const int vo = g < S_STEPS ? w_voff : (int)0x80000000u;
+        const int so = g < S_STEPS ? w_soff + g * S_WSTEP : 0;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-            bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, w_voff + pl * WBLK, so, 0));
+            bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, vo + pl * WBLK, so, 0));
     };
     auto wload_dyn = [&](int g) {
         switch (g % RB) {
@@ -669,45 +707,47 @@ __global__ __launch_bounds__(256, 2) void direct3s_kernel(Direct3sParams p) {
 #pragma unroll
     for (int g = 0; g < RB - 1; ++g) wload_dyn(g);
 
-    // ---- stage the patch: unit q = (voxel of the pair, group of 8 of the chunk's 32 channels); 2 units per thread ----
+    // ---- stage the patch: unit q = (voxel, group of 8 of the 128 channels): 64 x 16 units, 4 per thread ----
     {
         const __amdgpu_buffer_rsrc_t ars = rsrc_of(p.a, p.a_bytes);
-        u32x4 ld[2][2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int q = tid + 256 * u, vox = q >> 2, cg = q & 3;
-            const bool ok = n0 + (vox >> 6) < p.N;
-            const unsigned off = ok ? 4u * (unsigned)(((long)n0 * VS + vox) * CS + cc * 32 + cg * 8) : 0x80000000u;
-            ld[u][0] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)off, 0, 0);
-            ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(off + 16u), 0, 0);
-        }
-        for (int i = tid; i < 12 * S_ZREC; i += 256) {
+        for (int i = tid; i < 12 * S_CHUNKS * S_ZREC; i += 256) {
             const int arr = i / S_ZREC, r = i % S_ZREC;
             *reinterpret_cast<u32x4*>(patch + arr * S_ARR + S_ZBASE + r * 16) = u32x4{0u, 0u, 0u, 0u};
         }
+        {
+            constexpr int b = 0;
+            u32x4 ld[4][2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int q = tid + 256 * u, vox = q >> 2, cg = q & 3;
-            float v[8];
+            for (int u = 0; u < 4; ++u) {
+                const int q = tid + 256 * (4 * b + u), vox = q >> 4, cg = q & 15;
+                const unsigned off = 4u * (unsigned)(((long)n0 * VS + vox) * CS + cg * 8);
+                ld[u][0] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)off, 0, 0);
+                ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(off + 16u), 0, 0);
+            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ld[u][0][e]); v[4 + e] = __uint_as_float(ld[u][1][e]); }
-            u32x4 o[3];
-            cut8(v, o);
-            unsigned char* dst = patch + (cg >> 1) * S_KS + (cg & 1) * S_ARR + (S_LEAD + vox) * 16;
+            for (int u = 0; u < 4; ++u) {
+                const int q = tid + 256 * (4 * b + u), vox = q >> 4, cg = q & 15;
+                float v[8];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * S_PL) = o[pl];
+                for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ld[u][0][e]); v[4 + e] = __uint_as_float(ld[u][1][e]); }
+                u32x4 o[3];
+                cut8(v, o);
+                unsigned char* dst = patch + (cg >> 2) * S_CH + ((cg >> 1) & 1) * S_KS + (cg & 1) * S_ARR + (S_LEAD + vox) * 16;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * S_PL) = o[pl];
+            }
         }
     }
 
-    // ---- per-lane geometry: row block i = voxels 32 i .. 32 i + 31 of the wave's sample ----
+    // ---- per-lane geometry: row block i = voxels 32 i .. 32 i + 31 of the sample ----
     int vbase[2], zbase[2];
     unsigned vmask[2];                  // bit tap: the tap's neighbour is inside the 4 x 4 x 4 volume
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int v = 32 * i + l32, z = v >> 4, y = (v >> 2) & 3, x = v & 3;
-        const int rec = S_LEAD - 21 + wsm * VS + v;
-        vbase[i] = rec * 16 + h * S_ARR;
-        zbase[i] = S_ZBASE + (rec & 15) * 16 + h * S_ARR;
+        const int rec = S_LEAD - 21 + v;
+        vbase[i] = cc * S_CH + rec * 16 + h * S_ARR;
+        zbase[i] = cc * S_CH + S_ZBASE + (rec & 15) * 16 + h * S_ARR;
         unsigned m = 0;
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
@@ -766,15 +806,27 @@ __global__ __launch_bounds__(256, 2) void direct3s_kernel(Direct3sParams p) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- partial tile into slab cc; C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h ----
-    if (n0 + wsm < p.N) {
-        float* out = p.slabs + (long)cc * ((long)p.N * VS * CS);
-        const long m0 = (long)(n0 + wsm) * VS;
-        const int col = ct * 64 + cw * 32 + l32;
+    // ---- the four chunks' tiles added through LDS in chunk order ((0 + 1) + 2) + 3 - the order the slab reduce used -,
+    //      wave w finishing rows block (w >> 1), registers 8 (w & 1) .. + 7; C/D layout col = lane & 31,
+    //      row = (r & 3) + 8 (r >> 2) + 4 h ----
+    __syncthreads();                                    // every wave is done with the patch
+    float* red = reinterpret_cast<float*>(patch);       // [chunk][32 registers][64 lanes]
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) out[(m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * CS + col] = acc[i][r];
+        for (int r = 0; r < 16; ++r) red[(cc * 32 + i * 16 + r) * 64 + lane] = acc[i][r];
+    __syncthreads();
+    const long m0 = (long)n0 * VS;
+    const int col = ct * 32 + l32;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = cc * 8 + j, i = idx >> 4, r = idx & 15;
+        float t = ((red[idx * 64 + lane] + red[(32 + idx) * 64 + lane]) + red[(64 + idx) * 64 + lane]) + red[(96 + idx) * 64 + lane];
+        const long o = (m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * CS + col;
+        if (p.res) t += p.res[o];
+        if (p.relu) t = fmaxf(t, 0.f);
+        if (p.mask) t = (p.mask[o] > 0.f) ? t : 0.f;
+        p.out[o] = t;
     }
 }
 
@@ -821,11 +873,8 @@ bool mi_direct3_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, in
 size_t mi_direct3_wimg_bytes(int channels) {
     return channels == C ? (size_t)WIMG_BYTES : channels == CS ? (size_t)S_WIMG_BYTES : 0;
 }
-// split-K slabs the 128-channel kernel writes (the caller reduces them); 0 for the 64-channel kernel
-size_t mi_direct3_slab_bytes(int N, int channels) {
-    return channels == CS ? sizeof(float) * (size_t)S_CHUNKS * N * VS * CS : 0;
-}
-int mi_direct3_splits(int channels) { return channels == CS ? S_CHUNKS : 1; }
+// (rounds 2-3: split-K slabs of the 128-channel kernel; since round 4 both direct kernels are final in one launch)
+size_t mi_direct3_slab_bytes(int, int) { return 0; }
 
 // channels[i] = 64 or 128 selects the image format of weight i
 int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, const int* channels, int n, hipStream_t s) {
@@ -858,10 +907,11 @@ int mi_direct3_launch(const float* a, const void* wimg, float* out, const float*
     return MI_OK;
 }
 
-// 128-channel kernel: S_CHUNKS partial slabs of (N * 64, 128) floats into `slabs`; the caller sums them (+ epilogue)
-int mi_direct3s_launch(const float* a, const void* wimg, float* slabs, int N, hipStream_t s) {
-    Direct3sParams p = {a, (const unsigned char*)wimg, slabs, N, (unsigned)(4l * N * VS * CS)};
-    hipLaunchKernelGGL(direct3s_kernel, dim3((unsigned)(((N + 1) / 2) * 2 * S_CHUNKS)), dim3(256), 0, s, p);
+// 128-channel kernel: one workgroup per (sample, 32 output channels), final with the epilogue
+int mi_direct3s_launch(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
+                       hipStream_t s) {
+    Direct3sParams p = {a, (const unsigned char*)wimg, out, res, mask, relu, N, (unsigned)(4l * N * VS * CS)};
+    hipLaunchKernelGGL(direct3s_kernel, dim3((unsigned)(4 * N)), dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -872,7 +922,7 @@ int mi_direct3_wgrad_splits() { return WG_SPLITS; }
 // writes WG_SPLITS full-size slabs ([27][64][64] floats each) into `slabs`; the caller sums them
 int mi_direct3_wgrad_launch(const float* x, const float* dy, float* slabs, int N, int D, hipStream_t s) {
     Direct3WgradParams p = {x, dy, slabs, N, D, (unsigned)(4l * N * D * PLANE * C)};
-    hipLaunchKernelGGL(direct3_wgrad_kernel, dim3(9 * WG_SPLITS), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(direct3_wgrad_kernel, dim3(9 * WG_SPLITS), dim3(512), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -901,11 +951,6 @@ extern "C" int mi_conv3d_direct_f32(const float* a, const void* wimg, float* out
     if (!a || !wimg || !out) return MI_E_ARG;
     const int kind = mi_direct3_kind(N, Di, Hi, Wi, channels, channels, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1);
     if (kind == 1) return mi_direct3_launch(a, wimg, out, res, mask, relu, N, Di, (hipStream_t)stream);
-    if (kind == 2) {
-        if (!ws || ws_bytes < mi_direct3_slab_bytes(N, channels)) return MI_E_WORKSPACE;
-        int rc = mi_direct3s_launch(a, wimg, (float*)ws, N, (hipStream_t)stream);
-        if (rc) return rc;
-        return mi_direct3_finish_slabs((const float*)ws, S_CHUNKS, (long)N * VS * CS, out, res, mask, relu, (hipStream_t)stream);
-    }
+    if (kind == 2) return mi_direct3s_launch(a, wimg, out, res, mask, relu, N, (hipStream_t)stream);
     return MI_E_UNSUPPORTED;
 }

@@ -51,11 +51,11 @@ int mi_direct3_kind(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int k
                     int pw, int dd, int dh, int dw);
 size_t mi_direct3_wimg_bytes(int channels);
 size_t mi_direct3_slab_bytes(int N, int channels);
-int mi_direct3_splits(int channels);
 int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, const int* channels, int n, hipStream_t s);
 int mi_direct3_launch(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
                       int D, hipStream_t s);
-int mi_direct3s_launch(const float* a, const void* wimg, float* slabs, int N, hipStream_t s);
+int mi_direct3s_launch(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
+                       hipStream_t s);
 int mi_direct3_finish_slabs(const float* slabs, int n_slabs, long out_elems, float* out, const float* res, const float* mask,
                             int relu, hipStream_t s);
 size_t mi_direct3_wgrad_slab_bytes();
@@ -66,7 +66,7 @@ bool mi_cube2_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int 
                      int dd, int dh, int dw);
 size_t mi_cube2_slab_bytes(int N, int C);
 int mi_cube2_splits();
-int mi_cube2_launch(int dgrad, const float* a, const float* w, float* slabs, int N, int C, hipStream_t s);
+int mi_cube2_launch(int dgrad, const float* a, const float* w, float* slabs, int N, int C, hipStream_t s, const Cube2Final* fin = nullptr);
 // ... and the small dense products of the Linear layers (register-staged, final in one launch)
 bool mi_pair_wgrad_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw,
                           int dd, int dh, int dw);
@@ -1211,13 +1211,9 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         const int dg[1] = {mode == MODE_DGRAD ? 1 : 0}, ch[1] = {g.Ci};
         int rc = mi_direct3_prep(wl, il, dg, ch, 1, s);
         if (rc) return rc;
-        g_last_conv_kernel = dkind == 1 ? "direct3" : "direct3s + reduce";
+        g_last_conv_kernel = dkind == 1 ? "direct3" : "direct3s";
         if (dkind == 1) return mi_direct3_launch(a_src, ws, out, res, mask, relu, g.N, g.Di, s);
-        float* slabs = (float*)((char*)ws + dimg);               // 128-channel kernel: split-K slabs behind the image
-        rc = mi_direct3s_launch(a_src, ws, slabs, g.N, s);
-        if (rc) return rc;
-        return mi_direct3_finish_slabs(slabs, mi_direct3_splits(g.Ci), (long)g.N * g.Di * g.Hi * g.Wi * g.Ci, out, res, mask,
-                                       relu, s);
+        return mi_direct3s_launch(a_src, ws, out, res, mask, relu, g.N, s);       // 128-channel kernel: final as well
     }
     if (mode != MODE_WGRAD && conv_arith_bf16x3() && is_cube2(g) && ws && ws_bytes >= mi_cube2_slab_bytes(g.N, g.Ci)) {
         g_last_conv_kernel = "cube2 + reduce";
@@ -1312,6 +1308,7 @@ extern "C" int mi_conv3d_fwd_f32(const float* x, const float* w, float* y, const
 
 /* measurement aid: the kernel family the last mi_conv* call of the calling thread ran ("direct3", "cube2 + reduce", ...) */
 extern "C" const char* mi_debug_last_conv_kernel(void) { return g_last_conv_kernel; }
+void mi_note_conv_kernel(const char* name) { g_last_conv_kernel = name; }       // (entry points outside run_conv: conv_cube2.hip)
 
 /* nn.Linear (+ bias) followed by training-mode nn.BatchNorm1d (+ ReLU) in ONE launch - the projection MLP of the MoCo-3D
  * encoder (models/networks/moco_encoder_3d.py:238-255: Linear, BatchNorm1d, ReLU three times over a batch of <= 64 rows).

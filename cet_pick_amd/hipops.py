@@ -351,12 +351,40 @@ def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None):
         L.check(lib.mi_conv3d_direct_f32(L.ptr(x), L.ptr(img), L.ptr(y), L.ptr(res), None, int(relu), n, d, h, wd, ci,
                                          L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_direct_f32")
         return y
+    if nd5 and _cube2_final(lib, n, d, h, wd, ci, co, k3, stride, p3):
+        ws = _cube2_ws(lib, n, ci, x.device)
+        def call():
+            return _cube2_call(lib, x, w, y, res, None, int(relu), 0, n, ci, ws)
+        _prof_run("fwd", 2.0 * n * do * ho * wo * co * ci * 27, call)
+        return y
     ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), x.device, "conv")
     def call():
         return L.check(lib.mi_convnd_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(res), int(relu), n, d, h, wd, ci,
             co, *k3, stride, *p3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_fwd_f32")
     _prof_run("fwd", 2.0 * n * do * ho * wo * co * ci * k3[0] * k3[1] * k3[2], call)
     return y
+
+
+def _cube2_final(lib, n, d, h, wd, ci, co, k3, stride, p3):
+    """3^3 / stride 1 / padding 1 on a 2 x 2 x 2 volume (layer3, feature_3d): conv_cube2.hip, final in one launch
+    (mi_conv3d_cube2_f32; MI_CUBE2_REDUCE=1 keeps the partial sums + reduce launch of mi_convnd_*)."""
+    if os.environ.get("MI_CUBE2_REDUCE") or os.environ.get("MI_CONV_ARITH", "")[:1] == "f":
+        return False
+    return (tuple(k3) == (3, 3, 3) and tuple(p3) == (1, 1, 1) and
+            bool(lib.mi_conv3d_cube2_usable(n, d, h, wd, ci, co, 3, stride, 1)))
+
+
+def _cube2_ws(lib, n, c, device):
+    # arrival counters in front of the partial sums: zero at allocation, left zero by every call; one buffer per stream
+    return L.workspace(lib.mi_conv3d_cube2_workspace_bytes(n, c), device, "cube2", init=lambda b: b.zero_())
+
+
+def _cube2_call(lib, a, w, out, res, mask, relu, dgrad, n, c, ws):
+    rc = lib.mi_conv3d_cube2_f32(L.ptr(a), L.ptr(w), L.ptr(out), L.ptr(res), L.ptr(mask), relu, dgrad, n, c, L.ptr(ws),
+                                 ws.numel(), L.stream())
+    if rc:
+        L.drop_workspace(a.device, "cube2")         # its counters can no longer be trusted
+    return L.check(rc, "mi_conv3d_cube2_f32")
 
 
 def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None, dil=None):
@@ -382,6 +410,12 @@ def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None, dil=None):
         ws = _ws(lib.mi_conv3d_direct_workspace_bytes(n, ci), dy.device, "conv")
         L.check(lib.mi_conv3d_direct_f32(L.ptr(dy), L.ptr(img), L.ptr(dx), L.ptr(res), L.ptr(mask), 0, n, d, h, wd, ci,
                                          L.ptr(ws), ws.numel(), L.stream()), "mi_conv3d_direct_f32")
+        return dx
+    if nd5 and dil is None and _cube2_final(lib, n, d, h, wd, ci, co, k3, stride, p3):
+        ws = _cube2_ws(lib, n, ci, dy.device)
+        def call():
+            return _cube2_call(lib, dy, w, dx, res, mask, 0, 1, n, ci, ws)
+        _prof_run("dgrad", flops, call)
         return dx
     ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), dy.device, "conv")
     def call():

@@ -249,7 +249,7 @@ int mi_splitk_reduce_batch(const void* const* slabs, void* const* outs, const in
  * mi_conv3d_direct_f32 runs
  *   forward  (image with dgrad = 0): out = act(conv(a, w) + res)                       a = x,  relu as given, mask NULL
  *   dgrad    (image with dgrad = 1): out = (conv_transpose(a, w) + res) * (mask > 0)   a = dy, relu 0
- * `ws`: mi_conv3d_direct_workspace_bytes(N, channels) bytes (split-K slabs of the 128-channel kernel; 0 for 64).
+ * `ws`: mi_conv3d_direct_workspace_bytes(N, channels) bytes (0 since round 4: both direct kernels are final in one launch; rounds 2-3 kept split-K slabs of the 128-channel kernel there).
  * MI_E_UNSUPPORTED for any other shape (mi_conv3d_direct_usable: 0 / 1 (64 channels) / 2 (128 channels)). */
 size_t mi_conv3d_direct_wimg_bytes(int channels);
 size_t mi_conv3d_direct_workspace_bytes(int N, int channels);
@@ -258,6 +258,20 @@ int mi_conv3d_direct_prep(const void* const* w, void* const* img, const int* dgr
                           mi_stream_t stream);
 int mi_conv3d_direct_f32(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu,
                          int N, int Di, int Hi, int Wi, int channels, void* ws, size_t ws_bytes, mi_stream_t stream);
+
+/* 3^3 / stride 1 / padding 1 convolutions on 2 x 2 x 2 volumes, C -> C channels, C = 128 / 256 / 512 (layer3 and feature_3d
+ * of the MoCo-3D encoder, models/networks/moco_encoder_3d.py:55-84,172,178), bf16x3 arithmetic, FINAL IN ONE LAUNCH (round 4:
+ * the last of the four reduction quarters of an output tile to arrive sums them - in a fixed order - and applies the epilogue):
+ *   dgrad = 0: out = act(conv(a, w) + res)                      a = x (N, 2, 2, 2, C),  w = [27][Cin][Cout] f32, mask NULL
+ *   dgrad = 1: out = (conv_transpose(a, w) + res) * (mask > 0)  a = dy, relu 0
+ * mi_conv3d_fwd_f32 / mi_conv3d_dgrad_f32 take such shapes too (same kernel, partial sums + a reduce launch: their `ws` has no
+ * state).  `ws` here: mi_conv3d_cube2_workspace_bytes(N, C) bytes OWNED BY ONE STREAM whose first 16 KiB (arrival counters) are
+ * ZERO before the first call; every completed call leaves them zero.  MI_E_UNSUPPORTED for other shapes
+ * (mi_conv3d_cube2_usable). */
+size_t mi_conv3d_cube2_workspace_bytes(int N, int C);
+int mi_conv3d_cube2_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad);
+int mi_conv3d_cube2_f32(const float* a, const float* w, float* out, const float* res, const float* mask, int relu, int dgrad,
+                        int N, int C, void* ws, size_t ws_bytes, mi_stream_t stream);
 
 /* Dilated windows, stride 1 (kernel (3,3,3), dilation (1,4,4), padding (1,4,4): the 3-D head of the detector
  * network, models/networks/unet_small.py:38-41).  Same contract as mi_convnd_*; output extent per axis
