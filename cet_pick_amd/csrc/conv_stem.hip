@@ -197,8 +197,15 @@ __global__ __launch_bounds__(256) void stem_wprep_kernel(const float* w, unsigne
 
 // NBUF = 2: the kz slabs of the weights alternate between two LDS buffers (75 KB, two workgroups per CU); NBUF = 1: one buffer
 // (51 KB, THREE workgroups per CU), the next slab stored between two barriers under the last k-step's MFMAs.
-template <int NBUF>
-__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void stem_fwd_bf3_kernel(StemParams p, const unsigned char* wprep) {
+// ZPW = 2 (round 4): a wave owns TWO z-planes of the tile (tile 8 x 4 x 8 voxels, patch 21 planes: 66 KB with one weight
+// buffer, two workgroups per CU): every weight fragment read from LDS feeds two A fragments (LDS bytes per MFMA 0.75 -> 0.5 KB;
+// the reads ran at 73 % of the LDS rate), the patch is 2.6 instead of 3.25 input planes per output plane, and 64 samples of
+// 16^3 outputs are 1,024 workgroups = exactly two rounds of 512 resident ones (2,048 on 768 slots left a third round 2/3 empty).
+template <int NBUF, int ZPW>
+__global__ __launch_bounds__(256, ZPW == 2 ? 2 : (NBUF == 1 ? 3 : 2)) void stem_fwd_bf3_kernel(StemParams p, const unsigned char* wprep) {
+    constexpr int TZ = 4 * ZPW;                          // output z-planes per workgroup (shadows the file constant)
+    constexpr int PZ = S2 * (TZ - 1) + K7;               // 13 / 21 patch planes
+    constexpr int PPLANE = PZ * PYP * PROW;              // 8,736 / 14,112 bytes per bf16 plane
     __shared__ __attribute__((aligned(16))) unsigned char patchb[3 * PPLANE];
     __shared__ __attribute__((aligned(16))) unsigned char wl[NBUF][WSLAB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -262,31 +269,37 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void stem_fwd_bf3_kernel(St
     wstore(0);
     wload(1);
 
-    // lane base into a patch plane: output (ox, oy) = (l32 & 7, l32 >> 3) of z-plane `wave`, row + h
-    const int a_base = ((S2 * wave) * PYP + S2 * (l32 >> 3) + h) * PROW + 4 * (l32 & 7);
+    // lane base into a patch plane: output (ox, oy) = (l32 & 7, l32 >> 3) of z-plane ZPW * wave (+ zi), row + h
+    const int a_base = ((S2 * ZPW * wave) * PYP + S2 * (l32 >> 3) + h) * PROW + 4 * (l32 & 7);
+    constexpr int ZSTEP = S2 * PYP * PROW;               // patch bytes between two output z-planes
     const int b_base = (h * CO + l32) * 16;              // row ky = 2u + h, column l32 (+32 for the second tile)
 
-    f32x16 acc0, acc1;
+    f32x16 acc0[ZPW], acc1[ZPW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int zi = 0; zi < ZPW; ++zi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[zi][r] = 0.f; acc1[zi][r] = 0.f; }
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // smallest products first
 
     // fragments of k-step (kz, u) -> register set u & 1; the reads of step g+1 are issued before the MFMAs of step g
-    bf16x8 af[2][3], bf0[2][3], bf1[2][3];
+    bf16x8 af[2][ZPW][3], bf0[2][3], bf1[2][3];
     auto frags = [&](int kz, int u, auto SETc) {
         constexpr int SET = decltype(SETc)::value;
         const unsigned char* wb = wl[kz % NBUF] + b_base + u * (2 * CO * 16);
         const unsigned char* ab = patchb + a_base + (kz * PYP + 2 * u) * PROW;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-            const unsigned char* ap = ab + pl * PPLANE;
-            u32x4 v;
-            v.x = *reinterpret_cast<const unsigned*>(ap);
-            v.y = *reinterpret_cast<const unsigned*>(ap + 4);
-            v.z = *reinterpret_cast<const unsigned*>(ap + 8);
-            v.w = *reinterpret_cast<const unsigned*>(ap + 12) & 0x0000ffffu;     // kx = 7 is padding: exact zero
-            if (u == 3 && h) v = u32x4{0u, 0u, 0u, 0u};                           // ky = 7 is padding
-            af[SET][pl] = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+            for (int zi = 0; zi < ZPW; ++zi) {
+                const unsigned char* ap = ab + pl * PPLANE + zi * ZSTEP;
+                u32x4 v;
+                v.x = *reinterpret_cast<const unsigned*>(ap);
+                v.y = *reinterpret_cast<const unsigned*>(ap + 4);
+                v.z = *reinterpret_cast<const unsigned*>(ap + 8);
+                v.w = *reinterpret_cast<const unsigned*>(ap + 12) & 0x0000ffffu;     // kx = 7 is padding: exact zero
+                if (u == 3 && h) v = u32x4{0u, 0u, 0u, 0u};                           // ky = 7 is padding
+                af[SET][zi][pl] = __builtin_bit_cast(bf16x8, v);
+            }
             bf0[SET][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * WPL);
             bf1[SET][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * WPL + 32 * 16);
         }
@@ -294,10 +307,12 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void stem_fwd_bf3_kernel(St
     auto mfmas = [&](auto SETc) {
         constexpr int SET = decltype(SETc)::value;
 #pragma unroll
-        for (int pr = 0; pr < 6; ++pr) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SET][PA[pr]], bf0[SET][PB[pr]], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SET][PA[pr]], bf1[SET][PB[pr]], acc1, 0, 0, 0);
-        }
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int zi = 0; zi < ZPW; ++zi) {
+                acc0[zi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SET][zi][PA[pr]], bf0[SET][PB[pr]], acc0[zi], 0, 0, 0);
+                acc1[zi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SET][zi][PA[pr]], bf1[SET][PB[pr]], acc1[zi], 0, 0, 0);
+            }
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -340,27 +355,30 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void stem_fwd_bf3_kernel(St
     }
 
     // ---- epilogue: C/D layout col = lane & 31 (channel), row = (r&3) + 8*(r>>2) + 4*h (output voxel) ----
-    const int oz = oz0 + wave;
     float cs[2][2];                                      // [column tile][sum, sum of squares] of what is stored
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int co = j * 32 + l32;
         float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int ox = ox0 + (m & 7), oy = oy0 + (m >> 3);
-            const long o = ((((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * CO + co;
-            float v = j == 0 ? acc0[r] : acc1[r];
-            if (p.res) v += p.res[o];
-            if (p.relu) v = fmaxf(v, 0.f);
-            p.y[o] = v;
-            t0 += v; t1 = fmaf(v, v, t1);
+        for (int zi = 0; zi < ZPW; ++zi) {
+            const int oz = oz0 + ZPW * wave + zi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int ox = ox0 + (m & 7), oy = oy0 + (m >> 3);
+                const long o = ((((long)n * p.Do + oz) * p.Ho + oy) * p.Wo + ox) * CO + co;
+                float v = j == 0 ? acc0[zi][r] : acc1[zi][r];
+                if (p.res) v += p.res[o];
+                if (p.relu) v = fmaxf(v, 0.f);
+                p.y[o] = v;
+                t0 += v; t1 = fmaf(v, v, t1);
+            }
         }
         cs[j][0] = t0; cs[j][1] = t1;
     }
     // BatchNorm statistics of the following layer from the tile that is still in registers: the 128 voxels of the
-    // workgroup per channel (16 per lane in f32, then doubles in a fixed order), one partial per workgroup stored
+    // workgroup per channel (16 ZPW per lane in f32, then doubles in a fixed order), one partial per workgroup stored
     // [stat][channel][workgroup] so that the finalize reads a channel's partials as one contiguous run
     if (p.stats) {
         float* red = reinterpret_cast<float*>(patchb);   // (no LDS read is left behind the loop's last barrier)
@@ -800,11 +818,15 @@ int mi_stem7_fwd(const float* x, const float* w, float* y, const float* res, int
         hipLaunchKernelGGL(stem_wprep_kernel, dim3((K7 * 8 * CO * 8 + 255) / 256), dim3(256), 0, s, w, (unsigned short*)ws);
         MI_RETURN_IF_LAUNCH_FAILED();
         // one weight buffer / three workgroups per CU by default (captured step 1.632 against 1.646 ms, r03_experiments.txt item 23)
-        if (getenv("MI_STEM_FWD_NBUF2")) hipLaunchKernelGGL(stem_fwd_bf3_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, p, (const unsigned char*)ws);
-        else hipLaunchKernelGGL(stem_fwd_bf3_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, p, (const unsigned char*)ws);
+        // round 4: two z-planes per wave (tile 8 x 4 x 8) where the depth allows; MI_STEM_FWD_Z4=1 keeps the 8 x 4 x 4 tile
+        const bool z8 = Do % (2 * TZ) == 0 && !getenv("MI_STEM_FWD_Z4") && !getenv("MI_STEM_FWD_NBUF2");
+        const long nb = z8 ? blocks / 2 : blocks;
+        if (z8) hipLaunchKernelGGL((stem_fwd_bf3_kernel<1, 2>), dim3((unsigned)nb), dim3(256), 0, s, p, (const unsigned char*)ws);
+        else if (getenv("MI_STEM_FWD_NBUF2")) hipLaunchKernelGGL((stem_fwd_bf3_kernel<2, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p, (const unsigned char*)ws);
+        else hipLaunchKernelGGL((stem_fwd_bf3_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p, (const unsigned char*)ws);
         MI_RETURN_IF_LAUNCH_FAILED();
         if (sums) {
-            hipLaunchKernelGGL(stem_stats_finalize_kernel, dim3(2 * CO), dim3(256), 0, s, (const double*)p.stats, (int)blocks,
+            hipLaunchKernelGGL(stem_stats_finalize_kernel, dim3(2 * CO), dim3(256), 0, s, (const double*)p.stats, (int)nb,
                                sums);
             MI_RETURN_IF_LAUNCH_FAILED();
         }
