@@ -7,7 +7,7 @@ O=gpurun_out/$T"_final"
 cp $O/train/out_kernel_stats.csv profiles/${T}_train_kernel_stats.csv
 cp $O/infer/out_kernel_stats.csv profiles/${T}_infer_kernel_stats.csv
 python tools/pmc_summary.py $O/pmc_infer profiles/${T}_infer_traffic.json --sources infer_,common --per-step 5 \
-  --note "tools/prof_infer.py both 5: 5 fused decodes (logits 128x256x256, K=900) + 5 DoG picks (256x512x512, sigma 3/5); per-launch averages" > /dev/null
+  --note "tools/prof_infer.py both 3 (2 synchronized calls + 3 back to back of each chain): 5 fused decodes (logits 128x256x256, K=900) + 5 DoG picks (256x512x512, sigma 3/5); per-launch averages" > /dev/null
 mkdir -p $O/pmc_traffic $O/pmc_busy
 rm -rf $O/pmc_traffic/* $O/pmc_busy/*
 cp -r $O/pmc_train/FETCH_SIZE $O/pmc_train/WRITE_SIZE $O/pmc_traffic/
