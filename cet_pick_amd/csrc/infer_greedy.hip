@@ -771,7 +771,10 @@ __device__ __forceinline__ int decide(unsigned i, int4 r0, const unsigned long l
 // (states are read past the L1 - volatile - so decisions of other workgroups are seen as they land; a stale read only
 // defers a decision), compacts its picks with ONE returning atomic per workgroup, hands what is still open (a few dozen
 // candidates chip-wide) to a list, and the workgroup that finishes last resolves that list alone.
-constexpr int RA_T = 256, RA_PASSES = 16, RA_LBITS = 8, RA_LMAX = 1 << RA_LBITS, RA_REG = 11;   // RA_REG neighbour ids of a candidate live in registers
+// RA_LMAX: leftovers the last workgroup resolves inside LDS.  A few dozen in the steady state - but on the FIRST launch of the chain
+// in a process (workgroups start far apart, the early ones' passes run out) there are hundreds, and with a 256-entry table they
+// fell through to the global loop: 572 - 767 us once against 34 us with 2,048 entries (profiles/r04_experiments.txt item 15).
+constexpr int RA_T = 256, RA_PASSES = 16, RA_LBITS = 11, RA_LMAX = 1 << RA_LBITS, RA_REG = 11;   // RA_REG neighbour ids of a candidate live in registers
 
 // one pass over a candidate whose list (<= RA_REG entries) sits in registers: ONE round trip (the neighbours' states)
 __device__ __forceinline__ int decide_reg(const int (&ids)[RA_REG], int cnt, const volatile unsigned char* state) {
