@@ -541,21 +541,21 @@ def main():
                                      for t, v in sorted(by.items())},
                          "measured": "per conv call of 3 eager steps after the timed region: 8 back-to-back launches of the "
                                      "call (kernel + its split-K reduce) between two HIP events on the launch stream; "
-                                     "compare profiles/r03_train_kernel_stats.csv"},
+                                     "compare profiles/r04_train_kernel_stats.csv"},
         }
         # HBM traffic of the conv kernels from PMC counters (tools/pmc_run.sh + tools/pmc_summary.py: separate rocprofv3
         # --pmc passes of this workload; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), per conv call.
         # The summary carries the hash of the kernel sources it was measured on: a stale one is not quoted.
-        tpath = os.path.join(REPO, "profiles", "r03_conv_traffic.json")
+        tpath = os.path.join(REPO, "profiles", "r04_conv_traffic.json")
         if os.path.exists(tpath):
             from cet_pick_amd.build import source_sha16
             tj = json.load(open(tpath))
             if tj.get("source_sha16") == source_sha16(tj.get("source_prefixes")):
                 out["roofline"]["traffic"] = tj["hbm_bytes_per_step"] / (n_launch // 3)
-                out["roofline"]["traffic_note"] = ("bytes per conv call (%d per step), profiles/r03_conv_traffic.json"
+                out["roofline"]["traffic_note"] = ("bytes per conv call (%d per step), profiles/r04_conv_traffic.json"
                                                    % (n_launch // 3))
             else:
-                out["roofline"]["traffic_note"] = "stale: profiles/r03_conv_traffic.json was measured on other kernel sources"
+                out["roofline"]["traffic_note"] = "stale: profiles/r04_conv_traffic.json was measured on other kernel sources"
         if f32_ms is not None:
             out["f32_mfma_step"] = {"ms_per_step": f32_ms, "value": B / (f32_ms * 1e-3),
                                     "note": "the same step with MI_CONV_ARITH=f32 (v_mfma_f32_32x32x2_f32 in the generic kernel)"}
