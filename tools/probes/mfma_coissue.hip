@@ -9,10 +9,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
+// (loads: the value read by slot t is consumed - xor-ed into a register - by the slot that reuses its register, PER slots later at
+// 4/MFMA and four MFMAs later at 1/MFMA: every load is live, none waits for its own data)
 // KIND 0: nothing; 1: v_fma_f32; 2: v_and_b32 (independent); 3: v_perm_b32; 4: ds_read_b128; 5: ds_read_b64_tr_b16;
 // 6: ds_write_b128; 7: buffer_load_b128 (L2-resident); 8: s_add (scalar); 9: v_cndmask; 10: ds_read_b64
 // 11: v_sub_f32; 12: v_mul_f32; 13: v_add_u32; 14: v_lshlrev_b32; 15: v_alignbit_b32; 16: v_pk_add_f32 (2 floats); 17: v_xor_b32;
-// 18: v_cvt_pk_bf16_f32; 19: v_ffbh_u32; 20: v_mov_b32; 21: v_and_or_b32
+// 18: v_cvt_pk_bf16_f32; 19: v_ffbh_u32; 20: v_mov_b32; 21: v_and_or_b32; 22: ds_read_b32
 template <int KIND, int PER>
 __global__ __launch_bounds__(256, 2) void probe(float* out, const float* src, int iters) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[32768];
@@ -28,8 +30,8 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, const float* src, in
     u32x4 q[4] = {ua, ub, ua, ub};
     int sacc = 0;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 1 << 20, 0x00020000);
-    const int laddr = (tid * 16) & 16383;
     for (int it = 0; it < iters; ++it) {
+        const int laddr = (tid * 16 + it * 1024) & 16383;       // (iteration-dependent: the reads cannot be hoisted)
 #pragma unroll
         for (int t = 0; t < 12; ++t) {
             acc[t % 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t % 3], 0, 0, 0);
@@ -39,10 +41,11 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, const float* src, in
                 if (KIND == 1) v[j] = v[j] * 1.0001f + 0.5f;
                 if (KIND == 2) w[j] = w[j] & (0xffff0000u | it);
                 if (KIND == 3) w[j] = __builtin_amdgcn_perm(w[j], w[(j + 1) & 3], 0x07060302u);
-                if (KIND == 4) q[j] = *reinterpret_cast<const u32x4*>(lds + ((laddr + 1024 * (t & 7)) & 16383));
-                if (KIND == 5) { bf16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + ((laddr + 1024 * (t & 7)) & 16383))); q[j][0] = __builtin_bit_cast(unsigned long long, r) & 0xffffffffu; q[j][1] = __builtin_bit_cast(unsigned long long, r) >> 32; }
+                if (KIND == 4) { w[j] ^= q[j][0] ^ q[j][3]; q[j] = *reinterpret_cast<const u32x4*>(lds + ((laddr + 1024 * (t & 7)) & 16383)); }
+                if (KIND == 5) { w[j] ^= q[j][0] ^ q[j][1]; bf16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + ((laddr + 1024 * (t & 7)) & 16383))); q[j][0] = __builtin_bit_cast(unsigned long long, r) & 0xffffffffu; q[j][1] = __builtin_bit_cast(unsigned long long, r) >> 32; }
                 if (KIND == 6) *reinterpret_cast<u32x4*>(lds + 16384 + ((laddr + 1024 * (t & 7)) & 16383)) = q[j];
-                if (KIND == 7) q[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid * 16 + 4096 * (t & 7)) & 0xfffff, 0, 0);
+                if (KIND == 7) w[j] ^= q[j][0] ^ q[j][3];
+                if (KIND == 7) q[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid * 16 + 4096 * (t & 7) + it * 65536) & 0xfffff, 0, 0);
                 if (KIND == 11) v[j] = v[j] - v[(j + 1) & 3];
                 if (KIND == 12) v[j] = v[j] * v[(j + 1) & 3];
                 if (KIND == 13) w[j] = w[j] + w[(j + 1) & 3];
@@ -54,9 +57,10 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, const float* src, in
                 if (KIND == 19) w[j] = __builtin_clz(w[(j + 1) & 3] | 1u) + w[j];
                 if (KIND == 20) asm volatile("v_mov_b32 %0, %1" : "=v"(w[j]) : "v"(w[(j + 1) & 3]));
                 if (KIND == 21) w[j] = (w[j] & 0xffff0000u) | w[(j + 1) & 3];
+                if (KIND == 22) { w[j] ^= q[j][0]; q[j][0] = *reinterpret_cast<const unsigned*>(lds + ((tid * 4 + it * 256 + 1024 * (t & 7)) & 16383)); }
                 if (KIND == 8) sacc = __builtin_amdgcn_readfirstlane(sacc) + it;
                 if (KIND == 9) w[j] = (lane & (1 << k)) ? w[j] : w[(j + 1) & 3];
-                if (KIND == 10) { unsigned long long r = *reinterpret_cast<const unsigned long long*>(lds + ((tid * 8 + 1024 * (t & 7)) & 16383)); q[j][0] = (unsigned)r; q[j][1] = (unsigned)(r >> 32); }
+                if (KIND == 10) { w[j] ^= q[j][0] ^ q[j][1]; unsigned long long r = *reinterpret_cast<const unsigned long long*>(lds + ((tid * 8 + it * 512 + 1024 * (t & 7)) & 16383)); q[j][0] = (unsigned)r; q[j][1] = (unsigned)(r >> 32); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -106,6 +110,7 @@ int main() {
     row<2>("v_and_b32", base1, base2);
     row<3>("v_perm_b32", base1, base2);
     row<9>("v_cndmask_b32", base1, base2);
+    row<22>("ds_read_b32", base1, base2);
     row<4>("ds_read_b128", base1, base2);
     row<10>("ds_read_b64", base1, base2);
     row<5>("ds_read_b64_tr_b16", base1, base2);
