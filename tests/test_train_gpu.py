@@ -796,6 +796,44 @@ def test_linear_bn_one_launch_matches_two_launches_and_torch(m, ci, co, relu, bi
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,c", [(64, 256), (5, 256), (70, 128)])
+def test_cube2_final_launch_equals_partial_sums_plus_reduce(n, c, monkeypatch):
+    """mi_conv3d_cube2_f32 (layer3 / feature_3d: the last of a tile's four reduction-quarter workgroups sums them in slab order and
+    applies the epilogue) against the same kernel with partial sums + reduce launch (MI_CUBE2_REDUCE=1): forward with residual +
+    ReLU and data gradient with residual + mask BIT FOR BIT - the sum must not depend on who arrives last -, on two streams at
+    once (one workspace per stream), and the arrival counters are zero again after every call (moco_encoder_3d.py:55-84,172,178)."""
+    from cet_pick_amd import hipops as H, _lib as L
+    g = torch.Generator().manual_seed(n + c)
+    x = cl(torch.randn(n, c, 2, 2, 2, generator=g))
+    res = cl(torch.randn(n, c, 2, 2, 2, generator=g))
+    mask = cl(torch.randn(n, c, 2, 2, 2, generator=g))
+    dy = cl(torch.randn(n, c, 2, 2, 2, generator=g))
+    param, _ = make_w(c, c, 3, g)
+    monkeypatch.setenv("MI_CUBE2_REDUCE", "1")
+    yf0 = H.conv_fwd(x, param, 3, 1, 1, res, True)
+    yd0 = H.conv_dgrad(dy, param, (n, 2, 2, 2, c), 3, 1, 1, res, mask)
+    assert L.lib().mi_debug_last_conv_kernel().decode() == "cube2 + reduce"
+    monkeypatch.delenv("MI_CUBE2_REDUCE")
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    outs = []
+    for rep in range(3):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            yd1 = H.conv_dgrad(dy, param, (n, 2, 2, 2, c), 3, 1, 1, res, mask)
+        yf1 = H.conv_fwd(x, param, 3, 1, 1, res, True)
+        outs.append((yf1, yd1))
+    assert L.lib().mi_debug_last_conv_kernel().decode() == "cube2"
+    torch.cuda.synchronize()
+    for yf1, yd1 in outs:
+        assert torch.equal(yf1, yf0) and torch.equal(yd1, yd0)
+    tickets = [v for k, v in L._workspaces.items() if k[1] == "cube2"]
+    assert len(tickets) >= 2                                  # one workspace per stream
+    for ws in tickets:
+        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.gpu
 def test_conv_dispatch_by_shape(monkeypatch):
     """Which kernel family a convolution call takes (mi_debug_last_conv_kernel; tools/bench_conv.py --kernels prints the table):
     the encoder's shapes at the benchmark's crop size take the patch-resident kernels, other shapes the implicit GEMM, and the
