@@ -100,9 +100,13 @@ __device__ __forceinline__ void cut8(const float (&v)[8], u32x4 (&o)[3]) {
 // TWO: only two channel chunks of the patch are resident (a ring of two slots: 59 KB), the residual / mask operands of the
 // epilogue are fetched IN the epilogue instead of during the last chunk (64 registers less), so that two workgroups share a CU
 // (256 registers each) and one's prologue / epilogue runs under the other's MFMA loop.
-template <bool TWO>
+// CT: channels, in = out: 64 (layer1 at 32^3 crops) or - round 4 - 128 (layer2 at 64^3 crops: the same 8 x 8 planes, eight
+// 16-channel chunks of the patch through the ring, a workgroup per 64-channel block of the output: blockIdx.y).
+template <bool TWO, int CT = C>
 __global__ __launch_bounds__(256, TWO ? 2 : 1) void direct3_kernel(Direct3Params p) {
+    constexpr int KS = CT / 16, NSTEP = KS * NTAP;       // (shadow the 64-channel file constants)
     constexpr int NSLOT = TWO ? 2 : KS;
+    static_assert(NSTEP % RB == 0, "ring slots");
     __shared__ __attribute__((aligned(16))) unsigned char patch[NSLOT * KS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l32 = lane & 31;
@@ -110,15 +114,17 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void direct3_kernel(Direct3Params
     const int zb = blockIdx.x % (p.D / TZ), n = blockIdx.x / (p.D / TZ);
     const int z0 = zb * TZ;
 
-    const __amdgpu_buffer_rsrc_t wrs = rsrc_of(p.wimg, WIMG_BYTES);
+    const int cb = blockIdx.y;                           // 64-channel block of the output channels
+    const __amdgpu_buffer_rsrc_t wrs = rsrc_of(p.wimg, (CT / 64) * NSTEP * WSTEP);
     const int w_voff = cw * (3 * WBLK) + lane * 16;
+    const int w_cb = cb * (NSTEP * WSTEP);
     // weight fragments of k-step g (0..107; behind the image: zeros) -> ring slot g % RB
     bf16x8 bfr[RB][3];
     auto wload = [&](int g, auto SLOTc) {
         constexpr int SLOT = decltype(SLOTc)::value;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-            bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, w_voff + pl * WBLK, g * WSTEP, 0));
+            bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, g < NSTEP ? w_voff + pl * WBLK : (int)0x80000000u, g < NSTEP ? w_cb + g * WSTEP : 0, 0));
     };
     auto wload_dyn = [&](int g) {                        // (g is a constant after unrolling)
         switch (g % RB) {
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void direct3_kernel(Direct3Params
         const int q = tid + 256 * u, vox = q >> 1, hh = q & 1;
         const int z = z0 - 1 + (vox >> 6);
         const bool ok = (unsigned)z < (unsigned)p.D;      // planes outside the volume: zeros (offset out of range)
-        st_off[u] = ok ? 4u * (unsigned)((((long)n * p.D + z) * PLANE + (vox & 63)) * C + hh * 8) : 0x80000000u;
+        st_off[u] = ok ? 4u * (unsigned)((((long)n * p.D + z) * PLANE + (vox & 63)) * CT + hh * 8) : 0x80000000u;
         st_lds[u] = hh * ARR + (LEAD + vox) * 16;
     }
     u32x4 ld[2][2];
@@ -203,13 +209,13 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void direct3_kernel(Direct3Params
 
     // epilogue operands (residual, mask), fetched during the last chunk; a null pointer reads zeros (empty descriptor)
     const long m0 = ((long)n * p.D + z0 + tz) * PLANE;
-    const int col = cw * 32 + l32;
+    const int col = cb * 64 + cw * 32 + l32;
     unsigned eoff[2][16];
     float rv[2][16], mv[2][16];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) eoff[i][r] = 4u * (unsigned)((m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * C + col);
+        for (int r = 0; r < 16; ++r) eoff[i][r] = 4u * (unsigned)((m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * CT + col);
     const __amdgpu_buffer_rsrc_t rrs = rsrc_of(p.res, p.res ? p.a_bytes : 0u), mrs = rsrc_of(p.mask, p.mask ? p.a_bytes : 0u);
 
     stage_store(0);
@@ -303,13 +309,13 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void direct3_kernel(Direct3Params
             float rr[16], mm[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const unsigned eo = 4u * (unsigned)((m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * C + col);
+                const unsigned eo = 4u * (unsigned)((m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * CT + col);
                 rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, (int)eo, 0, 0));
                 mm[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mrs, (int)eo, 0, 0));
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const unsigned eo = 4u * (unsigned)((m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * C + col);
+                const unsigned eo = 4u * (unsigned)((m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * CT + col);
                 float v = acc[i][r] + rr[r];
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (has_mask) v = (mm[r] > 0.f) ? v : 0.f;
@@ -335,39 +341,41 @@ struct PrepBatch {
     const float* w[PREP_MAX];
     unsigned char* img[PREP_MAX];
     int dgrad[PREP_MAX];
-    int wide[PREP_MAX];       // 0: 64-channel image (this kernel's), 1: 128-channel image (direct3s_prep_body)
+    int wide[PREP_MAX];       // image format: 0 = kind 1, 1 = kind 2, 2 = kind 3 (direct3_prep_kernel)
 };
 __device__ void direct3s_prep_body(const float* w, unsigned char* img, int dgrad, int idx);
 constexpr int PREP_BLOCKS = NTAP * KS * 2 * 64 / 256;                     // 54
-constexpr int PREP_BLOCKS_WIDE = 4 * NTAP * 2 * 4 * 64 / 256;             // 216
-// one launch cuts every image of a batch, both formats: blockIdx.y = image, blockIdx.x = its blocks (the narrow format
-// uses the first 54 of them)
-__global__ __launch_bounds__(256) void direct3_prep_kernel(PrepBatch b) {
-    if (b.wide[blockIdx.y]) {
-        direct3s_prep_body(b.w[blockIdx.y], b.img[blockIdx.y], b.dgrad[blockIdx.y], blockIdx.x * 256 + threadIdx.x);
-        return;
-    }
-    if (blockIdx.x >= PREP_BLOCKS) return;
-    const float* w = b.w[blockIdx.y];
-    unsigned char* img = b.img[blockIdx.y];
-    const int dgrad = b.dgrad[blockIdx.y];
-    const int idx = blockIdx.x * 256 + threadIdx.x;          // (tap, ks, cw, lane); 27 * 4 * 2 * 64 = 54 * 256
-    const int lane = idx & 63, cw = (idx >> 6) & 1, ks = (idx >> 7) & 3, tap = idx >> 9;      // image order: [ks][tap]
-    const int nn = cw * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+constexpr int PREP_BLOCKS_WIDE = 4 * NTAP * 2 * 4 * 64 / 256;             // 216 (both 128-channel formats)
+// image of direct3_kernel<., CT>: [output block of 64][channel chunk][tap][column half][plane][lane] x 16 bytes;
+// idx = (cb, tap, ks, cw, lane): (CT / 64) * 27 * (CT / 16) * 2 * 64 entries
+template <int CT>
+__device__ void direct3_prep_body(const float* w, unsigned char* img, int dgrad, int idx) {
+    constexpr int KSn = CT / 16;
+    const int lane = idx & 63, cw = (idx >> 6) & 1, rest = idx >> 7, ks = rest % KSn, tap = (rest / KSn) % NTAP, cb = rest / (KSn * NTAP);
+    if (cb >= CT / 64) return;
+    const int nn = cb * 64 + cw * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
     float v[8];
     if (dgrad) {        // B'[tap][k = co][n = ci] = W[26 - tap][ci = n][co = k]
-        const float* src = w + ((long)(NTAP - 1 - tap) * C + nn) * C + k0;
+        const float* src = w + ((long)(NTAP - 1 - tap) * CT + nn) * CT + k0;
         const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
     } else {            // B[tap][k = ci][n = co] = W[tap][ci = k][co = n]
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = w[((long)tap * C + k0 + e) * C + nn];
+        for (int e = 0; e < 8; ++e) v[e] = w[((long)tap * CT + k0 + e) * CT + nn];
     }
     u32x4 o[3];
     cut8(v, o);
-    unsigned char* dst = img + (long)((ks * NTAP + tap) * 2 + cw) * (3 * WBLK) + lane * 16;
+    unsigned char* dst = img + (long)(((cb * KSn + ks) * NTAP + tap) * 2 + cw) * (3 * WBLK) + lane * 16;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * WBLK) = o[pl];
+}
+// one launch cuts every image of a batch, all formats: blockIdx.y = image, blockIdx.x = its blocks (the 64-channel format
+// uses the first 54 of them).  wide: 0 = direct3_kernel 64 channels, 1 = direct3s_kernel 128, 2 = direct3_kernel 128
+__global__ __launch_bounds__(256) void direct3_prep_kernel(PrepBatch b) {
+    const int fmt = b.wide[blockIdx.y], idx = blockIdx.x * 256 + threadIdx.x;
+    if (fmt == 1) direct3s_prep_body(b.w[blockIdx.y], b.img[blockIdx.y], b.dgrad[blockIdx.y], idx);
+    else if (fmt == 2) direct3_prep_body<128>(b.w[blockIdx.y], b.img[blockIdx.y], b.dgrad[blockIdx.y], idx);
+    else if (blockIdx.x < PREP_BLOCKS) direct3_prep_body<C>(b.w[blockIdx.y], b.img[blockIdx.y], b.dgrad[blockIdx.y], idx);
 }
 
 
@@ -854,7 +862,9 @@ __device__ void direct3s_prep_body(const float* w, unsigned char* img, int dgrad
 }  // namespace
 
 // ---- host side (internal: conv_igemm.hip's run_conv dispatches here; extern "C" wrappers at the end) ----
-// 0: not a direct shape; 1: 64 -> 64 channels on 8 x 8 planes (direct3_kernel); 2: 128 -> 128 on 4 x 4 x 4 (direct3s_kernel)
+// 0: not a direct shape; 1: 64 -> 64 channels on 8 x 8 planes (direct3_kernel); 2: 128 -> 128 on 4 x 4 x 4 (direct3s_kernel);
+// 3 (round 4): 128 -> 128 on 8 x 8 planes (direct3_kernel<., 128>: layer2 of a 64^3 crop) - reached through mi_conv3d_* /
+// mi_convnd_* only (image cut per call), not through the caller-kept images of mi_conv3d_direct_*
 int mi_direct3_kind(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph,
                     int pw, int dd, int dh, int dw) {
     const char* off = getenv("MI_CONV_NO_DIRECT");      // A/B switch: keep the implicit GEMM
@@ -863,6 +873,9 @@ int mi_direct3_kind(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int k
     if (N < 1 || 4l * N * Di * Hi * Wi * Ci >= 0x7fff0000l) return 0;
     if (Ci == C && Co == C && Hi == 8 && Wi == 8 && Di >= TZ && Di % TZ == 0) return 1;
     if (Ci == CS && Co == CS && Di == 4 && Hi == 4 && Wi == 4) return 2;
+    // (from 128 workgroups on: 64 of them - batch 8 of 64^3 crops - take 47.6 us where the implicit GEMM takes 39.5; batch 16: 51 against
+    // 62 us, batch 32: 71 against 105 us = 204 TFLOP/s, image cut included)
+    if (Ci == 128 && Co == 128 && Hi == 8 && Wi == 8 && Di >= TZ && Di % TZ == 0 && (long)N * Di >= 128 && (long)N * (Di / TZ) <= 0x7fffffffl) return 3;
     return 0;
 }
 bool mi_direct3_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph,
@@ -873,26 +886,39 @@ bool mi_direct3_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, in
 size_t mi_direct3_wimg_bytes(int channels) {
     return channels == C ? (size_t)WIMG_BYTES : channels == CS ? (size_t)S_WIMG_BYTES : 0;
 }
+size_t mi_direct3_wimg_bytes_kind(int kind) {
+    return kind == 1 ? (size_t)WIMG_BYTES : kind == 2 ? (size_t)S_WIMG_BYTES : kind == 3 ? (size_t)(2 * 8 * NTAP * WSTEP) : 0;
+}
 // (rounds 2-3: split-K slabs of the 128-channel kernel; since round 4 both direct kernels are final in one launch)
 size_t mi_direct3_slab_bytes(int, int) { return 0; }
 
-// channels[i] = 64 or 128 selects the image format of weight i
-int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, const int* channels, int n, hipStream_t s) {
+// kinds[i] = 1 / 2 / 3 (mi_direct3_kind) selects the image format of weight i
+int mi_direct3_prep_kind(const float* const* w, void* const* img, const int* dgrad, const int* kinds, int n, hipStream_t s) {
     for (int i0 = 0; i0 < n; i0 += PREP_MAX) {
         PrepBatch b = {};
         const int m = n - i0 < PREP_MAX ? n - i0 : PREP_MAX;
         bool any_wide = false;
         for (int i = 0; i < m; ++i) {
-            const int ch = channels[i0 + i];
-            if ((ch != C && ch != CS) || !w[i0 + i] || !img[i0 + i]) return MI_E_ARG;
+            const int kd = kinds[i0 + i];
+            if (kd < 1 || kd > 3 || !w[i0 + i] || !img[i0 + i]) return MI_E_ARG;
             b.w[i] = w[i0 + i]; b.img[i] = (unsigned char*)img[i0 + i]; b.dgrad[i] = dgrad[i0 + i];
-            b.wide[i] = ch == CS;
-            any_wide |= ch == CS;
+            b.wide[i] = kd - 1;
+            any_wide |= kd != 1;
         }
         hipLaunchKernelGGL(direct3_prep_kernel, dim3(any_wide ? PREP_BLOCKS_WIDE : PREP_BLOCKS, m), dim3(256), 0, s, b);
         MI_RETURN_IF_LAUNCH_FAILED();
     }
     return MI_OK;
+}
+// channels[i] = 64 or 128 selects the image format of weight i (kinds 1 / 2: the formats of the caller-kept images)
+int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, const int* channels, int n, hipStream_t s) {
+    if (n > 4096) return MI_E_ARG;
+    int kinds[4096];
+    for (int i = 0; i < n; ++i) {
+        if (channels[i] != C && channels[i] != CS) return MI_E_ARG;
+        kinds[i] = channels[i] == C ? 1 : 2;
+    }
+    return mi_direct3_prep_kind(w, img, dgrad, kinds, n, s);
 }
 
 // `a` = X (forward) / dY (data gradient); wimg from mi_direct3_prep with the matching `dgrad` flag
@@ -903,6 +929,14 @@ int mi_direct3_launch(const float* a, const void* wimg, float* out, const float*
     // MI_DIRECT3_FOUR_SLOTS=1: the whole patch resident, one workgroup per CU
     if (getenv("MI_DIRECT3_FOUR_SLOTS")) hipLaunchKernelGGL(direct3_kernel<false>, dim3((unsigned)(N * (D / TZ))), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(direct3_kernel<true>, dim3((unsigned)(N * (D / TZ))), dim3(256), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+// 128 channels on 8 x 8 planes (kind 3): the same kernel, eight chunks, two 64-channel output blocks (blockIdx.y)
+int mi_direct3_launch128(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
+                         int D, hipStream_t s) {
+    Direct3Params p = {a, (const unsigned char*)wimg, out, res, mask, relu, N, D, (unsigned)(4l * N * D * PLANE * 128)};
+    hipLaunchKernelGGL((direct3_kernel<true, 128>), dim3((unsigned)(N * (D / TZ)), 2), dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -935,7 +969,8 @@ extern "C" size_t mi_conv3d_direct_wimg_bytes(int channels) { return mi_direct3_
 extern "C" size_t mi_conv3d_direct_workspace_bytes(int N, int channels) { return mi_direct3_slab_bytes(N, channels); }
 
 extern "C" int mi_conv3d_direct_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
-    return mi_direct3_kind(N, Di, Hi, Wi, Ci, Co, k, k, k, stride, pad, pad, pad, 1, 1, 1);
+    const int kind = mi_direct3_kind(N, Di, Hi, Wi, Ci, Co, k, k, k, stride, pad, pad, pad, 1, 1, 1);
+    return kind <= 2 ? kind : 0;           // (kind 3 cuts its image per call inside mi_conv3d_* / mi_convnd_*)
 }
 
 extern "C" int mi_conv3d_direct_prep(const void* const* w, void* const* img, const int* dgrad, const int* channels, int n,

@@ -54,6 +54,10 @@ size_t mi_direct3_slab_bytes(int N, int channels);
 int mi_direct3_prep(const float* const* w, void* const* img, const int* dgrad, const int* channels, int n, hipStream_t s);
 int mi_direct3_launch(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
                       int D, hipStream_t s);
+size_t mi_direct3_wimg_bytes_kind(int kind);
+int mi_direct3_prep_kind(const float* const* w, void* const* img, const int* dgrad, const int* kinds, int n, hipStream_t s);
+int mi_direct3_launch128(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
+                         int D, hipStream_t s);
 int mi_direct3s_launch(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
                        hipStream_t s);
 int mi_direct3_finish_slabs(const float* slabs, int n_slabs, long out_elems, float* out, const float* res, const float* mask,
@@ -1149,7 +1153,7 @@ size_t direct3_ws_bytes(const Geom& g) {
     if (is_cube2(g)) return mi_cube2_slab_bytes(g.N, g.Ci);
     const int kind = direct3_kind(g);
     if (!kind) return 0;
-    size_t b = mi_align_up(mi_direct3_wimg_bytes(g.Ci), 256) + mi_direct3_slab_bytes(g.N, g.Ci);
+    size_t b = mi_align_up(mi_direct3_wimg_bytes_kind(kind), 256);
     if (kind == 1) b = std::max(b, mi_direct3_wgrad_slab_bytes());
     return b;
 }
@@ -1204,16 +1208,17 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
             return mi_small_gemm_launch(a_src, 1, g.Ci, xe, b_src, g.Co, 1, ye, nullptr, out, g.Ci, g.Co, g.N, s);
     }
     const int dkind = conv_arith_bf16x3() ? direct3_kind(g) : 0;
-    const size_t dimg = mi_align_up(mi_direct3_wimg_bytes(g.Ci), 256);
-    if (mode != MODE_WGRAD && dkind && ws && ws_bytes >= dimg + mi_direct3_slab_bytes(g.N, g.Ci)) {
+    const size_t dimg = mi_align_up(mi_direct3_wimg_bytes_kind(dkind), 256);
+    if (mode != MODE_WGRAD && dkind && ws && ws_bytes >= dimg) {
         const float* wl[1] = {b_src};
         void* il[1] = {ws};
-        const int dg[1] = {mode == MODE_DGRAD ? 1 : 0}, ch[1] = {g.Ci};
-        int rc = mi_direct3_prep(wl, il, dg, ch, 1, s);
+        const int dg[1] = {mode == MODE_DGRAD ? 1 : 0}, kd[1] = {dkind};
+        int rc = mi_direct3_prep_kind(wl, il, dg, kd, 1, s);
         if (rc) return rc;
-        g_last_conv_kernel = dkind == 1 ? "direct3" : "direct3s";
+        g_last_conv_kernel = dkind == 1 ? "direct3" : dkind == 2 ? "direct3s" : "direct3 (128 channels)";
         if (dkind == 1) return mi_direct3_launch(a_src, ws, out, res, mask, relu, g.N, g.Di, s);
-        return mi_direct3s_launch(a_src, ws, out, res, mask, relu, g.N, s);       // 128-channel kernel: final as well
+        if (dkind == 3) return mi_direct3_launch128(a_src, ws, out, res, mask, relu, g.N, g.Di, s);
+        return mi_direct3s_launch(a_src, ws, out, res, mask, relu, g.N, s);       // 128-channel kernel on 4^3: final as well
     }
     if (mode != MODE_WGRAD && conv_arith_bf16x3() && is_cube2(g) && ws && ws_bytes >= mi_cube2_slab_bytes(g.N, g.Ci)) {
         g_last_conv_kernel = "cube2 + reduce";

@@ -117,7 +117,8 @@ def test_conv_bf16x3_is_f32_equivalent(case, monkeypatch):
 
 @pytest.mark.parametrize("n,d,hw,c", [(3, 8, 8, 64), (5, 2, 8, 64), (2, 6, 8, 64), (64, 8, 8, 64),
                                       (5, 4, 4, 128), (2, 4, 4, 128), (64, 4, 4, 128),
-                                      (64, 2, 2, 256), (5, 2, 2, 256), (70, 2, 2, 128)])
+                                      (64, 2, 2, 256), (5, 2, 2, 256), (70, 2, 2, 128),
+                                      (16, 8, 8, 128), (66, 2, 8, 128), (17, 8, 8, 128)])
 def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
     """layer1- (3^3, stride 1, 64 -> 64, 8 x 8 planes) and layer2-shaped (128 -> 128, 4 x 4 x 4; odd batch: a half-empty
     sample pair) convolutions take the patch-resident direct kernels (conv_direct3.hip), 2 x 2 x 2 volumes (layer3,
@@ -151,7 +152,8 @@ def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
     for i in range(3):
         f32_equivalent(out["direct"][i].numpy(), cpu32[i].numpy(), ref64[i].numpy(), what="direct3 %s" % ("fwd", "dgrad", "wgrad")[i])
         scale = float(ref64[i].abs().max())
-        assert float((out["direct"][i] - out["igemm"][i]).abs().max()) / scale < 2e-6
+        # two fp32 evaluations in different summation orders over K = 27 c terms: the bound of the 64-channel cases, scaled by sqrt(K)
+        assert float((out["direct"][i] - out["igemm"][i]).abs().max()) / scale < 2e-6 * (c / 64.0) ** 0.5
 
 
 @pytest.mark.parametrize("n,gi,ci,co,with_ds", [(3, 8, 64, 128, True), (64, 8, 64, 128, True), (2, 8, 64, 128, False),
@@ -851,6 +853,8 @@ def test_conv_dispatch_by_shape(monkeypatch):
     assert fwd(4, 4, 128, 128).startswith("direct3s")
     assert fwd(4, 2, 256, 256).startswith("cube2")
     assert fwd(2, 16, 64, 64).startswith("implicit GEMM")          # layer1 of a 64^3 crop
+    assert fwd(16, 8, 128, 128) == "direct3 (128 channels)"        # layer2 of a 64^3 crop (round 4), from 128 workgroups on
+    assert fwd(2, 8, 128, 128).startswith("implicit GEMM")
     monkeypatch.setenv("MI_CONV_NO_DIRECT", "1")
     assert fwd(4, 8, 64, 64).startswith("implicit GEMM")
 
