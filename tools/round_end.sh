@@ -11,7 +11,7 @@ tools/refresh_profiles.sh $T
   echo "(us per call, hipGraph replay of 4 calls; direct3 / direct3s / s2 rows include the eager path's weight-image launch, which the engine"
   echo "does once per step instead)."
   echo
-  for c in "32 64" "64 8" "48 16"; do timeout -k 10 200 python tools/bench_conv.py --kernels $c 2>/dev/null; echo; done ) > $O/kernels_by_crop.txt
+  for c in "32 64" "64 32" "64 8" "48 16"; do timeout -k 10 200 python tools/bench_conv.py --kernels $c 2>/dev/null; echo; done ) > $O/kernels_by_crop.txt
 timeout -k 10 400 python tools/bench_detector.py > $O/detector.json 2> $O/detector.err
 timeout -k 10 200 python tools/stamp_step.py 64 50 > $O/stamp_plain.txt 2>&1
 timeout -k 10 200 python tools/stamp_step.py 64 50 --dist > $O/stamp_dist.txt 2>&1
