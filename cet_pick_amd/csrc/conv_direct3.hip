@@ -335,6 +335,197 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void direct3_kernel(Direct3Params
         }
 }
 
+// ---- the same convolution on planes LARGER than 8 x 8 (round 4: layer1 of 64^3 crops, 64 -> 64 channels on 16 x 16 x 16) ---------
+// A workgroup owns an 8 x 8 (y, x) tile of two z-planes; its patch is the tile with a REAL halo - 4 planes x 10 x 10 voxels, one
+// record per voxel at pitch 10, voxels outside the volume zero-filled while the patch is staged - so a tap is a plain record
+// offset (dz 100 + dy 10 + dx): no zero records, no address select.  Everything else is direct3_kernel<true>: two resident
+// 16-channel chunks (77 KB of LDS, two workgroups per CU), weight fragments streamed from the SAME pre-cut image (format of
+// kind 1), 6 ds_read_b128 + 3 buffer loads + 12 MFMAs per k-step and wave.  (Pitch 10: the 16 lanes of a ds_read_b128 group
+// cover records r .. r + 7 and r + 10 .. r + 17 - two of the sixteen 16-byte slots are hit twice; every other pitch >= 10 is worse.)
+constexpr int HP = 10;                      // patch pitch: 8 + 2 halo voxels
+constexpr int H_NV = PZ * HP * HP;          // 400 patch voxels
+constexpr int H_ARR = H_NV * 16;            // bytes of one (chunk, plane, k-half) array
+constexpr int H_PL = 2 * H_ARR;
+constexpr int H_KS = 3 * H_PL;              // one chunk: 38,400 bytes
+constexpr int H_UNITS = (2 * H_NV + 255) / 256;      // staging units (voxel, k-half) per thread and chunk: 4
+
+struct Direct3hParams {
+    const float* a;           // X (forward) or dY (data gradient): (N, D, H, W, 64)
+    const unsigned char* wimg;
+    float* out;
+    const float* res;
+    const float* mask;
+    int relu;
+    int N, D, H, W;
+    unsigned a_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void direct3h_kernel(Direct3hParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char patch[2 * H_KS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    const int tz = wave >> 1, cw = wave & 1;             // wave tile: z-plane tz of the pair x column half cw
+    const int txn = p.W / 8, tyn = p.H / 8;
+    int bi = blockIdx.x;
+    const int bx = bi % txn; bi /= txn;
+    const int by = bi % tyn; bi /= tyn;
+    const int zb = bi % (p.D / TZ), n = bi / (p.D / TZ);
+    const int z0 = zb * TZ, y0 = by * 8, x0 = bx * 8;
+
+    const __amdgpu_buffer_rsrc_t wrs = rsrc_of(p.wimg, WIMG_BYTES);
+    const int w_voff = cw * (3 * WBLK) + lane * 16;
+    bf16x8 bfr[RB][3];
+    auto wload = [&](int g, auto SLOTc) {
+        constexpr int SLOT = decltype(SLOTc)::value;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, g < NSTEP ? w_voff + pl * WBLK : (int)0x80000000u, g < NSTEP ? g * WSTEP : 0, 0));
+    };
+    auto wload_dyn = [&](int g) {
+        switch (g % RB) {
+            case 0: wload(g, std::integral_constant<int, 0>{}); break;
+            case 1: wload(g, std::integral_constant<int, 1>{}); break;
+            case 2: wload(g, std::integral_constant<int, 2>{}); break;
+            case 3: wload(g, std::integral_constant<int, 3>{}); break;
+            case 4: wload(g, std::integral_constant<int, 4>{}); break;
+            default: wload(g, std::integral_constant<int, 5>{}); break;
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < RB - 1; ++g) wload_dyn(g);
+
+    // ---- patch staging, one 16-channel chunk at a time: unit q = (patch voxel, k-half); voxels outside the volume read zeros ----
+    const __amdgpu_buffer_rsrc_t ars = rsrc_of(p.a, p.a_bytes);
+    unsigned st_off[H_UNITS];
+    int st_lds[H_UNITS];
+#pragma unroll
+    for (int u = 0; u < H_UNITS; ++u) {
+        const int q = tid + 256 * u, vox = q >> 1, hh = q & 1;
+        const int pz = vox / (HP * HP), py = (vox / HP) % HP, px = vox % HP;
+        const int z = z0 - 1 + pz, y = y0 - 1 + py, x = x0 - 1 + px;
+        const bool ok = q < 2 * H_NV && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        st_off[u] = ok ? 4u * (unsigned)(((((long)n * p.D + z) * p.H + y) * p.W + x) * C + hh * 8) : 0x80000000u;
+        st_lds[u] = q < 2 * H_NV ? hh * H_ARR + vox * 16 : -1;
+    }
+    u32x4 ld[H_UNITS][2];
+    auto stage_load = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < H_UNITS; ++u) {
+            ld[u][0] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(st_off[u] + 64u * c), 0, 0);
+            ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(st_off[u] + 64u * c + 16u), 0, 0);
+        }
+    };
+    auto stage_store = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < H_UNITS; ++u) {
+            if (st_lds[u] < 0) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ld[u][0][e]); v[4 + e] = __uint_as_float(ld[u][1][e]); }
+            u32x4 o[3];
+            cut8(v, o);
+            unsigned char* dst = patch + (c & 1) * H_KS + st_lds[u];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * H_PL) = o[pl];
+        }
+    };
+    stage_load(0);
+
+    // ---- per-lane geometry: row block i = tile rows 4 i .. 4 i + 3, MFMA row l32 = (y & 3, x); record of the (dz, dy, dx) = 0 corner ----
+    int vbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int y = 4 * i + (l32 >> 3), x = l32 & 7;
+        vbase[i] = ((tz * HP + y) * HP + x) * 16 + h * H_ARR;
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    const int col = cw * 32 + l32;
+    const __amdgpu_buffer_rsrc_t rrs = rsrc_of(p.res, p.res ? p.a_bytes : 0u), mrs = rsrc_of(p.mask, p.mask ? p.a_bytes : 0u);
+
+    stage_store(0);
+    stage_load(1);
+    __syncthreads();
+
+    bf16x8 af[2][2][3];
+    auto frags = [&](int c, int tap, auto SETc) {
+        constexpr int SET = decltype(SETc)::value;
+        const int imm = (((tap / 9) * HP + (tap / 3) % 3) * HP + tap % 3) * 16 + (c & 1) * H_KS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                af[SET][i][pl] = *reinterpret_cast<const bf16x8*>(patch + vbase[i] + imm + pl * H_PL);
+    };
+    auto frags_dyn = [&](int g, int c, int tap) {
+        if (g & 1) frags(c, tap, std::integral_constant<int, 1>{});
+        else frags(c, tap, std::integral_constant<int, 0>{});
+    };
+
+    frags_dyn(0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < KS; ++c) {
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int g = c * NTAP + tap;
+            wload_dyn(g + RB - 1);
+            if (tap == 9 && c + 1 < KS) {
+                stage_store(c + 1);
+                if (c + 2 < KS) stage_load(c + 2);
+            }
+            if (g + 1 < NSTEP) {
+                const int c2 = (g + 1) / NTAP, r2 = (g + 1) % NTAP;
+                if (r2 == 0) __syncthreads();            // next chunk of the patch visible (stored 17 k-steps ago)
+                frags_dyn(g + 1, c2, r2);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][0][PA[pr]], bfr[g % RB][PB[pr]], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][1][PA[pr]], bfr[g % RB][PB[pr]], acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h = (y & 3, x) of row block i ----
+    const bool has_mask = p.mask != nullptr;
+    const long zrow = ((long)n * p.D + z0 + tz) * p.H;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float rr[16], mm[16];
+        unsigned eo[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * h, y = 4 * i + (m >> 3), x = m & 7;
+            eo[r] = 4u * (unsigned)((((zrow + y0 + y) * p.W) + x0 + x) * C + col);
+            rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, (int)eo[r], 0, 0));
+            mm[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mrs, (int)eo[r], 0, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[i][r] + rr[r];
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (has_mask) v = (mm[r] > 0.f) ? v : 0.f;
+            p.out[eo[r] / 4] = v;
+        }
+    }
+}
+
 // ---- weight image: W[tap][ci][co] f32 -> bf16x3 B fragments, [k-step (channel chunk)][tap][column half][plane][lane] x 16 bytes ----
 constexpr int PREP_MAX = 16;
 struct PrepBatch {
@@ -876,6 +1067,11 @@ int mi_direct3_kind(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int k
     // (from 128 workgroups on: 64 of them - batch 8 of 64^3 crops - take 47.6 us where the implicit GEMM takes 39.5; batch 16: 51 against
     // 62 us, batch 32: 71 against 105 us = 204 TFLOP/s, image cut included)
     if (Ci == 128 && Co == 128 && Hi == 8 && Wi == 8 && Di >= TZ && Di % TZ == 0 && (long)N * Di >= 128 && (long)N * (Di / TZ) <= 0x7fffffffl) return 3;
+    // 5 (round 4): 64 -> 64 on planes of 8 x 8 tiles with a halo (direct3h_kernel: layer1 of a 64^3 crop), from 128 workgroups on
+    if (Ci == C && Co == C && Hi % 8 == 0 && Wi % 8 == 0 && (Hi > 8 || Wi > 8) && Di >= TZ && Di % TZ == 0) {
+        const long wgs = (long)N * (Di / TZ) * (Hi / 8) * (Wi / 8);
+        if (wgs >= 128 && wgs <= 0x7fffffffl) return 5;
+    }
     return 0;
 }
 bool mi_direct3_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph,
@@ -887,12 +1083,12 @@ size_t mi_direct3_wimg_bytes(int channels) {
     return channels == C ? (size_t)WIMG_BYTES : channels == CS ? (size_t)S_WIMG_BYTES : 0;
 }
 size_t mi_direct3_wimg_bytes_kind(int kind) {
-    return kind == 1 ? (size_t)WIMG_BYTES : kind == 2 ? (size_t)S_WIMG_BYTES : kind == 3 ? (size_t)(2 * 8 * NTAP * WSTEP) : 0;
+    return (kind == 1 || kind == 5) ? (size_t)WIMG_BYTES : kind == 2 ? (size_t)S_WIMG_BYTES : kind == 3 ? (size_t)(2 * 8 * NTAP * WSTEP) : 0;
 }
 // (rounds 2-3: split-K slabs of the 128-channel kernel; since round 4 both direct kernels are final in one launch)
 size_t mi_direct3_slab_bytes(int, int) { return 0; }
 
-// kinds[i] = 1 / 2 / 3 (mi_direct3_kind) selects the image format of weight i
+// kinds[i] = 1 / 2 / 3 / 5 (mi_direct3_kind) selects the image format of weight i (5 shares the format of 1)
 int mi_direct3_prep_kind(const float* const* w, void* const* img, const int* dgrad, const int* kinds, int n, hipStream_t s) {
     for (int i0 = 0; i0 < n; i0 += PREP_MAX) {
         PrepBatch b = {};
@@ -900,10 +1096,11 @@ int mi_direct3_prep_kind(const float* const* w, void* const* img, const int* dgr
         bool any_wide = false;
         for (int i = 0; i < m; ++i) {
             const int kd = kinds[i0 + i];
-            if (kd < 1 || kd > 3 || !w[i0 + i] || !img[i0 + i]) return MI_E_ARG;
+            if ((kd < 1 || kd > 3) && kd != 5) return MI_E_ARG;
+            if (!w[i0 + i] || !img[i0 + i]) return MI_E_ARG;
             b.w[i] = w[i0 + i]; b.img[i] = (unsigned char*)img[i0 + i]; b.dgrad[i] = dgrad[i0 + i];
-            b.wide[i] = kd - 1;
-            any_wide |= kd != 1;
+            b.wide[i] = kd == 5 ? 0 : kd - 1;
+            any_wide |= kd == 2 || kd == 3;
         }
         hipLaunchKernelGGL(direct3_prep_kernel, dim3(any_wide ? PREP_BLOCKS_WIDE : PREP_BLOCKS, m), dim3(256), 0, s, b);
         MI_RETURN_IF_LAUNCH_FAILED();
@@ -929,6 +1126,14 @@ int mi_direct3_launch(const float* a, const void* wimg, float* out, const float*
     // MI_DIRECT3_FOUR_SLOTS=1: the whole patch resident, one workgroup per CU
     if (getenv("MI_DIRECT3_FOUR_SLOTS")) hipLaunchKernelGGL(direct3_kernel<false>, dim3((unsigned)(N * (D / TZ))), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(direct3_kernel<true>, dim3((unsigned)(N * (D / TZ))), dim3(256), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+// 64 channels on planes of 8 x 8 tiles (kind 5)
+int mi_direct3h_launch(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
+                       int D, int H, int W, hipStream_t s) {
+    Direct3hParams p = {a, (const unsigned char*)wimg, out, res, mask, relu, N, D, H, W, (unsigned)(4l * N * D * H * W * C)};
+    hipLaunchKernelGGL(direct3h_kernel, dim3((unsigned)((long)N * (D / TZ) * (H / 8) * (W / 8))), dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -970,7 +1175,7 @@ extern "C" size_t mi_conv3d_direct_workspace_bytes(int N, int channels) { return
 
 extern "C" int mi_conv3d_direct_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
     const int kind = mi_direct3_kind(N, Di, Hi, Wi, Ci, Co, k, k, k, stride, pad, pad, pad, 1, 1, 1);
-    return kind <= 2 ? kind : 0;           // (kind 3 cuts its image per call inside mi_conv3d_* / mi_convnd_*)
+    return kind <= 2 ? kind : 0;           // (kinds 3 and 5 cut their image per call inside mi_conv3d_* / mi_convnd_*)
 }
 
 extern "C" int mi_conv3d_direct_prep(const void* const* w, void* const* img, const int* dgrad, const int* channels, int n,

@@ -118,9 +118,11 @@ def test_conv_bf16x3_is_f32_equivalent(case, monkeypatch):
 @pytest.mark.parametrize("n,d,hw,c", [(3, 8, 8, 64), (5, 2, 8, 64), (2, 6, 8, 64), (64, 8, 8, 64),
                                       (5, 4, 4, 128), (2, 4, 4, 128), (64, 4, 4, 128),
                                       (64, 2, 2, 256), (5, 2, 2, 256), (70, 2, 2, 128),
-                                      (16, 8, 8, 128), (66, 2, 8, 128), (17, 8, 8, 128)])
+                                      (16, 8, 8, 128), (66, 2, 8, 128), (17, 8, 8, 128),
+                                      (8, 16, 16, 64), (8, 4, 24, 64), (33, 2, 16, 64)])
 def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
-    """layer1- (3^3, stride 1, 64 -> 64, 8 x 8 planes) and layer2-shaped (128 -> 128, 4 x 4 x 4; odd batch: a half-empty
+    """(round 4: also 128 channels on 8 x 8 planes and 64 channels on 16 x 16 / 24 x 24 planes - layer2 / layer1 of larger crops.)
+    layer1- (3^3, stride 1, 64 -> 64, 8 x 8 planes) and layer2-shaped (128 -> 128, 4 x 4 x 4; odd batch: a half-empty
     sample pair) convolutions take the patch-resident direct kernels (conv_direct3.hip), 2 x 2 x 2 volumes (layer3,
     feature_3d) the register-staged dense GEMM (conv_cube2.hip); MI_CONV_NO_DIRECT=1 keeps the implicit GEMM.  Both are the bf16x3 arithmetic: equal up to the
     summation order, and both at f32 level against float64 - forward with residual + ReLU, data gradient with
@@ -855,6 +857,7 @@ def test_conv_dispatch_by_shape(monkeypatch):
     assert fwd(2, 16, 64, 64).startswith("implicit GEMM")          # layer1 of a 64^3 crop
     assert fwd(16, 8, 128, 128) == "direct3 (128 channels)"        # layer2 of a 64^3 crop (round 4), from 128 workgroups on
     assert fwd(2, 8, 128, 128).startswith("implicit GEMM")
+    assert fwd(8, 16, 64, 64) == "direct3h (8 x 8 tiles)"          # layer1 of a 64^3 crop (round 4), from 128 workgroups on
     monkeypatch.setenv("MI_CONV_NO_DIRECT", "1")
     assert fwd(4, 8, 64, 64).startswith("implicit GEMM")
 
