@@ -28,6 +28,7 @@
 //   dX[i] = sum_t dY[i + 1 - t] W[t]^T = sum_t' dY[i + t' - 1] W[2 - t']^T.
 #include "common.h"
 #include <type_traits>
+#include <algorithm>
 
 namespace {
 
@@ -535,6 +536,8 @@ struct PrepBatch {
     int wide[PREP_MAX];       // image format: 0 = kind 1, 1 = kind 2, 2 = kind 3 (direct3_prep_kernel)
 };
 __device__ void direct3s_prep_body(const float* w, unsigned char* img, int dgrad, int idx);
+__device__ void direct3s256_prep_body(const float* w, unsigned char* img, int dgrad, int idx);
+constexpr int PREP_BLOCKS_256 = 8 * NTAP * 2 * 8 * 64 / 256;              // 864 (direct3s_kernel<256>)
 constexpr int PREP_BLOCKS = NTAP * KS * 2 * 64 / 256;                     // 54
 constexpr int PREP_BLOCKS_WIDE = 4 * NTAP * 2 * 4 * 64 / 256;             // 216 (both 128-channel formats)
 // image of direct3_kernel<., CT>: [output block of 64][channel chunk][tap][column half][plane][lane] x 16 bytes;
@@ -561,11 +564,12 @@ __device__ void direct3_prep_body(const float* w, unsigned char* img, int dgrad,
     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * WBLK) = o[pl];
 }
 // one launch cuts every image of a batch, all formats: blockIdx.y = image, blockIdx.x = its blocks (the 64-channel format
-// uses the first 54 of them).  wide: 0 = direct3_kernel 64 channels, 1 = direct3s_kernel 128, 2 = direct3_kernel 128
+// uses the first 54 of them).  wide: 0 = direct3_kernel 64 channels, 1 = direct3s_kernel 128, 2 = direct3_kernel 128, 3 = direct3s_kernel 256
 __global__ __launch_bounds__(256) void direct3_prep_kernel(PrepBatch b) {
     const int fmt = b.wide[blockIdx.y], idx = blockIdx.x * 256 + threadIdx.x;
-    if (fmt == 1) direct3s_prep_body(b.w[blockIdx.y], b.img[blockIdx.y], b.dgrad[blockIdx.y], idx);
-    else if (fmt == 2) direct3_prep_body<128>(b.w[blockIdx.y], b.img[blockIdx.y], b.dgrad[blockIdx.y], idx);
+    if (fmt == 1) { if (blockIdx.x < PREP_BLOCKS_WIDE) direct3s_prep_body(b.w[blockIdx.y], b.img[blockIdx.y], b.dgrad[blockIdx.y], idx); }
+    else if (fmt == 2) { if (blockIdx.x < PREP_BLOCKS_WIDE) direct3_prep_body<128>(b.w[blockIdx.y], b.img[blockIdx.y], b.dgrad[blockIdx.y], idx); }
+    else if (fmt == 3) direct3s256_prep_body(b.w[blockIdx.y], b.img[blockIdx.y], b.dgrad[blockIdx.y], idx);
     else if (blockIdx.x < PREP_BLOCKS) direct3_prep_body<C>(b.w[blockIdx.y], b.img[blockIdx.y], b.dgrad[blockIdx.y], idx);
 }
 
@@ -873,22 +877,28 @@ struct Direct3sParams {
     unsigned a_bytes;
 };
 
+// CT: channels, in = out: 128 (layer2 at 32^3 crops) or - round 4 - 256 (layer3 at 64^3 crops): CT / 32 column blocks (workgroups per
+// sample) and CT / 128 passes of four 32-channel chunks through the same 120 KB patch, the accumulators kept across the passes.
+template <int CT>
 __global__ __launch_bounds__(256, 1) void direct3s_kernel(Direct3sParams p) {
+    constexpr int NCB = CT / 32;                         // column blocks = 32-channel chunks of the reduction
+    constexpr int NPASS = NCB / S_CHUNKS;
+    constexpr int WST = NCB * 3 * WBLK;                  // bytes per k-step of the image: [column block][plane]
     __shared__ __attribute__((aligned(16))) unsigned char patch[S_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int cc = __builtin_amdgcn_readfirstlane(tid >> 6);          // the wave's chunk of 32 input channels
+    const int cc = __builtin_amdgcn_readfirstlane(tid >> 6);          // the wave's chunk (of the pass) of 32 input channels
     const int h = lane >> 5, l32 = lane & 31;
-    const int ct = blockIdx.x & 3, n0 = blockIdx.x >> 2;              // column block of 32 output channels, sample
+    const int ct = blockIdx.x % NCB, n0 = blockIdx.x / NCB;           // column block of 32 output channels, sample
 
-    const __amdgpu_buffer_rsrc_t wrs = rsrc_of(p.wimg, S_WIMG_BYTES);
+    const __amdgpu_buffer_rsrc_t wrs = rsrc_of(p.wimg, NCB * S_STEPS * WST);
     const int w_voff = ct * (3 * WBLK) + lane * 16;
-    const int w_soff = cc * (S_STEPS * S_WSTEP);
+    int w_soff = cc * (S_STEPS * WST);
     bf16x8 bfr[RB][3];
     auto wload = [&](int g, auto SLOTc) {
         constexpr int SLOT = decltype(SLOTc)::value;
         // behind the chunk: zeros - the out-of-range offset goes into the CHECKED voffset (soffset is not range-checked)
         const int vo = g < S_STEPS ? w_voff : (int)0x80000000u;
-        const int so = g < S_STEPS ? w_soff + g * S_WSTEP : 0;
+        const int so = g < S_STEPS ? w_soff + g * WST : 0;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
             bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, vo + pl * WBLK, so, 0));
@@ -903,40 +913,34 @@ __global__ __launch_bounds__(256, 1) void direct3s_kernel(Direct3sParams p) {
             default: wload(g, std::integral_constant<int, 5>{}); break;
         }
     };
-#pragma unroll
-    for (int g = 0; g < RB - 1; ++g) wload_dyn(g);
-
-    // ---- stage the patch: unit q = (voxel, group of 8 of the 128 channels): 64 x 16 units, 4 per thread ----
-    {
-        const __amdgpu_buffer_rsrc_t ars = rsrc_of(p.a, p.a_bytes);
-        for (int i = tid; i < 12 * S_CHUNKS * S_ZREC; i += 256) {
-            const int arr = i / S_ZREC, r = i % S_ZREC;
-            *reinterpret_cast<u32x4*>(patch + arr * S_ARR + S_ZBASE + r * 16) = u32x4{0u, 0u, 0u, 0u};
-        }
-        {
-            constexpr int b = 0;
-            u32x4 ld[4][2];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = tid + 256 * (4 * b + u), vox = q >> 4, cg = q & 15;
-                const unsigned off = 4u * (unsigned)(((long)n0 * VS + vox) * CS + cg * 8);
-                ld[u][0] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)off, 0, 0);
-                ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(off + 16u), 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = tid + 256 * (4 * b + u), vox = q >> 4, cg = q & 15;
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ld[u][0][e]); v[4 + e] = __uint_as_float(ld[u][1][e]); }
-                u32x4 o[3];
-                cut8(v, o);
-                unsigned char* dst = patch + (cg >> 2) * S_CH + ((cg >> 1) & 1) * S_KS + (cg & 1) * S_ARR + (S_LEAD + vox) * 16;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * S_PL) = o[pl];
-            }
-        }
+    const __amdgpu_buffer_rsrc_t ars = rsrc_of(p.a, p.a_bytes);
+    for (int i = tid; i < 12 * S_CHUNKS * S_ZREC; i += 256) {
+        const int arr = i / S_ZREC, r = i % S_ZREC;
+        *reinterpret_cast<u32x4*>(patch + arr * S_ARR + S_ZBASE + r * 16) = u32x4{0u, 0u, 0u, 0u};
     }
+    // ---- stage 128 channels of the patch: unit q = (voxel, group of 8 channels): 64 x 16 units, 4 per thread ----
+    auto stage = [&](int pass) {
+        u32x4 ld[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = tid + 256 * u, vox = q >> 4, cg = q & 15;
+            const unsigned off = 4u * (unsigned)(((long)n0 * VS + vox) * CT + pass * 128 + cg * 8);
+            ld[u][0] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)off, 0, 0);
+            ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(off + 16u), 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = tid + 256 * u, vox = q >> 4, cg = q & 15;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ld[u][0][e]); v[4 + e] = __uint_as_float(ld[u][1][e]); }
+            u32x4 o[3];
+            cut8(v, o);
+            unsigned char* dst = patch + (cg >> 2) * S_CH + ((cg >> 1) & 1) * S_KS + (cg & 1) * S_ARR + (S_LEAD + vox) * 16;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * S_PL) = o[pl];
+        }
+    };
 
     // ---- per-lane geometry: row block i = voxels 32 i .. 32 i + 31 of the sample ----
     int vbase[2], zbase[2];
@@ -979,30 +983,38 @@ __global__ __launch_bounds__(256, 1) void direct3s_kernel(Direct3sParams p) {
         else frags(g, std::integral_constant<int, 0>{});
     };
 
-    __syncthreads();
-    frags_dyn(0);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < S_STEPS; ++g) {
-        wload_dyn(g + RB - 1);
-        if (g + 1 < S_STEPS) frags_dyn(g + 1);
+    for (int pass = 0; pass < NPASS; ++pass) {
+        w_soff = (pass * S_CHUNKS + cc) * (S_STEPS * WST);
+        if (pass > 0) __syncthreads();                  // every wave is done with the previous 128 channels of the patch
 #pragma unroll
-        for (int pr = 0; pr < 6; ++pr) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][0][PA[pr]], bfr[g % RB][PB[pr]], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][1][PA[pr]], bfr[g % RB][PB[pr]], acc[1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        for (int g = 0; g < RB - 1; ++g) wload_dyn(g);
+        stage(pass);
+        __syncthreads();
+        frags_dyn(0);
         __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+        for (int g = 0; g < S_STEPS; ++g) {
+            wload_dyn(g + RB - 1);
+            if (g + 1 < S_STEPS) frags_dyn(g + 1);
+    #pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][0][PA[pr]], bfr[g % RB][PB[pr]], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][1][PA[pr]], bfr[g % RB][PB[pr]], acc[1], 0, 0, 0);
+            }
+    #pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+    #pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---- the four chunks' tiles added through LDS in chunk order ((0 + 1) + 2) + 3 - the order the slab reduce used -,
@@ -1021,7 +1033,7 @@ __global__ __launch_bounds__(256, 1) void direct3s_kernel(Direct3sParams p) {
     for (int j = 0; j < 8; ++j) {
         const int idx = cc * 8 + j, i = idx >> 4, r = idx & 15;
         float t = ((red[idx * 64 + lane] + red[(32 + idx) * 64 + lane]) + red[(64 + idx) * 64 + lane]) + red[(96 + idx) * 64 + lane];
-        const long o = (m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * CS + col;
+        const long o = (m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * CT + col;
         if (p.res) t += p.res[o];
         if (p.relu) t = fmaxf(t, 0.f);
         if (p.mask) t = (p.mask[o] > 0.f) ? t : 0.f;
@@ -1029,26 +1041,31 @@ __global__ __launch_bounds__(256, 1) void direct3s_kernel(Direct3sParams p) {
     }
 }
 
-// weight image of the 128-channel kernel: [chunk 4][tap 27][ks 2][column block 4][plane 3][lane 64] x 16 bytes
-__device__ void direct3s_prep_body(const float* w, unsigned char* img, int dgrad, int idx) {
-    // idx = (chunk, tap, ks, cb, lane): 4 * 27 * 2 * 4 * 64 = 216 * 256
-    const int lane = idx & 63, cb = (idx >> 6) & 3, ksx = (idx >> 8) & 1, rest = idx >> 9, tap = rest % NTAP, cc = rest / NTAP;
+// weight image of direct3s_kernel<CT>: [chunk CT/32][tap 27][ks 2][column block CT/32][plane 3][lane 64] x 16 bytes
+template <int CT>
+__device__ void direct3s_prep_body_t(const float* w, unsigned char* img, int dgrad, int idx) {
+    constexpr int NCB = CT / 32;
+    // idx = (chunk, tap, ks, cb, lane): NCB * 27 * 2 * NCB * 64 entries (216 * 256 for 128 channels, 864 * 256 for 256)
+    const int lane = idx & 63, cb = (idx >> 6) % NCB, r1 = (idx >> 6) / NCB, ksx = r1 & 1, rest = r1 >> 1, tap = rest % NTAP, cc = rest / NTAP;
+    if (cc >= NCB) return;
     const int nn = cb * 32 + (lane & 31), k0 = cc * 32 + ksx * 16 + 8 * (lane >> 5);
     float v[8];
     if (dgrad) {
-        const float* src = w + ((long)(NTAP - 1 - tap) * CS + nn) * CS + k0;
+        const float* src = w + ((long)(NTAP - 1 - tap) * CT + nn) * CT + k0;
         const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
     } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = w[((long)tap * CS + k0 + e) * CS + nn];
+        for (int e = 0; e < 8; ++e) v[e] = w[((long)tap * CT + k0 + e) * CT + nn];
     }
     u32x4 o[3];
     cut8(v, o);
-    unsigned char* dst = img + (long)(((cc * NTAP + tap) * 2 + ksx) * 4 + cb) * (3 * WBLK) + lane * 16;
+    unsigned char* dst = img + (long)(((cc * NTAP + tap) * 2 + ksx) * NCB + cb) * (3 * WBLK) + lane * 16;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * WBLK) = o[pl];
 }
+__device__ void direct3s_prep_body(const float* w, unsigned char* img, int dgrad, int idx) { direct3s_prep_body_t<CS>(w, img, dgrad, idx); }
+__device__ void direct3s256_prep_body(const float* w, unsigned char* img, int dgrad, int idx) { direct3s_prep_body_t<256>(w, img, dgrad, idx); }
 
 }  // namespace
 
@@ -1067,6 +1084,8 @@ int mi_direct3_kind(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int k
     // (from 128 workgroups on: 64 of them - batch 8 of 64^3 crops - take 47.6 us where the implicit GEMM takes 39.5; batch 16: 51 against
     // 62 us, batch 32: 71 against 105 us = 204 TFLOP/s, image cut included)
     if (Ci == 128 && Co == 128 && Hi == 8 && Wi == 8 && Di >= TZ && Di % TZ == 0 && (long)N * Di >= 128 && (long)N * (Di / TZ) <= 0x7fffffffl) return 3;
+    // 4 (round 4): 256 -> 256 on 4 x 4 x 4 (direct3s_kernel<256>: layer3 of a 64^3 crop), from 128 workgroups on (batch >= 16)
+    if (Ci == 256 && Co == 256 && Di == 4 && Hi == 4 && Wi == 4 && N >= 16) return 4;
     // 5 (round 4): 64 -> 64 on planes of 8 x 8 tiles with a halo (direct3h_kernel: layer1 of a 64^3 crop), from 128 workgroups on
     if (Ci == C && Co == C && Hi % 8 == 0 && Wi % 8 == 0 && (Hi > 8 || Wi > 8) && Di >= TZ && Di % TZ == 0) {
         const long wgs = (long)N * (Di / TZ) * (Hi / 8) * (Wi / 8);
@@ -1083,26 +1102,26 @@ size_t mi_direct3_wimg_bytes(int channels) {
     return channels == C ? (size_t)WIMG_BYTES : channels == CS ? (size_t)S_WIMG_BYTES : 0;
 }
 size_t mi_direct3_wimg_bytes_kind(int kind) {
-    return (kind == 1 || kind == 5) ? (size_t)WIMG_BYTES : kind == 2 ? (size_t)S_WIMG_BYTES : kind == 3 ? (size_t)(2 * 8 * NTAP * WSTEP) : 0;
+    return (kind == 1 || kind == 5) ? (size_t)WIMG_BYTES : kind == 2 ? (size_t)S_WIMG_BYTES : kind == 3 ? (size_t)(2 * 8 * NTAP * WSTEP)
+         : kind == 4 ? (size_t)8 * S_STEPS * (8 * 3 * WBLK) : 0;
 }
 // (rounds 2-3: split-K slabs of the 128-channel kernel; since round 4 both direct kernels are final in one launch)
 size_t mi_direct3_slab_bytes(int, int) { return 0; }
 
-// kinds[i] = 1 / 2 / 3 / 5 (mi_direct3_kind) selects the image format of weight i (5 shares the format of 1)
+// kinds[i] = 1 .. 5 (mi_direct3_kind) selects the image format of weight i (5 shares the format of 1)
 int mi_direct3_prep_kind(const float* const* w, void* const* img, const int* dgrad, const int* kinds, int n, hipStream_t s) {
     for (int i0 = 0; i0 < n; i0 += PREP_MAX) {
         PrepBatch b = {};
         const int m = n - i0 < PREP_MAX ? n - i0 : PREP_MAX;
-        bool any_wide = false;
+        int blocks = PREP_BLOCKS;
         for (int i = 0; i < m; ++i) {
             const int kd = kinds[i0 + i];
-            if ((kd < 1 || kd > 3) && kd != 5) return MI_E_ARG;
-            if (!w[i0 + i] || !img[i0 + i]) return MI_E_ARG;
+            if (kd < 1 || kd > 5 || !w[i0 + i] || !img[i0 + i]) return MI_E_ARG;
             b.w[i] = w[i0 + i]; b.img[i] = (unsigned char*)img[i0 + i]; b.dgrad[i] = dgrad[i0 + i];
             b.wide[i] = kd == 5 ? 0 : kd - 1;
-            any_wide |= kd == 2 || kd == 3;
+            blocks = std::max(blocks, kd == 4 ? PREP_BLOCKS_256 : (kd == 2 || kd == 3) ? PREP_BLOCKS_WIDE : PREP_BLOCKS);
         }
-        hipLaunchKernelGGL(direct3_prep_kernel, dim3(any_wide ? PREP_BLOCKS_WIDE : PREP_BLOCKS, m), dim3(256), 0, s, b);
+        hipLaunchKernelGGL(direct3_prep_kernel, dim3(blocks, m), dim3(256), 0, s, b);
         MI_RETURN_IF_LAUNCH_FAILED();
     }
     return MI_OK;
@@ -1150,7 +1169,15 @@ int mi_direct3_launch128(const float* a, const void* wimg, float* out, const flo
 int mi_direct3s_launch(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
                        hipStream_t s) {
     Direct3sParams p = {a, (const unsigned char*)wimg, out, res, mask, relu, N, (unsigned)(4l * N * VS * CS)};
-    hipLaunchKernelGGL(direct3s_kernel, dim3((unsigned)(4 * N)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(direct3s_kernel<CS>, dim3((unsigned)(4 * N)), dim3(256), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+// 256 channels on 4 x 4 x 4 (kind 4): eight column blocks per sample, two passes of 128 channels
+int mi_direct3s_launch256(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
+                          hipStream_t s) {
+    Direct3sParams p = {a, (const unsigned char*)wimg, out, res, mask, relu, N, (unsigned)(4l * N * VS * 256)};
+    hipLaunchKernelGGL(direct3s_kernel<256>, dim3((unsigned)(8 * N)), dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

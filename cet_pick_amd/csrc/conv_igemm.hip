@@ -56,6 +56,8 @@ int mi_direct3_launch(const float* a, const void* wimg, float* out, const float*
                       int D, hipStream_t s);
 size_t mi_direct3_wimg_bytes_kind(int kind);
 int mi_direct3_prep_kind(const float* const* w, void* const* img, const int* dgrad, const int* kinds, int n, hipStream_t s);
+int mi_direct3s_launch256(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
+                          hipStream_t s);
 int mi_direct3h_launch(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
                        int D, int H, int W, hipStream_t s);
 int mi_direct3_launch128(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
@@ -1217,8 +1219,9 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         const int dg[1] = {mode == MODE_DGRAD ? 1 : 0}, kd[1] = {dkind};
         int rc = mi_direct3_prep_kind(wl, il, dg, kd, 1, s);
         if (rc) return rc;
-        g_last_conv_kernel = dkind == 1 ? "direct3" : dkind == 2 ? "direct3s" : dkind == 3 ? "direct3 (128 channels)" : "direct3h (8 x 8 tiles)";
+        g_last_conv_kernel = dkind == 1 ? "direct3" : dkind == 2 ? "direct3s" : dkind == 3 ? "direct3 (128 channels)" : dkind == 4 ? "direct3s (256 channels)" : "direct3h (8 x 8 tiles)";
         if (dkind == 1) return mi_direct3_launch(a_src, ws, out, res, mask, relu, g.N, g.Di, s);
+        if (dkind == 4) return mi_direct3s_launch256(a_src, ws, out, res, mask, relu, g.N, s);
         if (dkind == 5) return mi_direct3h_launch(a_src, ws, out, res, mask, relu, g.N, g.Di, g.Hi, g.Wi, s);
         if (dkind == 3) return mi_direct3_launch128(a_src, ws, out, res, mask, relu, g.N, g.Di, s);
         return mi_direct3s_launch(a_src, ws, out, res, mask, relu, g.N, s);       // 128-channel kernel on 4^3: final as well

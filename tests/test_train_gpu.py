@@ -119,7 +119,8 @@ def test_conv_bf16x3_is_f32_equivalent(case, monkeypatch):
                                       (5, 4, 4, 128), (2, 4, 4, 128), (64, 4, 4, 128),
                                       (64, 2, 2, 256), (5, 2, 2, 256), (70, 2, 2, 128),
                                       (16, 8, 8, 128), (66, 2, 8, 128), (17, 8, 8, 128),
-                                      (8, 16, 16, 64), (8, 4, 24, 64), (33, 2, 16, 64)])
+                                      (8, 16, 16, 64), (8, 4, 24, 64), (33, 2, 16, 64),
+                                      (16, 4, 4, 256), (19, 4, 4, 256)])
 def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
     """(round 4: also 128 channels on 8 x 8 planes and 64 channels on 16 x 16 / 24 x 24 planes - layer2 / layer1 of larger crops.)
     layer1- (3^3, stride 1, 64 -> 64, 8 x 8 planes) and layer2-shaped (128 -> 128, 4 x 4 x 4; odd batch: a half-empty
@@ -857,6 +858,7 @@ def test_conv_dispatch_by_shape(monkeypatch):
     assert fwd(2, 16, 64, 64).startswith("implicit GEMM")          # layer1 of a 64^3 crop
     assert fwd(16, 8, 128, 128) == "direct3 (128 channels)"        # layer2 of a 64^3 crop (round 4), from 128 workgroups on
     assert fwd(2, 8, 128, 128).startswith("implicit GEMM")
+    assert fwd(16, 4, 256, 256) == "direct3s (256 channels)"       # layer3 of a 64^3 crop (round 4), batch >= 16
     assert fwd(8, 16, 64, 64) == "direct3h (8 x 8 tiles)"          # layer1 of a 64^3 crop (round 4), from 128 workgroups on
     monkeypatch.setenv("MI_CONV_NO_DIRECT", "1")
     assert fwd(4, 8, 64, 64).startswith("implicit GEMM")
