@@ -120,7 +120,7 @@ def test_conv_bf16x3_is_f32_equivalent(case, monkeypatch):
                                       (64, 2, 2, 256), (5, 2, 2, 256), (70, 2, 2, 128),
                                       (16, 8, 8, 128), (66, 2, 8, 128), (17, 8, 8, 128),
                                       (8, 16, 16, 64), (8, 4, 24, 64), (33, 2, 16, 64),
-                                      (16, 4, 4, 256), (19, 4, 4, 256)])
+                                      (16, 4, 4, 256), (19, 4, 4, 256), (6, 4, (16, 24), 64)])
 def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
     """(round 4: also 128 channels on 8 x 8 planes and 64 channels on 16 x 16 / 24 x 24 planes - layer2 / layer1 of larger crops.)
     layer1- (3^3, stride 1, 64 -> 64, 8 x 8 planes) and layer2-shaped (128 -> 128, 4 x 4 x 4; odd batch: a half-empty
@@ -130,12 +130,13 @@ def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
     residual + mask, weight gradient; every z tile position (first / interior / last plane pair)."""
     from cet_pick_amd import hipops as H
     from conftest import f32_equivalent
+    hh, ww = hw if isinstance(hw, tuple) else (hw, hw)
     g = torch.Generator().manual_seed(100 * n + d + c)
-    x = torch.randn(n, c, d, hw, hw, generator=g) * torch.exp(2 * torch.randn(n, c, d, hw, hw, generator=g))
+    x = torch.randn(n, c, d, hh, ww, generator=g) * torch.exp(2 * torch.randn(n, c, d, hh, ww, generator=g))
     param, w = make_w(c, c, 3, g)
-    res = torch.randn(n, c, d, hw, hw, generator=g)
-    mask = torch.randn(n, c, d, hw, hw, generator=g)
-    dy = torch.randn(n, c, d, hw, hw, generator=g)
+    res = torch.randn(n, c, d, hh, ww, generator=g)
+    mask = torch.randn(n, c, d, hh, ww, generator=g)
+    dy = torch.randn(n, c, d, hh, ww, generator=g)
     def chain(xx, ww, rr, mm, dd):
         xx = xx.clone().requires_grad_(True)
         ww = ww.clone().requires_grad_(True)
@@ -148,7 +149,7 @@ def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
     for tag, off in (("direct", "0"), ("igemm", "1")):
         monkeypatch.setenv("MI_CONV_NO_DIRECT", off)
         yf = H.conv_fwd(cl(x), param, 3, 1, 1, cl(res), True)
-        yd = H.conv_dgrad(cl(dy), param, (n, d, hw, hw, c), 3, 1, 1, cl(res), cl(mask))
+        yd = H.conv_dgrad(cl(dy), param, (n, d, hh, ww, c), 3, 1, 1, cl(res), cl(mask))
         param.grad = None
         H.conv_wgrad_into(cl(x), cl(dy), param, 3, 1, 1)
         out[tag] = (yf.cpu(), yd.cpu(), param.grad.detach().cpu().clone())
