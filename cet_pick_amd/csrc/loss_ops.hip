@@ -10,6 +10,9 @@
 // similarities on the matrix cores (round 4: f32-equivalent products as six bf16 MFMAs of a 3-way cut, UclS) and folds exp() of it straight
 // into the four row sums the loss needs (online max, flash-attention style).  The backward recomputes the
 // tiles and contracts them with the features again on the matrix cores.
+// (the SLP vectoriser pairs the row bookkeeping of the contrastive loss into v_pk_mul_f32 / v_pk_add_f32: 15 cycles of matrix-pipe
+// throughput each next to the MFMAs against 5 for a scalar FP32 operation - tools/probes/mfma_coissue.hip)
+// hipcc-flags: -fno-slp-vectorize
 #include "common.h"
 #include "../../include/cetpick_hip.h"
 
@@ -55,13 +58,14 @@ template <int DIM> struct UclS {
     static constexpr int PLANE = 64 * PITCH;
     static constexpr int BYTES = 3 * PLANE;
     // rows [row0, row0 + 32) of feat -> A fragments
-    static __device__ __forceinline__ void load_a(const float* feat, int row, bool ok, int h, bf16x8 (&af)[KS][3]) {
+    // fs: factor applied to every feature before the cut (the forward pass folds 1 / T and log2(e) into the operands)
+    static __device__ __forceinline__ void load_a(const float* feat, int row, bool ok, int h, bf16x8 (&af)[KS][3], float fs = 1.f) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             float v[8];
             const float4 a = ok ? ld4(feat + (long)row * DIM + 16 * ks + 8 * h) : make_float4(0, 0, 0, 0);
             const float4 b = ok ? ld4(feat + (long)row * DIM + 16 * ks + 8 * h + 4) : make_float4(0, 0, 0, 0);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            v[0] = a.x * fs; v[1] = a.y * fs; v[2] = a.z * fs; v[3] = a.w * fs; v[4] = b.x * fs; v[5] = b.y * fs; v[6] = b.z * fs; v[7] = b.w * fs;
             ucl_cut8(v, af[ks]);
         }
     }
@@ -223,7 +227,7 @@ constexpr int UB = 64;            // rows per workgroup and columns per tile (2 
 constexpr int MAXDIM = 64;
 
 // per-lane online state of one row
-struct RowAcc { float m, sa, sp, so; };
+struct RowAcc { float m, ref, sa, sp, so; };      // m: running maximum; ref: what the three sums are relative to
 
 template <int DIM>
 // (three waves per SIMD: 168 registers, seven dwords of scratch outside the column walk - 118 ms against 127 for the C5 step)
@@ -239,12 +243,17 @@ __global__ __launch_bounds__(256, 3) void ucl_fwd_kernel(const float* feat, cons
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l32 = lane & 31;
     const int row0 = blockIdx.x * UB;
 
+    // The walk runs in the exponent's own units: both operands are scaled by sqrt(log2(e) / T) before the cut, so a tile element IS
+    // log2(e) S / T and exp() is one v_exp_f32 of a difference - the multiplication by 1 / T and the one inside __expf, per tile
+    // element and next to the MFMAs (FP32 vector work is paid in full there), become eight multiplications per
+    // thread and tile in the staging.  Row maxima leave the kernel in natural units (x ln 2).
+    const float fs = sqrtf(inv_T * 1.4426950408889634f);
     // A fragments: this wave's 32 rows, constant over the column walk (bf16x3 cut, once)
     bf16x8 af[SP::KS][3];
-    SP::load_a(feat, row0 + wm * 32 + l32, row0 + wm * 32 + l32 < n2, h, af);
+    SP::load_a(feat, row0 + wm * 32 + l32, row0 + wm * 32 + l32 < n2, h, af, fs);
     RowAcc st[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = {-INFINITY, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 16; ++r) st[r] = {-INFINITY, -INFINITY, 0.f, 0.f, 0.f};
     if (tid < UB) s_pair[tid] = -INFINITY;
 
     for (int col0 = 0; col0 < n2; col0 += UB) {
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(256, 3) void ucl_fwd_kernel(const float* feat, cons
             float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (col0 + c < n2) {
                 const float4 a = ld4(feat + (long)(col0 + c) * DIM + k8), b = ld4(feat + (long)(col0 + c) * DIM + k8 + 4);
-                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                v[0] = a.x * fs; v[1] = a.y * fs; v[2] = a.z * fs; v[3] = a.w * fs; v[4] = b.x * fs; v[5] = b.y * fs; v[6] = b.z * fs; v[7] = b.w * fs;
             }
             SP::stage(colb, c, k8, v);
         }
@@ -269,23 +278,42 @@ __global__ __launch_bounds__(256, 3) void ucl_fwd_kernel(const float* feat, cons
         const int rlo = row0 + wm * 32, clo = col0 + wn * 32;
         const bool pair_tile = !((clo + 32 <= rlo + n_half || clo >= rlo + 32 + n_half) &&
                                  (clo + 32 <= rlo - n_half || clo >= rlo + 32 - n_half));
+        // The sums of a row are kept relative to a REFERENCE that only moves when an element exceeds it by more than 2^64 (the
+        // first element, then almost never), not to the running maximum: per element one v_max for the maximum, one v_sub + v_exp
+        // for the term and three accumulations - the rescale-by-exp of the textbook online softmax (a second exp, a compare and
+        // four selects per element once the compiler has if-converted it) only runs when some lane of the wave needs it.
+        if (colok) {
+            float d[16], dmax;                            // element - reference, and the largest of the lane's sixteen
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (!colok) continue;
-            const float s = acc[r] * inv_T;
-            RowAcc& a = st[r];
-            if (s > a.m) {                                // rescale the running sums to the new maximum
-                const float sc = __expf(a.m - s);          // exp(-inf) = 0 on the first element
-                a.sa *= sc; a.sp *= sc; a.so *= sc; a.m = s;
+            for (int r = 0; r < 16; ++r) d[r] = acc[r] - st[r].ref;
+            dmax = fmaxf(fmaxf(d[0], d[1]), d[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) dmax = fmaxf(fmaxf(dmax, d[r]), d[r + 1]);
+            dmax = fmaxf(dmax, d[15]);
+            if (__builtin_amdgcn_ballot_w64(dmax > 64.f) != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    RowAcc& a = st[r];
+                    if (d[r] > 64.f) {
+                        const float sc = __builtin_amdgcn_exp2f(-d[r]);             // 2^(-inf) = 0 on the first element
+                        a.sa *= sc; a.sp *= sc; a.so *= sc; a.ref = acc[r]; d[r] = 0.f;
+                    }
+                }
             }
-            if (col != row) {                             // the diagonal only takes part in the maximum
-                const float e = __expf(s - a.m);
-                a.sa += e; a.sp += e * fp; a.so += e * fo;
-            }
-            if (pair_tile) {                              // (wave-uniform)
-                const int pr = row < n_half ? row + n_half : row - n_half;
-                if (col == pr) s_pair[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float s = acc[r];                   // log2(e) S / T
+                RowAcc& a = st[r];
+                a.m = fmaxf(a.m, s);
+                if (col != row) {                         // the diagonal only takes part in the maximum
+                    const float e = __builtin_amdgcn_exp2f(d[r]);
+                    a.sa += e; a.sp += e * fp; a.so += e * fo;
+                }
+                if (pair_tile) {                          // (wave-uniform)
+                    const int pr = row < n_half ? row + n_half : row - n_half;
+                    if (col == pr) s_pair[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = s;
+                }
             }
         }
     }
@@ -296,7 +324,7 @@ __global__ __launch_bounds__(256, 3) void ucl_fwd_kernel(const float* feat, cons
         float m = a.m;
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        const float sc = __expf(a.m - m);
+        const float sc = __builtin_amdgcn_exp2f(a.ref - m);          // (a lane that saw no column: ref = -inf, sums 0)
         float sa = a.sa * sc, sp = a.sp * sc, so = a.so * sc;
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sp += __shfl_xor(sp, o, 64); so += __shfl_xor(so, o, 64); }
@@ -308,15 +336,15 @@ __global__ __launch_bounds__(256, 3) void ucl_fwd_kernel(const float* feat, cons
     __syncthreads();
     if (tid < UB && row0 + tid < n2) {
         const float m0 = mrg[0][tid][0], m1 = mrg[1][tid][0], m = fmaxf(m0, m1);
-        const float c0 = __expf(m0 - m), c1 = __expf(m1 - m);
+        const float c0 = __builtin_amdgcn_exp2f(m0 - m), c1 = __builtin_amdgcn_exp2f(m1 - m);
         const int row = row0 + tid;
-        rowmax[row] = m;
+        rowmax[row] = m * 0.6931471805599453f;           // back to natural units
         // the masked diagonal contributes exp(0) = 1 to every column sum it belongs to (loss.py:622-624)
         const uint8_t rc = cls[row];
         s_all[row] = mrg[0][tid][1] * c0 + mrg[1][tid][1] * c1 + 1.f;
         s_pos[row] = mrg[0][tid][2] * c0 + mrg[1][tid][2] * c1 + ((rc & 1) ? 1.f : 0.f);
         s_other[row] = mrg[0][tid][3] * c0 + mrg[1][tid][3] * c1 + ((rc & 2) ? 1.f : 0.f);
-        e_pair[row] = __expf(s_pair[tid] - m);
+        e_pair[row] = __builtin_amdgcn_exp2f(s_pair[tid] - m);
     }
 }
 
