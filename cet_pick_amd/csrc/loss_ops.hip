@@ -379,8 +379,12 @@ __global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, cons
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l32 = lane & 31;
     const int row0 = blockIdx.x * UB;
 
+    // (as the forward pass: operands scaled by sqrt(log2(e) / T), a tile element is the exponent in base-2 units; the row maxima
+    // arrive in natural units and are converted once per row / column; the second product contracts W with the SCALED features, so
+    // the epilogue's factor is 1 / (T fs) instead of 1 / T)
+    const float fs = sqrtf(inv_T * 1.4426950408889634f), LOG2E = 1.4426950408889634f;
     bf16x8 af[SP::KS][3];
-    SP::load_a(feat, row0 + wm * 32 + l32, row0 + wm * 32 + l32 < n2, h, af);
+    SP::load_a(feat, row0 + wm * 32 + l32, row0 + wm * 32 + l32 < n2, h, af, fs);
     // per-row metadata of the 16 rows this lane sees in the C layout
     // TRANS == 0 needs five numbers per row and element: rowmax and g_all stay in registers, (g_pos, g_other, g_pair) of the
     // workgroup's 64 rows sit in LDS and come as ONE 16-byte broadcast read per row (all five in registers: 198 VGPRs, two
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, cons
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool ok = row < n2;
-        rm[r] = (!TRANS && ok) ? rowmax[row] : 0.f;
+        rm[r] = (!TRANS && ok) ? rowmax[row] * LOG2E : 0.f;
         ra[r] = (!TRANS && ok) ? g_all[row] : 0.f;
         rcl[r] = ok ? cls[row] : 0;
     }
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, cons
             float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (col0 + c < n2) {
                 const float4 a = ld4(feat + (long)(col0 + c) * DIM + k8), b = ld4(feat + (long)(col0 + c) * DIM + k8 + 4);
-                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                v[0] = a.x * fs; v[1] = a.y * fs; v[2] = a.z * fs; v[3] = a.w * fs; v[4] = b.x * fs; v[5] = b.y * fs; v[6] = b.z * fs; v[7] = b.w * fs;
             }
             SP::stage(colb, c, k8, v);                     // (both products read the planes)
         }
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, cons
             const bool ok = c < n2;
             colc[tid] = ok ? cls[c] : 0;
             if (TRANS) {
-                cmeta[tid][0] = ok ? rowmax[c] : 0.f; cmeta[tid][1] = ok ? g_all[c] : 0.f;
+                cmeta[tid][0] = ok ? rowmax[c] * LOG2E : 0.f; cmeta[tid][1] = ok ? g_all[c] : 0.f;
                 cmeta[tid][2] = ok ? g_pos[c] : 0.f; cmeta[tid][3] = ok ? g_other[c] : 0.f;
                 cmeta[tid][4] = ok ? g_pair[c] : 0.f;
             }
@@ -450,13 +454,13 @@ __global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int tr = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float s = acc[r] * inv_T;
+                const float s = acc[r];
                 float w;
                 if (!TRANS) {
                     const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
-                    w = __expf(s - rm[r]) * fmaf(c1, mq.y, fmaf(c0, mq.x, ra[r]));
+                    w = __builtin_amdgcn_exp2f(s - rm[r]) * fmaf(c1, mq.y, fmaf(c0, mq.x, ra[r]));
                 }
-                else w = __expf(s - cmx) * (c0 + ((rcl[r] & 1) ? c1 : 0.f) + ((rcl[r] & 2) ? c2 : 0.f));
+                else w = __builtin_amdgcn_exp2f(s - cmx) * (c0 + ((rcl[r] & 1) ? c1 : 0.f) + ((rcl[r] & 2) ? c2 : 0.f));
                 wrow[tr * WP + l32] = w;
             }
         } else
@@ -466,15 +470,15 @@ __global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, cons
             const int row = row0 + wm * 32 + tr;
             float w = 0.f;
             if (colok && row < n2 && col != row) {
-                const float s = acc[r] * inv_T;
+                const float s = acc[r];
                 const int pr = row < n_half ? row + n_half : row - n_half;
                 if (!TRANS) {
                     const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
-                    w = __expf(s - rm[r]) * (ra[r] + ((cc & 1) ? mq.x : 0.f) + ((cc & 2) ? mq.y : 0.f) +
+                    w = __builtin_amdgcn_exp2f(s - rm[r]) * (ra[r] + ((cc & 1) ? mq.x : 0.f) + ((cc & 2) ? mq.y : 0.f) +
                                              (col == pr ? mq.z : 0.f));
                 } else {
                     const float* cm = cmeta[lc];
-                    w = __expf(s - cm[0]) * (cm[1] + ((rcl[r] & 1) ? cm[2] : 0.f) + ((rcl[r] & 2) ? cm[3] : 0.f) +
+                    w = __builtin_amdgcn_exp2f(s - cm[0]) * (cm[1] + ((rcl[r] & 1) ? cm[2] : 0.f) + ((rcl[r] & 2) ? cm[3] : 0.f) +
                                              (col == pr ? cm[4] : 0.f));
                 }
             }
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, cons
         const int tr = q / DIM, k = q % DIM;
         const int row = row0 + tr;
         if (row < n2) {
-            const float v = (outm[tr * LD + k] + outm[(UB + tr) * LD + k]) * inv_T;
+            const float v = (outm[tr * LD + k] + outm[(UB + tr) * LD + k]) * (inv_T / fs);
             dfeat[(long)row * DIM + k] = accumulate ? dfeat[(long)row * DIM + k] + v : v;
         }
     }
