@@ -58,6 +58,12 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, const float* src, in
                 if (KIND == 20) asm volatile("v_mov_b32 %0, %1" : "=v"(w[j]) : "v"(w[(j + 1) & 3]));
                 if (KIND == 21) w[j] = (w[j] & 0xffff0000u) | w[(j + 1) & 3];
                 if (KIND == 22) { w[j] ^= q[j][0]; q[j][0] = *reinterpret_cast<const unsigned*>(lds + ((tid * 4 + it * 256 + 1024 * (t & 7)) & 16383)); }
+                if (KIND == 23) asm volatile("v_fmac_f32 %0, -1.0, %1" : "+v"(v[j]) : "v"(v[(j + 1) & 3]));
+                if (KIND == 24) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(v[(j + 1) & 3]));
+                if (KIND == 25) asm volatile("v_fma_f32 %0, -1.0, %1, %2" : "=v"(v[j]) : "v"(v[(j + 1) & 3]), "v"(v[j]));
+                if (KIND == 26) asm volatile("v_add_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(v[(j + 1) & 3]));
+                if (KIND == 27) asm volatile("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(v[(j + 1) & 3]));
+                if (KIND == 28) asm volatile("v_exp_f32 %0, %1" : "=v"(v[j]) : "v"(v[(j + 1) & 3]));
                 if (KIND == 8) sacc = __builtin_amdgcn_readfirstlane(sacc) + it;
                 if (KIND == 9) w[j] = (lane & (1 << k)) ? w[j] : w[(j + 1) & 3];
                 if (KIND == 10) { w[j] ^= q[j][0] ^ q[j][1]; unsigned long long r = *reinterpret_cast<const unsigned long long*>(lds + ((tid * 8 + it * 512 + 1024 * (t & 7)) & 16383)); q[j][0] = (unsigned)r; q[j][1] = (unsigned)(r >> 32); }
@@ -97,6 +103,12 @@ int main() {
     printf("bare MFMA: %.2f ns per MFMA (1 wave/SIMD), %.2f ns (2 waves/SIMD, per wave)\n", base1 * 1e9, base2 * 1e9);
     row<1>("v_fma_f32", base1, base2);
     row<11>("v_sub_f32", base1, base2);
+    row<24>("v_sub_f32 (asm)", base1, base2);
+    row<23>("v_fmac_f32 x,-1.0,hi", base1, base2);
+    row<25>("v_fma_f32 -1.0,hi,x", base1, base2);
+    row<26>("v_add_f32 (asm)", base1, base2);
+    row<27>("v_max_f32 (asm)", base1, base2);
+    row<28>("v_exp_f32 (asm)", base1, base2);
     row<12>("v_mul_f32", base1, base2);
     row<16>("v_pk_add_f32", base1, base2);
     row<13>("v_add_u32", base1, base2);
