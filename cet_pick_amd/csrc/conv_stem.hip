@@ -11,8 +11,8 @@
 //      double-buffered, one barrier per slab.  Reduction index inside a slab: k = ky*7 + kx, the lane half h owns
 //      k = 2t + h, whose patch offset differs from that of 2t by 1 (same row) or by PW - 6 (row wrap) - two lane
 //      base registers cover both cases, the rest is an immediate.
-// (no SLP vectorisation: it pairs the cut's subtractions into v_pk_add_f32 - 15 cycles of matrix-pipe throughput next to the MFMAs
-// against 5 for a scalar v_sub_f32, tools/probes/mfma_coissue.hip)
+// (no SLP vectorisation: it pairs the cut's subtractions into v_pk_add_f32 - 14 cycles of matrix-pipe throughput next to the MFMAs
+// where a scalar v_sub_f32 is hidden, tools/probes/mfma_coissue.hip)
 // hipcc-flags: -fno-slp-vectorize
 #include "common.h"
 #include <type_traits>

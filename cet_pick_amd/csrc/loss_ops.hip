@@ -10,8 +10,8 @@
 // similarities on the matrix cores (round 4: f32-equivalent products as six bf16 MFMAs of a 3-way cut, UclS) and folds exp() of it straight
 // into the four row sums the loss needs (online max, flash-attention style).  The backward recomputes the
 // tiles and contracts them with the features again on the matrix cores.
-// (the SLP vectoriser pairs the row bookkeeping of the contrastive loss into v_pk_mul_f32 / v_pk_add_f32: 15 cycles of matrix-pipe
-// throughput each next to the MFMAs against 5 for a scalar FP32 operation - tools/probes/mfma_coissue.hip)
+// (the SLP vectoriser pairs the row bookkeeping of the contrastive loss into v_pk_mul_f32 / v_pk_add_f32: 14 cycles of matrix-pipe
+// throughput each next to the MFMAs where the scalar FP32 operations they replace are hidden - tools/probes/mfma_coissue.hip)
 // hipcc-flags: -fno-slp-vectorize
 #include "common.h"
 #include "../../include/cetpick_hip.h"
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 3) void ucl_fwd_kernel(const float* feat, cons
 
     // The walk runs in the exponent's own units: both operands are scaled by sqrt(log2(e) / T) before the cut, so a tile element IS
     // log2(e) S / T and exp() is one v_exp_f32 of a difference - the multiplication by 1 / T and the one inside __expf, per tile
-    // element and next to the MFMAs (FP32 vector work is paid in full there), become eight multiplications per
+    // element and next to the MFMAs become eight multiplications per
     // thread and tile in the staging.  Row maxima leave the kernel in natural units (x ln 2).
     const float fs = sqrtf(inv_T * 1.4426950408889634f);
     // A fragments: this wave's 32 rows, constant over the column walk (bf16x3 cut, once)
