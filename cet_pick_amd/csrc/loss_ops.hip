@@ -460,7 +460,8 @@ __global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, cons
                     const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
                     w = __builtin_amdgcn_exp2f(s - rm[r]) * fmaf(c1, mq.y, fmaf(c0, mq.x, ra[r]));
                 }
-                else w = __builtin_amdgcn_exp2f(s - cmx) * (c0 + ((rcl[r] & 1) ? c1 : 0.f) + ((rcl[r] & 2) ? c2 : 0.f));
+                else    // (the row's class bits as 0 / 1 factors of two multiply-adds: a compare + select pair costs 5 cycles of matrix-pipe throughput)
+                    w = __builtin_amdgcn_exp2f(s - cmx) * fmaf((float)((rcl[r] >> 1) & 1), c2, fmaf((float)(rcl[r] & 1), c1, c0));
                 wrow[tr * WP + l32] = w;
             }
         } else
