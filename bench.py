@@ -534,6 +534,10 @@ def main():
                                        "frac_f32_mfma_peak is the same rate against the f32 MFMA peak (157.3)"
                                        if arith == "bf16x3" else "peak = f32 MFMA (v_mfma_f32_32x32x2_f32)"),
                          "frac_f32_mfma_peak": achieved / PEAK_F32_MATRIX_TFLOPS,
+                         # tools/probes/mfma_bf16_peak.hip, round 4: v_mfma_f32_32x32x16_bf16 from registers on the whole chip sustains
+                         # 2,130 TFLOP/s (2.05 GHz under MFMA load) - what the bf16x3 arithmetic can reach on this part; `frac` stays
+                         # against the nominal figure
+                         "frac_of_sustained_mfma": (achieved / (2130.0 / 6.0)) if arith == "bf16x3" else None,
                          "launches_per_step": n_launch // 3, "kernel_ms_per_step": ms / 3,
                          "algorithmic_gflop_per_step": flop / 3 / 1e9,
                          "by_mode": {t: {"launches_per_step": v[0] // 3, "gflop_per_step": v[1] / 3 / 1e9,
