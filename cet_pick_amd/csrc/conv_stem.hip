@@ -165,11 +165,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
 // FWD on the bf16 matrix pipe with f32-equivalent arithmetic (the "bf16x3" cut of conv_igemm.hip: a = a0 + a1 + a2
 // exactly, six products of weight <= 2 per f32 product, f32 accumulate).  The patch is cut ONCE while it is staged
 // (three bf16 planes of 48-byte rows); the weights are cut once per call by stem_wprep_kernel into the LDS image
-// [kz][plane][ky 0..7][co][kx 0..7] (ky = 7 and kx = 7 are zero padding), streamed one kz slab (24 KB) at a time.
-// One v_mfma_f32_32x32x16_bf16 takes K = 16 = two (kz, ky) rows x 8 kx: lane-half h owns row ky = 2u + h, whose eight
+// [slab][plane][row 0..7][co][kx 0..7] (rows r = 7 kz + ky, eight to a slab; rows 49..55 and kx = 7 are zero padding), streamed one
+// slab (24 KB) at a time.  One v_mfma_f32_32x32x16_bf16 takes K = 16 = two rows x 8 kx: lane-half h owns row 8 slab + 2u + h, whose eight
 // kx taps are eight CONSECUTIVE patch elements (stride-2 convolution: x = 2 ox + kx) - four ds_read_b32 per plane,
-// conflict-free on 48-byte rows.  28 k-steps x 6 products x 2 column tiles = 336 MFMAs of 32 cycles per wave against
-// 350 of 64 cycles in the f32 kernel.
+// conflict-free on 48-byte rows.  25 k-steps (round 4; 28 with the rows padded per kz) x 6 products x 2 column tiles = 300 MFMAs
+// of 32 cycles per wave and z-plane against 350 of 64 cycles in the f32 kernel.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int PYP = PY + 1;                              // + one zero row: the padded tap ky = 7 of the last output row
 constexpr int PROW = 2 * PW;                             // bytes per bf16 patch row
@@ -188,13 +188,16 @@ __device__ __forceinline__ void cut3(float a, unsigned& h0, unsigned& h1, unsign
 }
 
 __global__ __launch_bounds__(256) void stem_wprep_kernel(const float* w, unsigned short* out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;        // (kz, ky8, co, kx8)
+    const int i = blockIdx.x * 256 + threadIdx.x;        // (slab, row j of the slab, co, kx8)
     if (i >= K7 * 8 * CO * 8) return;
-    const int kx = i & 7, co = (i >> 3) & (CO - 1), ky = (i >> 9) & 7, kz = i >> 12;
-    const float v = (ky < K7 && kx < K7) ? w[((kz * K7 + ky) * K7 + kx) * CO + co] : 0.f;
+    // round 4: the 49 (kz, ky) rows of the window are numbered r = 7 kz + ky and packed eight to a slab (rows 49 .. 55 are zero
+    // padding): 25 k-steps of two rows instead of 7 x 4 with ky = 7 padded in every kz
+    const int kx = i & 7, co = (i >> 3) & (CO - 1), j = (i >> 9) & 7, slab = i >> 12;
+    const int r = 8 * slab + j, kz = r / K7, ky = r % K7;
+    const float v = (r < K7 * K7 && kx < K7) ? w[((kz * K7 + ky) * K7 + kx) * CO + co] : 0.f;
     unsigned h0, h1, h2;
     cut3(v, h0, h1, h2);
-    const int o = kz * (WSLAB / 2) + (ky * CO + co) * 8 + kx;
+    const int o = slab * (WSLAB / 2) + (j * CO + co) * 8 + kx;
     out[o] = (unsigned short)h0; out[o + WPL / 2] = (unsigned short)h1; out[o + WPL] = (unsigned short)h2;
 }
 
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256, ZPW == 2 ? 2 : (NBUF == 1 ? 3 : 2)) void stem_
     wload(1);
 
     // lane base into a patch plane: output (ox, oy) = (l32 & 7, l32 >> 3) of z-plane ZPW * wave (+ zi), row + h
-    const int a_base = ((S2 * ZPW * wave) * PYP + S2 * (l32 >> 3) + h) * PROW + 4 * (l32 & 7);
+    const int a_base = ((S2 * ZPW * wave) * PYP + S2 * (l32 >> 3)) * PROW + 4 * (l32 & 7);       // (the row of half h: frags)
     constexpr int ZSTEP = S2 * PYP * PROW;               // patch bytes between two output z-planes
     const int b_base = (h * CO + l32) * 16;              // row ky = 2u + h, column l32 (+32 for the second tile)
 
@@ -286,10 +289,14 @@ __global__ __launch_bounds__(256, ZPW == 2 ? 2 : (NBUF == 1 ? 3 : 2)) void stem_
 
     // fragments of k-step (kz, u) -> register set u & 1; the reads of step g+1 are issued before the MFMAs of step g
     bf16x8 af[2][ZPW][3], bf0[2][3], bf1[2][3];
-    auto frags = [&](int kz, int u, auto SETc) {
+    // k-step (slab sl, u): the lane's window row r = 8 sl + 2 u + h = (kz, ky) -> patch row kz PYP + ky; TAILc: the last
+    // k-step (sl = 6, u = 0), whose second row (r = 49) does not exist
+    auto frags = [&](int sl, int u, auto SETc, auto TAILc) {
         constexpr int SET = decltype(SETc)::value;
-        const unsigned char* wb = wl[kz % NBUF] + b_base + u * (2 * CO * 16);
-        const unsigned char* ab = patchb + a_base + (kz * PYP + 2 * u) * PROW;
+        constexpr bool TAIL = decltype(TAILc)::value;
+        const unsigned char* wb = wl[sl % NBUF] + b_base + u * (2 * CO * 16);
+        const int rr = 8 * sl + 2 * u + h;
+        const unsigned char* ab = patchb + a_base + ((rr / K7) * PYP + rr % K7) * PROW;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(256, ZPW == 2 ? 2 : (NBUF == 1 ? 3 : 2)) void stem_
                 v.y = *reinterpret_cast<const unsigned*>(ap + 4);
                 v.z = *reinterpret_cast<const unsigned*>(ap + 8);
                 v.w = *reinterpret_cast<const unsigned*>(ap + 12) & 0x0000ffffu;     // kx = 7 is padding: exact zero
-                if (u == 3 && h) v = u32x4{0u, 0u, 0u, 0u};                           // ky = 7 is padding
+                if (TAIL && h) v = u32x4{0u, 0u, 0u, 0u};                             // row 49 is padding
                 af[SET][zi][pl] = __builtin_bit_cast(bf16x8, v);
             }
             bf0[SET][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * WPL);
@@ -320,42 +327,49 @@ __global__ __launch_bounds__(256, ZPW == 2 ? 2 : (NBUF == 1 ? 3 : 2)) void stem_
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 
-    __syncthreads();
-    frags(0, 0, S0{});
-    for (int kz = 0; kz < K7; ++kz) {
+    using NoTail = std::false_type;
+    using Tail = std::true_type;
+    // one slab = four k-steps; `nextTail`: the k-step read at the end of this slab is the window's last one
+    auto slab_body = [&](int sl, auto nextTail) {
         if constexpr (NBUF == 2) {
-            // slab kz+1 (in registers since the previous iteration) -> the other buffer (last read during kz-1, before the
-            // barrier that ended it); then fetch slab kz+2
-            if (kz + 1 < K7) wstore((kz + 1) & 1);
-            wload(kz + 2);
+            // slab sl+1 (in registers since the previous iteration) -> the other buffer (last read during sl-1, before the
+            // barrier that ended it); then fetch slab sl+2
+            wstore((sl + 1) & 1);
+            wload(sl + 2);
         }
         __builtin_amdgcn_sched_barrier(0);
-        frags(kz, 1, S1{});
+        frags(sl, 1, S1{}, NoTail{});
         __builtin_amdgcn_sched_barrier(0);
         mfmas(S0{});
         __builtin_amdgcn_sched_barrier(0);
-        frags(kz, 2, S0{});
+        frags(sl, 2, S0{}, NoTail{});
         __builtin_amdgcn_sched_barrier(0);
         mfmas(S1{});
         __builtin_amdgcn_sched_barrier(0);
-        frags(kz, 3, S1{});
+        frags(sl, 3, S1{}, NoTail{});
         __builtin_amdgcn_sched_barrier(0);
         mfmas(S0{});
-        __syncthreads();                                   // NBUF 2: slab kz+1 visible; both: slab kz fully read
+        __syncthreads();                                   // NBUF 2: slab sl+1 visible; both: slab sl fully read
         if constexpr (NBUF == 1) {
-            // slab kz+1 (in registers) over slab kz, under the last k-step's MFMAs; then fetch slab kz+2
-            if (kz + 1 < K7) wstore(0);
-            wload(kz + 2);
+            // slab sl+1 (in registers) over slab sl, under the last k-step's MFMAs; then fetch slab sl+2
+            wstore(0);
+            wload(sl + 2);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(S1{});
-            __syncthreads();                               // slab kz+1 visible
-            if (kz + 1 < K7) frags(kz + 1, 0, S0{});
+            __syncthreads();                               // slab sl+1 visible
+            frags(sl + 1, 0, S0{}, nextTail);
         } else {
-            if (kz + 1 < K7) frags(kz + 1, 0, S0{});
+            frags(sl + 1, 0, S0{}, nextTail);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(S1{});
         }
-    }
+    };
+    __syncthreads();
+    frags(0, 0, S0{}, NoTail{});
+    for (int sl = 0; sl < K7 - 2; ++sl) slab_body(sl, NoTail{});        // slabs 0 .. 4 (rows 0 .. 39)
+    slab_body(K7 - 2, Tail{});                                          // slab 5, and the read of (slab 6, u = 0)
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(S0{});                                                        // row 48 (+ the padding row): the 25th k-step
 
     // ---- epilogue: C/D layout col = lane & 31 (channel), row = (r&3) + 8*(r>>2) + 4*h (output voxel) ----
     float cs[2][2];                                      // [column tile][sum, sum of squares] of what is stored
