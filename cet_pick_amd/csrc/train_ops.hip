@@ -1217,13 +1217,83 @@ extern "C" int mi_maxpool3d_fwd(const float* x, float* y, uint8_t* argmax, int N
     return MI_OK;
 }
 
+// Round 4: the stem's pool (k = 3, stride 2, padding 1) for planes of Wi * C / 4 = 256 vectors.  maxpool_bwd_kernel<2> spends ~500
+// instructions per wave on ONE output vector per thread (281 scalar + 206 vector: row decode with runtime divisors, 64-bit offsets
+// and tap indices of eight candidates) - 64 waves per SIMD x 2,100 issue cycles = the 55 us it takes, whatever its memory traffic
+// (profiles/r04_experiments.txt item 24).  Here a workgroup owns an input plane (n, zi), stages the one or two pooled planes that
+// contain it (argmax bytes + gradients) in LDS, and a thread keeps its (x, channel vector) column and walks y: which pooled windows
+// contain a coordinate, and at which tap, depends only on the coordinate's PARITY (even: one window, tap 1; odd: two, taps 2 and 0),
+// so the candidates are fixed per thread (x), per workgroup (z) and per unrolled half-iteration (y), a hit test is one XOR and a
+// has-zero-byte test on the argmax word, and the gradient vector is read only behind a hit.  Candidates are visited in (zo, yo, xo)
+// order as in the generic kernel: the sums are bit-identical.
+__global__ __launch_bounds__(256) void maxpool_bwd_k3s2_kernel(const float* dy, const uint8_t* arg, float* dx, int Di, int Hi, int Wi,
+                                                              int C, int Do, int Ho, int Wo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pool_lds[];
+    const int plane_o = Ho * Wo * C;                     // elements of one pooled plane
+    float* s_dy = reinterpret_cast<float*>(pool_lds);    // [2][Ho][Wo][C]
+    uint8_t* s_arg = pool_lds + 2 * (size_t)plane_o * sizeof(float);      // [2][Ho][Wo][C]
+    const int zi = blockIdx.x % Di, n = blockIdx.x / Di;
+    // windows along z: zi even -> zo = zi / 2 at tap 1; odd -> zo = (zi - 1) / 2 at tap 2 and (zi + 1) / 2 at tap 0 (if inside)
+    const int z0 = zi >> 1;
+    const int nz = (zi & 1) ? ((z0 + 1 < Do) ? 2 : 1) : 1;
+    for (int q = threadIdx.x; q < nz * plane_o / 4; q += 256) {
+        const int zq = q / (plane_o / 4), r = q % (plane_o / 4);
+        const long src = ((long)n * Do + z0 + zq) * plane_o + 4 * r;
+        *reinterpret_cast<float4*>(s_dy + zq * plane_o + 4 * r) = ld4(dy + src);
+        *reinterpret_cast<unsigned*>(s_arg + zq * plane_o + 4 * r) = *reinterpret_cast<const unsigned*>(arg + src);
+    }
+    __syncthreads();
+    const int CV = C >> 2;
+    const int cv = threadIdx.x % CV, xi = threadIdx.x / CV;          // (Wi * CV == 256: host check)
+    // the thread's x candidates: byte offset of (xo, channels 4 cv ..) inside a pooled row, and the x tap
+    const int x0 = xi >> 1;
+    const int nx = (xi & 1) ? ((x0 + 1 < Wo) ? 2 : 1) : 1;
+    const int xoff0 = x0 * C + 4 * cv, xoff1 = xoff0 + C;
+    const int tx0 = (xi & 1) ? 2 : 1;                    // (tap of the second candidate: 0)
+    float* out = dx + 4 * ((((long)n * Di + zi) * Hi * Wi + xi) * CV + cv);
+    const long ystride = 4l * Wi * CV;
+    for (int yi = 0; yi < Hi; ++yi) {
+        const int y0 = yi >> 1;
+        const int ny = (yi & 1) ? ((y0 + 1 < Ho) ? 2 : 1) : 1;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < nz; ++a) {
+            const int tz = (zi & 1) ? (a ? 0 : 2) : 1;
+            for (int b = 0; b < ny; ++b) {
+                const int ty = (yi & 1) ? (b ? 0 : 2) : 1;
+                const int rowb = (a * Ho + y0 + b) * Wo * C;          // byte offset of the pooled row in s_arg (x 4 in s_dy)
+                const int tzy = (tz * 3 + ty) * 3;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (c >= nx) break;
+                    const int o = rowb + (c ? xoff1 : xoff0);
+                    const unsigned tp = (unsigned)(tzy + (c ? 0 : tx0));
+                    const unsigned x = *reinterpret_cast<const unsigned*>(s_arg + o) ^ (tp * 0x01010101u);     // zero byte = hit
+                    if (((x - 0x01010101u) & ~x & 0x80808080u) != 0u) {
+                        const float4 d = *reinterpret_cast<const float4*>(s_dy + o);
+                        if ((x & 0x000000ffu) == 0u) acc[0] += d.x;
+                        if ((x & 0x0000ff00u) == 0u) acc[1] += d.y;
+                        if ((x & 0x00ff0000u) == 0u) acc[2] += d.z;
+                        if ((x & 0xff000000u) == 0u) acc[3] += d.w;
+                    }
+                }
+            }
+        }
+        st4(out + yi * ystride, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    }
+}
+
 extern "C" int mi_maxpool3d_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, int Di,
                                 int Hi, int Wi, int C, int k, int stride, int pad, mi_stream_t stream) {
     if (!dy || !argmax || !dx || C % 4 || k <= 0 || k > 6 || stride <= 0 || pad < 0) return MI_E_ARG;
     int Do = (Di + 2 * pad - k) / stride + 1, Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
     const long rows = (long)N * Di * Hi;
     if (rows >= (1l << 31)) return MI_E_UNSUPPORTED;
-    if (stride == 2)
+    const size_t lds_k3s2 = 2 * (size_t)Ho * Wo * C * 5;          // two pooled planes: gradients + argmax bytes
+    if (stride == 2 && k == 3 && pad == 1 && Wi * (C / 4) == 256 && lds_k3s2 <= 64 * 1024 && (long)N * Di < (1l << 31) &&
+        !getenv("MI_MAXPOOL_BWD_GENERIC"))
+        hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel, dim3((unsigned)(N * Di)), dim3(256), lds_k3s2, (hipStream_t)stream, dy, argmax, dx,
+                           Di, Hi, Wi, C, Do, Ho, Wo);
+    else if (stride == 2)
         hipLaunchKernelGGL(maxpool_bwd_kernel<2>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, N,
                            Di, Hi, Wi, C, Do, Ho, Wo, k, stride, pad);
     else if (stride == 1)

@@ -840,6 +840,30 @@ def test_cube2_final_launch_equals_partial_sums_plus_reduce(n, c, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 16, 16, 16, 64), (2, 5, 7, 16, 64), (3, 10, 12, 32, 32), (2, 2, 2, 64, 16), (1, 9, 3, 8, 128)])
+def test_maxpool_backward_parity_form_equals_generic(shape, monkeypatch):
+    """maxpool_bwd_k3s2_kernel (the stem's pool: a workgroup per input plane, pooled planes in LDS, candidates fixed by coordinate
+    parity; planes of Wi * C / 4 = 256 vectors) against the generic gather kernel (MI_MAXPOOL_BWD_GENERIC=1): BIT-identical - same
+    candidates, same order of additions - and both against torch's max_pool3d backward, also on odd depths / heights
+    (moco_encoder_3d.py:169)."""
+    from cet_pick_amd import hipops as H
+    n, d, h, w, c = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, c, d, h, w, generator=g)
+    xg = cl(x).requires_grad_(True)
+    y = H.maxpool3d(xg, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g).cuda()
+    (g_par,) = torch.autograd.grad(y, xg, dy, retain_graph=True)
+    monkeypatch.setenv("MI_MAXPOOL_BWD_GENERIC", "1")
+    (g_gen,) = torch.autograd.grad(y, xg, dy)
+    assert torch.equal(g_par, g_gen)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool3d(xr, 3, 2, 1)
+    yr.backward(dy.cpu().permute(0, 4, 1, 2, 3))
+    np.testing.assert_allclose(ncdhw(g_par).numpy(), xr.grad.numpy(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
 def test_conv_dispatch_by_shape(monkeypatch):
     """Which kernel family a convolution call takes (mi_debug_last_conv_kernel; tools/bench_conv.py --kernels prints the table):
     the encoder's shapes at the benchmark's crop size take the patch-resident kernels, other shapes the implicit GEMM, and the
