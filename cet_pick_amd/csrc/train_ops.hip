@@ -1226,21 +1226,28 @@ extern "C" int mi_maxpool3d_fwd(const float* x, float* y, uint8_t* argmax, int N
 // so the candidates are fixed per thread (x), per workgroup (z) and per unrolled half-iteration (y), a hit test is one XOR and a
 // has-zero-byte test on the argmax word, and the gradient vector is read only behind a hit.  Candidates are visited in (zo, yo, xo)
 // order as in the generic kernel: the sums are bit-identical.
+// (blockIdx.y: the plane is cut into gridDim.y bands of rows; a band stages only the pooled rows it needs: smaller workgroups, more of
+// them per CU and out of phase with each other - a workgroup's staging, candidate work and stores do not overlap by themselves)
 __global__ __launch_bounds__(256) void maxpool_bwd_k3s2_kernel(const float* dy, const uint8_t* arg, float* dx, int Di, int Hi, int Wi,
-                                                              int C, int Do, int Ho, int Wo) {
+                                                              int C, int Do, int Ho, int Wo, int band) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pool_lds[];
+    const int yb = blockIdx.y * band, ye = min(Hi, yb + band);       // this workgroup's rows
+    const int yo_lo = yb >> 1, yo_hi = min(Ho - 1, ye >> 1);           // pooled rows they can touch ((ye - 1 + 1) / 2)
+    const int Hb = band / 2 + 1;                         // pooled rows staged per plane (>= yo_hi - yo_lo + 1)
     const int plane_o = Ho * Wo * C;                     // elements of one pooled plane
-    float* s_dy = reinterpret_cast<float*>(pool_lds);    // [2][Ho][Wo][C]
-    uint8_t* s_arg = pool_lds + 2 * (size_t)plane_o * sizeof(float);      // [2][Ho][Wo][C]
+    const int plane_b = Hb * Wo * C;                     // ... of the staged band of it
+    float* s_dy = reinterpret_cast<float*>(pool_lds);    // [2][Hb][Wo][C]
+    uint8_t* s_arg = pool_lds + 2 * (size_t)plane_b * sizeof(float);      // [2][Hb][Wo][C]
     const int zi = blockIdx.x % Di, n = blockIdx.x / Di;
     // windows along z: zi even -> zo = zi / 2 at tap 1; odd -> zo = (zi - 1) / 2 at tap 2 and (zi + 1) / 2 at tap 0 (if inside)
     const int z0 = zi >> 1;
     const int nz = (zi & 1) ? ((z0 + 1 < Do) ? 2 : 1) : 1;
-    for (int q = threadIdx.x; q < nz * plane_o / 4; q += 256) {
-        const int zq = q / (plane_o / 4), r = q % (plane_o / 4);
-        const long src = ((long)n * Do + z0 + zq) * plane_o + 4 * r;
-        *reinterpret_cast<float4*>(s_dy + zq * plane_o + 4 * r) = ld4(dy + src);
-        *reinterpret_cast<unsigned*>(s_arg + zq * plane_o + 4 * r) = *reinterpret_cast<const unsigned*>(arg + src);
+    const int rows_b = (yo_hi - yo_lo + 1) * Wo * C / 4;              // vectors of the band that exist
+    for (int q = threadIdx.x; q < nz * rows_b; q += 256) {
+        const int zq = q / rows_b, r = q % rows_b;
+        const long src = ((long)n * Do + z0 + zq) * plane_o + (long)yo_lo * Wo * C + 4 * r;
+        *reinterpret_cast<float4*>(s_dy + zq * plane_b + 4 * r) = ld4(dy + src);
+        *reinterpret_cast<unsigned*>(s_arg + zq * plane_b + 4 * r) = *reinterpret_cast<const unsigned*>(arg + src);
     }
     __syncthreads();
     const int CV = C >> 2;
@@ -1252,7 +1259,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k3s2_kernel(const float* dy, 
     const int tx0 = (xi & 1) ? 2 : 1;                    // (tap of the second candidate: 0)
     float* out = dx + 4 * ((((long)n * Di + zi) * Hi * Wi + xi) * CV + cv);
     const long ystride = 4l * Wi * CV;
-    for (int yi = 0; yi < Hi; ++yi) {
+    for (int yi = yb; yi < ye; ++yi) {
         const int y0 = yi >> 1;
         const int ny = (yi & 1) ? ((y0 + 1 < Ho) ? 2 : 1) : 1;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1260,7 +1267,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k3s2_kernel(const float* dy, 
             const int tz = (zi & 1) ? (a ? 0 : 2) : 1;
             for (int b = 0; b < ny; ++b) {
                 const int ty = (yi & 1) ? (b ? 0 : 2) : 1;
-                const int rowb = (a * Ho + y0 + b) * Wo * C;          // byte offset of the pooled row in s_arg (x 4 in s_dy)
+                const int rowb = (a * Hb + y0 + b - yo_lo) * Wo * C;  // byte offset of the pooled row in s_arg (x 4 in s_dy)
                 const int tzy = (tz * 3 + ty) * 3;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -1288,11 +1295,15 @@ extern "C" int mi_maxpool3d_bwd(const float* dy, const uint8_t* argmax, float* d
     int Do = (Di + 2 * pad - k) / stride + 1, Ho = (Hi + 2 * pad - k) / stride + 1, Wo = (Wi + 2 * pad - k) / stride + 1;
     const long rows = (long)N * Di * Hi;
     if (rows >= (1l << 31)) return MI_E_UNSUPPORTED;
-    const size_t lds_k3s2 = 2 * (size_t)Ho * Wo * C * 5;          // two pooled planes: gradients + argmax bytes
+    // bands of rows per plane: 4 rows each by default (MI_MAXPOOL_BWD_BAND: tuning), the staged pooled rows of a band in LDS
+    int band = 4;
+    if (const char* v = getenv("MI_MAXPOOL_BWD_BAND")) { const int bv = atoi(v); if (bv >= 2 && bv % 2 == 0) band = bv; }
+    if (band > Hi) band = (Hi + 1) & ~1;
+    const size_t lds_k3s2 = 2 * (size_t)(band / 2 + 1) * Wo * C * 5;          // two pooled bands: gradients + argmax bytes
     if (stride == 2 && k == 3 && pad == 1 && Wi * (C / 4) == 256 && lds_k3s2 <= 64 * 1024 && (long)N * Di < (1l << 31) &&
         !getenv("MI_MAXPOOL_BWD_GENERIC"))
-        hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel, dim3((unsigned)(N * Di)), dim3(256), lds_k3s2, (hipStream_t)stream, dy, argmax, dx,
-                           Di, Hi, Wi, C, Do, Ho, Wo);
+        hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel, dim3((unsigned)(N * Di), (unsigned)((Hi + band - 1) / band)), dim3(256), lds_k3s2,
+                           (hipStream_t)stream, dy, argmax, dx, Di, Hi, Wi, C, Do, Ho, Wo, band);
     else if (stride == 2)
         hipLaunchKernelGGL(maxpool_bwd_kernel<2>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, N,
                            Di, Hi, Wi, C, Do, Ho, Wo, k, stride, pad);
