@@ -239,12 +239,16 @@ constexpr int PW_MAXTAP = 27;
 struct PairWgradParams {
     const float* x;           // (N, VI voxels, CI)
     const float* dy;          // (N, VO voxels, CO)
-    float* dw;                // [ntaps][CI][CO]
+    float* dw;                // [ntaps][CI][CO]: final (S == 1) or slab 0 of S slabs
     int N, VI, VO, CI, CO, ntaps;
     unsigned x_bytes, dy_bytes;
+    // geometry of the pairs (round 4: any cubic volume): per axis, tap t connects outputs lo .. lo + len - 1 to inputs stride * o + t - pad
+    int Di, Do, stride, pad, ks;
+    int S;                    // segments of a tap's chain of (pair, sample chunk) iterations: S slabs [S][ntaps][CI][CO], summed by the caller
+    long slab_stride;         // floats between slabs
     unsigned char order[PW_MAXTAP];       // taps, heaviest first
-    unsigned char cnt[PW_MAXTAP];         // pairs of a tap
-    unsigned char vi[PW_MAXTAP][8], vo[PW_MAXTAP][8];
+    unsigned short cnt[PW_MAXTAP];        // pairs of a tap
+    unsigned char lo[PW_MAXTAP][3], len[PW_MAXTAP][3];   // [tap][z, y, x]
 };
 
 typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
@@ -258,9 +262,17 @@ __global__ __launch_bounds__(512, 2) void pair_wgrad_kernel(PairWgradParams p) {
     // takes - a workgroup's time is its chain of pair iterations (the centre tap has 8), so an iteration is cut in two
     const int wm = (wave >> 1) & 1, wn = wave & 1, kh = wave >> 2;
     const int ncb = p.CO >> 6, nib = p.CI >> 6;
-    const int tap = p.order[blockIdx.x / (nib * ncb)];
-    const int rem = blockIdx.x % (nib * ncb), ib = rem / ncb, cb = rem % ncb;
-    const int npairs = p.cnt[tap], nchunks = (p.N + 63) >> 6, total = npairs * nchunks;
+    const int tiles = nib * ncb;
+    const int rem = blockIdx.x % tiles, ts = blockIdx.x / tiles;
+    const int tap = p.order[ts / p.S];
+    const int seg = ts % p.S;
+    const int ib = rem / ncb, cb = rem % ncb;
+    const int npairs = p.cnt[tap], nchunks = (p.N + 63) >> 6;
+    // this workgroup's share of the tap's chain: iterations it0 .. total - 1 (S == 1: the whole chain, the tile is final)
+    const int all = npairs * nchunks, per = (all + p.S - 1) / p.S;
+    const int it0 = seg * per, total = min(all, it0 + per);
+    const int tz = tap / (p.ks * p.ks), ty = (tap / p.ks) % p.ks, tx = tap % p.ks;
+    const int lz = p.lo[tap][0], ly = p.lo[tap][1], lx = p.lo[tap][2], ny = p.len[tap][1], nx = p.len[tap][2];
 
     // staging: thread = (sample row, 8 channels): one unit of X and one of dY per block
     const __amdgpu_buffer_rsrc_t xrs = rsrc_of2(p.x, p.x_bytes), yrs = rsrc_of2(p.dy, p.dy_bytes);
@@ -268,19 +280,28 @@ __global__ __launch_bounds__(512, 2) void pair_wgrad_kernel(PairWgradParams p) {
     const int st_lds = (cg >> 2) * PW_HALF + srow * PW_ROW + (cg & 3) * 16;
     // three blocks in flight: an iteration (12 MFMAs per wave) is far shorter than an L2 / HBM round trip
     u32x4 ldx[3][2], ldy[3][2];
-    auto fetch = [&](auto Sc, int it) {
+    // the fetches walk the chain in order: (pair, sample chunk) of the NEXT fetch as counters, advanced like an odometer (pairs of a tap:
+    // output voxels of the tap's box, z-major - ascending output voxel).  (Divisions per fetch cost every wave ~170 scalar instructions.)
+    int f_it = it0, f_chunk = it0 % nchunks, f_px, f_py, f_pz;
+    { const int pr = it0 / nchunks; f_px = pr % nx; f_py = (pr / nx) % ny; f_pz = pr / (nx * ny); }
+    auto fetch = [&](auto Sc, int) {
         constexpr int S = decltype(Sc)::value;
-        const int pr = it / nchunks, n = (it % nchunks) * 64 + srow;
-        const bool ok = it < total && n < p.N;
-        const unsigned xo = ok ? 4u * (unsigned)(((long)n * p.VI + p.vi[tap][pr]) * p.CI + ib * 64 + cg * 8) : 0x80000000u;
-        const unsigned yo = ok ? 4u * (unsigned)(((long)n * p.VO + p.vo[tap][pr]) * p.CO + cb * 64 + cg * 8) : 0x80000000u;
+        const int n = f_chunk * 64 + srow;
+        const bool ok = f_it < total && n < p.N;
+        const int oz = lz + f_pz, oy = ly + f_py, ox = lx + f_px;
+        const int vo = (oz * p.Do + oy) * p.Do + ox;
+        const int vi = ((p.stride * oz + tz - p.pad) * p.Di + p.stride * oy + ty - p.pad) * p.Di + p.stride * ox + tx - p.pad;
+        ++f_it;
+        if (++f_chunk == nchunks) { f_chunk = 0; if (++f_px == nx) { f_px = 0; if (++f_py == ny) { f_py = 0; ++f_pz; } } }
+        const unsigned xo = ok ? 4u * (unsigned)(((long)n * p.VI + vi) * p.CI + ib * 64 + cg * 8) : 0x80000000u;
+        const unsigned yo = ok ? 4u * (unsigned)(((long)n * p.VO + vo) * p.CO + cb * 64 + cg * 8) : 0x80000000u;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             ldx[S][q] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo + 16u * q), 0, 0);
             ldy[S][q] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(yo + 16u * q), 0, 0);
         }
     };
-    auto store = [&](auto Sc) {
+    auto store = [&](auto Sc, int boff) {
         constexpr int S = decltype(Sc)::value;
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
@@ -294,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void pair_wgrad_kernel(PairWgradParams p) {
             cut8r(v, o);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                *reinterpret_cast<u32x4*>(lds + op * PW_OP + pl * PW_PLANE + st_lds) = __builtin_bit_cast(u32x4, o[pl]);
+                *reinterpret_cast<u32x4*>(lds + boff + op * PW_OP + pl * PW_PLANE + st_lds) = __builtin_bit_cast(u32x4, o[pl]);
         }
     };
     // fragment addresses (transposing read: this lane names row q4 of its 16-lane group's 4-row block; see
@@ -309,17 +330,14 @@ __global__ __launch_bounds__(512, 2) void pair_wgrad_kernel(PairWgradParams p) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 
-    auto body = [&](auto Sc, int it) {
-        store(Sc);
-        __syncthreads();
-        fetch(Sc, it + 3);                               // (behind the last block: out of range, zeros, never stored)
+    auto multiply = [&](int boff) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[3], bf[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                const unsigned char* ap = lds + a_base + pl * PW_PLANE + ks * 16 * PW_ROW;
-                const unsigned char* bp = lds + b_base + pl * PW_PLANE + ks * 16 * PW_ROW;
+                const unsigned char* ap = lds + boff + a_base + pl * PW_PLANE + ks * 16 * PW_ROW;
+                const unsigned char* bp = lds + boff + b_base + pl * PW_PLANE + ks * 16 * PW_ROW;
                 const bf16x4w alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4w*)(ap));
                 const bf16x4w ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4w*)(ap + 4 * PW_ROW));
                 const bf16x4w blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4w*)(bp));
@@ -330,15 +348,29 @@ __global__ __launch_bounds__(512, 2) void pair_wgrad_kernel(PairWgradParams p) {
 #pragma unroll
             for (int pr = 0; pr < 6; ++pr) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pr]], bf[PB[pr]], acc, 0, 0, 0);
         }
+    };
+    auto body = [&](auto Sc, auto, int it) {
+        store(Sc, 0);
+        __syncthreads();
+        fetch(Sc, it + 3);                               // (behind the last block: out of range, zeros, never stored)
+        multiply(0);
         __syncthreads();                                 // every wave has read this block before the next one is stored
     };
-    fetch(std::integral_constant<int, 0>{}, 0);
-    fetch(std::integral_constant<int, 1>{}, 1);
-    fetch(std::integral_constant<int, 2>{}, 2);
-    for (int it = 0; it < total; it += 3) {
-        body(std::integral_constant<int, 0>{}, it);
-        if (it + 1 < total) body(std::integral_constant<int, 1>{}, it + 1);
-        if (it + 2 < total) body(std::integral_constant<int, 2>{}, it + 2);
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    fetch(I0{}, it0);
+    fetch(I1{}, it0 + 1);
+    fetch(I2{}, it0 + 2);
+    // (whole rounds of three without a branch between the bodies: the compiler's wait counts then name the oldest block only - with the
+    // tail's conditions inside the loop it drained the two younger blocks at every loop head)
+    int it = it0;
+    for (; it + 3 <= total; it += 3) {
+        body(I0{}, I1{}, it);
+        body(I1{}, I2{}, it + 1);
+        body(I2{}, I0{}, it + 2);
+    }
+    if (it < total) {
+        body(I0{}, I1{}, it);
+        if (it + 1 < total) body(I1{}, I2{}, it + 1);
     }
     // the two k-halves meet in LDS (staging is over): waves 4..7 publish, waves 0..3 add (first half + second half) and store
     float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(lds);
@@ -349,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void pair_wgrad_kernel(PairWgradParams p) {
     __syncthreads();
     if (kh == 0) {
         // final tile: C/D layout col = lane & 31 (co), row = ci
-        float* out = p.dw + ((long)tap * p.CI + ib * 64 + 32 * wm) * p.CO + cb * 64 + 32 * wn + l32;
+        float* out = p.dw + seg * p.slab_stride + ((long)tap * p.CI + ib * 64 + 32 * wm) * p.CO + cb * 64 + 32 * wn + l32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[(long)((r & 3) + 8 * (r >> 2) + 4 * h) * p.CO] = acc[r] + red[wave][r][lane];
     }
@@ -542,40 +574,84 @@ bool mi_cube2_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int 
 }
 
 
-// weight gradient through pair_wgrad_kernel: k^3 window (k = 3, pad 1 or k = 1, pad 0), output volume 2 x 2 x 2, stride 1
-// (input 2^3) or 2 (input 4^3), channels multiples of 64
+// weight gradient through pair_wgrad_kernel: k^3 window (k = 3, pad 1 or k = 1, pad 0), cubic volumes, stride 1 or 2, channels multiples
+// of 64.  Round 3: outputs of 2 x 2 x 2 (layer3).  Round 4: any cubic output up to 8^3 - layer2 (4^3, up to 64 pairs per tap), layer2.0's
+// stride-2 convolution and 1 x 1 x 1 shortcut - with a tap's chain of pairs cut into S segments (S slabs, summed by the caller's reduce).
+namespace {
+struct PairGeom { int ntaps, maxcnt; long pairs; };
+PairGeom pair_geom(int Di, int k, int stride, PairWgradParams* p) {
+    const int pad = k == 3 ? 1 : 0, Do = (Di + 2 * pad - k) / stride + 1;
+    PairGeom r = {k * k * k, 0, 0};
+    for (int t = 0; t < r.ntaps; ++t) {
+        const int tt[3] = {t / (k * k), (t / k) % k, t % k};
+        int c = 1;
+        for (int a = 0; a < 3; ++a) {
+            int lo = Do, hi = -1;
+            for (int o = 0; o < Do; ++o) {
+                const int i = stride * o + tt[a] - pad;
+                if (i >= 0 && i < Di) { lo = std::min(lo, o); hi = std::max(hi, o); }
+            }
+            const int len = hi >= lo ? hi - lo + 1 : 0;
+            if (p) { p->lo[t][a] = (unsigned char)(len ? lo : 0); p->len[t][a] = (unsigned char)std::max(len, 1); }
+            c *= len;
+        }
+        if (p) p->cnt[t] = (unsigned short)c;
+        r.maxcnt = std::max(r.maxcnt, c);
+        r.pairs += c;
+    }
+    return r;
+}
+}  // namespace
+
 bool mi_pair_wgrad_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw,
                           int dd, int dh, int dw) {
     const char* off = getenv("MI_CONV_NO_DIRECT");
     if (off && atoi(off) != 0) return false;
-    if (kd != 3 || kh != 3 || kw != 3 || pd != 1 || ph != 1 || pw != 1 || dd != 1 || dh != 1 || dw != 1) return false;
-    if (!((stride == 1 && Di == 2) || (stride == 2 && Di == 4)) || Hi != Di || Wi != Di) return false;
+    if (kd != kh || kd != kw || pd != ph || pd != pw || dd != 1 || dh != 1 || dw != 1) return false;
+    if (!((kd == 3 && pd == 1) || (kd == 1 && pd == 0)) || (stride != 1 && stride != 2)) return false;
+    if (Hi != Di || Wi != Di || Di < 2) return false;
+    const int Do = (Di + 2 * pd - kd) / stride + 1;
+    // largest output extent taken: 2 (layer3) by default - on 4^3 (layer2) the segmented form is no faster than the implicit GEMM
+    // (r04_experiments.txt item 26); MI_PAIR_WGRAD_MAXOUT=4 (or 8) takes those too
+    const char* wide = getenv("MI_PAIR_WGRAD_MAXOUT");
+    if (Do < 1 || Do > (wide ? atoi(wide) : 2) || Do > 8) return false;
     if (Ci < 64 || Co < 64 || (Ci & 63) || (Co & 63)) return false;
-    return N >= 1 && 4l * N * Di * Hi * Wi * Ci < 0x7fff0000l && 4l * N * 8 * Co < 0x7fff0000l;
+    return N >= 1 && 4l * N * Di * Hi * Wi * Ci < 0x7fff0000l && 4l * N * Do * Do * Do * Co < 0x7fff0000l;
 }
 
-int mi_pair_wgrad_launch(const float* x, const float* dy, float* dwt, int N, int Di, int Ci, int Co, int stride, hipStream_t s) {
+// segments of a tap's chain: about eight iterations per workgroup (four while that leaves CUs without one), at most 16
+int mi_pair_wgrad_splits(int N, int Di, int Ci, int Co, int k, int stride) {
+    const PairGeom g = pair_geom(Di, k, stride, nullptr);
+    if (g.maxcnt <= 8) return 1;                                   // 2^3 outputs: final in one launch (round 3)
+    const char* e = getenv("MI_PAIR_WGRAD_SPLITS");
+    if (e && atoi(e) > 0) return std::min(atoi(e), 64);
+    const int iters = g.maxcnt * ((N + 63) / 64), tiles = (Ci / 64) * (Co / 64);
+    int S = (iters + 7) / 8;
+    if (g.ntaps * tiles * S < 256) S = (iters + 3) / 4;
+    return std::max(1, std::min(S, 16));
+}
+size_t mi_pair_wgrad_slab_bytes(int N, int Di, int Ci, int Co, int k, int stride) {
+    const int S = mi_pair_wgrad_splits(N, Di, Ci, Co, k, stride);
+    return S > 1 ? sizeof(float) * (size_t)S * k * k * k * Ci * Co : 0;
+}
+
+// S == 1: `dwt` is final.  S > 1 (mi_pair_wgrad_splits): S slabs of [k^3][Ci][Co] floats into `slabs`; the caller sums them
+int mi_pair_wgrad_launch(const float* x, const float* dy, float* dwt, float* slabs, int N, int Di, int Ci, int Co, int k, int stride,
+                         hipStream_t s) {
     PairWgradParams p = {};
-    p.x = x; p.dy = dy; p.dw = dwt; p.N = N; p.VI = Di * Di * Di; p.VO = 8; p.CI = Ci; p.CO = Co; p.ntaps = 27;
-    p.x_bytes = (unsigned)(4l * N * p.VI * Ci); p.dy_bytes = (unsigned)(4l * N * 8 * Co);
-    for (int t = 0; t < 27; ++t) {
-        const int tz = t / 9, ty = (t / 3) % 3, tx = t % 3;
-        int c = 0;
-        for (int vo = 0; vo < 8; ++vo) {
-            const int iz = stride * ((vo >> 2) & 1) + tz - 1, iy = stride * ((vo >> 1) & 1) + ty - 1, ix = stride * (vo & 1) + tx - 1;
-            if (iz < 0 || iz >= Di || iy < 0 || iy >= Di || ix < 0 || ix >= Di) continue;
-            p.vi[t][c] = (unsigned char)((iz * Di + iy) * Di + ix);
-            p.vo[t][c] = (unsigned char)vo;
-            ++c;
-        }
-        p.cnt[t] = (unsigned char)c;
-    }
-    // heaviest taps first (stable); a tap without a pair (none with these geometries) would write zeros
+    const PairGeom g = pair_geom(Di, k, stride, &p);
+    const int pad = k == 3 ? 1 : 0, Do = (Di + 2 * pad - k) / stride + 1;
+    const int S = mi_pair_wgrad_splits(N, Di, Ci, Co, k, stride);
+    if (S > 1 && !slabs) return MI_E_ARG;
+    p.x = x; p.dy = dy; p.dw = S > 1 ? slabs : dwt; p.N = N; p.VI = Di * Di * Di; p.VO = Do * Do * Do; p.CI = Ci; p.CO = Co; p.ntaps = g.ntaps;
+    p.x_bytes = (unsigned)(4l * N * p.VI * Ci); p.dy_bytes = (unsigned)(4l * N * p.VO * Co);
+    p.Di = Di; p.Do = Do; p.stride = stride; p.pad = pad; p.ks = k; p.S = S; p.slab_stride = (long)g.ntaps * Ci * Co;
+    // heaviest taps first (stable); a tap without a pair (none with these geometries) writes zeros
     int n = 0;
-    for (int want = 8; want >= 0; --want)
-        for (int t = 0; t < 27; ++t)
+    for (int want = g.maxcnt; want >= 0; --want)
+        for (int t = 0; t < g.ntaps; ++t)
             if (p.cnt[t] == want) p.order[n++] = (unsigned char)t;
-    hipLaunchKernelGGL(pair_wgrad_kernel, dim3((unsigned)(27 * (Ci / 64) * (Co / 64))), dim3(512), 0, s, p);
+    hipLaunchKernelGGL(pair_wgrad_kernel, dim3((unsigned)(g.ntaps * (Ci / 64) * (Co / 64) * S)), dim3(512), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

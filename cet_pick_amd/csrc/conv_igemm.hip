@@ -78,7 +78,13 @@ int mi_cube2_launch(int dgrad, const float* a, const float* w, float* slabs, int
 // ... and the small dense products of the Linear layers (register-staged, final in one launch)
 bool mi_pair_wgrad_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw,
                           int dd, int dh, int dw);
-int mi_pair_wgrad_launch(const float* x, const float* dy, float* dwt, int N, int Di, int Ci, int Co, int stride, hipStream_t s);
+int mi_pairw_splits(int N, int Di, int Ci, int Co, int k, int stride);
+size_t mi_pairw_workspace_bytes(int N, int Di, int Ci, int Co, int k, int stride);
+int mi_pairw_launch(const float* x, const float* dy, float* dwt, void* ws, int N, int Di, int Ci, int Co, int k, int stride, hipStream_t s);
+int mi_pair_wgrad_splits(int N, int Di, int Ci, int Co, int k, int stride);
+size_t mi_pair_wgrad_slab_bytes(int N, int Di, int Ci, int Co, int k, int stride);
+int mi_pair_wgrad_launch(const float* x, const float* dy, float* dwt, float* slabs, int N, int Di, int Ci, int Co, int k, int stride,
+                         hipStream_t s);
 bool mi_small_gemm_usable(long M, long N, long K);
 int mi_small_gemm_launch(const float* a, long lda_m, long lda_k, long a_elems, const float* b, long ldb_k, long ldb_n,
                          long b_elems, const float* bias, float* c, int M, int N, int K, hipStream_t s,
@@ -1236,8 +1242,24 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
     if (mode == MODE_WGRAD && conv_arith_bf16x3() &&
         mi_pair_wgrad_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw))
     {
-        g_last_conv_kernel = "pair_wgrad";
-        return mi_pair_wgrad_launch(a_src, b_src, out, g.N, g.Di, g.Ci, g.Co, g.stride, s);
+        // MI_PAIRW=1: pre-cut operand images + LDS-DMA (conv_pairw.hip; measured, not faster: r04_experiments.txt item 26)
+        const char* pw = getenv("MI_PAIRW");
+        if (pw && atoi(pw) != 0 && ws && ws_bytes >= mi_pairw_workspace_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride)) {
+            const int splits = mi_pairw_splits(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride);
+            g_last_conv_kernel = splits > 1 ? "pairw + reduce" : "pairw";
+            int rc = mi_pairw_launch(a_src, b_src, out, ws, g.N, g.Di, g.Ci, g.Co, g.kd, g.stride, s);
+            if (rc || splits == 1) return rc;
+            if (defer_splits) { *defer_splits = splits; return MI_OK; }
+            return mi_direct3_finish_slabs((const float*)ws, splits, (long)g.kd * g.kh * g.kw * g.Ci * g.Co, out, nullptr, nullptr, 0, s);
+        }
+        const int splits = mi_pair_wgrad_splits(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride);
+        if (splits == 1 || (ws && ws_bytes >= mi_pair_wgrad_slab_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride))) {
+            g_last_conv_kernel = splits > 1 ? "pair_wgrad + reduce" : "pair_wgrad";
+            int rc = mi_pair_wgrad_launch(a_src, b_src, out, (float*)ws, g.N, g.Di, g.Ci, g.Co, g.kd, g.stride, s);
+            if (rc || splits == 1) return rc;
+            if (defer_splits) { *defer_splits = splits; return MI_OK; }
+            return mi_direct3_finish_slabs((const float*)ws, splits, (long)g.kd * g.kh * g.kw * g.Ci * g.Co, out, nullptr, nullptr, 0, s);
+        }
     }
     if (mode == MODE_WGRAD && dkind == 1 && ws && ws_bytes >= mi_direct3_wgrad_slab_bytes()) {
         g_last_conv_kernel = "direct3_wgrad + reduce";
@@ -1301,6 +1323,9 @@ extern "C" size_t mi_conv3d_workspace_bytes(int N, int Di, int Hi, int Wi, int C
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
     best = std::max(best, direct3_ws_bytes(g));
+    if (mi_pair_wgrad_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw))
+        best = std::max(std::max(best, mi_pair_wgrad_slab_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride)),
+                        mi_pairw_workspace_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride));
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;
@@ -1403,6 +1428,9 @@ extern "C" size_t mi_convnd_workspace_bytes(int N, int Di, int Hi, int Wi, int C
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
     best = std::max(best, direct3_ws_bytes(g));
+    if (mi_pair_wgrad_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw))
+        best = std::max(std::max(best, mi_pair_wgrad_slab_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride)),
+                        mi_pairw_workspace_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride));
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;
@@ -1474,6 +1502,9 @@ extern "C" size_t mi_convnd_dil_workspace_bytes(int N, int Di, int Hi, int Wi, i
     if (!geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return 0;
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
     best = std::max(best, direct3_ws_bytes(g));
+    if (mi_pair_wgrad_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw))
+        best = std::max(std::max(best, mi_pair_wgrad_slab_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride)),
+                        mi_pairw_workspace_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride));
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;

@@ -44,6 +44,8 @@ CASES = [
     (64, 1, 1, 1, 256, 128, 1, 1, 0),    # linear
     (70, 4, 4, 4, 64, 128, 3, 2, 1),     # 2^3 output, stride 2, two sample chunks: pair_wgrad_kernel
     (5, 2, 2, 2, 128, 64, 3, 1, 1),
+    (70, 4, 4, 4, 128, 128, 3, 1, 1),    # layer2, two sample chunks: pair_wgrad_kernel in segments (round 4)
+    (5, 6, 6, 6, 64, 64, 3, 2, 1),       # 3^3 output
 ]
 
 
@@ -861,6 +863,36 @@ def test_maxpool_backward_parity_form_equals_generic(shape, monkeypatch):
     yr = F.max_pool3d(xr, 3, 2, 1)
     yr.backward(dy.cpu().permute(0, 4, 1, 2, 3))
     np.testing.assert_allclose(ncdhw(g_par).numpy(), xr.grad.numpy(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["pair_wgrad", "pairw", "pairw64"])
+@pytest.mark.parametrize("case", [(64, 4, 128, 128, 3, 1), (70, 4, 128, 128, 3, 1), (9, 8, 64, 128, 3, 2), (9, 8, 64, 128, 1, 2),
+                                  (5, 6, 64, 64, 3, 2), (33, 2, 256, 128, 3, 1), (3, 8, 64, 64, 3, 1)])
+def test_pair_weight_gradient_forms_match_float64(case, form, monkeypatch):
+    """The opt-in weight-gradient kernels of round 4 (r04_experiments.txt item 26) on layer2 / layer2.0 / layer3 / layer1 shapes:
+    pair_wgrad_kernel with a tap's chain in segments (MI_PAIR_WGRAD_MAXOUT) and pairw_kernel from pre-cut operand images
+    (MI_PAIRW=1; 128 x 128 and 64 x 64 tiles) against float64, with the error bound of the default path (bf16x3 = f32-equivalent)."""
+    from cet_pick_amd import hipops as H, _lib as L
+    n, d, ci, co, k, s = case
+    pad = 1 if k == 3 else 0
+    monkeypatch.setenv("MI_PAIR_WGRAD_MAXOUT", "8")
+    monkeypatch.setenv("MI_PAIRW", "0" if form == "pair_wgrad" else "1")
+    if form == "pairw64":
+        monkeypatch.setenv("MI_PAIRW_B2", "1")
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, ci, d, d, d, generator=g)
+    param, w = make_w(co, ci, k, g)
+    x64 = x.double().cuda()
+    w64 = w.double().cuda().requires_grad_(True)
+    y64 = F.conv3d(x64, w64, stride=s, padding=pad)
+    dy = torch.randn(y64.shape, generator=g)
+    (gw,) = torch.autograd.grad(y64, w64, dy.double().cuda())
+    param.grad = None
+    H.conv_wgrad_into(cl(x), cl(dy), param, k, s, pad)
+    assert L.lib().mi_debug_last_conv_kernel().decode().startswith("pair_wgrad" if form == "pair_wgrad" else "pairw")
+    scale = float(gw.abs().max())
+    assert float((param.grad.double() - gw).abs().max()) <= 2e-6 * scale * max(1.0, (n * d ** 3 / 512) ** 0.5)
 
 
 @pytest.mark.gpu
