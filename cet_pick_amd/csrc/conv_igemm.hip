@@ -218,8 +218,11 @@ template <int MODE, int BM, int BN, int BK, bool STEM, bool BF3 = false>
 __global__ __launch_bounds__(NTHREADS, BF3 ? 3 : 1) void conv_igemm_kernel(ConvParams p) {
     static_assert(!BF3 || (!STEM && (BK == 16 || BK == 32)), "bf16x3 path: generic layers, 16- or 32-deep slices");
     static_assert(BK == 16 || BK == 32 || BK == 64, "slice depth");
-    static_assert(BN == 64 || BN == 128, "tile width");
-    constexpr int WM = 2, WN = 2;
+    static_assert(BN == 32 || BN == 64 || BN == 128, "tile width");
+    static_assert(BN != 32 || (BF3 && BM == 128 && BK == 32), "32-wide tiles: 128 rows, bf16x3, 32-deep slices");
+    // four waves: 2 x 2 wave tiles; a 32-column tile (round 4: the 32-channel layers of the detector's U-Net, where half of a
+    // 64-wide tile's MFMAs multiplied padding) stacks them 4 x 1
+    constexpr int WN = BN == 32 ? 1 : 2, WM = 4 / WN;
     constexpr int LDK = BK + 4;
     constexpr int KH = BK / 2;                       // k's owned by one lane-half per slice
     constexpr int KC = BK / 4;                       // 16-B chunks along k per RowK row
@@ -897,6 +900,13 @@ Plan make_plan(int mode, bool stem, long M, int Ncols, long red_len, int red_ch,
     if (int v = env_int("MI_CONV_BK")) if ((v == 16 || v == 32 || v == 64) && (red_ch == 0 || red_ch % v == 0)) pl.bk = v;
     if (pl.bk != 32 || stem) pl.bn = 64;
     if (pl.bk == 64 && (stem || pl.bm != 128)) pl.bk = 32;     // 64-deep slices: 128x64 tiles only
+    // forward convolutions with at most 32 output channels (the detector's 32-channel layers and head): 128 x 32 tiles, where
+    // there are rows for two workgroups per CU (MI_CONV_NARROW=0: the 64 x 64 tile with half its columns empty)
+    {
+        const char* nv = getenv("MI_CONV_NARROW");
+        if (mode == MODE_FWD && !stem && Ncols <= 32 && pl.bk == 32 && pl.bm == 64 && pl.bn == 64 && conv_arith_bf16x3() &&
+            !(nv && atoi(nv) == 0) && tiles_x_of(128) >= 512) { pl.bm = 128; pl.bn = 32; }
+    }
     pl.tiles_x = tiles_x_of(pl.bm);
     const long tiles = pl.tiles_x * ((Ncols + pl.bn - 1) / pl.bn);
     const long nk = (red_len + pl.bk - 1) / pl.bk;
@@ -933,6 +943,13 @@ int launch_mode(const ConvParams& p, const Plan& pl, hipStream_t s) {
         // (a 128 x 64 bf16x3 tile was built and measured in round 2: layer-1 forward 100.6 us against 52.8 us, layer-2
         // 43.4 against 33.4, layer-3 25.0 against 23.7 - a batch-64 step does not have the rows for it: 32,768 im2col
         // rows are 256 tiles of 128, one per CU)
+        if constexpr (MODE == MODE_FWD) {
+            if (conv_arith_bf16x3() && pl.bm == 128 && pl.bn == 32 && pl.bk == 32) {
+                hipLaunchKernelGGL((conv_igemm_kernel<MODE, 128, 32, 32, false, true>), grid, dim3(NTHREADS), 0, s, p);
+                MI_RETURN_IF_LAUNCH_FAILED();
+                return MI_OK;
+            }
+        }
         if (conv_arith_bf16x3() && pl.bm == 64 && pl.bn == 64 && (pl.bk == 32 || pl.bk == 16)) {
             if (pl.bk == 32) hipLaunchKernelGGL((conv_igemm_kernel<MODE, 64, 64, 32, false, true>), grid, dim3(NTHREADS), 0, s, p);
             else hipLaunchKernelGGL((conv_igemm_kernel<MODE, 64, 64, 16, false, true>), grid, dim3(NTHREADS), 0, s, p);

@@ -51,6 +51,40 @@ def test_dilated_conv_fwd_dgrad_wgrad(shape, k, pad, dil):
     np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("shape,co,k,pad,dil", [((2, 1, 256, 256, 32), 32, (1, 3, 3), (0, 1, 1), None),      # U-Net 32 -> 32
+                                                ((3, 1, 150, 151, 64), 32, (1, 3, 3), (0, 1, 1), None),      # ragged rows, 64 -> 32
+                                                ((1, 16, 64, 65, 32), 32, (3, 3, 3), (1, 4, 4), (1, 4, 4)),  # the dilated head
+                                                ((2, 1, 256, 256, 32), 16, (1, 3, 3), (0, 1, 1), None),      # 16 of the 32 columns
+                                                ((1, 1, 300, 300, 32), 32, (1, 1, 1), (0, 0, 0), None)])     # 1 x 1
+def test_narrow_tile_forward_matches_wide_tile_and_float64(shape, co, k, pad, dil, monkeypatch):
+    """conv_igemm_kernel<FWD, 128, 32, 32> (round 4: forward convolutions with at most 32 output channels on 128 x 32 tiles) against
+    the 64 x 64 tile it replaces (MI_CONV_NARROW=0) and float64: same cut, same six products, same slice order - the two tiles agree
+    to rounding-order noise, and both hold the f32-equivalent bound; with the fused residual + ReLU epilogue as well
+    (models/networks/unet_small.py:30-97)."""
+    from cet_pick_amd import hipops as H, _lib as L
+    n, d, h, w, ci = shape
+    g = torch.Generator().manual_seed(sum(shape) + co)
+    x = torch.randn(n, ci, d, h, w, generator=g)
+    wt = torch.randn(co, ci, *k, generator=g) * (2.0 / (ci * k[0] * k[1] * k[2])) ** 0.5
+    y64 = F.conv3d(x.double().cuda(), wt.double().cuda(), padding=pad, dilation=dil or 1)
+    wk = wt.permute(2, 3, 4, 1, 0).contiguous().cuda().permute(4, 3, 0, 1, 2)
+    xc = _cl(x)
+    res = torch.randn(y64.shape, generator=g)
+    outs = {}
+    for narrow in ("1", "0"):
+        monkeypatch.setenv("MI_CONV_NARROW", narrow)
+        y = H.conv_fwd(xc, wk, k, 1, pad, dil=dil)
+        outs[narrow] = (y, H.conv_fwd(xc, wk, k, 1, pad, _cl(res), True, dil=dil))
+    ref = y64.permute(0, 2, 3, 4, 1)
+    scale = float(ref.abs().max())
+    e_n = float((outs["1"][0].double() - ref).abs().max())
+    e_w = float((outs["0"][0].double() - ref).abs().max())
+    assert e_n <= 2e-6 * scale and e_n <= 1.5 * e_w + 1e-7 * scale
+    assert float((outs["1"][0] - outs["0"][0]).abs().max()) <= 1e-6 * scale
+    ref2 = torch.relu(ref + _cl(res).double())
+    assert float((outs["1"][1].double() - ref2).abs().max()) <= 2e-6 * max(scale, float(ref2.abs().max()))
+
+
 @pytest.mark.parametrize("h,w", [(16, 16), (13, 9), (1, 7)])
 def test_maxpool2d_ceil(h, w):
     from cet_pick_amd import _lib as L
