@@ -85,6 +85,26 @@ def test_narrow_tile_forward_matches_wide_tile_and_float64(shape, co, k, pad, di
     assert float((outs["1"][1].double() - ref2).abs().max()) <= 2e-6 * max(scale, float(ref2.abs().max()))
 
 
+@pytest.mark.parametrize("rows,c", [(4096, 32), (70001, 32), (5000, 16), (4099, 64)])
+def test_l2norm_rows_of_few_channels_equal_the_wave_per_row_kernel(rows, c, monkeypatch):
+    """l2norm_small_fwd_kernel (C / 4 lanes per row; the detector's projection head, unet_small.py:93-97 `F.normalize(proj, dim=1)`)
+    against the wave-per-row kernel (MI_L2NORM_GENERIC=1): BIT-identical rows and norms (the butterfly's order of additions is kept),
+    a zero row included, and both against torch."""
+    from cet_pick_amd import hipops as H
+    g = torch.Generator().manual_seed(rows + c)
+    x = (torch.randn(rows, c, generator=g) * torch.exp(2 * torch.randn(rows, 1, generator=g)))
+    x[7] = 0.0
+    xc = x.cuda().requires_grad_(True)
+    y_small = H.l2_normalize(xc)
+    dy = torch.randn(rows, c, generator=g).cuda()
+    (gx_small,) = torch.autograd.grad(y_small, xc, dy)
+    monkeypatch.setenv("MI_L2NORM_GENERIC", "1")
+    y_gen = H.l2_normalize(xc)
+    (gx_gen,) = torch.autograd.grad(y_gen, xc, dy)
+    assert torch.equal(y_small.detach(), y_gen.detach()) and torch.equal(gx_small, gx_gen)
+    np.testing.assert_allclose(y_small.detach().cpu().numpy(), F.normalize(x, dim=1).numpy(), rtol=2e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("h,w", [(16, 16), (13, 9), (1, 7)])
 def test_maxpool2d_ceil(h, w):
     from cet_pick_amd import _lib as L
