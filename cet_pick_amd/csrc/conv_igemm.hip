@@ -1211,7 +1211,7 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         }
     }
     // the 7^3 stride-2 stem has its own direct kernels (conv_stem.hip); anything they decline runs below
-    if (is_stem7(g) && !env_int("MI_CONV_NO_STEM")) {
+    if (is_stem7(g) && !env_int("MI_CONV_NO_STEM") && !res_bcast) {
         int rc = MI_E_UNSUPPORTED;
         if (mode == MODE_FWD)
             rc = mi_stem7_fwd(a_src, b_src, out, res, relu, g.N, g.Di, g.Hi, g.Wi, g.Co, conv_arith_bf16x3() ? 1 : 0, ws,
@@ -1234,7 +1234,7 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         if (mode == MODE_WGRAD && mi_small_gemm_usable(g.Ci, g.Co, g.N))
             return mi_small_gemm_launch(a_src, 1, g.Ci, xe, b_src, g.Co, 1, ye, nullptr, out, g.Ci, g.Co, g.N, s);
     }
-    const int dkind = conv_arith_bf16x3() ? direct3_kind(g) : 0;
+    const int dkind = (conv_arith_bf16x3() && !res_bcast) ? direct3_kind(g) : 0;      // (a bias row: the generic kernel's epilogue)
     const size_t dimg = mi_align_up(mi_direct3_wimg_bytes_kind(dkind), 256);
     if (mode != MODE_WGRAD && dkind && ws && ws_bytes >= dimg) {
         const float* wl[1] = {b_src};
@@ -1249,7 +1249,7 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         if (dkind == 3) return mi_direct3_launch128(a_src, ws, out, res, mask, relu, g.N, g.Di, s);
         return mi_direct3s_launch(a_src, ws, out, res, mask, relu, g.N, s);       // 128-channel kernel on 4^3: final as well
     }
-    if (mode != MODE_WGRAD && conv_arith_bf16x3() && is_cube2(g) && ws && ws_bytes >= mi_cube2_slab_bytes(g.N, g.Ci)) {
+    if (mode != MODE_WGRAD && conv_arith_bf16x3() && !res_bcast && is_cube2(g) && ws && ws_bytes >= mi_cube2_slab_bytes(g.N, g.Ci)) {
         g_last_conv_kernel = "cube2 + reduce";
         int rc = mi_cube2_launch(mode == MODE_DGRAD ? 1 : 0, a_src, b_src, (float*)ws, g.N, g.Ci, s);
         if (rc) return rc;
@@ -1463,6 +1463,18 @@ extern "C" int mi_convnd_fwd_f32(const float* x, const float* w, float* y, const
     Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
     if (!x || !w || !y || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
     return run_conv(MODE_FWD, g, x, w, y, res, nullptr, relu, ws, ws_bytes, (hipStream_t)stream);
+}
+
+/* y = act(conv(x, w) + bias[co]) - the same launch with the residual read as ONE row of Co values.  Evaluation-mode BatchNorm
+ * folds into it (w' = w * gamma / sqrt(var + eps) per output channel, bias = beta - mean * gamma / sqrt(var + eps)): the detector's
+ * U-Net at inference (models/networks/unet_small.py:30-97, unet.py:198-399: conv -> BatchNorm -> ReLU) drops its BatchNorm passes. */
+extern "C" int mi_convnd_fwd_bias_f32(const float* x, const float* w, float* y, const float* bias, int relu,
+                                      int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw,
+                                      int stride, int pd, int ph, int pw, void* ws, size_t ws_bytes,
+                                      mi_stream_t stream) {
+    Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
+    if (!x || !w || !y || !bias || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
+    return run_conv(MODE_FWD, g, x, w, y, bias, nullptr, relu, ws, ws_bytes, (hipStream_t)stream, nullptr, 1);
 }
 
 extern "C" int mi_convnd_dgrad_f32(const float* dy, const float* w, float* dx, const float* res,

@@ -631,6 +631,63 @@ class _ConvFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None):
+    """y = act(conv(x, w) + bias[co]) in one launch (mi_convnd_fwd_bias_f32), inference only: no autograd node.  `out`: a
+    contiguous (N, [D,] Ho, Wo, Co) tensor (or a leading-axis slice of one) that receives the result."""
+    _f32c(x, "x")
+    if not _phys_ok(w):
+        raise L.HipExtensionError("conv weight is not in kernel layout [tap][Cin][Cout]")
+    nd5 = x.dim() == 5
+    k3, p3 = _k3(k, nd5), _p3(pad, nd5)
+    x5 = _as5d(x)
+    n, d, h, wd, ci = x5.shape
+    co = w.shape[0]
+    do, ho, wo = _out_dims(x5.shape, k3, stride, p3)
+    shape = (n, do, ho, wo, co) if nd5 else (n, ho, wo, co)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise L.HipExtensionError("conv_bias_fwd: `out` must be a contiguous fp32 %s tensor on %s" % (shape, x.device))
+    lib = L.lib()
+    ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), x.device, "conv")
+    def call():
+        return L.check(lib.mi_convnd_fwd_bias_f32(L.ptr(x), L.ptr(w), L.ptr(out), L.ptr(_f32c(bias, "bias")), int(relu), n, d, h,
+            wd, ci, co, *k3, stride, *p3, L.ptr(ws), ws.numel(), L.stream()), "mi_convnd_fwd_bias_f32")
+    _prof_run("fwd", 2.0 * n * do * ho * wo * co * ci * k3[0] * k3[1] * k3[2], call)
+    return out
+
+
+def conv_bn(conv, bn, x, relu=False):
+    """bn(conv(x), relu) for a HipConv2d / HipConvNd followed by a HipBatchNorm.  At inference (evaluation-mode BatchNorm with
+    running statistics, no gradient) the BatchNorm folds into the convolution: w' = w * gamma / sqrt(var + eps) per output
+    channel, bias = beta - mean * gamma / sqrt(var + eps), one launch with a bias + ReLU epilogue and no BatchNorm pass over
+    the activation (reference: conv -> BatchNorm2d -> ReLU, models/networks/unet.py:198-249,319-399).  The folded weights are
+    kept on the BatchNorm module and rebuilt when any of the five tensors they come from changes."""
+    folded = (not bn.training and bn.track_running_stats and not torch.is_grad_enabled() and x.is_cuda and
+              getattr(conv, "dil", None) in (None, (1, 1, 1)) and FOLD_EVAL_BN)
+    if not folded:
+        return bn(conv(x), relu=relu)
+    src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (float(bn.eps),)
+    cache = getattr(bn, "_folded", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            inv = torch.rsqrt(bn.running_var.double() + bn.eps)
+            sc = inv if bn.weight is None else bn.weight.double() * inv
+            sh = -bn.running_mean.double() * sc
+            if bn.bias is not None:
+                sh = sh + bn.bias.double()
+            wf = (conv.weight.double() * sc.view(-1, *([1] * (conv.weight.dim() - 1)))).float()
+            cache = (key, wf, sh.float().contiguous())
+        if not _phys_ok(wf):
+            raise L.HipExtensionError("folded convolution weight left the kernel layout")
+        bn._folded = cache
+    return conv_bias_fwd(x, cache[1], cache[2], conv.k, conv.stride, conv.pad, relu)
+
+
+FOLD_EVAL_BN = os.environ.get("CETPICK_FOLD_BN", "1") != "0"
+
+
 def convnd_weight_param(co, ci, k3, device=None):
     """Parameter with logical shape (co, ci, kd, kh, kw) over physical storage [kd,kh,kw,ci,co]."""
     phys = torch.empty(*k3, ci, co, device=device)

@@ -36,8 +36,8 @@ class DownConv(nn.Module):
         self.norm1 = H.HipBatchNorm(co)
 
     def forward(self, x):
-        y = self.norm0(self.conv1(x), relu=True)
-        y = self.norm1(self.conv2(y), relu=True)
+        y = H.conv_bn(self.conv1, self.norm0, x, relu=True)
+        y = H.conv_bn(self.conv2, self.norm1, y, relu=True)
         return (H.maxpool2d_ceil(y, 2) if self.pooling else y), y
 
 
@@ -59,8 +59,8 @@ class UpConv(nn.Module):
         if not (2 * h - 1 <= ho <= 2 * h and 2 * w - 1 <= wo <= 2 * w):
             raise L.HipExtensionError("encoder / decoder extents do not match (%s vs 2x%s)" % (tuple(enc.shape), tuple(dec.shape)))
         up = self.norm0(self.upconv(dec, ho, wo), relu=True)
-        y = self.norm1(self.conv1(H.concat_channels(up, enc)), relu=True)
-        return self.norm2(self.conv2(y), relu=True)
+        y = H.conv_bn(self.conv1, self.norm1, H.concat_channels(up, enc), relu=True)
+        return H.conv_bn(self.conv2, self.norm2, y, relu=True)
 
 
 class UNet(nn.Module):
@@ -88,14 +88,21 @@ class UNet(nn.Module):
                 if getattr(m, "bias", None) is not None:
                     nn.init.constant_(m.bias, 0)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out (inference only): the tensor - e.g. a slice of the volume's feature map - that receives the result."""
         skips = []
         for blk in self.down_convs:
             x, before_pool = blk(x)
             skips.append(before_pool)
         for i, blk in enumerate(self.up_convs):
             x = blk(skips[-(i + 2)], x)
-        return H.bias_add(self.conv_final(x), self.conv_final)
+        if not torch.is_grad_enabled() and x.is_cuda and H.FOLD_EVAL_BN:      # the 1 x 1 convolution with its bias in the epilogue
+            return H.conv_bias_fwd(x, self.conv_final.weight, self.conv_final.bias, 1, 1, 0, out=out)
+        y = H.bias_add(self.conv_final(x), self.conv_final)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
 
 
 class TomoConvUNet(nn.Module):
@@ -130,13 +137,13 @@ class TomoConvUNet(nn.Module):
             # 128 x 512 x 512 volume - exist for one chunk only; what stays is the 32-channel feature volume the 3-D head reads
             y = None
             for c0 in range(0, b * d, chunk):
-                yc = self.unet(self.bn1(self.conv1(x[c0:c0 + chunk]), relu=True))
-                if y is None:
-                    y = torch.empty((b * d,) + tuple(yc.shape[1:]), dtype=yc.dtype, device=yc.device)
-                y[c0:c0 + chunk].copy_(yc)
-                del yc
+                f = H.conv_bn(self.conv1, self.bn1, x[c0:c0 + chunk], relu=True)
+                if y is None:                             # (the U-Net keeps its input's extent: 'same' convolutions, ceil-mode pools)
+                    y = torch.empty((b * d,) + tuple(f.shape[1:3]) + (self.unet.conv_final.co,), dtype=f.dtype, device=f.device)
+                self.unet(f, out=y[c0:c0 + chunk])        # the last convolution writes the chunk's slice itself
+                del f
         else:
-            y = self.unet(self.bn1(self.conv1(x), relu=True))
+            y = self.unet(H.conv_bn(self.conv1, self.bn1, x, relu=True))
         _, hh, ww, ch = y.shape
         v = y.view(b, d, hh, ww, ch)                                              # slices are the z axis again
         v = self.feature_head[0](v, relu=True)

@@ -219,6 +219,12 @@ size_t mi_convnd_workspace_bytes(int N, int Di, int Hi, int Wi, int Ci, int Co, 
 int mi_convnd_fwd_f32(const float* x, const float* w, float* y, const float* res, int relu, int N,
                       int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd,
                       int ph, int pw, void* ws, size_t ws_bytes, mi_stream_t stream);
+/* y = act(conv(x, w) + bias[Co]): mi_convnd_fwd_f32 with the residual read as one row of Co values (a bias).  Replaces the
+ * reference's conv -> BatchNorm(eval) -> ReLU triple at inference (models/networks/unet.py:198-249,319-399) once the caller has
+ * folded the BatchNorm's scale into w and its shift into bias. */
+int mi_convnd_fwd_bias_f32(const float* x, const float* w, float* y, const float* bias, int relu, int N, int Di,
+                           int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph,
+                           int pw, void* ws, size_t ws_bytes, mi_stream_t stream);
 int mi_convnd_dgrad_f32(const float* dy, const float* w, float* dx, const float* res,
                         const float* mask, int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh,
                         int kw, int stride, int pd, int ph, int pw, void* ws, size_t ws_bytes,

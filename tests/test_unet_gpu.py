@@ -237,6 +237,47 @@ def test_unet_inference_in_slice_chunks_matches_whole_volume_and_oracle():
         net.eval()
 
 
+def test_unet_inference_with_folded_batchnorm_equals_the_unfolded_passes(monkeypatch):
+    """Round 4: at inference evaluation-mode BatchNorm is folded into the convolution in front of it (scaled weights + a bias and
+    ReLU epilogue: mi_convnd_fwd_bias_f32) and the last 1 x 1 convolution adds its bias and writes its chunk of the feature volume
+    itself.  Against the unfolded sequence (conv, bn_apply, bias_add, chunk copy: hipops.FOLD_EVAL_BN off) on a network whose
+    running statistics are not the identity, chunked and whole; and the folded weights follow an in-place change of the
+    statistics (models/networks/unet.py:198-249,319-399, unet_small.py:30-97)."""
+    from cet_pick_amd import hipops as H
+    net = _net()
+    g = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, H.HipBatchNorm):
+                m.running_mean.copy_((torch.randn(m.running_mean.shape, generator=g) * 0.2).cuda())
+                m.running_var.copy_((torch.rand(m.running_var.shape, generator=g) + 0.5).cuda())
+                m.weight.copy_((torch.rand(m.weight.shape, generator=g) + 0.5).cuda())
+                m.bias.copy_((torch.randn(m.bias.shape, generator=g) * 0.1).cuda())
+        net.unet.conv_final.bias.copy_((torch.randn(net.unet.conv_final.bias.shape, generator=g) * 0.1).cuda())
+    x = torch.randn(1, 21, 72, 88, generator=g).cuda()
+    outs = {}
+    with torch.no_grad():
+        for fold in (True, False):
+            monkeypatch.setattr(H, "FOLD_EVAL_BN", fold)
+            for chunk in (8, 0):
+                net.slice_chunk = chunk
+                outs[(fold, chunk)] = {k: v.clone() for k, v in net(x)[0].items()}
+    for h in HEADS:
+        ref = outs[(False, 0)][h]
+        tol = 2e-5 * max(1.0, float(ref.abs().max()))
+        for key in ((True, 8), (True, 0), (False, 8)):
+            assert float((outs[key][h] - ref).abs().max()) <= tol, (h, key)
+    # the folded weights are rebuilt when a statistic changes in place
+    monkeypatch.setattr(H, "FOLD_EVAL_BN", True)
+    with torch.no_grad():
+        net.bn1.running_var.mul_(4.0)
+        a = net(x)[0]["hm"].clone()
+        monkeypatch.setattr(H, "FOLD_EVAL_BN", False)
+        b = net(x)[0]["hm"]
+    assert float((a - outs[(True, 0)]["hm"]).abs().max()) > 0
+    assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
 def test_unet_weight_cache_follows_parameter_updates():
     net = _net()
     x = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
