@@ -243,7 +243,70 @@ __global__ __launch_bounds__(256) void zhead_bwd_weight_final_kernel(const doubl
 }
 int zhead_w_blocks(long voxels, int C) { return (int)std::max<long>(1, std::min<long>(voxels / ((256 / C) * 64) + 1, 1024)); }
 
+// ---- the detector's first convolution at inference: nn.Conv2d(1, 16, 7, stride 2, padding 3) per slice (unet_small.py:35) ----
+// One input channel: 49 taps x 16 outputs.  The implicit GEMM gathers 49 single floats per row behind a tap table (1.9 ms per
+// 128 x 512 x 512 tomogram, 7 TFLOP/s: 13 GFLOP that write 0.5 GB).  Here a workgroup owns a 16 x 16 tile of output pixels: the 37 x 37
+// input patch goes through LDS once, a thread keeps its pixel's 16 accumulators and walks the window a row at a time, the weights come
+// as scalar operands (they are the same for every lane); bias + ReLU in the epilogue, four 16-byte stores.
+constexpr int S2D_T = 16, S2D_P = 2 * S2D_T + 5, S2D_PP = S2D_P + 1;          // tile, patch extent, patch pitch
+__global__ __launch_bounds__(256) void stem2d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int relu,
+                                                        int H, int W, int Ho, int Wo) {
+    __shared__ float patch[S2D_P * S2D_PP];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z, ty0 = blockIdx.y * S2D_T, tx0 = blockIdx.x * S2D_T;
+    const float* img = x + (long)n * H * W;
+    const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
+    for (int i = tid; i < S2D_P * S2D_P; i += 256) {
+        const int py = i / S2D_P, px = i % S2D_P;
+        const int yy = iy0 + py, xx = ix0 + px;
+        patch[py * S2D_PP + px] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? img[(long)yy * W + xx] : 0.f;
+    }
+    __syncthreads();
+    const int ly = tid >> 4, lx = tid & 15;
+    const int yo = ty0 + ly, xo = tx0 + lx;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    // one window row at a time (a rolled loop: unrolled, the compiler hoisted all 784 weights into registers and spilled); the weights
+    // are the same for every lane: scalar loads, a scalar operand per multiply-add - no LDS traffic for them
+#pragma unroll 1
+    for (int ky = 0; ky < 7; ++ky) {
+        float v[7];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) v[kx] = patch[(2 * ly + ky) * S2D_PP + 2 * lx + kx];
+        const float* wr = w + ky * 7 * 16;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] = fmaf(v[kx], wr[kx * 16 + c], acc[c]);
+    }
+    if (yo >= Ho || xo >= Wo) return;
+    float* out = y + (((long)n * Ho + yo) * Wo + xo) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 b4 = bias ? ld4(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 o = make_float4(acc[4 * q] + b4.x, acc[4 * q + 1] + b4.y, acc[4 * q + 2] + b4.z, acc[4 * q + 3] + b4.w);
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        st4(out + 4 * q, o);
+    }
+}
+
 }  // namespace
+
+/* y = act(conv2d(x, w, 7 x 7, stride 2, padding 3) + bias) for ONE input channel and 16 output channels per image: x (N, H, W),
+ * w [7][7][1][16] (kernel layout), bias[16] or NULL, y (N, Ho, Wo, 16) with Ho = (H - 1) / 2 + 1.  Inference-path replacement of the
+ * implicit GEMM for the detector's first layer (models/networks/unet_small.py:35, `conv1`). */
+extern "C" int mi_stem2d_fwd_bias_f32(const float* x, const float* w, const float* bias, float* y, int relu, int N, int H, int W,
+                                      mi_stream_t stream) {
+    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0) return MI_E_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if (N > 65535 || (Ho + S2D_T - 1) / S2D_T > 65535) return MI_E_UNSUPPORTED;
+    hipLaunchKernelGGL(stem2d_fwd_kernel, dim3((unsigned)((Wo + S2D_T - 1) / S2D_T), (unsigned)((Ho + S2D_T - 1) / S2D_T), (unsigned)N),
+                       dim3(256), 0, (hipStream_t)stream, x, w, bias, y, relu, H, W, Ho, Wo);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
 
 extern "C" int mi_maxpool2d_ceil_fwd(const float* x, float* y, uint8_t* argmax, int N, int Hi, int Wi, int C, int k,
                                      mi_stream_t stream) {

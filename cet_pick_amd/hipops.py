@@ -649,6 +649,14 @@ def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None):
     elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
         raise L.HipExtensionError("conv_bias_fwd: `out` must be a contiguous fp32 %s tensor on %s" % (shape, x.device))
     lib = L.lib()
+    if (ci == 1 and co == 16 and d == 1 and tuple(k3) == (1, 7, 7) and stride == 2 and tuple(p3) == (0, 3, 3) and n <= 65535
+            and not os.environ.get("MI_NO_STEM2D")):
+        # the detector's first layer: one input channel - a direct kernel instead of 49 single-float gathers per row
+        def call():
+            return L.check(lib.mi_stem2d_fwd_bias_f32(L.ptr(x), L.ptr(w), L.ptr(_f32c(bias, "bias")), L.ptr(out), int(relu), n, h, wd,
+                                                      L.stream()), "mi_stem2d_fwd_bias_f32")
+        _prof_run("fwd", 2.0 * n * do * ho * wo * co * 49, call)
+        return out
     ws = _ws(lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3), x.device, "conv")
     def call():
         return L.check(lib.mi_convnd_fwd_bias_f32(L.ptr(x), L.ptr(w), L.ptr(out), L.ptr(_f32c(bias, "bias")), int(relu), n, d, h,

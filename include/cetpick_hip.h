@@ -225,6 +225,11 @@ int mi_convnd_fwd_f32(const float* x, const float* w, float* y, const float* res
 int mi_convnd_fwd_bias_f32(const float* x, const float* w, float* y, const float* bias, int relu, int N, int Di,
                            int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph,
                            int pw, void* ws, size_t ws_bytes, mi_stream_t stream);
+/* y = act(conv2d(x, w, 7 x 7, stride 2, padding 3) + bias): ONE input channel, 16 output channels, x (N, H, W), w in kernel layout
+ * [7][7][1][16], bias[16] or NULL, y (N, Ho, Wo, 16) channels-last with Ho = (H - 1) / 2 + 1 (models/networks/unet_small.py:35: the
+ * detector's first layer, with its evaluation-mode BatchNorm folded in by the caller). */
+int mi_stem2d_fwd_bias_f32(const float* x, const float* w, const float* bias, float* y, int relu, int N, int H, int W,
+                           mi_stream_t stream);
 int mi_convnd_dgrad_f32(const float* dy, const float* w, float* dx, const float* res,
                         const float* mask, int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh,
                         int kw, int stride, int pd, int ph, int pw, void* ws, size_t ws_bytes,

@@ -85,6 +85,26 @@ def test_narrow_tile_forward_matches_wide_tile_and_float64(shape, co, k, pad, di
     assert float((outs["1"][1].double() - ref2).abs().max()) <= 2e-6 * max(scale, float(ref2.abs().max()))
 
 
+@pytest.mark.parametrize("n,h,w", [(3, 64, 64), (2, 37, 51), (1, 512, 512), (5, 7, 9)])
+def test_first_layer_direct_kernel_matches_torch_and_the_generic_kernel(n, h, w, monkeypatch):
+    """stem2d_fwd_kernel (Conv2d(1, 16, 7, stride 2, padding 3) + bias + ReLU at inference, unet_small.py:35) against torch and against
+    the implicit GEMM with the same bias epilogue (MI_NO_STEM2D=1), odd extents and partial tiles included."""
+    from cet_pick_amd import hipops as H
+    g = torch.Generator().manual_seed(n + h + w)
+    x = torch.randn(n, 1, h, w, generator=g)
+    wt = torch.randn(16, 1, 7, 7, generator=g) * 0.2
+    b = torch.randn(16, generator=g) * 0.3
+    ref = F.relu(F.conv2d(x, wt, b, stride=2, padding=3))
+    wk = wt.permute(2, 3, 1, 0).contiguous().cuda().permute(3, 2, 0, 1)
+    xc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y = H.conv_bias_fwd(xc, wk, b.cuda(), 7, 2, 3, relu=True)
+    monkeypatch.setenv("MI_NO_STEM2D", "1")
+    y_gen = H.conv_bias_fwd(xc, wk, b.cuda(), 7, 2, 3, relu=True)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(y.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6 * scale)
+    np.testing.assert_allclose(y.cpu().numpy(), y_gen.cpu().numpy(), rtol=0, atol=2e-6 * scale)
+
+
 @pytest.mark.parametrize("rows,c", [(4096, 32), (70001, 32), (5000, 16), (4099, 64)])
 def test_l2norm_rows_of_few_channels_equal_the_wave_per_row_kernel(rows, c, monkeypatch):
     """l2norm_small_fwd_kernel (C / 4 lanes per row; the detector's projection head, unet_small.py:93-97 `F.normalize(proj, dim=1)`)
