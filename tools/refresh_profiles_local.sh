@@ -23,3 +23,8 @@ for f in ("conv_traffic", "mfma_busy", "infer_traffic"):
     d = json.load(open("profiles/${T}_%s.json" % f))
     print(f, d["source_sha16"], len(d["kernels"]), "kernels", d.get("hbm_bytes_per_step"))
 PY
+# tools/round_end.sh's other outputs, as they are
+for pair in kernels_by_crop.txt:kernels_by_crop.txt detector.json:detector_bench.json stamp_plain.txt:stamp_step.txt stamp_dist.txt:stamp_step_dist.txt unet_layers.txt:unet_layers.txt; do
+  src=$O/${pair%%:*}; dst=profiles/${T}_${pair##*:}
+  if [ -s $src ]; then cp $src $dst; fi
+done

@@ -13,6 +13,7 @@ tools/refresh_profiles.sh $T
   echo
   for c in "32 64" "64 32" "64 8" "48 16"; do timeout -k 10 200 python tools/bench_conv.py --kernels $c 2>/dev/null; echo; done ) > $O/kernels_by_crop.txt
 timeout -k 10 400 python tools/bench_detector.py > $O/detector.json 2> $O/detector.err
+timeout -k 10 300 python tools/ab/unet_layers.py > $O/unet_layers.txt 2> $O/unet_layers.err
 timeout -k 10 200 python tools/stamp_step.py 64 50 > $O/stamp_plain.txt 2>&1
 timeout -k 10 200 python tools/stamp_step.py 64 50 --dist > $O/stamp_dist.txt 2>&1
 echo "round_end done"
