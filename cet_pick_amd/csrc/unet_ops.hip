@@ -84,6 +84,33 @@ __global__ __launch_bounds__(256) void shuffle2x2_kernel(const float* t, const f
         st4(y + 4 * i, r);
     }
 }
+// Inference tail of an up-convolution block in ONE pass (unet.py:319-399: ConvTranspose2d -> BatchNorm -> ReLU -> cat with the encoder
+// feature): out[n][yo][xo][0:Co] = relu(scale * t[n][yo/2][xo/2][(a*2+b)*Co + co] + shift), out[..][Co:Co+Ce] = enc[n][yo][xo][:] - instead
+// of the shuffle, the BatchNorm pass and the concatenation each reading and writing the feature map (scale / shift: the evaluation-mode
+// BatchNorm with the transposed convolution's bias folded in, built by the caller).
+__global__ __launch_bounds__(256) void upconv_tail_kernel(const float* t, const float* scale, const float* shift, const float* enc,
+                                                         float* out, int N, int H, int W, int Co, int Ce, int Ho, int Wo) {
+    const int CU = Co >> 2, CV = (Co + Ce) >> 2;
+    const long total = (long)N * Ho * Wo * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        long v = i / CV;
+        float4 r;
+        if (cv < CU) {
+            const int xo = (int)(v % Wo); long q = v / Wo;
+            const int yo = (int)(q % Ho);
+            const int n = (int)(q / Ho);
+            const int h = yo >> 1, a = yo & 1, w = xo >> 1, b = xo & 1;
+            r = ld4(t + ((((long)n * H + h) * W + w) * 4 + (a * 2 + b)) * Co + 4 * cv);
+            const float4 sc = ld4(scale + 4 * cv), sh = ld4(shift + 4 * cv);
+            r.x = fmaxf(fmaf(r.x, sc.x, sh.x), 0.f); r.y = fmaxf(fmaf(r.y, sc.y, sh.y), 0.f);
+            r.z = fmaxf(fmaf(r.z, sc.z, sh.z), 0.f); r.w = fmaxf(fmaf(r.w, sc.w, sh.w), 0.f);
+        } else {
+            r = ld4(enc + v * Ce + 4 * (cv - CU));
+        }
+        st4(out + 4 * i, r);
+    }
+}
 // backward of the shuffle: dt[n][h][w][(a*2+b)*Co + co] = dy[n][2h+a][2w+b][co] (0 in the cropped rim)
 __global__ __launch_bounds__(256) void unshuffle2x2_kernel(const float* dy, float* dt, int N, int H, int W, int Co,
                                                           int Ho, int Wo) {
@@ -338,6 +365,19 @@ extern "C" int mi_shuffle2x2_fwd(const float* t, const float* bias, float* y, in
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
+/* out = cat(relu(scale * shuffle(t) + shift), enc) over the channel axis, channels-last: t (N, H, W, 4*Co) from the 1 x 1 product of the
+ * transposed convolution, enc (N, Ho, Wo, Ce), out (N, Ho, Wo, Co + Ce); Ho in {2H - 1, 2H}, Wo likewise (the reference's autocrop). */
+extern "C" int mi_upconv_tail_fwd(const float* t, const float* scale, const float* shift, const float* enc, float* out, int N, int H,
+                                  int W, int Co, int Ce, int Ho, int Wo, mi_stream_t stream) {
+    if (!t || !scale || !shift || !enc || !out || N <= 0 || H <= 0 || W <= 0 || Co <= 0 || Ce <= 0 || (Co & 3) || (Ce & 3)) return MI_E_ARG;
+    if (Ho > 2 * H || Ho < 2 * H - 1 || Wo > 2 * W || Wo < 2 * W - 1) return MI_E_ARG;
+    const long total = (long)N * Ho * Wo * ((Co + Ce) >> 2);
+    hipLaunchKernelGGL(upconv_tail_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, t, scale, shift, enc, out, N, H, W,
+                       Co, Ce, Ho, Wo);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
 extern "C" int mi_shuffle2x2_bwd(const float* dy, float* dt, int N, int H, int W, int Co, int Ho, int Wo,
                                  mi_stream_t stream) {
     if (!dy || !dt || Co % 4 || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Ho > 2 * H || Wo > 2 * W) return MI_E_ARG;

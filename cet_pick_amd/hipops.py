@@ -693,6 +693,38 @@ def conv_bn(conv, bn, x, relu=False):
     return conv_bias_fwd(x, cache[1], cache[2], conv.k, conv.stride, conv.pad, relu)
 
 
+def upconv_bn_relu_concat(up, bn, dec, enc):
+    """cat(relu(bn(up(dec))), enc) over the channel axis (unet.py:319-399).  At inference one 1 x 1 product + ONE pass that shuffles,
+    applies the folded BatchNorm (the transposed convolution's bias included), the ReLU and writes the concatenation
+    (mi_upconv_tail_fwd) - instead of shuffle, BatchNorm and concat passes over the feature map."""
+    ho, wo = enc.shape[1], enc.shape[2]
+    folded = (not bn.training and bn.track_running_stats and not torch.is_grad_enabled() and dec.is_cuda and FOLD_EVAL_BN)
+    if not folded:
+        return concat_channels(bn(up(dec, ho, wo), relu=True), enc)
+    src = (up.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (float(bn.eps),)
+    cache = getattr(bn, "_folded_up", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            inv = torch.rsqrt(bn.running_var.double() + bn.eps)
+            sc = inv if bn.weight is None else bn.weight.double() * inv
+            sh = -bn.running_mean.double() * sc
+            if up.bias is not None:
+                sh = sh + up.bias.double() * sc
+            if bn.bias is not None:
+                sh = sh + bn.bias.double()
+            cache = (key, sc.float().contiguous(), sh.float().contiguous())
+        bn._folded_up = cache
+    _f32c(dec, "dec"); _f32c(enc, "enc")
+    n, h, w, _ = dec.shape
+    co, ce = up.co, enc.shape[-1]
+    t = conv_fwd(dec, up.gemm_view(), 1, 1, 0)
+    out = torch.empty((n, ho, wo, co + ce), dtype=torch.float32, device=dec.device)
+    L.check(L.lib().mi_upconv_tail_fwd(L.ptr(t), L.ptr(cache[1]), L.ptr(cache[2]), L.ptr(enc), L.ptr(out), n, h, w, co, ce, ho, wo,
+                                       L.stream()), "mi_upconv_tail_fwd")
+    return out
+
+
 FOLD_EVAL_BN = os.environ.get("CETPICK_FOLD_BN", "1") != "0"
 
 

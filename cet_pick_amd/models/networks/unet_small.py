@@ -58,8 +58,7 @@ class UpConv(nn.Module):
         ho, wo = enc.shape[1], enc.shape[2]                  # autocrop (:253-266): odd encoder extents lose a row
         if not (2 * h - 1 <= ho <= 2 * h and 2 * w - 1 <= wo <= 2 * w):
             raise L.HipExtensionError("encoder / decoder extents do not match (%s vs 2x%s)" % (tuple(enc.shape), tuple(dec.shape)))
-        up = self.norm0(self.upconv(dec, ho, wo), relu=True)
-        y = H.conv_bn(self.conv1, self.norm1, H.concat_channels(up, enc), relu=True)
+        y = H.conv_bn(self.conv1, self.norm1, H.upconv_bn_relu_concat(self.upconv, self.norm0, dec, enc), relu=True)
         return H.conv_bn(self.conv2, self.norm2, y, relu=True)
 
 

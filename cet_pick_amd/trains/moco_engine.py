@@ -229,6 +229,22 @@ class MocoStepEngine:
         H.stamp("step:end")
         return self.loss
 
+    @staticmethod
+    def _drain_watchdog():
+        """Data parallel, before a capture: let the process group's watchdog thread finish with the Works of the eager steps.
+        The watchdog polls its list every 100 ms (hipEventQuery on each Work's end event) and drops the Works it finds
+        complete.  A Work of the eager warm-up steps that is still on that list when the capture starts gets polled DURING
+        the capture - and ProcessGroupNCCL's internal communication stream, on which that end event was recorded, is by then
+        part of the capture: ROCm answers hipErrorCapturedEvent ("operation not permitted on an event last recorded in a
+        capturing stream") for an event whose stream is capturing NOW, the watchdog rethrows and the process aborts
+        (profiles/r04_watchdog_abort.txt: 1 run in ~10; `thread_local` capture mode cured the other form of this race, the
+        query of an unrelated event under `global` mode).  The list has no accessor, so the drain is a wait: the device is
+        idle (synchronised by the caller), every Work is complete, and three poll periods later the list is empty.  Paid once
+        per capture, never per step.  CETPICK_WATCHDOG_DRAIN_S overrides the 0.3 s."""
+        import os
+        import time
+        time.sleep(float(os.environ.get("CETPICK_WATCHDOG_DRAIN_S", "0.3")))
+
     def _capture(self, im_q, im_k):
         """Record one step into a hipGraph.  Returns the graph, or None when the data-parallel ranks agreed to stay
         eager.  With collectives in the step every rank must take the same decision: a rank that replays a graph
@@ -236,6 +252,8 @@ class MocoStepEngine:
         self._static_q = im_q.clone()
         self._static_k = im_k.clone()
         torch.cuda.synchronize()
+        if self.dist_on:
+            self._drain_watchdog()
         graph = torch.cuda.CUDAGraph(keep_graph=True)      # the hipGraph_t stays queryable (node_counts)
         err = None
         try:

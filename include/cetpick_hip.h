@@ -314,6 +314,11 @@ int mi_maxpool2d_ceil_bwd(const float* dy, const uint8_t* argmax, float* dx, int
  * (Ho, Wo) <= (2H, 2W) (`autocrop`, unet.py:253-266).  bwd: the inverse scatter (zeros in the cropped rim). */
 int mi_shuffle2x2_fwd(const float* t, const float* bias, float* y, int N, int H, int W, int Co, int Ho, int Wo,
                       mi_stream_t stream);
+/* Inference tail of an up-convolution block in one pass (models/networks/unet.py:319-399: ConvTranspose2d(2, stride 2) -> BatchNorm2d
+ * (eval) -> ReLU -> torch.cat with the encoder feature): out (N, Ho, Wo, Co + Ce) = cat(relu(scale[co] * shuffle(t) + shift[co]), enc);
+ * t (N, H, W, 4*Co) is the 1 x 1 product of the transposed convolution, scale / shift the BatchNorm with the bias folded in. */
+int mi_upconv_tail_fwd(const float* t, const float* scale, const float* shift, const float* enc, float* out, int N, int H,
+                       int W, int Co, int Ce, int Ho, int Wo, mi_stream_t stream);
 int mi_shuffle2x2_bwd(const float* dy, float* dt, int N, int H, int W, int Co, int Ho, int Wo,
                       mi_stream_t stream);
 /* torch.cat((a, b), 1) (unet.py:385) over M rows, and its backward. */
