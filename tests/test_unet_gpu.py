@@ -85,6 +85,30 @@ def test_narrow_tile_forward_matches_wide_tile_and_float64(shape, co, k, pad, di
     assert float((outs["1"][1].double() - ref2).abs().max()) <= 2e-6 * max(scale, float(ref2.abs().max()))
 
 
+@pytest.mark.parametrize("n,h,w,ho,wo,co,ce", [(2, 8, 8, 16, 16, 32, 32), (3, 5, 7, 9, 14, 64, 64), (1, 16, 16, 31, 31, 128, 128),
+                                              (2, 4, 4, 8, 7, 32, 64)])
+def test_upconv_tail_equals_shuffle_batchnorm_relu_concat(n, h, w, ho, wo, co, ce):
+    """mi_upconv_tail_fwd (inference: pixel shuffle + transposed-convolution bias + evaluation-mode BatchNorm + ReLU + concat with the
+    encoder feature in ONE pass, unet.py:319-399) against the separate passes, odd (auto-cropped) extents included."""
+    from cet_pick_amd import hipops as H
+    g = torch.Generator().manual_seed(n + h + wo + co)
+    up = H.HipConvTranspose2x2(2 * co, co)
+    bn = H.HipBatchNorm(co)
+    with torch.no_grad():
+        up.bias.copy_(torch.randn(co, generator=g) * 0.2)
+        bn.weight.copy_(torch.rand(co, generator=g) + 0.5); bn.bias.copy_(torch.randn(co, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(co, generator=g) * 0.2); bn.running_var.copy_(torch.rand(co, generator=g) + 0.5)
+    up, bn = up.cuda(), bn.cuda().eval()
+    dec = torch.randn(n, h, w, 2 * co, generator=g).cuda()
+    enc = torch.randn(n, ho, wo, ce, generator=g).cuda()
+    with torch.no_grad():
+        fused = H.upconv_bn_relu_concat(up, bn, dec, enc)
+        ref = H.concat_channels(bn(up(dec, ho, wo), relu=True), enc)
+    assert fused.shape == ref.shape == (n, ho, wo, co + ce)
+    assert torch.equal(fused[..., co:], ref[..., co:])
+    assert float((fused - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("n,h,w", [(3, 64, 64), (2, 37, 51), (1, 512, 512), (5, 7, 9)])
 def test_first_layer_direct_kernel_matches_torch_and_the_generic_kernel(n, h, w, monkeypatch):
     """stem2d_fwd_kernel (Conv2d(1, 16, 7, stride 2, padding 3) + bias + ReLU at inference, unet_small.py:35) against torch and against

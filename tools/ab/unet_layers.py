@@ -1,5 +1,5 @@
 """Per-convolution table of one unet_4 forward on 128 x 512 x 512 (the detector's C3 configuration): shape, GFLOP, time, TFLOP/s.
-The shapes are captured by wrapping hipops.conv_fwd; the times are hipops.PROFILE's HIP-event times of the same launches."""
+The shapes are captured by wrapping hipops.conv_fwd / conv_bias_fwd; the times are hipops.PROFILE's HIP-event times of the same launches."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from cet_pick_amd import hipops as H
@@ -19,6 +19,14 @@ def wrapped(x, w, k, stride, pad, res=None, relu=False, dil=None):
         shapes.append((tuple(x.shape), w.shape[0], k, stride, dil))
     return y
 H.conv_fwd = wrapped
+orig_b = H.conv_bias_fwd
+def wrapped_b(x, w, bias, k, stride, pad, relu=False, out=None):     # inference: BatchNorm folded, bias + ReLU epilogue
+    before = len(H.PROFILE) if H.PROFILE is not None else 0
+    y = orig_b(x, w, bias, k, stride, pad, relu, out)
+    if H.PROFILE is not None and len(H.PROFILE) > before:
+        shapes.append((tuple(x.shape), w.shape[0], k, stride, None))
+    return y
+H.conv_bias_fwd = wrapped_b
 with torch.no_grad():
     net(vol); torch.cuda.synchronize()
     H.PROFILE = []
