@@ -319,7 +319,68 @@ def _cached_image(w, dgrad, n, d, h, wd, k3, stride, p3):
     return ACTIVE_IMAGES.get(w, dgrad, n, d, h, wd)
 
 
-def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None):
+SMALLK = os.environ.get("CETPICK_SMALLK", "1") != "0"
+
+
+def _smallk_taps(x, w, k3, stride, p3, dil, nd5):
+    """1 / 3: this forward convolution can take the short-reduction inference kernel (conv_smallk.hip) as a 1 x 1 / (3, 1, 1)
+    convolution; 0: not."""
+    if not SMALLK or torch.is_grad_enabled() or not x.is_cuda or stride != 1:
+        return 0
+    if dil is not None and tuple(_k3(dil, nd5)) != (1, 1, 1):
+        return 0
+    ci, co = x.shape[-1], w.shape[0]
+    # at most 64 output channels: every wave streams the whole weight image of its columns, which beyond that outweighs the
+    # activations it reads (measured: the transposed convolutions' products to 128 - 512 columns are 20 % slower than on the implicit GEMM)
+    if ci % 16 or co % 32 or co > 64 or x.numel() * 4 >= 0x7fff0000:
+        return 0
+    if tuple(k3) == (1, 1, 1) and tuple(p3) == (0, 0, 0):
+        return 1
+    if nd5 and tuple(k3) == (3, 1, 1) and tuple(p3) == (1, 0, 0) and 3 * ci <= 512:
+        return 3
+    return 0
+
+
+def _smallk_image(w, owner, K, co):
+    """The weight image of conv_smallk.hip for the kernel-layout weights `w` (a (K, co) matrix in memory), kept on `owner` (the
+    parameter or folded-weight tensor that outlives the call) and rebuilt when the storage or its version changes."""
+    lib = L.lib()
+    holder = owner if owner is not None else w
+    key = (w.data_ptr(), holder._version, K, co)
+    cache = getattr(holder, "_mi_smallk", None)
+    if cache is None or cache[0] != key:
+        img = torch.empty(int(lib.mi_smallk_image_bytes(K, co)), dtype=torch.uint8, device=w.device)
+        L.check(lib.mi_smallk_prep(L.ptr(w), L.ptr(img), K, co, L.stream()), "mi_smallk_prep")
+        cache = (key, img)
+        try:
+            holder._mi_smallk = cache
+        except AttributeError:
+            pass
+    return cache[1]
+
+
+def _smallk_call(x, w, bias, relu, ntaps, out=None, owner=None):
+    _f32c(x, "x")
+    if not _phys_ok(w):
+        raise L.HipExtensionError("conv weight is not in kernel layout [tap][Cin][Cout]")
+    ci, co = x.shape[-1], w.shape[0]
+    m = x.numel() // ci
+    shape = tuple(x.shape[:-1]) + (co,)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise L.HipExtensionError("`out` must be a contiguous fp32 %s tensor on %s" % (shape, x.device))
+    img = _smallk_image(w, owner, ntaps * ci, co)
+    plane, d = (x.shape[2] * x.shape[3], x.shape[1]) if ntaps == 3 else (1, 1)
+    lib = L.lib()
+    def call():
+        return L.check(lib.mi_smallk_fwd_f32(L.ptr(x), L.ptr(img), L.ptr(bias), L.ptr(out), int(relu), m, ci, co, ntaps, plane, d,
+                                             L.stream()), "mi_smallk_fwd_f32")
+    _prof_run("fwd", 2.0 * m * co * ci * ntaps, call)
+    return out
+
+
+def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None, owner=None):
     """y = act(conv(x, w) + res).  x: (N,D,H,W,Ci) or (N,H,W,Ci) channels-last; w in kernel layout.
     dil: per-axis dilation (stride 1 only)."""
     _f32c(x, "x")
@@ -327,6 +388,10 @@ def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None):
         raise L.HipExtensionError("conv weight is not in kernel layout [tap][Cin][Cout]")
     nd5 = x.dim() == 5
     k3, p3 = _k3(k, nd5), _p3(pad, nd5)
+    if res is None:
+        taps = _smallk_taps(x, w, k3, stride, p3, dil, nd5)
+        if taps:                                      # inference, short reduction: no tile pipeline (conv_smallk.hip)
+            return _smallk_call(x, w, None, relu, taps, owner=owner)
     x5 = _as5d(x)
     n, d, h, wd, ci = x5.shape
     co = w.shape[0]
@@ -639,6 +704,9 @@ def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None):
         raise L.HipExtensionError("conv weight is not in kernel layout [tap][Cin][Cout]")
     nd5 = x.dim() == 5
     k3, p3 = _k3(k, nd5), _p3(pad, nd5)
+    taps = _smallk_taps(x, w, k3, stride, p3, None, nd5)
+    if taps:
+        return _smallk_call(x, w, _f32c(bias, "bias"), relu, taps, out=out)
     x5 = _as5d(x)
     n, d, h, wd, ci = x5.shape
     co = w.shape[0]
@@ -718,7 +786,7 @@ def upconv_bn_relu_concat(up, bn, dec, enc):
     _f32c(dec, "dec"); _f32c(enc, "enc")
     n, h, w, _ = dec.shape
     co, ce = up.co, enc.shape[-1]
-    t = conv_fwd(dec, up.gemm_view(), 1, 1, 0)
+    t = conv_fwd(dec, up.gemm_view(), 1, 1, 0, owner=up.weight)
     out = torch.empty((n, ho, wo, co + ce), dtype=torch.float32, device=dec.device)
     L.check(L.lib().mi_upconv_tail_fwd(L.ptr(t), L.ptr(cache[1]), L.ptr(cache[2]), L.ptr(enc), L.ptr(out), n, h, w, co, ce, ho, wo,
                                        L.stream()), "mi_upconv_tail_fwd")

@@ -230,6 +230,15 @@ int mi_convnd_fwd_bias_f32(const float* x, const float* w, float* y, const float
  * detector's first layer, with its evaluation-mode BatchNorm folded in by the caller). */
 int mi_stem2d_fwd_bias_f32(const float* x, const float* w, const float* bias, float* y, int relu, int N, int H, int W,
                            mi_stream_t stream);
+/* Forward convolutions with a short reduction, inference path (round 4; no gradient form - training keeps mi_convnd_*): 1 x 1
+ * (ntaps 1) or (3, 1, 1) with padding (1, 0, 0) (ntaps 3: `plane` = H * W rows per z-plane, `D` planes per sample) on channels-last rows
+ * x (M, Ci) -> y (M, Co) = act(x . W + bias), bias may be NULL.  Ci a multiple of 16, Co of 32.  `img` (mi_smallk_image_bytes(ntaps * Ci, Co)
+ * bytes) is written by mi_smallk_prep from the kernel-layout weights [tap][Ci][Co] once per set of weights.  Replaces the implicit GEMM
+ * for the detector's 1 x 1 layers and (3, 1, 1) head (models/networks/unet.py:319-399,880-886, unet_small.py:86-97). */
+size_t mi_smallk_image_bytes(int K, int Co);
+int mi_smallk_prep(const float* w, void* img, int K, int Co, mi_stream_t stream);
+int mi_smallk_fwd_f32(const float* x, const void* img, const float* bias, float* y, int relu, long M, int Ci, int Co,
+                      int ntaps, long plane, int D, mi_stream_t stream);
 int mi_convnd_dgrad_f32(const float* dy, const float* w, float* dx, const float* res,
                         const float* mask, int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh,
                         int kw, int stride, int pd, int ph, int pw, void* ws, size_t ws_bytes,

@@ -109,6 +109,47 @@ def test_upconv_tail_equals_shuffle_batchnorm_relu_concat(n, h, w, ho, wo, co, c
     assert float((fused - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape,co,k,pad", [((3, 1, 37, 41, 32), 32, (1, 1, 1), (0, 0, 0)),      # last layer of the U-Net, ragged rows
+                                            ((2, 1, 32, 32, 64), 64, (1, 1, 1), (0, 0, 0)),      # two column blocks per wave
+                                            ((1, 1, 16, 24, 256), 64, (1, 1, 1), (0, 0, 0)),     # sixteen k-steps
+                                            ((2, 1, 8, 8, 16), 32, (1, 1, 1), (0, 0, 0)),        # one k-step
+                                            ((2, 5, 9, 11, 32), 32, (3, 1, 1), (1, 0, 0)),       # the (3, 1, 1) head, two samples
+                                            ((1, 1, 6, 6, 48), 64, (3, 1, 1), (1, 0, 0))])      # one plane: only the centre tap exists
+def test_short_reduction_kernel_matches_generic_kernel_and_float64(shape, co, k, pad, monkeypatch):
+    """smallk_fwd_kernel (inference: 1 x 1 and (3, 1, 1) convolutions without the implicit GEMM's tile pipeline; unet.py:319-399,880-886,
+    unet_small.py:86-97) against the generic kernel (hipops.SMALLK off) and float64, with and without the bias + ReLU epilogue."""
+    from cet_pick_amd import hipops as H, _lib as L
+    n, d, h, w, ci = shape
+    g = torch.Generator().manual_seed(sum(shape) + co)
+    x = torch.randn(n, ci, d, h, w, generator=g) * torch.exp(torch.randn(n, ci, d, h, w, generator=g))
+    wt = torch.randn(co, ci, *k, generator=g) * (1.0 / (ci * k[0])) ** 0.5
+    b = torch.randn(co, generator=g) * 0.3
+    y64 = F.conv3d(x.double().cuda(), wt.double().cuda(), padding=pad).permute(0, 2, 3, 4, 1)
+    wk = wt.permute(2, 3, 4, 1, 0).contiguous().cuda().permute(4, 3, 0, 1, 2)
+    xc = _cl(x)
+    scale = float(y64.abs().max())
+    with torch.no_grad():
+        y = H.conv_fwd(xc, wk, k, 1, pad)
+        assert getattr(wk, "_mi_smallk", None) is not None              # the short-reduction path ran and kept its image
+        yb = H.conv_bias_fwd(xc, wk, b.cuda(), k, 1, pad, relu=True)
+        monkeypatch.setattr(H, "SMALLK", False)
+        y_gen = H.conv_fwd(xc, wk, k, 1, pad)
+        yb_gen = H.conv_bias_fwd(xc, wk, b.cuda(), k, 1, pad, relu=True)
+    # the f32-equivalent bound against float64; and no worse than the generic kernel beyond the order of the additions (same
+    # cut, same six products per k-step: 16 k-steps in another grouping measured 1.8x)
+    e, e_gen = float((y.double() - y64).abs().max()), float((y_gen.double() - y64).abs().max())
+    assert e <= 2e-6 * scale and e <= 2.5 * e_gen + 1e-7 * scale
+    ref_b = torch.relu(y64 + b.double().cuda())
+    assert float((yb.double() - ref_b).abs().max()) <= 2e-6 * max(scale, 1.0)
+    assert float((yb - yb_gen).abs().max()) <= 1e-6 * max(scale, 1.0)
+    # the image follows an in-place change of the weights
+    with torch.no_grad():
+        monkeypatch.setattr(H, "SMALLK", True)
+        wk.mul_(2.0)
+        y2 = H.conv_fwd(xc, wk, k, 1, pad)
+    assert float((y2.double() - 2 * y64).abs().max()) <= 4e-6 * scale
+
+
 @pytest.mark.parametrize("n,h,w", [(3, 64, 64), (2, 37, 51), (1, 512, 512), (5, 7, 9)])
 def test_first_layer_direct_kernel_matches_torch_and_the_generic_kernel(n, h, w, monkeypatch):
     """stem2d_fwd_kernel (Conv2d(1, 16, 7, stride 2, padding 3) + bias + ReLU at inference, unet_small.py:35) against torch and against

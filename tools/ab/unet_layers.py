@@ -12,9 +12,9 @@ net = net.cuda().eval()
 vol = torch.randn(1, 128, 512, 512, device="cuda")
 shapes = []
 orig = H.conv_fwd
-def wrapped(x, w, k, stride, pad, res=None, relu=False, dil=None):
+def wrapped(x, w, k, stride, pad, res=None, relu=False, dil=None, **kw):
     before = len(H.PROFILE) if H.PROFILE is not None else 0
-    y = orig(x, w, k, stride, pad, res, relu, dil)
+    y = orig(x, w, k, stride, pad, res, relu, dil, **kw)
     if H.PROFILE is not None and len(H.PROFILE) > before:
         shapes.append((tuple(x.shape), w.shape[0], k, stride, dil))
     return y
