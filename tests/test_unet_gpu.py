@@ -254,6 +254,30 @@ def test_concat_split_and_zhead():
         np.testing.assert_allclose(_cf(y).numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("c,k", [(32, 1), (32, 3), (16, 4), (64, 2)])
+def test_zhead_with_a_lane_group_per_voxel_matches_torch_and_the_thread_per_voxel_kernel(c, k, monkeypatch):
+    """zhead_rows_kernel (round 4: C / 4 lanes per voxel read a row as one coalesced line; the heat-map head of the detector,
+    unet_small.py:86-97, from 4,096 voxels on) against torch and the thread-per-voxel kernel (MI_ZHEAD_GENERIC=1)."""
+    from cet_pick_amd import _lib as L
+    g = torch.Generator().manual_seed(c + k)
+    n, d, h, w = 2, 5, 27, 31
+    x = torch.randn(n, c, d, h, w, generator=g)
+    wt = torch.randn(k, c, 3, 1, 1, generator=g) * 0.2
+    ref = F.conv3d(x, wt, padding=(1, 0, 0))
+    wk = wt[:, :, :, 0, 0].permute(2, 1, 0).contiguous().cuda()
+    xc = _cl(x)
+    lib = L.lib()
+    ys = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("MI_ZHEAD_GENERIC", "1")
+        y = torch.empty(n, d, h, w, k, device="cuda")
+        L.check(lib.mi_zhead_fwd(L.ptr(xc), L.ptr(wk), L.ptr(y), n, d, h * w, c, k, L.stream()), "zhead")
+        ys.append(y)
+    np.testing.assert_allclose(_cf(ys[0]).numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ys[0].cpu().numpy(), ys[1].cpu().numpy(), rtol=0, atol=2e-6 * float(ref.abs().max()))
+
+
 def _net():
     from cet_pick_amd.models.networks.unet_small import TomoConvUNet
     from cet_pick_amd.synthetic import seeded_state_dict
