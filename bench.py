@@ -164,8 +164,9 @@ def inference_secondary(dev, with_cpu=True, rank=0, world=1):
         GREPS = 8
         g = torch.cuda.CUDAGraph()
         # N > 1: the process group's watchdog thread polls its finished works with hipEventQuery at its own pace; inside a
-        # "global" mode capture that call from another thread is fatal (MocoStepEngine._capture): thread_local mode is the
-        # cure (HIP then checks only the capturing thread's own captures); nothing is drained
+        # "global" mode capture that call from another thread is fatal (MocoStepEngine._capture): thread_local mode cures
+        # that.  The other race of a data-parallel capture (hipErrorCapturedEvent, MocoStepEngine._drain_watchdog) needs a
+        # captured collective - RCCL's stream joining the capture - and this capture holds none, so no drain is needed HERE
         import torch.distributed as _dist
         pg = _dist.is_available() and _dist.is_initialized()
         with torch.cuda.graph(g, capture_error_mode="thread_local" if pg else "global"):

@@ -31,7 +31,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int S2_WBLK = 1024;                // one B fragment: 64 lanes x 16 bytes
-constexpr int S2_RING = 4;                   // weight k-steps in flight
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_s2(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);

@@ -173,7 +173,6 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int PYP = PY + 1;                              // + one zero row: the padded tap ky = 7 of the last output row
 constexpr int PROW = 2 * PW;                             // bytes per bf16 patch row
-constexpr int PPLANE = PZ * PYP * PROW;                  // 8736 bytes
 constexpr int WPL = 8 * CO * 16;                         // bytes per plane of a kz slab: [ky8][co][kx8] bf16
 constexpr int WSLAB = 3 * WPL;                           // 24576 bytes
 constexpr size_t WPREP_BYTES = (size_t)K7 * WSLAB;       // 172032 bytes

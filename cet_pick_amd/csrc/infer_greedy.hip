@@ -839,10 +839,13 @@ __global__ __launch_bounds__(RA_T) void rounds_all_kernel(GreedyHeader* hdr, con
         __syncthreads();
     }
     // The last workgroup to get here resolves the leftovers (its own included).  What it reads from the others - their
-    // states and list entries - was stored past the caches (volatile = sc0 sc1 accesses), drained by the barrier's
-    // vmcnt(0) before the owner's ticket (an agent-scope atomic), and is loaded the same way: no device-scope fence (the
-    // L2 write-back / invalidate pair costs tens of microseconds on this part - MI355X_MICROARCH.md, inter-workgroup
-    // visibility, the sc1 form).
+    // states and list entries - was stored past the caches (volatile = sc0 sc1 accesses) and is loaded the same way: no
+    // device-scope fence (the L2 write-back / invalidate pair costs tens of microseconds on this part -
+    // MI355X_MICROARCH.md, inter-workgroup visibility, the sc1 form).  Every storing wave drains its stores explicitly
+    // (on gfx9 a workgroup barrier emits no vmcnt(0) by itself; the volatile stores' own waits are the compiler's choice,
+    // not a contract) before the barrier in front of the owner's ticket, an agent-scope atomic.  `kept` is a plain store:
+    // no workgroup reads it inside this kernel.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) s_last = (atomicAdd(&hdr->ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
     __syncthreads();

@@ -224,7 +224,6 @@ int vl_blocks(long n) { return (int)std::max<long>(1, std::min<long>((n + 256 * 
 // debiased contrastive loss: row sums of E = exp((S - rowmax) * (1 - I)),  S = F F^T / T
 // ------------------------------------------------------------------------------------------------
 constexpr int UB = 64;            // rows per workgroup and columns per tile (2 x 2 waves of 32 x 32)
-constexpr int MAXDIM = 64;
 
 // per-lane online state of one row
 struct RowAcc { float m, ref, sa, sp, so; };      // m: running maximum; ref: what the three sums are relative to
@@ -369,7 +368,6 @@ __global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, cons
     constexpr int COLF = (UB * LD + 3) & ~3;              // (the W tiles start 16-byte aligned)
     __shared__ __attribute__((aligned(16))) float arena[COLF + 4 * 32 * WP];
     static_assert(2 * UB * LD <= COLF + 4 * 32 * WP, "epilogue does not fit the arena");
-    float* const colf = arena;
     float (*const wt)[32 * WP] = reinterpret_cast<float (*)[32 * WP]>(arena + COLF);
     __shared__ __attribute__((aligned(16))) unsigned char colb[SP::BYTES];      // the tile's bf16x3 planes (first product)
     __shared__ float cmeta[UB][5];                        // TRANS: rowmax, g_* of the tile's columns

@@ -321,11 +321,26 @@ def _cached_image(w, dgrad, n, d, h, wd, k3, stride, p3):
 
 SMALLK = os.environ.get("CETPICK_SMALLK", "1") != "0"
 
+# Bumped by every kernel that writes parameters through raw pointers (sgd_step_, ema_update_: torch's version counters do
+# not see those writes).  Part of the key of every cached derivative of a weight (conv_smallk images, folded BatchNorm).
+WEIGHT_EPOCH = 0
 
-def _smallk_taps(x, w, k3, stride, p3, dil, nd5):
+
+def _bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def inference_mode():
+    """True when the CALLER runs without autograd.  To be evaluated where the user's grad mode is visible - a module's
+    forward, never inside an autograd.Function (grad mode is always off in there) - and handed down explicitly."""
+    return not torch.is_grad_enabled()
+
+
+def _smallk_taps(x, w, k3, stride, p3, dil, nd5, inference):
     """1 / 3: this forward convolution can take the short-reduction inference kernel (conv_smallk.hip) as a 1 x 1 / (3, 1, 1)
-    convolution; 0: not."""
-    if not SMALLK or torch.is_grad_enabled() or not x.is_cuda or stride != 1:
+    convolution; 0: not.  `inference`: the caller's word that no gradient will be asked of this call (inference_mode())."""
+    if not SMALLK or not inference or not x.is_cuda or stride != 1:
         return 0
     if dil is not None and tuple(_k3(dil, nd5)) != (1, 1, 1):
         return 0
@@ -346,7 +361,7 @@ def _smallk_image(w, owner, K, co):
     parameter or folded-weight tensor that outlives the call) and rebuilt when the storage or its version changes."""
     lib = L.lib()
     holder = owner if owner is not None else w
-    key = (w.data_ptr(), holder._version, K, co)
+    key = (w.data_ptr(), holder._version, WEIGHT_EPOCH, K, co)
     cache = getattr(holder, "_mi_smallk", None)
     if cache is None or cache[0] != key:
         img = torch.empty(int(lib.mi_smallk_image_bytes(K, co)), dtype=torch.uint8, device=w.device)
@@ -380,16 +395,18 @@ def _smallk_call(x, w, bias, relu, ntaps, out=None, owner=None):
     return out
 
 
-def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None, owner=None):
+def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None, owner=None, inference=False):
     """y = act(conv(x, w) + res).  x: (N,D,H,W,Ci) or (N,H,W,Ci) channels-last; w in kernel layout.
-    dil: per-axis dilation (stride 1 only)."""
+    dil: per-axis dilation (stride 1 only).  inference: the caller ran inference_mode() where the user's grad mode is visible
+    (this function is also called from autograd.Function.forward, where grad mode is always off); `owner`: the tensor that
+    outlives a temporary view `w` and keeps its cached weight image."""
     _f32c(x, "x")
     if not _phys_ok(w):
         raise L.HipExtensionError("conv weight is not in kernel layout [tap][Cin][Cout]")
     nd5 = x.dim() == 5
     k3, p3 = _k3(k, nd5), _p3(pad, nd5)
     if res is None:
-        taps = _smallk_taps(x, w, k3, stride, p3, dil, nd5)
+        taps = _smallk_taps(x, w, k3, stride, p3, dil, nd5, inference)
         if taps:                                      # inference, short reduction: no tile pipeline (conv_smallk.hip)
             return _smallk_call(x, w, None, relu, taps, owner=owner)
     x5 = _as5d(x)
@@ -670,11 +687,12 @@ class _ConvFn(torch.autograd.Function):
     """y = act(conv(x, W)); W's gradient goes to mod.weight.grad directly."""
 
     @staticmethod
-    def forward(ctx, x, w, mod, relu, mask_dx=False):
+    def forward(ctx, x, w, mod, relu, mask_dx=False, inference=False):
         ctx.mod, ctx.relu, ctx.mask_dx = mod, relu, mask_dx
         y = _stem_fwd_with_stats(x, w, mod) if (getattr(mod, "stats_for_bn", False) and not relu) else None
         if y is None:
-            y = conv_fwd(x, w, mod.k, mod.stride, mod.pad, None, relu, dil=getattr(mod, "dil", None))
+            y = conv_fwd(x, w, mod.k, mod.stride, mod.pad, None, relu, dil=getattr(mod, "dil", None), owner=mod.weight,
+                         inference=inference)
         ctx.save_for_backward(x, y if relu else None)
         ctx.x_needs_grad = x.requires_grad
         return y
@@ -693,7 +711,7 @@ class _ConvFn(torch.autograd.Function):
         if ctx.x_needs_grad:
             # mask_dx: x is the output of a ReLU whose derivative the producer left to this layer (see basic_block)
             dx = conv_dgrad(dy, mod.weight, x.shape, mod.k, mod.stride, mod.pad, None, x if ctx.mask_dx else None, dil=dil)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
 def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None):
@@ -704,7 +722,9 @@ def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None):
         raise L.HipExtensionError("conv weight is not in kernel layout [tap][Cin][Cout]")
     nd5 = x.dim() == 5
     k3, p3 = _k3(k, nd5), _p3(pad, nd5)
-    taps = _smallk_taps(x, w, k3, stride, p3, None, nd5)
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        raise L.HipExtensionError("conv_bias_fwd is inference only (no autograd node)")
+    taps = _smallk_taps(x, w, k3, stride, p3, None, nd5, True)
     if taps:
         return _smallk_call(x, w, _f32c(bias, "bias"), relu, taps, out=out)
     x5 = _as5d(x)
@@ -744,7 +764,7 @@ def conv_bn(conv, bn, x, relu=False):
     if not folded:
         return bn(conv(x), relu=relu)
     src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (float(bn.eps),)
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (float(bn.eps), WEIGHT_EPOCH)
     cache = getattr(bn, "_folded", None)
     if cache is None or cache[0] != key:
         with torch.no_grad():
@@ -770,7 +790,7 @@ def upconv_bn_relu_concat(up, bn, dec, enc):
     if not folded:
         return concat_channels(bn(up(dec, ho, wo), relu=True), enc)
     src = (up.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (float(bn.eps),)
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (float(bn.eps), WEIGHT_EPOCH)
     cache = getattr(bn, "_folded_up", None)
     if cache is None or cache[0] != key:
         with torch.no_grad():
@@ -786,7 +806,7 @@ def upconv_bn_relu_concat(up, bn, dec, enc):
     _f32c(dec, "dec"); _f32c(enc, "enc")
     n, h, w, _ = dec.shape
     co, ce = up.co, enc.shape[-1]
-    t = conv_fwd(dec, up.gemm_view(), 1, 1, 0, owner=up.weight)
+    t = conv_fwd(dec, up.gemm_view(), 1, 1, 0, owner=up.weight, inference=True)      # (`folded` above: no gradient)
     out = torch.empty((n, ho, wo, co + ce), dtype=torch.float32, device=dec.device)
     L.check(L.lib().mi_upconv_tail_fwd(L.ptr(t), L.ptr(cache[1]), L.ptr(cache[2]), L.ptr(enc), L.ptr(out), n, h, w, co, ce, ho, wo,
                                        L.stream()), "mi_upconv_tail_fwd")
@@ -814,7 +834,7 @@ class HipConvNd(nn.Module):
             self.weight.uniform_(-bound, bound)
 
     def forward(self, x, relu=False):
-        return _ConvFn.apply(x, self.weight, self, relu)
+        return _ConvFn.apply(x, self.weight, self, relu, False, inference_mode())
 
 
 class HipConv3d(nn.Module):
@@ -830,7 +850,7 @@ class HipConv3d(nn.Module):
             self.weight.uniform_(-bound, bound)
 
     def forward(self, x, relu=False, mask_dx=False):
-        return _ConvFn.apply(x, self.weight, self, relu, mask_dx)
+        return _ConvFn.apply(x, self.weight, self, relu, mask_dx, inference_mode())
 
 
 class HipConv2d(nn.Module):
@@ -845,12 +865,12 @@ class HipConv2d(nn.Module):
             self.weight.uniform_(-bound, bound)
 
     def forward(self, x, relu=False):
-        return _ConvFn.apply(x, self.weight, self, relu)
+        return _ConvFn.apply(x, self.weight, self, relu, False, inference_mode())
 
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, mod):
+    def forward(ctx, x, w, b, mod, inference=False):
         m, ci = x.shape
         w5 = w.view(w.shape[0], ci, 1, 1, 1) if w.dim() == 5 else _as5(w)
         y = None
@@ -904,7 +924,7 @@ class _LinearFn(torch.autograd.Function):
             L.check(lib.mi_linear_fwd_f32(L.ptr(x), L.ptr(w5), L.ptr(b), L.ptr(y), m, ci, co, L.ptr(ws), ws.numel(),
                                           L.stream()), "mi_linear_fwd_f32")
         else:
-            y = conv_fwd(x.view(m, 1, 1, 1, ci), w5, 1, 1, 0).view(m, -1)
+            y = conv_fwd(x.view(m, 1, 1, 1, ci), w5, 1, 1, 0, owner=w, inference=inference).view(m, -1)
             if b is not None:
                 L.check(L.lib().mi_bias_add(L.ptr(y), L.ptr(b), m, y.shape[1], L.stream()), "mi_bias_add")
         ctx.mod = mod
@@ -944,7 +964,7 @@ class _LinearFn(torch.autograd.Function):
         dx = None
         if ctx.x_needs_grad:
             dx = conv_dgrad(dy.view(m, 1, 1, 1, co), _as5(mod.weight), (m, 1, 1, 1, ci), 1, 1, 0).view(m, ci)
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 def _as5(w2):
@@ -968,7 +988,7 @@ class HipLinear(nn.Module):
     def forward(self, x):
         if not _phys_ok(self.weight):
             raise L.HipExtensionError("linear weight is not in kernel layout [in][out]")
-        return _LinearFn.apply(_f32c(x, "x"), self.weight, self.bias, self)
+        return _LinearFn.apply(_f32c(x, "x"), self.weight, self.bias, self, inference_mode())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1682,12 +1702,14 @@ def column_std_mean(x):
 # optimiser-side passes
 # ------------------------------------------------------------------------------------------------
 def ema_update_(k_flat, q_flat, m):
+    _bump_weight_epoch()                 # a raw-pointer write: torch's version counters do not see it
     L.check(L.lib().mi_ema_update(L.ptr(k_flat), L.ptr(q_flat), float(m), k_flat.numel(), L.stream()),
             "mi_ema_update")
 
 
 def sgd_step_(p_flat, g_flat, lr, weight_decay=0.0, lr_dev=None, grad_scale=1.0):
     """p -= lr * (grad_scale * g + wd * p); grad_scale = 1 / world when g is the SUM of the ranks' gradients."""
+    _bump_weight_epoch()
     L.check(L.lib().mi_sgd_step(L.ptr(p_flat), L.ptr(g_flat), L.ptr(lr_dev), float(lr), float(weight_decay),
                                 float(grad_scale), p_flat.numel(), L.stream()), "mi_sgd_step")
 
@@ -1750,10 +1772,10 @@ class _ConvT2x2Fn(torch.autograd.Function):
     """nn.ConvTranspose2d(ci, co, 2, stride=2) cropped to (ho, wo): 1x1 implicit GEMM to 4*co columns + pixel shuffle."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, mod, ho, wo):
+    def forward(ctx, x, w, bias, mod, ho, wo, inference=False):
         n, h, wd, ci = x.shape
         co = mod.co
-        t = conv_fwd(x, mod.gemm_view(), 1, 1, 0)
+        t = conv_fwd(x, mod.gemm_view(), 1, 1, 0, owner=mod.weight, inference=inference)
         y = torch.empty((n, ho, wo, co), dtype=torch.float32, device=x.device)
         L.check(L.lib().mi_shuffle2x2_fwd(L.ptr(t), L.ptr(bias), L.ptr(y), n, h, wd, co, ho, wo, L.stream()),
                 "mi_shuffle2x2_fwd")
@@ -1785,7 +1807,7 @@ class _ConvT2x2Fn(torch.autograd.Function):
             if acc:
                 g.add_(tgt)
         dx = conv_dgrad(dt, mod.gemm_view(), x.shape, 1, 1, 0) if ctx.x_needs_grad else None
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 class HipConvTranspose2x2(nn.Module):
@@ -1809,7 +1831,7 @@ class HipConvTranspose2x2(nn.Module):
     def forward(self, x, ho=None, wo=None):
         n, h, w, _ = x.shape
         return _ConvT2x2Fn.apply(_f32c(x, "x"), self.weight, self.bias, self, 2 * h if ho is None else ho,
-                                 2 * w if wo is None else wo)
+                                 2 * w if wo is None else wo, inference_mode())
 
 
 class _ConcatFn(torch.autograd.Function):

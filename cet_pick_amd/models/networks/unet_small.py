@@ -122,6 +122,14 @@ class TomoConvUNet(nn.Module):
                 with torch.no_grad():
                     m.weight.normal_(std=0.001)
 
+    def _all_bn_eval(self):
+        """Every BatchNorm under the net normalises with running statistics: only then are the slices independent and the
+        chunked forward equal to the whole-volume one (a BatchNorm left in train mode, or built with
+        track_running_stats=False, takes batch statistics - per chunk they would differ, and running statistics would be
+        updated once per chunk)."""
+        return all((not m.training) and m.track_running_stats and m.running_mean is not None
+                   for m in self.modules() if isinstance(m, H.HipBatchNorm))
+
     def forward(self, x):
         if x.dim() > 4:
             x = x.squeeze()
@@ -130,7 +138,7 @@ class TomoConvUNet(nn.Module):
         b, d, h, w = x.shape
         x = L.require_cuda(x, "x").contiguous().view(b * d, h, w, 1)              # one image per slice
         chunk = int(getattr(self, "slice_chunk", 16))
-        if not self.training and not torch.is_grad_enabled() and chunk > 0 and b * d > chunk:
+        if not self.training and not torch.is_grad_enabled() and chunk > 0 and b * d > chunk and self._all_bn_eval():
             # inference on a whole tomogram: the per-slice 2-D U-Net runs `slice_chunk` slices at a time (evaluation-mode
             # BatchNorm: slices are independent), so its activations - the skip connections of every level, 17.7 GB for a
             # 128 x 512 x 512 volume - exist for one chunk only; what stays is the 32-channel feature volume the 3-D head reads

@@ -231,18 +231,30 @@ class MocoStepEngine:
 
     @staticmethod
     def _drain_watchdog():
-        """Data parallel, before a capture: let the process group's watchdog thread finish with the Works of the eager steps.
+        """Data parallel, before a capture: wait until the process group's watchdog thread holds no Work of the eager steps.
         The watchdog polls its list every 100 ms (hipEventQuery on each Work's end event) and drops the Works it finds
         complete.  A Work of the eager warm-up steps that is still on that list when the capture starts gets polled DURING
         the capture - and ProcessGroupNCCL's internal communication stream, on which that end event was recorded, is by then
         part of the capture: ROCm answers hipErrorCapturedEvent ("operation not permitted on an event last recorded in a
         capturing stream") for an event whose stream is capturing NOW, the watchdog rethrows and the process aborts
         (profiles/r04_watchdog_abort.txt: 1 run in ~10; `thread_local` capture mode cured the other form of this race, the
-        query of an unrelated event under `global` mode).  The list has no accessor, so the drain is a wait: the device is
-        idle (synchronised by the caller), every Work is complete, and three poll periods later the list is empty.  Paid once
-        per capture, never per step.  CETPICK_WATCHDOG_DRAIN_S overrides the 0.3 s."""
+        query of an unrelated event under `global` mode).
+        The drain is a synchronisation, not a timer: the caller has synchronised the device (every Work is complete), and
+        `ProcessGroup._wait_for_pending_works()` (c10d: ProcessGroupNCCL::waitForPendingWorks) returns once it has seen, under
+        the watchdog's own two mutexes, BOTH the watchdog's work list and its completed-work list empty - it re-checks every
+        watchdog poll period until then.  Nothing is issued between that return and the capture, so the list is still empty
+        when the capture begins, and every collective of the captured step is synchronous (no Work is registered under
+        capture).  Paid once per capture, never per step.  Only a torch build without the binding falls back to waiting
+        three poll periods (CETPICK_WATCHDOG_DRAIN_S, default 0.3 s) - and says so."""
+        d = _dist()
+        pg = d.distributed_c10d._get_default_group()
+        wait = getattr(pg, "_wait_for_pending_works", None)
+        if wait is not None:
+            wait()
+            return
         import os
         import time
+        warnings.warn("this torch has no ProcessGroup._wait_for_pending_works: draining the watchdog by a timed wait")
         time.sleep(float(os.environ.get("CETPICK_WATCHDOG_DRAIN_S", "0.3")))
 
     def _capture(self, im_q, im_k):
@@ -257,12 +269,11 @@ class MocoStepEngine:
         graph = torch.cuda.CUDAGraph(keep_graph=True)      # the hipGraph_t stays queryable (node_counts)
         err = None
         try:
-            # Data parallel: the process group's watchdog THREAD polls (hipEventQuery) the works of the eager warm-up steps
-            # at its own pace; under the default "global" capture mode such a call from another thread while this one is
-            # capturing is an error that terminates the process (hipErrorStreamCaptureUnsupported: seen once in ~20 runs of
-            # the one-rank rehearsal).  "thread_local" restricts only the capturing thread - which issues everything the
-            # step needs; HIP then checks only this thread's own capture list, so no drain of the watchdog is needed (the
-            # device was synchronised above: every warm-up work has finished, whenever the watchdog gets to see it).
+            # Data parallel: the process group's watchdog THREAD polls (hipEventQuery) Works at its own pace.  Two races, two
+            # cures: (1) under the default "global" capture mode ANY such call from another thread while this one is
+            # capturing terminates the process (hipErrorStreamCaptureUnsupported) - "thread_local" restricts only the capturing
+            # thread; (2) a query of an event whose own stream has joined the capture fails in either mode
+            # (hipErrorCapturedEvent) - _drain_watchdog() above emptied the watchdog's list, and nothing captured adds to it.
             mode = "thread_local" if self.dist_on else "global"
             with torch.cuda.graph(graph, capture_error_mode=mode):       # records, does not execute
                 self._step_eager(self._static_q, self._static_k)
@@ -313,6 +324,7 @@ class MocoStepEngine:
             return self._step_eager(im_q, im_k)
         self._static_q.copy_(im_q)
         self._static_k.copy_(im_k)
+        H._bump_weight_epoch()                          # the replayed SGD / momentum kernels write the arenas (no Python runs)
         self._graph.replay()
         return self.loss
 
