@@ -50,6 +50,12 @@ Peak3Grid mi_peak3_grid(int D, int H, int W);
 bool mi_peak3_usable(const float* in, const float* val_out, const float* nms_out, int D, int H, int W);
 int mi_launch_peak3(Peak3Params p, const Peak3Grid& g, bool sigmoid, hipStream_t s);
 
+// the decode in one launch (infer_decode1.hip): march + per-workgroup best lists + last-arriver selection
+size_t mi_decode1_extra_bytes(int D, int H, int W);
+bool mi_decode1_usable(const float* in, const float* val_out, int D, int H, int W, int K);
+int mi_launch_decode1(const float* in, float* val_out, int D, int H, int W, bool sigmoid, int K, float* dets, int* n_valid_out,
+                      DecodeHeader* hdr, uint2* cands, unsigned* seg_count, void* extra, hipStream_t s);
+
 // fused x pass + DoG + 3x3 xy-NMS + statistics + candidate compaction of the picker (infer_dogx.hip)
 struct DogxParams {
     const float* y1;        // smaller sigma, after the z and y passes

@@ -736,7 +736,8 @@ extern "C" size_t mi_decode_workspace_bytes(int D, int H, int W, int K) {
     const Peak3Grid g = mi_peak3_grid(D, H, W);
     size_t n_cand = std::max(n, (size_t)g.n_seg * g.seg_cap);
     return mi_align_up(sizeof(DecodeHeader), 256) + mi_align_up(n_cand * sizeof(uint2), 256) +
-           mi_align_up((size_t)MI_SEL_CAP * sizeof(uint2), 256) + mi_align_up((size_t)g.n_seg * sizeof(unsigned), 256);
+           mi_align_up((size_t)MI_SEL_CAP * sizeof(uint2), 256) + mi_align_up((size_t)g.n_seg * sizeof(unsigned), 256) +
+           mi_decode1_extra_bytes(D, H, W);
 }
 
 extern "C" int mi_sigmoid_nms_topk(const float* logits, float* heat_out, int D, int H, int W,
@@ -759,6 +760,8 @@ extern "C" int mi_sigmoid_nms_topk(const float* logits, float* heat_out, int D, 
     uint2* sel = (uint2*)w;
     w += mi_align_up((size_t)MI_SEL_CAP * sizeof(uint2), 256);
     unsigned* seg_count = (unsigned*)w;
+    w += mi_align_up((size_t)g.n_seg * sizeof(unsigned), 256);
+    void* extra1 = (void*)w;                                // table + bounds of the one-launch decode
     // bit 1 of `apply_sigmoid`: the caller vouches that the workspace header is clean - zeroed once by
     // mi_decode_workspace_init and, since then, only used by calls that passed this bit (they leave it clean again)
     const int self_clean = (apply_sigmoid & 2) ? 1 : 0;
@@ -773,6 +776,11 @@ extern "C" int mi_sigmoid_nms_topk(const float* logits, float* heat_out, int D, 
         attr_set = true;
     }
     float* val_out = apply_sigmoid ? heat_out : nullptr;
+
+    if (!fiber && k == 3 && mi_decode1_usable(logits, val_out, D, H, W, K))
+        // ONE launch: march, per-workgroup best lists, selection by the last workgroup to finish (infer_decode1.hip)
+        return mi_launch_decode1(logits, val_out, D, H, W, apply_sigmoid != 0, K, dets, (int*)n_valid_out, hdr, cands, seg_count,
+                                 extra1, s);
 
     if (!fiber && k == 3 && mi_peak3_usable(logits, val_out, nullptr, D, H, W)) {
         // register march: per-wave candidate segments, no global candidate counter

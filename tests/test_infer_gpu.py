@@ -321,3 +321,44 @@ def test_decode_workspace_stays_clean_between_calls():
         L.check(lib.mi_sigmoid_nms_topk(L.ptr(t), None, 10, 40, 64, 3, 0, 0, 200, L.ptr(dets), None, L.ptr(ws), ws.numel(),
                                         L.stream()), "mi_sigmoid_nms_topk")
         _cmp_dets(dets.cpu().numpy(), wa, floor=0)
+
+
+def test_decode_one_launch_paths_match_the_chain_and_the_oracle(monkeypatch):
+    """infer_decode1.hip (one launch: per-workgroup best lists + selection by the last workgroup) against the three-launch
+    chain (MI_DECODE_CHAIN=1) and the oracle, on inputs that take each of its paths: the plain one; every one of the K best
+    inside ONE workgroup's region (its list is too short: the bound check sends the call to the exact radix select over
+    the segments); K above what the tables hold; a grid of more than 256 workgroups (table read in chunks); a plateau
+    region (lanes run out of list slots: spill)."""
+    from oracle import infer_ref as O
+    from cet_pick_amd.models import decode as Dm
+
+    def both(logits, K, sig=True):
+        t = dev(logits)[None, None]
+        fn = (lambda: Dm.sigmoid_tomo_decode(t, kernel=3, K=K)) if sig else (lambda: (t, Dm.tomo_decode(t, kernel=3, K=K)))
+        heat, d1 = fn()
+        monkeypatch.setenv("MI_DECODE_CHAIN", "1")
+        heat2, d2 = fn()
+        monkeypatch.delenv("MI_DECODE_CHAIN")
+        np.testing.assert_array_equal(heat[0, 0].cpu().numpy(), heat2[0, 0].cpu().numpy())
+        np.testing.assert_array_equal(d1[0].cpu().numpy(), d2[0].cpu().numpy())
+        want = O.tomo_decode(heat[0, 0].cpu().numpy(), kernel=3, K=K)
+        _cmp_dets(d1[0].cpu().numpy(), want, floor=0)
+        return d1[0].cpu().numpy()
+
+    rng = np.random.default_rng(5)
+    # plain: the benchmark's kind of volume, smaller
+    both(make_logits((32, 128, 256), seed=9), 300)
+    # all strong peaks inside one workgroup's 32 rows x 4 planes (z 0..3, y 0..31): more than its list holds
+    lg = (rng.standard_normal((16, 64, 256)) - 4).astype(np.float32)
+    zz, yy, xx = np.meshgrid(np.arange(0, 4, 2), np.arange(1, 31, 3), np.arange(2, 250, 4), indexing="ij")
+    lg[zz.ravel(), yy.ravel(), xx.ravel()] = rng.uniform(2, 6, zz.size).astype(np.float32)
+    d = both(lg, 200)
+    assert np.all(d[:, 2] < 4) and np.all(d[:, 1] < 32)
+    # K larger than (workgroups x list length)
+    both(make_logits((8, 64, 64), seed=2), 900)
+    # 512 workgroups (2 x 32 x 4): the selecting workgroup reads the table in two chunks
+    both(make_logits((16, 1024, 512), seed=4), 500)
+    # plateau slab inside noise (every voxel of the slab is a maximum of its window): spill path, ties by index
+    hm = (rng.random((12, 40, 256)) * 0.5 + 0.05).astype(np.float32)
+    hm[4:8, 8:24, 64:192] = 0.9
+    both(hm, 700, sig=False)
