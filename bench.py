@@ -102,6 +102,65 @@ def cpu_baseline(batch, steps, seed):
     return batch * steps / dt, torch.get_num_threads()
 
 
+def entry_point_record(batch, min_iters=50):
+    """What `moco_main` delivers through its own loader: the C2 tomogram written as an MRC file + the
+    reference's image list, `cet_pick_amd.moco_main.build(opt)` (encoders, MoCo, SGD, trainer = step engine,
+    TomoFileMocoLoader: device load_rec / preprocess -> DoG picks -> crop centres), one warm-up epoch (it captures the
+    hipGraph), then `trainer.train(epoch, loader)` - the real run_epoch with its meters - timed by the wall clock over
+    >= `min_iters` iterations.  Sub-tomograms/s = iterations x batch / seconds.  N = 1 only."""
+    import shutil
+    import tempfile
+    from cet_pick_amd import moco_main
+    from cet_pick_amd.opts import opts
+    from cet_pick_amd.synthetic import make_tomo
+    from cet_pick_amd.utils import mrc
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp(prefix="cetpick_entry_")
+    try:
+        os.chdir(tmp)
+        os.makedirs("data")
+        vol, _ = make_tomo((128, 512, 512), seed=317)
+        mrc.write(os.path.join("data", "c2.rec"), vol)
+        with open(os.path.join("data", "train_images.txt"), "w") as f:
+            f.write("image_name\trec_path\nc2\tc2.rec\n")
+        opt = opts().parse(["moco", "--arch", "moco3d_18", "--dataset", "simsiam3d", "--order", "zxy", "--batch_size", str(batch),
+                            "--lr", "0.001", "--exp_id", "bench_entry", "--debug", "0", "--dog", "3,5", "--num_epochs", "1"])
+        t_build = time.perf_counter()
+        opt, model, optimizer, trainer, loader, _, _, _ = moco_main.build(opt)
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - t_build
+        iters = len(loader)
+        epochs = max(1, -(-min_iters // max(iters, 1)))
+        loader.set_epoch(0)
+        trainer.train(0, loader)                            # warm-up: eager steps, graph capture, allocator
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for e in range(1, epochs + 1):
+            loader.set_epoch(e)
+            log_dict, _ = trainer.train(e, loader)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_it = epochs * iters
+        rec = {"value": n_it * batch / dt, "unit": "subtomograms/sec", "iterations": n_it, "epochs": epochs,
+               "ms_per_iteration": dt / n_it * 1e3, "crop_centres": int(len(loader.centres)), "final_loss": float(log_dict["loss"]),
+               "setup_s": t_build,
+               "path": "python -m cet_pick_amd.moco_main moco --arch moco3d_18 --batch_size %d: MRC file -> device loader -> DoG "
+                       "picks -> TomoFileMocoLoader (mi_crop_normalize_table, two launches per batch) -> BaseTrainer.run_epoch -> "
+                       "MocoStepEngine (hipGraph)" % batch}
+        trainer.close()
+        return rec
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round present (the profile refresh of a round writes its own tag)"""
+    import glob
+    c = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_" + suffix)))
+    return c[-1] if c else None
+
+
 def _traffic(fname, kernels):
     """HBM bytes per launch of `kernels` from a PMC summary under profiles/ (tools/pmc_summary.py), or None when the
     summary was measured on other kernel sources than the ones in the tree (its source hash no longer matches)."""
@@ -222,7 +281,7 @@ def inference_secondary(dev, with_cpu=True, rank=0, world=1):
     out = {
         "metric": "voxels/sec (heatmap+NMS)",
         "decode_sigmoid_nms_topk": entry("logits 1x1x128x256x256, k=3, K=900: sigmoid+clamp -> (3,3,3) NMS -> top-K", logits.numel(),
-                                         t_dec, {"peak3_march_kernel": 1, "topk_filter_seg_kernel": 1, "topk_final_kernel": 1},
+                                         t_dec, {"decode1_kernel": 1},
                                          INFER_TRAFFIC),
         "dog_pick": entry("tomogram 256x512x512, sigma=(3,5), nms_xy k=3, greedy d=14", v.numel(), t_dog,
                           DOG_KERNELS, INFER_TRAFFIC),
@@ -308,8 +367,8 @@ def inference_secondary(dev, with_cpu=True, rank=0, world=1):
 
 # PMC traffic summary of the inference chains (tools/pmc_run.sh + tools/pmc_summary.py) and the kernels of the picker's
 # chain that it is summed over - EVERY launch of the call, not only the Gaussians
-INFER_TRAFFIC = "r04_infer_traffic.json"
-DOG_KERNELS = ("not", "peak3_", "topk_", "zero_header", "nms_march")      # = everything the picker launches
+INFER_TRAFFIC = os.path.basename(_latest_profile("infer_traffic.json") or "r05_infer_traffic.json")
+DOG_KERNELS = ("not", "decode1_", "peak3_", "topk_", "zero_header", "nms_march")      # = everything the picker launches
 
 T_START = time.perf_counter()
 
@@ -365,6 +424,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-conv-profile", action="store_true", help="skip the per-launch roofline pass (clean rocprofv3 runs of the step)")
+    ap.add_argument("--no-entry-point", action="store_true", help="skip the moco_main entry-point record (MRC file -> loader -> run_epoch)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
@@ -546,21 +606,21 @@ def main():
                                      for t, v in sorted(by.items())},
                          "measured": "per conv call of 3 eager steps after the timed region: 8 back-to-back launches of the "
                                      "call (kernel + its split-K reduce) between two HIP events on the launch stream; "
-                                     "compare profiles/r04_train_kernel_stats.csv"},
+                                     "compare profiles/%s" % os.path.basename(_latest_profile("train_kernel_stats.csv") or "r05_train_kernel_stats.csv")},
         }
         # HBM traffic of the conv kernels from PMC counters (tools/pmc_run.sh + tools/pmc_summary.py: separate rocprofv3
         # --pmc passes of this workload; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), per conv call.
         # The summary carries the hash of the kernel sources it was measured on: a stale one is not quoted.
-        tpath = os.path.join(REPO, "profiles", "r04_conv_traffic.json")
-        if os.path.exists(tpath):
+        tpath = _latest_profile("conv_traffic.json")
+        if tpath:
             from cet_pick_amd.build import source_sha16
             tj = json.load(open(tpath))
             if tj.get("source_sha16") == source_sha16(tj.get("source_prefixes")):
                 out["roofline"]["traffic"] = tj["hbm_bytes_per_step"] / (n_launch // 3)
-                out["roofline"]["traffic_note"] = ("bytes per conv call (%d per step), profiles/r04_conv_traffic.json"
-                                                   % (n_launch // 3))
+                out["roofline"]["traffic_note"] = ("bytes per conv call (%d per step), profiles/%s"
+                                                   % (n_launch // 3, os.path.basename(tpath)))
             else:
-                out["roofline"]["traffic_note"] = "stale: profiles/r04_conv_traffic.json was measured on other kernel sources"
+                out["roofline"]["traffic_note"] = "stale: profiles/%s was measured on other kernel sources" % os.path.basename(tpath)
         if f32_ms is not None:
             out["f32_mfma_step"] = {"ms_per_step": f32_ms, "value": B / (f32_ms * 1e-3),
                                     "note": "the same step with MI_CONV_ARITH=f32 (v_mfma_f32_32x32x2_f32 in the generic kernel)"}
@@ -582,7 +642,28 @@ def main():
             out["cpu_baseline"] = {"value": v, "unit": "subtomograms/sec", "cores": cores, "kind": "port",
                                    "sample": "4 MoCo steps of batch 64 (after 1 warm-up) of the same workload "
                                              "with oracle/train_ref.py (torch fp32, all host cores)"}
+    if rank == 0 and world == 1 and not dist_active and not args.no_entry_point:
+        engine.close()                              # (its graph and buffers are no longer needed: the record builds its own)
+        out["entry_point"] = entry_point_record(B)
+        out["entry_point"]["ratio_to_value"] = out["entry_point"]["value"] / out["value"]
+        log("entry-point record done")
     if rank == 0:
+        # the whole metric as top-level scalars, in front of the long nested blocks (the driver's parsed record keeps these)
+        head = {}
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step"):
+            head[k] = out[k]
+        sec = out.get("secondary") or {}
+        dec, dog = sec.get("decode_sigmoid_nms_topk"), sec.get("dog_pick")
+        head["voxels_per_sec_decode"] = dec["voxels_per_sec"] if dec else None
+        head["voxels_per_sec_dog"] = dog["voxels_per_sec"] if dog else None
+        head["decode_ms"] = dec["ms"] if dec else None
+        head["dog_ms"] = dog["ms"] if dog else None
+        head["f32_mfma_ms_per_step"] = out["f32_mfma_step"]["ms_per_step"] if "f32_mfma_step" in out else None
+        head["entry_point_value"] = out["entry_point"]["value"] if "entry_point" in out else None
+        head["unet4_forward_ms"] = (sec.get("detector") or {}).get("unet4_forward", {}).get("ms")
+        head["semi_train_step_ms"] = (sec.get("detector") or {}).get("semi_train_step", {}).get("ms")
+        head.update({k: v for k, v in out.items() if k not in head})
+        out = head
         emit(out)                                    # the line is out before any tear-down
     if dist_active:
         # tear-down in dependency order: the captured hipGraph (it holds the RCCL kernels and the events of the async

@@ -36,6 +36,7 @@ SIGNATURES = {
     "mi_greedy_nms3d_workspace_bytes": (_Z, [_I, _I, _I]),
     "mi_greedy_nms3d": (_I, [_P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _I, _P, _Z, _P]),
     "mi_crop_normalize": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "mi_crop_normalize_table": (_I, [_P, _P, _P, _P, _P, _c.c_int64, _I, _I, _I, _I, _I, _I, _P, _P]),
     "mi_u8_roundtrip_normalize": (_I, [_P, _P, _Z, _F, _F, _P]),
     # training path
     "mi_gauss2d_slices": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),

@@ -95,13 +95,12 @@ __global__ void u8_roundtrip_normalize_kernel(const float* __restrict__ x, float
 
 // window start along an axis: the reference slices [c - s//2, c - s//2 + s) (z windows are odd:
 // c - s//2 .. c + s//2, xy windows even: c - s/2 .. c + s/2 - 1)
-__global__ __launch_bounds__(256) void crop_kernel(const float* __restrict__ vol, int D, int H, int W,
-                                                  const int* __restrict__ centres, int cz, int cy,
-                                                  int cx, int mode, int flip_x, float* __restrict__ out) {
+__device__ __forceinline__ void crop_body(const float* __restrict__ vol, int D, int H, int W, int c_x, int c_y, int c_z,
+                                          int cz, int cy, int cx, int mode, int flip_x, float* __restrict__ out) {
     __shared__ float red[2][4];
     extern __shared__ float plane[];               // SUMZ: cy*cx floats
     const int n = blockIdx.x, tid = threadIdx.x;
-    const int x0 = centres[3 * n + 0] - cx / 2, y0 = centres[3 * n + 1] - cy / 2, z0 = centres[3 * n + 2] - cz / 2;
+    const int x0 = c_x - cx / 2, y0 = c_y - cy / 2, z0 = c_z - cz / 2;
     const long HW = (long)H * W;
     const int vox = cz * cy * cx, pix = cy * cx;
     auto at = [&](int z, int y, int x) {
@@ -147,6 +146,112 @@ __global__ __launch_bounds__(256) void crop_kernel(const float* __restrict__ vol
     }
 }
 
+// z-normalised (or raw) crops whose rows fit a wave and whose voxels fit the registers of 1024 threads (32^3, 6 x 48 x 48,
+// 6 x 64 x 64 ...): ONE read of the crop.  A wave takes 64 / cxp rows of the crop at a time (cxp = cx rounded up to a power
+// of two: lanes run along x, a 32-wide row pair is one 256-byte access), a thread keeps its <= 32 values, the statistics go
+// through one workgroup reduction, the normalised values leave as coalesced rows.  The generic kernel reads the crop twice
+// with three integer divisions per element on 256 threads: 90 us for the 64 crops of a MoCo batch - a tenth of the training
+// step it feeds (tools/ab/entry_host.py); this one takes a few microseconds.
+constexpr int CF_T = 1024, CF_MAXIT = 32;
+__device__ __forceinline__ void crop_fast_body(const float* __restrict__ vol, int D, int H, int W, int c_x, int c_y, int c_z,
+                                               int cz, int cy, int cx, int lcxp, int znorm, int flip_x, float* __restrict__ out) {
+    __shared__ double rs[2][CF_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cxp = 1 << lcxp, rpw = 64 >> lcxp;              // rows a wave takes per iteration
+    const int x = lane & (cxp - 1), sub = lane >> lcxp;
+    const int x0 = c_x - cx / 2, y0 = c_y - cy / 2, z0 = c_z - cz / 2;
+    const int n_rows = cz * cy, step = (CF_T / 64) * rpw;
+    const bool x_ok = x < cx;
+    const int sx = clampi(x0 + (flip_x ? cx - 1 - x : x), 0, W - 1);
+    const long HW = (long)H * W;
+    float v[CF_MAXIT];
+    int row = wv * rpw + sub;
+    int z = row / cy, y = row - z * cy;                       // (one division per thread; the march below only adds)
+    const int dz = step / cy, dy = step - dz * cy;
+    double s = 0, ss = 0;
+#pragma unroll
+    for (int k = 0; k < CF_MAXIT; ++k) {
+        v[k] = 0.f;
+        if (row + k * step < n_rows && x_ok) {
+            v[k] = vol[(long)clampi(z0 + z, 0, D - 1) * HW + (long)clampi(y0 + y, 0, H - 1) * W + sx];
+            s += v[k]; ss += (double)v[k] * v[k];
+        }
+        z += dz; y += dy;
+        if (y >= cy) { y -= cy; ++z; }
+    }
+    float m = 0.f, inv = 1.f;
+    if (znorm) {
+        s = wave_sum(s); ss = wave_sum(ss);
+        if (lane == 0) { rs[0][wv] = s; rs[1][wv] = ss; }
+        __syncthreads();
+        double S = 0, SS = 0;
+#pragma unroll
+        for (int w = 0; w < CF_T / 64; ++w) { S += rs[0][w]; SS += rs[1][w]; }
+        const int vox = n_rows * cx;
+        const double mean = S / vox;
+        double var = (SS - vox * mean * mean) / (vox - 1);    // unbiased, as torch.std
+        if (var < 0) var = 0;
+        m = (float)mean; inv = (float)(1.0 / sqrt(var));
+    }
+    float* o = out + (long)blockIdx.x * n_rows * cx;
+#pragma unroll
+    for (int k = 0; k < CF_MAXIT; ++k) {
+        const int r = row + k * step;
+        if (r < n_rows && x_ok) o[(long)r * cx + x] = znorm ? (v[k] - m) * inv : v[k];
+    }
+}
+
+__global__ __launch_bounds__(CF_T) void crop_fast_kernel(const float* __restrict__ vol, int D, int H, int W,
+                                                        const int* __restrict__ centres, int cz, int cy, int cx, int lcxp,
+                                                        int znorm, int flip_x, float* __restrict__ out) {
+    const int n = blockIdx.x;
+    crop_fast_body(vol, D, H, W, centres[3 * n + 0], centres[3 * n + 1], centres[3 * n + 2], cz, cy, cx, lcxp, znorm, flip_x, out);
+}
+
+// 0 when the fast kernel does not take the shape / mode, else log2 of the padded row width + 1
+int crop_fast_shape(int cz, int cy, int cx, int mode) {
+    if ((mode != CROP_RAW && mode != CROP_ZNORM) || cx > 64 || getenv("MI_CROP_GENERIC")) return 0;
+    int l = 0;
+    while ((1 << l) < cx) ++l;
+    const int step = (CF_T / 64) * (64 >> l);
+    if (((long)cz * cy + step - 1) / step > CF_MAXIT) return 0;
+    return l + 1;
+}
+
+__global__ __launch_bounds__(256) void crop_kernel(const float* __restrict__ vol, int D, int H, int W,
+                                                  const int* __restrict__ centres, int cz, int cy,
+                                                  int cx, int mode, int flip_x, float* __restrict__ out) {
+    const int n = blockIdx.x;
+    crop_body(vol, D, H, W, centres[3 * n + 0], centres[3 * n + 1], centres[3 * n + 2], cz, cy, cx, mode, flip_x, out);
+}
+
+// The same crops with everything a batch needs already on the device (mi_crop_normalize_table): crop n of the launch is
+// sample order[first + n] of the dataset; its tomogram, centre and (second view) shift come from per-sample tables.  No
+// per-batch host work, no index upload: the reference's DataLoader workers (datasets/particle_pre_3d_vol.py:70-85 under
+// moco_main.py:122-130) become two launches per batch.
+__global__ __launch_bounds__(256) void crop_table_kernel(const mi_vol_desc* __restrict__ vols, const int* __restrict__ owner,
+                                                        const int* __restrict__ centres, const int* __restrict__ shift,
+                                                        const long long* __restrict__ order, long long first, int cz, int cy,
+                                                        int cx, int mode, int flip_x, float* __restrict__ out) {
+    const long long i = order ? order[first + blockIdx.x] : first + blockIdx.x;
+    const mi_vol_desc d = vols[owner ? owner[i] : 0];
+    int c_x = centres[3 * i + 0], c_y = centres[3 * i + 1], c_z = centres[3 * i + 2];
+    if (shift) { c_x += shift[3 * i + 0]; c_y += shift[3 * i + 1]; c_z += shift[3 * i + 2]; }
+    crop_body(d.vol, d.D, d.H, d.W, c_x, c_y, c_z, cz, cy, cx, mode, flip_x, out);
+}
+
+__global__ __launch_bounds__(CF_T) void crop_table_fast_kernel(const mi_vol_desc* __restrict__ vols, const int* __restrict__ owner,
+                                                              const int* __restrict__ centres, const int* __restrict__ shift,
+                                                              const long long* __restrict__ order, long long first, int cz,
+                                                              int cy, int cx, int lcxp, int znorm, int flip_x,
+                                                              float* __restrict__ out) {
+    const long long i = order ? order[first + blockIdx.x] : first + blockIdx.x;
+    const mi_vol_desc d = vols[owner ? owner[i] : 0];
+    int c_x = centres[3 * i + 0], c_y = centres[3 * i + 1], c_z = centres[3 * i + 2];
+    if (shift) { c_x += shift[3 * i + 0]; c_y += shift[3 * i + 1]; c_z += shift[3 * i + 2]; }
+    crop_fast_body(d.vol, d.D, d.H, d.W, c_x, c_y, c_z, cz, cy, cx, lcxp, znorm, flip_x, out);
+}
+
 }  // namespace
 
 extern "C" int mi_crop_normalize(const float* vol, int D, int H, int W, const int32_t* centres_xyz,
@@ -169,10 +274,38 @@ extern "C" int mi_crop_normalize(const float* vol, int D, int H, int W, const in
         MI_RETURN_IF_LAUNCH_FAILED();
         return MI_OK;
     }
+    if (const int f = crop_fast_shape(cz, cy, cx, mode)) {
+        hipLaunchKernelGGL(crop_fast_kernel, dim3(n), dim3(CF_T), 0, (hipStream_t)stream, vol, D, H, W, (const int*)centres_xyz,
+                           cz, cy, cx, f - 1, mode == CROP_ZNORM ? 1 : 0, flip_x, out);
+        MI_RETURN_IF_LAUNCH_FAILED();
+        return MI_OK;
+    }
     size_t lds = (mode == CROP_SUMZ_MINMAX) ? sizeof(float) * (size_t)cy * cx : 0;
     if (lds > 64 * 1024) return MI_E_UNSUPPORTED;
     hipLaunchKernelGGL(crop_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, vol, D, H, W,
                        (const int*)centres_xyz, cz, cy, cx, mode, flip_x, out);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_crop_normalize_table(const mi_vol_desc* vols, const int32_t* owner, const int32_t* centres_xyz,
+                                       const int32_t* shift_xyz, const int64_t* order, int64_t first, int n, int cz, int cy,
+                                       int cx, int mode, int flip_x, float* out, mi_stream_t stream) {
+    if (n == 0) return MI_OK;
+    if (!vols || !centres_xyz || !out || n < 0 || first < 0) return MI_E_ARG;
+    if (cz <= 0 || cy <= 0 || cx <= 0 || mode < 0 || mode > 2) return MI_E_ARG;      // (mode 3 keeps its own kernel)
+    if (const int f = crop_fast_shape(cz, cy, cx, mode)) {
+        hipLaunchKernelGGL(crop_table_fast_kernel, dim3(n), dim3(CF_T), 0, (hipStream_t)stream, vols, (const int*)owner,
+                           (const int*)centres_xyz, (const int*)shift_xyz, (const long long*)order, (long long)first, cz, cy, cx,
+                           f - 1, mode == CROP_ZNORM ? 1 : 0, flip_x, out);
+        MI_RETURN_IF_LAUNCH_FAILED();
+        return MI_OK;
+    }
+    const size_t lds = (mode == CROP_SUMZ_MINMAX) ? sizeof(float) * (size_t)cy * cx : 0;
+    if (lds > 64 * 1024) return MI_E_UNSUPPORTED;
+    hipLaunchKernelGGL(crop_table_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, vols, (const int*)owner,
+                       (const int*)centres_xyz, (const int*)shift_xyz, (const long long*)order, (long long)first, cz, cy, cx,
+                       mode, flip_x, out);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

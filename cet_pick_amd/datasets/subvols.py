@@ -33,6 +33,52 @@ def _crop(vol, centres, size, mode, flip_x=False):
     return out
 
 
+class CropTable:
+    """Everything `mi_crop_normalize_table` needs to cut any batch of a dataset, resident on the device: one descriptor
+    per tomogram (pointer + extents), and per sample its tomogram, its centre (x, y, z) and the second view's shift.
+    Built once per dataset; a batch is then `cut(order, first, n, ...)` - one launch per view, no host arithmetic, no
+    host-to-device copy (the per-batch work of the reference's DataLoader workers, datasets/particle_pre_3d_vol.py:70-85)."""
+
+    def __init__(self, vols, owner, centres, shift=None):
+        dev = vols[0].device
+        self.vols = [L.require_cuda(v, "vol").contiguous() for v in vols]          # (kept alive: the table holds raw pointers)
+        for v in self.vols:
+            if v.dtype != torch.float32 or v.dim() != 3:
+                raise L.HipExtensionError("CropTable: tomograms must be (D, H, W) float32 device tensors")
+        desc = np.zeros((len(self.vols), 3), dtype=np.int64)                          # struct mi_vol_desc {ptr; D, H; W, 0}
+        for i, v in enumerate(self.vols):
+            d, h, w = (int(a) for a in v.shape)
+            desc[i] = (v.data_ptr(), d | (h << 32), w)
+        self.desc = torch.as_tensor(desc).to(dev)
+        self.owner = torch.as_tensor(np.ascontiguousarray(owner, dtype=np.int32)).to(dev)
+        self.centres = _centres(centres, dev)
+        self.shift = _centres(shift, dev) if shift is not None else None
+        self.n = int(self.centres.shape[0])
+        if int(self.owner.numel()) != self.n or (self.shift is not None and tuple(self.shift.shape) != tuple(self.centres.shape)):
+            raise L.HipExtensionError("CropTable: owner / centres / shift disagree in length")
+
+    def epoch_order(self, order):
+        """the epoch's sample order (any int array) as the device array `cut` indexes"""
+        return torch.as_tensor(np.ascontiguousarray(order, dtype=np.int64)).to(self.desc.device)
+
+    def cut(self, order, first, n, size, mode=ZNORM, shifted=False, flip_x=False, out=None):
+        """crops of samples order[first : first + n] (order None: samples first .. first + n - 1) -> (n, 1, cz, cy, cx)
+        ((n, 1, cy, cx) for mode SUMZ_MINMAX)"""
+        cz, cy, cx = [int(v) for v in size]
+        if first < 0 or n < 0 or first + n > (self.n if order is None else int(order.numel())):
+            raise L.HipExtensionError("CropTable.cut: samples [%d, %d) outside the epoch's order" % (first, first + n))
+        shape = (n, 1, cy, cx) if mode == SUMZ_MINMAX else (n, 1, cz, cy, cx)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=self.desc.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+            raise L.HipExtensionError("CropTable.cut: `out` must be a contiguous float32 %s tensor" % (shape,))
+        L.check(L.lib().mi_crop_normalize_table(L.ptr(self.desc), L.ptr(self.owner), L.ptr(self.centres),
+                                                L.ptr(self.shift if shifted else None), L.ptr(order), int(first), int(n),
+                                                cz, cy, cx, int(mode), int(bool(flip_x)), L.ptr(out), L.stream()),
+                "mi_crop_normalize_table")
+        return out
+
+
 def extract_subvols(v, tomo_coords, subvol_size):
     """:117-128 for every pick: (n, 1, sy, sx) float32 = min-max(sum_z v[z-sz//2 : z+sz//2+1, ...]).
     subvol_size = (sz, sy, sx); an odd sz gives the z-1..z+1 slab of the reference."""

@@ -24,6 +24,7 @@ class SyntheticMocoLoader:
                                  g.integers(hc + 1, z - hc - 1, n_crops)], 1).astype(np.int32)
         self.shift = g.integers(-1, 2, (n_crops, 3)).astype(np.int32)
         self.crop, self.batch_size, self.seed, self.epoch = crop, batch_size, seed, 0
+        self.table = S.CropTable([self.vol], np.zeros(n_crops, dtype=np.int32), self.centres, self.shift)
 
     def set_epoch(self, epoch):
         self.epoch = epoch
@@ -32,9 +33,9 @@ class SyntheticMocoLoader:
         return len(self.centres) // self.batch_size
 
     def __iter__(self):
-        order = np.random.default_rng(self.seed + 1000 * self.epoch).permutation(len(self.centres))
-        c = (self.crop,) * 3
+        # (the epoch's order goes to the device once; a batch is two launches of mi_crop_normalize_table)
+        order = self.table.epoch_order(np.random.default_rng(self.seed + 1000 * self.epoch).permutation(len(self.centres)))
+        c, B = (self.crop,) * 3, self.batch_size
         for b in range(len(self)):
-            idx = order[b * self.batch_size:(b + 1) * self.batch_size]
-            yield {"input": S.crop_znorm(self.vol, self.centres[idx], c),
-                   "input_aug": S.crop_znorm(self.vol, self.centres[idx] + self.shift[idx], c, flip_x=True)}
+            yield {"input": self.table.cut(order, b * B, B, c),
+                   "input_aug": self.table.cut(order, b * B, B, c, shifted=True, flip_x=True)}

@@ -128,12 +128,17 @@ class TomoFileMocoLoader(SyntheticMocoLoader):
         self.shift = g.integers(-1, 2, self.centres.shape).astype(np.int32)
         self.crop, self.batch_size, self.epoch = crop, int(opt.batch_size), 0
         self.rank, self.world = rank, world
+        # the bookkeeping of every batch, on the device once: tomogram descriptors, owner / centre / shift per sample
+        self.table = S.CropTable(self.vols, self.owner, self.centres, self.shift)
         print("Loaded {} {} samples".format(split, len(self.centres)))
 
     def __len__(self):
         return (len(self.centres) // self.world) // self.batch_size
 
     def _cut(self, idx, shifted):
+        """one view of the samples `idx` with the per-batch bookkeeping on the HOST (rounds 3-4: index arithmetic in numpy, an
+        index upload and a scatter per tomogram); kept as the reference form of what `__iter__` serves
+        (tests/test_loader_gpu.py) - the batches themselves come from the device-side table"""
         c = (self.crop,) * 3
         out = torch.empty((len(idx), 1) + c, dtype=torch.float32, device=self.vols[0].device)
         for v in np.unique(self.owner[idx]):
@@ -142,8 +147,15 @@ class TomoFileMocoLoader(SyntheticMocoLoader):
             out[torch.as_tensor(sel, device=out.device)] = S.crop_znorm(self.vols[v], cen, c, flip_x=shifted)
         return out
 
+    def epoch_order(self):
+        """this rank's sample order of the epoch (DistributedSampler semantics: one seeded permutation, rank-strided)"""
+        return np.random.default_rng(self.seed + 1000 * self.epoch).permutation(len(self.centres))[self.rank::self.world]
+
     def __iter__(self):
-        order = np.random.default_rng(self.seed + 1000 * self.epoch).permutation(len(self.centres))[self.rank::self.world]
+        # one upload per EPOCH (the permutation); a batch is two launches that index it - no numpy slice, no np.unique, no
+        # host-to-device copy, no scatter per tomogram (moco_main.py:122-156's DataLoader, minus its workers)
+        order = self.table.epoch_order(self.epoch_order())
+        c, B = (self.crop,) * 3, self.batch_size
         for b in range(len(self)):
-            idx = order[b * self.batch_size:(b + 1) * self.batch_size]
-            yield {"input": self._cut(idx, False), "input_aug": self._cut(idx, True)}
+            yield {"input": self.table.cut(order, b * B, B, c),
+                   "input_aug": self.table.cut(order, b * B, B, c, shifted=True, flip_x=True)}

@@ -24,7 +24,9 @@ from .trains.train_factory import train_factory
 from .utils.utils import adjust_learning_rate
 
 
-def main(opt):
+def build(opt):
+    """Everything `main` sets up before its epoch loop (moco_main.py:27-130): process group, the two encoders under MoCo, SGD,
+    checkpoint resume, trainer (step engine), loader.  -> (opt, model, optimizer, trainer, loader, start_epoch, rank, world)."""
     torch.manual_seed(opt.seed)
     np.random.seed(opt.seed)
     random.seed(opt.seed)
@@ -70,6 +72,11 @@ def main(opt):
     else:
         from .datasets.tomo_files import TomoFileMocoLoader
         loader = TomoFileMocoLoader(opt, crop=opt.bbox, device=opt.device, rank=rank, world=world)
+    return opt, model, optimizer, trainer, loader, start_epoch, rank, world
+
+
+def main(opt):
+    opt, model, optimizer, trainer, loader, start_epoch, rank, world = build(opt)
     log = open(os.path.join(opt.save_dir, "log.txt"), "a") if rank == 0 else None
     for epoch in range(start_epoch + 1, opt.num_epochs + 1):
         np.random.seed(epoch)

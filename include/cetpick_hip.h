@@ -147,6 +147,19 @@ int mi_greedy_nms3d(const float* vol, int D, int H, int W, float d, float scale,
  * flip_x mirrors the crop along x (second contrastive view). */
 int mi_crop_normalize(const float* vol, int D, int H, int W, const int32_t* centres_xyz, int n,
                       int cz, int cy, int cx, int mode, int flip_x, float* out, mi_stream_t stream);
+
+/* The same crops for a batch whose bookkeeping already lives on the device (replaces the per-batch host work of the
+ * reference's DataLoader path, datasets/particle_pre_3d_vol.py:70-85 under moco_main.py:122-130): crop i of the launch
+ * is dataset sample s = order[first + i] (order == NULL: s = first + i); it is cut from tomogram vols[owner[s]]
+ * (owner == NULL: vols[0]) around centres_xyz[s] (+ shift_xyz[s] when shift_xyz != NULL).  All arrays are device
+ * memory.  Modes 0..2 of mi_crop_normalize. */
+typedef struct mi_vol_desc {
+    const float* vol;
+    int32_t D, H, W, reserved;
+} mi_vol_desc;
+int mi_crop_normalize_table(const mi_vol_desc* vols, const int32_t* owner, const int32_t* centres_xyz,
+                            const int32_t* shift_xyz, const int64_t* order, int64_t first, int n, int cz, int cy,
+                            int cx, int mode, int flip_x, float* out, mi_stream_t stream);
 /* simsiam_test_hm_3d.py:45-51 on min-max'ed crops: y = (floor(255 x) / 255 - mean) / std  (ToPILImage -> ToTensor ->
  * Normalize; mean / std = the dataset statistics of tomo_pre_proj_angle_select_new3d_vol.py:238-239).  y may alias x. */
 int mi_u8_roundtrip_normalize(const float* x, float* y, size_t n, float mean, float std, mi_stream_t stream);

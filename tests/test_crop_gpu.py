@@ -81,3 +81,26 @@ def test_chain_and_u8_normalize_vs_oracle():
     mean, std = S.subvol_mean_std(sub)
     y = S.to_uint8_normalize(sub, mean, std).cpu().numpy()
     np.testing.assert_allclose(y, O.u8_roundtrip_normalize(sub.cpu().numpy(), mean, std), rtol=0, atol=1e-6)
+
+
+def test_fast_crop_kernel_equals_the_generic_one(monkeypatch):
+    """crop_fast_kernel (one read of the crop, 1024 threads, lanes along x) against the generic kernel (MI_CROP_GENERIC=1) on the
+    shapes it takes - 32^3 (MoCo), 6 x 48 x 48 and 6 x 64 x 64 (the 3-D chain's windows), a ragged 5 x 7 x 19 - raw and
+    z-normalised, mirrored, with centres at the volume's edges (clamped reads)."""
+    import numpy as np
+    import torch
+    from cet_pick_amd.datasets import subvols as S
+    rng = np.random.default_rng(3)
+    vol = torch.as_tensor(rng.standard_normal((40, 90, 100)).astype(np.float32)).cuda()
+    for size in ((32, 32, 32), (6, 48, 48), (6, 64, 64), (5, 7, 19)):
+        cen = np.stack([rng.integers(0, 100, 24), rng.integers(0, 90, 24), rng.integers(0, 40, 24)], 1).astype(np.int32)
+        for mode in (S.RAW, S.ZNORM):
+            for flip in (False, True):
+                a = S._crop(vol, cen, size, mode, flip)
+                monkeypatch.setenv("MI_CROP_GENERIC", "1")
+                b = S._crop(vol, cen, size, mode, flip)
+                monkeypatch.delenv("MI_CROP_GENERIC")
+                if mode == S.RAW:
+                    assert torch.equal(a, b)
+                else:
+                    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=3e-6)

@@ -122,6 +122,41 @@ def test_moco_main_trains_on_mrc_files(tmp_path, monkeypatch):
     assert os.path.exists(os.path.join(save_dir, "model_last_contrastive.pth"))
 
 
+def test_device_side_loader_serves_the_crops_of_the_host_side_one(tmp_path, monkeypatch):
+    """the MoCo loader's per-batch bookkeeping lives on the device (mi_crop_normalize_table: the epoch's
+    order uploaded once, a batch = two launches that index the per-sample tables).  One epoch of it - batches that mix the
+    two tomograms, both views, two ranks' strided shares - must be bit for bit what the host-side form (`_cut`: numpy index
+    slices, an upload and a scatter per tomogram and view) serves."""
+    from cet_pick_amd.datasets.tomo_files import TomoFileMocoLoader
+    from cet_pick_amd.datasets.synthetic_moco import SyntheticMocoLoader
+    from cet_pick_amd.datasets import subvols as S
+    from cet_pick_amd.opts import opts
+    monkeypatch.chdir(tmp_path)
+    _write_listed_tomograms(tmp_path)
+    o = opts().parse(["moco", "--arch", "moco3d_18", "--dataset", "simsiam3d", "--order", "zxy", "--batch_size", "16",
+                      "--exp_id", "g", "--debug", "0", "--dog", "2.5,5"])
+    for rank, world in ((0, 1), (1, 2)):
+        loader = TomoFileMocoLoader(o, crop=32, device="cuda", rank=rank, world=world)
+        assert len(set(loader.owner.tolist())) == 2
+        loader.set_epoch(3)
+        order = loader.epoch_order()
+        n = 0
+        for b, batch in enumerate(loader):
+            idx = order[b * 16:(b + 1) * 16]
+            assert torch.equal(batch["input"], loader._cut(idx, False)), (rank, b)
+            assert torch.equal(batch["input_aug"], loader._cut(idx, True)), (rank, b)
+            n += 1
+        assert n == len(loader) >= 2
+    # the synthetic loader takes the same path
+    sl = SyntheticMocoLoader(shape=(40, 96, 96), crop=32, n_crops=64, batch_size=16, seed=5)
+    sl.set_epoch(2)
+    order = np.random.default_rng(5 + 2000).permutation(64)
+    for b, batch in enumerate(sl):
+        idx = order[b * 16:(b + 1) * 16]
+        assert torch.equal(batch["input"], S.crop_znorm(sl.vol, sl.centres[idx], (32,) * 3))
+        assert torch.equal(batch["input_aug"], S.crop_znorm(sl.vol, sl.centres[idx] + sl.shift[idx], (32,) * 3, flip_x=True))
+
+
 def test_simsiam_main_and_exploration_on_mrc_files(tmp_path, monkeypatch):
     from cet_pick_amd import simsiam_main, simsiam_test_hm_3d
     from cet_pick_amd.opts import opts
