@@ -224,6 +224,7 @@ int vl_blocks(long n) { return (int)std::max<long>(1, std::min<long>((n + 256 * 
 // debiased contrastive loss: row sums of E = exp((S - rowmax) * (1 - I)),  S = F F^T / T
 // ------------------------------------------------------------------------------------------------
 constexpr int UB = 64;            // rows per workgroup and columns per tile (2 x 2 waves of 32 x 32)
+constexpr int UCL_FLUSH = 16;     // column tiles per first-level accumulator of the backward's second product
 
 // per-lane online state of one row
 struct RowAcc { float m, ref, sa, sp, so; };      // m: running maximum; ref: what the three sums are relative to
@@ -404,13 +405,24 @@ __global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, cons
         ra[r] = (!TRANS && ok) ? g_all[row] : 0.f;
         rcl[r] = ok ? cls[row] : 0;
     }
-    f32x16 out[NT];
+    // Two levels of accumulation: `out` collects UCL_FLUSH column tiles on the matrix pipe and is then added into `tot` by the
+    // vector unit.  One accumulator for the whole walk (2N / 32 tiles x 12 MFMAs = 73,728 dependent accumulations at 2N =
+    // 196,608) showed a bias of -2e-5 of the sum, growing linearly with N - the MFMA aligns its products to the (large)
+    // accumulator and drops what falls below it, always towards zero (tools/ab/ucl_bwd_diag.py: -1.9e-5 / -6e-6 at 196,608 /
+    // 24,576 rows against dense float64 rows; a row of dF is ~1/400 of its terms' magnitudes, so that was 4e-4 of the row).
+    f32x16 out[NT], tot[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { out[j][r] = 0.f; tot[j][r] = 0.f; }
 
     for (int col0 = 0; col0 < n2; col0 += UB) {
+        if ((col0 / UB) % UCL_FLUSH == UCL_FLUSH - 1) {     // (uniform)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { tot[j][r] += out[j][r]; out[j][r] = 0.f; }
+        }
         __syncthreads();
         for (int q = tid; q < UB * (DIM / 8); q += 256) {
             const int c = q / (DIM / 8), k8 = (q % (DIM / 8)) * 8;
@@ -518,6 +530,10 @@ __global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, cons
             }
         }
     }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[j][r] += tot[j][r];
     // sum the two column halves and write
     __syncthreads();                                      // the arena is free
     float* const outm = arena;                            // [2][UB][LD]

@@ -94,3 +94,32 @@ def test_streamed_contrastive_loss_equals_the_dense_form(thresh):
     b = O.tomo_cr_semi_loss(hm, hm_cr, pj, pj_cr, gt4, 0.8, 0.1, 0.07, 0.5, 0.1, streamed={"block": 500})
     for x, y in zip(a, b):
         np.testing.assert_allclose(y.item(), x.item(), rtol=2e-6)
+
+
+@pytest.mark.parametrize("thresh", [1.0, 0.4])
+def test_streamed_contrastive_loss_gradients_equal_autograd_through_the_dense_form(thresh):
+    """`_StreamedUCL` (blocked forward, analytic blocked backward: the oracle of the C5 step's GRADIENTS at 16 pairs) against
+    autograd through the dense oracle - which is pinned to the reference's gradients by test_unbiased_con_loss - in float64,
+    with ragged blocks."""
+    pred, gt, f, f_cr, lab, o1, o2 = losses_inputs()
+    d = lambda t: t.double().clone().requires_grad_()
+    A = [d(t) for t in (f, f_cr, o1, o2)]
+    sup, unsup = O.unbiased_con_loss(lab.double(), A[2], A[3], A[0], A[1], 0.07, 0.03, thresh)
+    (sup + 0.1 * unsup).backward()
+    for block in (37, 4096):
+        B = [d(t) for t in (f, f_cr, o1, o2)]
+        s2, u2 = O.unbiased_con_loss_streamed_grad(lab.double(), B[2], B[3], B[0], B[1], 0.07, 0.03, thresh, block=block)
+        (s2 + 0.1 * u2).backward()
+        np.testing.assert_allclose(s2.item(), sup.item(), rtol=1e-10)
+        np.testing.assert_allclose(u2.item(), unsup.item(), rtol=1e-10)
+        for a, b in zip(A, B):
+            np.testing.assert_allclose(b.grad.numpy(), a.grad.numpy(), rtol=1e-8, atol=1e-12 * float(a.grad.abs().max()) + 1e-300)
+    # through the step's loss, flips included
+    from cet_pick_amd.synthetic import semi_loss_inputs
+    gt4, hm, hm_cr, pj, pj_cr = semi_loss_inputs(0.8)
+    la = [t.double().clone().requires_grad_() for t in (hm, hm_cr, pj, pj_cr)]
+    lb = [t.double().clone().requires_grad_() for t in (hm, hm_cr, pj, pj_cr)]
+    O.tomo_cr_semi_loss(*la, gt4.double(), 0.8, 0.1, 0.07, 0.5, 0.1)[0].backward()
+    O.tomo_cr_semi_loss(*lb, gt4.double(), 0.8, 0.1, 0.07, 0.5, 0.1, streamed={"block": 500, "grad": True})[0].backward()
+    for a, b in zip(la, lb):
+        np.testing.assert_allclose(b.grad.numpy(), a.grad.numpy(), rtol=1e-8, atol=1e-12)

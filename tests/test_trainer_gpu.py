@@ -249,6 +249,68 @@ def test_semi_detector_step_at_c5_size_vs_oracle(pairs):
         np.testing.assert_allclose(so[rows].cpu().numpy(), (E * ((cls >> 1) & 1).double()).sum(1).cpu().numpy(), rtol=2e-4, atol=1e-6)
         np.testing.assert_allclose(ep[rows].cpu().numpy(), E[torch.arange(rows.numel()), (rows + n2 // 2) % n2].cpu().numpy(),
                                    rtol=2e-4, atol=1e-7)
+        # ---- the BACKWARD of the streaming kernel at this size (ucl_bwd_kernel<32, 0> row side and
+        # <32, 1> column side), on sampled rows against dense float64 rows:
+        #   dF[i] = 1/T sum_{j != i} ( c(i; j) E_ij + c(j; i) E_ji ) F[j],  E_ij = exp(S_ij - rowmax_i),
+        #   c(i; j) = g_all[i] + g_pos[i] [pos j] + g_other[i] [other j] + g_pair[i] [j = pair(i)]
+        # with random upstream gradients for the four differentiable outputs (the row maximum is the kernel's own, checked above)
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        ups = [torch.rand(n2, device="cuda", generator=gen) * sc for sc in (1.0, 3.0, 2.0, 50.0)]
+        fg = f32.clone().requires_grad_()
+        _, a2, p2, o2, e2 = _UclRowSumsFn.apply(fg, cls, 1.0 / opt.temp)
+        (a2 * ups[0] + p2 * ups[1] + o2 * ups[2] + e2 * ups[3]).sum().backward()
+        dF = fg.grad
+        rows = torch.arange(5, n2, 2311, device="cuda")                             # 86 rows from both halves
+        ar = torch.arange(rows.numel(), device="cuda")
+        md = m.double()
+        posd, othd = (cls & 1).double(), ((cls >> 1) & 1).double()
+        U = [u.double() for u in ups]
+        S = (fd[rows] @ fd.t()) / opt.temp                                         # S_ij = S_ji
+        pair = (rows + n2 // 2) % n2
+        Er = torch.exp(S - md[rows][:, None])                                       # E_ij, row side
+        Wr = Er * (U[0][rows][:, None] + U[1][rows][:, None] * posd[None, :] + U[2][rows][:, None] * othd[None, :])
+        Wr[ar, pair] += U[3][rows] * Er[ar, pair]
+        Ec = torch.exp(S - md[None, :])                                             # E_ji, column side
+        Wc = Ec * (U[0][None, :] + U[1][None, :] * posd[rows][:, None] + U[2][None, :] * othd[rows][:, None])
+        Wc[ar, pair] += U[3][pair] * Ec[ar, pair]                                   # j with pair(j) = i is j = pair(i)
+        W = Wr + Wc
+        W[ar, rows] = 0
+        want = (W @ fd) / opt.temp
+        got = dF[rows].double()
+        scale = want.abs().max(1, keepdim=True)[0]
+        err = float(((got - want).abs() / scale).max())
+        # a row of dF is a sum of 196,608 vectors in all directions: it is ~1/400 of the sum of its terms' magnitudes, so
+        # fp32 summation alone leaves ~sqrt(N) eps x 400 ~ 1e-5 .. 1e-3 of the row.  The bound is therefore two-sided: against
+        # the magnitude of what is summed (a wrong coefficient, class bit, pair term or a dropped tile is O(1) of it) ...
+        mag = ((W.abs() @ fd.abs()) / opt.temp).max(1, keepdim=True)[0]
+        assert float(((got - want).abs() / mag).max()) <= 5e-6, float(((got - want).abs() / mag).max())
+        # ... and against the same dense rows evaluated in float32 by plain torch: no further from float64 than twice that
+        W32 = W.float()
+        want32 = ((W32 @ f32) / opt.temp).double()
+        err32 = float(((want32 - want).abs() / scale).max())
+        assert err <= 2 * err32 + 2e-4, (err, err32)
+        # ---- the step's parameter gradients of the layers the loss reaches first (the (3, 1, 1) heads, the dilated 3-D feature
+        # head) against the oracle under autograd in float64, its contrastive term in the differentiable blocked form
+        # (oracle/loss_ref.py::_StreamedUCL, pinned to autograd through the dense form in tests/test_oracle_losses.py)
+        rsd = {k: (v.double().clone().requires_grad_(v.is_floating_point() and k.endswith(".weight") or k.endswith(".bias"))
+                   if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        o1g = OU.tomo_conv_unet_forward(rsd, x.double(), 4, heads, training=True)
+        o2g = OU.tomo_conv_unet_forward(rsd, x_aug.double(), 4, heads, training=True)
+        tot64 = OL.tomo_cr_semi_loss(o1g["hm"], o2g["hm"], o1g["proj"], o2g["proj"], gt.double(), 0.2, opt.tau, opt.temp, opt.thresh,
+                                     opt.cr_weight, streamed={"block": 2048, "device": "cuda", "dtype": torch.float64, "grad": True})[0]
+        tot64.backward()
+        assert abs(tot64.item() - ref64[0].item()) <= 1e-9 * abs(ref64[0].item())
+        checked = 0
+        for name, prm in model.named_parameters():
+            if not name.startswith(("hm.", "proj.", "feature_head.")):
+                continue
+            g64 = rsd[name].grad
+            assert g64 is not None, name
+            g = prm.grad.detach().double().cpu()
+            err = float((g - g64).abs().max() / g64.abs().max())
+            assert err <= 2e-4, (name, err)
+            checked += 1
+        assert checked >= 4
 
 
 def test_symmetric_moco_variant_vs_oracle():
