@@ -168,8 +168,19 @@ __global__ __launch_bounds__(MT, 1) void dogm_xz_kernel(DogmXZ p, MTaps<RA> wa, 
     // per pair of values), the Toeplitz block reads, the stores of the finished tile, the next tile's loads.  Each piece is
     // placed behind ONE MFMA and fenced there (sched_barrier): left to the scheduler - and with sched_group_barrier masks too -
     // the cuts went out as blocks between runs of MFMAs and the two pipes took turns (305 - 345 us).
+    // the Toeplitz blocks of both filters in REGISTERS (27 x 4: a wave alone on its SIMD has 512): read from LDS where they are used
+    // they cost an LDS instruction + a wait per MFMA pair out of an issue budget of six
+    u32x4 T5r[NF5][3], T3r[NF3][3];
+#pragma unroll
+    for (int f = 0; f < NF5; ++f)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) T5r[f][pl] = L.t[(f * 3 + pl) * 64 + lane];
+#pragma unroll
+    for (int f = 0; f < NF3; ++f)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) T3r[f][pl] = L.t[((NF5 + f) * 3 + pl) * 64 + lane];
     const bool x_inside = xw + 16 * NF5 <= W;               // (uniform) the window does not leave the row: immediate offsets
-    const bool col_ok = x0 + n < W;
+    const bool x_full = x0 + 32 <= W;                       // (uniform)
     const unsigned zstride = 4u * (unsigned)(H * W);
     for (int it = 0; it < p.n_iter; ++it) {
         const int y = p.ylo + it * p.rows_per_iter + r_local;
@@ -191,26 +202,33 @@ __global__ __launch_bounds__(MT, 1) void dogm_xz_kernel(DogmXZ p, MTaps<RA> wa, 
                 }
             }
         };
-        // word d of the three planes of a fragment <- the exact cut of the values a (element 2 d) and b (element 2 d + 1)
-        auto cut2 = [&](float va, float vb, int d, u32x4 (&o)[3]) {
+        // The exact cut of a pair of values (elements 2 d, 2 d + 1 of a fragment) in two halves of 5 / 6 vector instructions, so that
+        // no MFMA has more than six behind it (11 behind one MFMA stretch that gap from 32 to 52 cycles): half A = the top plane and
+        // the two remainders, half B = the middle and bottom planes.  `HC` carries the remainders from A to B.
+        struct HC { float ra[4], rb[4]; };
+        auto hcA = [&](float va, float vb, int d, HC& st, u32x4 (&o)[3]) {
             const unsigned a0 = __float_as_uint(va), b0 = __float_as_uint(vb);
-            const float ra = va - __uint_as_float(a0 & 0xffff0000u), rb = vb - __uint_as_float(b0 & 0xffff0000u);
-            const unsigned a1 = __float_as_uint(ra), b1 = __float_as_uint(rb);
-            const unsigned a2 = __float_as_uint(ra - __uint_as_float(a1 & 0xffff0000u));
-            const unsigned b2 = __float_as_uint(rb - __uint_as_float(b1 & 0xffff0000u));
-            constexpr unsigned HI2 = 0x07060302u;
-            o[0][d] = __builtin_amdgcn_perm(b0, a0, HI2);
-            o[1][d] = __builtin_amdgcn_perm(b1, a1, HI2);
-            o[2][d] = __builtin_amdgcn_perm(b2, a2, HI2);
+            st.ra[d] = va - __uint_as_float(a0 & 0xffff0000u);
+            st.rb[d] = vb - __uint_as_float(b0 & 0xffff0000u);
+            o[0][d] = __builtin_amdgcn_perm(b0, a0, 0x07060302u);
         };
-        auto cut_raw2 = [&](const u32x4 (&raw)[2 * NF5], int s, int d, u32x4 (&o)[3]) {      // k-step s = raw[2 s], raw[2 s + 1]
+        auto hcB = [&](int d, HC& st, u32x4 (&o)[3]) {
+            const unsigned a1 = __float_as_uint(st.ra[d]), b1 = __float_as_uint(st.rb[d]);
+            const unsigned a2 = __float_as_uint(st.ra[d] - __uint_as_float(a1 & 0xffff0000u));
+            const unsigned b2 = __float_as_uint(st.rb[d] - __uint_as_float(b1 & 0xffff0000u));
+            o[1][d] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+            o[2][d] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
+        };
+        // half-op q = 0 .. 7 of the cut of k-step s of `raw` / of half sp of an accumulator
+        auto hc_raw = [&](const u32x4 (&raw)[2 * NF5], int s, int q, HC& st, u32x4 (&o)[3]) {
+            const int d = q >> 1;
+            if (q & 1) { hcB(d, st, o); return; }
             const u32x4& w = raw[2 * s + (d >> 1)];
-            cut2(__uint_as_float(w[2 * (d & 1)]), __uint_as_float(w[2 * (d & 1) + 1]), d, o);
+            hcA(__uint_as_float(w[2 * (d & 1)]), __uint_as_float(w[2 * (d & 1) + 1]), d, st, o);
         };
-        auto cut_acc2 = [&](const f32x16& a, int sp, int d, u32x4 (&o)[3]) { cut2(a[8 * sp + 2 * d], a[8 * sp + 2 * d + 1], d, o); };
-        auto toep = [&](int f, u32x4 (&o)[3]) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) o[pl] = L.t[(f * 3 + pl) * 64 + lane];
+        auto hc_acc = [&](const f32x16& a, int sp, int q, HC& st, u32x4 (&o)[3]) {
+            const int d = q >> 1;
+            if (q & 1) hcB(d, st, o); else hcA(a[8 * sp + 2 * d], a[8 * sp + 2 * d + 1], d, st, o);
         };
         // six MFMAs, `side(k)` fenced behind the k-th
         auto grp = [&](f32x16& acc, const u32x4 (&a)[3], const u32x4 (&b)[3], auto&& side) {
@@ -229,75 +247,82 @@ __global__ __launch_bounds__(MT, 1) void dogm_xz_kernel(DogmXZ p, MTaps<RA> wa, 
 #pragma unroll
             for (int e = 0; e < 16; ++e) { z5[k][e] = 0.f; z3[k][e] = 0.f; }
         u32x4 rawA[2 * NF5], rawB[2 * NF5];
-        u32x4 afc[3], ta[3];                                 // A fragment of k-step 0 of the coming tile; T5[0]
+        u32x4 afc[3];                                        // A fragment of k-step 0 of the coming tile
+        HC h0;
         issue(0, rawA);
+        issue(1, rawB);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) cut_raw2(rawA, 0, d, afc);
-        toep(0, ta);
+        for (int q = 0; q < 8; ++q) hc_raw(rawA, 0, q, h0, afc);
+        // z pass with the operand roles swapped: A = the x pass's result (its accumulator layout IS an A fragment: lane = x', k = z
+        // along the registers), B = T  ->  C[x'][z']: lane = z', registers = x' in runs of four consecutive (r & 3)  ->  16-byte
+        // stores, 4 per tile and sigma instead of 16 four-byte ones (the address unit takes ~16 cycles per store instruction
+        // whatever its width: 32 of them per tile and wave were 2,000 cycles of every CU's 4 waves)
+        const int zi = n;                                    // this lane's output plane inside a tile
         auto step = [&](int t, f32x16& z5_t, f32x16& z3_t, f32x16& z5_p, f32x16& z3_p, f32x16& z5_pp, f32x16& z3_pp,
                         u32x4 (&raw)[2 * NF5], u32x4 (&rawn)[2 * NF5]) {
-            // ---- x pass of tile t (rows z = G0 + 32 t + (lane & 31)); on entry afc = cut k-step 0, ta = T5[0]
+            // ---- x pass of tile t (rows z = G0 + 32 t + (lane & 31)); on entry afc = cut k-step 0
+            // (no branch inside a step: a lone wave issues one instruction per 4 cycles, an MFMA leaves room for six - scalar ones
+            // included; what the last steps need not do - loads past the volume, the cut of a tile that does not exist - they do
+            // on clamped or stale data that nothing reads)
             f32x16 x5, x3;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { x5[e] = 0.f; x3[e] = 0.f; }
-            u32x4 tb[3], afn[3], b5[2][3], b3[2][3];
-            const bool more = t + 1 < NTX;                  // (uniform)
+            u32x4 afn[3], b5[2][3], b3[2][3];
+            HC hn, h30, h50, h31, h51;
 #pragma unroll
             for (int s = 0; s < NF5; ++s) {
-                // x5 += af[s] T5[s]     behind the MFMAs: T3[s] (T3[0] for the z pass at the end), the cut of k-step s + 1 - or, in the
-                //                       last group, of the first half of x3 (complete since the group before)
-                grp(x5, afc, ta, [&](int k) {
-                    if (k == 0) toep(NF5 + (s < NF3 ? s : 0), tb);
-                    if (k < 4) { if (s + 1 < NF5) cut_raw2(raw, s + 1, k, afn); else cut_acc2(x3, 0, k, b3[0]); }
-                    if (s == 0 && k >= 4 && more) { /* the next tile's loads: a whole step ahead (second half in the next group) */ }
+                // x5 += af[s] T5[s]     behind the MFMAs: six half-cuts of k-step s + 1 - or, in the last group, the whole cut of the
+                //                       first half of x3 (complete since the group before)
+                grp(x5, afc, T5r[s], [&](int k) {
+                    if (s + 1 < NF5) hc_raw(raw, s + 1, k, hn, afn);
+                    else { hc_acc(x3, 0, k, h30, b3[0]); if (k < 2) hc_acc(x3, 0, 6 + k, h30, b3[0]); }
                 });
                 if (s < NF3) {
-                    // x3 += af[s] T3[s]  behind: T5[s + 1]
-                    grp(x3, afc, tb, [&](int k) { if (k == 0) toep(s + 1, ta); });
+                    // x3 += af[s] T3[s]  behind: the last two half-cuts of k-step s + 1
+                    grp(x3, afc, T3r[s], [&](int k) { if (k < 2) hc_raw(raw, s + 1, 6 + k, hn, afn); });
                 }
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) afc[pl] = afn[pl];
             }
-            if (more) issue(t + 1, rawn);                    // in flight under the whole z pass and the next x pass's first groups
+            // `raw` is free (every k-step of tile t has been cut): tile t + 2 goes into it now and has a whole step to land - tile
+            // t + 1 was issued a step ago into `rawn` (with ONE wave per SIMD a load that is waited for is pure dead time: issued in
+            // the z pass of the step that ends with its first cut, the loads cost ~15 us of the kernel)
+            issue(min(t + 2, NTX - 1), raw);
+            __builtin_amdgcn_sched_barrier(0);
             // ---- z pass: the two k-steps of this tile go into output tiles t (steps 0, 1), t - 1 (2, 3), t - 2 (4: wide only)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { z5_t[e] = 0.f; z3_t[e] = 0.f; }
             const int j = t - 2;
             const bool st_ok = j >= 0 && j < NJ;             // (uniform)
-            const bool st_full = 32 * j + 32 <= D - 2 * p.bz;        // (uniform) every row of the tile is live
-            const unsigned vbase = col_ok ? 4u * (unsigned)(((p.bz + 4 * h) * H + y) * W + x0 + n) : 0x80000000u;
-            auto store3 = [&](const f32x16& acc, const __amdgpu_buffer_rsrc_t& rs, int k) {         // rows 3 k .. 3 k + 2 (k = 5: row 15)
-                if (!st_ok) return;
-#pragma unroll
-                for (int r = 3 * k; r < min(3 * k + 3, 16); ++r) {
-                    const int rz = 32 * j + (r & 3) + 8 * (r >> 2);                                // (+ 4 h in vbase)
-                    if (st_full) {
-                        // the row in the scalar offset (it stays inside the volume): no vector arithmetic per store
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), rs, (int)vbase, (int)(zstride * (unsigned)rz), 0);
-                    } else {
-                        const unsigned off = (p.bz + rz + 4 * h < D - p.bz) ? vbase + zstride * (unsigned)rz : 0x80000000u;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), rs, (int)off, 0, 0);
-                    }
-                }
+            const bool z_ok = p.bz + 32 * j + zi < D - p.bz;
+            // this lane's plane and row, columns x0 + 4 h ..; the tile's 32 j planes ride in the scalar offset, the run's 8 (r >> 2)
+            // columns in the immediate
+            const unsigned vbase = (st_ok && z_ok) ? 4u * (unsigned)(((p.bz + zi) * H + y) * W + x0 + 4 * h) : 0x80000000u;
+            const unsigned soff = st_ok ? zstride * (unsigned)(32 * j) : 0u;
+            auto store4 = [&](const f32x16& acc, const __amdgpu_buffer_rsrc_t& rs, int gq) {
+                const u32x4 v = {__float_as_uint(acc[4 * gq]), __float_as_uint(acc[4 * gq + 1]), __float_as_uint(acc[4 * gq + 2]),
+                                 __float_as_uint(acc[4 * gq + 3])};
+                const unsigned off = (x_full || x0 + 8 * gq + 4 * h < W) ? vbase + 32u * (unsigned)gq : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, (int)soff, 0);
             };
-            // z3_t += T3[0] b3[0]     behind: T3[2], the cut of the first half of x5 (complete with the last x group)
-            grp(z3_t, tb, b3[0], [&](int k) { if (k == 0) toep(NF5 + 2, ta); if (k >= 1 && k < 5) cut_acc2(x5, 0, k - 1, b5[0]); });
-            // z3_p += T3[2] b3[0]     behind: T5[0], the cut of the second half of x3
-            grp(z3_p, ta, b3[0], [&](int k) { if (k == 0) toep(0, tb); if (k < 4) cut_acc2(x3, 1, k, b3[1]); });
-            // z5_t += T5[0] b5[0]     behind: T5[2], the cut of the second half of x5
-            grp(z5_t, tb, b5[0], [&](int k) { if (k == 0) toep(2, ta); if (k < 4) cut_acc2(x5, 1, k, b5[1]); });
-            // z5_p += T5[2] b5[0]     behind: T5[4], the narrow half of the finished tile t - 2 leaves (complete a step ago)
-            grp(z5_p, ta, b5[0], [&](int k) { if (k == 0) toep(4, tb); store3(z3_pp, g1rs, k); });
-            // z5_pp += T5[4] b5[0]    behind: T3[1]
-            grp(z5_pp, tb, b5[0], [&](int k) { if (k == 0) toep(NF5 + 1, ta); });
-            // z3_t += T3[1] b3[1]     behind: T3[3]
-            grp(z3_t, ta, b3[1], [&](int k) { if (k == 0) toep(NF5 + 3, tb); });
-            // z3_p += T3[3] b3[1]     behind: T5[1], the wide half of tile t - 2 leaves
-            grp(z3_p, tb, b3[1], [&](int k) { if (k == 0) toep(1, ta); store3(z5_pp, g2rs, k); });
-            // z5_t += T5[1] b5[1]     behind: T5[3]
-            grp(z5_t, ta, b5[1], [&](int k) { if (k == 0) toep(3, tb); });
-            // z5_p += T5[3] b5[1]     behind: T5[0] and the cut of k-step 0 of the next tile (its loads went out 9 groups ago)
-            grp(z5_p, tb, b5[1], [&](int k) { if (k == 0) toep(0, ta); if (k >= 1 && k < 5 && more) cut_raw2(rawn, 0, k - 1, afc); });
+            // z3_t += x3[0] T3[0]     behind: six half-cuts of the first half of x5 (complete with the last x group)
+            grp(z3_t, b3[0], T3r[0], [&](int k) { hc_acc(x5, 0, k, h50, b5[0]); });
+            // z3_p += x3[0] T3[2]     behind: the rest of that cut, four half-cuts of the second half of x3
+            grp(z3_p, b3[0], T3r[2], [&](int k) { if (k < 2) hc_acc(x5, 0, 6 + k, h50, b5[0]); else hc_acc(x3, 1, k - 2, h31, b3[1]); });
+            // z5_t += x5[0] T5[0]     behind: the rest of x3's second half, two half-cuts of x5's
+            grp(z5_t, b5[0], T5r[0], [&](int k) { if (k < 4) hc_acc(x3, 1, 4 + k, h31, b3[1]); else hc_acc(x5, 1, k - 4, h51, b5[1]); });
+            // z5_p += x5[0] T5[2]     behind: the rest of x5's second half
+            grp(z5_p, b5[0], T5r[2], [&](int k) { hc_acc(x5, 1, 2 + k, h51, b5[1]); });
+            // z5_pp += x5[0] T5[4]    behind: the narrow half of the finished tile t - 2 leaves (it was complete a step ago)
+            grp(z5_pp, b5[0], T5r[4], [&](int k) { if (k >= 2) store4(z3_pp, g1rs, k - 2); });
+            // z3_t += x3[1] T3[1]
+            grp(z3_t, b3[1], T3r[1], [&](int) {});
+            // z3_p += x3[1] T3[3]     behind: the wide half of tile t - 2 leaves
+            grp(z3_p, b3[1], T3r[3], [&](int k) { if (k >= 2) store4(z5_pp, g2rs, k - 2); });
+            // z5_t += x5[1] T5[1]     behind: two half-cuts of k-step 0 of the next tile (loaded during the previous step)
+            grp(z5_t, b5[1], T5r[1], [&](int k) { if (k >= 4) hc_raw(rawn, 0, k - 4, h0, afc); });
+            // z5_p += x5[1] T5[3]     behind: the rest of that cut
+            grp(z5_p, b5[1], T5r[3], [&](int k) { hc_raw(rawn, 0, 2 + k, h0, afc); });
         };
         for (int t0 = 0; t0 < NTX; t0 += 6) {              // six steps per turn: accumulator roles (3) and load buffers (2) are static
             step(t0, z5[0], z3[0], z5[2], z3[2], z5[1], z3[1], rawA, rawB);

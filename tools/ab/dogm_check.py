@@ -11,8 +11,9 @@ def run():
     s, c, n, cut, heat = Im.dog_pick(v, [3, 5], return_heat=True)
     k = int(n.item())
     return s[:k].cpu().numpy(), c[:k].cpu().numpy(), float(cut.item()), heat.cpu().numpy()
+os.environ["MI_DOGM"] = "1"
 s0, c0, cut0, h0 = run()
-os.environ["MI_NO_DOGM"] = "1"
+del os.environ["MI_DOGM"]
 s1, c1, cut1, h1 = run()
 print("picks", len(s0), len(s1), "cutoff", cut0, cut1)
 d = np.abs(h0 - h1)
