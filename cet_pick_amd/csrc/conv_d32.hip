@@ -1,0 +1,292 @@
+// Patch-resident direct convolution for the detector's 32-output-channel layers, forward / inference (round 5).
+//
+// Replaces (reference, cet_pick/...): the Conv2d(32|64, 32, 3, padding=1) + BatchNorm2d + ReLU layers of the 256 x 256 level of
+// models/networks/unet.py:198-249,319-399 (BatchNorm folded into weights + bias at inference, hipops.conv_bn) and the two
+// Conv3d(32, 32, 3, padding=(1,4,4), dilation=(1,4,4)) + ReLU of the feature head, models/networks/unet_small.py:52-60.
+// These are 11.7 ms of the 30.6 ms the convolutions of a 128 x 512 x 512 forward take, at 77 - 120 TFLOP/s on the implicit
+// GEMM's 128 x 32 tile (profiles/r04_unet_layers.txt): nine or 27 one-tap slices per tile, each re-gathering, re-cutting and
+// re-staging its 128 im2col rows.  Here (the scheme of conv_direct3.hip's direct3h_kernel, for 32 output channels):
+//   * a workgroup owns a tile of outputs and stages its input PATCH once - tile + halo, every input channel, cut exactly into
+//     three bf16 planes while it is staged (16-byte records per voxel and 8-channel half: an MFMA A fragment of any tap is ONE
+//     ds_read_b128 at lane base + immediate) - and then runs all taps from LDS;
+//   * the dilated head (dilation 4 in x and y) is 16 interleaved sub-images that never mix: a tile is 8 x 8 outputs of ONE
+//     (x mod 4, y mod 4) class on two z-planes, its patch 10 x 10 x 4 voxels of that class - so a tap is again a plain record
+//     offset.  The 2-D layers (D = 1, dilation 1) take 16 x 16 tiles with an 18 x 18 patch;
+//   * weights come pre-cut as B fragments ([channel chunk][tap][plane][lane] x 16 bytes, mi_conv_d32_prep; 32 output columns =
+//     one fragment per k-step) and stream from L2 through a six-deep register ring, as in the direct3 kernels;
+//   * epilogue: + bias (folded BatchNorm), ReLU, 128-byte rows of 32 channels.
+// f32-equivalent bf16x3 arithmetic (six products of the exact three-way cut, f32 accumulation), as every convolution here.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DCO = 32;                     // output channels
+constexpr int DW_BLK = 1024;                // one B fragment plane: 64 lanes x 16 bytes
+constexpr int DW_STEP = 3 * DW_BLK;         // bytes per k-step of the weight image
+constexpr int DRB = 6;                      // weight k-steps in flight
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t d_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void d_cut8(const float (&v)[8], u32x4 (&o)[3]) {
+    unsigned u0[8], u1[8], u2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        u0[t] = __float_as_uint(v[t]);
+        const float r1 = v[t] - __uint_as_float(u0[t] & 0xffff0000u);
+        u1[t] = __float_as_uint(r1);
+        u2[t] = __float_as_uint(r1 - __uint_as_float(u1[t] & 0xffff0000u));
+    }
+    constexpr unsigned HI2 = 0x07060302u;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        o[0][d] = __builtin_amdgcn_perm(u0[2 * d + 1], u0[2 * d], HI2);
+        o[1][d] = __builtin_amdgcn_perm(u1[2 * d + 1], u1[2 * d], HI2);
+        o[2][d] = __builtin_amdgcn_perm(u2[2 * d + 1], u2[2 * d], HI2);
+    }
+}
+
+struct D32Params {
+    const float* x;           // (N, D, H, W, CIN) channels-last
+    const unsigned char* wimg;
+    const float* bias;        // [32] or null
+    float* out;               // (N, D, H, W, 32)
+    int relu;
+    int N, D, H, W;
+    unsigned x_bytes, out_bytes, w_bytes;
+};
+
+// CIN: 32 or 64 input channels.  NZT: 1 (2-D layers: D planes are independent images) or 3 z taps.  DIL: xy dilation (1 or 4).
+// Tile of a workgroup (4 waves), in voxels of ONE dilation class: TX x TY x TZ = 16 x 16 x 1 (two 4 x 8 row blocks per wave) for
+// NZT = 1, 8 x 8 x 2 (one row block per wave) for NZT = 3.
+template <int CIN, int NZT, int DIL>
+struct D32Cfg {
+    static constexpr int TX = NZT == 1 ? 16 : 8, TY = NZT == 1 ? 16 : 8, TZ = NZT == 1 ? 1 : 2;
+    static constexpr int BPW = NZT == 1 ? 2 : 1;              // row blocks (4 y x 8 x) per wave
+    static constexpr int PX = TX + 2, PY = TY + 2, PZ = TZ + NZT - 1;
+    static constexpr int NV = PX * PY * PZ;                    // patch voxels: 324 / 400
+    static constexpr int ARR = NV * 16;                        // one (chunk, plane, k-half) array
+    static constexpr int PL = 2 * ARR, CH = 3 * PL;            // plane, chunk
+    static constexpr int KS = CIN / 16;
+    static constexpr int LDS = KS * CH;                        // 62,208 (2-D, 32 ch) / 124,416 (2-D, 64 ch) / 76,800 (head)
+    static constexpr int NTAP = 9 * NZT;
+    static constexpr int NSTEP = KS * NTAP;
+    static constexpr int UNITS = (NV * KS * 2 + 255) / 256;    // staging units (voxel, chunk, k-half) per thread
+};
+
+template <int CIN, int NZT, int DIL>
+__global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL>::LDS <= 80 * 1024) ? 2 : 1) void conv_d32_kernel(D32Params p) {
+    typedef D32Cfg<CIN, NZT, DIL> G;
+    __shared__ __attribute__((aligned(16))) unsigned char patch[G::LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    // tile index -> (image n, z tile, dilation class, tile y, tile x)
+    const int cw = p.W / DIL, chh = p.H / DIL;                   // extents of a class sub-image
+    const int txn = cw / G::TX, tyn = chh / G::TY, tzn = p.D / G::TZ;
+    int bi = blockIdx.x;
+    const int tx = bi % txn; bi /= txn;
+    const int ty = bi % tyn; bi /= tyn;
+    const int cls = bi % (DIL * DIL); bi /= (DIL * DIL);
+    const int tz = bi % tzn, n = bi / tzn;
+    const int cx = cls % DIL, cy = cls / DIL;
+    const int x0 = tx * G::TX, y0 = ty * G::TY, z0 = tz * G::TZ; // tile origin in class coordinates (x, y) / planes (z)
+
+    const __amdgpu_buffer_rsrc_t wrs = d_rsrc(p.wimg, p.w_bytes);
+    bf16x8 bfr[DRB][3];
+    auto wload = [&](int g, auto SLOTc) {
+        constexpr int SLOT = decltype(SLOTc)::value;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                wrs, g < G::NSTEP ? lane * 16 + pl * DW_BLK : (int)0x80000000u, g < G::NSTEP ? g * DW_STEP : 0, 0));
+    };
+    auto wload_dyn = [&](int g) {
+        switch (g % DRB) {
+            case 0: wload(g, std::integral_constant<int, 0>{}); break;
+            case 1: wload(g, std::integral_constant<int, 1>{}); break;
+            case 2: wload(g, std::integral_constant<int, 2>{}); break;
+            case 3: wload(g, std::integral_constant<int, 3>{}); break;
+            case 4: wload(g, std::integral_constant<int, 4>{}); break;
+            default: wload(g, std::integral_constant<int, 5>{}); break;
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < DRB - 1; ++g) wload_dyn(g);
+
+    // ---- the patch, every chunk at once: unit q = (voxel, chunk, k-half); voxels outside the volume read zeros (the padding) ----
+    {
+        const __amdgpu_buffer_rsrc_t xrs = d_rsrc(p.x, p.x_bytes);
+        u32x4 ld[G::UNITS][2];
+        int dst[G::UNITS];
+#pragma unroll
+        for (int u = 0; u < G::UNITS; ++u) {
+            const int q = tid + 256 * u;
+            const int hh = q & 1, c = (q >> 1) % G::KS, vox = (q >> 1) / G::KS;
+            const int pz = vox / (G::PX * G::PY), py = (vox / G::PX) % G::PY, px = vox % G::PX;
+            const int z = z0 + pz - (NZT - 1) / 2, y = (y0 + py - 1) * DIL + cy, x = (x0 + px - 1) * DIL + cx;
+            const bool ok = vox < G::NV && (unsigned)z < (unsigned)p.D && y0 + py - 1 >= 0 && y0 + py - 1 < chh && x0 + px - 1 >= 0 &&
+                            x0 + px - 1 < cw;
+            const unsigned off = ok ? 4u * (unsigned)(((((long)n * p.D + z) * p.H + y) * p.W + x) * CIN + c * 16 + hh * 8) : 0x80000000u;
+            ld[u][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0);
+            ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 16, 0);
+            dst[u] = vox < G::NV ? c * G::CH + hh * G::ARR + vox * 16 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < G::UNITS; ++u) {
+            if (dst[u] < 0) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ld[u][0][e]); v[4 + e] = __uint_as_float(ld[u][1][e]); }
+            u32x4 o[3];
+            d_cut8(v, o);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(patch + dst[u] + pl * G::PL) = o[pl];
+        }
+    }
+    // ---- per-lane geometry: row block b of this wave = 4 y x 8 x outputs; MFMA row l32 = (y & 3, x); record of the tap (0, 0, 0) ----
+    int vbase[G::BPW];
+    int by_[G::BPW], bx_[G::BPW], bz_[G::BPW];
+#pragma unroll
+    for (int i = 0; i < G::BPW; ++i) {
+        const int b = wave * G::BPW + i;
+        if (NZT == 1) { bz_[i] = 0; by_[i] = 4 * (b >> 1); bx_[i] = 8 * (b & 1); }
+        else { bz_[i] = b >> 1; by_[i] = 4 * (b & 1); bx_[i] = 0; }
+        vbase[i] = ((bz_[i] * G::PY + by_[i] + (l32 >> 3)) * G::PX + bx_[i] + (l32 & 7)) * 16 + h * G::ARR;
+    }
+    f32x16 acc[G::BPW];
+#pragma unroll
+    for (int i = 0; i < G::BPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    __syncthreads();
+
+    bf16x8 af[2][G::BPW][3];
+    auto frags = [&](int c, int tap, auto SETc) {
+        constexpr int SET = decltype(SETc)::value;
+        const int tzz = tap / 9, tyy = (tap / 3) % 3, txx = tap % 3;
+        const int imm = ((tzz * G::PY + tyy) * G::PX + txx) * 16 + c * G::CH;
+#pragma unroll
+        for (int i = 0; i < G::BPW; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                af[SET][i][pl] = *reinterpret_cast<const bf16x8*>(patch + vbase[i] + imm + pl * G::PL);
+    };
+    auto frags_dyn = [&](int g, int c, int tap) {
+        if (g & 1) frags(c, tap, std::integral_constant<int, 1>{});
+        else frags(c, tap, std::integral_constant<int, 0>{});
+    };
+    frags_dyn(0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < G::KS; ++c) {
+#pragma unroll
+        for (int tap = 0; tap < G::NTAP; ++tap) {
+            const int g = c * G::NTAP + tap;
+            wload_dyn(g + DRB - 1);
+            if (g + 1 < G::NSTEP) frags_dyn(g + 1, (g + 1) / G::NTAP, (g + 1) % G::NTAP);
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int i = 0; i < G::BPW; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][i][PA[pr]], bfr[g % DRB][PB[pr]], acc[i], 0, 0, 0);
+            // issue order inside the k-step: every load behind an MFMA
+#pragma unroll
+            for (int k = 0; k < 3 * G::BPW; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            if constexpr (G::BPW == 2) __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- epilogue: C/D layout col = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 h = (y & 3, x) of the row block ----
+    const float bv = p.bias ? p.bias[l32] : 0.f;
+    const __amdgpu_buffer_rsrc_t ors = d_rsrc(p.out, p.out_bytes);
+#pragma unroll
+    for (int i = 0; i < G::BPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int y = (y0 + by_[i] + (m >> 3)) * DIL + cy, x = (x0 + bx_[i] + (m & 7)) * DIL + cx, z = z0 + bz_[i];
+            float v = acc[i][r] + bv;
+            if (p.relu) v = fmaxf(v, 0.f);
+            const unsigned off = 4u * (unsigned)(((((long)n * p.D + z) * p.H + y) * p.W + x) * DCO + l32);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, (int)off, 0, 0);
+        }
+}
+
+// weight image: W[tap][ci][co = 32] f32 -> bf16x3 B fragments [chunk][tap][plane][lane] x 16 bytes; idx = (chunk, tap, lane)
+__global__ __launch_bounds__(256) void conv_d32_prep_kernel(const float* w, unsigned char* img, int cin, int ntap) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int ks = cin / 16;
+    if (idx >= ks * ntap * 64) return;
+    const int lane = idx & 63, tap = (idx >> 6) % ntap, c = (idx >> 6) / ntap;
+    const int nn = lane & 31, k0 = c * 16 + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = w[((long)tap * cin + k0 + e) * DCO + nn];
+    u32x4 o[3];
+    d_cut8(v, o);
+    unsigned char* dst = img + (size_t)(c * ntap + tap) * DW_STEP + lane * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * DW_BLK) = o[pl];
+}
+
+}  // namespace
+
+// 1: 2-D 3 x 3 (kd = 1, any D: independent planes), dilation 1; 2: 3 x 3 x 3 with dilation (1, 4, 4); 0: not a shape of this kernel
+extern "C" int mi_conv_d32_kind(int N, int D, int H, int W, int Ci, int Co, int kd, int kh, int kw, int dd, int dh, int dw) {
+    if (getenv("MI_NO_D32")) return 0;
+    if (Co != DCO || N < 1 || kh != 3 || kw != 3 || dd != 1) return 0;
+    if (4l * N * D * H * W * (Ci > DCO ? Ci : DCO) >= 0x7fff0000l) return 0;
+    if (kd == 1 && dh == 1 && dw == 1 && (Ci == 32 || Ci == 64) && H % 16 == 0 && W % 16 == 0) return 1;
+    if (kd == 3 && dh == 4 && dw == 4 && Ci == 32 && H % 32 == 0 && W % 32 == 0 && D % 2 == 0) return 2;
+    return 0;
+}
+extern "C" size_t mi_conv_d32_image_bytes(int Ci, int ntap) { return (size_t)(Ci / 16) * ntap * DW_STEP; }
+
+// w: [tap][Ci][32] f32 (kernel layout); img: mi_conv_d32_image_bytes(Ci, ntap) bytes
+extern "C" int mi_conv_d32_prep(const float* w, void* img, int Ci, int ntap, mi_stream_t stream) {
+    if (!w || !img || (Ci != 32 && Ci != 64) || (ntap != 9 && ntap != 27)) return MI_E_ARG;
+    const int n = (Ci / 16) * ntap * 64;
+    hipLaunchKernelGGL(conv_d32_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)img, Ci, ntap);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+// y = act(conv(x, W) + bias): x (N, D, H, W, Ci) channels-last, y (N, D, H, W, 32); `kind` as mi_conv_d32_kind returns it
+extern "C" int mi_conv_d32_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W,
+                                   int Ci, int kind, mi_stream_t stream) {
+    if (!x || !wimg || !y || N < 1) return MI_E_ARG;
+    D32Params p = {};
+    p.x = x; p.wimg = (const unsigned char*)wimg; p.bias = bias; p.out = y; p.relu = relu;
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.x_bytes = (unsigned)(4l * N * D * H * W * Ci);
+    p.out_bytes = (unsigned)(4l * N * D * H * W * DCO);
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == 1 && (Ci == 32 || Ci == 64) && H % 16 == 0 && W % 16 == 0) {
+        p.w_bytes = (unsigned)mi_conv_d32_image_bytes(Ci, 9);
+        const long grid = (long)N * D * (H / 16) * (W / 16);
+        if (grid > 0x7fffffffl) return MI_E_UNSUPPORTED;
+        if (Ci == 32) hipLaunchKernelGGL((conv_d32_kernel<32, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_d32_kernel<64, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    } else if (kind == 2 && Ci == 32 && H % 32 == 0 && W % 32 == 0 && D % 2 == 0) {
+        p.w_bytes = (unsigned)mi_conv_d32_image_bytes(Ci, 27);
+        const long grid = (long)N * (D / 2) * 16 * (H / 32) * (W / 32);
+        if (grid > 0x7fffffffl) return MI_E_UNSUPPORTED;
+        hipLaunchKernelGGL((conv_d32_kernel<32, 3, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    } else return MI_E_UNSUPPORTED;
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}

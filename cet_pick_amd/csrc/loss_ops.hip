@@ -410,14 +410,17 @@ __global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, cons
     // 196,608) showed a bias of -2e-5 of the sum, growing linearly with N - the MFMA aligns its products to the (large)
     // accumulator and drops what falls below it, always towards zero (tools/ab/ucl_bwd_diag.py: -1.9e-5 / -6e-6 at 196,608 /
     // 24,576 rows against dense float64 rows; a row of dF is ~1/400 of its terms' magnitudes, so that was 4e-4 of the row).
-    f32x16 out[NT], tot[NT];
+    // (64-wide features - two accumulators per wave - keep the single level: the second pair of totals would cost the kernel a
+    // resident wave per SIMD; the detector's projection head is 32 wide)
+    constexpr bool TWO_LEVEL = NT == 1;
+    f32x16 out[NT], tot[TWO_LEVEL ? NT : 1];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { out[j][r] = 0.f; tot[j][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { out[j][r] = 0.f; if (TWO_LEVEL) tot[j][r] = 0.f; }
 
     for (int col0 = 0; col0 < n2; col0 += UB) {
-        if ((col0 / UB) % UCL_FLUSH == UCL_FLUSH - 1) {     // (uniform)
+        if (TWO_LEVEL && (col0 / UB) % UCL_FLUSH == UCL_FLUSH - 1) {     // (uniform)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -530,10 +533,12 @@ __global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, cons
             }
         }
     }
+    if (TWO_LEVEL) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[j][r] += tot[j][r];
+            for (int r = 0; r < 16; ++r) out[j][r] += tot[j][r];
+    }
     // sum the two column halves and write
     __syncthreads();                                      // the arena is free
     float* const outm = arena;                            // [2][UB][LD]

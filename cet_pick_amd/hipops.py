@@ -374,6 +374,50 @@ def _smallk_image(w, owner, K, co):
     return cache[1]
 
 
+def _d32_kind(x5shape, ci, co, k3, stride, p3, d3, inference):
+    """0, or the kind (1: 3 x 3 per plane, 2: the dilated 3-D head) of conv_d32.hip's direct inference kernel for this forward
+    convolution (32 output channels; padding = dilation * (k - 1) / 2)."""
+    if not inference or stride != 1 or co != 32 or not _arith_bf16x3():
+        return 0
+    d3 = tuple(d3) if d3 is not None else (1, 1, 1)
+    if tuple(p3) != tuple(dl * (kk - 1) // 2 for dl, kk in zip(d3, k3)):
+        return 0
+    n, d, h, wd, _ = x5shape
+    return int(L.lib().mi_conv_d32_kind(n, d, h, wd, ci, co, *k3, *d3))
+
+
+def _d32_call(x, w, bias, relu, kind, owner=None, out=None):
+    """y = act(conv(x, w) + bias) on conv_d32.hip; the pre-cut weight image is kept on `owner` (rebuilt when the weights change)."""
+    _f32c(x, "x")
+    if not _phys_ok(w):
+        raise L.HipExtensionError("conv weight is not in kernel layout [tap][Cin][Cout]")
+    lib = L.lib()
+    x5 = _as5d(x)
+    n, d, h, wd, ci = x5.shape
+    ntap = 9 if kind == 1 else 27
+    holder = owner if owner is not None else w
+    key = (w.data_ptr(), holder._version, WEIGHT_EPOCH, ci, ntap)
+    cache = getattr(holder, "_mi_d32", None)
+    if cache is None or cache[0] != key:
+        img = torch.empty(int(lib.mi_conv_d32_image_bytes(ci, ntap)), dtype=torch.uint8, device=w.device)
+        L.check(lib.mi_conv_d32_prep(L.ptr(w), L.ptr(img), ci, ntap, L.stream()), "mi_conv_d32_prep")
+        cache = (key, img)
+        try:
+            holder._mi_d32 = cache
+        except AttributeError:
+            pass
+    shape = tuple(x.shape[:-1]) + (32,)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise L.HipExtensionError("`out` must be a contiguous fp32 %s tensor on %s" % (shape, x.device))
+    def call():
+        return L.check(lib.mi_conv_d32_fwd_f32(L.ptr(x), L.ptr(cache[1]), L.ptr(bias), L.ptr(out), int(relu), n, d, h, wd, ci, kind,
+                                               L.stream()), "mi_conv_d32_fwd_f32")
+    _prof_run("fwd", 2.0 * n * d * h * wd * 32 * ci * ntap, call)
+    return out
+
+
 def _smallk_call(x, w, bias, relu, ntaps, out=None, owner=None):
     _f32c(x, "x")
     if not _phys_ok(w):
@@ -409,6 +453,9 @@ def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None, owner=None, i
         taps = _smallk_taps(x, w, k3, stride, p3, dil, nd5, inference)
         if taps:                                      # inference, short reduction: no tile pipeline (conv_smallk.hip)
             return _smallk_call(x, w, None, relu, taps, owner=owner)
+        kind = _d32_kind(_as5d(x).shape, x.shape[-1], w.shape[0], k3, stride, p3, _k3(dil, nd5) if dil is not None else None, inference)
+        if kind:                                      # inference, 32 output channels: patch-resident direct kernel (conv_d32.hip)
+            return _d32_call(x, w, None, relu, kind, owner=owner)
     x5 = _as5d(x)
     n, d, h, wd, ci = x5.shape
     co = w.shape[0]
@@ -727,6 +774,9 @@ def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None):
     taps = _smallk_taps(x, w, k3, stride, p3, None, nd5, True)
     if taps:
         return _smallk_call(x, w, _f32c(bias, "bias"), relu, taps, out=out)
+    kind = _d32_kind(_as5d(x).shape, x.shape[-1], w.shape[0], k3, stride, p3, None, True)
+    if kind:
+        return _d32_call(x, w, _f32c(bias, "bias"), relu, kind, out=out)
     x5 = _as5d(x)
     n, d, h, wd, ci = x5.shape
     co = w.shape[0]

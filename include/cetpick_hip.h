@@ -314,6 +314,20 @@ size_t mi_convnd_dil_workspace_bytes(int N, int Di, int Hi, int Wi, int Ci, int 
 int mi_convnd_dil_fwd_f32(const float* x, const float* w, float* y, const float* res, int relu, int N, int Di,
                           int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int pd, int ph, int pw,
                           int dd, int dh, int dw, void* ws, size_t ws_bytes, mi_stream_t stream);
+
+/* Patch-resident direct convolution to 32 output channels, forward / inference (conv_d32.hip): the detector's
+ * Conv2d(32|64, 32, 3, padding=1) layers with their BatchNorm folded into weights + bias
+ * (models/networks/unet.py:198-249) and the Conv3d(32, 32, 3, padding=(1,4,4), dilation=(1,4,4)) + ReLU of the
+ * feature head (models/networks/unet_small.py:52-60).
+ *   mi_conv_d32_kind: 1 = 3x3 on every plane (kd = 1, dilation 1, Ci 32 or 64, H and W multiples of 16); 2 = 3x3x3 with
+ *     dilation (1,4,4) (Ci 32, H and W multiples of 32, D even); 0 = not taken.  stride 1, padding = dilation * (k - 1) / 2.
+ *   mi_conv_d32_prep: w in kernel layout [tap][Ci][32] -> the pre-cut bf16x3 image (mi_conv_d32_image_bytes(Ci, 9 | 27)).
+ *   mi_conv_d32_fwd_f32: y = act(conv(x) + bias); x (N, D, H, W, Ci), y (N, D, H, W, 32) channels-last; bias may be NULL. */
+int mi_conv_d32_kind(int N, int D, int H, int W, int Ci, int Co, int kd, int kh, int kw, int dd, int dh, int dw);
+size_t mi_conv_d32_image_bytes(int Ci, int ntap);
+int mi_conv_d32_prep(const float* w, void* img, int Ci, int ntap, mi_stream_t stream);
+int mi_conv_d32_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W,
+                        int Ci, int kind, mi_stream_t stream);
 int mi_convnd_dil_dgrad_f32(const float* dy, const float* w, float* dx, const float* res, const float* mask,
                             int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int pd,
                             int ph, int pw, int dd, int dh, int dw, void* ws, size_t ws_bytes,

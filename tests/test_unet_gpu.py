@@ -129,11 +129,11 @@ def test_short_reduction_kernel_matches_generic_kernel_and_float64(shape, co, k,
     xc = _cl(x)
     scale = float(y64.abs().max())
     with torch.no_grad():
-        y = H.conv_fwd(xc, wk, k, 1, pad)
+        y = H.conv_fwd(xc, wk, k, 1, pad, inference=True)      # (the caller states inference: hipops.inference_mode())
         assert getattr(wk, "_mi_smallk", None) is not None              # the short-reduction path ran and kept its image
         yb = H.conv_bias_fwd(xc, wk, b.cuda(), k, 1, pad, relu=True)
         monkeypatch.setattr(H, "SMALLK", False)
-        y_gen = H.conv_fwd(xc, wk, k, 1, pad)
+        y_gen = H.conv_fwd(xc, wk, k, 1, pad, inference=True)
         yb_gen = H.conv_bias_fwd(xc, wk, b.cuda(), k, 1, pad, relu=True)
     # the f32-equivalent bound against float64; and no worse than the generic kernel beyond the order of the additions (same
     # cut, same six products per k-step: 16 k-steps in another grouping measured 1.8x)
@@ -441,3 +441,43 @@ def test_unet_training_forward_backward_vs_oracle():
     # running statistics follow nn.BatchNorm2d's update
     np.testing.assert_allclose(net.bn1.running_var.cpu().numpy(), ref_sd["bn1.running_var"].numpy(), rtol=1e-4)
     assert int(net.bn1.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("case", ["2d_32", "2d_64", "head"])
+def test_direct_32_channel_kernel_matches_the_implicit_gemm_and_float64(case, monkeypatch):
+    """conv_d32.hip (patch-resident direct convolution to 32 output channels, inference: the detector's 256 x 256 level and its
+    dilated 3-D head) against the implicit GEMM it replaces (MI_NO_D32=1) and a float64 convolution: f32-equivalent (no further
+    from float64 than the implicit GEMM by more than 2x), borders (zero padding, dilation classes at the image edge) included."""
+    import torch.nn.functional as F
+    from cet_pick_amd import hipops as H
+    g = torch.Generator().manual_seed(17)
+    if case == "head":
+        n, d, h, w, ci, k3, pad, dil = 1, 6, 64, 96, 32, (3, 3, 3), (1, 4, 4), (1, 4, 4)
+    else:
+        n, d, h, w, ci, k3, pad, dil = 3, 1, 48, 64, (32 if case == "2d_32" else 64), (1, 3, 3), (0, 1, 1), (1, 1, 1)
+    x = (torch.randn(n, d, h, w, ci, generator=g) * torch.exp(torch.randn(n, d, h, w, 1, generator=g))).cuda()
+    wt = torch.randn(*k3, ci, 32, generator=g) / (ci * 9) ** 0.5          # kernel layout [kd, kh, kw, ci, co]
+    wdev = wt.cuda().permute(4, 3, 0, 1, 2)                               # logical (co, ci, kd, kh, kw) over that storage
+    bias = torch.randn(32, generator=g).cuda()
+    want = F.conv3d(x.double().cpu().permute(0, 4, 1, 2, 3), wt.double().permute(4, 3, 0, 1, 2), bias.double().cpu(), padding=pad,
+                    dilation=dil).clamp_min(0).permute(0, 2, 3, 4, 1)
+    with torch.no_grad():
+        if case == "head":
+            want = F.conv3d(x.double().cpu().permute(0, 4, 1, 2, 3), wt.double().permute(4, 3, 0, 1, 2), None, padding=pad,
+                            dilation=dil).clamp_min(0).permute(0, 2, 3, 4, 1)
+            run = lambda: H.conv_fwd(x, wdev, k3, 1, pad, relu=True, dil=dil, inference=True)
+        else:
+            w4 = wdev[:, :, 0]                                                                      # 2-D layer: (co, ci, kh, kw)
+            x4 = x[:, 0]
+            run = lambda: H.conv_bias_fwd(x4, w4, bias, 3, 1, 1, relu=True).unsqueeze(1)
+        got = run()
+        kernel = H.L.lib().mi_conv_d32_kind(n, d, h, w, ci, 32, *k3, *dil)
+        assert kernel in (1, 2)
+        monkeypatch.setenv("MI_NO_D32", "1")
+        ref = run()
+        monkeypatch.delenv("MI_NO_D32")
+    scale = float(want.abs().max())
+    e_got = float((got.double().cpu() - want).abs().max()) / scale
+    e_ref = float((ref.double().cpu() - want).abs().max()) / scale
+    assert e_got <= 2 * e_ref + 1e-6, (e_got, e_ref)
+    assert e_got < 5e-6
