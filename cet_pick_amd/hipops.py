@@ -37,6 +37,9 @@ def _prof_run(tag, flops, fn):
 STAMPS = None           # tools/stamp_step.py: (device int64 buffer, [names]) - wall-clock stamps recorded into the step
 
 
+STAMP_TAG = ""          # prefix of the stamps' names (models/moco.py labels the two encoder branches)
+
+
 def stamp(name):
     """Measurement aid: a one-thread launch on the current stream that writes the 100 MHz wall clock; a no-op unless
     tools/stamp_step.py armed it.  Recorded into a captured step it times the step's phases WITHOUT a profiler attached."""
@@ -46,7 +49,7 @@ def stamp(name):
     if len(names) >= buf.numel():
         raise L.HipExtensionError("stamp buffer full")
     L.check(L.lib().mi_debug_stamp(buf.data_ptr() + 8 * len(names), L.stream()), "mi_debug_stamp")
-    names.append(name)
+    names.append(STAMP_TAG + name)
 
 
 def _ws(nbytes, device, tag):
@@ -1274,16 +1277,25 @@ class _BNReluPoolFn(torch.autograd.Function):
         dev = x.device
         dp = dp.contiguous()
         m = n * d * h * w
-        # gradient behind the ReLU: the pool's backward (materialised once; gathering it inside both BatchNorm passes
-        # was measured slower), then BatchNorm's two halves with the ReLU mask recomputed from x
-        dy = torch.empty_like(x)
-        L.check(lib.mi_maxpool3d_bwd(L.ptr(dp), L.ptr(arg), L.ptr(dy), n, d, h, w, c, k, stride, pad, L.stream()),
-                "mi_maxpool3d_bwd")
-        ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         gamma, beta = mod.weight, mod.bias
-        L.check(lib.mi_bn_relu_bwd_reduce_x(L.ptr(dy), L.ptr(x), m, c, L.ptr(save), L.ptr(gamma), L.ptr(beta), L.ptr(sums),
-                                            L.ptr(ws), ws.numel(), L.stream()), "mi_bn_relu_bwd_reduce_x")
+        # the pool's backward materialised once, then BatchNorm's two halves with the ReLU mask recomputed from x.  Opt-in
+        # (MI_POOL_BWD_GATHER=1, the stem's geometry): both halves gather the pooled gradient themselves - half the bytes, 8 us
+        # faster alone, 30 us slower inside the captured step (r05_experiments.txt item 6)
+        gather = bool(lib.mi_bn_relu_maxpool3d_bwd_usable(n, d, h, w, c, k, stride, pad))
+        if gather:
+            ws = _ws(lib.mi_bn_relu_maxpool3d_bwd_workspace_bytes(n, d, h, w, c), dev, "pool_bwd")
+            L.check(lib.mi_bn_relu_maxpool3d_bwd_reduce(L.ptr(dp), L.ptr(arg), L.ptr(x), n, d, h, w, c, k, stride, pad, L.ptr(save),
+                                                        L.ptr(gamma), L.ptr(beta), L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()),
+                    "mi_bn_relu_maxpool3d_bwd_reduce")
+            dy = None
+        else:
+            dy = torch.empty_like(x)
+            L.check(lib.mi_maxpool3d_bwd(L.ptr(dp), L.ptr(arg), L.ptr(dy), n, d, h, w, c, k, stride, pad, L.stream()),
+                    "mi_maxpool3d_bwd")
+            ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
+            L.check(lib.mi_bn_relu_bwd_reduce_x(L.ptr(dy), L.ptr(x), m, c, L.ptr(save), L.ptr(gamma), L.ptr(beta), L.ptr(sums),
+                                                L.ptr(ws), ws.numel(), L.stream()), "mi_bn_relu_bwd_reduce_x")
         dg = db = None
         acc_g = acc_b = False
         if gamma is not None and gamma.requires_grad:
@@ -1297,10 +1309,17 @@ class _BNReluPoolFn(torch.autograd.Function):
                 L.check(lib.mi_bn_param_grads(L.ptr(sums), c, L.ptr(dg), L.ptr(db), L.stream()), "mi_bn_param_grads")
             import torch.distributed as dist
             dist_all_reduce(sums)
-        dx = dy                                            # in place: each element is read, then written, by one thread
-        L.check(lib.mi_bn_relu_bwd_apply_x(L.ptr(dy), L.ptr(x), L.ptr(dx), m, c, L.ptr(save), L.ptr(gamma), L.ptr(beta),
-                                           L.ptr(sums), ctx.count, L.ptr(None if distributed else dg),
-                                           L.ptr(None if distributed else db), L.stream()), "mi_bn_relu_bwd_apply_x")
+        if gather:
+            dx = torch.empty_like(x)
+            L.check(lib.mi_bn_relu_maxpool3d_bwd_apply(L.ptr(dp), L.ptr(arg), L.ptr(x), L.ptr(dx), n, d, h, w, c, k, stride, pad,
+                                                       L.ptr(save), L.ptr(gamma), L.ptr(beta), L.ptr(sums), ctx.count,
+                                                       L.ptr(None if distributed else dg), L.ptr(None if distributed else db),
+                                                       L.stream()), "mi_bn_relu_maxpool3d_bwd_apply")
+        else:
+            dx = dy                                        # in place: each element is read, then written, by one thread
+            L.check(lib.mi_bn_relu_bwd_apply_x(L.ptr(dy), L.ptr(x), L.ptr(dx), m, c, L.ptr(save), L.ptr(gamma), L.ptr(beta),
+                                               L.ptr(sums), ctx.count, L.ptr(None if distributed else dg),
+                                               L.ptr(None if distributed else db), L.stream()), "mi_bn_relu_bwd_apply_x")
         if acc_g:
             gamma.grad.add_(dg)
         if acc_b:

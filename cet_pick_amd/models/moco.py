@@ -79,6 +79,7 @@ class MoCo(nn.Module):
     def _key_branch(self, im_k):
         with torch.no_grad():
             self._momentum_update_key_encoder()
+            H.stamp("ema")
             k = self.encoder_k(im_k)[0]["proj"]
             return k                                       # un-normalised: the logits kernel normalises both branches
 
@@ -99,11 +100,15 @@ class MoCo(nn.Module):
             cur = torch.cuda.current_stream()
             self._side.wait_stream(cur)                    # inputs and last step's SGD are ordered before it
             with torch.cuda.stream(self._side):
-                H.stamp("k:start")
+                H.STAMP_TAG = "k:"
+                H.stamp("start")
                 k_raw = self._key_branch(im_k)
-                H.stamp("k:end")
+                H.stamp("end")
+            H.STAMP_TAG = "q:"
+            H.stamp("start")
             q_raw = self.encoder_q(im_q)[0]["proj"]
-            H.stamp("q:end")
+            H.stamp("end")
+            H.STAMP_TAG = ""
             cur.wait_stream(self._side)
             H.stamp("joined")
             k_raw.record_stream(cur)

@@ -866,6 +866,49 @@ def test_maxpool_backward_parity_form_equals_generic(shape, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 16, 16, 16, 64), (2, 5, 7, 16, 64), (3, 10, 12, 32, 32), (2, 2, 2, 64, 16), (1, 9, 3, 8, 128)])
+def test_stem_backward_gather_form_equals_dense_form_and_torch(shape, monkeypatch):
+    """Round 5: the backward of maxpool3d(relu(bn(x)), 3, 2, 1) with the pooled gradient gathered inside both BatchNorm halves
+    (bn_relu_pool_bwd_k3s2_kernel<false / true>, opt-in MI_POOL_BWD_GATHER=1: no dense gradient behind the ReLU) against the default
+    form (pool backward, column reduce, apply) and against torch (BatchNorm3d + ReLU + MaxPool3d), on the stem's
+    geometry class incl. odd depths / heights and a last band of fewer than four rows (moco_encoder_3d.py:170-172)."""
+    from cet_pick_amd import hipops as H, _lib as L
+    n, d, h, w, c = shape
+    assert L.lib().mi_bn_relu_maxpool3d_bwd_usable(n, d, h, w, c, 3, 2, 1) == 0          # opt-in
+    monkeypatch.setenv("MI_POOL_BWD_GATHER", "1")
+    assert L.lib().mi_bn_relu_maxpool3d_bwd_usable(n, d, h, w, c, 3, 2, 1) == 1
+    g = torch.Generator().manual_seed(sum(shape) + 5)
+    x = torch.randn(n, c, d, h, w, generator=g) * 2 + 0.5
+    bn_ref = torch.nn.BatchNorm3d(c)
+    with torch.no_grad():
+        bn_ref.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn_ref.bias.copy_(torch.randn(c, generator=g) * 0.3)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool3d(torch.relu(bn_ref(xr)), 3, 2, 1)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    got = {}
+    for form in ("gather", "dense"):
+        if form == "dense":
+            monkeypatch.delenv("MI_POOL_BWD_GATHER")
+            assert L.lib().mi_bn_relu_maxpool3d_bwd_usable(n, d, h, w, c, 3, 2, 1) == 0
+        bn = H.HipBatchNorm(c)
+        bn.load_state_dict(bn_ref.state_dict())
+        bn = bn.cuda().train()
+        xc = cl(x).requires_grad_(True)
+        y = H.bn_relu_maxpool3d(xc, bn, 3, 2, 1)
+        y.backward(cl(dy))
+        got[form] = (xc.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+    for a, b in zip(got["gather"], got["dense"]):
+        # same gathered gradient, same mask; the two sums are added in another order (f32 over 4 rows, then fp64)
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-6 * scale
+    np.testing.assert_allclose(ncdhw(got["gather"][0]).numpy(), xr.grad.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(got["gather"][1].cpu().numpy(), bn_ref.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(got["gather"][2].cpu().numpy(), bn_ref.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("form", ["pair_wgrad", "pairw", "pairw64"])
 @pytest.mark.parametrize("case", [(64, 4, 128, 128, 3, 1), (70, 4, 128, 128, 3, 1), (9, 8, 64, 128, 3, 2), (9, 8, 64, 128, 1, 2),
                                   (5, 6, 64, 64, 3, 2), (33, 2, 256, 128, 3, 1), (3, 8, 64, 64, 3, 1)])

@@ -83,8 +83,10 @@ timed(eng, x, y, 20)
 print("stamped  %.4f ms/step  (%d stamps per step)" % (timed(eng, x, y, R), n_per), flush=True)
 acc = None
 K = 10
+STEADY = "--steady" in sys.argv      # stamps of the LAST of six back-to-back replays (the host runs ahead of the device, as in training)
 for _ in range(K):
-    eng.step(x, y)
+    for _ in range(6 if STEADY else 1):
+        eng.step(x, y)
     torch.cuda.synchronize()
     t = buf[base:base + n_per].cpu().double().numpy()
     t = (t - t[0]) / 100.0                # 100 MHz -> us
