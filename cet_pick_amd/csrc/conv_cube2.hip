@@ -236,10 +236,11 @@ constexpr int PW_PLANE = 2 * PW_HALF;
 constexpr int PW_OP = 3 * PW_PLANE;             // one operand block (64 samples x 64 channels x 3 planes): 24,576 bytes
 constexpr int PW_MAXTAP = 27;
 
+constexpr int PW_MAXPROB = 4;     // round 5: problems of one geometry per launch (blockIdx.y)
 struct PairWgradParams {
-    const float* x;           // (N, VI voxels, CI)
-    const float* dy;          // (N, VO voxels, CO)
-    float* dw;                // [ntaps][CI][CO]: final (S == 1) or slab 0 of S slabs
+    const float* x[PW_MAXPROB];       // (N, VI voxels, CI)
+    const float* dy[PW_MAXPROB];      // (N, VO voxels, CO)
+    float* dw[PW_MAXPROB];            // [ntaps][CI][CO]: final (S == 1) or slab 0 of S slabs
     int N, VI, VO, CI, CO, ntaps;
     unsigned x_bytes, dy_bytes;
     // geometry of the pairs (round 4: any cubic volume): per axis, tap t connects outputs lo .. lo + len - 1 to inputs stride * o + t - pad
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void pair_wgrad_kernel(PairWgradParams p) {
     const int lz = p.lo[tap][0], ly = p.lo[tap][1], lx = p.lo[tap][2], ny = p.len[tap][1], nx = p.len[tap][2];
 
     // staging: thread = (sample row, 8 channels): one unit of X and one of dY per block
-    const __amdgpu_buffer_rsrc_t xrs = rsrc_of2(p.x, p.x_bytes), yrs = rsrc_of2(p.dy, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t xrs = rsrc_of2(p.x[blockIdx.y], p.x_bytes), yrs = rsrc_of2(p.dy[blockIdx.y], p.dy_bytes);
     const int srow = tid >> 3, cg = tid & 7;
     const int st_lds = (cg >> 2) * PW_HALF + srow * PW_ROW + (cg & 3) * 16;
     // three blocks in flight: an iteration (12 MFMAs per wave) is far shorter than an L2 / HBM round trip
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void pair_wgrad_kernel(PairWgradParams p) {
     __syncthreads();
     if (kh == 0) {
         // final tile: C/D layout col = lane & 31 (co), row = ci
-        float* out = p.dw + seg * p.slab_stride + ((long)tap * p.CI + ib * 64 + 32 * wm) * p.CO + cb * 64 + 32 * wn + l32;
+        float* out = p.dw[blockIdx.y] + seg * p.slab_stride + ((long)tap * p.CI + ib * 64 + 32 * wm) * p.CO + cb * 64 + 32 * wn + l32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[(long)((r & 3) + 8 * (r >> 2) + 4 * h) * p.CO] = acc[r] + red[wave][r][lane];
     }
@@ -636,14 +637,19 @@ size_t mi_pair_wgrad_slab_bytes(int N, int Di, int Ci, int Co, int k, int stride
 }
 
 // S == 1: `dwt` is final.  S > 1 (mi_pair_wgrad_splits): S slabs of [k^3][Ci][Co] floats into `slabs`; the caller sums them
-int mi_pair_wgrad_launch(const float* x, const float* dy, float* dwt, float* slabs, int N, int Di, int Ci, int Co, int k, int stride,
-                         hipStream_t s) {
+int mi_pair_wgrad_batch_max() { return PW_MAXPROB; }
+int mi_pair_wgrad_launch_batch(const float* const* xs, const float* const* dys, float* const* dws, float* const* slabs, int nb, int N,
+                               int Di, int Ci, int Co, int k, int stride, hipStream_t s) {
+    if (nb < 1 || nb > PW_MAXPROB) return MI_E_ARG;
     PairWgradParams p = {};
     const PairGeom g = pair_geom(Di, k, stride, &p);
     const int pad = k == 3 ? 1 : 0, Do = (Di + 2 * pad - k) / stride + 1;
     const int S = mi_pair_wgrad_splits(N, Di, Ci, Co, k, stride);
-    if (S > 1 && !slabs) return MI_E_ARG;
-    p.x = x; p.dy = dy; p.dw = S > 1 ? slabs : dwt; p.N = N; p.VI = Di * Di * Di; p.VO = Do * Do * Do; p.CI = Ci; p.CO = Co; p.ntaps = g.ntaps;
+    for (int i = 0; i < nb; ++i) {
+        if (S > 1 && !slabs[i]) return MI_E_ARG;
+        p.x[i] = xs[i]; p.dy[i] = dys[i]; p.dw[i] = S > 1 ? slabs[i] : dws[i];
+    }
+    p.N = N; p.VI = Di * Di * Di; p.VO = Do * Do * Do; p.CI = Ci; p.CO = Co; p.ntaps = g.ntaps;
     p.x_bytes = (unsigned)(4l * N * p.VI * Ci); p.dy_bytes = (unsigned)(4l * N * p.VO * Co);
     p.Di = Di; p.Do = Do; p.stride = stride; p.pad = pad; p.ks = k; p.S = S; p.slab_stride = (long)g.ntaps * Ci * Co;
     // heaviest taps first (stable); a tap without a pair (none with these geometries) writes zeros
@@ -651,9 +657,17 @@ int mi_pair_wgrad_launch(const float* x, const float* dy, float* dwt, float* sla
     for (int want = g.maxcnt; want >= 0; --want)
         for (int t = 0; t < g.ntaps; ++t)
             if (p.cnt[t] == want) p.order[n++] = (unsigned char)t;
-    hipLaunchKernelGGL(pair_wgrad_kernel, dim3((unsigned)(g.ntaps * (Ci / 64) * (Co / 64) * S)), dim3(512), 0, s, p);
+    hipLaunchKernelGGL(pair_wgrad_kernel, dim3((unsigned)(g.ntaps * (Ci / 64) * (Co / 64) * S), (unsigned)nb), dim3(512), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
+}
+int mi_pair_wgrad_launch(const float* x, const float* dy, float* dwt, float* slabs, int N, int Di, int Ci, int Co, int k, int stride,
+                         hipStream_t s) {
+    const float* xs[1] = {x};
+    const float* dys[1] = {dy};
+    float* dws[1] = {dwt};
+    float* sl[1] = {slabs};
+    return mi_pair_wgrad_launch_batch(xs, dys, dws, sl, 1, N, Di, Ci, Co, k, stride, s);
 }
 
 size_t mi_cube2_slab_bytes(int N, int C) { return sizeof(float) * (size_t)KQ * N * 8 * C; }

@@ -594,12 +594,16 @@ constexpr int WOP = 3 * WPL;                // one operand (X or dY) of one z-pl
 constexpr int WBUF = 2 * WOP;               // one staging buffer
 constexpr int WZERO = PLANE * WROW;         // byte offset of the zero row in a half
 
+// Round 5: up to WG_MAXPROB convolutions of ONE geometry per launch (layer1's four weight gradients exist together when the data-gradient
+// chain leaves the stage): nprob x splits workgroups per (dz, dy) pair, `splits` chains per problem (mi_direct3_wgrad_batch_splits).
+constexpr int WG_MAXPROB = 4;
 struct Direct3WgradParams {
-    const float* x;           // (N, D, 8, 8, 64)
-    const float* dy;          // (N, D, 8, 8, 64)
-    float* slabs;             // WG_SPLITS slabs of [27][64][64] floats
+    const float* x[WG_MAXPROB];       // (N, D, 8, 8, 64) each
+    const float* dy[WG_MAXPROB];      // (N, D, 8, 8, 64)
+    float* slabs[WG_MAXPROB];         // `splits` slabs of [27][64][64] floats per problem
     int N, D;
     unsigned bytes;           // extent of x / dy
+    int nprob, splits;        // workgroups per (dz, dy) pair = nprob * splits
 };
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -616,19 +620,21 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l32 = lane & 31, i16 = lane & 15, g16 = (lane >> 4) & 1;
     const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;      // k-half of the plane; wave block: ci half wm x co half wn
-    const int grp = blockIdx.x / WG_SPLITS, split = blockIdx.x % WG_SPLITS;
+    const int per_grp = p.nprob * p.splits;
+    const int grp = blockIdx.x / per_grp, rem = blockIdx.x % per_grp;
+    const int pb = rem / p.splits, split = rem % p.splits, stride = p.splits;
     const int dz = grp / 3, dy = grp % 3;
     const int n_planes = p.N * p.D;
 
     // ---- staging: a thread's unit = (voxel, 8 channels) of X and the same unit of dY: 64 voxels x 8 channel groups ----
-    const __amdgpu_buffer_rsrc_t xrs = rsrc_of(p.x, p.bytes), yrs = rsrc_of(p.dy, p.bytes);
+    const __amdgpu_buffer_rsrc_t xrs = rsrc_of(p.x[pb], p.bytes), yrs = rsrc_of(p.dy[pb], p.bytes);
     const int st_vox = tid >> 3, st_cg = tid & 7;
     const unsigned st_src = 4u * (unsigned)(st_vox * C + st_cg * 8);
     const int st_lds = (st_cg >> 2) * WHALF + st_vox * WROW + (st_cg & 3) * 16;
     // plane index of this workgroup's i-th tile, or -1 behind the last: every WG_SPLITS-th (n, z) whose partner plane
     // z + dz - 1 is inside the volume
     auto next_plane = [&](int from) {
-        for (int pi = from; pi < n_planes; pi += WG_SPLITS) {
+        for (int pi = from; pi < n_planes; pi += stride) {
             const int zi = pi % p.D + dz - 1;
             if ((unsigned)zi < (unsigned)p.D) return pi;
         }
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
     }
 
     int cur = next_plane(split);
-    int nxt = cur >= 0 ? next_plane(cur + WG_SPLITS) : -1;
+    int nxt = cur >= 0 ? next_plane(cur + stride) : -1;
     stage_load(cur);
     if (cur >= 0) { stage_store_unit(0, 0); stage_store_unit(0, 1); }
     stage_load(nxt);
@@ -771,7 +777,7 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
     }
     constexpr int DXO[3] = {1, 0, 2};                     // MFMA order of the taps: the one that was read, then the derived ones
     while (cur >= 0) {
-        const int nn = nxt >= 0 ? next_plane(nxt + WG_SPLITS) : -1;      // the plane after next: fetched during this one
+        const int nn = nxt >= 0 ? next_plane(nxt + stride) : -1;      // the plane after next: fetched during this one
         const unsigned ybase = nn >= 0 ? 4u * (unsigned)((long)nn * PLANE * C) : 0x80000000u;
         const unsigned xbase = nn >= 0 ? 4u * (unsigned)((long)(nn + dz - 1) * PLANE * C) : 0x80000000u;
         __builtin_amdgcn_sched_barrier(0);
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
     }
     __syncthreads();
     if (kh == 1) return;
-    float* out = p.slabs + (long)split * (NTAP * C * C);
+    float* out = p.slabs[pb] + (long)split * (NTAP * C * C);
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
         const int tap = (dz * 3 + dy) * 3 + dx;
@@ -1187,8 +1193,34 @@ int mi_direct3_wgrad_splits() { return WG_SPLITS; }
 
 // writes WG_SPLITS full-size slabs ([27][64][64] floats each) into `slabs`; the caller sums them
 int mi_direct3_wgrad_launch(const float* x, const float* dy, float* slabs, int N, int D, hipStream_t s) {
-    Direct3WgradParams p = {x, dy, slabs, N, D, (unsigned)(4l * N * D * PLANE * C)};
+    Direct3WgradParams p = {};
+    p.x[0] = x; p.dy[0] = dy; p.slabs[0] = slabs; p.N = N; p.D = D; p.bytes = (unsigned)(4l * N * D * PLANE * C);
+    p.nprob = 1; p.splits = WG_SPLITS;
     hipLaunchKernelGGL(direct3_wgrad_kernel, dim3(9 * WG_SPLITS), dim3(512), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+// nb (2..WG_MAXPROB) problems of one geometry in one launch: problem i leaves mi_direct3_wgrad_batch_splits(nb) slabs in slabs[i]
+int mi_direct3_wgrad_batch_max() { return WG_MAXPROB; }
+// A batched problem is cut into WG_BATCH_SPLITS chains per (dz, dy) pair WHATEVER nb is (so a problem's gradient does not depend on
+// its neighbours in the launch): four problems x 7 x 9 = 252 workgroups, each walking four times the planes of a single launch's
+// workgroup - launch, prologue, pipeline fill, the LDS hand-over and the slab store are paid once per 73 planes instead of once per
+// 19.  Measured in the captured step (r05_experiments.txt item 7): 28 chains per problem (1,008 workgroups, four rounds) 1.561 ms =
+// the four single launches; 14: 1.535; 7: 1.524.  (MI_D3W_BATCH_SPLITS: tuning.)
+constexpr int WG_BATCH_SPLITS = 7;
+int mi_direct3_wgrad_batch_splits(int nb) {
+    if (nb < 1 || nb > WG_MAXPROB) return 0;
+    if (const char* v = getenv("MI_D3W_BATCH_SPLITS")) { const int sv = atoi(v); if (sv >= 1 && sv <= WG_SPLITS) return sv; }
+    return WG_BATCH_SPLITS;
+}
+int mi_direct3_wgrad_launch_batch(const float* const* xs, const float* const* dys, float* const* slabs, int nb, int N, int D,
+                                  hipStream_t s) {
+    if (nb < 1 || nb > WG_MAXPROB) return MI_E_ARG;
+    Direct3WgradParams p = {};
+    for (int i = 0; i < nb; ++i) { p.x[i] = xs[i]; p.dy[i] = dys[i]; p.slabs[i] = slabs[i]; }
+    p.N = N; p.D = D; p.bytes = (unsigned)(4l * N * D * PLANE * C);
+    p.nprob = nb; p.splits = mi_direct3_wgrad_batch_splits(nb);
+    hipLaunchKernelGGL(direct3_wgrad_kernel, dim3(9 * nb * p.splits), dim3(512), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

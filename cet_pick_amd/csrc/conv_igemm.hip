@@ -69,6 +69,12 @@ int mi_direct3_finish_slabs(const float* slabs, int n_slabs, long out_elems, flo
 size_t mi_direct3_wgrad_slab_bytes();
 int mi_direct3_wgrad_splits();
 int mi_direct3_wgrad_launch(const float* x, const float* dy, float* slabs, int N, int D, hipStream_t s);
+int mi_direct3_wgrad_batch_max();
+int mi_direct3_wgrad_batch_splits(int nb);
+int mi_direct3_wgrad_launch_batch(const float* const* xs, const float* const* dys, float* const* slabs, int nb, int N, int D, hipStream_t s);
+int mi_pair_wgrad_batch_max();
+int mi_pair_wgrad_launch_batch(const float* const* xs, const float* const* dys, float* const* dws, float* const* slabs, int nb, int N, int Di,
+                               int Ci, int Co, int k, int stride, hipStream_t s);
 // conv_cube2.hip: 3^3 convolutions on 2 x 2 x 2 volumes (layer3 / feature_3d) as a dense GEMM with register-staged operands
 bool mi_cube2_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw,
                      int dd, int dh, int dw);
@@ -109,6 +115,7 @@ struct BorderClass { short pos0[3], cnt[3], tlo[3], tcnt[3]; };
 constexpr int LUT_TAPS = 352;      // 7^3 = 343 rounded up to a multiple of 32
 constexpr int LUT_INVALID = 0x070707;   // bit 7 of a per-axis mask byte is never set (k <= 7)
 
+constexpr int MI_WGRAD_BATCH_MAX = 4;
 struct ConvParams {
     const float* a_src;   // gathered tensor: X (FWD, WGRAD) or dY (DGRAD)
     const float* b_src;   // W (FWD, DGRAD) or dY (WGRAD)
@@ -138,6 +145,12 @@ struct ConvParams {
     int tiles_x;                   // row tiles
     int fold;                      // pair the two ends of the work list on a CU (class launches)
     int wbox;                      // WGRAD: walk only the voxel box that is valid for the tile's tap
+    // Round 5: nbatch > 0 = that many problems of this one geometry in the launch, problem = blockIdx.y (weight gradients of a stage:
+    // the launch's fixed costs once instead of per convolution); a_src / b_src / out are then taken from the tables
+    int nbatch;
+    const float* a_tab[MI_WGRAD_BATCH_MAX];
+    const float* b_tab[MI_WGRAD_BATCH_MAX];
+    float* out_tab[MI_WGRAD_BATCH_MAX];
 };
 
 // All gathers are raw buffer loads: 32-bit byte offset against a descriptor of the whole tensor.  An offset
@@ -360,7 +373,8 @@ __global__ __launch_bounds__(NTHREADS, BF3 ? 3 : 1) void conv_igemm_kernel(ConvP
                                               : make_dec(Dz, Dy, Dx);          // class grid
 
     // ---- per-thread staging state --------------------------------------------------------------
-    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(p.a_src, p.a_bytes), b_rs = make_rsrc(p.b_src, p.b_bytes);
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(p.nbatch ? p.a_tab[blockIdx.y] : p.a_src, p.a_bytes),
+                                 b_rs = make_rsrc(p.nbatch ? p.b_tab[blockIdx.y] : p.b_src, p.b_bytes);
     unsigned a_off[A_CH];            // byte offset of the row base (+ chunk) in a_src, mod 2^32 (padding rows
                                      // start "before" the tensor); WGRAD: tap + ci offset
     unsigned a_msk[A_CH];            // RowK: per-axis validity bits (z | y<<8 | x<<16), 0 = row off
@@ -802,7 +816,7 @@ __global__ __launch_bounds__(NTHREADS, BF3 ? 3 : 1) void conv_igemm_kernel(ConvP
     if (kt < kt1) iteration(kt, 0, Set0{});
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* outp = p.out + (long)blk_z * p.slab_stride;
+    float* outp = (p.nbatch ? p.out_tab[blockIdx.y] : p.out) + (long)blk_z * p.slab_stride;
     const bool direct = (p.slab_stride == 0);
     const bool mapped = (MODE != MODE_WGRAD) && p.n_classes > 1;
 #pragma unroll
@@ -938,7 +952,7 @@ Plan make_plan(int mode, bool stem, long M, int Ncols, long red_len, int red_ch,
 
 template <int MODE, bool STEM>
 int launch_mode(const ConvParams& p, const Plan& pl, hipStream_t s) {
-    dim3 grid((unsigned)(pl.tiles_x * ((p.Ncols + pl.bn - 1) / pl.bn) * pl.splits));    // 1-D, decoded in the kernel
+    dim3 grid((unsigned)(pl.tiles_x * ((p.Ncols + pl.bn - 1) / pl.bn) * pl.splits), (unsigned)std::max(1, p.nbatch));    // x: decoded in the kernel
     if constexpr (!STEM) {
         // (a 128 x 64 bf16x3 tile was built and measured in round 2: layer-1 forward 100.6 us against 52.8 us, layer-2
         // 43.4 against 33.4, layer-3 25.0 against 23.7 - a batch-64 step does not have the rows for it: 32,768 im2col
@@ -1500,6 +1514,73 @@ extern "C" int mi_convnd_wgrad_slabs_f32(const float* x, const float* dy, float*
     Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
     if (!x || !dy || !dw || !splits_out || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
     return run_conv(MODE_WGRAD, g, x, dy, dw, nullptr, nullptr, 0, ws, ws_bytes, (hipStream_t)stream, splits_out);
+}
+
+/* nb weight gradients of ONE geometry in one launch (the engine issues a stage's weight gradients together, behind the stage's
+ * data-gradient chain): problem i reads xs[i] / dys[i] and leaves *splits_out slabs in wss[i] (> 1: the caller's
+ * mi_splitk_reduce_batch sums them into dws[i]) or, *splits_out == 1, the final gradient in dws[i].  MI_E_UNSUPPORTED: this
+ * geometry has no batched kernel - the caller issues nb single calls.  ws_bytes: size of EACH workspace. */
+extern "C" int mi_convnd_wgrad_slabs_batch_f32(const float* const* xs, const float* const* dys, float* const* dws, void* const* wss,
+                                               int nb, int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw,
+                                               int stride, int pd, int ph, int pw, size_t ws_bytes, int* splits_out,
+                                               mi_stream_t stream) {
+    Geom g = make_geom_nd(N, Di, Hi, Wi, Ci, Co, kd, kh, kw, stride, pd, ph, pw);
+    if (!xs || !dys || !dws || !wss || !splits_out || nb < 1 || !geom_ok(g) || g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MI_E_ARG;
+    for (int i = 0; i < nb; ++i) if (!xs[i] || !dys[i] || !dws[i]) return MI_E_ARG;
+    if (nb < 2 || !conv_arith_bf16x3() || env_int("MI_NO_WGRAD_BATCH")) return MI_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    float* slabs[MI_WGRAD_BATCH_MAX];
+    if (nb > MI_WGRAD_BATCH_MAX) return MI_E_UNSUPPORTED;
+    for (int i = 0; i < nb; ++i) slabs[i] = (float*)wss[i];
+    if (is_stem7(g)) return MI_E_UNSUPPORTED;
+    // same order of preference as run_conv(MODE_WGRAD, ...)
+    if (mi_pair_wgrad_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw)) {
+        if (getenv("MI_PAIRW") && atoi(getenv("MI_PAIRW")) != 0) return MI_E_UNSUPPORTED;
+        if (nb > mi_pair_wgrad_batch_max()) return MI_E_UNSUPPORTED;
+        const int splits = mi_pair_wgrad_splits(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride);
+        if (splits > 1) {
+            if (ws_bytes < mi_pair_wgrad_slab_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride)) return MI_E_UNSUPPORTED;
+            for (int i = 0; i < nb; ++i) if (!wss[i]) return MI_E_ARG;
+        }
+        g_last_conv_kernel = splits > 1 ? "pair_wgrad x nb + reduce" : "pair_wgrad x nb";
+        *splits_out = splits;
+        return mi_pair_wgrad_launch_batch(xs, dys, dws, slabs, nb, g.N, g.Di, g.Ci, g.Co, g.kd, g.stride, s);
+    }
+    if (direct3_kind(g) == 1) {
+        if (nb > mi_direct3_wgrad_batch_max() || ws_bytes < mi_direct3_wgrad_slab_bytes()) return MI_E_UNSUPPORTED;
+        for (int i = 0; i < nb; ++i) if (!wss[i]) return MI_E_ARG;
+        g_last_conv_kernel = "direct3_wgrad x nb + reduce";
+        *splits_out = mi_direct3_wgrad_batch_splits(nb);
+        return mi_direct3_wgrad_launch_batch(xs, dys, slabs, nb, g.N, g.Di, s);
+    }
+    Setup st;
+    int rc = setup_conv(MODE_WGRAD, g, &st);
+    if (rc) return rc;
+    if (g.Ci == 1) return MI_E_UNSUPPORTED;
+    ConvParams& p = st.p;
+    Plan& pl = st.pl;
+    // the single launch's split count: the slabs (and their sum) are then the single launches' bit for bit.  (MI_WGRAD_BATCH_SPLITS:
+    // tuning - a problem's share of the chip is 1 / nb of what the plan assumed, fewer and longer splits would do)
+    int splits = pl.splits;
+    if (const char* v = getenv("MI_WGRAD_BATCH_SPLITS")) { const int sv = atoi(v); if (sv >= 1 && sv <= pl.splits) splits = sv; }
+    const long out_elems = p.M * p.Ncols;
+    if (splits > 1) {
+        if (ws_bytes < sizeof(float) * (size_t)out_elems * splits) return MI_E_UNSUPPORTED;
+        for (int i = 0; i < nb; ++i) if (!wss[i]) return MI_E_ARG;
+    }
+    pl.splits = splits;
+    p.splits = splits;
+    p.res = nullptr; p.mask = nullptr; p.relu = 0; p.res_bcast = 0;
+    p.a_src = xs[0]; p.b_src = dys[0];
+    p.nbatch = nb;
+    for (int i = 0; i < nb; ++i) { p.a_tab[i] = xs[i]; p.b_tab[i] = dys[i]; p.out_tab[i] = splits > 1 ? slabs[i] : dws[i]; }
+    p.out = p.out_tab[0];
+    p.slab_stride = splits > 1 ? out_elems : 0;
+    g_last_conv_kernel = splits > 1 ? "implicit GEMM x nb + reduce" : "implicit GEMM x nb";
+    rc = launch_mode<MODE_WGRAD, false>(p, pl, s);
+    if (rc) return rc;
+    *splits_out = splits;
+    return MI_OK;
 }
 
 extern "C" int mi_splitk_reduce_batch(const void* const* slabs, void* const* outs, const int* n_slabs, const long* out_elems,

@@ -654,6 +654,102 @@ def _side_or_now(fn, rows):
         fn()
 
 
+class _WgradJob:
+    """One deferred convolution weight gradient (slab form): callable like the closures next to it in SIDE_WGRADS; jobs of one
+    geometry that are issued together go out as ONE launch (run_wgrad_jobs -> mi_convnd_wgrad_slabs_batch_f32)."""
+    __slots__ = ("x", "dy", "tgt", "slab", "geom")
+
+    def __init__(self, x, dy, tgt, slab, geom):
+        self.x, self.dy, self.tgt, self.slab, self.geom = x, dy, tgt, slab, geom
+
+    def __call__(self):
+        import ctypes
+        splits = ctypes.c_int(0)
+        L.check(L.lib().mi_convnd_wgrad_slabs_f32(L.ptr(self.x), L.ptr(self.dy), L.ptr(self.tgt), *self.geom, L.ptr(self.slab),
+                                                  self.slab.numel(), ctypes.addressof(splits), L.stream()),
+                "mi_convnd_wgrad_slabs_f32")
+        if splits.value > 1:
+            DEFERRED_WGRADS.append((self.slab, self.tgt, int(splits.value), self.tgt.numel()))
+
+
+WGRAD_BATCH = os.environ.get("CETPICK_WGRAD_BATCH", "1") != "0"
+WGRAD_BATCH_MAX = 4
+
+# Outside a MocoStepEngine step (plain autograd: loss.backward() of any trainer) the same grouping happens at the END of the backward
+# pass: the jobs wait in _BACKWARD_END and one autograd final callback issues them (run_wgrad_jobs + the slab reduce) on the caller's
+# stream.  Engine and plain sequence thus launch the same kernels on the same chains - their gradients stay equal bit for bit
+# (tests/test_trainer_gpu.py::test_engine_step_equals_plain_sequence_bitwise) although a batched layer1 gradient is cut into other
+# chains than a single one.
+_BACKWARD_END = None
+
+
+def _defer_to_backward_end(job):
+    global _BACKWARD_END
+    if _BACKWARD_END is None:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_backward_end)
+        except RuntimeError:                               # not inside a backward pass (a direct call): launch now
+            return False
+        _BACKWARD_END = []
+    _BACKWARD_END.append(job)
+    return True
+
+
+def _flush_backward_end():
+    global _BACKWARD_END, DEFERRED_WGRADS
+    items, _BACKWARD_END = _BACKWARD_END, None
+    if not items:
+        return
+    saved, DEFERRED_WGRADS = DEFERRED_WGRADS, []
+    try:
+        run_wgrad_jobs(items)
+        flush_wgrad_reduces()
+    finally:
+        DEFERRED_WGRADS = saved
+
+
+def run_wgrad_jobs(items):
+    """Issue the collected weight-gradient launches of a stage on the current stream: convolution jobs of one geometry in
+    groups of up to four per launch, everything else (and what the library declines) one by one, in collection order."""
+    import ctypes
+    groups, order = {}, []
+    for it in items:
+        if isinstance(it, _WgradJob) and WGRAD_BATCH and DEFERRED_WGRADS is not None:
+            key = it.geom + (it.slab.numel(),)
+            if key not in groups:
+                groups[key] = []
+                order.append(groups[key])
+            groups[key].append(it)
+        else:
+            order.append(it)
+    lib = L.lib()
+    for it in order:
+        if not isinstance(it, list):
+            it()
+            continue
+        for i0 in range(0, len(it), WGRAD_BATCH_MAX):
+            jobs = it[i0:i0 + WGRAD_BATCH_MAX]
+            rc = -3
+            if len(jobs) > 1:
+                n = len(jobs)
+                xs = (ctypes.c_void_p * n)(*[j.x.data_ptr() for j in jobs])
+                dys = (ctypes.c_void_p * n)(*[j.dy.data_ptr() for j in jobs])
+                dws = (ctypes.c_void_p * n)(*[j.tgt.data_ptr() for j in jobs])
+                wss = (ctypes.c_void_p * n)(*[j.slab.data_ptr() for j in jobs])
+                splits = ctypes.c_int(0)
+                rc = lib.mi_convnd_wgrad_slabs_batch_f32(ctypes.cast(xs, ctypes.c_void_p), ctypes.cast(dys, ctypes.c_void_p),
+                                                         ctypes.cast(dws, ctypes.c_void_p), ctypes.cast(wss, ctypes.c_void_p), n,
+                                                         *jobs[0].geom, jobs[0].slab.numel(), ctypes.addressof(splits), L.stream())
+                if rc == 0 and splits.value > 1:
+                    for j in jobs:
+                        DEFERRED_WGRADS.append((j.slab, j.tgt, int(splits.value), j.tgt.numel()))
+            if rc == -3:                                   # MI_E_UNSUPPORTED (or a single job): one launch each
+                for j in jobs:
+                    j()
+            else:
+                L.check(rc, "mi_convnd_wgrad_slabs_batch_f32")
+
+
 def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
     """dW for `param`, written (or accumulated) into param.grad."""
     nd5 = x.dim() == 5
@@ -664,8 +760,9 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
     g, acc = _grad_target(param)
     tgt = torch.empty_like(g) if acc else g
     flops = 2.0 * dy.numel() * ci * k3[0] * k3[1] * k3[2]
-    if DEFERRED_WGRADS is not None and not acc and PROFILE is None and (dil is None or tuple(_k3(dil, nd5)) == (1, 1, 1)):
-        import ctypes
+    slab_form = not acc and PROFILE is None and (dil is None or tuple(_k3(dil, nd5)) == (1, 1, 1)) and x.is_cuda
+    if slab_form and (DEFERRED_WGRADS is not None or (WGRAD_BATCH and lib.mi_conv3d_direct_usable(n, d, h, wd, ci, co, k3[0], stride, p3[0]) == 1
+                                                      and k3[0] == k3[1] == k3[2] and p3[0] == p3[1] == p3[2])):
         nbytes = lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3)
         slab = getattr(param, "_mi_slabs", None)
         if slab is None or slab.numel() < nbytes or slab.device != x.device:
@@ -674,15 +771,13 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
                 param._mi_slabs = slab
             # (pinned: a captured hipGraph writes and reads the old buffer on every replay - MocoStepEngine pins the slabs
             # when it captures; an eager call that needs more space gets a buffer of its own and the graph's stays alive)
-        def launch():
-            splits = ctypes.c_int(0)
-            L.check(lib.mi_convnd_wgrad_slabs_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, d, h, wd, ci, co, *k3, stride, *p3,
-                                                  L.ptr(slab), slab.numel(), ctypes.addressof(splits), L.stream()),
-                    "mi_convnd_wgrad_slabs_f32")
-            if splits.value > 1:
-                DEFERRED_WGRADS.append((slab, tgt, int(splits.value), tgt.numel()))
-        _side_or_now(launch, dy.numel() // co)
-        return
+        _f32c(x, "x"), _f32c(dy, "dy")
+        job = _WgradJob(x, dy, tgt, slab, (n, d, h, wd, ci, co) + tuple(k3) + (stride,) + tuple(p3))
+        if DEFERRED_WGRADS is not None:
+            _side_or_now(job, dy.numel() // co)
+            return
+        if _defer_to_backward_end(job):                    # plain autograd: layer1's weight gradients, batched at the end
+            return
     if dil is not None and tuple(_k3(dil, nd5)) != (1, 1, 1):
         d3 = _k3(dil, nd5)
         ws = _ws(lib.mi_convnd_dil_workspace_bytes(n, d, h, wd, ci, co, *k3, *p3, *d3), x.device, "conv")

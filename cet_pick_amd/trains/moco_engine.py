@@ -152,8 +152,7 @@ class MocoStepEngine:
             self._wside = torch.cuda.Stream(device=self.arena_q.flat_grad.device)
         self._wside.wait_stream(cur)
         with torch.cuda.stream(self._wside):
-            for fn in items:
-                fn()
+            H.run_wgrad_jobs(items)                   # (convolutions of one geometry: one launch for the group)
             H.flush_wgrad_reduces()                   # the stage's split-K slabs, behind the launches that wrote them
             if enqueue:
                 self._wside_keep.append(self.moco._pending_keys)
@@ -199,8 +198,7 @@ class MocoStepEngine:
             self._wside_used = False
             loss.backward(self._one)                   # (a kept seed: autograd's ones_like(loss) is a fill launch per step)
             if H.SIDE_WGRADS:                          # collected behind the last stage boundary: in line
-                for fn in H.SIDE_WGRADS:
-                    fn()
+                H.run_wgrad_jobs(H.SIDE_WGRADS)
             H.SIDE_WGRADS = None
             if self._wside_used:
                 torch.cuda.current_stream().wait_stream(self._wside)

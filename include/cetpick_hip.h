@@ -269,6 +269,15 @@ int mi_convnd_wgrad_slabs_f32(const float* x, const float* dy, float* dw, int N,
                               int* splits_out, mi_stream_t stream);
 int mi_splitk_reduce_batch(const void* const* slabs, void* const* outs, const int* n_slabs, const long* out_elems, int n,
                            mi_stream_t stream);
+/* Round 5: nb (2..4) weight gradients of ONE geometry in ONE launch - the weight gradients of a residual stage exist together
+ * once loss.backward() (trains/base_trainer.py:497) has left the stage (moco_encoder_3d.py:55-84: layer1's four, layer2's and
+ * layer3's three equal convolutions), and a launch's fixed costs are a third of each when they run one by one.  Problem i reads
+ * xs[i] / dys[i] and leaves *splits_out slabs in wss[i] (each workspace ws_bytes long; > 1: mi_splitk_reduce_batch sums them into
+ * dws[i]) or, *splits_out == 1, the final gradient in dws[i].  The pointer arrays are HOST arrays.  MI_E_UNSUPPORTED: no batched
+ * kernel for this geometry / nb (or MI_NO_WGRAD_BATCH=1) - issue nb single calls. */
+int mi_convnd_wgrad_slabs_batch_f32(const float* const* xs, const float* const* dys, float* const* dws, void* const* wss, int nb,
+                                    int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd,
+                                    int ph, int pw, size_t ws_bytes, int* splits_out, mi_stream_t stream);
 
 /* Patch-resident direct kernels for the 3^3 / stride 1 / padding 1 convolutions of the MoCo-3D encoder's residual layers
  * (models/networks/moco_encoder_3d.py:55-84,170-171), forward and data gradient, bf16x3 arithmetic:

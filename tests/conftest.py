@@ -82,6 +82,7 @@ def assert_relu_flips_on_edge(masks, pre64, pre32=None, max_units=8, rel=1e-4):
     forward pass itself is ill-conditioned (pre32: the CPU fp32 oracle's inputs of the same pass), <= 4 x the largest
     fp32-vs-float64 difference in that layer: a decision is only the GPU's to take where fp32 cannot resolve it.  At most
     `max_units` per layer.  Returns {layer: number of units that differ}."""
+    import torch
     flips = {}
     for name, m in masks.items():
         p64 = pre64[name + ".pre"].detach()

@@ -939,6 +939,65 @@ def test_pair_weight_gradient_forms_match_float64(case, form, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case,nb,family", [((16, 8, 64, 64, 3, 1), 4, "direct3_wgrad x nb"), ((16, 8, 64, 64, 3, 1), 3, "direct3_wgrad x nb"),
+                                            ((24, 4, 128, 128, 3, 1), 3, "implicit GEMM x nb"), ((20, 2, 256, 256, 3, 1), 4, "pair_wgrad x nb"),
+                                            ((6, 8, 32, 48, 3, 1), 2, "implicit GEMM x nb"), ((16, 8, 64, 64, 3, 1), 5, "direct3_wgrad x nb")])
+def test_batched_weight_gradients_against_single_launches(case, nb, family):
+    """Round 5: the weight gradients of a stage's equal convolutions in ONE launch (hipops.run_wgrad_jobs ->
+    mi_convnd_wgrad_slabs_batch_f32; layer1's four on direct3_wgrad_kernel, layer2's three on the implicit GEMM, layer3's on
+    pair_wgrad_kernel) against one launch per convolution.  Implicit GEMM and pair_wgrad: same chains, same slabs, same reduce -
+    EQUAL BIT FOR BIT.  direct3_wgrad cuts a batched problem into 7 chains per (dz, dy) pair instead of 28 (that is where the time
+    goes): equal to float64 within the single launch's bound, and a problem's gradient does not depend on its neighbours in the
+    launch (the same convolution in a launch of two, bit for bit).  Five jobs = a launch of four and a single one.
+    (moco_encoder_3d.py:55-84)"""
+    from cet_pick_amd import hipops as H, _lib as L
+    n, d, ci, co, k, s_ = case
+    pad = 1
+    g = torch.Generator().manual_seed(sum(case) + nb)
+    xs = [cl(torch.randn(n, ci, d, d, d, generator=g)) for _ in range(nb)]
+    do = (d + 2 * pad - k) // s_ + 1
+    dys = [cl(torch.randn(n, co, do, do, do, generator=g)) for _ in range(nb)]
+    single, batch, pair = [[make_w(co, ci, k, g)[0] for _ in range(nb)] for _ in range(3)]
+
+    def batched(params, idx):
+        H.SIDE_WGRADS = []
+        for i in idx:
+            params[i].grad = None
+            H.conv_wgrad_into(xs[i], dys[i], params[i], k, s_, pad)
+        assert len(H.SIDE_WGRADS) == len(idx) and all(isinstance(j, H._WgradJob) for j in H.SIDE_WGRADS)
+        H.run_wgrad_jobs(H.SIDE_WGRADS)
+        H.SIDE_WGRADS = None
+        name = L.lib().mi_debug_last_conv_kernel().decode()
+        H.flush_wgrad_reduces()
+        return name
+
+    H.DEFERRED_WGRADS = []
+    try:
+        for x, dy, prm in zip(xs, dys, single):
+            prm.grad = None
+            H.conv_wgrad_into(x, dy, prm, k, s_, pad)
+        H.flush_wgrad_reduces()
+        name = batched(batch, list(range(nb)))
+        assert name.startswith(family if nb != 5 else "direct3_wgrad + reduce"), name
+        batched(pair, [0, nb - 1])                     # the first and the last problem again, in a launch of two
+    finally:
+        H.DEFERRED_WGRADS = None
+        H.SIDE_WGRADS = None
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(single, batch)):
+        x64 = ncdhw(xs[i]).double().cuda()
+        w64 = torch.zeros(co, ci, k, k, k, dtype=torch.float64, device="cuda", requires_grad=True)
+        (gw,) = torch.autograd.grad(F.conv3d(x64, w64, stride=s_, padding=pad), w64, ncdhw(dys[i]).double().cuda())
+        bound = 2e-6 * float(gw.abs().max()) * max(1.0, (n * do ** 3 / 512) ** 0.5)
+        assert float((b.grad.double() - gw).abs().max()) <= bound
+        assert float((a.grad.double() - gw).abs().max()) <= bound
+        if not family.startswith("direct3") or (nb == 5 and i == 4):
+            assert torch.equal(a.grad, b.grad), i
+        if i in (0, nb - 1) and nb != 5:
+            assert torch.equal(pair[i].grad, b.grad), i
+
+
+@pytest.mark.gpu
 def test_conv_dispatch_by_shape(monkeypatch):
     """Which kernel family a convolution call takes (mi_debug_last_conv_kernel; tools/bench_conv.py --kernels prints the table):
     the encoder's shapes at the benchmark's crop size take the patch-resident kernels, other shapes the implicit GEMM, and the
