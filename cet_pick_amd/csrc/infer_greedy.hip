@@ -969,14 +969,122 @@ __global__ __launch_bounds__(RA_T) void rounds_all_kernel(GreedyHeader* hdr, con
 // its 16 waves: one 8-byte LDS read feeds ER_PPW compares, the lanes' counts are summed by shuffles at the end.  n^2
 // compares spread over the chip, no sort, one launch.
 constexpr int ER_T = 1024, ER_CHUNK = 4096, ER_PPW = 4, ER_PPG = ER_PPW * (ER_T / 64);   // 64 picks per workgroup
+constexpr int ER_KPT = 16;                           // keys a thread keeps in registers (16 x 1,024 = the usual number of picks)
+constexpr int ER_FINE = 4096, ER_MCAP = 2048;        // score cells; the largest cell the interval form accepts (a workgroup's picks stay in LDS)
+static_assert(2 * ER_MCAP <= ER_CHUNK && ER_FINE % ER_T == 0, "members alias the key chunk: n / G + the largest cell");
 
 __global__ __launch_bounds__(ER_T) void emit_rank_kernel(GreedyHeader* hdr, const unsigned long long* kept, unsigned cap,
                                                         int H, int W, float* scores, int32_t* coords, int32_t* n_out,
-                                                        int max_out) {
+                                                        int max_out, int ER_NO_INTERVALS) {
     __shared__ unsigned long long keys[ER_CHUNK];
     const unsigned n = min(hdr->n_kept, cap);
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long hw = (long)H * W;
+    // Round 5: rank by INTERVALS first.  The score range of the picks [lo, hi] is cut into ER_FINE equal cells; every workgroup counts
+    // all cells (the same counts everywhere, so all take the same decisions), and runs of consecutive cells are dealt to the
+    // workgroups by the running count - workgroup b owns the cells whose first pick has sorted position in [b n / G, (b + 1) n / G) -
+    // so that everybody ranks ~n / G picks whatever the score distribution (DoG picks crowd at the cut-off: equal-width intervals per
+    // workgroup left one of them 2,000 picks, 21 us).  A pick's row = the picks in higher cells than its workgroup's + the greater
+    // picks among the workgroup's own (kept in LDS): ~3 n + (n / G)^2 operations per workgroup instead of 64 n compares.  Keys are
+    // unique (score bits, flat index) and the cell of a key is monotone in the key: the rows are the sorted order, exactly.  A cell
+    // with more than ER_MCAP picks (a plateau of equal scores) keeps the n^2 form below.
+    if (!ER_NO_INTERVALS && n > 0) {
+        __shared__ unsigned s_cnt[ER_FINE], s_wsum[ER_T / 64], s_lo[ER_T / 64], s_hi[ER_T / 64], s_nm, s_f0, s_f1, s_above, s_big;
+        unsigned long long* members = keys;              // ER_MCAP <= ER_CHUNK
+        const unsigned G = gridDim.x;
+        for (int i = tid; i < ER_FINE; i += ER_T) s_cnt[i] = 0u;
+        if (tid == 0) { s_nm = 0u; s_f0 = ER_FINE; s_f1 = 0u; s_above = 0u; s_big = 0u; }
+        // the first ER_KPT keys of a thread stay in registers over the three passes (n <= 16 k: all of them); the rest comes from L2 again
+        unsigned long long kr[ER_KPT];
+#pragma unroll
+        for (int e = 0; e < ER_KPT; ++e) { const unsigned q = tid + e * ER_T; kr[e] = q < n ? kept[q] : 0ull; }
+        auto for_keys = [&](auto&& f) {
+#pragma unroll
+            for (int e = 0; e < ER_KPT; ++e) if ((unsigned)(tid + e * ER_T) < n) f(kr[e]);
+            for (unsigned q = tid + ER_KPT * ER_T; q < n; q += ER_T) f(kept[q]);
+        };
+        unsigned lo = 0xffffffffu, hi = 0u;
+        for_keys([&](unsigned long long k) { const unsigned h = (unsigned)(k >> 32); lo = min(lo, h); hi = max(hi, h); });
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64)); hi = max(hi, (unsigned)__shfl_xor((int)hi, o, 64)); }
+        if (lane == 0) { s_lo[wv] = lo; s_hi[wv] = hi; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ER_T / 64; ++i) { lo = min(lo, s_lo[i]); hi = max(hi, s_hi[i]); }
+        const unsigned long long span = (unsigned long long)(hi - lo) + 1ull;
+        // cell = floor((h - lo) * cscale / 2^32), cscale = floor(ER_FINE * 2^32 / span): monotone in h, < ER_FINE; ONE 64-bit division per
+        // thread instead of one per key (a 64-bit division is ~150 instructions: 32 of them per thread were 40 us)
+        const unsigned long long cscale = ((unsigned long long)ER_FINE << 32) / span;
+        auto cell_of = [&](unsigned long long k) {
+            return (unsigned)((((unsigned long long)((unsigned)(k >> 32) - lo)) * cscale) >> 32);
+        };
+        for_keys([&](unsigned long long k) { atomicAdd(&s_cnt[cell_of(k)], 1u); });
+        __syncthreads();
+        // exclusive running count of the cells in ASCENDING cell order (thread t: cells 4 t .. 4 t + 3), the owner of a cell from it
+        constexpr int CPT = ER_FINE / ER_T;
+        unsigned c[CPT], tsum = 0u;
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) { c[e] = s_cnt[CPT * tid + e]; tsum += c[e]; }
+        unsigned incl = tsum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned v = (unsigned)__shfl_up((int)incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        unsigned base = incl - tsum;
+        for (int i = 0; i < wv; ++i) base += s_wsum[i];
+        unsigned big = 0u;
+        const unsigned long long gscale = ((unsigned long long)G << 32) / n;
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) {
+            if (c[e]) {
+                const unsigned owner = (unsigned)(((unsigned long long)base * gscale) >> 32);       // base < n: owner < G, monotone
+                if (owner == blockIdx.x) {                 // (few threads: a workgroup owns a handful of cells)
+                    atomicMin(&s_f0, (unsigned)(CPT * tid + e)); atomicMax(&s_f1, (unsigned)(CPT * tid + e));
+                    atomicMax(&s_above, base + c[e]);      // the running count behind the workgroup's last cell
+                }
+                big = max(big, c[e]);
+            }
+            base += c[e];
+        }
+        if (big > ER_MCAP) s_big = 1u;
+        __syncthreads();
+        // (a workgroup's picks: at most n / G + the largest cell; more than ER_MCAP only with a cell of that size)
+        if (!s_big && n / G + 4 + ER_MCAP <= ER_CHUNK) {      // (uniform over the grid)
+            const unsigned f0 = s_f0, f1 = s_f1, above = n - s_above;
+            if (f0 <= f1) {
+                for_keys([&](unsigned long long k) {
+                    const unsigned f = cell_of(k);
+                    if (f >= f0 && f <= f1) { const unsigned slot = atomicAdd(&s_nm, 1u); if (slot < ER_CHUNK) members[slot] = k; }
+                });
+            }
+            __syncthreads();
+            const unsigned nm = min(s_nm, (unsigned)ER_CHUNK);      // (<= n / G + 1 + the largest cell <= ER_CHUNK)
+            {
+                for (unsigned q = tid; q < nm; q += ER_T) {
+                    const unsigned long long k = members[q];
+                    unsigned r = above;
+                    for (unsigned j = 0; j < nm; ++j) r += members[j] > k ? 1u : 0u;      // (LDS broadcast reads)
+                    if (r < (unsigned)max_out) {
+                        const long idx = (long)(k & 0xffffffffull);
+                        scores[r] = unorder_bits((unsigned)(k >> 32));
+                        const long z = idx / hw, t2 = idx - z * hw;
+                        coords[3 * r + 0] = (int)(t2 % W);
+                        coords[3 * r + 1] = (int)(t2 / W);
+                        coords[3 * r + 2] = (int)z;
+                    }
+                }
+                if (blockIdx.x == 0 && threadIdx.x == 0) {
+                    unsigned ov = hdr->overflow;
+                    if (hdr->n_kept > cap || hdr->n_kept > (unsigned)max_out) ov |= 2u;
+                    int v = (int)min(n, (unsigned)max_out);
+                    if (ov) v = -(int)ov;   // -1: candidate overflow, -2: pick overflow
+                    *n_out = v;
+                }
+                return;
+            }
+        }
+        __syncthreads();                                  // (the n^2 form reuses `keys`)
+    }
     for (unsigned g0 = blockIdx.x * ER_PPG; g0 < n; g0 += gridDim.x * ER_PPG) {      // (workgroup-uniform trip count)
         unsigned long long key[ER_PPW];
         unsigned rank[ER_PPW];
@@ -1096,8 +1204,9 @@ int greedy_tail(const GreedyWs& w, int D, int H, int W, float d, float scale, fl
     hipLaunchKernelGGL(rounds_all_kernel, dim3(512), dim3(RA_T), 0, s, w.hdr, w.G, w.map, w.bits, w.runs, n_vox, w.cap,
                        w.nbr, w.state, w.act_a, w.act_b, w.kept, w.kept_cap, sx);
     MI_RETURN_IF_LAUNCH_FAILED();
+    const int er_n2 = getenv("MI_EMIT_RANK_N2") ? 1 : 0;                 // A/B: the round-4 n^2 form only
     hipLaunchKernelGGL(emit_rank_kernel, dim3(256), dim3(ER_T), 0, s, w.hdr, w.kept, w.kept_cap, H, W, scores, coords,
-                       n_out, max_out);
+                       n_out, max_out, er_n2);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
