@@ -160,6 +160,50 @@ def test_greedy_nms_golden(golden):
     np.testing.assert_array_equal(c, g["coords_d6_s15"])
 
 
+@pytest.mark.parametrize("case", ["plateau", "many", "skewed"])
+def test_greedy_nms_output_order_by_intervals_and_by_counting(case, monkeypatch):
+    """emit_rank_kernel, round 5: picks ranked by score intervals (cells dealt to the workgroups by the running count) - and the n^2
+    counting form it keeps for a cell of more than 2,048 equal-score picks (`plateau`: 6,859 isolated peaks of ONE value: ordered by the
+    kernels' priority key (score bits, flat index), greater key first, in both forms), with more picks than a workgroup's threads
+    hold in registers (`many`: 35,937 peaks > 16 x 1,024) and with scores crowded at one end (`skewed`).  Isolated peaks further apart
+    than the suppression distance: every peak is a pick, so the expected output is the peaks sorted - exact; both forms
+    (MI_EMIT_RANK_N2=1) give the same arrays."""
+    from cet_pick_amd.utils import image as Im
+    rng = np.random.default_rng({"plateau": 1, "many": 2, "skewed": 3}[case])
+    step, d = 6, 4
+    m = 19 if case == "plateau" else 33 if case == "many" else 24
+    shape = (m * step, m * step, m * step)
+    vol = np.zeros(shape, np.float32)
+    zz, yy, xx = np.meshgrid(*[np.arange(m) * step + 2] * 3, indexing="ij")
+    n = m ** 3
+    if case == "plateau":
+        vals = np.full(n, 3.0, np.float32)
+    elif case == "many":
+        vals = (1.0 + rng.permutation(n) / n).astype(np.float32)
+    else:
+        vals = (1.0 + 1e-3 * rng.random(n) ** 8).astype(np.float32)
+        vals[:5] = 50.0 + np.arange(5)
+        vals = np.unique(vals)                 # unique scores (ties are ordered by index: covered by `plateau`)
+        vals = rng.permutation(vals)
+        n = len(vals)
+    flat = (zz.ravel() * shape[1] + yy.ravel()) * shape[2] + xx.ravel()
+    flat = flat[:n]
+    vol.ravel()[flat] = vals
+    s, c = Im.non_maximum_suppression_3d(vol, d, threshold=0.5)
+    assert len(s) == n
+    order = np.lexsort((flat, -vals.astype(np.float64)))          # score descending, flat index ascending among equals
+    if case == "plateau":
+        # equal scores: the priority key is (score bits, flat index) - the greater key first
+        order = np.argsort(-flat, kind="stable")
+    np.testing.assert_array_equal(s, vals[order])
+    want = np.stack([flat[order] % shape[2], (flat[order] // shape[2]) % shape[1], flat[order] // (shape[1] * shape[2])], 1)
+    np.testing.assert_array_equal(c, want)
+    monkeypatch.setenv("MI_EMIT_RANK_N2", "1")
+    s2, c2 = Im.non_maximum_suppression_3d(vol, d, threshold=0.5)
+    np.testing.assert_array_equal(s2, s)
+    np.testing.assert_array_equal(c2, c)
+
+
 def test_dog_pick_golden(golden):
     from cet_pick_amd.utils import image as Im
     g = golden("dog_small.npz")
