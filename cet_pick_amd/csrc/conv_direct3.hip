@@ -614,8 +614,15 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 // the two halves of the reduction are added through LDS once, before the slab is written.  Measured (profiles/r04_experiments.txt
 // item 12): 40.0 -> 38.7 us; of those 8.8 us are launch + prologue + the 12 MB of slabs, and 19 planes x 72 MFMAs per SIMD at the
 // 2.05 GHz the chip sustains under MFMA load are 21.4 us - the loop runs at 0.72 of the matrix pipe.
+// Round 5, V4 = true: the same kernel for layer2's shape - 128 -> 128 channels on 4 x 4 x 4 volumes (moco_encoder_3d.py:171; the implicit
+// GEMM took 3 x 30-50 us for its three equal convolutions inside the step).  The staging unit is a SAMPLE's whole volume (64 voxels =
+// 4 k-steps, like an 8 x 8 plane), so the z offset of a tap is a row select like its y offset (no partner plane, nothing skipped); a
+// lane's eight k values are two image rows of four: the x-shifted fragments get a zero at BOTH row edges; a workgroup owns one
+// (dz, dy) pair and one 64 x 64 block of the 128 x 128 channels (36 groups instead of 9).
+template <bool V4>
 __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WBUF];
+    constexpr int CT = V4 ? 128 : C;                   // channels of a voxel in memory
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l32 = lane & 31, i16 = lane & 15, g16 = (lane >> 4) & 1;
@@ -623,17 +630,22 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
     const int per_grp = p.nprob * p.splits;
     const int grp = blockIdx.x / per_grp, rem = blockIdx.x % per_grp;
     const int pb = rem / p.splits, split = rem % p.splits, stride = p.splits;
-    const int dz = grp / 3, dy = grp % 3;
-    const int n_planes = p.N * p.D;
+    const int pair = V4 ? grp % 9 : grp, chb = V4 ? grp / 9 : 0;
+    const int ci0 = (chb >> 1) * 64, co0 = (chb & 1) * 64;             // this workgroup's 64 x 64 channel block
+    const int dz = pair / 3, dy = pair % 3;
+    const int n_planes = p.N * p.D;                    // V4: D = 1, a "plane" is a sample
 
     // ---- staging: a thread's unit = (voxel, 8 channels) of X and the same unit of dY: 64 voxels x 8 channel groups ----
     const __amdgpu_buffer_rsrc_t xrs = rsrc_of(p.x[pb], p.bytes), yrs = rsrc_of(p.dy[pb], p.bytes);
     const int st_vox = tid >> 3, st_cg = tid & 7;
-    const unsigned st_src = 4u * (unsigned)(st_vox * C + st_cg * 8);
+    const unsigned st_src = 4u * (unsigned)(st_vox * CT + st_cg * 8);
+    const unsigned x_ch = 4u * (unsigned)ci0, y_ch = 4u * (unsigned)co0;
+    const int zsh = V4 ? 0 : dz - 1;                   // partner plane of X (V4: the sample itself)
     const int st_lds = (st_cg >> 2) * WHALF + st_vox * WROW + (st_cg & 3) * 16;
     // plane index of this workgroup's i-th tile, or -1 behind the last: every WG_SPLITS-th (n, z) whose partner plane
     // z + dz - 1 is inside the volume
     auto next_plane = [&](int from) {
+        if (V4) return from < n_planes ? from : -1;
         for (int pi = from; pi < n_planes; pi += stride) {
             const int zi = pi % p.D + dz - 1;
             if ((unsigned)zi < (unsigned)p.D) return pi;
@@ -642,8 +654,8 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
     };
     u32x4 ldx[2], ldy[2];
     auto stage_load = [&](int pi) {                     // pi < 0: nothing to fetch (offsets out of range: zeros)
-        const unsigned ybase = pi >= 0 ? 4u * (unsigned)((long)pi * PLANE * C) : 0x80000000u;
-        const unsigned xbase = pi >= 0 ? 4u * (unsigned)((long)(pi + dz - 1) * PLANE * C) : 0x80000000u;
+        const unsigned ybase = pi >= 0 ? 4u * (unsigned)((long)pi * PLANE * CT) + y_ch : 0x80000000u;
+        const unsigned xbase = pi >= 0 ? 4u * (unsigned)((long)(pi + zsh) * PLANE * CT) + x_ch : 0x80000000u;
         ldx[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src), 0, 0);
         ldx[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src + 16u), 0, 0);
         ldy[0] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(ybase + st_src), 0, 0);
@@ -679,8 +691,13 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
 #pragma unroll
         for (int hi = 0; hi < 2; ++hi) {
             const int v = 16 * (2 * kh + lk) + 8 * h + 4 * hi + q4;
-            const int yi = (v >> 3) + dy - 1;
-            a_sel[lk][hi] = wm * WHALF + ((unsigned)yi < 8u ? (yi * 8 + (v & 7)) * WROW : WZERO) + coloff;
+            if (V4) {      // v = (z, y, x) of a 4 x 4 x 4 volume: the input voxel (z + dz - 1, y + dy - 1, x), x shifted in registers
+                const int zi = (v >> 4) + dz - 1, yi = ((v >> 2) & 3) + dy - 1;
+                a_sel[lk][hi] = wm * WHALF + (((unsigned)zi < 4u && (unsigned)yi < 4u) ? ((zi * 4 + yi) * 4 + (v & 3)) * WROW : WZERO) + coloff;
+            } else {
+                const int yi = (v >> 3) + dy - 1;
+                a_sel[lk][hi] = wm * WHALF + ((unsigned)yi < 8u ? (yi * 8 + (v & 7)) * WROW : WZERO) + coloff;
+            }
         }
 
     f32x16 acc[3];
@@ -741,10 +758,12 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
             o[0] = c[0] << 16;
 #pragma unroll
             for (int j = 1; j < 4; ++j) o[j] = __builtin_amdgcn_alignbit(c[j], c[j - 1], 16);
+            if (V4) o[2] &= 0xffff0000u;               // element 4 = x 0 of the second row: nothing to its left
         } else {
 #pragma unroll
             for (int j = 0; j < 3; ++j) o[j] = __builtin_amdgcn_alignbit(c[j + 1], c[j], 16);
             o[3] = c[3] >> 16;
+            if (V4) o[1] &= 0x0000ffffu;               // element 3 = x 3 of the first row: nothing to its right
         }
         af[set][dxv][pl] = __builtin_bit_cast(bf16x8, o);
     };
@@ -778,8 +797,8 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
     constexpr int DXO[3] = {1, 0, 2};                     // MFMA order of the taps: the one that was read, then the derived ones
     while (cur >= 0) {
         const int nn = nxt >= 0 ? next_plane(nxt + stride) : -1;      // the plane after next: fetched during this one
-        const unsigned ybase = nn >= 0 ? 4u * (unsigned)((long)nn * PLANE * C) : 0x80000000u;
-        const unsigned xbase = nn >= 0 ? 4u * (unsigned)((long)(nn + dz - 1) * PLANE * C) : 0x80000000u;
+        const unsigned ybase = nn >= 0 ? 4u * (unsigned)((long)nn * PLANE * CT) + y_ch : 0x80000000u;
+        const unsigned xbase = nn >= 0 ? 4u * (unsigned)((long)(nn + zsh) * PLANE * CT) + x_ch : 0x80000000u;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int lk = 0; lk < 2; ++lk) {
@@ -828,14 +847,14 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
     }
     __syncthreads();
     if (kh == 1) return;
-    float* out = p.slabs[pb] + (long)split * (NTAP * C * C);
+    float* out = p.slabs[pb] + (long)split * (NTAP * CT * CT);
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
         const int tap = (dz * 3 + dy) * 3 + dx;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int ci = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
-            out[((long)tap * C + ci) * C + 32 * wn + l32] = acc[dx][r] + red[((wave * 3 + dx) * 16 + r) * 64 + lane];
+            const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+            out[((long)tap * CT + ci) * CT + co0 + 32 * wn + l32] = acc[dx][r] + red[((wave * 3 + dx) * 16 + r) * 64 + lane];
         }
     }
 }
@@ -1196,7 +1215,7 @@ int mi_direct3_wgrad_launch(const float* x, const float* dy, float* slabs, int N
     Direct3WgradParams p = {};
     p.x[0] = x; p.dy[0] = dy; p.slabs[0] = slabs; p.N = N; p.D = D; p.bytes = (unsigned)(4l * N * D * PLANE * C);
     p.nprob = 1; p.splits = WG_SPLITS;
-    hipLaunchKernelGGL(direct3_wgrad_kernel, dim3(9 * WG_SPLITS), dim3(512), 0, s, p);
+    hipLaunchKernelGGL(direct3_wgrad_kernel<false>, dim3(9 * WG_SPLITS), dim3(512), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -1220,7 +1239,30 @@ int mi_direct3_wgrad_launch_batch(const float* const* xs, const float* const* dy
     for (int i = 0; i < nb; ++i) { p.x[i] = xs[i]; p.dy[i] = dys[i]; p.slabs[i] = slabs[i]; }
     p.N = N; p.D = D; p.bytes = (unsigned)(4l * N * D * PLANE * C);
     p.nprob = nb; p.splits = mi_direct3_wgrad_batch_splits(nb);
-    hipLaunchKernelGGL(direct3_wgrad_kernel, dim3(9 * nb * p.splits), dim3(512), 0, s, p);
+    hipLaunchKernelGGL(direct3_wgrad_kernel<false>, dim3(9 * nb * p.splits), dim3(512), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+// ---- layer2's shape (128 -> 128 on 4 x 4 x 4, kind 2): direct3_wgrad_kernel<true> ----
+// single launch: 7 chains of samples per group (36 groups: 252 workgroups); batched (2..4 problems): 2 chains per problem whatever nb
+// (3 problems: 216 workgroups, each walking half the batch) - MI_D3SW_BATCH_SPLITS: tuning
+constexpr int WS_SPLITS = 7, WS_BATCH_SPLITS = 2;
+size_t mi_direct3s_wgrad_slab_bytes() { return sizeof(float) * (size_t)WS_SPLITS * NTAP * CS * CS; }
+int mi_direct3s_wgrad_splits(int nb) {
+    if (nb < 1 || nb > WG_MAXPROB) return 0;
+    if (nb == 1) return WS_SPLITS;
+    if (const char* v = getenv("MI_D3SW_BATCH_SPLITS")) { const int sv = atoi(v); if (sv >= 1 && sv <= WS_SPLITS) return sv; }
+    return WS_BATCH_SPLITS;
+}
+// problem i leaves mi_direct3s_wgrad_splits(nb) slabs of [27][128][128] floats in slabs[i]; the caller sums them
+int mi_direct3s_wgrad_launch_batch(const float* const* xs, const float* const* dys, float* const* slabs, int nb, int N, hipStream_t s) {
+    if (nb < 1 || nb > WG_MAXPROB || N < 1) return MI_E_ARG;
+    Direct3WgradParams p = {};
+    for (int i = 0; i < nb; ++i) { p.x[i] = xs[i]; p.dy[i] = dys[i]; p.slabs[i] = slabs[i]; }
+    p.N = N; p.D = 1; p.bytes = (unsigned)(4l * N * PLANE * CS);
+    p.nprob = nb; p.splits = mi_direct3s_wgrad_splits(nb);
+    hipLaunchKernelGGL(direct3_wgrad_kernel<true>, dim3(36 * nb * p.splits), dim3(512), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

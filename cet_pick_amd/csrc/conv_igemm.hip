@@ -72,6 +72,9 @@ int mi_direct3_wgrad_launch(const float* x, const float* dy, float* slabs, int N
 int mi_direct3_wgrad_batch_max();
 int mi_direct3_wgrad_batch_splits(int nb);
 int mi_direct3_wgrad_launch_batch(const float* const* xs, const float* const* dys, float* const* slabs, int nb, int N, int D, hipStream_t s);
+size_t mi_direct3s_wgrad_slab_bytes();
+int mi_direct3s_wgrad_splits(int nb);
+int mi_direct3s_wgrad_launch_batch(const float* const* xs, const float* const* dys, float* const* slabs, int nb, int N, hipStream_t s);
 int mi_pair_wgrad_batch_max();
 int mi_pair_wgrad_launch_batch(const float* const* xs, const float* const* dys, float* const* dws, float* const* slabs, int nb, int N, int Di,
                                int Ci, int Co, int k, int stride, hipStream_t s);
@@ -1196,6 +1199,7 @@ size_t direct3_ws_bytes(const Geom& g) {
     if (!kind) return 0;
     size_t b = mi_align_up(mi_direct3_wimg_bytes_kind(kind), 256);
     if (kind == 1) b = std::max(b, mi_direct3_wgrad_slab_bytes());
+    if (kind == 2) b = std::max(b, mi_direct3s_wgrad_slab_bytes());
     return b;
 }
 
@@ -1303,6 +1307,20 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
                            (const float*)ws, splits, out_elems, out, (const float*)nullptr, (const float*)nullptr, 0, n4);
         MI_RETURN_IF_LAUNCH_FAILED();
         return MI_OK;
+    }
+    // (opt-in, MI_D3S_WGRAD=1: 68 against 87 us for layer2's three gradients alone, but the captured step is 10-30 us SLOWER with it:
+    // its workgroups keep 100 KB of LDS each, and next to layer1's data-gradient chain that costs more than the implicit GEMM's
+    // small workgroups do - r05_experiments.txt item 9)
+    if (mode == MODE_WGRAD && dkind == 2 && ws && ws_bytes >= mi_direct3s_wgrad_slab_bytes() && env_int("MI_D3S_WGRAD")) {
+        g_last_conv_kernel = "direct3s_wgrad + reduce";
+        const float* xs[1] = {a_src};
+        const float* dys[1] = {b_src};
+        float* sl[1] = {(float*)ws};
+        int rc = mi_direct3s_wgrad_launch_batch(xs, dys, sl, 1, g.N, s);
+        if (rc) return rc;
+        const int splits = mi_direct3s_wgrad_splits(1);
+        if (defer_splits) { *defer_splits = splits; return MI_OK; }
+        return mi_direct3_finish_slabs((const float*)ws, splits, 27l * g.Ci * g.Co, out, nullptr, nullptr, 0, s);
     }
     Setup st;
     int rc = setup_conv(mode, g, &st);
@@ -1552,6 +1570,13 @@ extern "C" int mi_convnd_wgrad_slabs_batch_f32(const float* const* xs, const flo
         g_last_conv_kernel = "direct3_wgrad x nb + reduce";
         *splits_out = mi_direct3_wgrad_batch_splits(nb);
         return mi_direct3_wgrad_launch_batch(xs, dys, slabs, nb, g.N, g.Di, s);
+    }
+    if (direct3_kind(g) == 2 && env_int("MI_D3S_WGRAD")) {
+        if (nb > mi_direct3_wgrad_batch_max() || ws_bytes < mi_direct3s_wgrad_slab_bytes()) return MI_E_UNSUPPORTED;
+        for (int i = 0; i < nb; ++i) if (!wss[i]) return MI_E_ARG;
+        g_last_conv_kernel = "direct3s_wgrad x nb + reduce";
+        *splits_out = mi_direct3s_wgrad_splits(nb);
+        return mi_direct3s_wgrad_launch_batch(xs, dys, slabs, nb, g.N, s);
     }
     Setup st;
     int rc = setup_conv(MODE_WGRAD, g, &st);

@@ -761,7 +761,7 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
     tgt = torch.empty_like(g) if acc else g
     flops = 2.0 * dy.numel() * ci * k3[0] * k3[1] * k3[2]
     slab_form = not acc and PROFILE is None and (dil is None or tuple(_k3(dil, nd5)) == (1, 1, 1)) and x.is_cuda
-    if slab_form and (DEFERRED_WGRADS is not None or (WGRAD_BATCH and lib.mi_conv3d_direct_usable(n, d, h, wd, ci, co, k3[0], stride, p3[0]) == 1
+    if slab_form and (DEFERRED_WGRADS is not None or (WGRAD_BATCH and lib.mi_conv3d_direct_usable(n, d, h, wd, ci, co, k3[0], stride, p3[0]) in (1, 2)
                                                       and k3[0] == k3[1] == k3[2] and p3[0] == p3[1] == p3[2])):
         nbytes = lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3)
         slab = getattr(param, "_mi_slabs", None)
@@ -776,7 +776,7 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
         if DEFERRED_WGRADS is not None:
             _side_or_now(job, dy.numel() // co)
             return
-        if _defer_to_backward_end(job):                    # plain autograd: layer1's weight gradients, batched at the end
+        if _defer_to_backward_end(job):                    # plain autograd: layer1's / layer2's weight gradients, batched at the end
             return
     if dil is not None and tuple(_k3(dil, nd5)) != (1, 1, 1):
         d3 = _k3(dil, nd5)

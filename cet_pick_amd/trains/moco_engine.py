@@ -134,10 +134,20 @@ class MocoStepEngine:
                 H.dist_all_reduce(self.arena_q.flat_grad[a:b])
             self.buckets_sent.append(tag)
 
+    # CETPICK_L2_WGRAD_LATE=1 (measured, not faster: r05_experiments.txt item 9): layer2's weight gradients wait for layer1's marker and
+    # run next to the stem chain instead of next to layer1's data-gradient chain; the layer2 bucket of the gradient exchange then goes
+    # out with layer1's.
+    l2_late = os.environ.get("CETPICK_L2_WGRAD_LATE", "0") != "0"
+
     def _on_marker(self, tag):
-        if self.side_wgrads and tag in ("layer3", "layer2", "layer1"):
+        late = self.l2_late and self.side_wgrads
+        if self.side_wgrads and tag in ("layer3", "layer2", "layer1") and not (late and tag == "layer2"):
             self._issue_side_wgrads(enqueue=(tag == "layer3"))
         if self.dist_on:
+            if late and tag == "layer2":
+                return
+            if late and tag == "layer1":
+                self._reduce_bucket("layer2")
             self._reduce_bucket(tag)
 
     def _issue_side_wgrads(self, enqueue=False):

@@ -940,9 +940,10 @@ def test_pair_weight_gradient_forms_match_float64(case, form, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,nb,family", [((16, 8, 64, 64, 3, 1), 4, "direct3_wgrad x nb"), ((16, 8, 64, 64, 3, 1), 3, "direct3_wgrad x nb"),
-                                            ((24, 4, 128, 128, 3, 1), 3, "implicit GEMM x nb"), ((20, 2, 256, 256, 3, 1), 4, "pair_wgrad x nb"),
+                                            ((24, 4, 128, 128, 3, 1), 3, "direct3s_wgrad x nb"), ((64, 4, 128, 128, 3, 1), 2, "direct3s_wgrad x nb"), ((7, 4, 128, 128, 3, 1), 4, "direct3s_wgrad x nb"),
+                                            ((24, 4, 128, 64, 3, 1), 3, "implicit GEMM x nb"), ((24, 4, 128, 128, 3, 1), 3, "implicit GEMM x nb"), ((20, 2, 256, 256, 3, 1), 4, "pair_wgrad x nb"),
                                             ((6, 8, 32, 48, 3, 1), 2, "implicit GEMM x nb"), ((16, 8, 64, 64, 3, 1), 5, "direct3_wgrad x nb")])
-def test_batched_weight_gradients_against_single_launches(case, nb, family):
+def test_batched_weight_gradients_against_single_launches(case, nb, family, monkeypatch):
     """Round 5: the weight gradients of a stage's equal convolutions in ONE launch (hipops.run_wgrad_jobs ->
     mi_convnd_wgrad_slabs_batch_f32; layer1's four on direct3_wgrad_kernel, layer2's three on the implicit GEMM, layer3's on
     pair_wgrad_kernel) against one launch per convolution.  Implicit GEMM and pair_wgrad: same chains, same slabs, same reduce -
@@ -953,6 +954,8 @@ def test_batched_weight_gradients_against_single_launches(case, nb, family):
     from cet_pick_amd import hipops as H, _lib as L
     n, d, ci, co, k, s_ = case
     pad = 1
+    if family.startswith("direct3s"):
+        monkeypatch.setenv("MI_D3S_WGRAD", "1")        # layer2's shape on direct3_wgrad_kernel<true>: opt-in (the default: implicit GEMM)
     g = torch.Generator().manual_seed(sum(case) + nb)
     xs = [cl(torch.randn(n, ci, d, d, d, generator=g)) for _ in range(nb)]
     do = (d + 2 * pad - k) // s_ + 1
@@ -1019,8 +1022,24 @@ def test_conv_dispatch_by_shape(monkeypatch):
     assert fwd(2, 8, 128, 128).startswith("implicit GEMM")
     assert fwd(16, 4, 256, 256) == "direct3s (256 channels)"       # layer3 of a 64^3 crop (round 4), batch >= 16
     assert fwd(8, 16, 64, 64) == "direct3h (8 x 8 tiles)"          # layer1 of a 64^3 crop (round 4), from 128 workgroups on
+    # weight gradients (round 5: layer2's shape has direct3_wgrad_kernel<true> too, opt-in)
+    def wgrad(n, d, ci, co, k=3, s=1, p=1):
+        x = torch.randn(n, d, d, d, ci, device="cuda")
+        do = (d + 2 * p - k) // s + 1
+        dy = torch.randn(n, do, do, do, co, device="cuda")
+        w = H.conv_weight_param(co, ci, k); w.data = w.data.cuda()
+        H.conv_wgrad_into(x, dy, w, k, s, p)
+        return lib.mi_debug_last_conv_kernel().decode()
+    assert wgrad(4, 8, 64, 64) == "direct3_wgrad + reduce"
+    assert wgrad(4, 4, 128, 128).startswith("implicit GEMM")       # (direct3_wgrad_kernel<true> is opt-in: slower inside the step)
+    assert wgrad(4, 2, 256, 256).startswith("pair_wgrad")
+    assert wgrad(4, 4, 128, 64).startswith("implicit GEMM")
+    monkeypatch.setenv("MI_D3S_WGRAD", "1")
+    assert wgrad(4, 4, 128, 128) == "direct3s_wgrad + reduce"
+    monkeypatch.delenv("MI_D3S_WGRAD")
     monkeypatch.setenv("MI_CONV_NO_DIRECT", "1")
     assert fwd(4, 8, 64, 64).startswith("implicit GEMM")
+    assert wgrad(4, 4, 128, 128).startswith("implicit GEMM")
 
 
 @pytest.mark.gpu
