@@ -231,7 +231,9 @@ struct Cursor {
 //   "KRow" plane, one [BK][32 columns] sub-tile per 32 columns (64-byte rows) : fragments by ds_read_b64_tr_b16
 //          (the transposing LDS read of gfx950: 4 k's x 16 columns per 16-lane group, conflict-free on 64-byte rows)
 template <int MODE, int BM, int BN, int BK, bool STEM, bool BF3 = false>
-__global__ __launch_bounds__(NTHREADS, BF3 ? 3 : 1) void conv_igemm_kernel(ConvParams p) {
+// (occupancy asked for: 3 workgroups per SIMD-quad for the bf16x3 tiles, 2 for the 128-row x 32-column inference tile, whose
+// 8 accumulator blocks per wave do not fit the 168 registers of occupancy 3 - the compiler said so on every build)
+__global__ __launch_bounds__(NTHREADS, BF3 ? ((BM == 128 && BN == 32) ? 2 : 3) : 1) void conv_igemm_kernel(ConvParams p) {
     static_assert(!BF3 || (!STEM && (BK == 16 || BK == 32)), "bf16x3 path: generic layers, 16- or 32-deep slices");
     static_assert(BK == 16 || BK == 32 || BK == 64, "slice depth");
     static_assert(BN == 32 || BN == 64 || BN == 128, "tile width");

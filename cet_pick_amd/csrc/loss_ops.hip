@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 3) void ucl_fwd_kernel(const float* feat, cons
 // with c(i; j) = g_all[i] + g_pos[i] [pos j] + g_other[i] [other j] + g_pair[i] [j == pair(i)], zero on the diagonal.
 // The W tile goes through LDS to become the A operand of the second product.
 template <int DIM, int TRANS>
-__global__ __launch_bounds__(256, 3) void ucl_bwd_kernel(const float* feat, const uint8_t* cls, int n2, int n_half,
+__global__ __launch_bounds__(256, DIM == 64 ? 2 : 3) void ucl_bwd_kernel(const float* feat, const uint8_t* cls, int n2, int n_half,
                                                      float inv_T, const float* rowmax, const float* g_all,
                                                      const float* g_pos, const float* g_other, const float* g_pair,
                                                      float* dfeat, int accumulate) {
