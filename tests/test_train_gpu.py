@@ -122,9 +122,11 @@ def test_conv_bf16x3_is_f32_equivalent(case, monkeypatch):
                                       (64, 2, 2, 256), (5, 2, 2, 256), (70, 2, 2, 128),
                                       (16, 8, 8, 128), (66, 2, 8, 128), (17, 8, 8, 128),
                                       (8, 16, 16, 64), (8, 4, 24, 64), (33, 2, 16, 64),
-                                      (16, 4, 4, 256), (19, 4, 4, 256), (6, 4, (16, 24), 64)])
+                                      (16, 4, 4, 256), (19, 4, 4, 256), (6, 4, (16, 24), 64),
+                                      (8, 8, (14, 15), 64), (4, 16, (15, 23), 64)])
 def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
-    """(round 4: also 128 channels on 8 x 8 planes and 64 channels on 16 x 16 / 24 x 24 planes - layer2 / layer1 of larger crops.)
+    """(round 4: also 128 channels on 8 x 8 planes and 64 channels on 16 x 16 / 24 x 24 planes - layer2 / layer1 of larger crops;
+    round 5: ragged planes, 14 x 15 and 15 x 23 - the last tile of a row / column hangs over the edge.)
     layer1- (3^3, stride 1, 64 -> 64, 8 x 8 planes) and layer2-shaped (128 -> 128, 4 x 4 x 4; odd batch: a half-empty
     sample pair) convolutions take the patch-resident direct kernels (conv_direct3.hip), 2 x 2 x 2 volumes (layer3,
     feature_3d) the register-staged dense GEMM (conv_cube2.hip); MI_CONV_NO_DIRECT=1 keeps the implicit GEMM.  Both are the bf16x3 arithmetic: equal up to the
@@ -1022,6 +1024,8 @@ def test_conv_dispatch_by_shape(monkeypatch):
     assert fwd(2, 8, 128, 128).startswith("implicit GEMM")
     assert fwd(16, 4, 256, 256) == "direct3s (256 channels)"       # layer3 of a 64^3 crop (round 4), batch >= 16
     assert fwd(8, 16, 64, 64) == "direct3h (8 x 8 tiles)"          # layer1 of a 64^3 crop (round 4), from 128 workgroups on
+    assert fwd(16, 12, 64, 64).startswith("implicit GEMM")         # layer1 of a 48^3 crop: a 12 x 12 plane fills 56 % of four tiles (measured slower)
+    assert fwd(8, 14, 64, 64) == "direct3h (8 x 8 tiles)"          # ragged planes from 75 % fill on (round 5)
     # weight gradients (round 5: layer2's shape has direct3_wgrad_kernel<true> too, opt-in)
     def wgrad(n, d, ci, co, k=3, s=1, p=1):
         x = torch.randn(n, d, d, d, ci, device="cuda")
