@@ -657,10 +657,10 @@ def _side_or_now(fn, rows):
 class _WgradJob:
     """One deferred convolution weight gradient (slab form): callable like the closures next to it in SIDE_WGRADS; jobs of one
     geometry that are issued together go out as ONE launch (run_wgrad_jobs -> mi_convnd_wgrad_slabs_batch_f32)."""
-    __slots__ = ("x", "dy", "tgt", "slab", "geom")
+    __slots__ = ("x", "dy", "tgt", "slab", "geom", "param")
 
-    def __init__(self, x, dy, tgt, slab, geom):
-        self.x, self.dy, self.tgt, self.slab, self.geom = x, dy, tgt, slab, geom
+    def __init__(self, x, dy, tgt, slab, geom, param=None):
+        self.x, self.dy, self.tgt, self.slab, self.geom, self.param = x, dy, tgt, slab, geom, param
 
     def __call__(self):
         import ctypes
@@ -685,13 +685,17 @@ _BACKWARD_END = None
 
 def _defer_to_backward_end(job):
     global _BACKWARD_END
+    try:
+        # (one callback per job: the first one to run flushes everything, the others find the list empty - and a list left
+        # behind by a backward pass that raised cannot stay unflushed for ever)
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_backward_end)
+    except RuntimeError:                                   # not inside a backward pass (a direct call): launch now
+        return False
     if _BACKWARD_END is None:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_flush_backward_end)
-        except RuntimeError:                               # not inside a backward pass (a direct call): launch now
-            return False
         _BACKWARD_END = []
     _BACKWARD_END.append(job)
+    if job.param is not None:
+        job.param._mi_wgrad_pending = True                 # (a second contribution to this parameter flushes first: conv_wgrad_into)
     return True
 
 
@@ -714,6 +718,8 @@ def run_wgrad_jobs(items):
     import ctypes
     groups, order = {}, []
     for it in items:
+        if isinstance(it, _WgradJob) and it.param is not None:
+            it.param._mi_wgrad_pending = False
         if isinstance(it, _WgradJob) and WGRAD_BATCH and DEFERRED_WGRADS is not None:
             key = it.geom + (it.slab.numel(),)
             if key not in groups:
@@ -757,6 +763,13 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
     n, d, h, wd, ci = _as5d(x).shape
     co = dy.shape[-1]
     lib = L.lib()
+    if getattr(param, "_mi_wgrad_pending", False):
+        # a module applied twice in one backward pass (the symmetric MoCo loss): the first contribution still waits for the end of
+        # the pass with this parameter's gradient as its target and its slab buffer - it goes out now, this one accumulates onto it
+        if DEFERRED_WGRADS is not None:
+            raise L.HipExtensionError("MocoStepEngine: a convolution applied twice in one backward pass (its first weight gradient is "
+                                      "still queued for the side stream) - run this model without the step engine")
+        _flush_backward_end()
     g, acc = _grad_target(param)
     tgt = torch.empty_like(g) if acc else g
     flops = 2.0 * dy.numel() * ci * k3[0] * k3[1] * k3[2]
@@ -772,8 +785,10 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
             # (pinned: a captured hipGraph writes and reads the old buffer on every replay - MocoStepEngine pins the slabs
             # when it captures; an eager call that needs more space gets a buffer of its own and the graph's stays alive)
         _f32c(x, "x"), _f32c(dy, "dy")
-        job = _WgradJob(x, dy, tgt, slab, (n, d, h, wd, ci, co) + tuple(k3) + (stride,) + tuple(p3))
+        job = _WgradJob(x, dy, tgt, slab, (n, d, h, wd, ci, co) + tuple(k3) + (stride,) + tuple(p3), param)
         if DEFERRED_WGRADS is not None:
+            if SIDE_WGRADS is not None:
+                param._mi_wgrad_pending = True             # (cleared by run_wgrad_jobs)
             _side_or_now(job, dy.numel() // co)
             return
         if _defer_to_backward_end(job):                    # plain autograd: layer1's / layer2's weight gradients, batched at the end
