@@ -620,10 +620,12 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 // 4 k-steps, like an 8 x 8 plane), so the z offset of a tap is a row select like its y offset (no partner plane, nothing skipped); a
 // lane's eight k values are two image rows of four: the x-shifted fragments get a zero at BOTH row edges; a workgroup owns one
 // (dz, dy) pair and one 64 x 64 block of the 128 x 128 channels (36 groups instead of 9).
-template <bool V4>
+// CT = channels of a voxel in memory (64 / 128 / 256): a workgroup owns one 64 x 64 block of the CT x CT channels, 9 (CT / 64)^2 groups.
+// <false, 64> layer1 and <true, 128> layer2 of 32^3 crops; <false, 128> layer2 and <true, 256> layer3 of 64^3 crops.
+template <bool V4, int CT>
 __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WBUF];
-    constexpr int CT = V4 ? 128 : C;                   // channels of a voxel in memory
+    constexpr int NBLK = CT / 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l32 = lane & 31, i16 = lane & 15, g16 = (lane >> 4) & 1;
@@ -631,8 +633,8 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
     const int per_grp = p.nprob * p.splits;
     const int grp = blockIdx.x / per_grp, rem = blockIdx.x % per_grp;
     const int pb = rem / p.splits, split = rem % p.splits, stride = p.splits;
-    const int pair = V4 ? grp % 9 : grp, chb = V4 ? grp / 9 : 0;
-    const int ci0 = (chb >> 1) * 64, co0 = (chb & 1) * 64;             // this workgroup's 64 x 64 channel block
+    const int pair = grp % 9, chb = grp / 9;
+    const int ci0 = (chb / NBLK) * 64, co0 = (chb % NBLK) * 64;        // this workgroup's 64 x 64 channel block
     const int dz = pair / 3, dy = pair % 3;
     const int n_planes = p.N * p.D;                    // V4: D = 1, a "plane" is a sample
 
@@ -1223,7 +1225,7 @@ int mi_direct3_wgrad_launch(const float* x, const float* dy, float* slabs, int N
     Direct3WgradParams p = {};
     p.x[0] = x; p.dy[0] = dy; p.slabs[0] = slabs; p.N = N; p.D = D; p.bytes = (unsigned)(4l * N * D * PLANE * C);
     p.nprob = 1; p.splits = WG_SPLITS;
-    hipLaunchKernelGGL(direct3_wgrad_kernel<false>, dim3(9 * WG_SPLITS), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((direct3_wgrad_kernel<false, 64>), dim3(9 * WG_SPLITS), dim3(512), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -1247,7 +1249,7 @@ int mi_direct3_wgrad_launch_batch(const float* const* xs, const float* const* dy
     for (int i = 0; i < nb; ++i) { p.x[i] = xs[i]; p.dy[i] = dys[i]; p.slabs[i] = slabs[i]; }
     p.N = N; p.D = D; p.bytes = (unsigned)(4l * N * D * PLANE * C);
     p.nprob = nb; p.splits = mi_direct3_wgrad_batch_splits(nb);
-    hipLaunchKernelGGL(direct3_wgrad_kernel<false>, dim3(9 * nb * p.splits), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((direct3_wgrad_kernel<false, 64>), dim3(9 * nb * p.splits), dim3(512), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -1270,7 +1272,28 @@ int mi_direct3s_wgrad_launch_batch(const float* const* xs, const float* const* d
     for (int i = 0; i < nb; ++i) { p.x[i] = xs[i]; p.dy[i] = dys[i]; p.slabs[i] = slabs[i]; }
     p.N = N; p.D = 1; p.bytes = (unsigned)(4l * N * PLANE * CS);
     p.nprob = nb; p.splits = mi_direct3s_wgrad_splits(nb);
-    hipLaunchKernelGGL(direct3_wgrad_kernel<true>, dim3(36 * nb * p.splits), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((direct3_wgrad_kernel<true, 128>), dim3(36 * nb * p.splits), dim3(512), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+// ---- 64^3 crops: layer2 (128 -> 128 on 8 x 8 planes, kind 3) and layer3 (256 -> 256 on 4 x 4 x 4, kind 4), single launches ----
+// kind 3: 36 groups x 7 chains of planes; kind 4: 144 groups x 2 chains of samples.  Slabs of [27][CT][CT] floats.
+int mi_direct3x_wgrad_splits(int kind) { return kind == 3 ? 7 : kind == 4 ? 2 : 0; }
+size_t mi_direct3x_wgrad_slab_bytes(int kind) {
+    const size_t ct = kind == 3 ? 128 : kind == 4 ? 256 : 0;
+    return sizeof(float) * (size_t)mi_direct3x_wgrad_splits(kind) * NTAP * ct * ct;
+}
+int mi_direct3x_wgrad_launch(int kind, const float* x, const float* dy, float* slabs, int N, int D, hipStream_t s) {
+    Direct3WgradParams p = {};
+    p.x[0] = x; p.dy[0] = dy; p.slabs[0] = slabs; p.nprob = 1; p.splits = mi_direct3x_wgrad_splits(kind);
+    if (kind == 3) {
+        p.N = N; p.D = D; p.bytes = (unsigned)(4l * N * D * PLANE * 128);
+        hipLaunchKernelGGL((direct3_wgrad_kernel<false, 128>), dim3(36 * p.splits), dim3(512), 0, s, p);
+    } else if (kind == 4) {
+        p.N = N; p.D = 1; p.bytes = (unsigned)(4l * N * PLANE * 256);
+        hipLaunchKernelGGL((direct3_wgrad_kernel<true, 256>), dim3(144 * p.splits), dim3(512), 0, s, p);
+    } else return MI_E_UNSUPPORTED;
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

@@ -75,6 +75,9 @@ int mi_direct3_wgrad_launch_batch(const float* const* xs, const float* const* dy
 size_t mi_direct3s_wgrad_slab_bytes();
 int mi_direct3s_wgrad_splits(int nb);
 int mi_direct3s_wgrad_launch_batch(const float* const* xs, const float* const* dys, float* const* slabs, int nb, int N, hipStream_t s);
+int mi_direct3x_wgrad_splits(int kind);
+size_t mi_direct3x_wgrad_slab_bytes(int kind);
+int mi_direct3x_wgrad_launch(int kind, const float* x, const float* dy, float* slabs, int N, int D, hipStream_t s);
 int mi_pair_wgrad_batch_max();
 int mi_pair_wgrad_launch_batch(const float* const* xs, const float* const* dys, float* const* dws, float* const* slabs, int nb, int N, int Di,
                                int Ci, int Co, int k, int stride, hipStream_t s);
@@ -1202,6 +1205,7 @@ size_t direct3_ws_bytes(const Geom& g) {
     size_t b = mi_align_up(mi_direct3_wimg_bytes_kind(kind), 256);
     if (kind == 1) b = std::max(b, mi_direct3_wgrad_slab_bytes());
     if (kind == 2) b = std::max(b, mi_direct3s_wgrad_slab_bytes());
+    if (kind == 3 || kind == 4) b = std::max(b, mi_direct3x_wgrad_slab_bytes(kind));
     return b;
 }
 
@@ -1321,6 +1325,17 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         int rc = mi_direct3s_wgrad_launch_batch(xs, dys, sl, 1, g.N, s);
         if (rc) return rc;
         const int splits = mi_direct3s_wgrad_splits(1);
+        if (defer_splits) { *defer_splits = splits; return MI_OK; }
+        return mi_direct3_finish_slabs((const float*)ws, splits, 27l * g.Ci * g.Co, out, nullptr, nullptr, 0, s);
+    }
+    // 64^3 crops: layer2 (kind 3: 71.3 against 100.5 us at batch 32, 41.8 against 57.7 at batch 16; MI_NO_D3X_WGRAD=1: the implicit GEMM)
+    // and - opt-in, MI_D3X_WGRAD_256=1: 59.3 against 60.4 / 38.0 against 35.6 us, no gain - layer3 (kind 4) on the same kernel
+    if (mode == MODE_WGRAD && ((dkind == 3 && !env_int("MI_NO_D3X_WGRAD")) || (dkind == 4 && env_int("MI_D3X_WGRAD_256"))) && ws &&
+        ws_bytes >= mi_direct3x_wgrad_slab_bytes(dkind)) {
+        g_last_conv_kernel = dkind == 3 ? "direct3_wgrad (128 channels) + reduce" : "direct3s_wgrad (256 channels) + reduce";
+        int rc = mi_direct3x_wgrad_launch(dkind, a_src, b_src, (float*)ws, g.N, g.Di, s);
+        if (rc) return rc;
+        const int splits = mi_direct3x_wgrad_splits(dkind);
         if (defer_splits) { *defer_splits = splits; return MI_OK; }
         return mi_direct3_finish_slabs((const float*)ws, splits, 27l * g.Ci * g.Co, out, nullptr, nullptr, 0, s);
     }

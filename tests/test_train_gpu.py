@@ -150,6 +150,7 @@ def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
     ref64 = chain(x.double(), w.double(), res.double(), mask.double(), dy.double())
     cpu32 = chain(x, w, res, mask, dy)                   # the arbiter: the same chain in fp32 on the CPU
     out = {}
+    monkeypatch.setenv("MI_D3X_WGRAD_256", "1")          # (layer3 of 64^3 crops on direct3_wgrad_kernel<true, 256>: opt-in, tested here)
     for tag, off in (("direct", "0"), ("igemm", "1")):
         monkeypatch.setenv("MI_CONV_NO_DIRECT", off)
         yf = H.conv_fwd(cl(x), param, 3, 1, 1, cl(res), True)
@@ -1037,6 +1038,8 @@ def test_conv_dispatch_by_shape(monkeypatch):
     assert wgrad(4, 8, 64, 64) == "direct3_wgrad + reduce"
     assert wgrad(4, 4, 128, 128).startswith("implicit GEMM")       # (direct3_wgrad_kernel<true> is opt-in: slower inside the step)
     assert wgrad(4, 2, 256, 256).startswith("pair_wgrad")
+    assert wgrad(16, 8, 128, 128) == "direct3_wgrad (128 channels) + reduce"     # layer2 of a 64^3 crop (round 5)
+    assert wgrad(16, 4, 256, 256).startswith("implicit GEMM")                     # layer3 of a 64^3 crop: the kernel exists, no gain (opt-in)
     assert wgrad(4, 4, 128, 64).startswith("implicit GEMM")
     monkeypatch.setenv("MI_D3S_WGRAD", "1")
     assert wgrad(4, 4, 128, 128) == "direct3s_wgrad + reduce"
