@@ -605,6 +605,7 @@ struct Direct3WgradParams {
     int N, D;
     unsigned bytes;           // extent of x / dy
     int nprob, splits;        // workgroups per (dz, dy) pair = nprob * splits
+    int H, W;                 // TILED: the plane (multiples of 8); a unit is an 8 x 8 tile of it
 };
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -622,9 +623,17 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 // (dz, dy) pair and one 64 x 64 block of the 128 x 128 channels (36 groups instead of 9).
 // CT = channels of a voxel in memory (64 / 128 / 256): a workgroup owns one 64 x 64 block of the CT x CT channels, 9 (CT / 64)^2 groups.
 // <false, 64> layer1 and <true, 128> layer2 of 32^3 crops; <false, 128> layer2 and <true, 256> layer3 of 64^3 crops.
-template <bool V4, int CT>
+// TILED (round 5, <false, 64, true>: layer1 of 64^3 crops, 16 x 16 planes): the unit is an 8 x 8 TILE of a plane.  The tile of X is
+// staged already shifted by the workgroup's dy (rows of the neighbouring tile, zeros outside the plane), so the fragment rows need no
+// select; the x-shifted fragments take their edge element from ONE halo column per side (X[.][x0 - 1], X[.][x0 + 8]: 8 rows x 64
+// channels x 3 bf16 planes x 2 sides = 6 KB per buffer, staged by all 512 threads - two floats each - and read back as 2-byte LDS reads,
+// six per k-step).
+constexpr int W_HB = 3 * 2 * 8 * 128;       // halo bytes of one staging buffer: [plane][side][row][64 channels] bf16
+template <bool V4, int CT, bool TILED = false>
 __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WBUF];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WBUF + (TILED ? 2 * W_HB : 16)];
+    unsigned char* const halo = lds + 2 * WBUF;
+    static_assert(!TILED || (!V4 && CT == 64), "tiled planes: the 64-channel geometry");
     constexpr int NBLK = CT / 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -636,12 +645,16 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
     const int pair = grp % 9, chb = grp / 9;
     const int ci0 = (chb / NBLK) * 64, co0 = (chb % NBLK) * 64;        // this workgroup's 64 x 64 channel block
     const int dz = pair / 3, dy = pair % 3;
-    const int n_planes = p.N * p.D;                    // V4: D = 1, a "plane" is a sample
+    const int tiles_x = TILED ? p.W >> 3 : 1, tiles = TILED ? (p.H >> 3) * tiles_x : 1;
+    const int n_planes = p.N * p.D * tiles;            // units: V4: D = 1, a "plane" is a sample; TILED: the 8 x 8 tiles of every plane
 
     // ---- staging: a thread's unit = (voxel, 8 channels) of X and the same unit of dY: 64 voxels x 8 channel groups ----
     const __amdgpu_buffer_rsrc_t xrs = rsrc_of(p.x[pb], p.bytes), yrs = rsrc_of(p.dy[pb], p.bytes);
     const int st_vox = tid >> 3, st_cg = tid & 7;
-    const unsigned st_src = 4u * (unsigned)(st_vox * CT + st_cg * 8);
+    const unsigned st_src = TILED ? 4u * (unsigned)(((st_vox >> 3) * p.W + (st_vox & 7)) * C + st_cg * 8)
+                                  : 4u * (unsigned)(st_vox * CT + st_cg * 8);
+    // TILED: this thread's halo unit = (side, row, channel pair)
+    const int h_side = tid >> 8, h_row = (tid >> 5) & 7, h_c2 = tid & 31;
     const unsigned x_ch = 4u * (unsigned)ci0, y_ch = 4u * (unsigned)co0;
     const int zsh = V4 ? 0 : dz - 1;                   // partner plane of X (V4: the sample itself)
     const int st_lds = (st_cg >> 2) * WHALF + st_vox * WROW + (st_cg & 3) * 16;
@@ -650,19 +663,56 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
     auto next_plane = [&](int from) {
         if (V4) return from < n_planes ? from : -1;
         for (int pi = from; pi < n_planes; pi += stride) {
-            const int zi = pi % p.D + dz - 1;
+            const int zi = (pi / tiles) % p.D + dz - 1;
             if ((unsigned)zi < (unsigned)p.D) return pi;
         }
         return -1;
     };
     u32x4 ldx[2], ldy[2];
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 ldh = {0u, 0u};
+    // byte offsets of unit pi's operands: dY tile, X tile (TILED: + this thread's halo element), 0x80000000 = nothing to fetch (zeros)
+    unsigned u_y, u_x, u_h;
+    auto unit_offsets = [&](int pi) {
+        if (pi < 0) { u_y = u_x = u_h = 0x80000000u; return; }
+        if (!TILED) {
+            u_y = 4u * (unsigned)((long)pi * PLANE * CT) + y_ch + st_src;
+            u_x = 4u * (unsigned)((long)(pi + zsh) * PLANE * CT) + x_ch + st_src;
+            u_h = 0x80000000u;
+            return;
+        }
+        const int pl = pi / tiles, t = pi % tiles, y0 = (t / tiles_x) * 8, x0 = (t % tiles_x) * 8;
+        u_y = 4u * (unsigned)((((long)pl * p.H + y0) * p.W + x0) * C) + st_src;
+        const int xr = y0 + (st_vox >> 3) + dy - 1;                       // the row of X this thread stages: shifted by the tap's dy
+        u_x = (unsigned)xr < (unsigned)p.H
+                  ? 4u * (unsigned)((((long)(pl + dz - 1) * p.H + xr) * p.W + x0 + (st_vox & 7)) * C + st_cg * 8) : 0x80000000u;
+        const int hr = y0 + h_row + dy - 1, hc = h_side ? x0 + 8 : x0 - 1;
+        u_h = ((unsigned)hr < (unsigned)p.H && (unsigned)hc < (unsigned)p.W)
+                  ? 4u * (unsigned)((((long)(pl + dz - 1) * p.H + hr) * p.W + hc) * C + 2 * h_c2) : 0x80000000u;
+    };
     auto stage_load = [&](int pi) {                     // pi < 0: nothing to fetch (offsets out of range: zeros)
-        const unsigned ybase = pi >= 0 ? 4u * (unsigned)((long)pi * PLANE * CT) + y_ch : 0x80000000u;
-        const unsigned xbase = pi >= 0 ? 4u * (unsigned)((long)(pi + zsh) * PLANE * CT) + x_ch : 0x80000000u;
-        ldx[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src), 0, 0);
-        ldx[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src + 16u), 0, 0);
-        ldy[0] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(ybase + st_src), 0, 0);
-        ldy[1] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(ybase + st_src + 16u), 0, 0);
+        unit_offsets(pi);
+        ldx[0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)u_x, 0, 0);
+        ldx[1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(u_x + 16u), 0, 0);
+        ldy[0] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)u_y, 0, 0);
+        ldy[1] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(u_y + 16u), 0, 0);
+        if (TILED) ldh = __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)u_h, 0, 0);
+    };
+    // TILED: the halo unit's two floats cut into three bf16 planes, one 4-byte store per plane
+    unsigned hcu[3];
+    auto halo_cut = [&]() {
+        const float a = __uint_as_float(ldh[0]), b = __uint_as_float(ldh[1]);
+        const float a1 = a - __uint_as_float(ldh[0] & 0xffff0000u), b1 = b - __uint_as_float(ldh[1] & 0xffff0000u);
+        const float a2 = a1 - __uint_as_float(__float_as_uint(a1) & 0xffff0000u), b2 = b1 - __uint_as_float(__float_as_uint(b1) & 0xffff0000u);
+        constexpr unsigned HI2 = 0x07060302u;
+        hcu[0] = __builtin_amdgcn_perm(ldh[1], ldh[0], HI2);
+        hcu[1] = __builtin_amdgcn_perm(__float_as_uint(b1), __float_as_uint(a1), HI2);
+        hcu[2] = __builtin_amdgcn_perm(__float_as_uint(b2), __float_as_uint(a2), HI2);
+    };
+    auto halo_store = [&](int buf) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<unsigned*>(halo + buf * W_HB + ((pl * 2 + h_side) * 8 + h_row) * 128 + h_c2 * 4) = hcu[pl];
     };
     auto stage_store_unit = [&](int buf, int op) {          // op 0: X, 1: dY
         float v[8];
@@ -676,6 +726,7 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
         unsigned char* dst = lds + buf * WBUF + op * WOP + st_lds;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * WPL) = o[pl];
+        if (TILED && op == 0) { halo_cut(); halo_store(buf); }
     };
 
     // ---- fragment addresses (transposing read: this lane names row q of its 16-lane group's 4-row block) ----
@@ -697,11 +748,18 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
             if (V4) {      // v = (z, y, x) of a 4 x 4 x 4 volume: the input voxel (z + dz - 1, y + dy - 1, x), x shifted in registers
                 const int zi = (v >> 4) + dz - 1, yi = ((v >> 2) & 3) + dy - 1;
                 a_sel[lk][hi] = wm * WHALF + (((unsigned)zi < 4u && (unsigned)yi < 4u) ? ((zi * 4 + yi) * 4 + (v & 3)) * WROW : WZERO) + coloff;
+            } else if (TILED) {                               // (the tile of X was staged shifted by dy: row v is the partner of output row v)
+                a_sel[lk][hi] = wm * WHALF + v * WROW + coloff;
             } else {
                 const int yi = (v >> 3) + dy - 1;
                 a_sel[lk][hi] = wm * WHALF + ((unsigned)yi < 8u ? (yi * 8 + (v & 7)) * WROW : WZERO) + coloff;
             }
         }
+    // TILED: this lane's halo elements of local k-step lk: image row 2 (2 kh + lk) + h, channel 32 wm + l32
+    int h_off[2];
+#pragma unroll
+    for (int lk = 0; lk < 2; ++lk) h_off[lk] = (2 * (2 * kh + lk) + h) * 128 + (32 * wm + l32) * 2;
+    unsigned hl[2][2][3];             // [set][side][plane]
 
     f32x16 acc[3];
 #pragma unroll
@@ -741,6 +799,11 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
             const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb + pl * WPL + a_sel[lk][0]));
             const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(xb + pl * WPL + a_sel[lk][1]));
             af[SET][1][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            if (TILED) {
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd)
+                    hl[SET][sd][pl] = *reinterpret_cast<const unsigned short*>(halo + buf * W_HB + ((pl * 2 + sd) * 8) * 128 + h_off[lk]);
+            }
         }
     };
     auto read_piece_dyn = [&](int buf, int lk, int j) {
@@ -762,11 +825,13 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
 #pragma unroll
             for (int j = 1; j < 4; ++j) o[j] = __builtin_amdgcn_alignbit(c[j], c[j - 1], 16);
             if (V4) o[2] &= 0xffff0000u;               // element 4 = x 0 of the second row: nothing to its left
+            if (TILED) o[0] |= hl[set][0][pl];         // element 0 <- X[.][x0 - 1]
         } else {
 #pragma unroll
             for (int j = 0; j < 3; ++j) o[j] = __builtin_amdgcn_alignbit(c[j + 1], c[j], 16);
             o[3] = c[3] >> 16;
             if (V4) o[1] &= 0x0000ffffu;               // element 3 = x 3 of the first row: nothing to its right
+            if (TILED) o[3] |= hl[set][1][pl] << 16;   // element 7 <- X[.][x0 + 8]
         }
         af[set][dxv][pl] = __builtin_bit_cast(bf16x8, o);
     };
@@ -800,8 +865,7 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
     constexpr int DXO[3] = {1, 0, 2};                     // MFMA order of the taps: the one that was read, then the derived ones
     while (cur >= 0) {
         const int nn = nxt >= 0 ? next_plane(nxt + stride) : -1;      // the plane after next: fetched during this one
-        const unsigned ybase = nn >= 0 ? 4u * (unsigned)((long)nn * PLANE * CT) + y_ch : 0x80000000u;
-        const unsigned xbase = nn >= 0 ? 4u * (unsigned)((long)(nn + zsh) * PLANE * CT) + x_ch : 0x80000000u;
+        unit_offsets(nn);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int lk = 0; lk < 2; ++lk) {
@@ -819,9 +883,13 @@ __global__ __launch_bounds__(512, 2) void direct3_wgrad_kernel(Direct3WgradParam
                 // the fetch of the plane after next (its staging registers were consumed by the cuts above) ...
                 if (lk == 1 && m >= 14) {
                     const int i = m - 14, hf = i & 1;
-                    if (i < 2) ldx[hf] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xbase + st_src + 16u * hf), 0, 0);
-                    else ldy[hf] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(ybase + st_src + 16u * hf), 0, 0);
+                    if (i < 2) ldx[hf] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(u_x + 16u * hf), 0, 0);
+                    else ldy[hf] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(u_y + 16u * hf), 0, 0);
+                    if (TILED && i == 3) ldh = __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)u_h, 0, 0);
                 }
+                // TILED: the next unit's halo column, behind the X unit's pieces (its registers were fetched with the unit's)
+                if (TILED && lk == 0 && m == 14) halo_cut();
+                if (TILED && lk == 0 && m == 15) halo_store(buf ^ 1);
                 // ... and the fragment reads of the next k-step.  The last k-step of a plane reads the NEXT plane's first
                 // k-step, which is complete once every wave has stored its last unit: the barrier sits behind MFMA 13
                 if (lk == 0) {
@@ -1273,6 +1341,19 @@ int mi_direct3s_wgrad_launch_batch(const float* const* xs, const float* const* d
     p.N = N; p.D = 1; p.bytes = (unsigned)(4l * N * PLANE * CS);
     p.nprob = nb; p.splits = mi_direct3s_wgrad_splits(nb);
     hipLaunchKernelGGL((direct3_wgrad_kernel<true, 128>), dim3(36 * nb * p.splits), dim3(512), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+// ---- 64 channels on planes of 8 x 8 tiles (kind 5 with H, W multiples of 8: layer1 of 64^3 crops): direct3_wgrad_kernel<false, 64, true> ----
+// 28 chains of tiles per (dz, dy) pair like the 8 x 8 form (same slab layout, mi_direct3_wgrad_slab_bytes / _splits)
+int mi_direct3t_wgrad_launch(const float* x, const float* dy, float* slabs, int N, int D, int H, int W, hipStream_t s) {
+    if (H % 8 || W % 8 || H < 8 || W < 8) return MI_E_UNSUPPORTED;
+    Direct3WgradParams p = {};
+    p.x[0] = x; p.dy[0] = dy; p.slabs[0] = slabs; p.N = N; p.D = D; p.H = H; p.W = W;
+    p.bytes = (unsigned)(4l * N * D * H * W * C);
+    p.nprob = 1; p.splits = WG_SPLITS;
+    hipLaunchKernelGGL((direct3_wgrad_kernel<false, 64, true>), dim3(9 * WG_SPLITS), dim3(512), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

@@ -75,6 +75,7 @@ int mi_direct3_wgrad_launch_batch(const float* const* xs, const float* const* dy
 size_t mi_direct3s_wgrad_slab_bytes();
 int mi_direct3s_wgrad_splits(int nb);
 int mi_direct3s_wgrad_launch_batch(const float* const* xs, const float* const* dys, float* const* slabs, int nb, int N, hipStream_t s);
+int mi_direct3t_wgrad_launch(const float* x, const float* dy, float* slabs, int N, int D, int H, int W, hipStream_t s);
 int mi_direct3x_wgrad_splits(int kind);
 size_t mi_direct3x_wgrad_slab_bytes(int kind);
 int mi_direct3x_wgrad_launch(int kind, const float* x, const float* dy, float* slabs, int N, int D, hipStream_t s);
@@ -1203,7 +1204,7 @@ size_t direct3_ws_bytes(const Geom& g) {
     const int kind = direct3_kind(g);
     if (!kind) return 0;
     size_t b = mi_align_up(mi_direct3_wimg_bytes_kind(kind), 256);
-    if (kind == 1) b = std::max(b, mi_direct3_wgrad_slab_bytes());
+    if (kind == 1 || kind == 5) b = std::max(b, mi_direct3_wgrad_slab_bytes());
     if (kind == 2) b = std::max(b, mi_direct3s_wgrad_slab_bytes());
     if (kind == 3 || kind == 4) b = std::max(b, mi_direct3x_wgrad_slab_bytes(kind));
     return b;
@@ -1325,6 +1326,16 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         int rc = mi_direct3s_wgrad_launch_batch(xs, dys, sl, 1, g.N, s);
         if (rc) return rc;
         const int splits = mi_direct3s_wgrad_splits(1);
+        if (defer_splits) { *defer_splits = splits; return MI_OK; }
+        return mi_direct3_finish_slabs((const float*)ws, splits, 27l * g.Ci * g.Co, out, nullptr, nullptr, 0, s);
+    }
+    // 64 channels on planes of whole 8 x 8 tiles (layer1 of 64^3 crops; MI_NO_D3T_WGRAD=1: the implicit GEMM)
+    if (mode == MODE_WGRAD && dkind == 5 && g.Hi % 8 == 0 && g.Wi % 8 == 0 && ws && ws_bytes >= mi_direct3_wgrad_slab_bytes() &&
+        !env_int("MI_NO_D3T_WGRAD")) {
+        g_last_conv_kernel = "direct3_wgrad (8 x 8 tiles) + reduce";
+        int rc = mi_direct3t_wgrad_launch(a_src, b_src, (float*)ws, g.N, g.Di, g.Hi, g.Wi, s);
+        if (rc) return rc;
+        const int splits = mi_direct3_wgrad_splits();
         if (defer_splits) { *defer_splits = splits; return MI_OK; }
         return mi_direct3_finish_slabs((const float*)ws, splits, 27l * g.Ci * g.Co, out, nullptr, nullptr, 0, s);
     }

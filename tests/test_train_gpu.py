@@ -1039,6 +1039,8 @@ def test_conv_dispatch_by_shape(monkeypatch):
     assert wgrad(4, 4, 128, 128).startswith("implicit GEMM")       # (direct3_wgrad_kernel<true> is opt-in: slower inside the step)
     assert wgrad(4, 2, 256, 256).startswith("pair_wgrad")
     assert wgrad(16, 8, 128, 128) == "direct3_wgrad (128 channels) + reduce"     # layer2 of a 64^3 crop (round 5)
+    assert wgrad(8, 16, 64, 64) == "direct3_wgrad (8 x 8 tiles) + reduce"         # layer1 of a 64^3 crop (round 5)
+    assert wgrad(8, 14, 64, 64).startswith("implicit GEMM")                       # (ragged planes: forward / data gradient only)
     assert wgrad(16, 4, 256, 256).startswith("implicit GEMM")                     # layer3 of a 64^3 crop: the kernel exists, no gain (opt-in)
     assert wgrad(4, 4, 128, 64).startswith("implicit GEMM")
     monkeypatch.setenv("MI_D3S_WGRAD", "1")
