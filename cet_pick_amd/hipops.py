@@ -648,10 +648,12 @@ SIDE_ROWS_MAX = int(os.environ.get("CETPICK_SIDE_ROWS", "32768"))
 
 
 def _side_or_now(fn, rows):
+    """True: queued for the side stream (MocoStepEngine issues it at the stage boundary); False: launched now."""
     if SIDE_WGRADS is not None and rows <= SIDE_ROWS_MAX and PROFILE is None:
         SIDE_WGRADS.append(fn)
-    else:
-        fn()
+        return True
+    fn()
+    return False
 
 
 class _WgradJob:
@@ -787,9 +789,8 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
         _f32c(x, "x"), _f32c(dy, "dy")
         job = _WgradJob(x, dy, tgt, slab, (n, d, h, wd, ci, co) + tuple(k3) + (stride,) + tuple(p3), param)
         if DEFERRED_WGRADS is not None:
-            if SIDE_WGRADS is not None:
-                param._mi_wgrad_pending = True             # (cleared by run_wgrad_jobs)
-            _side_or_now(job, dy.numel() // co)
+            if _side_or_now(job, dy.numel() // co):
+                param._mi_wgrad_pending = True             # queued: cleared by run_wgrad_jobs (a second contribution before that raises)
             return
         if _defer_to_backward_end(job):                    # plain autograd: layer1's / layer2's weight gradients, batched at the end
             return
