@@ -117,8 +117,18 @@ __global__ __launch_bounds__(256) void colreduce_finalize_kernel(const double* p
                                                                 int C, double* sums, float* sums_f32, int n_f32) {
     const int c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
     double s = 0;
-    if (c < 2 * C)
-        for (int b = l; b < n_part; b += 32) s += partials[(long)b * 2 * C + c];
+    if (c < 2 * C) {
+        // eight loads in flight, added in the rolled loop's order (same sums; rolled, each load waited for the one before it)
+        int b = l;
+        for (; b + 7 * 32 < n_part; b += 8 * 32) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partials[(long)(b + 32 * u) * 2 * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < n_part; b += 32) s += partials[(long)b * 2 * C + c];
+    }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
     if (l == 0 && c < 2 * C) {
@@ -130,7 +140,9 @@ __global__ __launch_bounds__(256) void colreduce_finalize_kernel(const double* p
 int colreduce_blocks(long M, int C) {
     int RS = 256 / (C / 4);
     long b = (M + (long)RS * 8 - 1) / ((long)RS * 8);
-    return (int)std::max<long>(1, std::min<long>(b, 512));
+    long cap = 512;
+    if (const char* v = getenv("MI_COLREDUCE_BLOCKS")) { const long cv = atol(v); if (cv >= 1 && cv <= 4096) cap = cv; }      // tuning
+    return (int)std::max<long>(1, std::min<long>(b, cap));
 }
 bool colreduce_ok(int C) { return C >= 4 && (C % 4) == 0 && (C / 4) <= 256 && (256 % (C / 4)) == 0; }
 
