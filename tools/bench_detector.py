@@ -22,13 +22,17 @@ def timeit(fn, n=5, warm=2):
     return (time.perf_counter() - t0) / n
 
 
-def run(small=False):
+def run(small=False, only_semi=False):
     from cet_pick_amd.utils import loader
     from cet_pick_amd.models.model import create_model
     from cet_pick_amd.models.loss import UnbiasedConLoss
     from cet_pick_amd.synthetic import seeded_state_dict
     from cet_pick_amd import hipops as H
     out = {}
+    heads = {"hm": 1, "proj": 32}
+    g = torch.Generator().manual_seed(0)
+    if only_semi:                     # (rocprofv3 of the C5 step alone: profiles/rNN_c5_kernel_stats.csv)
+        return _semi_step(out, small, heads, g, create_model, seeded_state_dict)
     # a12: load_rec (xzy order, compress) + preprocess of a 256 x 512 x 512 tomogram already on the host
     shape = (64, 128, 128) if small else (512, 256, 512)          # file order (x, z, y): 256 slices of 512 x 512
     rec = np.random.default_rng(0).standard_normal(shape).astype(np.float32)
@@ -59,7 +63,7 @@ def run(small=False):
                             "conv_gflop": cflops / 1e9, "conv_ms": cms, "conv_tflops": cflops / cms / 1e9,
                             "peak_mem_gb": (torch.cuda.max_memory_allocated() - mem_base) / 2 ** 30,
                             # the convolutions run in the bf16x3 arithmetic: ceiling 2500 / 6 TFLOP/s of f32-equivalent work
-                            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (every conv of one forward)",
+                            "roofline": {"bound": "mfma", "kernel": "every convolution launch of one forward (conv_d32 / conv_igemm / conv_smallk / stem2d)",
                                          "achieved": cflops / cms / 1e9, "peak": 2500.0 / 6, "unit": "TFLOP/s",
                                          "frac": cflops / cms / 1e9 / (2500.0 / 6), "traffic": None,
                                          "whole_forward_tflops": cflops / t / 1e12}}
@@ -85,6 +89,10 @@ def run(small=False):
     flops = 2.0 * (2 * n) ** 2 * dim * (1 + 4)             # S tiles: 1 forward pass + 2 x (S + W.F) backward passes
     out["unbiased_con_loss_fwd_bwd"] = {"N": n, "dim": dim, "ms": t * 1e3, "dense_matrix_bytes_avoided": 4 * (2 * n) ** 2,
                                         "mfma_tflops": flops / t / 1e12}
+    return _semi_step(out, small, heads, g, create_model, seeded_state_dict)
+
+
+def _semi_step(out, small, heads, g, create_model, seeded_state_dict):
     # C5: one semi-supervised training step, 16 pairs of 6 x 64 x 64 crops
     from cet_pick_amd.trains.train_factory import train_factory
     topt = SimpleNamespace(task="semi", arch="unet_4", pn=False, ge=False, tau=0.1, temp=0.07, thresh=0.5, cr_weight=0.1,
@@ -122,4 +130,4 @@ def run(small=False):
 
 
 if __name__ == "__main__":
-    print(json.dumps(run(small="--small" in sys.argv)))
+    print(json.dumps(run(small="--small" in sys.argv, only_semi="--only-semi" in sys.argv)))

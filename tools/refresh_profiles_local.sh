@@ -2,10 +2,11 @@
 # Summaries of tools/refresh_profiles.sh's raw output -> profiles/<tag>_* (stamped with the kernel-source hashes).
 set -e
 cd "$(dirname "$0")/.."
-T=${1:-r04}
+T=${1:-r05}
 O=gpurun_out/$T"_final"
 cp $O/train/out_kernel_stats.csv profiles/${T}_train_kernel_stats.csv
 cp $O/infer/out_kernel_stats.csv profiles/${T}_infer_kernel_stats.csv
+if [ -s $O/c5/out_kernel_stats.csv ]; then cp $O/c5/out_kernel_stats.csv profiles/${T}_c5_kernel_stats.csv; fi
 python tools/pmc_summary.py $O/pmc_infer profiles/${T}_infer_traffic.json --sources infer_,common --per-step 5 \
   --note "tools/prof_infer.py both 3 (2 synchronized calls + 3 back to back of each chain): 5 fused decodes (logits 128x256x256, K=900) + 5 DoG picks (256x512x512, sigma 3/5); per-launch averages" > /dev/null
 mkdir -p $O/pmc_traffic $O/pmc_busy

@@ -4,6 +4,6 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${1:-timeline}
 mkdir -p $O
-( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace -d $O -o out --output-format csv -- python3 $R/bench.py --no-conv-profile --no-secondary --no-cpu-baseline --steps 12 --warmup 5 > $O/run.log 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace -d $O -o out --output-format csv -- python3 $R/bench.py --no-conv-profile --no-secondary --no-cpu-baseline --no-entry-point --steps 12 --warmup 5 > $O/run.log 2>&1 )
 python3 $R/tools/trace_timeline.py $O/out_kernel_trace.csv 2 > $O/timeline.txt
 tail -3 $O/timeline.txt
