@@ -121,6 +121,7 @@ SIGNATURES = {
     "mi_avgpool_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "mi_avgpool_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "mi_bias_add": (_I, [_P, _P, _L, _I, _P]),
+    "mi_copy_pair_f32": (_I, [_P, _P, _P, _P, _L, _P]),
     "mi_relu_mask": (_I, [_P, _P, _P, _P, _L, _P]),
     "mi_l2norm_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "mi_l2norm_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),

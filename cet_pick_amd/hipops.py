@@ -1894,6 +1894,19 @@ def sgd_step_(p_flat, g_flat, lr, weight_decay=0.0, lr_dev=None, grad_scale=1.0)
                                 float(grad_scale), p_flat.numel(), L.stream()), "mi_sgd_step")
 
 
+def copy_pair_(dst0, src0, dst1, src1):
+    """dst0.copy_(src0); dst1.copy_(src1) - as ONE launch when the four are contiguous f32 device tensors of one size."""
+    ts = (dst0, src0, dst1, src1)
+    if (all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts) and src0.shape == dst0.shape
+            and src1.shape == dst1.shape and dst0.numel() == dst1.numel() and dst0.numel() % 4 == 0
+            and all(t.data_ptr() % 16 == 0 for t in ts)):
+        L.check(L.lib().mi_copy_pair_f32(L.ptr(dst0), L.ptr(src0), L.ptr(dst1), L.ptr(src1), dst0.numel(), L.stream()),
+                "mi_copy_pair_f32")
+        return
+    dst0.copy_(src0)
+    dst1.copy_(src1)
+
+
 def queue_enqueue_(queue, queue_ptr, keys):
     c, r = queue.shape
     b = keys.shape[0]

@@ -330,8 +330,11 @@ class MocoStepEngine:
                 raise ValueError("data-parallel graph step: batch %s differs from the captured %s (use drop_last)"
                                  % (tuple(im_q.shape), tuple(self._static_q.shape)))
             return self._step_eager(im_q, im_k)
-        self._static_q.copy_(im_q)
-        self._static_k.copy_(im_k)
+        if os.environ.get("CETPICK_COPY_PAIR", "1") != "0":
+            H.copy_pair_(self._static_q, im_q, self._static_k, im_k)      # (one launch for both views)
+        else:
+            self._static_q.copy_(im_q)
+            self._static_k.copy_(im_k)
         H._bump_weight_epoch()                          # the replayed SGD / momentum kernels write the arenas (no Python runs)
         self._graph.replay()
         return self.loss

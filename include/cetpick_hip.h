@@ -470,6 +470,9 @@ int mi_maxpool3d_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, i
 int mi_avgpool_fwd(const float* x, float* y, int B, int S, int C, mi_stream_t stream);
 int mi_avgpool_bwd(const float* dy, float* dx, int B, int S, int C, mi_stream_t stream);
 int mi_bias_add(float* y, const float* bias, long M, int C, mi_stream_t stream);
+/* dst0 <- src0 and dst1 <- src1 (n floats each, n % 4 == 0, 16-byte aligned) in one launch: the two views of a batch
+ * (trains/base_trainer.py:486-491: batch['input'], batch['input_aug']) into the step engine's static input buffers. */
+int mi_copy_pair_f32(float* dst0, const float* src0, float* dst1, const float* src1, long n, mi_stream_t stream);
 /* out = (dy + add) * (y > 0)   (ReLU backward; add may be NULL; n % 4 == 0) */
 int mi_relu_mask(const float* dy, const float* y, const float* add, float* out, long n,
                  mi_stream_t stream);
