@@ -380,7 +380,18 @@ __global__ __launch_bounds__(256) void cand_index_kernel(const uint2* cands, con
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         double a = 0, s = 0, ss = 0;
-        for (int i = tid; i < n_part; i += 256) { a += partials[3 * i]; s += partials[3 * i + 1]; ss += partials[3 * i + 2]; }
+        // four partial rows in flight, added in the rolled loop's order (same sums)
+        int i = tid;
+        for (; i + 3 * 256 < n_part; i += 4 * 256) {
+            double v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) v[u][q] = partials[3 * (i + 256 * u) + q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a += v[u][0]; s += v[u][1]; ss += v[u][2]; }
+        }
+        for (; i < n_part; i += 256) { a += partials[3 * i]; s += partials[3 * i + 1]; ss += partials[3 * i + 2]; }
         s_red[tid] = a; s_red[256 + tid] = s; s_red[512 + tid] = ss;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
@@ -436,7 +447,7 @@ __global__ __launch_bounds__(256) void cand_index_kernel(const uint2* cands, con
         seg_range[sg0 + tid] = (st + ct <= cap) ? make_uint2(st, ct) : make_uint2(0u, 0u);
     }
     // pass 2: place, in order (the second read comes from L2)
-    const long hw = (long)H * W;
+    const unsigned hw = (unsigned)H * (unsigned)W;         // (flat indices are 32-bit here: 32-bit divisions, a 64-bit one is ~150 instructions)
     for (unsigned sg = sg0 + wv; sg < sg_end; sg += 4) {
         const unsigned cnt = min(seg_count[sg], seg_cap);
         const uint2* base = cands + (size_t)sg * seg_cap;
@@ -463,8 +474,8 @@ __global__ __launch_bounds__(256) void cand_index_kernel(const uint2* cands, con
                 const unsigned long long km = __ballot(keep);
                 if (!km) continue;
                 const unsigned long long below = km & ((1ull << lane) - 1ull);
-                const long rem = (long)c[u].y % hw;
-                const int yy = (int)(rem / W);
+                const unsigned zq = c[u].y / hw, rem = c[u].y - zq * hw;
+                const int yy = (int)(rem / (unsigned)W);
                 int rb = keep ? min(max((yy - ya) >> 3, 0), nb - 1) : 0;
                 // the row block of the previous survivor: the nearest kept lane below, or the last one of the step before
                 const int prev_lane = below ? 63 - __builtin_clzll(below) : 0;
@@ -473,8 +484,8 @@ __global__ __launch_bounds__(256) void cand_index_kernel(const uint2* cands, con
                 if (keep) {
                     const unsigned slot = pos + (unsigned)__popcll(below);
                     G[slot] = ((unsigned long long)order_bits(__uint_as_float(c[u].x)) << 32) | (unsigned long long)c[u].y;
-                    coord[slot] = ((unsigned)yy << 16) | (unsigned)(rem % W);
-                    coordz[slot] = (unsigned)((long)c[u].y / hw);
+                    coord[slot] = ((unsigned)yy << 16) | (rem - (unsigned)yy * (unsigned)W);
+                    coordz[slot] = zq;
                     for (int r = rb_prev + 1; r <= rb; ++r) sb[r] = slot;       // blocks that start at this entry
                 }
                 rb_last = __shfl(rb, 63 - __builtin_clzll(km), 64);
