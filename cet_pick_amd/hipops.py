@@ -649,7 +649,9 @@ SIDE_ROWS_MAX = int(os.environ.get("CETPICK_SIDE_ROWS", "32768"))
 
 def _side_or_now(fn, rows):
     """True: queued for the side stream (MocoStepEngine issues it at the stage boundary); False: launched now."""
-    if SIDE_WGRADS is not None and rows <= SIDE_ROWS_MAX and PROFILE is None:
+    # (bench.py's roofline pass - PROFILE - times every call by itself: closures run where they are; convolution jobs are still
+    # collected, so that the pass times the launches the step really makes - run_wgrad_jobs times a group as one call)
+    if SIDE_WGRADS is not None and rows <= SIDE_ROWS_MAX and (PROFILE is None or isinstance(fn, _WgradJob)):
         SIDE_WGRADS.append(fn)
         return True
     fn()
@@ -659,10 +661,10 @@ def _side_or_now(fn, rows):
 class _WgradJob:
     """One deferred convolution weight gradient (slab form): callable like the closures next to it in SIDE_WGRADS; jobs of one
     geometry that are issued together go out as ONE launch (run_wgrad_jobs -> mi_convnd_wgrad_slabs_batch_f32)."""
-    __slots__ = ("x", "dy", "tgt", "slab", "geom", "param")
+    __slots__ = ("x", "dy", "tgt", "slab", "geom", "param", "flops")
 
-    def __init__(self, x, dy, tgt, slab, geom, param=None):
-        self.x, self.dy, self.tgt, self.slab, self.geom, self.param = x, dy, tgt, slab, geom, param
+    def __init__(self, x, dy, tgt, slab, geom, param=None, flops=0.0):
+        self.x, self.dy, self.tgt, self.slab, self.geom, self.param, self.flops = x, dy, tgt, slab, geom, param, flops
 
     def __call__(self):
         import ctypes
@@ -731,6 +733,9 @@ def run_wgrad_jobs(items):
         else:
             order.append(it)
     lib = L.lib()
+    if PROFILE is not None:
+        _run_wgrad_jobs_profiled(order)
+        return
     for it in order:
         if not isinstance(it, list):
             it()
@@ -758,6 +763,49 @@ def run_wgrad_jobs(items):
                 L.check(rc, "mi_convnd_wgrad_slabs_batch_f32")
 
 
+def _run_wgrad_jobs_profiled(order):
+    """bench.py's roofline pass: a group's launch + the reduce of its slabs is ONE timed call (what the step launches), with the
+    group's algorithmic FLOPs; the slabs are reduced here instead of in the stage's deferred reduce."""
+    import ctypes
+    global DEFERRED_WGRADS
+    lib = L.lib()
+    for it in order:
+        if not isinstance(it, list):
+            if isinstance(it, _WgradJob):
+                it = [it]
+            else:
+                it()
+                continue
+        for i0 in range(0, len(it), WGRAD_BATCH_MAX):
+            jobs = it[i0:i0 + WGRAD_BATCH_MAX]
+
+            def call(jobs=jobs):
+                global DEFERRED_WGRADS
+                saved, DEFERRED_WGRADS = DEFERRED_WGRADS, []
+                try:
+                    rc = -3
+                    if len(jobs) > 1:
+                        n = len(jobs)
+                        arr = lambda vals: ctypes.cast((ctypes.c_void_p * n)(*vals), ctypes.c_void_p)
+                        keep = [arr([j.x.data_ptr() for j in jobs]), arr([j.dy.data_ptr() for j in jobs]),
+                                arr([j.tgt.data_ptr() for j in jobs]), arr([j.slab.data_ptr() for j in jobs])]
+                        splits = ctypes.c_int(0)
+                        rc = lib.mi_convnd_wgrad_slabs_batch_f32(*keep, n, *jobs[0].geom, jobs[0].slab.numel(), ctypes.addressof(splits),
+                                                                 L.stream())
+                        if rc == 0 and splits.value > 1:
+                            for j in jobs:
+                                DEFERRED_WGRADS.append((j.slab, j.tgt, int(splits.value), j.tgt.numel()))
+                    if rc == -3:
+                        for j in jobs:
+                            j()
+                    else:
+                        L.check(rc, "mi_convnd_wgrad_slabs_batch_f32")
+                    flush_wgrad_reduces()
+                finally:
+                    DEFERRED_WGRADS = saved
+            _prof_run("wgrad", sum(j.flops for j in jobs), call)
+
+
 def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
     """dW for `param`, written (or accumulated) into param.grad."""
     nd5 = x.dim() == 5
@@ -775,7 +823,10 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
     g, acc = _grad_target(param)
     tgt = torch.empty_like(g) if acc else g
     flops = 2.0 * dy.numel() * ci * k3[0] * k3[1] * k3[2]
-    slab_form = not acc and PROFILE is None and (dil is None or tuple(_k3(dil, nd5)) == (1, 1, 1)) and x.is_cuda
+    # (under bench.py's roofline pass only the jobs the engine will queue take the job form - run_wgrad_jobs times them group by group -,
+    # everything else is timed right here, call by call)
+    slab_form = (not acc and (dil is None or tuple(_k3(dil, nd5)) == (1, 1, 1)) and x.is_cuda and
+                 (PROFILE is None or (DEFERRED_WGRADS is not None and SIDE_WGRADS is not None and dy.numel() // co <= SIDE_ROWS_MAX)))
     if slab_form and (DEFERRED_WGRADS is not None or (WGRAD_BATCH and lib.mi_conv3d_direct_usable(n, d, h, wd, ci, co, k3[0], stride, p3[0]) in (1, 2)
                                                       and k3[0] == k3[1] == k3[2] and p3[0] == p3[1] == p3[2])):
         nbytes = lib.mi_convnd_workspace_bytes(n, d, h, wd, ci, co, *k3, stride, *p3)
@@ -787,7 +838,7 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
             # (pinned: a captured hipGraph writes and reads the old buffer on every replay - MocoStepEngine pins the slabs
             # when it captures; an eager call that needs more space gets a buffer of its own and the graph's stays alive)
         _f32c(x, "x"), _f32c(dy, "dy")
-        job = _WgradJob(x, dy, tgt, slab, (n, d, h, wd, ci, co) + tuple(k3) + (stride,) + tuple(p3), param)
+        job = _WgradJob(x, dy, tgt, slab, (n, d, h, wd, ci, co) + tuple(k3) + (stride,) + tuple(p3), param, flops)
         if DEFERRED_WGRADS is not None:
             if _side_or_now(job, dy.numel() // co):
                 param._mi_wgrad_pending = True             # queued: cleared by run_wgrad_jobs (a second contribution before that raises)
