@@ -25,10 +25,10 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DCO = 32;                     // output channels
+constexpr int DCO = 32;                     // output channels of the 32-column form (CO = 64: two column halves per wave)
 constexpr int DW_BLK = 1024;                // one B fragment plane: 64 lanes x 16 bytes
-constexpr int DW_STEP = 3 * DW_BLK;         // bytes per k-step of the weight image
-constexpr int DRB = 6;                      // weight k-steps in flight
+constexpr int DW_STEP = 3 * DW_BLK;         // bytes per k-step and 32-column half of the weight image
+constexpr int DRB = 6;                      // weight k-steps in flight (32 columns; 64 columns: 3 - the ring is 2 x 3 fragments per k-step)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t d_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
@@ -61,13 +61,18 @@ struct D32Params {
     unsigned x_bytes, out_bytes, w_bytes;
 };
 
-// CIN: 32 or 64 input channels.  NZT: 1 (2-D layers: D planes are independent images) or 3 z taps.  DIL: xy dilation (1 or 4).
+// CIN: 16, 32 or 64 input channels.  NZT: 1 (2-D layers: D planes are independent images) or 3 z taps.  DIL: xy dilation (1 or 4).
 // Tile of a workgroup (4 waves), in voxels of ONE dilation class: TX x TY x TZ = 16 x 16 x 1 (two 4 x 8 row blocks per wave) for
 // NZT = 1, 8 x 8 x 2 (one row block per wave) for NZT = 3.
-template <int CIN, int NZT, int DIL>
+// Round 5, CO = 64 (the 128 x 128 level of the U-Net: 32 / 64 / 128 -> 64, 2-D): every A fragment feeds TWO column halves (12 MFMAs per
+// row block and k-step); TYT = 8 halves the tile (16 x 8, one row block per wave) where the patch of 128 input channels would not fit.
+template <int CIN, int NZT, int DIL, int CO = 32, int TYT = 16>
 struct D32Cfg {
-    static constexpr int TX = NZT == 1 ? 16 : 8, TY = NZT == 1 ? 16 : 8, TZ = NZT == 1 ? 1 : 2;
-    static constexpr int BPW = NZT == 1 ? 2 : 1;              // row blocks (4 y x 8 x) per wave
+    static constexpr int TX = NZT == 1 ? 16 : 8, TY = NZT == 1 ? TYT : 8, TZ = NZT == 1 ? 1 : 2;
+    static constexpr int BPW = NZT == 1 ? TYT / 8 : 1;        // row blocks (4 y x 8 x) per wave
+    static constexpr int NCH = CO / 32;                        // 32-column halves
+    static constexpr int RB = CO == 32 ? DRB : 3;              // weight k-steps in flight
+    static constexpr int WSTEP = NCH * DW_STEP;                // bytes per k-step of the weight image: [column half][plane][lane] x 16
     static constexpr int PX = TX + 2, PY = TY + 2, PZ = TZ + NZT - 1;
     static constexpr int NV = PX * PY * PZ;                    // patch voxels: 324 / 400
     static constexpr int ARR = NV * 16;                        // one (chunk, plane, k-half) array
@@ -79,9 +84,9 @@ struct D32Cfg {
     static constexpr int UNITS = (NV * KS * 2 + 255) / 256;    // staging units (voxel, chunk, k-half) per thread
 };
 
-template <int CIN, int NZT, int DIL>
-__global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL>::LDS <= 80 * 1024) ? 2 : 1) void conv_d32_kernel(D32Params p) {
-    typedef D32Cfg<CIN, NZT, DIL> G;
+template <int CIN, int NZT, int DIL, int CO = 32, int TYT = 16>
+__global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1024) ? 2 : 1) void conv_d32_kernel(D32Params p) {
+    typedef D32Cfg<CIN, NZT, DIL, CO, TYT> G;
     __shared__ __attribute__((aligned(16))) unsigned char patch[G::LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l32 = lane & 31;
@@ -97,16 +102,18 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL>::LDS <= 80 * 1024) ? 2 
     const int x0 = tx * G::TX, y0 = ty * G::TY, z0 = tz * G::TZ; // tile origin in class coordinates (x, y) / planes (z)
 
     const __amdgpu_buffer_rsrc_t wrs = d_rsrc(p.wimg, p.w_bytes);
-    bf16x8 bfr[DRB][3];
+    bf16x8 bfr[G::RB][G::NCH][3];
     auto wload = [&](int g, auto SLOTc) {
-        constexpr int SLOT = decltype(SLOTc)::value;
+        constexpr int SLOT = decltype(SLOTc)::value % G::RB;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-            bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                wrs, g < G::NSTEP ? lane * 16 + pl * DW_BLK : (int)0x80000000u, g < G::NSTEP ? g * DW_STEP : 0, 0));
+        for (int ch = 0; ch < G::NCH; ++ch)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bfr[SLOT][ch][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                    wrs, g < G::NSTEP ? lane * 16 + (ch * 3 + pl) * DW_BLK : (int)0x80000000u, g < G::NSTEP ? g * G::WSTEP : 0, 0));
     };
     auto wload_dyn = [&](int g) {
-        switch (g % DRB) {
+        switch (g % G::RB) {
             case 0: wload(g, std::integral_constant<int, 0>{}); break;
             case 1: wload(g, std::integral_constant<int, 1>{}); break;
             case 2: wload(g, std::integral_constant<int, 2>{}); break;
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL>::LDS <= 80 * 1024) ? 2 
         }
     };
 #pragma unroll
-    for (int g = 0; g < DRB - 1; ++g) wload_dyn(g);
+    for (int g = 0; g < G::RB - 1; ++g) wload_dyn(g);
 
     // ---- the patch, every chunk at once: unit q = (voxel, chunk, k-half); voxels outside the volume read zeros (the padding) ----
     {
@@ -158,11 +165,13 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL>::LDS <= 80 * 1024) ? 2 
         else { bz_[i] = b >> 1; by_[i] = 4 * (b & 1); bx_[i] = 0; }
         vbase[i] = ((bz_[i] * G::PY + by_[i] + (l32 >> 3)) * G::PX + bx_[i] + (l32 & 7)) * 16 + h * G::ARR;
     }
-    f32x16 acc[G::BPW];
+    f32x16 acc[G::BPW][G::NCH];
 #pragma unroll
     for (int i = 0; i < G::BPW; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int ch = 0; ch < G::NCH; ++ch)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][ch][r] = 0.f;
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
     __syncthreads();
 
@@ -188,13 +197,15 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL>::LDS <= 80 * 1024) ? 2 
 #pragma unroll
         for (int tap = 0; tap < G::NTAP; ++tap) {
             const int g = c * G::NTAP + tap;
-            wload_dyn(g + DRB - 1);
+            wload_dyn(g + G::RB - 1);
             if (g + 1 < G::NSTEP) frags_dyn(g + 1, (g + 1) / G::NTAP, (g + 1) % G::NTAP);
 #pragma unroll
             for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
                 for (int i = 0; i < G::BPW; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][i][PA[pr]], bfr[g % DRB][PB[pr]], acc[i], 0, 0, 0);
+#pragma unroll
+                    for (int ch = 0; ch < G::NCH; ++ch)
+                        acc[i][ch] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][i][PA[pr]], bfr[g % G::RB][ch][PB[pr]], acc[i][ch], 0, 0, 0);
             // issue order inside the k-step: every load behind an MFMA
 #pragma unroll
             for (int k = 0; k < 3 * G::BPW; ++k) {
@@ -202,43 +213,48 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL>::LDS <= 80 * 1024) ? 2 
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < 3 * G::NCH; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
-            if constexpr (G::BPW == 2) __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            constexpr int REST = 6 * G::BPW * G::NCH - 3 * G::BPW - 3 * G::NCH;
+            if constexpr (REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, REST, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     // ---- epilogue: C/D layout col = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 h = (y & 3, x) of the row block ----
-    const float bv = p.bias ? p.bias[l32] : 0.f;
     const __amdgpu_buffer_rsrc_t ors = d_rsrc(p.out, p.out_bytes);
 #pragma unroll
-    for (int i = 0; i < G::BPW; ++i)
+    for (int ch = 0; ch < G::NCH; ++ch) {
+        const float bv = p.bias ? p.bias[ch * 32 + l32] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int y = (y0 + by_[i] + (m >> 3)) * DIL + cy, x = (x0 + bx_[i] + (m & 7)) * DIL + cx, z = z0 + bz_[i];
-            float v = acc[i][r] + bv;
-            if (p.relu) v = fmaxf(v, 0.f);
-            const unsigned off = 4u * (unsigned)(((((long)n * p.D + z) * p.H + y) * p.W + x) * DCO + l32);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, (int)off, 0, 0);
-        }
+        for (int i = 0; i < G::BPW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int y = (y0 + by_[i] + (m >> 3)) * DIL + cy, x = (x0 + bx_[i] + (m & 7)) * DIL + cx, z = z0 + bz_[i];
+                float v = acc[i][ch][r] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                const unsigned off = 4u * (unsigned)(((((long)n * p.D + z) * p.H + y) * p.W + x) * CO + ch * 32 + l32);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, (int)off, 0, 0);
+            }
+    }
 }
 
 // weight image: W[tap][ci][co = 32] f32 -> bf16x3 B fragments [chunk][tap][plane][lane] x 16 bytes; idx = (chunk, tap, lane)
-__global__ __launch_bounds__(256) void conv_d32_prep_kernel(const float* w, unsigned char* img, int cin, int ntap) {
+// (co = 64: [chunk][tap][column half][plane][lane]; idx = (chunk, tap, column half, lane))
+__global__ __launch_bounds__(256) void conv_d32_prep_kernel(const float* w, unsigned char* img, int cin, int ntap, int co) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int ks = cin / 16;
-    if (idx >= ks * ntap * 64) return;
-    const int lane = idx & 63, tap = (idx >> 6) % ntap, c = (idx >> 6) / ntap;
-    const int nn = lane & 31, k0 = c * 16 + 8 * (lane >> 5);
+    const int ks = cin / 16, nch = co / 32;
+    if (idx >= ks * ntap * nch * 64) return;
+    const int lane = idx & 63, ch = (idx >> 6) % nch, tap = ((idx >> 6) / nch) % ntap, c = (idx >> 6) / (nch * ntap);
+    const int nn = ch * 32 + (lane & 31), k0 = c * 16 + 8 * (lane >> 5);
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = w[((long)tap * cin + k0 + e) * DCO + nn];
+    for (int e = 0; e < 8; ++e) v[e] = w[((long)tap * cin + k0 + e) * co + nn];
     u32x4 o[3];
     d_cut8(v, o);
-    unsigned char* dst = img + (size_t)(c * ntap + tap) * DW_STEP + lane * 16;
+    unsigned char* dst = img + (size_t)((c * ntap + tap) * nch + ch) * DW_STEP + lane * 16;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * DW_BLK) = o[pl];
 }
@@ -248,9 +264,13 @@ __global__ __launch_bounds__(256) void conv_d32_prep_kernel(const float* w, unsi
 // 1: 2-D 3 x 3 (kd = 1, any D: independent planes), dilation 1; 2: 3 x 3 x 3 with dilation (1, 4, 4); 0: not a shape of this kernel
 extern "C" int mi_conv_d32_kind(int N, int D, int H, int W, int Ci, int Co, int kd, int kh, int kw, int dd, int dh, int dw) {
     if (getenv("MI_NO_D32")) return 0;
+    // 3 (round 5): 2-D 3 x 3 to 64 output channels from 32 / 64 / 128 (the 128 x 128 level); MI_NO_D64=1: the implicit GEMM
+    if (Co == 64 && N >= 1 && kd == 1 && kh == 3 && kw == 3 && dd == 1 && dh == 1 && dw == 1 && (Ci == 32 || Ci == 64 || Ci == 128) &&
+        H % 16 == 0 && W % 16 == 0 && 4l * N * D * H * W * (Ci > 64 ? Ci : 64) < 0x7fff0000l && !getenv("MI_NO_D64"))
+        return 3;
     if (Co != DCO || N < 1 || kh != 3 || kw != 3 || dd != 1) return 0;
     if (4l * N * D * H * W * (Ci > DCO ? Ci : DCO) >= 0x7fff0000l) return 0;
-    if (kd == 1 && dh == 1 && dw == 1 && (Ci == 32 || Ci == 64) && H % 16 == 0 && W % 16 == 0) return 1;
+    if (kd == 1 && dh == 1 && dw == 1 && (Ci == 16 || Ci == 32 || Ci == 64) && H % 16 == 0 && W % 16 == 0) return 1;
     if (kd == 3 && dh == 4 && dw == 4 && Ci == 32 && H % 32 == 0 && W % 32 == 0 && D % 2 == 0) return 2;
     return 0;
 }
@@ -258,9 +278,18 @@ extern "C" size_t mi_conv_d32_image_bytes(int Ci, int ntap) { return (size_t)(Ci
 
 // w: [tap][Ci][32] f32 (kernel layout); img: mi_conv_d32_image_bytes(Ci, ntap) bytes
 extern "C" int mi_conv_d32_prep(const float* w, void* img, int Ci, int ntap, mi_stream_t stream) {
-    if (!w || !img || (Ci != 32 && Ci != 64) || (ntap != 9 && ntap != 27)) return MI_E_ARG;
+    if (!w || !img || (Ci != 16 && Ci != 32 && Ci != 64) || (ntap != 9 && ntap != 27)) return MI_E_ARG;
     const int n = (Ci / 16) * ntap * 64;
-    hipLaunchKernelGGL(conv_d32_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)img, Ci, ntap);
+    hipLaunchKernelGGL(conv_d32_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)img, Ci, ntap, DCO);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+// the 64-output-channel form (kind 3): image of [chunk][tap][column half][plane][lane] x 16 bytes
+extern "C" size_t mi_conv_d64_image_bytes(int Ci, int ntap) { return (size_t)(Ci / 16) * ntap * 2 * DW_STEP; }
+extern "C" int mi_conv_d64_prep(const float* w, void* img, int Ci, int ntap, mi_stream_t stream) {
+    if (!w || !img || (Ci != 32 && Ci != 64 && Ci != 128) || ntap != 9) return MI_E_ARG;
+    const int n = (Ci / 16) * ntap * 2 * 64;
+    hipLaunchKernelGGL(conv_d32_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)img, Ci, ntap, 64);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
@@ -275,17 +304,26 @@ extern "C" int mi_conv_d32_fwd_f32(const float* x, const void* wimg, const float
     p.x_bytes = (unsigned)(4l * N * D * H * W * Ci);
     p.out_bytes = (unsigned)(4l * N * D * H * W * DCO);
     hipStream_t s = (hipStream_t)stream;
-    if (kind == 1 && (Ci == 32 || Ci == 64) && H % 16 == 0 && W % 16 == 0) {
+    if (kind == 1 && (Ci == 16 || Ci == 32 || Ci == 64) && H % 16 == 0 && W % 16 == 0) {
         p.w_bytes = (unsigned)mi_conv_d32_image_bytes(Ci, 9);
         const long grid = (long)N * D * (H / 16) * (W / 16);
         if (grid > 0x7fffffffl) return MI_E_UNSUPPORTED;
-        if (Ci == 32) hipLaunchKernelGGL((conv_d32_kernel<32, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p);
+        if (Ci == 16) hipLaunchKernelGGL((conv_d32_kernel<16, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p);      // (the 16 -> 32 layer: one chunk, 9 k-steps)
+        else if (Ci == 32) hipLaunchKernelGGL((conv_d32_kernel<32, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv_d32_kernel<64, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p);
     } else if (kind == 2 && Ci == 32 && H % 32 == 0 && W % 32 == 0 && D % 2 == 0) {
         p.w_bytes = (unsigned)mi_conv_d32_image_bytes(Ci, 27);
         const long grid = (long)N * (D / 2) * 16 * (H / 32) * (W / 32);
         if (grid > 0x7fffffffl) return MI_E_UNSUPPORTED;
         hipLaunchKernelGGL((conv_d32_kernel<32, 3, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    } else if (kind == 3 && (Ci == 32 || Ci == 64 || Ci == 128) && H % 16 == 0 && W % 16 == 0) {
+        p.w_bytes = (unsigned)mi_conv_d64_image_bytes(Ci, 9);
+        p.out_bytes = (unsigned)(4l * N * D * H * W * 64);
+        const long grid = (long)N * D * (H / (Ci == 128 ? 8 : 16)) * (W / 16);
+        if (grid > 0x7fffffffl) return MI_E_UNSUPPORTED;
+        if (Ci == 32) hipLaunchKernelGGL((conv_d32_kernel<32, 1, 1, 64, 16>), dim3((unsigned)grid), dim3(256), 0, s, p);
+        else if (Ci == 64) hipLaunchKernelGGL((conv_d32_kernel<64, 1, 1, 64, 16>), dim3((unsigned)grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_d32_kernel<128, 1, 1, 64, 8>), dim3((unsigned)grid), dim3(256), 0, s, p);
     } else return MI_E_UNSUPPORTED;
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;

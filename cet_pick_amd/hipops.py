@@ -378,9 +378,9 @@ def _smallk_image(w, owner, K, co):
 
 
 def _d32_kind(x5shape, ci, co, k3, stride, p3, d3, inference):
-    """0, or the kind (1: 3 x 3 per plane, 2: the dilated 3-D head) of conv_d32.hip's direct inference kernel for this forward
-    convolution (32 output channels; padding = dilation * (k - 1) / 2)."""
-    if not inference or stride != 1 or co != 32 or not _arith_bf16x3():
+    """0, or the kind (1: 3 x 3 per plane to 32 channels, 2: the dilated 3-D head, 3: 3 x 3 per plane to 64 channels) of conv_d32.hip's
+    direct inference kernel for this forward convolution (padding = dilation * (k - 1) / 2)."""
+    if not inference or stride != 1 or co not in (32, 64) or not _arith_bf16x3():
         return 0
     d3 = tuple(d3) if d3 is not None else (1, 1, 1)
     if tuple(p3) != tuple(dl * (kk - 1) // 2 for dl, kk in zip(d3, k3)):
@@ -397,19 +397,24 @@ def _d32_call(x, w, bias, relu, kind, owner=None, out=None):
     lib = L.lib()
     x5 = _as5d(x)
     n, d, h, wd, ci = x5.shape
-    ntap = 9 if kind == 1 else 27
+    ntap = 27 if kind == 2 else 9
+    co = 64 if kind == 3 else 32
     holder = owner if owner is not None else w
-    key = (w.data_ptr(), holder._version, WEIGHT_EPOCH, ci, ntap)
+    key = (w.data_ptr(), holder._version, WEIGHT_EPOCH, ci, ntap, co)
     cache = getattr(holder, "_mi_d32", None)
     if cache is None or cache[0] != key:
-        img = torch.empty(int(lib.mi_conv_d32_image_bytes(ci, ntap)), dtype=torch.uint8, device=w.device)
-        L.check(lib.mi_conv_d32_prep(L.ptr(w), L.ptr(img), ci, ntap, L.stream()), "mi_conv_d32_prep")
+        if co == 64:
+            img = torch.empty(int(lib.mi_conv_d64_image_bytes(ci, ntap)), dtype=torch.uint8, device=w.device)
+            L.check(lib.mi_conv_d64_prep(L.ptr(w), L.ptr(img), ci, ntap, L.stream()), "mi_conv_d64_prep")
+        else:
+            img = torch.empty(int(lib.mi_conv_d32_image_bytes(ci, ntap)), dtype=torch.uint8, device=w.device)
+            L.check(lib.mi_conv_d32_prep(L.ptr(w), L.ptr(img), ci, ntap, L.stream()), "mi_conv_d32_prep")
         cache = (key, img)
         try:
             holder._mi_d32 = cache
         except AttributeError:
             pass
-    shape = tuple(x.shape[:-1]) + (32,)
+    shape = tuple(x.shape[:-1]) + (co,)
     if out is None:
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
     elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
@@ -417,7 +422,7 @@ def _d32_call(x, w, bias, relu, kind, owner=None, out=None):
     def call():
         return L.check(lib.mi_conv_d32_fwd_f32(L.ptr(x), L.ptr(cache[1]), L.ptr(bias), L.ptr(out), int(relu), n, d, h, wd, ci, kind,
                                                L.stream()), "mi_conv_d32_fwd_f32")
-    _prof_run("fwd", 2.0 * n * d * h * wd * 32 * ci * ntap, call)
+    _prof_run("fwd", 2.0 * n * d * h * wd * co * ci * ntap, call)
     return out
 
 

@@ -335,6 +335,11 @@ int mi_convnd_dil_fwd_f32(const float* x, const float* w, float* y, const float*
 int mi_conv_d32_kind(int N, int D, int H, int W, int Ci, int Co, int kd, int kh, int kw, int dd, int dh, int dw);
 size_t mi_conv_d32_image_bytes(int Ci, int ntap);
 int mi_conv_d32_prep(const float* w, void* img, int Ci, int ntap, mi_stream_t stream);
+/* Round 5: the same kernel to 64 output channels (mi_conv_d32_kind returns 3: 2-D 3 x 3, Ci 32 / 64 / 128, H and W multiples of 16 -
+ * the 128 x 128 level of the U-Net, unet.py:198-249): image [chunk][tap][column half][plane][lane]; forward through
+ * mi_conv_d32_fwd_f32(..., kind = 3) with y (N, D, H, W, 64).  MI_NO_D64=1 keeps the implicit GEMM. */
+size_t mi_conv_d64_image_bytes(int Ci, int ntap);
+int mi_conv_d64_prep(const float* w, void* img, int Ci, int ntap, mi_stream_t stream);
 int mi_conv_d32_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W,
                         int Ci, int kind, mi_stream_t stream);
 int mi_convnd_dil_dgrad_f32(const float* dy, const float* w, float* dx, const float* res, const float* mask,
