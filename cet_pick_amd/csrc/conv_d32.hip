@@ -59,6 +59,7 @@ struct D32Params {
     int relu;
     int N, D, H, W;
     unsigned x_bytes, out_bytes, w_bytes;
+    int co_total;             // channels of an output voxel in memory (CO, or a multiple of 64: blockIdx.y = 64-column block, one image each)
 };
 
 // CIN: 16, 32 or 64 input channels.  NZT: 1 (2-D layers: D planes are independent images) or 3 z taps.  DIL: xy dilation (1 or 4).
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1
     const int cx = cls % DIL, cy = cls / DIL;
     const int x0 = tx * G::TX, y0 = ty * G::TY, z0 = tz * G::TZ; // tile origin in class coordinates (x, y) / planes (z)
 
-    const __amdgpu_buffer_rsrc_t wrs = d_rsrc(p.wimg, p.w_bytes);
+    const int co0 = blockIdx.y * CO;                             // (64-column block of a wider layer: its own weight image)
+    const __amdgpu_buffer_rsrc_t wrs = d_rsrc(p.wimg + (size_t)blockIdx.y * p.w_bytes, p.w_bytes);
     bf16x8 bfr[G::RB][G::NCH][3];
     auto wload = [&](int g, auto SLOTc) {
         constexpr int SLOT = decltype(SLOTc)::value % G::RB;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1
     const __amdgpu_buffer_rsrc_t ors = d_rsrc(p.out, p.out_bytes);
 #pragma unroll
     for (int ch = 0; ch < G::NCH; ++ch) {
-        const float bv = p.bias ? p.bias[ch * 32 + l32] : 0.f;
+        const float bv = p.bias ? p.bias[co0 + ch * 32 + l32] : 0.f;
 #pragma unroll
         for (int i = 0; i < G::BPW; ++i)
 #pragma unroll
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1
                 const int y = (y0 + by_[i] + (m >> 3)) * DIL + cy, x = (x0 + bx_[i] + (m & 7)) * DIL + cx, z = z0 + bz_[i];
                 float v = acc[i][ch][r] + bv;
                 if (p.relu) v = fmaxf(v, 0.f);
-                const unsigned off = 4u * (unsigned)(((((long)n * p.D + z) * p.H + y) * p.W + x) * CO + ch * 32 + l32);
+                const unsigned off = 4u * (unsigned)(((((long)n * p.D + z) * p.H + y) * p.W + x) * p.co_total + co0 + ch * 32 + l32);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, (int)off, 0, 0);
             }
     }
@@ -243,18 +245,20 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1
 
 // weight image: W[tap][ci][co = 32] f32 -> bf16x3 B fragments [chunk][tap][plane][lane] x 16 bytes; idx = (chunk, tap, lane)
 // (co = 64: [chunk][tap][column half][plane][lane]; idx = (chunk, tap, column half, lane))
+// (co = 64 b: b blocks of 64 columns (blockIdx.y), each [chunk][tap][column half][plane][lane]; idx = (chunk, tap, column half, lane))
 __global__ __launch_bounds__(256) void conv_d32_prep_kernel(const float* w, unsigned char* img, int cin, int ntap, int co) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int ks = cin / 16, nch = co / 32;
+    const int cob = co > 64 ? 64 : co;                   // columns of one image
+    const int ks = cin / 16, nch = cob / 32;
     if (idx >= ks * ntap * nch * 64) return;
     const int lane = idx & 63, ch = (idx >> 6) % nch, tap = ((idx >> 6) / nch) % ntap, c = (idx >> 6) / (nch * ntap);
-    const int nn = ch * 32 + (lane & 31), k0 = c * 16 + 8 * (lane >> 5);
+    const int nn = blockIdx.y * cob + ch * 32 + (lane & 31), k0 = c * 16 + 8 * (lane >> 5);
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = w[((long)tap * cin + k0 + e) * co + nn];
     u32x4 o[3];
     d_cut8(v, o);
-    unsigned char* dst = img + (size_t)((c * ntap + tap) * nch + ch) * DW_STEP + lane * 16;
+    unsigned char* dst = img + (size_t)blockIdx.y * ((size_t)ks * ntap * nch * DW_STEP) + (size_t)((c * ntap + tap) * nch + ch) * DW_STEP + lane * 16;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * DW_BLK) = o[pl];
 }
@@ -265,8 +269,10 @@ __global__ __launch_bounds__(256) void conv_d32_prep_kernel(const float* w, unsi
 extern "C" int mi_conv_d32_kind(int N, int D, int H, int W, int Ci, int Co, int kd, int kh, int kw, int dd, int dh, int dw) {
     if (getenv("MI_NO_D32")) return 0;
     // 3 (round 5): 2-D 3 x 3 to 64 output channels from 32 / 64 / 128 (the 128 x 128 level); MI_NO_D64=1: the implicit GEMM
-    if (Co == 64 && N >= 1 && kd == 1 && kh == 3 && kw == 3 && dd == 1 && dh == 1 && dw == 1 && (Ci == 32 || Ci == 64 || Ci == 128) &&
-        H % 16 == 0 && W % 16 == 0 && 4l * N * D * H * W * (Ci > 64 ? Ci : 64) < 0x7fff0000l && !getenv("MI_NO_D64"))
+    // (Co = 128 / 256: 64-column blocks, a workgroup each, the patch staged once per block)
+    if ((Co == 64 || Co == 128 || Co == 256) && N >= 1 && kd == 1 && kh == 3 && kw == 3 && dd == 1 && dh == 1 && dw == 1 &&
+        (Ci == 32 || Ci == 64 || Ci == 128) && H % 16 == 0 && W % 16 == 0 && 4l * N * D * H * W * (Ci > Co ? Ci : Co) < 0x7fff0000l &&
+        !getenv("MI_NO_D64") && (Co == 64 || !getenv("MI_NO_D64_WIDE")))
         return 3;
     if (Co != DCO || N < 1 || kh != 3 || kw != 3 || dd != 1) return 0;
     if (4l * N * D * H * W * (Ci > DCO ? Ci : DCO) >= 0x7fff0000l) return 0;
@@ -286,6 +292,14 @@ extern "C" int mi_conv_d32_prep(const float* w, void* img, int Ci, int ntap, mi_
 }
 // the 64-output-channel form (kind 3): image of [chunk][tap][column half][plane][lane] x 16 bytes
 extern "C" size_t mi_conv_d64_image_bytes(int Ci, int ntap) { return (size_t)(Ci / 16) * ntap * 2 * DW_STEP; }
+// w: [tap][Ci][Co] with Co = 64, 128 or 256; img: (Co / 64) x mi_conv_d64_image_bytes(Ci, ntap) bytes (one image per 64-column block)
+extern "C" int mi_conv_d64_prep_co(const float* w, void* img, int Ci, int Co, int ntap, mi_stream_t stream) {
+    if (!w || !img || (Ci != 32 && Ci != 64 && Ci != 128) || (Co != 64 && Co != 128 && Co != 256) || ntap != 9) return MI_E_ARG;
+    const int n = (Ci / 16) * ntap * 2 * 64;
+    hipLaunchKernelGGL(conv_d32_prep_kernel, dim3((n + 255) / 256, Co / 64), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)img, Ci, ntap, Co);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
 extern "C" int mi_conv_d64_prep(const float* w, void* img, int Ci, int ntap, mi_stream_t stream) {
     if (!w || !img || (Ci != 32 && Ci != 64 && Ci != 128) || ntap != 9) return MI_E_ARG;
     const int n = (Ci / 16) * ntap * 2 * 64;
@@ -294,6 +308,8 @@ extern "C" int mi_conv_d64_prep(const float* w, void* img, int Ci, int ntap, mi_
     return MI_OK;
 }
 
+extern "C" int mi_conv_d64_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W,
+                                   int Ci, int Co, mi_stream_t stream);
 // y = act(conv(x, W) + bias): x (N, D, H, W, Ci) channels-last, y (N, D, H, W, 32); `kind` as mi_conv_d32_kind returns it
 extern "C" int mi_conv_d32_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W,
                                    int Ci, int kind, mi_stream_t stream) {
@@ -303,6 +319,7 @@ extern "C" int mi_conv_d32_fwd_f32(const float* x, const void* wimg, const float
     p.N = N; p.D = D; p.H = H; p.W = W;
     p.x_bytes = (unsigned)(4l * N * D * H * W * Ci);
     p.out_bytes = (unsigned)(4l * N * D * H * W * DCO);
+    p.co_total = DCO;
     hipStream_t s = (hipStream_t)stream;
     if (kind == 1 && (Ci == 16 || Ci == 32 || Ci == 64) && H % 16 == 0 && W % 16 == 0) {
         p.w_bytes = (unsigned)mi_conv_d32_image_bytes(Ci, 9);
@@ -316,15 +333,32 @@ extern "C" int mi_conv_d32_fwd_f32(const float* x, const void* wimg, const float
         const long grid = (long)N * (D / 2) * 16 * (H / 32) * (W / 32);
         if (grid > 0x7fffffffl) return MI_E_UNSUPPORTED;
         hipLaunchKernelGGL((conv_d32_kernel<32, 3, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
-    } else if (kind == 3 && (Ci == 32 || Ci == 64 || Ci == 128) && H % 16 == 0 && W % 16 == 0) {
-        p.w_bytes = (unsigned)mi_conv_d64_image_bytes(Ci, 9);
-        p.out_bytes = (unsigned)(4l * N * D * H * W * 64);
-        const long grid = (long)N * D * (H / (Ci == 128 ? 8 : 16)) * (W / 16);
-        if (grid > 0x7fffffffl) return MI_E_UNSUPPORTED;
-        if (Ci == 32) hipLaunchKernelGGL((conv_d32_kernel<32, 1, 1, 64, 16>), dim3((unsigned)grid), dim3(256), 0, s, p);
-        else if (Ci == 64) hipLaunchKernelGGL((conv_d32_kernel<64, 1, 1, 64, 16>), dim3((unsigned)grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv_d32_kernel<128, 1, 1, 64, 8>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    } else if (kind == 3) {
+        return mi_conv_d64_fwd_f32(x, wimg, bias, y, relu, N, D, H, W, Ci, 64, stream);
     } else return MI_E_UNSUPPORTED;
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+// kind 3 with Co = 64, 128 or 256: y (N, D, H, W, Co); wimg from mi_conv_d64_prep_co (Co / 64 images); a workgroup per tile and 64-column block
+extern "C" int mi_conv_d64_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W,
+                                   int Ci, int Co, mi_stream_t stream) {
+    if (!x || !wimg || !y || N < 1) return MI_E_ARG;
+    if ((Ci != 32 && Ci != 64 && Ci != 128) || (Co != 64 && Co != 128 && Co != 256) || H % 16 || W % 16) return MI_E_UNSUPPORTED;
+    D32Params p = {};
+    p.x = x; p.wimg = (const unsigned char*)wimg; p.bias = bias; p.out = y; p.relu = relu;
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.x_bytes = (unsigned)(4l * N * D * H * W * Ci);
+    p.out_bytes = (unsigned)(4l * N * D * H * W * Co);
+    p.co_total = Co;
+    p.w_bytes = (unsigned)mi_conv_d64_image_bytes(Ci, 9);
+    const long grid = (long)N * D * (H / (Ci == 128 ? 8 : 16)) * (W / 16);
+    if (grid > 0x7fffffffl) return MI_E_UNSUPPORTED;
+    const dim3 g((unsigned)grid, (unsigned)(Co / 64));
+    hipStream_t s = (hipStream_t)stream;
+    if (Ci == 32) hipLaunchKernelGGL((conv_d32_kernel<32, 1, 1, 64, 16>), g, dim3(256), 0, s, p);
+    else if (Ci == 64) hipLaunchKernelGGL((conv_d32_kernel<64, 1, 1, 64, 16>), g, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_d32_kernel<128, 1, 1, 64, 8>), g, dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

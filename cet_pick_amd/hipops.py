@@ -380,7 +380,7 @@ def _smallk_image(w, owner, K, co):
 def _d32_kind(x5shape, ci, co, k3, stride, p3, d3, inference):
     """0, or the kind (1: 3 x 3 per plane to 32 channels, 2: the dilated 3-D head, 3: 3 x 3 per plane to 64 channels) of conv_d32.hip's
     direct inference kernel for this forward convolution (padding = dilation * (k - 1) / 2)."""
-    if not inference or stride != 1 or co not in (32, 64) or not _arith_bf16x3():
+    if not inference or stride != 1 or co not in (32, 64, 128, 256) or not _arith_bf16x3():
         return 0
     d3 = tuple(d3) if d3 is not None else (1, 1, 1)
     if tuple(p3) != tuple(dl * (kk - 1) // 2 for dl, kk in zip(d3, k3)):
@@ -398,14 +398,14 @@ def _d32_call(x, w, bias, relu, kind, owner=None, out=None):
     x5 = _as5d(x)
     n, d, h, wd, ci = x5.shape
     ntap = 27 if kind == 2 else 9
-    co = 64 if kind == 3 else 32
+    co = int(w.shape[0]) if kind == 3 else 32
     holder = owner if owner is not None else w
     key = (w.data_ptr(), holder._version, WEIGHT_EPOCH, ci, ntap, co)
     cache = getattr(holder, "_mi_d32", None)
     if cache is None or cache[0] != key:
-        if co == 64:
-            img = torch.empty(int(lib.mi_conv_d64_image_bytes(ci, ntap)), dtype=torch.uint8, device=w.device)
-            L.check(lib.mi_conv_d64_prep(L.ptr(w), L.ptr(img), ci, ntap, L.stream()), "mi_conv_d64_prep")
+        if kind == 3:
+            img = torch.empty((co // 64) * int(lib.mi_conv_d64_image_bytes(ci, ntap)), dtype=torch.uint8, device=w.device)
+            L.check(lib.mi_conv_d64_prep_co(L.ptr(w), L.ptr(img), ci, co, ntap, L.stream()), "mi_conv_d64_prep_co")
         else:
             img = torch.empty(int(lib.mi_conv_d32_image_bytes(ci, ntap)), dtype=torch.uint8, device=w.device)
             L.check(lib.mi_conv_d32_prep(L.ptr(w), L.ptr(img), ci, ntap, L.stream()), "mi_conv_d32_prep")
@@ -420,6 +420,9 @@ def _d32_call(x, w, bias, relu, kind, owner=None, out=None):
     elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
         raise L.HipExtensionError("`out` must be a contiguous fp32 %s tensor on %s" % (shape, x.device))
     def call():
+        if kind == 3:
+            return L.check(lib.mi_conv_d64_fwd_f32(L.ptr(x), L.ptr(cache[1]), L.ptr(bias), L.ptr(out), int(relu), n, d, h, wd, ci, co,
+                                                   L.stream()), "mi_conv_d64_fwd_f32")
         return L.check(lib.mi_conv_d32_fwd_f32(L.ptr(x), L.ptr(cache[1]), L.ptr(bias), L.ptr(out), int(relu), n, d, h, wd, ci, kind,
                                                L.stream()), "mi_conv_d32_fwd_f32")
     _prof_run("fwd", 2.0 * n * d * h * wd * co * ci * ntap, call)

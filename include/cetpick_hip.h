@@ -340,6 +340,11 @@ int mi_conv_d32_prep(const float* w, void* img, int Ci, int ntap, mi_stream_t st
  * mi_conv_d32_fwd_f32(..., kind = 3) with y (N, D, H, W, 64).  MI_NO_D64=1 keeps the implicit GEMM. */
 size_t mi_conv_d64_image_bytes(int Ci, int ntap);
 int mi_conv_d64_prep(const float* w, void* img, int Ci, int ntap, mi_stream_t stream);
+/* Co = 64, 128 or 256 (kind 3 too): one image per 64-column block - img holds (Co / 64) x mi_conv_d64_image_bytes(Ci, 9) bytes -,
+ * a workgroup per tile and block; y (N, D, H, W, Co).  MI_NO_D64_WIDE=1 keeps Co > 64 on the implicit GEMM. */
+int mi_conv_d64_prep_co(const float* w, void* img, int Ci, int Co, int ntap, mi_stream_t stream);
+int mi_conv_d64_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W, int Ci,
+                        int Co, mi_stream_t stream);
 int mi_conv_d32_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W,
                         int Ci, int kind, mi_stream_t stream);
 int mi_convnd_dil_dgrad_f32(const float* dy, const float* w, float* dx, const float* res, const float* mask,

@@ -443,7 +443,7 @@ def test_unet_training_forward_backward_vs_oracle():
     assert int(net.bn1.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("case", ["2d_16", "2d_32", "2d_64", "head", "2d_32_to_64", "2d_64_to_64", "2d_128_to_64"])
+@pytest.mark.parametrize("case", ["2d_16", "2d_32", "2d_64", "head", "2d_32_to_64", "2d_64_to_64", "2d_128_to_64", "2d_64_to_128", "2d_128_to_128", "2d_128_to_256"])
 def test_direct_32_channel_kernel_matches_the_implicit_gemm_and_float64(case, monkeypatch):
     """conv_d32.hip (patch-resident direct convolution to 32 output channels, inference: the detector's 256 x 256 level and its
     dilated 3-D head) against the implicit GEMM it replaces (MI_NO_D32=1) and a float64 convolution: f32-equivalent (no further
@@ -451,7 +451,7 @@ def test_direct_32_channel_kernel_matches_the_implicit_gemm_and_float64(case, mo
     import torch.nn.functional as F
     from cet_pick_amd import hipops as H
     g = torch.Generator().manual_seed(17)
-    co = 64 if case.endswith("_to_64") else 32        # (round 5: the same kernel to 64 output channels - the 128 x 128 level)
+    co = int(case.split("_")[-1]) if "_to_" in case else 32      # (round 5: the same kernel to 64-column blocks of 64 / 128 / 256 channels)
     if case == "head":
         n, d, h, w, ci, k3, pad, dil = 1, 6, 64, 96, 32, (3, 3, 3), (1, 4, 4), (1, 4, 4)
     else:
@@ -473,7 +473,7 @@ def test_direct_32_channel_kernel_matches_the_implicit_gemm_and_float64(case, mo
             run = lambda: H.conv_bias_fwd(x4, w4, bias, 3, 1, 1, relu=True).unsqueeze(1)
         got = run()
         kernel = H.L.lib().mi_conv_d32_kind(n, d, h, w, ci, co, *k3, *dil)
-        assert kernel == (3 if co == 64 else 2 if case == "head" else 1)
+        assert kernel == (3 if co >= 64 else 2 if case == "head" else 1)
         monkeypatch.setenv("MI_NO_D32", "1")
         ref = run()
         monkeypatch.delenv("MI_NO_D32")
