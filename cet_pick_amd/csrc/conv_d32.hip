@@ -78,11 +78,13 @@ struct D32Cfg {
     static constexpr int NV = PX * PY * PZ;                    // patch voxels: 324 / 400
     static constexpr int ARR = NV * 16;                        // one (chunk, plane, k-half) array
     static constexpr int PL = 2 * ARR, CH = 3 * PL;            // plane, chunk
-    static constexpr int KS = CIN / 16;
-    static constexpr int LDS = KS * CH;                        // 62,208 (2-D, 32 ch) / 124,416 (2-D, 64 ch) / 76,800 (head)
+    static constexpr int KS = CIN / 16;                        // 16-channel chunks of the reduction
+    static constexpr int NPH = CIN > 128 ? CIN / 128 : 1;      // phases: the patch of 128 channels at a time (256 input channels: two)
+    static constexpr int KSP = KS / NPH;                       // chunks resident per phase
+    static constexpr int LDS = KSP * CH;                        // 62,208 (2-D, 32 ch) / 124,416 (2-D, 64 ch) / 76,800 (head)
     static constexpr int NTAP = 9 * NZT;
     static constexpr int NSTEP = KS * NTAP;
-    static constexpr int UNITS = (NV * KS * 2 + 255) / 256;    // staging units (voxel, chunk, k-half) per thread
+    static constexpr int UNITS = (NV * KSP * 2 + 255) / 256;   // staging units (voxel, chunk, k-half) per thread and phase
 };
 
 template <int CIN, int NZT, int DIL, int CO = 32, int TYT = 16>
@@ -127,20 +129,21 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1
 #pragma unroll
     for (int g = 0; g < G::RB - 1; ++g) wload_dyn(g);
 
-    // ---- the patch, every chunk at once: unit q = (voxel, chunk, k-half); voxels outside the volume read zeros (the padding) ----
-    {
+    // ---- the patch, every chunk of a phase at once: unit q = (voxel, chunk, k-half); voxels outside the volume read zeros (the padding).
+    //      (256 input channels: two phases of 128 - the second patch overwrites the first behind a barrier, the accumulators stay) ----
+    auto stage = [&](int ph) {
         const __amdgpu_buffer_rsrc_t xrs = d_rsrc(p.x, p.x_bytes);
         u32x4 ld[G::UNITS][2];
         int dst[G::UNITS];
 #pragma unroll
         for (int u = 0; u < G::UNITS; ++u) {
             const int q = tid + 256 * u;
-            const int hh = q & 1, c = (q >> 1) % G::KS, vox = (q >> 1) / G::KS;
+            const int hh = q & 1, c = (q >> 1) % G::KSP, vox = (q >> 1) / G::KSP;
             const int pz = vox / (G::PX * G::PY), py = (vox / G::PX) % G::PY, px = vox % G::PX;
             const int z = z0 + pz - (NZT - 1) / 2, y = (y0 + py - 1) * DIL + cy, x = (x0 + px - 1) * DIL + cx;
             const bool ok = vox < G::NV && (unsigned)z < (unsigned)p.D && y0 + py - 1 >= 0 && y0 + py - 1 < chh && x0 + px - 1 >= 0 &&
                             x0 + px - 1 < cw;
-            const unsigned off = ok ? 4u * (unsigned)(((((long)n * p.D + z) * p.H + y) * p.W + x) * CIN + c * 16 + hh * 8) : 0x80000000u;
+            const unsigned off = ok ? 4u * (unsigned)(((((long)n * p.D + z) * p.H + y) * p.W + x) * CIN + (ph * G::KSP + c) * 16 + hh * 8) : 0x80000000u;
             ld[u][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0);
             ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 16, 0);
             dst[u] = vox < G::NV ? c * G::CH + hh * G::ARR + vox * 16 : -1;
@@ -156,7 +159,8 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(patch + dst[u] + pl * G::PL) = o[pl];
         }
-    }
+    };
+    stage(0);
     // ---- per-lane geometry: row block b of this wave = 4 y x 8 x outputs; MFMA row l32 = (y & 3, x); record of the tap (0, 0, 0) ----
     int vbase[G::BPW];
     int by_[G::BPW], bx_[G::BPW], bz_[G::BPW];
@@ -196,11 +200,19 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < G::KS; ++c) {
+        if (G::NPH > 1 && c > 0 && c % G::KSP == 0) {             // next phase: every wave is done with the resident patch
+            __syncthreads();
+            stage(c / G::KSP);
+            __syncthreads();
+            frags_dyn(c * G::NTAP, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int tap = 0; tap < G::NTAP; ++tap) {
             const int g = c * G::NTAP + tap;
             wload_dyn(g + G::RB - 1);
-            if (g + 1 < G::NSTEP) frags_dyn(g + 1, (g + 1) / G::NTAP, (g + 1) % G::NTAP);
+            // (fragments of the next k-step - unless it belongs to the next phase's patch)
+            if (g + 1 < G::NSTEP && ((g + 1) / G::NTAP) / G::KSP == c / G::KSP) frags_dyn(g + 1, ((g + 1) / G::NTAP) % G::KSP, (g + 1) % G::NTAP);
 #pragma unroll
             for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
@@ -271,7 +283,7 @@ extern "C" int mi_conv_d32_kind(int N, int D, int H, int W, int Ci, int Co, int 
     // 3 (round 5): 2-D 3 x 3 to 64 output channels from 32 / 64 / 128 (the 128 x 128 level); MI_NO_D64=1: the implicit GEMM
     // (Co = 128 / 256: 64-column blocks, a workgroup each, the patch staged once per block)
     if ((Co == 64 || Co == 128 || Co == 256) && N >= 1 && kd == 1 && kh == 3 && kw == 3 && dd == 1 && dh == 1 && dw == 1 &&
-        (Ci == 32 || Ci == 64 || Ci == 128) && H % 16 == 0 && W % 16 == 0 && 4l * N * D * H * W * (Ci > Co ? Ci : Co) < 0x7fff0000l &&
+        (Ci == 32 || Ci == 64 || Ci == 128 || Ci == 256) && H % 16 == 0 && W % 16 == 0 && 4l * N * D * H * W * (Ci > Co ? Ci : Co) < 0x7fff0000l &&
         !getenv("MI_NO_D64") && (Co == 64 || !getenv("MI_NO_D64_WIDE")))
         return 3;
     if (Co != DCO || N < 1 || kh != 3 || kw != 3 || dd != 1) return 0;
@@ -294,7 +306,7 @@ extern "C" int mi_conv_d32_prep(const float* w, void* img, int Ci, int ntap, mi_
 extern "C" size_t mi_conv_d64_image_bytes(int Ci, int ntap) { return (size_t)(Ci / 16) * ntap * 2 * DW_STEP; }
 // w: [tap][Ci][Co] with Co = 64, 128 or 256; img: (Co / 64) x mi_conv_d64_image_bytes(Ci, ntap) bytes (one image per 64-column block)
 extern "C" int mi_conv_d64_prep_co(const float* w, void* img, int Ci, int Co, int ntap, mi_stream_t stream) {
-    if (!w || !img || (Ci != 32 && Ci != 64 && Ci != 128) || (Co != 64 && Co != 128 && Co != 256) || ntap != 9) return MI_E_ARG;
+    if (!w || !img || (Ci != 32 && Ci != 64 && Ci != 128 && Ci != 256) || (Co != 64 && Co != 128 && Co != 256) || ntap != 9) return MI_E_ARG;
     const int n = (Ci / 16) * ntap * 2 * 64;
     hipLaunchKernelGGL(conv_d32_prep_kernel, dim3((n + 255) / 256, Co / 64), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)img, Ci, ntap, Co);
     MI_RETURN_IF_LAUNCH_FAILED();
@@ -344,7 +356,7 @@ extern "C" int mi_conv_d32_fwd_f32(const float* x, const void* wimg, const float
 extern "C" int mi_conv_d64_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W,
                                    int Ci, int Co, mi_stream_t stream) {
     if (!x || !wimg || !y || N < 1) return MI_E_ARG;
-    if ((Ci != 32 && Ci != 64 && Ci != 128) || (Co != 64 && Co != 128 && Co != 256) || H % 16 || W % 16) return MI_E_UNSUPPORTED;
+    if ((Ci != 32 && Ci != 64 && Ci != 128 && Ci != 256) || (Co != 64 && Co != 128 && Co != 256) || H % 16 || W % 16) return MI_E_UNSUPPORTED;
     D32Params p = {};
     p.x = x; p.wimg = (const unsigned char*)wimg; p.bias = bias; p.out = y; p.relu = relu;
     p.N = N; p.D = D; p.H = H; p.W = W;
@@ -352,13 +364,14 @@ extern "C" int mi_conv_d64_fwd_f32(const float* x, const void* wimg, const float
     p.out_bytes = (unsigned)(4l * N * D * H * W * Co);
     p.co_total = Co;
     p.w_bytes = (unsigned)mi_conv_d64_image_bytes(Ci, 9);
-    const long grid = (long)N * D * (H / (Ci == 128 ? 8 : 16)) * (W / 16);
+    const long grid = (long)N * D * (H / (Ci >= 128 ? 8 : 16)) * (W / 16);
     if (grid > 0x7fffffffl) return MI_E_UNSUPPORTED;
     const dim3 g((unsigned)grid, (unsigned)(Co / 64));
     hipStream_t s = (hipStream_t)stream;
     if (Ci == 32) hipLaunchKernelGGL((conv_d32_kernel<32, 1, 1, 64, 16>), g, dim3(256), 0, s, p);
     else if (Ci == 64) hipLaunchKernelGGL((conv_d32_kernel<64, 1, 1, 64, 16>), g, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv_d32_kernel<128, 1, 1, 64, 8>), g, dim3(256), 0, s, p);
+    else if (Ci == 128) hipLaunchKernelGGL((conv_d32_kernel<128, 1, 1, 64, 8>), g, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_d32_kernel<256, 1, 1, 64, 8>), g, dim3(256), 0, s, p);       // (two phases of 128 input channels)
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

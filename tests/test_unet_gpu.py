@@ -443,7 +443,7 @@ def test_unet_training_forward_backward_vs_oracle():
     assert int(net.bn1.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("case", ["2d_16", "2d_32", "2d_64", "head", "2d_32_to_64", "2d_64_to_64", "2d_128_to_64", "2d_64_to_128", "2d_128_to_128", "2d_128_to_256"])
+@pytest.mark.parametrize("case", ["2d_16", "2d_32", "2d_64", "head", "2d_32_to_64", "2d_64_to_64", "2d_128_to_64", "2d_64_to_128", "2d_128_to_128", "2d_128_to_256", "2d_256_to_128", "2d_256_to_256"])
 def test_direct_32_channel_kernel_matches_the_implicit_gemm_and_float64(case, monkeypatch):
     """conv_d32.hip (patch-resident direct convolution to 32 output channels, inference: the detector's 256 x 256 level and its
     dilated 3-D head) against the implicit GEMM it replaces (MI_NO_D32=1) and a float64 convolution: f32-equivalent (no further
