@@ -78,6 +78,7 @@ SIGNATURES = {
     "mi_conv_d32_prep": (_I, [_P, _P, _I, _I, _P]),
     "mi_conv_d64_prep": (_I, [_P, _P, _I, _I, _P]),
     "mi_conv_d64_prep_co": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mi_conv_d32_1x1_fwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mi_conv_d64_fwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mi_conv_d32_fwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mi_convnd_dil_fwd_f32": (_I, [_P, _P, _P, _P, _I] + [_I] * 15 + [_P, _Z, _P]),

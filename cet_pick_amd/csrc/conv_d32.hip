@@ -67,14 +67,15 @@ struct D32Params {
 // NZT = 1, 8 x 8 x 2 (one row block per wave) for NZT = 3.
 // Round 5, CO = 64 (the 128 x 128 level of the U-Net: 32 / 64 / 128 -> 64, 2-D): every A fragment feeds TWO column halves (12 MFMAs per
 // row block and k-step); TYT = 8 halves the tile (16 x 8, one row block per wave) where the patch of 128 input channels would not fit.
-template <int CIN, int NZT, int DIL, int CO = 32, int TYT = 16>
+// KSZ = 1: the 1 x 1 products (the transposed convolutions' 4 Co columns, the last layer): the patch is the tile, one tap per chunk.
+template <int CIN, int NZT, int DIL, int CO = 32, int TYT = 16, int KSZ = 3>
 struct D32Cfg {
     static constexpr int TX = NZT == 1 ? 16 : 8, TY = NZT == 1 ? TYT : 8, TZ = NZT == 1 ? 1 : 2;
     static constexpr int BPW = NZT == 1 ? TYT / 8 : 1;        // row blocks (4 y x 8 x) per wave
     static constexpr int NCH = CO / 32;                        // 32-column halves
     static constexpr int RB = CO == 32 ? DRB : 3;              // weight k-steps in flight
     static constexpr int WSTEP = NCH * DW_STEP;                // bytes per k-step of the weight image: [column half][plane][lane] x 16
-    static constexpr int PX = TX + 2, PY = TY + 2, PZ = TZ + NZT - 1;
+    static constexpr int PX = TX + KSZ - 1, PY = TY + KSZ - 1, PZ = TZ + NZT - 1;
     static constexpr int NV = PX * PY * PZ;                    // patch voxels: 324 / 400
     static constexpr int ARR = NV * 16;                        // one (chunk, plane, k-half) array
     static constexpr int PL = 2 * ARR, CH = 3 * PL;            // plane, chunk
@@ -82,14 +83,15 @@ struct D32Cfg {
     static constexpr int NPH = CIN > 128 ? CIN / 128 : 1;      // phases: the patch of 128 channels at a time (256 input channels: two)
     static constexpr int KSP = KS / NPH;                       // chunks resident per phase
     static constexpr int LDS = KSP * CH;                        // 62,208 (2-D, 32 ch) / 124,416 (2-D, 64 ch) / 76,800 (head)
-    static constexpr int NTAP = 9 * NZT;
+    static constexpr int NTAP = KSZ * KSZ * NZT;
     static constexpr int NSTEP = KS * NTAP;
     static constexpr int UNITS = (NV * KSP * 2 + 255) / 256;   // staging units (voxel, chunk, k-half) per thread and phase
 };
 
-template <int CIN, int NZT, int DIL, int CO = 32, int TYT = 16>
-__global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1024) ? 2 : 1) void conv_d32_kernel(D32Params p) {
-    typedef D32Cfg<CIN, NZT, DIL, CO, TYT> G;
+template <int CIN, int NZT, int DIL, int CO = 32, int TYT = 16, int KSZ = 3>
+__global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT, KSZ>::LDS <= 80 * 1024) ? 2 : 1) void conv_d32_kernel(D32Params p) {
+    typedef D32Cfg<CIN, NZT, DIL, CO, TYT, KSZ> G;
+    constexpr int HALO = (KSZ - 1) / 2;
     __shared__ __attribute__((aligned(16))) unsigned char patch[G::LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l32 = lane & 31;
@@ -104,8 +106,12 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1
     const int cx = cls % DIL, cy = cls / DIL;
     const int x0 = tx * G::TX, y0 = ty * G::TY, z0 = tz * G::TZ; // tile origin in class coordinates (x, y) / planes (z)
 
-    const int co0 = blockIdx.y * CO;                             // (64-column block of a wider layer: its own weight image)
-    const __amdgpu_buffer_rsrc_t wrs = d_rsrc(p.wimg + (size_t)blockIdx.y * p.w_bytes, p.w_bytes);
+    // 64-column blocks of a wider layer, an image each: a workgroup per block (blockIdx.y) - or, for the 1 x 1 products (LOOPCB), every
+    // block in turn over the ONE staged tile (the tile is all a 1 x 1 product reads: staging it once per block made the wide ones slower)
+    constexpr bool LOOPCB = KSZ == 1 && G::NPH == 1 && CO == 64;
+    const int ncb = LOOPCB ? p.co_total / CO : 1;
+    int co0 = blockIdx.y * CO;
+    __amdgpu_buffer_rsrc_t wrs = d_rsrc(p.wimg + (size_t)blockIdx.y * p.w_bytes, p.w_bytes);
     bf16x8 bfr[G::RB][G::NCH][3];
     auto wload = [&](int g, auto SLOTc) {
         constexpr int SLOT = decltype(SLOTc)::value % G::RB;
@@ -140,9 +146,9 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1
             const int q = tid + 256 * u;
             const int hh = q & 1, c = (q >> 1) % G::KSP, vox = (q >> 1) / G::KSP;
             const int pz = vox / (G::PX * G::PY), py = (vox / G::PX) % G::PY, px = vox % G::PX;
-            const int z = z0 + pz - (NZT - 1) / 2, y = (y0 + py - 1) * DIL + cy, x = (x0 + px - 1) * DIL + cx;
-            const bool ok = vox < G::NV && (unsigned)z < (unsigned)p.D && y0 + py - 1 >= 0 && y0 + py - 1 < chh && x0 + px - 1 >= 0 &&
-                            x0 + px - 1 < cw;
+            const int z = z0 + pz - (NZT - 1) / 2, y = (y0 + py - HALO) * DIL + cy, x = (x0 + px - HALO) * DIL + cx;
+            const bool ok = vox < G::NV && (unsigned)z < (unsigned)p.D && y0 + py - HALO >= 0 && y0 + py - HALO < chh && x0 + px - HALO >= 0 &&
+                            x0 + px - HALO < cw;
             const unsigned off = ok ? 4u * (unsigned)(((((long)n * p.D + z) * p.H + y) * p.W + x) * CIN + (ph * G::KSP + c) * 16 + hh * 8) : 0x80000000u;
             ld[u][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0);
             ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 16, 0);
@@ -172,19 +178,13 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1
         vbase[i] = ((bz_[i] * G::PY + by_[i] + (l32 >> 3)) * G::PX + bx_[i] + (l32 & 7)) * 16 + h * G::ARR;
     }
     f32x16 acc[G::BPW][G::NCH];
-#pragma unroll
-    for (int i = 0; i < G::BPW; ++i)
-#pragma unroll
-        for (int ch = 0; ch < G::NCH; ++ch)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][ch][r] = 0.f;
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
     __syncthreads();
 
     bf16x8 af[2][G::BPW][3];
     auto frags = [&](int c, int tap, auto SETc) {
         constexpr int SET = decltype(SETc)::value;
-        const int tzz = tap / 9, tyy = (tap / 3) % 3, txx = tap % 3;
+        const int tzz = tap / (KSZ * KSZ), tyy = (tap / KSZ) % KSZ, txx = tap % KSZ;
         const int imm = ((tzz * G::PY + tyy) * G::PX + txx) * 16 + c * G::CH;
 #pragma unroll
         for (int i = 0; i < G::BPW; ++i)
@@ -196,6 +196,20 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1
         if (g & 1) frags(c, tap, std::integral_constant<int, 1>{});
         else frags(c, tap, std::integral_constant<int, 0>{});
     };
+    const __amdgpu_buffer_rsrc_t ors = d_rsrc(p.out, p.out_bytes);
+  for (int cb = 0; cb < ncb; ++cb) {
+    if (LOOPCB && cb > 0) {                                      // next 64-column block: its image, its ring
+        co0 = cb * CO;
+        wrs = d_rsrc(p.wimg + (size_t)cb * p.w_bytes, p.w_bytes);
+#pragma unroll
+        for (int g = 0; g < G::RB - 1; ++g) wload_dyn(g);
+    }
+#pragma unroll
+    for (int i = 0; i < G::BPW; ++i)
+#pragma unroll
+        for (int ch = 0; ch < G::NCH; ++ch)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][ch][r] = 0.f;
     frags_dyn(0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -237,7 +251,6 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1
         }
     }
     // ---- epilogue: C/D layout col = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 h = (y & 3, x) of the row block ----
-    const __amdgpu_buffer_rsrc_t ors = d_rsrc(p.out, p.out_bytes);
 #pragma unroll
     for (int ch = 0; ch < G::NCH; ++ch) {
         const float bv = p.bias ? p.bias[co0 + ch * 32 + l32] : 0.f;
@@ -253,6 +266,7 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT>::LDS <= 80 * 1
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, (int)off, 0, 0);
             }
     }
+  }
 }
 
 // weight image: W[tap][ci][co = 32] f32 -> bf16x3 B fragments [chunk][tap][plane][lane] x 16 bytes; idx = (chunk, tap, lane)
@@ -280,6 +294,11 @@ __global__ __launch_bounds__(256) void conv_d32_prep_kernel(const float* w, unsi
 // 1: 2-D 3 x 3 (kd = 1, any D: independent planes), dilation 1; 2: 3 x 3 x 3 with dilation (1, 4, 4); 0: not a shape of this kernel
 extern "C" int mi_conv_d32_kind(int N, int D, int H, int W, int Ci, int Co, int kd, int kh, int kw, int dd, int dh, int dw) {
     if (getenv("MI_NO_D32")) return 0;
+    // 4 (round 5): 1 x 1 products, 32 or 64 / 128 / 256 / 512 output columns from 32 / 64 / 128 / 256 input channels (MI_NO_D32_1X1=1: off)
+    if (kd == 1 && kh == 1 && kw == 1 && dd == 1 && dh == 1 && dw == 1 && N >= 1 && (Co == 32 || (Co % 64 == 0 && Co >= 64 && Co <= 512)) &&
+        (Ci == 32 || Ci == 64 || Ci == 128 || (Ci == 256 && getenv("MI_D32_1X1_256"))) && H % 8 == 0 && W % 16 == 0 &&
+        4l * N * D * H * W * (Ci > Co ? Ci : Co) < 0x7fff0000l && !getenv("MI_NO_D32_1X1"))
+        return 4;       // (256 input channels: two phases and a workgroup per column block - 0.405 against 0.370 ms on the implicit GEMM: opt-in)
     // 3 (round 5): 2-D 3 x 3 to 64 output channels from 32 / 64 / 128 (the 128 x 128 level); MI_NO_D64=1: the implicit GEMM
     // (Co = 128 / 256: 64-column blocks, a workgroup each, the patch staged once per block)
     if ((Co == 64 || Co == 128 || Co == 256) && N >= 1 && kd == 1 && kh == 3 && kw == 3 && dd == 1 && dh == 1 && dw == 1 &&
@@ -296,7 +315,7 @@ extern "C" size_t mi_conv_d32_image_bytes(int Ci, int ntap) { return (size_t)(Ci
 
 // w: [tap][Ci][32] f32 (kernel layout); img: mi_conv_d32_image_bytes(Ci, ntap) bytes
 extern "C" int mi_conv_d32_prep(const float* w, void* img, int Ci, int ntap, mi_stream_t stream) {
-    if (!w || !img || (Ci != 16 && Ci != 32 && Ci != 64) || (ntap != 9 && ntap != 27)) return MI_E_ARG;
+    if (!w || !img || (Ci != 16 && Ci != 32 && Ci != 64 && Ci != 128 && Ci != 256) || (ntap != 9 && ntap != 27 && ntap != 1)) return MI_E_ARG;
     const int n = (Ci / 16) * ntap * 64;
     hipLaunchKernelGGL(conv_d32_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)img, Ci, ntap, DCO);
     MI_RETURN_IF_LAUNCH_FAILED();
@@ -306,7 +325,7 @@ extern "C" int mi_conv_d32_prep(const float* w, void* img, int Ci, int ntap, mi_
 extern "C" size_t mi_conv_d64_image_bytes(int Ci, int ntap) { return (size_t)(Ci / 16) * ntap * 2 * DW_STEP; }
 // w: [tap][Ci][Co] with Co = 64, 128 or 256; img: (Co / 64) x mi_conv_d64_image_bytes(Ci, ntap) bytes (one image per 64-column block)
 extern "C" int mi_conv_d64_prep_co(const float* w, void* img, int Ci, int Co, int ntap, mi_stream_t stream) {
-    if (!w || !img || (Ci != 32 && Ci != 64 && Ci != 128 && Ci != 256) || (Co != 64 && Co != 128 && Co != 256) || ntap != 9) return MI_E_ARG;
+    if (!w || !img || (Ci != 32 && Ci != 64 && Ci != 128 && Ci != 256) || Co % 64 || Co < 64 || Co > 512 || (ntap != 9 && ntap != 1)) return MI_E_ARG;
     const int n = (Ci / 16) * ntap * 2 * 64;
     hipLaunchKernelGGL(conv_d32_prep_kernel, dim3((n + 255) / 256, Co / 64), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)img, Ci, ntap, Co);
     MI_RETURN_IF_LAUNCH_FAILED();
@@ -348,6 +367,41 @@ extern "C" int mi_conv_d32_fwd_f32(const float* x, const void* wimg, const float
     } else if (kind == 3) {
         return mi_conv_d64_fwd_f32(x, wimg, bias, y, relu, N, D, H, W, Ci, 64, stream);
     } else return MI_E_UNSUPPORTED;
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+// kind 4: y = act(x W + bias) per voxel (1 x 1): Co = 32 (image: mi_conv_d32_prep(w, img, Ci, 1)) or a multiple of 64 up to 512
+// (mi_conv_d64_prep_co(w, img, Ci, Co, 1): Co / 64 images); 16 x 8 tiles, the patch is the tile
+extern "C" int mi_conv_d32_1x1_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W,
+                                       int Ci, int Co, mi_stream_t stream) {
+    if (!x || !wimg || !y || N < 1) return MI_E_ARG;
+    if ((Ci != 32 && Ci != 64 && Ci != 128 && Ci != 256) || !(Co == 32 || (Co % 64 == 0 && Co >= 64 && Co <= 512)) || H % 8 || W % 16)
+        return MI_E_UNSUPPORTED;
+    D32Params p = {};
+    p.x = x; p.wimg = (const unsigned char*)wimg; p.bias = bias; p.out = y; p.relu = relu;
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.x_bytes = (unsigned)(4l * N * D * H * W * Ci);
+    p.out_bytes = (unsigned)(4l * N * D * H * W * Co);
+    p.co_total = Co;
+    const long grid = (long)N * D * (H / 8) * (W / 16);
+    if (grid > 0x7fffffffl) return MI_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (Co == 32) {
+        p.w_bytes = (unsigned)mi_conv_d32_image_bytes(Ci, 1);
+        const dim3 g((unsigned)grid);
+        if (Ci == 32) hipLaunchKernelGGL((conv_d32_kernel<32, 1, 1, 32, 8, 1>), g, dim3(256), 0, s, p);
+        else if (Ci == 64) hipLaunchKernelGGL((conv_d32_kernel<64, 1, 1, 32, 8, 1>), g, dim3(256), 0, s, p);
+        else if (Ci == 128) hipLaunchKernelGGL((conv_d32_kernel<128, 1, 1, 32, 8, 1>), g, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_d32_kernel<256, 1, 1, 32, 8, 1>), g, dim3(256), 0, s, p);
+    } else {
+        p.w_bytes = (unsigned)mi_conv_d64_image_bytes(Ci, 1);
+        const dim3 g((unsigned)grid, (unsigned)(Ci <= 128 ? 1 : Co / 64));       // (<= 128 input channels: the workgroup loops over the blocks)
+        if (Ci == 32) hipLaunchKernelGGL((conv_d32_kernel<32, 1, 1, 64, 8, 1>), g, dim3(256), 0, s, p);
+        else if (Ci == 64) hipLaunchKernelGGL((conv_d32_kernel<64, 1, 1, 64, 8, 1>), g, dim3(256), 0, s, p);
+        else if (Ci == 128) hipLaunchKernelGGL((conv_d32_kernel<128, 1, 1, 64, 8, 1>), g, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_d32_kernel<256, 1, 1, 64, 8, 1>), g, dim3(256), 0, s, p);
+    }
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

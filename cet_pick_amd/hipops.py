@@ -380,7 +380,7 @@ def _smallk_image(w, owner, K, co):
 def _d32_kind(x5shape, ci, co, k3, stride, p3, d3, inference):
     """0, or the kind (1: 3 x 3 per plane to 32 channels, 2: the dilated 3-D head, 3: 3 x 3 per plane to 64 channels) of conv_d32.hip's
     direct inference kernel for this forward convolution (padding = dilation * (k - 1) / 2)."""
-    if not inference or stride != 1 or co not in (32, 64, 128, 256) or not _arith_bf16x3():
+    if not inference or stride != 1 or not (co == 32 or (co % 64 == 0 and 64 <= co <= 512)) or not _arith_bf16x3():
         return 0
     d3 = tuple(d3) if d3 is not None else (1, 1, 1)
     if tuple(p3) != tuple(dl * (kk - 1) // 2 for dl, kk in zip(d3, k3)):
@@ -397,13 +397,13 @@ def _d32_call(x, w, bias, relu, kind, owner=None, out=None):
     lib = L.lib()
     x5 = _as5d(x)
     n, d, h, wd, ci = x5.shape
-    ntap = 27 if kind == 2 else 9
-    co = int(w.shape[0]) if kind == 3 else 32
+    ntap = 27 if kind == 2 else 1 if kind == 4 else 9
+    co = int(w.shape[0]) if kind in (3, 4) else 32
     holder = owner if owner is not None else w
     key = (w.data_ptr(), holder._version, WEIGHT_EPOCH, ci, ntap, co)
     cache = getattr(holder, "_mi_d32", None)
     if cache is None or cache[0] != key:
-        if kind == 3:
+        if kind == 3 or (kind == 4 and co >= 64):
             img = torch.empty((co // 64) * int(lib.mi_conv_d64_image_bytes(ci, ntap)), dtype=torch.uint8, device=w.device)
             L.check(lib.mi_conv_d64_prep_co(L.ptr(w), L.ptr(img), ci, co, ntap, L.stream()), "mi_conv_d64_prep_co")
         else:
@@ -420,6 +420,9 @@ def _d32_call(x, w, bias, relu, kind, owner=None, out=None):
     elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
         raise L.HipExtensionError("`out` must be a contiguous fp32 %s tensor on %s" % (shape, x.device))
     def call():
+        if kind == 4:
+            return L.check(lib.mi_conv_d32_1x1_fwd_f32(L.ptr(x), L.ptr(cache[1]), L.ptr(bias), L.ptr(out), int(relu), n, d, h, wd, ci, co,
+                                                       L.stream()), "mi_conv_d32_1x1_fwd_f32")
         if kind == 3:
             return L.check(lib.mi_conv_d64_fwd_f32(L.ptr(x), L.ptr(cache[1]), L.ptr(bias), L.ptr(out), int(relu), n, d, h, wd, ci, co,
                                                    L.stream()), "mi_conv_d64_fwd_f32")
@@ -461,11 +464,13 @@ def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None, owner=None, i
     nd5 = x.dim() == 5
     k3, p3 = _k3(k, nd5), _p3(pad, nd5)
     if res is None:
+        kind = _d32_kind(_as5d(x).shape, x.shape[-1], w.shape[0], k3, stride, p3, _k3(dil, nd5) if dil is not None else None, inference)
+        if kind == 4:                                 # inference, 1 x 1 (the transposed convolutions' products): tile-resident kernel
+            return _d32_call(x, w, None, relu, kind, owner=owner)
         taps = _smallk_taps(x, w, k3, stride, p3, dil, nd5, inference)
         if taps:                                      # inference, short reduction: no tile pipeline (conv_smallk.hip)
             return _smallk_call(x, w, None, relu, taps, owner=owner)
-        kind = _d32_kind(_as5d(x).shape, x.shape[-1], w.shape[0], k3, stride, p3, _k3(dil, nd5) if dil is not None else None, inference)
-        if kind:                                      # inference, 32 output channels: patch-resident direct kernel (conv_d32.hip)
+        if kind:                                      # inference, 3 x 3: patch-resident direct kernel (conv_d32.hip)
             return _d32_call(x, w, None, relu, kind, owner=owner)
     x5 = _as5d(x)
     n, d, h, wd, ci = x5.shape
@@ -944,10 +949,12 @@ def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None):
     k3, p3 = _k3(k, nd5), _p3(pad, nd5)
     if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
         raise L.HipExtensionError("conv_bias_fwd is inference only (no autograd node)")
+    kind = _d32_kind(_as5d(x).shape, x.shape[-1], w.shape[0], k3, stride, p3, None, True)
+    if kind == 4:                                     # 1 x 1: the tile-resident kernel (in front of the short-reduction one)
+        return _d32_call(x, w, _f32c(bias, "bias"), relu, kind, out=out)
     taps = _smallk_taps(x, w, k3, stride, p3, None, nd5, True)
     if taps:
         return _smallk_call(x, w, _f32c(bias, "bias"), relu, taps, out=out)
-    kind = _d32_kind(_as5d(x).shape, x.shape[-1], w.shape[0], k3, stride, p3, None, True)
     if kind:
         return _d32_call(x, w, _f32c(bias, "bias"), relu, kind, out=out)
     x5 = _as5d(x)

@@ -343,6 +343,11 @@ int mi_conv_d64_prep(const float* w, void* img, int Ci, int ntap, mi_stream_t st
 /* Co = 64, 128 or 256 (kind 3 too): one image per 64-column block - img holds (Co / 64) x mi_conv_d64_image_bytes(Ci, 9) bytes -,
  * a workgroup per tile and block; y (N, D, H, W, Co).  MI_NO_D64_WIDE=1 keeps Co > 64 on the implicit GEMM. */
 int mi_conv_d64_prep_co(const float* w, void* img, int Ci, int Co, int ntap, mi_stream_t stream);
+/* mi_conv_d32_kind = 4: 1 x 1 products (the 2 x 2 transposed convolutions' 4 Co columns, unet.py:251-317, and the last 1 x 1 layer):
+ * y = act(x W + bias) per voxel, the tile resident in LDS.  Co = 32 (image: mi_conv_d32_prep(w, img, Ci, 1)) or a multiple of 64
+ * up to 512 (mi_conv_d64_prep_co(w, img, Ci, Co, 1)); Ci 32 / 64 / 128 / 256; H % 8 == 0, W % 16 == 0.  MI_NO_D32_1X1=1: off. */
+int mi_conv_d32_1x1_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W,
+                            int Ci, int Co, mi_stream_t stream);
 int mi_conv_d64_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W, int Ci,
                         int Co, mi_stream_t stream);
 int mi_conv_d32_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W,

@@ -118,6 +118,7 @@ def test_upconv_tail_equals_shuffle_batchnorm_relu_concat(n, h, w, ho, wo, co, c
 def test_short_reduction_kernel_matches_generic_kernel_and_float64(shape, co, k, pad, monkeypatch):
     """smallk_fwd_kernel (inference: 1 x 1 and (3, 1, 1) convolutions without the implicit GEMM's tile pipeline; unet.py:319-399,880-886,
     unet_small.py:86-97) against the generic kernel (hipops.SMALLK off) and float64, with and without the bias + ReLU epilogue."""
+    monkeypatch.setenv("MI_NO_D32_1X1", "1")        # (round 5: 1 x 1 products take conv_d32's tile-resident form first; this test is conv_smallk's)
     from cet_pick_amd import hipops as H, _lib as L
     n, d, h, w, ci = shape
     g = torch.Generator().manual_seed(sum(shape) + co)
@@ -443,7 +444,8 @@ def test_unet_training_forward_backward_vs_oracle():
     assert int(net.bn1.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("case", ["2d_16", "2d_32", "2d_64", "head", "2d_32_to_64", "2d_64_to_64", "2d_128_to_64", "2d_64_to_128", "2d_128_to_128", "2d_128_to_256", "2d_256_to_128", "2d_256_to_256"])
+@pytest.mark.parametrize("case", ["2d_16", "2d_32", "2d_64", "head", "2d_32_to_64", "2d_64_to_64", "2d_128_to_64", "2d_64_to_128", "2d_128_to_128", "2d_128_to_256", "2d_256_to_128", "2d_256_to_256",
+                                  "1x1_32_to_32", "1x1_64_to_128", "1x1_128_to_256", "1x1_256_to_512", "1x1_64_to_32"])
 def test_direct_32_channel_kernel_matches_the_implicit_gemm_and_float64(case, monkeypatch):
     """conv_d32.hip (patch-resident direct convolution to 32 output channels, inference: the detector's 256 x 256 level and its
     dilated 3-D head) against the implicit GEMM it replaces (MI_NO_D32=1) and a float64 convolution: f32-equivalent (no further
@@ -454,10 +456,13 @@ def test_direct_32_channel_kernel_matches_the_implicit_gemm_and_float64(case, mo
     co = int(case.split("_")[-1]) if "_to_" in case else 32      # (round 5: the same kernel to 64-column blocks of 64 / 128 / 256 channels)
     if case == "head":
         n, d, h, w, ci, k3, pad, dil = 1, 6, 64, 96, 32, (3, 3, 3), (1, 4, 4), (1, 4, 4)
+    elif case.startswith("1x1"):          # (the transposed convolutions' products and the last layer: kind 4, the tile is the patch)
+        monkeypatch.setenv("MI_D32_1X1_256", "1")          # (256 input channels: built, not faster than the implicit GEMM, opt-in)
+        n, d, h, w, ci, k3, pad, dil = 3, 1, 40, 64, int(case.split("_")[1]), (1, 1, 1), (0, 0, 0), (1, 1, 1)
     else:
         n, d, h, w, ci, k3, pad, dil = 3, 1, 48, 64, int(case.split("_")[1]), (1, 3, 3), (0, 1, 1), (1, 1, 1)
     x = (torch.randn(n, d, h, w, ci, generator=g) * torch.exp(torch.randn(n, d, h, w, 1, generator=g))).cuda()
-    wt = torch.randn(*k3, ci, co, generator=g) / (ci * 9) ** 0.5          # kernel layout [kd, kh, kw, ci, co]
+    wt = torch.randn(*k3, ci, co, generator=g) / (ci * k3[1] * k3[2]) ** 0.5          # kernel layout [kd, kh, kw, ci, co]
     wdev = wt.cuda().permute(4, 3, 0, 1, 2)                               # logical (co, ci, kd, kh, kw) over that storage
     bias = torch.randn(co, generator=g).cuda()
     want = F.conv3d(x.double().cpu().permute(0, 4, 1, 2, 3), wt.double().permute(4, 3, 0, 1, 2), bias.double().cpu(), padding=pad,
@@ -470,10 +475,10 @@ def test_direct_32_channel_kernel_matches_the_implicit_gemm_and_float64(case, mo
         else:
             w4 = wdev[:, :, 0]                                                                      # 2-D layer: (co, ci, kh, kw)
             x4 = x[:, 0]
-            run = lambda: H.conv_bias_fwd(x4, w4, bias, 3, 1, 1, relu=True).unsqueeze(1)
+            run = lambda: H.conv_bias_fwd(x4, w4, bias, k3[1], 1, pad[1], relu=True).unsqueeze(1)
         got = run()
         kernel = H.L.lib().mi_conv_d32_kind(n, d, h, w, ci, co, *k3, *dil)
-        assert kernel == (3 if co >= 64 else 2 if case == "head" else 1)
+        assert kernel == (4 if case.startswith("1x1") else 3 if co >= 64 else 2 if case == "head" else 1)
         monkeypatch.setenv("MI_NO_D32", "1")
         ref = run()
         monkeypatch.delenv("MI_NO_D32")
