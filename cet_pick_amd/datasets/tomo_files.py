@@ -130,6 +130,8 @@ class TomoFileMocoLoader(SyntheticMocoLoader):
         self.rank, self.world = rank, world
         # the bookkeeping of every batch, on the device once: tomogram descriptors, owner / centre / shift per sample
         self.table = S.CropTable(self.vols, self.owner, self.centres, self.shift)
+        self.prefetch = os.environ.get("CETPICK_LOADER_PREFETCH", "1") != "0"
+        self._stream = None
         print("Loaded {} {} samples".format(split, len(self.centres)))
 
     def __len__(self):
@@ -156,6 +158,35 @@ class TomoFileMocoLoader(SyntheticMocoLoader):
         # host-to-device copy, no scatter per tomogram (moco_main.py:122-156's DataLoader, minus its workers)
         order = self.table.epoch_order(self.epoch_order())
         c, B = (self.crop,) * 3, self.batch_size
+        dev = self.vols[0].device
+        if dev.type != "cuda" or not self.prefetch:
+            for b in range(len(self)):
+                yield {"input": self.table.cut(order, b * B, B, c),
+                       "input_aug": self.table.cut(order, b * B, B, c, shifted=True, flip_x=True)}
+            return
+        # One batch ahead on a stream of the loader's own (what the reference's DataLoader workers are for): the two crop launches of
+        # batch b + 1 run next to training step b instead of in front of step b + 1.  The consumer's stream waits for the batch's
+        # event; the tensors are handed over with record_stream (the allocator must not recycle them for the loader's stream early).
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=dev)
+        side = self._stream
+
+        def cut(b):
+            if b == 0:
+                side.wait_stream(torch.cuda.current_stream(dev))    # (the epoch's order upload; the table has been there since __init__)
+            with torch.cuda.stream(side):
+                batch = {"input": self.table.cut(order, b * B, B, c),
+                         "input_aug": self.table.cut(order, b * B, B, c, shifted=True, flip_x=True)}
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return batch, ev
+
+        nxt = cut(0) if len(self) else None
         for b in range(len(self)):
-            yield {"input": self.table.cut(order, b * B, B, c),
-                   "input_aug": self.table.cut(order, b * B, B, c, shifted=True, flip_x=True)}
+            batch, ev = nxt
+            nxt = cut(b + 1) if b + 1 < len(self) else None
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ev)
+            for t in batch.values():
+                t.record_stream(cur)
+            yield batch

@@ -146,12 +146,21 @@ class BaseTrainer(object):
         n_pending = 0
         t0 = end = time.time()
 
+        engine_sums = phase == "train" and self.engine is not None and hasattr(self.engine, "take_loss_sum")
+        if engine_sums:
+            self.engine.take_loss_sum()                     # (steps taken outside this epoch)
+
         def flush():
             nonlocal n_pending
             if n_pending:
-                for l in self.loss_stats:
-                    avg_loss_stats[l].update(float(dev_sums[l].item()) / n_pending, n_pending)
-                    dev_sums[l] = None
+                if engine_sums:                             # the step engine accumulates its loss inside the step (one graph node)
+                    tot = self.engine.take_loss_sum()
+                    for l in self.loss_stats:
+                        avg_loss_stats[l].update(tot / n_pending, n_pending)
+                else:
+                    for l in self.loss_stats:
+                        avg_loss_stats[l].update(float(dev_sums[l].item()) / n_pending, n_pending)
+                        dev_sums[l] = None
                 n_pending = 0
 
         if self.engine is not None and self.optimizer is not None:
@@ -175,9 +184,10 @@ class BaseTrainer(object):
                     if self.exchange is not None:
                         self.exchange.sync()
                     self.optimizer.step()
-            for l in self.loss_stats:
-                v = loss_stats[l].detach().float().mean()
-                dev_sums[l] = v.clone() if dev_sums[l] is None else dev_sums[l] + v
+            if not engine_sums:
+                for l in self.loss_stats:
+                    v = loss_stats[l].detach().float().mean()
+                    dev_sums[l] = v.clone() if dev_sums[l] is None else dev_sums[l] + v
             n_pending += 1
             batch_time.update(time.time() - end)
             end = time.time()

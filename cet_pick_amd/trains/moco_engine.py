@@ -32,6 +32,9 @@ class MocoStepEngine:
         self._one = torch.ones((), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self._loss_buf = self.loss
+        # running sum of the steps' losses since take_loss_sum(): accumulated by one launch INSIDE the step (a graph node) - run_epoch's
+        # meters read it at print time instead of launching a mean and an add behind every step
+        self.loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
         d = _dist()
         self.world = d.get_world_size() if d else 1
         self.dist_on = H._distributed()
@@ -241,8 +244,15 @@ class MocoStepEngine:
                     grad_scale=1.0 / self.world)
         if self._images is not None:
             self._images.refresh("q")                  # next step's forward / data-gradient images of encoder_q
+        self.loss_sum.add_(self.loss)
         H.stamp("step:end")
         return self.loss
+
+    def take_loss_sum(self):
+        """Sum of the losses of the steps since the last call (one host sync), and reset."""
+        v = float(self.loss_sum.item())
+        self.loss_sum.zero_()
+        return v
 
     @staticmethod
     def _drain_watchdog():
