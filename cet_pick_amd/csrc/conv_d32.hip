@@ -60,6 +60,12 @@ struct D32Params {
     int N, D, H, W;
     unsigned x_bytes, out_bytes, w_bytes;
     int co_total;             // channels of an output voxel in memory (CO, or a multiple of 64: blockIdx.y = 64-column block, one image each)
+    // up-convolution epilogue (1 x 1 products only; up_co > 0): column j = (a 2 + b) up_co + co of input voxel (y, x) goes to
+    // out[n][2 y + a][2 x + b][co] of an (N, up_ho, up_wo, up_stride)-channel tensor as relu(scale[co] acc + shift[co]) - the pixel shuffle,
+    // the folded BatchNorm + bias and the ReLU of mi_upconv_tail_fwd, written straight into the concatenation's first up_co channels
+    int up_co, up_ho, up_wo, up_stride;
+    const float* up_scale;
+    const float* up_shift;
 };
 
 // CIN: 16, 32 or 64 input channels.  NZT: 1 (2-D layers: D planes are independent images) or 3 z taps.  DIL: xy dilation (1 or 4).
@@ -253,6 +259,22 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT, KSZ>::LDS <= 8
     // ---- epilogue: C/D layout col = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 h = (y & 3, x) of the row block ----
 #pragma unroll
     for (int ch = 0; ch < G::NCH; ++ch) {
+        if (KSZ == 1 && p.up_co > 0) {                               // (uniform) the up-convolution's shuffled, normalised output
+            const int col = co0 + ch * 32 + l32, ab = col / p.up_co, co = col - ab * p.up_co;
+            const float sc = p.up_scale[co], sh = p.up_shift[co];
+#pragma unroll
+            for (int i = 0; i < G::BPW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int yo = 2 * (y0 + by_[i] + (m >> 3)) + (ab >> 1), xo = 2 * (x0 + bx_[i] + (m & 7)) + (ab & 1);
+                    const float v = fmaxf(fmaf(acc[i][ch][r], sc, sh), 0.f);
+                    const unsigned off = (yo < p.up_ho && xo < p.up_wo)
+                                             ? 4u * (unsigned)(((((long)n * p.D + z0) * p.up_ho + yo) * p.up_wo + xo) * p.up_stride + co) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, (int)off, 0, 0);
+                }
+            continue;
+        }
         const float bv = p.bias ? p.bias[co0 + ch * 32 + l32] : 0.f;
 #pragma unroll
         for (int i = 0; i < G::BPW; ++i)
@@ -402,6 +424,36 @@ extern "C" int mi_conv_d32_1x1_fwd_f32(const float* x, const void* wimg, const f
         else if (Ci == 128) hipLaunchKernelGGL((conv_d32_kernel<128, 1, 1, 64, 8, 1>), g, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv_d32_kernel<256, 1, 1, 64, 8, 1>), g, dim3(256), 0, s, p);
     }
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+// The 2 x 2 / stride-2 transposed convolution of an up-convolution block at inference (unet.py:251-317,319-399) in ONE launch: the 1 x 1
+// product to 4 Co columns (kind 4; wimg = mi_conv_d64_prep_co(w, img, Ci, 4 Co, 1)) with the pixel shuffle, scale / shift (evaluation-mode
+// BatchNorm with the bias folded in) and ReLU in its epilogue, written into out (N, Ho, Wo, cstride)[..., 0:Co] - the concatenation buffer
+// whose channels Co.. the caller fills with the encoder feature.  x (N, H, W, Ci); Ho in {2 H - 1, 2 H}, Wo likewise.
+extern "C" int mi_conv_d32_upconv_fwd_f32(const float* x, const void* wimg, const float* scale, const float* shift, float* out, int N,
+                                          int H, int W, int Ci, int Co, int Ho, int Wo, int cstride, mi_stream_t stream) {
+    if (!x || !wimg || !scale || !shift || !out || N < 1) return MI_E_ARG;
+    const int C4 = 4 * Co;
+    if ((Ci != 32 && Ci != 64 && Ci != 128) || C4 % 64 || C4 < 64 || C4 > 512 || Co % 32 || H % 8 || W % 16) return MI_E_UNSUPPORTED;
+    if (Ho > 2 * H || Ho < 2 * H - 1 || Wo > 2 * W || Wo < 2 * W - 1 || cstride < Co) return MI_E_ARG;
+    if (4l * N * Ho * Wo * cstride >= 0x7fff0000l || 4l * N * H * W * Ci >= 0x7fff0000l) return MI_E_UNSUPPORTED;
+    D32Params p = {};
+    p.x = x; p.wimg = (const unsigned char*)wimg; p.bias = nullptr; p.out = out; p.relu = 1;
+    p.N = N; p.D = 1; p.H = H; p.W = W;
+    p.x_bytes = (unsigned)(4l * N * H * W * Ci);
+    p.out_bytes = (unsigned)(4l * N * Ho * Wo * cstride);
+    p.co_total = C4;
+    p.up_co = Co; p.up_ho = Ho; p.up_wo = Wo; p.up_stride = cstride; p.up_scale = scale; p.up_shift = shift;
+    p.w_bytes = (unsigned)mi_conv_d64_image_bytes(Ci, 1);
+    const long grid = (long)N * (H / 8) * (W / 16);
+    if (grid > 0x7fffffffl) return MI_E_UNSUPPORTED;
+    const dim3 g((unsigned)grid, 1);
+    hipStream_t s = (hipStream_t)stream;
+    if (Ci == 32) hipLaunchKernelGGL((conv_d32_kernel<32, 1, 1, 64, 8, 1>), g, dim3(256), 0, s, p);
+    else if (Ci == 64) hipLaunchKernelGGL((conv_d32_kernel<64, 1, 1, 64, 8, 1>), g, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_d32_kernel<128, 1, 1, 64, 8, 1>), g, dim3(256), 0, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

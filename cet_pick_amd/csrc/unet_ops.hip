@@ -415,6 +415,24 @@ extern "C" int mi_upconv_tail_fwd(const float* t, const float* scale, const floa
     return MI_OK;
 }
 
+// dst[m][c0 : c0 + Cs] = src[m][:] for the M rows of a (M, Ct) tensor: the encoder feature into the concatenation buffer whose first
+// channels the up-convolution's fused epilogue writes (mi_conv_d32_upconv_fwd_f32)
+__global__ __launch_bounds__(256) void copy_channels_into_kernel(const float* src, int Cs, float* dst, int Ct, int c0, long M) {
+    const int CV = Cs >> 2;
+    const long total = M * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / CV;
+        const int cv = (int)(i - m * CV);
+        st4(dst + m * Ct + c0 + 4 * cv, ld4(src + 4 * i));
+    }
+}
+extern "C" int mi_copy_channels_into(const float* src, int Cs, float* dst, int Ct, int c0, long M, mi_stream_t stream) {
+    if (!src || !dst || Cs <= 0 || (Cs & 3) || (Ct & 3) || (c0 & 3) || c0 < 0 || c0 + Cs > Ct || M <= 0) return MI_E_ARG;
+    hipLaunchKernelGGL(copy_channels_into_kernel, dim3(ew_blocks(M * (Cs >> 2))), dim3(256), 0, (hipStream_t)stream, src, Cs, dst, Ct, c0, M);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
 extern "C" int mi_shuffle2x2_bwd(const float* dy, float* dt, int N, int H, int W, int Co, int Ho, int Wo,
                                  mi_stream_t stream) {
     if (!dy || !dt || Co % 4 || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Ho > 2 * H || Wo > 2 * W) return MI_E_ARG;

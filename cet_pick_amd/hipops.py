@@ -1036,14 +1036,36 @@ def upconv_bn_relu_concat(up, bn, dec, enc):
     _f32c(dec, "dec"); _f32c(enc, "enc")
     n, h, w, _ = dec.shape
     co, ce = up.co, enc.shape[-1]
-    t = conv_fwd(dec, up.gemm_view(), 1, 1, 0, owner=up.weight, inference=True)      # (`folded` above: no gradient)
+    lib = L.lib()
+    ci = dec.shape[-1]
     out = torch.empty((n, ho, wo, co + ce), dtype=torch.float32, device=dec.device)
+    if (UPCONV_FUSED and _arith_bf16x3() and PROFILE is None and ci in (32, 64, 128) and co % 32 == 0 and 64 <= 4 * co <= 512
+            and h % 8 == 0 and w % 16 == 0 and _phys_ok(up.gemm_view())):
+        # the product, the pixel shuffle, the folded BatchNorm and the ReLU in ONE launch (conv_d32.hip, 1 x 1 form with the
+        # up-convolution epilogue) straight into the concatenation; the encoder feature goes into the other channels
+        wv = up.gemm_view()
+        key = (wv.data_ptr(), up.weight._version, WEIGHT_EPOCH, ci, co, "up")
+        wc = getattr(up.weight, "_mi_d32_up", None)
+        if wc is None or wc[0] != key:
+            img = torch.empty((4 * co // 64) * int(lib.mi_conv_d64_image_bytes(ci, 1)), dtype=torch.uint8, device=dec.device)
+            L.check(lib.mi_conv_d64_prep_co(L.ptr(wv), L.ptr(img), ci, 4 * co, 1, L.stream()), "mi_conv_d64_prep_co")
+            wc = (key, img)
+            up.weight._mi_d32_up = wc
+        rc = lib.mi_conv_d32_upconv_fwd_f32(L.ptr(dec), L.ptr(wc[1]), L.ptr(cache[1]), L.ptr(cache[2]), L.ptr(out), n, h, w, ci, co,
+                                            ho, wo, co + ce, L.stream())
+        if rc == 0:
+            L.check(lib.mi_copy_channels_into(L.ptr(enc), ce, L.ptr(out), co + ce, co, n * ho * wo, L.stream()), "mi_copy_channels_into")
+            return out
+        if rc != -3:
+            L.check(rc, "mi_conv_d32_upconv_fwd_f32")
+    t = conv_fwd(dec, up.gemm_view(), 1, 1, 0, owner=up.weight, inference=True)      # (`folded` above: no gradient)
     L.check(L.lib().mi_upconv_tail_fwd(L.ptr(t), L.ptr(cache[1]), L.ptr(cache[2]), L.ptr(enc), L.ptr(out), n, h, w, co, ce, ho, wo,
                                        L.stream()), "mi_upconv_tail_fwd")
     return out
 
 
 FOLD_EVAL_BN = os.environ.get("CETPICK_FOLD_BN", "1") != "0"
+UPCONV_FUSED = os.environ.get("CETPICK_UPCONV_FUSED", "1") != "0"       # the transposed convolution's product with the tail in its epilogue
 
 
 def convnd_weight_param(co, ci, k3, device=None):

@@ -348,6 +348,16 @@ int mi_conv_d64_prep_co(const float* w, void* img, int Ci, int Co, int ntap, mi_
  * up to 512 (mi_conv_d64_prep_co(w, img, Ci, Co, 1)); Ci 32 / 64 / 128 / 256; H % 8 == 0, W % 16 == 0.  MI_NO_D32_1X1=1: off. */
 int mi_conv_d32_1x1_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W,
                             int Ci, int Co, mi_stream_t stream);
+/* The 2 x 2 / stride-2 transposed convolution of an up-convolution block at inference (unet.py:251-317,319-399) in ONE launch: the
+ * 1 x 1 product to 4 Co columns with the pixel shuffle, scale / shift (evaluation-mode BatchNorm, bias folded in) and ReLU in its
+ * epilogue, written into out (N, Ho, Wo, cstride)[..., 0:Co] - the first Co channels of the concatenation, whose channels Co.. the
+ * caller fills with the encoder feature.  wimg: mi_conv_d64_prep_co(w, img, Ci, 4 Co, 1).  Ci 32 / 64 / 128, Co a multiple of 32 with
+ * 64 <= 4 Co <= 512, H % 8 == 0, W % 16 == 0; MI_E_UNSUPPORTED otherwise (then: the product + mi_upconv_tail_fwd). */
+/* dst[m][c0 : c0 + Cs] = src[m][:] over the M rows of a (M, Ct) tensor (channel counts and c0 multiples of 4): the encoder feature
+ * into the concatenation buffer of an up-convolution block (torch.cat((up, enc), 1), unet.py:392) behind mi_conv_d32_upconv_fwd_f32. */
+int mi_copy_channels_into(const float* src, int Cs, float* dst, int Ct, int c0, long M, mi_stream_t stream);
+int mi_conv_d32_upconv_fwd_f32(const float* x, const void* wimg, const float* scale, const float* shift, float* out, int N, int H,
+                               int W, int Ci, int Co, int Ho, int Wo, int cstride, mi_stream_t stream);
 int mi_conv_d64_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W, int Ci,
                         int Co, mi_stream_t stream);
 int mi_conv_d32_fwd_f32(const float* x, const void* wimg, const float* bias, float* y, int relu, int N, int D, int H, int W,

@@ -86,10 +86,13 @@ def test_narrow_tile_forward_matches_wide_tile_and_float64(shape, co, k, pad, di
 
 
 @pytest.mark.parametrize("n,h,w,ho,wo,co,ce", [(2, 8, 8, 16, 16, 32, 32), (3, 5, 7, 9, 14, 64, 64), (1, 16, 16, 31, 31, 128, 128),
-                                              (2, 4, 4, 8, 7, 32, 64)])
+                                              (2, 4, 4, 8, 7, 32, 64),
+                                              (2, 16, 16, 32, 32, 32, 32), (1, 8, 32, 15, 63, 64, 32), (2, 8, 16, 16, 31, 32, 64)])
 def test_upconv_tail_equals_shuffle_batchnorm_relu_concat(n, h, w, ho, wo, co, ce):
     """mi_upconv_tail_fwd (inference: pixel shuffle + transposed-convolution bias + evaluation-mode BatchNorm + ReLU + concat with the
-    encoder feature in ONE pass, unet.py:319-399) against the separate passes, odd (auto-cropped) extents included."""
+    encoder feature in ONE pass, unet.py:319-399) against the separate passes, odd (auto-cropped) extents included.  Round 5: where the
+    1 x 1 product runs on conv_d32.hip (rows % 8, columns % 16, <= 128 input channels: the last three cases) the tail is the product's
+    EPILOGUE (mi_conv_d32_upconv_fwd_f32 + mi_copy_channels_into) - same comparison, and the two-launch form (UPCONV_FUSED off) too."""
     from cet_pick_amd import hipops as H
     g = torch.Generator().manual_seed(n + h + wo + co)
     up = H.HipConvTranspose2x2(2 * co, co)
@@ -107,6 +110,17 @@ def test_upconv_tail_equals_shuffle_batchnorm_relu_concat(n, h, w, ho, wo, co, c
     assert fused.shape == ref.shape == (n, ho, wo, co + ce)
     assert torch.equal(fused[..., co:], ref[..., co:])
     assert float((fused - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    in_epilogue = h % 8 == 0 and w % 16 == 0 and 2 * co <= 128
+    assert (getattr(up.weight, "_mi_d32_up", None) is not None) == in_epilogue
+    if in_epilogue:
+        saved, H.UPCONV_FUSED = H.UPCONV_FUSED, False
+        try:
+            with torch.no_grad():
+                two = H.upconv_bn_relu_concat(up, bn, dec, enc)
+        finally:
+            H.UPCONV_FUSED = saved
+        assert torch.equal(two[..., co:], fused[..., co:])
+        assert float((two - fused).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("shape,co,k,pad", [((3, 1, 37, 41, 32), 32, (1, 1, 1), (0, 0, 0)),      # last layer of the U-Net, ragged rows
