@@ -59,6 +59,7 @@ SIGNATURES = {
     "mi_smallk_image_bytes": (_Z, [_I, _I]),
     "mi_smallk_prep": (_I, [_P, _P, _I, _I, _P]),
     "mi_smallk_fwd_f32": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _L, _I, _P]),
+    "mi_smallk_heads_fwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _L, _I, _P]),
     "mi_convnd_wgrad_slabs_batch_f32": (_I, [_P, _P, _P, _P] + [_I] * 14 + [_Z, _P, _P]),
     "mi_convnd_wgrad_slabs_f32": (_I, [_P, _P, _P] + [_I] * 13 + [_P, _Z, _P, _P]),
     "mi_splitk_reduce_batch": (_I, [_P, _P, _P, _P, _I, _P]),

@@ -156,7 +156,131 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(SmallKParams p) {
     }
 }
 
+// ---- the detector's two heads over the feature volume in ONE pass (round 5; unet_small.py:86-97 + models/utils.py: `proj` =
+// normalize(Conv3d(C, 32, (3,1,1))(v)), `hm` = Conv3d(C, K <= 4, (3,1,1))(v)) ------------------------------------------------------------
+// smallk_fwd_kernel<1> for the 32 `proj` columns with (a) the L2 normalisation of a row in the epilogue - a row's 32 columns sit in the
+// 32 lanes of a half-wave: four DPP butterflies and one swizzle per row, no second pass over the 1 GB volume - and (b) the `hm` outputs
+// as a by-product of the A fragments: a lane holds 8 of its row's K values per k-step, so K_hm dot products cost 8 K_hm FMAs per k-step
+// on the vector unit (f32, as mi_zhead_fwd), the two k-halves of a row meet by one swizzle - no third pass over the volume either.
+struct SmallKHeadParams {
+    SmallKParams s;
+    const float* w_hm;        // [3][Ci][K_hm] (HipZHead's storage)
+    float* y_hm;              // (M, K_hm)
+    int k_hm;
+};
+
+__device__ __forceinline__ float half_sum32(float v) {          // sum over the 32 lanes of this lane's half-wave, in every lane
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401f));                      // lane ^ 16
+    return v;
+}
+
+template <int KH>
+__global__ __launch_bounds__(256) void smallk_head_kernel(SmallKHeadParams hp) {
+    const SmallKParams& p = hp.s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    const long m0 = (long)blockIdx.x * 128 + wave * 32;
+    const __amdgpu_buffer_rsrc_t xrs = rsrc_sk(p.x, p.x_bytes), irs = rsrc_sk(p.img, p.img_bytes);
+    const long m = m0 + l32;
+    const bool row_ok = m < p.M;
+    const int cpt = p.Ci >> 4, KS = 3 * cpt;
+    const int z = (int)((m / p.plane) % p.D);
+    auto a_off = [&](int ks) -> unsigned {
+        const int t = ks / cpt, c0 = (ks - t * cpt) * 16 + 8 * h;
+        const int zz = z + t - 1;
+        const bool ok = row_ok && zz >= 0 && zz < p.D;
+        return ok ? 4u * (unsigned)((m + (long)(t - 1) * p.plane) * p.Ci + c0) : 0x80000000u;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float hm[KH];
+#pragma unroll
+    for (int k = 0; k < KH; ++k) hm[k] = 0.f;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    u32x4 araw[2][2], braw[2][3];
+    auto fetch = [&](int ks, auto SETc) {
+        constexpr int SET = decltype(SETc)::value;
+        const unsigned ao = ks < KS ? a_off(ks) : 0x80000000u;
+        araw[SET][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)ao, 0, 0);
+        araw[SET][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(ao + 16u), 0, 0);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const unsigned bo = ks < KS ? (unsigned)(((long)ks * 3 + pl) * 64 + lane) * 16u : 0x80000000u;
+            braw[SET][pl] = __builtin_amdgcn_raw_buffer_load_b128(irs, (int)bo, 0, 0);
+        }
+    };
+    auto step = [&](int ks, auto SETc) {
+        constexpr int SET = decltype(SETc)::value;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(araw[SET][0][e]); v[4 + e] = __uint_as_float(araw[SET][1][e]); }
+        // hm: this lane's 8 K values of its row against w_hm[tap][c0 + e][k] (rows outside the volume were loaded as zeros)
+        const float* wr = hp.w_hm + (long)(ks / cpt) * p.Ci * KH + (long)((ks % cpt) * 16 + 8 * h) * KH;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int k = 0; k < KH; ++k) hm[k] = fmaf(v[e], wr[e * KH + k], hm[k]);
+        bf16x8 af[3], bf[3];
+        cut8k(v, af);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bf[pl] = __builtin_bit_cast(bf16x8, braw[SET][pl]);
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[pr]], bf[PB[pr]], acc, 0, 0, 0);
+    };
+    using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+    fetch(0, S0{});
+    for (int ks = 0; ks < KS; ks += 2) {
+        fetch(ks + 1, S1{});
+        step(ks, S0{});
+        fetch(ks + 2, S0{});
+        if (ks + 1 < KS) step(ks + 1, S1{});
+    }
+    // hm: the two k-halves of row l32 sit in lanes l32 and l32 + 32
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+        const float o = __shfl_xor(hm[k], 32, 64);
+        if (h == 0 && row_ok) hp.y_hm[m * KH + k] = hm[k] + o;
+    }
+    // proj: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h: normalise every row over its 32 columns (F.normalize: eps 1e-12)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float t = acc[r];
+        const float ss = half_sum32(t * t);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        if (row < p.M) p.y[row * 32 + l32] = t * inv;
+    }
+}
+
 }  // namespace
+
+/* The detector's heads in one pass over the feature volume x (M = N D H W rows of Ci channels; `plane` = H W, D planes per sample):
+ *   y_proj (M, 32) = normalize(conv(3,1,1)(x; img))       img: mi_smallk_prep of the (3, 1, 1) weights [3][Ci][32] (K = 3 Ci)
+ *   y_hm   (M, K)  = conv(3,1,1)(x; w_hm), K <= 4         w_hm: [3][Ci][K] f32 (no bias), f32 FMAs as mi_zhead_fwd
+ * (unet_small.py:86-97: `proj` + F.normalize, `hm`).  Ci a multiple of 16 with 3 Ci <= 512; inference only. */
+extern "C" int mi_smallk_heads_fwd_f32(const float* x, const void* img, float* y_proj, const float* w_hm, float* y_hm, int k_hm, long M,
+                                       int Ci, long plane, int D, mi_stream_t stream) {
+    if (!x || !img || !y_proj || !w_hm || !y_hm || M <= 0 || k_hm < 1 || k_hm > 4 || !mi_smallk_image_bytes(3 * Ci, 32)) return MI_E_ARG;
+    if (plane <= 0 || D <= 0 || M % (plane * D) != 0 || 3 * Ci > 512) return MI_E_ARG;
+    if (4l * M * Ci >= 0x7fff0000l || (M + 127) / 128 > 0x7fffffffl) return MI_E_UNSUPPORTED;
+    SmallKHeadParams hp = {};
+    hp.s = SmallKParams{x, (const unsigned char*)img, nullptr, y_proj, M, Ci, 32, 3, 0, plane, D, (unsigned)(4l * M * Ci),
+                        (unsigned)mi_smallk_image_bytes(3 * Ci, 32)};
+    hp.w_hm = w_hm; hp.y_hm = y_hm; hp.k_hm = k_hm;
+    const dim3 grid((unsigned)((M + 127) / 128));
+    hipStream_t s = (hipStream_t)stream;
+    if (k_hm == 1) hipLaunchKernelGGL(smallk_head_kernel<1>, grid, dim3(256), 0, s, hp);
+    else if (k_hm == 2) hipLaunchKernelGGL(smallk_head_kernel<2>, grid, dim3(256), 0, s, hp);
+    else if (k_hm == 3) hipLaunchKernelGGL(smallk_head_kernel<3>, grid, dim3(256), 0, s, hp);
+    else hipLaunchKernelGGL(smallk_head_kernel<4>, grid, dim3(256), 0, s, hp);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
 
 /* Forward convolution with a short reduction, inference path (no gradient form): 1 x 1 (ntaps = 1) or (3, 1, 1) with padding (1, 0, 0)
  * (ntaps = 3: `plane` = H * W rows per z-plane, `D` planes per sample) over channels-last rows x (M, Ci) -> y (M, Co) = act(x . W + bias).

@@ -432,6 +432,32 @@ def _d32_call(x, w, bias, relu, kind, owner=None, out=None):
     return out
 
 
+HEADS_FUSED = os.environ.get("CETPICK_HEADS_FUSED", "1") != "0"
+
+
+def detector_heads_fused(v, proj, hm):
+    """(normalize(proj(v)), hm(v)) for the detector's heads at inference in ONE pass over the feature volume v (N, D, H, W, C) - or None
+    when the pair is not the one conv_smallk.hip's head kernel takes (proj: HipConvNd(C, 32, (3,1,1), padding (1,0,0)), hm: HipZHead(C,
+    K <= 4); unet_small.py:86-97).  The caller has established inference (no gradient)."""
+    if not (HEADS_FUSED and SMALLK and v.is_cuda and v.dim() == 5 and _arith_bf16x3()):
+        return None
+    if not (isinstance(proj, HipConvNd) and isinstance(hm, HipZHead)):
+        return None
+    n, d, h, wd, c = v.shape
+    if (proj.co != 32 or proj.ci != c or tuple(proj.k) != (3, 1, 1) or tuple(proj.pad) != (1, 0, 0) or tuple(proj.dil) != (1, 1, 1)
+            or hm.c != c or not 1 <= hm.k_out <= 4 or c % 16 or 3 * c > 512 or v.numel() * 4 >= 0x7fff0000
+            or not _phys_ok(proj.weight) or not hm.weight.permute(2, 3, 4, 1, 0).is_contiguous()):
+        return None
+    _f32c(v, "v")
+    img = _smallk_image(proj.weight, None, 3 * c, 32)
+    m = n * d * h * wd
+    y = torch.empty((n, d, h, wd, 32), dtype=torch.float32, device=v.device)
+    yh = torch.empty((n, d, h, wd, hm.k_out), dtype=torch.float32, device=v.device)
+    L.check(L.lib().mi_smallk_heads_fwd_f32(L.ptr(v), L.ptr(img), L.ptr(y), L.ptr(hm.weight), L.ptr(yh), hm.k_out, m, c, h * wd, d,
+                                            L.stream()), "mi_smallk_heads_fwd_f32")
+    return y, yh
+
+
 def _smallk_call(x, w, bias, relu, ntaps, out=None, owner=None):
     _f32c(x, "x")
     if not _phys_ok(w):

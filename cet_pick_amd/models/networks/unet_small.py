@@ -156,6 +156,13 @@ class TomoConvUNet(nn.Module):
         v = self.feature_head[0](v, relu=True)
         v = self.feature_head[2](v, relu=True)
         ret = {}
+        if not self.training and not torch.is_grad_enabled() and set(self.heads) == {"hm", "proj"}:
+            # inference: both heads in one pass over the feature volume (proj's normalisation in its epilogue, hm as a by-product)
+            pair = H.detector_heads_fused(v, self.__getattr__("proj"), self.__getattr__("hm"))
+            if pair is not None:
+                ret["proj"] = pair[0].permute(0, 4, 1, 2, 3)
+                ret["hm"] = pair[1].permute(0, 4, 1, 2, 3)
+                return [{k: ret[k] for k in self.heads}]
         for head in self.heads:
             out = self.__getattr__(head)(v)
             if "proj" in head:

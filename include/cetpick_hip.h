@@ -252,6 +252,12 @@ size_t mi_smallk_image_bytes(int K, int Co);
 int mi_smallk_prep(const float* w, void* img, int K, int Co, mi_stream_t stream);
 int mi_smallk_fwd_f32(const float* x, const void* img, const float* bias, float* y, int relu, long M, int Ci, int Co,
                       int ntaps, long plane, int D, mi_stream_t stream);
+/* Round 5: the detector's two heads in ONE pass over the feature volume (unet_small.py:86-97: `proj` = F.normalize(Conv3d(C, 32,
+ * (3,1,1), padding (1,0,0))(v)), `hm` = Conv3d(C, K <= 4, (3,1,1))(v)): y_proj (M, 32) normalised in the epilogue, y_hm (M, K) as a
+ * by-product of the fragments the product loads (f32 FMAs, as mi_zhead_fwd).  img: mi_smallk_prep(w_proj, img, 3 Ci, 32);
+ * w_hm: [3][Ci][K] f32.  M = N D plane rows.  Inference only. */
+int mi_smallk_heads_fwd_f32(const float* x, const void* img, float* y_proj, const float* w_hm, float* y_hm, int k_hm, long M, int Ci,
+                            long plane, int D, mi_stream_t stream);
 int mi_convnd_dgrad_f32(const float* dy, const float* w, float* dx, const float* res,
                         const float* mask, int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh,
                         int kw, int stride, int pd, int ph, int pw, void* ws, size_t ws_bytes,

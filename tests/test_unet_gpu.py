@@ -123,6 +123,35 @@ def test_upconv_tail_equals_shuffle_batchnorm_relu_concat(n, h, w, ho, wo, co, c
         assert float((two - fused).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape,k_hm", [((1, 6, 24, 40, 32), 1), ((2, 3, 9, 7, 32), 1), ((1, 1, 16, 16, 32), 3), ((1, 5, 8, 24, 64), 4)])
+def test_detector_heads_in_one_pass_equal_the_separate_heads(shape, k_hm):
+    """smallk_head_kernel (round 5; unet_small.py:86-97): `proj` = F.normalize(Conv3d(C, 32, (3,1,1))(v)) and `hm` = Conv3d(C, K,
+    (3,1,1))(v) in ONE pass over the feature volume - the normalisation in the product's epilogue, hm from the fragments it loads -
+    against the three separate kernels (short-reduction convolution, L2 normalise, z head) and float64; ragged row counts, one plane
+    (only the centre tap exists), two samples (no tap crosses a sample)."""
+    from cet_pick_amd import hipops as H
+    n, d, h, w, c = shape
+    g = torch.Generator().manual_seed(sum(shape) + k_hm)
+    v = (torch.randn(n, d, h, w, c, generator=g) * torch.exp(torch.randn(n, d, h, w, 1, generator=g))).cuda()
+    proj = H.HipConvNd(c, 32, (3, 1, 1), (1, 0, 0)).cuda()
+    hm = H.HipZHead(c, k_hm).cuda()
+    with torch.no_grad():
+        proj.weight.copy_(torch.randn(proj.weight.shape, generator=g).cuda() * 0.2)
+        hm.weight.copy_(torch.randn(hm.weight.shape, generator=g).cuda() * 0.1)
+        pair = H.detector_heads_fused(v, proj, hm)
+        assert pair is not None
+        sep_p = H.l2_normalize(proj(v).view(-1, 32)).view(n, d, h, w, 32)
+        sep_h = hm(v)
+    x64 = v.double().permute(0, 4, 1, 2, 3)
+    p64 = F.normalize(F.conv3d(x64, proj.weight.double(), padding=(1, 0, 0)), dim=1).permute(0, 2, 3, 4, 1)
+    h64 = F.conv3d(x64, hm.weight.double(), padding=(1, 0, 0)).permute(0, 2, 3, 4, 1)
+    assert float((pair[0].double() - p64).abs().max()) <= 2e-6
+    assert float((sep_p.double() - p64).abs().max()) <= 2e-6
+    sc = float(h64.abs().max())
+    assert float((pair[1].double() - h64).abs().max()) <= 2e-6 * sc
+    assert float((sep_h.double() - h64).abs().max()) <= 2e-6 * sc
+
+
 @pytest.mark.parametrize("shape,co,k,pad", [((3, 1, 37, 41, 32), 32, (1, 1, 1), (0, 0, 0)),      # last layer of the U-Net, ragged rows
                                             ((2, 1, 32, 32, 64), 64, (1, 1, 1), (0, 0, 0)),      # two column blocks per wave
                                             ((1, 1, 16, 24, 256), 64, (1, 1, 1), (0, 0, 0)),     # sixteen k-steps
