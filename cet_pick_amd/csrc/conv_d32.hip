@@ -66,6 +66,10 @@ struct D32Params {
     int up_co, up_ho, up_wo, up_stride;
     const float* up_scale;
     const float* up_shift;
+    // 2 x 2 max-pool of the output as a by-product (2-D 3 x 3 forms; H, W even): pool (N, D, H / 2, W / 2, co_total).  A lane's sixteen
+    // accumulators of a row block are a 4 (y) x 4 (x) patch of ONE column - the four windows of the patch never leave the lane.
+    float* pool;
+    unsigned pool_bytes;
 };
 
 // CIN: 16, 32 or 64 input channels.  NZT: 1 (2-D layers: D planes are independent images) or 3 z taps.  DIL: xy dilation (1 or 4).
@@ -277,16 +281,32 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT, KSZ>::LDS <= 8
         }
         const float bv = p.bias ? p.bias[co0 + ch * 32 + l32] : 0.f;
 #pragma unroll
-        for (int i = 0; i < G::BPW; ++i)
+        for (int i = 0; i < G::BPW; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int y = (y0 + by_[i] + (m >> 3)) * DIL + cy, x = (x0 + bx_[i] + (m & 7)) * DIL + cx, z = z0 + bz_[i];
                 float v = acc[i][ch][r] + bv;
                 if (p.relu) v = fmaxf(v, 0.f);
+                acc[i][ch][r] = v;
                 const unsigned off = 4u * (unsigned)(((((long)n * p.D + z) * p.H + y) * p.W + x) * p.co_total + co0 + ch * 32 + l32);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, (int)off, 0, 0);
             }
+            if (NZT == 1 && DIL == 1 && KSZ == 3 && p.pool) {          // (uniform) the 2 x 2 windows of this lane's 4 x 4 patch
+                const __amdgpu_buffer_rsrc_t prs = d_rsrc(p.pool, p.pool_bytes);
+                const int hp = p.H >> 1, wp = p.W >> 1;
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        const int r0 = 8 * py + 2 * px;              // registers r = 4 y_local + x_local: (2 py, 2 px) .. (2 py + 1, 2 px + 1)
+                        const float v = fmaxf(fmaxf(acc[i][ch][r0], acc[i][ch][r0 + 1]), fmaxf(acc[i][ch][r0 + 4], acc[i][ch][r0 + 5]));
+                        const int yo = ((y0 + by_[i]) >> 1) + py, xo = ((x0 + bx_[i] + 4 * h) >> 1) + px;
+                        const unsigned off = 4u * (unsigned)(((((long)n * p.D + z0) * hp + yo) * wp + xo) * p.co_total + co0 + ch * 32 + l32);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), prs, (int)off, 0, 0);
+                    }
+            }
+        }
     }
   }
 }
@@ -454,6 +474,42 @@ extern "C" int mi_conv_d32_upconv_fwd_f32(const float* x, const void* wimg, cons
     if (Ci == 32) hipLaunchKernelGGL((conv_d32_kernel<32, 1, 1, 64, 8, 1>), g, dim3(256), 0, s, p);
     else if (Ci == 64) hipLaunchKernelGGL((conv_d32_kernel<64, 1, 1, 64, 8, 1>), g, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_d32_kernel<128, 1, 1, 64, 8, 1>), g, dim3(256), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+// kinds 1 and 3 (2-D 3 x 3) with the 2 x 2 max-pool of the result as a second output (unet.py:198-249: conv -> BatchNorm -> ReLU -> MaxPool2d(2),
+// the un-pooled tensor is the skip connection): y (N, D, H, W, Co) and y_pool (N, D, H / 2, W / 2, Co); Co = 32 (kind 1) or 64 / 128 / 256
+// (kind 3); H, W multiples of 16.  The images are those of mi_conv_d32_prep / mi_conv_d64_prep_co.
+extern "C" int mi_conv_d32_fwd_pool_f32(const float* x, const void* wimg, const float* bias, float* y, float* y_pool, int relu, int N, int D,
+                                        int H, int W, int Ci, int Co, mi_stream_t stream) {
+    if (!x || !wimg || !y || !y_pool || N < 1) return MI_E_ARG;
+    if (H % 16 || W % 16) return MI_E_UNSUPPORTED;
+    D32Params p = {};
+    p.x = x; p.wimg = (const unsigned char*)wimg; p.bias = bias; p.out = y; p.relu = relu;
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.x_bytes = (unsigned)(4l * N * D * H * W * Ci);
+    p.out_bytes = (unsigned)(4l * N * D * H * W * Co);
+    p.co_total = Co;
+    p.pool = y_pool; p.pool_bytes = (unsigned)(4l * N * D * (H / 2) * (W / 2) * Co);
+    hipStream_t s = (hipStream_t)stream;
+    if (Co == 32 && (Ci == 16 || Ci == 32 || Ci == 64)) {
+        p.w_bytes = (unsigned)mi_conv_d32_image_bytes(Ci, 9);
+        const long grid = (long)N * D * (H / 16) * (W / 16);
+        if (grid > 0x7fffffffl) return MI_E_UNSUPPORTED;
+        if (Ci == 16) hipLaunchKernelGGL((conv_d32_kernel<16, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p);
+        else if (Ci == 32) hipLaunchKernelGGL((conv_d32_kernel<32, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_d32_kernel<64, 1, 1>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    } else if ((Co == 64 || Co == 128 || Co == 256) && (Ci == 32 || Ci == 64 || Ci == 128 || Ci == 256)) {
+        p.w_bytes = (unsigned)mi_conv_d64_image_bytes(Ci, 9);
+        const long grid = (long)N * D * (H / (Ci >= 128 ? 8 : 16)) * (W / 16);
+        if (grid > 0x7fffffffl) return MI_E_UNSUPPORTED;
+        const dim3 g((unsigned)grid, (unsigned)(Co / 64));
+        if (Ci == 32) hipLaunchKernelGGL((conv_d32_kernel<32, 1, 1, 64, 16>), g, dim3(256), 0, s, p);
+        else if (Ci == 64) hipLaunchKernelGGL((conv_d32_kernel<64, 1, 1, 64, 16>), g, dim3(256), 0, s, p);
+        else if (Ci == 128) hipLaunchKernelGGL((conv_d32_kernel<128, 1, 1, 64, 8>), g, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_d32_kernel<256, 1, 1, 64, 8>), g, dim3(256), 0, s, p);
+    } else return MI_E_UNSUPPORTED;
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

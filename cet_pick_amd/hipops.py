@@ -389,7 +389,10 @@ def _d32_kind(x5shape, ci, co, k3, stride, p3, d3, inference):
     return int(L.lib().mi_conv_d32_kind(n, d, h, wd, ci, co, *k3, *d3))
 
 
-def _d32_call(x, w, bias, relu, kind, owner=None, out=None):
+POOL_FUSED = os.environ.get("CETPICK_POOL_FUSED", "1") != "0"
+
+
+def _d32_call(x, w, bias, relu, kind, owner=None, out=None, pool=False):
     """y = act(conv(x, w) + bias) on conv_d32.hip; the pre-cut weight image is kept on `owner` (rebuilt when the weights change)."""
     _f32c(x, "x")
     if not _phys_ok(w):
@@ -419,6 +422,12 @@ def _d32_call(x, w, bias, relu, kind, owner=None, out=None):
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
     elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
         raise L.HipExtensionError("`out` must be a contiguous fp32 %s tensor on %s" % (shape, x.device))
+    if pool:                                          # kinds 1 / 3: the 2 x 2 max-pool of the result as a second output
+        pooled = torch.empty(tuple(x.shape[:-3]) + (h // 2, wd // 2, co), dtype=torch.float32, device=x.device)
+        L.check(lib.mi_conv_d32_fwd_pool_f32(L.ptr(x), L.ptr(cache[1]), L.ptr(bias), L.ptr(out), L.ptr(pooled), int(relu), n, d, h, wd, ci,
+                                             co, L.stream()), "mi_conv_d32_fwd_pool_f32")
+        return out, pooled
+
     def call():
         if kind == 4:
             return L.check(lib.mi_conv_d32_1x1_fwd_f32(L.ptr(x), L.ptr(cache[1]), L.ptr(bias), L.ptr(out), int(relu), n, d, h, wd, ci, co,
@@ -965,7 +974,7 @@ class _ConvFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
-def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None):
+def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None, pool=False):
     """y = act(conv(x, w) + bias[co]) in one launch (mi_convnd_fwd_bias_f32), inference only: no autograd node.  `out`: a
     contiguous (N, [D,] Ho, Wo, Co) tensor (or a leading-axis slice of one) that receives the result."""
     _f32c(x, "x")
@@ -976,6 +985,12 @@ def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None):
     if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
         raise L.HipExtensionError("conv_bias_fwd is inference only (no autograd node)")
     kind = _d32_kind(_as5d(x).shape, x.shape[-1], w.shape[0], k3, stride, p3, None, True)
+    if pool:
+        # (y, maxpool2x2(y)) in one launch where the patch-resident 2-D kernel runs and nothing else asks for the result elsewhere;
+        # None: the caller pools by itself
+        if kind in (1, 3) and out is None and POOL_FUSED and PROFILE is None and x.dim() == 4:
+            return _d32_call(x, w, _f32c(bias, "bias"), relu, kind, pool=True)
+        return None
     if kind == 4:                                     # 1 x 1: the tile-resident kernel (in front of the short-reduction one)
         return _d32_call(x, w, _f32c(bias, "bias"), relu, kind, out=out)
     taps = _smallk_taps(x, w, k3, stride, p3, None, nd5, True)
@@ -1009,16 +1024,18 @@ def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None):
     return out
 
 
-def conv_bn(conv, bn, x, relu=False):
+def conv_bn(conv, bn, x, relu=False, pool=False):
     """bn(conv(x), relu) for a HipConv2d / HipConvNd followed by a HipBatchNorm.  At inference (evaluation-mode BatchNorm with
     running statistics, no gradient) the BatchNorm folds into the convolution: w' = w * gamma / sqrt(var + eps) per output
     channel, bias = beta - mean * gamma / sqrt(var + eps), one launch with a bias + ReLU epilogue and no BatchNorm pass over
     the activation (reference: conv -> BatchNorm2d -> ReLU, models/networks/unet.py:198-249,319-399).  The folded weights are
-    kept on the BatchNorm module and rebuilt when any of the five tensors they come from changes."""
+    kept on the BatchNorm module and rebuilt when any of the five tensors they come from changes.  pool: returns (y, maxpool 2 x 2
+    ceil-mode of y) - unet.py:198-249's down-convolution block."""
     folded = (not bn.training and bn.track_running_stats and not torch.is_grad_enabled() and x.is_cuda and
               getattr(conv, "dil", None) in (None, (1, 1, 1)) and FOLD_EVAL_BN)
     if not folded:
-        return bn(conv(x), relu=relu)
+        y = bn(conv(x), relu=relu)
+        return (y, maxpool2d_ceil(y, 2)) if pool else y
     src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
     key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (float(bn.eps), WEIGHT_EPOCH)
     cache = getattr(bn, "_folded", None)
@@ -1034,6 +1051,14 @@ def conv_bn(conv, bn, x, relu=False):
         if not _phys_ok(wf):
             raise L.HipExtensionError("folded convolution weight left the kernel layout")
         bn._folded = cache
+    if pool:
+        # pool = True: (y, MaxPool2d(2, ceil_mode)(y)) - in one launch where the patch-resident kernel takes the layer (the pool is
+        # its epilogue's by-product), else the pooling pass behind it
+        both = conv_bias_fwd(x, cache[1], cache[2], conv.k, conv.stride, conv.pad, relu, pool=True)
+        if both is not None:
+            return both
+        y = conv_bias_fwd(x, cache[1], cache[2], conv.k, conv.stride, conv.pad, relu)
+        return y, maxpool2d_ceil(y, 2)
     return conv_bias_fwd(x, cache[1], cache[2], conv.k, conv.stride, conv.pad, relu)
 
 

@@ -37,8 +37,11 @@ class DownConv(nn.Module):
 
     def forward(self, x):
         y = H.conv_bn(self.conv1, self.norm0, x, relu=True)
+        if self.pooling:
+            y, pooled = H.conv_bn(self.conv2, self.norm1, y, relu=True, pool=True)     # (inference: the pool is conv2's epilogue)
+            return pooled, y
         y = H.conv_bn(self.conv2, self.norm1, y, relu=True)
-        return (H.maxpool2d_ceil(y, 2) if self.pooling else y), y
+        return y, y
 
 
 class UpConv(nn.Module):

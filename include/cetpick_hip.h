@@ -359,6 +359,12 @@ int mi_conv_d32_1x1_fwd_f32(const float* x, const void* wimg, const float* bias,
  * epilogue, written into out (N, Ho, Wo, cstride)[..., 0:Co] - the first Co channels of the concatenation, whose channels Co.. the
  * caller fills with the encoder feature.  wimg: mi_conv_d64_prep_co(w, img, Ci, 4 Co, 1).  Ci 32 / 64 / 128, Co a multiple of 32 with
  * 64 <= 4 Co <= 512, H % 8 == 0, W % 16 == 0; MI_E_UNSUPPORTED otherwise (then: the product + mi_upconv_tail_fwd). */
+/* mi_conv_d32_kind 1 / 3 (2-D 3 x 3) with the 2 x 2 max-pool of the result as a SECOND output (unet.py:198-249: conv -> BatchNorm ->
+ * ReLU -> MaxPool2d(2, ceil_mode) - the un-pooled tensor is the skip connection): y (N, D, H, W, Co), y_pool (N, D, H / 2, W / 2, Co);
+ * H, W multiples of 16; images as for mi_conv_d32_fwd_f32 / mi_conv_d64_fwd_f32.  A lane's accumulators of a row block are a 4 x 4
+ * patch of one channel: the windows never leave the lane. */
+int mi_conv_d32_fwd_pool_f32(const float* x, const void* wimg, const float* bias, float* y, float* y_pool, int relu, int N, int D, int H,
+                             int W, int Ci, int Co, mi_stream_t stream);
 /* dst[m][c0 : c0 + Cs] = src[m][:] over the M rows of a (M, Ct) tensor (channel counts and c0 multiples of 4): the encoder feature
  * into the concatenation buffer of an up-convolution block (torch.cat((up, enc), 1), unet.py:392) behind mi_conv_d32_upconv_fwd_f32. */
 int mi_copy_channels_into(const float* src, int Cs, float* dst, int Ct, int c0, long M, mi_stream_t stream);

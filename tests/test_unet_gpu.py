@@ -143,8 +143,9 @@ def test_detector_heads_in_one_pass_equal_the_separate_heads(shape, k_hm):
         sep_p = H.l2_normalize(proj(v).view(-1, 32)).view(n, d, h, w, 32)
         sep_h = hm(v)
     x64 = v.double().permute(0, 4, 1, 2, 3)
-    p64 = F.normalize(F.conv3d(x64, proj.weight.double(), padding=(1, 0, 0)), dim=1).permute(0, 2, 3, 4, 1)
-    h64 = F.conv3d(x64, hm.weight.double(), padding=(1, 0, 0)).permute(0, 2, 3, 4, 1)
+    with torch.no_grad():
+        p64 = F.normalize(F.conv3d(x64, proj.weight.double(), padding=(1, 0, 0)), dim=1).permute(0, 2, 3, 4, 1)
+        h64 = F.conv3d(x64, hm.weight.double(), padding=(1, 0, 0)).permute(0, 2, 3, 4, 1)
     assert float((pair[0].double() - p64).abs().max()) <= 2e-6
     assert float((sep_p.double() - p64).abs().max()) <= 2e-6
     sc = float(h64.abs().max())
