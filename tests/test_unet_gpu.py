@@ -123,6 +123,33 @@ def test_upconv_tail_equals_shuffle_batchnorm_relu_concat(n, h, w, ho, wo, co, c
         assert float((two - fused).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("ci,co,h,w", [(16, 32, 32, 48), (32, 32, 16, 16), (32, 64, 32, 32), (64, 64, 16, 48), (64, 128, 16, 32), (128, 128, 16, 16)])
+def test_down_convolution_pool_in_the_epilogue_equals_the_pooling_pass(ci, co, h, w):
+    """mi_conv_d32_fwd_pool_f32 (round 5; unet.py:198-249): conv -> folded BatchNorm -> ReLU with the 2 x 2 max-pool as a second output of
+    the same launch: the un-pooled tensor equals the plain launch's bit for bit, the pooled one equals MaxPool2d(2, ceil_mode) of it bit
+    for bit (every form of the kernel: 32 columns, 64-column blocks, 16 x 16 and 16 x 8 tiles)."""
+    from cet_pick_amd import hipops as H
+    g = torch.Generator().manual_seed(ci + co + h)
+    conv = H.HipConv2d(ci, co, 3, 1, 1).cuda()
+    bn = H.HipBatchNorm(co)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(co, generator=g) + 0.5); bn.bias.copy_(torch.randn(co, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(co, generator=g) * 0.2); bn.running_var.copy_(torch.rand(co, generator=g) + 0.5)
+    bn = bn.cuda().eval()
+    x = torch.randn(3, h, w, ci, generator=g).cuda()
+    with torch.no_grad():
+        y, pooled = H.conv_bn(conv, bn, x, relu=True, pool=True)
+        y_plain = H.conv_bn(conv, bn, x, relu=True)
+        saved, H.POOL_FUSED = H.POOL_FUSED, False
+        try:
+            y2, pooled2 = H.conv_bn(conv, bn, x, relu=True, pool=True)
+        finally:
+            H.POOL_FUSED = saved
+    assert torch.equal(y, y_plain) and torch.equal(y2, y_plain)
+    assert pooled.shape == (3, h // 2, w // 2, co)
+    assert torch.equal(pooled, H.maxpool2d_ceil(y_plain, 2)) and torch.equal(pooled2, pooled)
+
+
 @pytest.mark.parametrize("shape,k_hm", [((1, 6, 24, 40, 32), 1), ((2, 3, 9, 7, 32), 1), ((1, 1, 16, 16, 32), 3), ((1, 5, 8, 24, 64), 4)])
 def test_detector_heads_in_one_pass_equal_the_separate_heads(shape, k_hm):
     """smallk_head_kernel (round 5; unet_small.py:86-97): `proj` = F.normalize(Conv3d(C, 32, (3,1,1))(v)) and `hm` = Conv3d(C, K,
