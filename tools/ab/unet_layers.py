@@ -20,9 +20,9 @@ def wrapped(x, w, k, stride, pad, res=None, relu=False, dil=None, **kw):
     return y
 H.conv_fwd = wrapped
 orig_b = H.conv_bias_fwd
-def wrapped_b(x, w, bias, k, stride, pad, relu=False, out=None):     # inference: BatchNorm folded, bias + ReLU epilogue
+def wrapped_b(x, w, bias, k, stride, pad, relu=False, out=None, **kw):     # inference: BatchNorm folded, bias + ReLU epilogue
     before = len(H.PROFILE) if H.PROFILE is not None else 0
-    y = orig_b(x, w, bias, k, stride, pad, relu, out)
+    y = orig_b(x, w, bias, k, stride, pad, relu, out, **kw)
     if H.PROFILE is not None and len(H.PROFILE) > before:
         shapes.append((tuple(x.shape), w.shape[0], k, stride, None))
     return y
