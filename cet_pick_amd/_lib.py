@@ -81,6 +81,7 @@ SIGNATURES = {
     "mi_conv_d64_prep_co": (_I, [_P, _P, _I, _I, _I, _P]),
     "mi_conv_d32_1x1_fwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mi_conv_d32_fwd_pool_f32": (_I, [_P, _P, _P, _P, _P] + [_I] * 7 + [_P]),
+    "mi_conv_d32_fwd_pool_strided_f32": (_I, [_P, _P, _P, _P, _I, _P] + [_I] * 7 + [_P]),
     "mi_copy_channels_into": (_I, [_P, _I, _P, _I, _I, _L, _P]),
     "mi_conv_d32_upconv_fwd_f32": (_I, [_P, _P, _P, _P, _P] + [_I] * 8 + [_P]),
     "mi_conv_d64_fwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -70,6 +70,7 @@ struct D32Params {
     // accumulators of a row block are a 4 (y) x 4 (x) patch of ONE column - the four windows of the patch never leave the lane.
     float* pool;
     unsigned pool_bytes;
+    int pool_stride;          // channels of a pooled voxel in memory (co_total may be the stride of a wider buffer `out` is a channel slice of)
 };
 
 // CIN: 16, 32 or 64 input channels.  NZT: 1 (2-D layers: D planes are independent images) or 3 z taps.  DIL: xy dilation (1 or 4).
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256, (D32Cfg<CIN, NZT, DIL, CO, TYT, KSZ>::LDS <= 8
                         const int r0 = 8 * py + 2 * px;              // registers r = 4 y_local + x_local: (2 py, 2 px) .. (2 py + 1, 2 px + 1)
                         const float v = fmaxf(fmaxf(acc[i][ch][r0], acc[i][ch][r0 + 1]), fmaxf(acc[i][ch][r0 + 4], acc[i][ch][r0 + 5]));
                         const int yo = ((y0 + by_[i]) >> 1) + py, xo = ((x0 + bx_[i] + 4 * h) >> 1) + px;
-                        const unsigned off = 4u * (unsigned)(((((long)n * p.D + z0) * hp + yo) * wp + xo) * p.co_total + co0 + ch * 32 + l32);
+                        const unsigned off = 4u * (unsigned)(((((long)n * p.D + z0) * hp + yo) * wp + xo) * p.pool_stride + co0 + ch * 32 + l32);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), prs, (int)off, 0, 0);
                     }
             }
@@ -481,17 +482,27 @@ extern "C" int mi_conv_d32_upconv_fwd_f32(const float* x, const void* wimg, cons
 // kinds 1 and 3 (2-D 3 x 3) with the 2 x 2 max-pool of the result as a second output (unet.py:198-249: conv -> BatchNorm -> ReLU -> MaxPool2d(2),
 // the un-pooled tensor is the skip connection): y (N, D, H, W, Co) and y_pool (N, D, H / 2, W / 2, Co); Co = 32 (kind 1) or 64 / 128 / 256
 // (kind 3); H, W multiples of 16.  The images are those of mi_conv_d32_prep / mi_conv_d64_prep_co.
+extern "C" int mi_conv_d32_fwd_pool_strided_f32(const float* x, const void* wimg, const float* bias, float* y, int y_cstride, float* y_pool,
+                                                int relu, int N, int D, int H, int W, int Ci, int Co, mi_stream_t stream);
 extern "C" int mi_conv_d32_fwd_pool_f32(const float* x, const void* wimg, const float* bias, float* y, float* y_pool, int relu, int N, int D,
                                         int H, int W, int Ci, int Co, mi_stream_t stream) {
-    if (!x || !wimg || !y || !y_pool || N < 1) return MI_E_ARG;
+    return mi_conv_d32_fwd_pool_strided_f32(x, wimg, bias, y, Co, y_pool, relu, N, D, H, W, Ci, Co, stream);
+}
+// ... with y a CHANNEL SLICE of a wider tensor: voxel v's Co channels at y + v * y_cstride (y_cstride >= Co, a multiple of 4) - the skip
+// connection written straight into the concatenation buffer of the up-convolution block that consumes it (torch.cat((up, enc), 1),
+// unet.py:392): y = cat + Co_up, y_cstride = Co_up + Co.  y_pool stays dense (N, D, H / 2, W / 2, Co).
+extern "C" int mi_conv_d32_fwd_pool_strided_f32(const float* x, const void* wimg, const float* bias, float* y, int y_cstride, float* y_pool,
+                                                int relu, int N, int D, int H, int W, int Ci, int Co, mi_stream_t stream) {
+    if (!x || !wimg || !y || !y_pool || N < 1 || y_cstride < Co || (y_cstride & 3)) return MI_E_ARG;
     if (H % 16 || W % 16) return MI_E_UNSUPPORTED;
+    if (4l * N * D * H * W * y_cstride >= 0x7fff0000l) return MI_E_UNSUPPORTED;
     D32Params p = {};
     p.x = x; p.wimg = (const unsigned char*)wimg; p.bias = bias; p.out = y; p.relu = relu;
     p.N = N; p.D = D; p.H = H; p.W = W;
     p.x_bytes = (unsigned)(4l * N * D * H * W * Ci);
-    p.out_bytes = (unsigned)(4l * N * D * H * W * Co);
-    p.co_total = Co;
-    p.pool = y_pool; p.pool_bytes = (unsigned)(4l * N * D * (H / 2) * (W / 2) * Co);
+    p.out_bytes = (unsigned)(4l * (((long)N * D * H * W - 1) * y_cstride + Co));
+    p.co_total = y_cstride;
+    p.pool = y_pool; p.pool_bytes = (unsigned)(4l * N * D * (H / 2) * (W / 2) * Co); p.pool_stride = Co;
     hipStream_t s = (hipStream_t)stream;
     if (Co == 32 && (Ci == 16 || Ci == 32 || Ci == 64)) {
         p.w_bytes = (unsigned)mi_conv_d32_image_bytes(Ci, 9);

@@ -418,15 +418,26 @@ def _d32_call(x, w, bias, relu, kind, owner=None, out=None, pool=False):
         except AttributeError:
             pass
     shape = tuple(x.shape[:-1]) + (co,)
+    if pool:                                          # kinds 1 / 3: the 2 x 2 max-pool of the result as a second output
+        cstride = co
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        else:
+            # a channel slice of a wider contiguous tensor (the concatenation buffer of the up-convolution block that will consume it)
+            cstride = int(out.stride(-2))
+            want = tuple(cstride * v for v in ([shape[-3] * shape[-2], shape[-2], 1] if len(shape) == 4 else
+                                               [shape[-4] * shape[-3] * shape[-2], shape[-3] * shape[-2], shape[-2], 1])) + (1,)
+            if (tuple(out.shape) != shape or out.dtype != torch.float32 or out.device != x.device or tuple(out.stride()) != want
+                    or cstride < co or cstride % 4 or out.data_ptr() % 16):
+                raise L.HipExtensionError("`out` must be an fp32 %s tensor or a channel slice of a wider contiguous one" % (shape,))
+        pooled = torch.empty(tuple(x.shape[:-3]) + (h // 2, wd // 2, co), dtype=torch.float32, device=x.device)
+        L.check(lib.mi_conv_d32_fwd_pool_strided_f32(L.ptr(x), L.ptr(cache[1]), L.ptr(bias), L.ptr(out), cstride, L.ptr(pooled),
+                                                     int(relu), n, d, h, wd, ci, co, L.stream()), "mi_conv_d32_fwd_pool_strided_f32")
+        return out, pooled
     if out is None:
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
     elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
         raise L.HipExtensionError("`out` must be a contiguous fp32 %s tensor on %s" % (shape, x.device))
-    if pool:                                          # kinds 1 / 3: the 2 x 2 max-pool of the result as a second output
-        pooled = torch.empty(tuple(x.shape[:-3]) + (h // 2, wd // 2, co), dtype=torch.float32, device=x.device)
-        L.check(lib.mi_conv_d32_fwd_pool_f32(L.ptr(x), L.ptr(cache[1]), L.ptr(bias), L.ptr(out), L.ptr(pooled), int(relu), n, d, h, wd, ci,
-                                             co, L.stream()), "mi_conv_d32_fwd_pool_f32")
-        return out, pooled
 
     def call():
         if kind == 4:
@@ -988,8 +999,8 @@ def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None, pool=False):
     if pool:
         # (y, maxpool2x2(y)) in one launch where the patch-resident 2-D kernel runs and nothing else asks for the result elsewhere;
         # None: the caller pools by itself
-        if kind in (1, 3) and out is None and POOL_FUSED and PROFILE is None and x.dim() == 4:
-            return _d32_call(x, w, _f32c(bias, "bias"), relu, kind, pool=True)
+        if kind in (1, 3) and POOL_FUSED and PROFILE is None and x.dim() == 4:
+            return _d32_call(x, w, _f32c(bias, "bias"), relu, kind, pool=True, out=out)
         return None
     if kind == 4:                                     # 1 x 1: the tile-resident kernel (in front of the short-reduction one)
         return _d32_call(x, w, _f32c(bias, "bias"), relu, kind, out=out)
@@ -1024,7 +1035,25 @@ def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None, pool=False):
     return out
 
 
-def conv_bn(conv, bn, x, relu=False, pool=False):
+CONCAT_DIRECT = os.environ.get("CETPICK_CONCAT_DIRECT", "1") != "0"
+
+
+def skip_into_concat_ok(conv, bn, x, co_up):
+    """True when a down-convolution block's last layer (conv -> bn -> ReLU -> pool on x) can write its un-pooled output - the skip
+    connection - straight into the concatenation buffer of the up-convolution block that consumes it, AND that block's transposed
+    convolution will write the other channels there with its fused epilogue (upconv_bn_relu_concat): inference, both on conv_d32.hip."""
+    if not (CONCAT_DIRECT and POOL_FUSED and UPCONV_FUSED and FOLD_EVAL_BN and PROFILE is None and x.is_cuda and x.dim() == 4
+            and not torch.is_grad_enabled() and not bn.training and bn.track_running_stats and _arith_bf16x3()):
+        return False
+    n, h, w, ci = x.shape
+    co = conv.co
+    if co != co_up or co not in (32, 64) or h % 16 or w % 32:          # the up block: 2 co -> co on (h / 2, w / 2), rows % 8, columns % 16
+        return False
+    k3, p3 = _k3(conv.k, False), _p3(conv.pad, False)
+    return _d32_kind((n, 1, h, w, ci), ci, co, k3, conv.stride, p3, None, True) in (1, 3)
+
+
+def conv_bn(conv, bn, x, relu=False, pool=False, out=None):
     """bn(conv(x), relu) for a HipConv2d / HipConvNd followed by a HipBatchNorm.  At inference (evaluation-mode BatchNorm with
     running statistics, no gradient) the BatchNorm folds into the convolution: w' = w * gamma / sqrt(var + eps) per output
     channel, bias = beta - mean * gamma / sqrt(var + eps), one launch with a bias + ReLU epilogue and no BatchNorm pass over
@@ -1034,6 +1063,8 @@ def conv_bn(conv, bn, x, relu=False, pool=False):
     folded = (not bn.training and bn.track_running_stats and not torch.is_grad_enabled() and x.is_cuda and
               getattr(conv, "dil", None) in (None, (1, 1, 1)) and FOLD_EVAL_BN)
     if not folded:
+        if out is not None:
+            raise L.HipExtensionError("conv_bn: `out` needs the folded inference path (skip_into_concat_ok)")
         y = bn(conv(x), relu=relu)
         return (y, maxpool2d_ceil(y, 2)) if pool else y
     src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
@@ -1054,21 +1085,27 @@ def conv_bn(conv, bn, x, relu=False, pool=False):
     if pool:
         # pool = True: (y, MaxPool2d(2, ceil_mode)(y)) - in one launch where the patch-resident kernel takes the layer (the pool is
         # its epilogue's by-product), else the pooling pass behind it
-        both = conv_bias_fwd(x, cache[1], cache[2], conv.k, conv.stride, conv.pad, relu, pool=True)
+        both = conv_bias_fwd(x, cache[1], cache[2], conv.k, conv.stride, conv.pad, relu, pool=True, out=out)
         if both is not None:
             return both
+        if out is not None:
+            raise L.HipExtensionError("conv_bn: `out` (a channel slice) needs the patch-resident kernel (skip_into_concat_ok)")
         y = conv_bias_fwd(x, cache[1], cache[2], conv.k, conv.stride, conv.pad, relu)
         return y, maxpool2d_ceil(y, 2)
+    if out is not None:
+        raise L.HipExtensionError("conv_bn: `out` is the pooled form's (pool=True)")
     return conv_bias_fwd(x, cache[1], cache[2], conv.k, conv.stride, conv.pad, relu)
 
 
-def upconv_bn_relu_concat(up, bn, dec, enc):
+def upconv_bn_relu_concat(up, bn, dec, enc, cat=None):
     """cat(relu(bn(up(dec))), enc) over the channel axis (unet.py:319-399).  At inference one 1 x 1 product + ONE pass that shuffles,
     applies the folded BatchNorm (the transposed convolution's bias included), the ReLU and writes the concatenation
     (mi_upconv_tail_fwd) - instead of shuffle, BatchNorm and concat passes over the feature map."""
     ho, wo = enc.shape[1], enc.shape[2]
     folded = (not bn.training and bn.track_running_stats and not torch.is_grad_enabled() and dec.is_cuda and FOLD_EVAL_BN)
     if not folded:
+        if cat is not None:
+            raise L.HipExtensionError("upconv_bn_relu_concat: `cat` needs the folded inference path")
         return concat_channels(bn(up(dec, ho, wo), relu=True), enc)
     src = (up.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
     key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (float(bn.eps), WEIGHT_EPOCH)
@@ -1084,11 +1121,28 @@ def upconv_bn_relu_concat(up, bn, dec, enc):
                 sh = sh + bn.bias.double()
             cache = (key, sc.float().contiguous(), sh.float().contiguous())
         bn._folded_up = cache
-    _f32c(dec, "dec"); _f32c(enc, "enc")
+    _f32c(dec, "dec")
+    if cat is None:
+        _f32c(enc, "enc")                                # (with `cat`, enc is a channel slice of it: checked below)
     n, h, w, _ = dec.shape
     co, ce = up.co, enc.shape[-1]
     lib = L.lib()
     ci = dec.shape[-1]
+    if cat is not None:
+        # `enc` IS cat[..., co:] (the down-convolution block wrote it there: skip_into_concat_ok): only the first co channels are missing
+        if (tuple(cat.shape) != (n, ho, wo, co + ce) or not cat.is_contiguous() or enc.data_ptr() != cat.data_ptr() + 4 * co):
+            raise L.HipExtensionError("upconv_bn_relu_concat: `cat` is not the buffer `enc` is a channel slice of")
+        wv = up.gemm_view()
+        key = (wv.data_ptr(), up.weight._version, WEIGHT_EPOCH, ci, co, "up")
+        wc = getattr(up.weight, "_mi_d32_up", None)
+        if wc is None or wc[0] != key:
+            img = torch.empty((4 * co // 64) * int(lib.mi_conv_d64_image_bytes(ci, 1)), dtype=torch.uint8, device=dec.device)
+            L.check(lib.mi_conv_d64_prep_co(L.ptr(wv), L.ptr(img), ci, 4 * co, 1, L.stream()), "mi_conv_d64_prep_co")
+            wc = (key, img)
+            up.weight._mi_d32_up = wc
+        L.check(lib.mi_conv_d32_upconv_fwd_f32(L.ptr(dec), L.ptr(wc[1]), L.ptr(cache[1]), L.ptr(cache[2]), L.ptr(cat), n, h, w, ci, co,
+                                               ho, wo, co + ce, L.stream()), "mi_conv_d32_upconv_fwd_f32")
+        return cat
     out = torch.empty((n, ho, wo, co + ce), dtype=torch.float32, device=dec.device)
     if (UPCONV_FUSED and _arith_bf16x3() and PROFILE is None and ci in (32, 64, 128) and co % 32 == 0 and 64 <= 4 * co <= 512
             and h % 8 == 0 and w % 16 == 0 and _phys_ok(up.gemm_view())):

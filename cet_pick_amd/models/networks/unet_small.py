@@ -35,13 +35,21 @@ class DownConv(nn.Module):
         self.norm0 = H.HipBatchNorm(co)
         self.norm1 = H.HipBatchNorm(co)
 
-    def forward(self, x):
+    def forward(self, x, co_up=None):
+        """-> (input of the next level, skip connection, concatenation buffer or None).  co_up: the channels the up-convolution block
+        that consumes the skip connection puts in front of it - at inference, where both layers run on the patch-resident kernel, the skip
+        connection is written straight into that block's concatenation buffer (no concatenation pass)."""
         y = H.conv_bn(self.conv1, self.norm0, x, relu=True)
         if self.pooling:
+            if co_up is not None and H.skip_into_concat_ok(self.conv2, self.norm1, y, co_up):
+                n, h, w, _ = y.shape
+                cat = torch.empty((n, h, w, co_up + self.conv2.co), dtype=torch.float32, device=y.device)
+                skip, pooled = H.conv_bn(self.conv2, self.norm1, y, relu=True, pool=True, out=cat[..., co_up:])
+                return pooled, skip, cat
             y, pooled = H.conv_bn(self.conv2, self.norm1, y, relu=True, pool=True)     # (inference: the pool is conv2's epilogue)
-            return pooled, y
+            return pooled, y, None
         y = H.conv_bn(self.conv2, self.norm1, y, relu=True)
-        return y, y
+        return y, y, None
 
 
 class UpConv(nn.Module):
@@ -56,12 +64,12 @@ class UpConv(nn.Module):
         self.norm1 = H.HipBatchNorm(co)
         self.norm2 = H.HipBatchNorm(co)
 
-    def forward(self, enc, dec):
+    def forward(self, enc, dec, cat=None):
         h, w = dec.shape[1], dec.shape[2]
         ho, wo = enc.shape[1], enc.shape[2]                  # autocrop (:253-266): odd encoder extents lose a row
         if not (2 * h - 1 <= ho <= 2 * h and 2 * w - 1 <= wo <= 2 * w):
             raise L.HipExtensionError("encoder / decoder extents do not match (%s vs 2x%s)" % (tuple(enc.shape), tuple(dec.shape)))
-        y = H.conv_bn(self.conv1, self.norm1, H.upconv_bn_relu_concat(self.upconv, self.norm0, dec, enc), relu=True)
+        y = H.conv_bn(self.conv1, self.norm1, H.upconv_bn_relu_concat(self.upconv, self.norm0, dec, enc, cat=cat), relu=True)
         return H.conv_bn(self.conv2, self.norm2, y, relu=True)
 
 
@@ -93,11 +101,15 @@ class UNet(nn.Module):
     def forward(self, x, out=None):
         """out (inference only): the tensor - e.g. a slice of the volume's feature map - that receives the result."""
         skips = []
-        for blk in self.down_convs:
-            x, before_pool = blk(x)
-            skips.append(before_pool)
+        nd = len(self.down_convs)
+        for j, blk in enumerate(self.down_convs):
+            # the skip connection of down block j is consumed by up block nd - 2 - j
+            up = self.up_convs[nd - 2 - j] if j < nd - 1 else None
+            x, before_pool, cat = blk(x, co_up=up.upconv.co if up is not None else None)
+            skips.append((before_pool, cat))
         for i, blk in enumerate(self.up_convs):
-            x = blk(skips[-(i + 2)], x)
+            enc, cat = skips[-(i + 2)]
+            x = blk(enc, x, cat=cat)
         if not torch.is_grad_enabled() and x.is_cuda and H.FOLD_EVAL_BN:      # the 1 x 1 convolution with its bias in the epilogue
             return H.conv_bias_fwd(x, self.conv_final.weight, self.conv_final.bias, 1, 1, 0, out=out)
         y = H.bias_add(self.conv_final(x), self.conv_final)

@@ -365,6 +365,11 @@ int mi_conv_d32_1x1_fwd_f32(const float* x, const void* wimg, const float* bias,
  * patch of one channel: the windows never leave the lane. */
 int mi_conv_d32_fwd_pool_f32(const float* x, const void* wimg, const float* bias, float* y, float* y_pool, int relu, int N, int D, int H,
                              int W, int Ci, int Co, mi_stream_t stream);
+/* ... with y a channel slice of a wider tensor (voxel v's Co channels at y + v * y_cstride): the skip connection written straight into
+ * the concatenation buffer of the up-convolution block that consumes it (y = cat + Co_up, y_cstride = Co_up + Co), whose first Co_up
+ * channels mi_conv_d32_upconv_fwd_f32 writes later - no concatenation pass at all.  y_pool stays dense. */
+int mi_conv_d32_fwd_pool_strided_f32(const float* x, const void* wimg, const float* bias, float* y, int y_cstride, float* y_pool, int relu,
+                                     int N, int D, int H, int W, int Ci, int Co, mi_stream_t stream);
 /* dst[m][c0 : c0 + Cs] = src[m][:] over the M rows of a (M, Ct) tensor (channel counts and c0 multiples of 4): the encoder feature
  * into the concatenation buffer of an up-convolution block (torch.cat((up, enc), 1), unet.py:392) behind mi_conv_d32_upconv_fwd_f32. */
 int mi_copy_channels_into(const float* src, int Cs, float* dst, int Ct, int c0, long M, mi_stream_t stream);

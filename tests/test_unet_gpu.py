@@ -123,6 +123,37 @@ def test_upconv_tail_equals_shuffle_batchnorm_relu_concat(n, h, w, ho, wo, co, c
         assert float((two - fused).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
 
 
+def test_skip_connections_written_into_the_concatenation_equal_the_copied_form():
+    """Round 5: at inference a down-convolution block writes its skip connection straight into the concatenation buffer of the
+    up-convolution block that consumes it (mi_conv_d32_fwd_pool_strided_f32) and that block's transposed convolution writes the other
+    channels there (mi_conv_d32_upconv_fwd_f32): no concatenation pass.  Same kernels, same values: the U-Net's output is EQUAL BIT FOR BIT
+    to the form with the copies (CONCAT_DIRECT off) and to the one with the separate pooling / up-convolution tail passes
+    (unet.py:198-249,319-399,722-886)."""
+    from cet_pick_amd import hipops as H
+    from cet_pick_amd.models.networks.unet_small import UNet
+    torch.manual_seed(3)
+    net = UNet(16, out_channels=32, n_blocks=4).cuda().eval()
+    for m in net.modules():
+        if isinstance(m, H.HipBatchNorm):
+            with torch.no_grad():
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1)
+    x = torch.randn(3, 64, 96, 16, device="cuda")
+    outs = {}
+    with torch.no_grad():
+        for tag, flags in (("direct", {}), ("copied", {"CONCAT_DIRECT": False}),
+                           ("separate", {"CONCAT_DIRECT": False, "POOL_FUSED": False, "UPCONV_FUSED": False})):
+            saved = {k: getattr(H, k) for k in flags}
+            for k, v in flags.items():
+                setattr(H, k, v)
+            try:
+                outs[tag] = net(x).clone()
+            finally:
+                for k, v in saved.items():
+                    setattr(H, k, v)
+    assert torch.equal(outs["direct"], outs["copied"])
+    assert float((outs["direct"] - outs["separate"]).abs().max()) <= 2e-6 * float(outs["separate"].abs().max())
+
+
 @pytest.mark.parametrize("ci,co,h,w", [(16, 32, 32, 48), (32, 32, 16, 16), (32, 64, 32, 32), (64, 64, 16, 48), (64, 128, 16, 32), (128, 128, 16, 16)])
 def test_down_convolution_pool_in_the_epilogue_equals_the_pooling_pass(ci, co, h, w):
     """mi_conv_d32_fwd_pool_f32 (round 5; unet.py:198-249): conv -> folded BatchNorm -> ReLU with the 2 x 2 max-pool as a second output of
