@@ -1,0 +1,347 @@
+// Patch-resident direct 3 x 3 convolution on small 2-D planes, forward and data gradient, training (round 6).
+//
+// Replaces (reference, cet_pick/...): the Conv2d(C, C, 3, padding=1) layers of the SimSiam 2-D encoder's BasicBlocks,
+// models/networks/simsiam_model_2d.py:473-502 (conv1 / conv2 of every stride-1 block) inside TomoResClassifier2D.forward :776-819 -
+// at --bbox 36 (docs/explore.md:67): 64 -> 64 channels on 36 x 36, 128 -> 128 on 18 x 18, 256 -> 256 on 9 x 9, batch 256 per view.
+// These ran on the implicit GEMM at 135 - 155 TFLOP/s: nine one-tap slices per tile, each re-gathering, re-cutting and re-staging
+// its im2col rows.  Here (the scheme of conv_direct3.hip's direct3h_kernel, in 2-D):
+//   * the batch is ONE tall image of N H rows in which a zero row separates consecutive planes (padded row P = n (H + 1) + 1 + y):
+//     a workgroup owns 128 consecutive output voxels of the FLAT (n, y, x) order x 64 output channels - any H, W, N tile without a
+//     ragged edge (36 x 36 = 40.5 MFMA row blocks per plane) - and its patch is the padded rows those voxels touch, W + 2 wide;
+//   * the patch is staged one 16-channel chunk at a time, cut exactly into three bf16 planes on the way (16-byte records per voxel
+//     and 8-channel half: an MFMA A fragment of any tap is ONE ds_read_b128 at lane base + immediate); two chunks are resident
+//     (chunk c + 1 is fetched, cut and stored in the shadow of chunk c's 9 x 12 MFMAs per wave), so the LDS footprint does not
+//     depend on the channel count and two workgroups share a CU;
+//   * weights come pre-cut as B fragments ([64-column block][chunk][tap][column half][plane][lane] x 16 bytes) and stream from L2
+//     through a six-deep register ring; the data gradient is the same kernel on dY with the image built transposed and tap-flipped;
+//   * epilogue: (+ residual) (ReLU) (x (mask > 0)), rows of the flat voxel order: out[o C + col].
+// f32-equivalent bf16x3 arithmetic (six products of the exact three-way cut, f32 accumulation), as every convolution here.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PW_BLK = 1024;                // one B fragment plane: 64 lanes x 16 bytes
+constexpr int PW_STEP = 2 * 3 * PW_BLK;     // bytes per k-step: [column half][plane]
+constexpr int P_RB = 6;                     // weight k-steps in flight
+constexpr int P_TM = 128;                   // output voxels per workgroup (wave tile: 64 voxels x 32 columns)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t p_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void p_cut8(const float (&v)[8], u32x4 (&o)[3]) {
+    unsigned u0[8], u1[8], u2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        u0[t] = __float_as_uint(v[t]);
+        const float r1 = v[t] - __uint_as_float(u0[t] & 0xffff0000u);
+        u1[t] = __float_as_uint(r1);
+        u2[t] = __float_as_uint(r1 - __uint_as_float(u1[t] & 0xffff0000u));
+    }
+    constexpr unsigned HI2 = 0x07060302u;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        o[0][d] = __builtin_amdgcn_perm(u0[2 * d + 1], u0[2 * d], HI2);
+        o[1][d] = __builtin_amdgcn_perm(u1[2 * d + 1], u1[2 * d], HI2);
+        o[2][d] = __builtin_amdgcn_perm(u2[2 * d + 1], u2[2 * d], HI2);
+    }
+}
+
+struct P2DParams {
+    const float* a;           // X (forward) or dY (data gradient): (N, H, W, CT) channels-last
+    const unsigned char* wimg;
+    float* out;               // (N, H, W, CT)
+    const float* res;         // out = act(acc + res)          (may be null)
+    const float* mask;        // out *= (mask > 0)             (may be null)
+    int relu;
+    int N, H;
+    long total;               // N H W output voxels
+    unsigned a_bytes;
+};
+
+// W_: plane width (the patch pitch W_ + 2 is a compile-time constant: tap offsets are ds_read immediates); HMIN: smallest plane
+// height this instance is launched on (bounds the zero rows a tile can contain); CT: channels, in = out.
+template <int W_, int HMIN, int CT>
+struct P2DCfg {
+    static constexpr int PX = W_ + 2;
+    static constexpr int R = (P_TM - 1 + W_ - 1) / W_ + 1;              // image rows 128 consecutive voxels can touch
+    static constexpr int NB = (R - 1 + HMIN - 1) / HMIN;               // plane boundaries among them
+    static constexpr int PR = R + NB + 2;                               // patch rows: + separators + halo
+    static constexpr int NV = PR * PX;
+    static constexpr int ARR = NV * 16;                                 // one (chunk, plane, k-half) array
+    static constexpr int PL = 2 * ARR, KSB = 3 * PL;                    // plane, chunk
+    static constexpr int LDS = 2 * KSB;                                 // two resident chunks
+    static constexpr int UNITS = (2 * NV + 255) / 256;                  // staging units (voxel, k-half) per thread and chunk
+    static constexpr int KS = CT / 16, NSTEP = KS * 9;
+    static_assert(KS % 2 == 0 && 18 % P_RB == 0, "chunk pairs keep ring and LDS slots static");
+    static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+};
+
+template <int W_, int HMIN, int CT>
+__global__ __launch_bounds__(256, 2) void p2d_kernel(P2DParams p) {
+    typedef P2DCfg<W_, HMIN, CT> G;
+    __shared__ __attribute__((aligned(16))) unsigned char patch[G::LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    const int mh = wave >> 1, cw = wave & 1;             // wave tile: voxel half mh of the 128 x column half cw
+    const int cb = blockIdx.y;                           // 64-channel block of the output channels
+    const long o0 = (long)blockIdx.x * P_TM;             // first output voxel (flat)
+    const int HW = p.H * W_;
+    // padded row of the first voxel; the patch starts one row above it
+    const int n0 = (int)(o0 / HW), y0 = (int)(o0 - (long)n0 * HW) / W_;
+    const int pstart = n0 * (p.H + 1) + y0;              // = P(o0) - 1
+
+    const __amdgpu_buffer_rsrc_t wrs = p_rsrc(p.wimg, (unsigned)((CT / 64) * G::NSTEP * PW_STEP));
+    const int w_voff = cw * (3 * PW_BLK) + lane * 16;
+    const int w_cb = cb * (G::NSTEP * PW_STEP);
+    bf16x8 bfr[P_RB][3];
+    auto wload = [&](int g, auto SLOTc) {
+        constexpr int SLOT = decltype(SLOTc)::value;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            bfr[SLOT][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                wrs, g < G::NSTEP ? w_voff + pl * PW_BLK : (int)0x80000000u, g < G::NSTEP ? w_cb + g * PW_STEP : 0, 0));
+    };
+    // (slot = static position of the k-step inside its chunk pair; g itself is a run-time value)
+    auto wload_at = [&](int g, int slot) {
+        switch (slot % P_RB) {
+            case 0: wload(g, std::integral_constant<int, 0>{}); break;
+            case 1: wload(g, std::integral_constant<int, 1>{}); break;
+            case 2: wload(g, std::integral_constant<int, 2>{}); break;
+            case 3: wload(g, std::integral_constant<int, 3>{}); break;
+            case 4: wload(g, std::integral_constant<int, 4>{}); break;
+            default: wload(g, std::integral_constant<int, 5>{}); break;
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < P_RB - 1; ++g) wload_at(g, g);
+
+    // ---- patch staging, one 16-channel chunk at a time: unit q = (patch voxel, k-half); separator rows, halo columns and rows
+    //      outside the batch read zeros (offset out of range) ----
+    const __amdgpu_buffer_rsrc_t ars = p_rsrc(p.a, p.a_bytes);
+    unsigned st_off[G::UNITS];
+    int st_lds[G::UNITS];
+#pragma unroll
+    for (int u = 0; u < G::UNITS; ++u) {
+        const int q = tid + 256 * u, vox = q >> 1, hh = q & 1;
+        const int pr = vox / G::PX, pc = vox - pr * G::PX;
+        const int P = pstart + pr;                       // padded row: n (H + 1) + 1 + y; 0 (mod H + 1) = separator
+        const int n = P / (p.H + 1), y = P - n * (p.H + 1) - 1, x = pc - 1;
+        const bool ok = vox < G::NV && y >= 0 && n < p.N && (unsigned)x < (unsigned)W_;
+        st_off[u] = ok ? 4u * (unsigned)((((long)n * p.H + y) * W_ + x) * CT + hh * 8) : 0x80000000u;
+        st_lds[u] = vox < G::NV ? hh * G::ARR + vox * 16 : -1;
+    }
+    u32x4 ld[G::UNITS][2];
+    auto stage_load = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < G::UNITS; ++u) {
+            ld[u][0] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)st_off[u], 64 * c, 0);
+            ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)st_off[u], 64 * c + 16, 0);
+        }
+    };
+    auto stage_store = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < G::UNITS; ++u) {
+            if (st_lds[u] < 0) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ld[u][0][e]); v[4 + e] = __uint_as_float(ld[u][1][e]); }
+            u32x4 o[3];
+            p_cut8(v, o);
+            unsigned char* dst = patch + slot * G::KSB + st_lds[u];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * G::PL) = o[pl];
+        }
+    };
+    stage_load(0);
+
+    // ---- per-lane geometry: row block i = voxels o0 + 64 mh + 32 i .. + 31, MFMA row l32; record of the tap (0, 0) = (y - 1, x - 1) ----
+    int vbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        long o = o0 + 64 * mh + 32 * i + l32;
+        if (o >= p.total) o = p.total - 1;               // (rows behind the batch: computed on a valid voxel, never stored)
+        const int n = (int)(o / HW), rem = (int)(o - (long)n * HW), y = rem / W_, x = rem - y * W_;
+        const int prow = n * (p.H + 1) + 1 + y - pstart; // >= 1
+        vbase[i] = ((prow - 1) * G::PX + x) * 16 + h * G::ARR;
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // smallest products first
+
+    stage_store(0);
+    stage_load(1);
+    __syncthreads();
+
+    bf16x8 af[2][2][3];
+    auto frags = [&](int slot, int tap, auto SETc) {
+        constexpr int SET = decltype(SETc)::value;
+        const int imm = ((tap / 3) * G::PX + tap % 3) * 16 + slot * G::KSB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                af[SET][i][pl] = *reinterpret_cast<const bf16x8*>(patch + vbase[i] + imm + pl * G::PL);
+    };
+    auto frags_at = [&](int s, int slot, int tap) {      // s: static position inside the chunk pair (its parity picks the set)
+        if (s & 1) frags(slot, tap, std::integral_constant<int, 1>{});
+        else frags(slot, tap, std::integral_constant<int, 0>{});
+    };
+
+    frags_at(0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int cp = 0; cp < G::KS / 2; ++cp) {             // chunk pairs: 18 k-steps, every register-ring / LDS slot static inside
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            const int cc = s / 9, tap = s % 9, c = 2 * cp + cc, g = cp * 18 + s;
+            wload_at(g + P_RB - 1, s + P_RB - 1);
+            // the next chunk of the patch: cut + stored a few taps into this chunk (its loads have been in flight since the
+            // previous chunk), the loads of the chunk after it right behind
+            if (tap == 2 && c + 1 < G::KS) {
+                stage_store((cc + 1) & 1);
+                if (c + 2 < G::KS) stage_load(c + 2);
+            }
+            if (g + 1 < G::NSTEP) {
+                if (tap == 8) __syncthreads();           // next chunk of the patch visible (stored six k-steps ago)
+                frags_at(s + 1, ((s + 1) / 9) & 1, (s + 1) % 9);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][0][PA[pr]], bfr[s % P_RB][PB[pr]], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][1][PA[pr]], bfr[s % P_RB][PB[pr]], acc[1], 0, 0, 0);
+            }
+            // issue order inside the k-step: every load behind an MFMA
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h of row block i; a row IS a flat voxel ----
+    const bool has_mask = p.mask != nullptr;
+    const int col = cb * 64 + cw * 32 + l32;
+    const __amdgpu_buffer_rsrc_t rrs = p_rsrc(p.res, p.res ? p.a_bytes : 0u), mrs = p_rsrc(p.mask, p.mask ? p.a_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t ors = p_rsrc(p.out, p.a_bytes);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float rr[16], mm[16];
+        unsigned eo[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long o = o0 + 64 * mh + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+            eo[r] = o < p.total ? 4u * (unsigned)(o * CT + col) : 0x80000000u;
+            rr[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, (int)eo[r], 0, 0));
+            mm[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mrs, (int)eo[r], 0, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[i][r] + rr[r];
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (has_mask) v = (mm[r] > 0.f) ? v : 0.f;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ors, (int)eo[r], 0, 0);
+        }
+    }
+}
+
+// ---- weight image: W[tap][ci][co] f32 -> bf16x3 B fragments [64-column block][chunk][tap][column half][plane][lane] x 16 bytes ----
+constexpr int PP_MAX = 16;
+struct P2DPrepBatch {
+    const float* w[PP_MAX];
+    unsigned char* img[PP_MAX];
+    int dgrad[PP_MAX];
+    int ct[PP_MAX];
+};
+// idx = (cb, chunk, tap, cw, lane): (ct / 64) (ct / 16) 9 x 2 x 64 entries per image
+__global__ __launch_bounds__(256) void p2d_prep_kernel(P2DPrepBatch b) {
+    const int ct = b.ct[blockIdx.y], ks = ct / 16;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (ct / 64) * ks * 9 * 128) return;
+    const int lane = idx & 63, cw = (idx >> 6) & 1, rest = idx >> 7, tap = rest % 9, c = (rest / 9) % ks, cb = rest / (9 * ks);
+    const float* w = b.w[blockIdx.y];
+    const int nn = cb * 64 + cw * 32 + (lane & 31), k0 = c * 16 + 8 * (lane >> 5);
+    float v[8];
+    if (b.dgrad[blockIdx.y]) {      // B'[tap][k = co][n = ci] = W[8 - tap][ci = n][co = k]
+        const float* src = w + ((long)(8 - tap) * ct + nn) * ct + k0;
+        const float4 a = *reinterpret_cast<const float4*>(src), d = *reinterpret_cast<const float4*>(src + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = d.x; v[5] = d.y; v[6] = d.z; v[7] = d.w;
+    } else {                        // B[tap][k = ci][n = co] = W[tap][ci = k][co = n]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = w[((long)tap * ct + k0 + e) * ct + nn];
+    }
+    u32x4 o[3];
+    p_cut8(v, o);
+    unsigned char* dst = b.img[blockIdx.y] + (size_t)(((cb * ks + c) * 9 + tap) * 2 + cw) * (3 * PW_BLK) + lane * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * PW_BLK) = o[pl];
+}
+
+template <int W_, int HMIN, int CT>
+int p2d_launch(const P2DParams& p, hipStream_t s) {
+    const long tiles = (p.total + P_TM - 1) / P_TM;
+    if (tiles > 0x7fffffffl) return MI_E_UNSUPPORTED;
+    hipLaunchKernelGGL((p2d_kernel<W_, HMIN, CT>), dim3((unsigned)tiles, CT / 64), dim3(256), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+}  // namespace
+
+// 1: a shape of p2d_kernel - 3 x 3, stride 1, padding 1, C -> C channels on (N, H, W) planes with (W, C) one of (36, 64), (18, 128),
+// (9, 256) (the SimSiam 2-D encoder at --bbox 36) and H >= W; MI_NO_P2D=1: off (the implicit GEMM takes the layer)
+extern "C" int mi_conv2d_p2d_usable(int N, int H, int W, int C) {
+    if (getenv("MI_NO_P2D") || N < 1 || H < W) return 0;
+    if (!((W == 36 && C == 64) || (W == 18 && C == 128) || (W == 9 && C == 256))) return 0;
+    if (4l * N * H * W * C >= 0x7fff0000l) return 0;
+    return 1;
+}
+extern "C" size_t mi_conv2d_p2d_wimg_bytes(int C) { return (size_t)(C / 64) * (C / 16) * 9 * PW_STEP; }
+
+// One launch cuts n weight images (n <= 16 per launch, more in several): w[i] = (3, 3, C_i, C_i) kernel-layout weights, img[i] =
+// mi_conv2d_p2d_wimg_bytes(C_i) bytes, dgrad[i] != 0: the transposed, tap-flipped image of the data gradient.
+extern "C" int mi_conv2d_p2d_prep(const void* const* w, void* const* img, const int* dgrad, const int* channels, int n, mi_stream_t stream) {
+    if (!w || !img || !dgrad || !channels || n < 0) return MI_E_ARG;
+    for (int i0 = 0; i0 < n; i0 += PP_MAX) {
+        P2DPrepBatch b = {};
+        const int m = n - i0 < PP_MAX ? n - i0 : PP_MAX;
+        int cmax = 0;
+        for (int i = 0; i < m; ++i) {
+            const int c = channels[i0 + i];
+            if (!w[i0 + i] || !img[i0 + i] || (c != 64 && c != 128 && c != 256)) return MI_E_ARG;
+            b.w[i] = (const float*)w[i0 + i]; b.img[i] = (unsigned char*)img[i0 + i]; b.dgrad[i] = dgrad[i0 + i]; b.ct[i] = c;
+            cmax = c > cmax ? c : cmax;
+        }
+        const int entries = (cmax / 64) * (cmax / 16) * 9 * 128;
+        hipLaunchKernelGGL(p2d_prep_kernel, dim3((entries + 255) / 256, m), dim3(256), 0, (hipStream_t)stream, b);
+        MI_RETURN_IF_LAUNCH_FAILED();
+    }
+    return MI_OK;
+}
+
+// out = act(conv3x3(a; image) + res) * (mask > 0): a, out, res, mask (N, H, W, C) channels-last f32; res / mask may be null
+extern "C" int mi_conv2d_p2d_f32(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
+                                 int H, int W, int C, mi_stream_t stream) {
+    if (!a || !wimg || !out) return MI_E_ARG;
+    if (!mi_conv2d_p2d_usable(N, H, W, C)) return MI_E_UNSUPPORTED;
+    P2DParams p = {};
+    p.a = a; p.wimg = (const unsigned char*)wimg; p.out = out; p.res = res; p.mask = mask; p.relu = relu;
+    p.N = N; p.H = H; p.total = (long)N * H * W; p.a_bytes = (unsigned)(4l * N * H * W * C);
+    hipStream_t s = (hipStream_t)stream;
+    if (W == 36) return p2d_launch<36, 36, 64>(p, s);
+    if (W == 18) return p2d_launch<18, 18, 128>(p, s);
+    return p2d_launch<9, 9, 256>(p, s);
+}

@@ -499,6 +499,76 @@ def _smallk_call(x, w, bias, relu, ntaps, out=None, owner=None):
     return out
 
 
+# Pre-cut weight images of the SimSiam 2-D encoder's 3 x 3 / stride-1 layers (conv_p2d.hip).  An engine that knows when the weights
+# change (SimSiamStepEngine: behind its SGD kernel) keeps them in ACTIVE_P2D = {(weight address, dgrad): image} for the duration of its
+# step and re-cuts them all in one or two launches; everywhere else the image lives on the parameter and is rebuilt when the
+# parameter's version (torch ops) or the weight epoch (raw-pointer writes) moved.
+ACTIVE_P2D = None
+
+
+def p2d_usable(x_shape, ci, co, k3, stride, p3, dil=None):
+    """True when conv_p2d.hip takes this 2-D convolution (forward of x / data gradient onto x): (N, H, W, C) -> C channels, 3 x 3,
+    stride 1, padding 1, (W, C) one of the SimSiam 2-D encoder's three at --bbox 36."""
+    if len(x_shape) != 4 or ci != co or tuple(k3) != (1, 3, 3) or stride != 1 or tuple(p3) != (0, 1, 1) or dil is not None:
+        return False
+    if not _arith_bf16x3():
+        return False
+    n, h, w, _ = x_shape
+    return bool(L.lib().mi_conv2d_p2d_usable(int(n), int(h), int(w), int(ci)))
+
+
+def p2d_prep(items):
+    """items: [(weight, dgrad flag, image tensor)] - all cut in one launch per 16 (mi_conv2d_p2d_prep) on the current stream."""
+    import ctypes
+    n = len(items)
+    if not n:
+        return
+    ws = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in items])
+    imgs = (ctypes.c_void_p * n)(*[it[2].data_ptr() for it in items])
+    dg = (ctypes.c_int * n)(*[int(bool(it[1])) for it in items])
+    ch = (ctypes.c_int * n)(*[int(it[0].shape[0]) for it in items])
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    L.check(L.lib().mi_conv2d_p2d_prep(cast(ws), cast(imgs), cast(dg), cast(ch), n, L.stream()), "mi_conv2d_p2d_prep")
+
+
+def _p2d_image(w, dgrad):
+    dgrad = int(bool(dgrad))
+    if ACTIVE_P2D is not None and PROFILE is None:
+        img = ACTIVE_P2D.get((w.data_ptr(), dgrad))
+        if img is not None:
+            return img
+    if not _phys_ok(w):
+        raise L.HipExtensionError("conv weight is not in kernel layout [tap][Cin][Cout]")
+    key = (w.data_ptr(), w._version, WEIGHT_EPOCH)
+    cache = getattr(w, "_mi_p2d", None)
+    if cache is None:
+        cache = {}
+        try:
+            w._mi_p2d = cache
+        except AttributeError:
+            pass
+    ent = cache.get(dgrad)
+    if ent is None or ent[0] != key:
+        img = ent[1] if (ent is not None and ent[1].device == w.device) else torch.empty(int(L.lib().mi_conv2d_p2d_wimg_bytes(int(w.shape[0]))), dtype=torch.uint8,
+                                                         device=w.device)
+        p2d_prep([(w, dgrad, img)])
+        ent = (key, img)
+        cache[dgrad] = ent
+    return ent[1]
+
+
+def _p2d_call(a, w, dgrad, res, mask, relu, tag):
+    n, h, wd, c = a.shape
+    out = torch.empty_like(a)
+    img = _p2d_image(w, dgrad)
+    lib = L.lib()
+    def call():
+        return L.check(lib.mi_conv2d_p2d_f32(L.ptr(a), L.ptr(img), L.ptr(out), L.ptr(res), L.ptr(mask), int(relu), n, h, wd, c,
+                                             L.stream()), "mi_conv2d_p2d_f32")
+    _prof_run(tag, 2.0 * a.numel() * c * 9, call)
+    return out
+
+
 def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None, owner=None, inference=False):
     """y = act(conv(x, w) + res).  x: (N,D,H,W,Ci) or (N,H,W,Ci) channels-last; w in kernel layout.
     dil: per-axis dilation (stride 1 only).  inference: the caller ran inference_mode() where the user's grad mode is visible
@@ -518,6 +588,10 @@ def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None, owner=None, i
             return _smallk_call(x, w, None, relu, taps, owner=owner)
         if kind:                                      # inference, 3 x 3: patch-resident direct kernel (conv_d32.hip)
             return _d32_call(x, w, None, relu, kind, owner=owner)
+    if not nd5 and x.is_cuda and p2d_usable(x.shape, x.shape[-1], w.shape[0], k3, stride, p3, dil):
+        if res is not None:
+            _f32c(res, "res")
+        return _p2d_call(x, owner if owner is not None else w, False, res, None, relu, "fwd")
     x5 = _as5d(x)
     n, d, h, wd, ci = x5.shape
     co = w.shape[0]
@@ -585,6 +659,12 @@ def conv_dgrad(dy, w, in_shape, k, stride, pad, res=None, mask=None, dil=None):
     shape5 = tuple(in_shape) if nd5 else (in_shape[0], 1) + tuple(in_shape[1:])
     n, d, h, wd, ci = shape5
     co = w.shape[0]
+    if not nd5 and dy.is_cuda and p2d_usable(tuple(in_shape), ci, co, k3, stride, p3, dil):
+        if res is not None:
+            _f32c(res, "res")
+        if mask is not None:
+            _f32c(mask, "mask")
+        return _p2d_call(dy, w, True, res, mask, False, "dgrad")
     dx = torch.empty(tuple(in_shape), dtype=torch.float32, device=dy.device)
     lib = L.lib()
     flops = 2.0 * dy.numel() * ci * k3[0] * k3[1] * k3[2]

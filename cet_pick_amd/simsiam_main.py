@@ -46,21 +46,23 @@ def init_distributed(opt):
     return dist.get_rank(), dist.get_world_size()
 
 
-def main(opt):
+def build(opt):
+    """Everything `main` sets up before its epoch loop (simsiam_main.py:25-93): process group, model, SGD, checkpoint resume,
+    trainer (step engine for the 2-D encoder), dataset.  -> (opt, model, optimizer, trainer, dataset) (+ .rank / .world on opt)."""
     torch.manual_seed(opt.seed)
     rank, world = init_distributed(opt)
+    opt.rank_, opt.world_ = rank, world
     Dataset = SyntheticSimSiamDataset
     opt = opts().update_dataset_info_and_set_heads(opt, Dataset)
-    logger = TextLog(opt, enabled=rank == 0)
 
     print("Creating model...")
     model = create_model(opt.arch, opt.heads, opt.head_conv, local_path=opt.pretrained_model)
     if opt.distributed:
         H.convert_sync_batchnorm(model)
     optimizer = torch.optim.SGD(filter(lambda p: p.requires_grad, model.parameters()), opt.lr)
-    start_epoch = 0
+    opt.start_epoch_ = 0
     if opt.load_model != "":
-        model, optimizer, start_epoch = load_model(model, opt.load_model, optimizer, opt.resume, opt.lr, opt.lr_step)
+        model, optimizer, opt.start_epoch_ = load_model(model, opt.load_model, optimizer, opt.resume, opt.lr, opt.lr_step)
 
     trainer = train_factory[opt.task](opt, model, optimizer)
     if opt.distributed:
@@ -73,6 +75,13 @@ def main(opt):
     if use_files(opt):
         from .datasets.tomo_files import TomoFileSimSiamDataset as Dataset
     dataset = Dataset(opt, "train", (3, opt.bbox, opt.bbox), sigma1=opt.dog, device=opt.device, rank=rank, world=world)
+    return opt, model, optimizer, trainer, dataset
+
+
+def main(opt):
+    opt, model, optimizer, trainer, dataset = build(opt)
+    rank, start_epoch = opt.rank_, opt.start_epoch_
+    logger = TextLog(opt, enabled=rank == 0)
     print("Starting training...")
     for epoch in range(start_epoch + 1, opt.num_epochs + 1):
         np.random.seed(epoch)
@@ -93,8 +102,8 @@ def main(opt):
         if epoch in opt.lr_step and rank == 0:
             save_model(os.path.join(opt.save_dir, "model_{}.pth".format(epoch)), epoch, model, optimizer)
     logger.close()
+    trainer.close()
     if opt.distributed:
-        trainer.close()
         dist.destroy_process_group()
 
 

@@ -134,6 +134,22 @@ class BaseTrainer(object):
         self._make_engine()
 
     # ---- the hot loop ----------------------------------------------------------------------------
+    def train_step(self, x1, x2, eager=False):
+        """One training step on a resident pair of view batches, as run_epoch's loop body performs it (the bench's step loop and
+        the engine-equals-plain-sequence tests).  `eager`: keep a step engine out of its hipGraph for this call.  -> loss (device)."""
+        if self.engine is not None:
+            if eager and hasattr(self.engine, "step_eager"):
+                return self.engine.step_eager(x1, x2)
+            return self.engine.step(x1, x2)
+        self.model_with_loss.train()
+        _, loss, _ = self.model_with_loss({"input": x1, "input_aug": x2}, 0, "train")
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.exchange is not None:
+            self.exchange.sync()
+        self.optimizer.step()
+        return loss.detach()
+
     def run_epoch(self, phase, epoch, data_loader):
         opt = self.opt
         mwl = self.model_with_loss

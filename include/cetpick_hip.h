@@ -307,6 +307,20 @@ int mi_conv3d_direct_prep(const void* const* w, void* const* img, const int* dgr
 int mi_conv3d_direct_f32(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu,
                          int N, int Di, int Hi, int Wi, int channels, void* ws, size_t ws_bytes, mi_stream_t stream);
 
+/* Round 6: patch-resident direct kernel for the 3 x 3 / stride 1 / padding 1 convolutions of the SimSiam 2-D encoder's BasicBlocks
+ * (models/networks/simsiam_model_2d.py:473-502; TomoResClassifier2D.forward :776-819) at --bbox 36 (docs/explore.md:67), forward and
+ * data gradient, bf16x3 arithmetic: C -> C channels on (N, H, W, C) channels-last planes with (W, C) = (36, 64), (18, 128), (9, 256),
+ * H >= W (csrc/conv_p2d.hip: the batch tiled as ONE flat run of voxels, 128 per workgroup, a zero row between planes).
+ *   mi_conv2d_p2d_usable: 1 for such a shape (MI_NO_P2D=1: 0);  mi_conv2d_p2d_wimg_bytes(C): bytes of one weight image;
+ *   mi_conv2d_p2d_prep: n images in one launch from (3, 3, C_i, C_i) kernel-layout weights (dgrad[i] != 0: the transposed,
+ *     tap-flipped image of the data gradient; the four arrays are HOST arrays);
+ *   mi_conv2d_p2d_f32: out = act(conv(a; image) + res) * (mask > 0); res / mask may be NULL (forward: a = x; dgrad: a = dy, relu 0). */
+int mi_conv2d_p2d_usable(int N, int H, int W, int C);
+size_t mi_conv2d_p2d_wimg_bytes(int C);
+int mi_conv2d_p2d_prep(const void* const* w, void* const* img, const int* dgrad, const int* channels, int n, mi_stream_t stream);
+int mi_conv2d_p2d_f32(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N, int H, int W,
+                      int C, mi_stream_t stream);
+
 /* 3^3 / stride 1 / padding 1 convolutions on 2 x 2 x 2 volumes, C -> C channels, C = 128 / 256 / 512 (layer3 and feature_3d
  * of the MoCo-3D encoder, models/networks/moco_encoder_3d.py:55-84,172,178), bf16x3 arithmetic, FINAL IN ONE LAUNCH (round 4:
  * the last of the four reduction quarters of an output tile to arrive sums them - in a fixed order - and applies the epilogue):

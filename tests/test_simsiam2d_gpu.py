@@ -215,3 +215,47 @@ def test_simsiam2d3d_encoder_matches_reference_golden(golden):
     with torch.no_grad():
         ft = net.forward_test(xs[0], xs[1])
     np.testing.assert_allclose(ft["pred"].cpu().numpy(), g["test_pred"], rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("case", [(5, 36, 36, 64), (3, 40, 36, 64), (7, 18, 18, 128), (9, 9, 9, 256), (37, 9, 9, 256)])
+def test_conv2d_direct_plane_kernel_matches_the_implicit_gemm_and_float64(case, monkeypatch):
+    """conv_p2d.hip (round 6): the 3 x 3 / stride-1 layers of the 2-D encoder, forward and data gradient (with the residual /
+    mask / ReLU epilogues), against float64 and against the implicit GEMM - batch sizes whose flat voxel run ends inside a
+    128-voxel tile, planes that straddle tiles, a plane taller than wide."""
+    from cet_pick_amd import hipops as H
+    n, h, w, c = case
+    g = torch.Generator().manual_seed(sum(case))
+    tol = 2e-6 * max(1.0, (c / 64) ** 0.5)      # f32 accumulation over K = 9 c terms: rounding noise grows with sqrt(K)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(c, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5
+    param = H.conv2d_weight_param(c, c, 3)
+    with torch.no_grad():
+        param.copy_(wt)
+    param.data = param.data.cuda()
+    xc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    assert H.p2d_usable(tuple(xc.shape), c, c, (1, 3, 3), 1, (0, 1, 1))
+    res = torch.randn(n, h, w, c, generator=g).cuda()
+    y = H.conv_fwd(xc, param, 3, 1, 1)
+    y_res = H.conv_fwd(xc, param, 3, 1, 1, res=res, relu=True)
+    y64 = F.conv2d(x.double(), wt.double(), padding=1).permute(0, 2, 3, 1)
+    sc = float(y64.abs().max())
+    assert float((y.cpu().double() - y64).abs().max()) <= tol * sc
+    assert float((y_res.cpu().double() - torch.relu(y64 + res.cpu().double())).abs().max()) <= tol * sc
+    dy = torch.randn(n, h, w, c, generator=g).cuda()
+    mask = torch.randn(n, h, w, c, generator=g).cuda()
+    dx = H.conv_dgrad(dy, param, tuple(xc.shape), 3, 1, 1)
+    dx_m = H.conv_dgrad(dy, param, tuple(xc.shape), 3, 1, 1, res=res, mask=mask)
+    dx64 = F.conv_transpose2d(dy.cpu().double().permute(0, 3, 1, 2), wt.double(), padding=1).permute(0, 2, 3, 1)
+    sc = float(dx64.abs().max())
+    assert float((dx.cpu().double() - dx64).abs().max()) <= tol * sc
+    want = (dx64 + res.cpu().double()) * (mask.cpu() > 0)
+    assert float((dx_m.cpu().double() - want).abs().max()) <= tol * sc
+    # the weights change (a torch op bumps the version): the cached images follow
+    with torch.no_grad():
+        param.mul_(0.5)
+    assert float((H.conv_fwd(xc, param, 3, 1, 1).cpu().double() - 0.5 * y64).abs().max()) <= tol * float(y64.abs().max())
+    # same products on the implicit GEMM: rounding-order noise only
+    monkeypatch.setenv("MI_NO_P2D", "1")
+    assert not H.p2d_usable(tuple(xc.shape), c, c, (1, 3, 3), 1, (0, 1, 1))
+    y_ig = H.conv_fwd(xc, param, 3, 1, 1)
+    assert float((y_ig.cpu().double() - 0.5 * y64).abs().max()) <= tol * float(y64.abs().max())
