@@ -159,6 +159,8 @@ SIGNATURES = {
     "mi_conv3d_s2_dgrad_img_f32": (_I, [_P] * 6 + [_I] * 4 + [_P]),
     "mi_ema_update": (_I, [_P, _P, _F, _L, _P]),
     "mi_sgd_step": (_I, [_P, _P, _P, _F, _F, _F, _L, _P]),
+    "mi_sgd_step2": (_I, [_P, _P, _P, _P, _F, _F, _F, _L, _P]),
+    "mi_scalar_accumulate": (_I, [_P, _P, _P, _P, _P, _P]),
     "mi_queue_enqueue": (_I, [_P, _P, _P, _I, _I, _I, _P]),
 }
 

@@ -1705,6 +1705,44 @@ extern "C" int mi_sgd_step(float* p, const float* g, const float* lr_dev, float 
     return MI_OK;
 }
 
+// Round 6 (SimSiamStepEngine): the same step for a model whose two views wrote their parameter gradients into two arenas (the
+// second view's contribution lands in g2 instead of being added to g by a launch per parameter): p <- p - lr (gs (g + g2) + wd p)
+__global__ __launch_bounds__(256) void sgd2_kernel(float* p, const float* g, const float* g2, const float* lr_dev, float lr_host, float wd,
+                                                  float gs, long n) {
+    const float lr = lr_dev ? *lr_dev : lr_host;
+    long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 a = ld4(p + 4 * i), b = ld4(g + 4 * i), c = ld4(g2 + 4 * i);
+        b.x += c.x; b.y += c.y; b.z += c.z; b.w += c.w;
+        a.x -= lr * (gs * b.x + wd * a.x); a.y -= lr * (gs * b.y + wd * a.y);
+        a.z -= lr * (gs * b.z + wd * a.z); a.w -= lr * (gs * b.w + wd * a.w);
+        st4(p + 4 * i, a);
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) p[i] -= lr * (gs * (g[i] + g2[i]) + wd * p[i]);
+}
+extern "C" int mi_sgd_step2(float* p, const float* g, const float* g2, const float* lr_dev, float lr, float weight_decay,
+                            float grad_scale, long n, mi_stream_t stream) {
+    if (!p || !g || !g2 || n <= 0 || ((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)g2 & 15)) return MI_E_ARG;
+    hipLaunchKernelGGL(sgd2_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, g2, lr_dev, lr, weight_decay,
+                       grad_scale, n);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+// sums[i] += *src[i], i < n <= 4: the loss meters of a training step, accumulated by one launch INSIDE the step (a graph node)
+__global__ void scalar_accumulate_kernel(float* sums, const float* a, const float* b, const float* c, const float* d) {
+    const float* src[4] = {a, b, c, d};
+    const int i = threadIdx.x;
+    if (i < 4 && src[i]) sums[i] += *src[i];
+}
+extern "C" int mi_scalar_accumulate(float* sums, const float* a, const float* b, const float* c, const float* d, mi_stream_t stream) {
+    if (!sums) return MI_E_ARG;
+    hipLaunchKernelGGL(scalar_accumulate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, a, b, c, d);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
 extern "C" int mi_queue_enqueue(float* queue, int64_t* queue_ptr, const float* keys, int B, int C, int R,
                                 mi_stream_t stream) {
     if (!queue || !queue_ptr || !keys || B <= 0 || C <= 0 || R <= 0 || (R % B)) return MI_E_ARG;  // moco.py:47

@@ -112,6 +112,12 @@ def _grad_target(param):
             view = torch.empty_like(param)        # preserve_format keeps the kernel layout
         param.grad = view
         return view, False
+    view2 = getattr(param, "_mi_grad_view2", None)
+    if view2 is not None and not param._mi_grad2_used:
+        # the second contribution of a step (a two-view model: SimSiamStepEngine) goes into the second gradient arena - the optimizer
+        # kernel adds the two - instead of through a temporary and a grad.add_ launch per parameter
+        param._mi_grad2_used = True
+        return view2, False
     if g.stride() != param.stride():
         raise L.HipExtensionError("param.grad layout differs from the parameter's kernel layout")
     return g, True
@@ -122,7 +128,7 @@ class ParamArena:
     momentum update (models/moco.py:31-39), SGD (moco_main.py:79) and the gradient all-reduce are
     single passes.  Parameters keep their identity, logical shapes and kernel strides."""
 
-    def __init__(self, module):
+    def __init__(self, module, second_grad_arena=False):
         params = [p for p in module.parameters()]
         if not params:
             raise ValueError("module has no parameters")
@@ -143,6 +149,13 @@ class ParamArena:
             p._mi_grad_view = torch.as_strided(self.flat_grad, p.shape, p.stride(), o)
             p.grad = None
         self.numel = total
+        # a second gradient arena for models that apply every parameter twice per step (the two views of SimSiam): see _grad_target
+        self.flat_grad2 = None
+        if second_grad_arena:
+            self.flat_grad2 = torch.zeros(total, dtype=torch.float32, device=dev)
+            for p, o in zip(params, offs):
+                p._mi_grad_view2 = torch.as_strided(self.flat_grad2, p.shape, p.stride(), o)
+                p._mi_grad2_used = False
 
     def attach_grads(self):
         for p in self.params:
@@ -152,6 +165,20 @@ class ParamArena:
         """set_to_none semantics: the next backward overwrites the arena views."""
         for p in self.params:
             p.grad = None
+        if self.flat_grad2 is not None:
+            for p in self.params:
+                p._mi_grad2_used = False
+
+    def settle_grads(self):
+        """After a backward pass, before a kernel reads the flat arenas: a parameter the pass did not reach (or reached once, with two
+        arenas) holds last step's values there - zero it.  (No launch when every parameter was reached, the usual case.)"""
+        for p in self.params:
+            if p.grad is None:
+                p._mi_grad_view.zero_()
+            elif p.grad.data_ptr() != p._mi_grad_view.data_ptr():
+                p._mi_grad_view.copy_(p.grad)
+            if self.flat_grad2 is not None and not p._mi_grad2_used:
+                p._mi_grad_view2.zero_()
 
 
 class GradExchange:
@@ -2165,6 +2192,21 @@ def sgd_step_(p_flat, g_flat, lr, weight_decay=0.0, lr_dev=None, grad_scale=1.0)
     _bump_weight_epoch()
     L.check(L.lib().mi_sgd_step(L.ptr(p_flat), L.ptr(g_flat), L.ptr(lr_dev), float(lr), float(weight_decay),
                                 float(grad_scale), p_flat.numel(), L.stream()), "mi_sgd_step")
+
+
+def sgd_step2_(p_flat, g_flat, g2_flat, lr, weight_decay=0.0, lr_dev=None, grad_scale=1.0):
+    """p -= lr * (grad_scale * (g + g2) + wd * p): two gradient arenas (one per view of a two-view model)."""
+    _bump_weight_epoch()
+    L.check(L.lib().mi_sgd_step2(L.ptr(p_flat), L.ptr(g_flat), L.ptr(g2_flat), L.ptr(lr_dev), float(lr), float(weight_decay),
+                                 float(grad_scale), p_flat.numel(), L.stream()), "mi_sgd_step2")
+
+
+def scalar_accumulate_(sums, *scalars):
+    """sums[i] += scalars[i] (0-d / 1-element f32 device tensors, at most four) in one launch."""
+    if len(scalars) > 4 or sums.numel() < len(scalars):
+        raise L.HipExtensionError("scalar_accumulate_: at most four scalars, sums at least as long")
+    ptrs = [L.ptr(_f32c(t, "scalar")) for t in scalars] + [None] * (4 - len(scalars))
+    L.check(L.lib().mi_scalar_accumulate(L.ptr(sums), *ptrs, L.stream()), "mi_scalar_accumulate")
 
 
 def copy_pair_(dst0, src0, dst1, src1):

@@ -65,7 +65,7 @@ _FLAGS = [
     ("--compress", _S), ("--gauss", dict(type=float, default=0)), ("--cluster_head", _S),
     ("--out_id", dict(type=str, default="output")), ("--order", dict(type=str, default="xzy")),
     ("--dog", dict(type=list_of_floats, default=[2.5, 5])),
-    # MI355X build only (not a reference flag): replay the MoCo step from a hipGraph (default) or launch it eagerly
+    # MI355X build only (not a reference flag): replay the MoCo / SimSiam step from a hipGraph (default) or launch it eagerly
     ("--hipgraph", dict(dest="hipgraph", action="store_true", default=None)),
     ("--no_hipgraph", dict(dest="hipgraph", action="store_false")),
 ]
@@ -117,7 +117,8 @@ class opts(object):
             if opt.task in ("semi", "semiclass"):
                 opt.head_conv = 32
         if opt.hipgraph is None:
-            opt.hipgraph = opt.task == "moco"           # the engine-driven task; others run their step eagerly
+            # the engine-driven tasks (trains/moco_engine.py, trains/simsiam_engine.py); others run their step eagerly
+            opt.hipgraph = opt.task in ("moco", "simsiam", "simsiam3d", "simsiam2d3d")
         opt.pad = 127 if "hourglass" in opt.arch else 31
         opt.num_stacks = 2 if opt.arch == "hourglass" else 1
         if opt.warm:

@@ -100,6 +100,14 @@ class BaseTrainer(object):
             wd = self.optimizer.param_groups[0].get("weight_decay", 0.0) if self.optimizer is not None else 0.0
             self.engine = MocoStepEngine(model, lr=self._lr(), weight_decay=wd,
                                          use_graph=bool(getattr(self.opt, "hipgraph", False)))
+        elif self._simsiam_engine_ok(model):
+            # two-view SimSiam models under plain SGD: flat arenas, fused optimizer, device meters, hipGraph (trains/simsiam_engine.py)
+            from .simsiam_engine import SimSiamStepEngine
+            wd = self.optimizer.param_groups[0].get("weight_decay", 0.0)
+            self.engine = SimSiamStepEngine(self.model_with_loss, lr=self._lr(), weight_decay=wd,
+                                            use_graph=bool(getattr(self.opt, "hipgraph", False)))
+            if H._distributed():
+                self.engine.broadcast_state(0)
         elif H._distributed():
             # every other task: stock optimizer, gradients averaged over the ranks between backward() and step()
             self.exchange = H.GradExchange(model)
@@ -107,6 +115,22 @@ class BaseTrainer(object):
             import torch.distributed as dist
             for b in model.buffers():
                 dist.broadcast(b, 0)
+
+    def _simsiam_engine_ok(self, model):
+        """The step engine replaces `zero_grad / backward / optimizer.step` only where it is the same arithmetic: a two-view SimSiam
+        model on the GPU under torch.optim.SGD without momentum / dampening / nesterov, every parameter trained by that optimizer."""
+        import os
+        if os.environ.get("CETPICK_SIMSIAM_ENGINE", "1") == "0" or self.opt.task not in ("simsiam", "simsiam3d", "simsiam2d3d"):
+            return False
+        o = self.optimizer
+        if not isinstance(o, torch.optim.SGD) or len(o.param_groups) != 1:
+            return False
+        g = o.param_groups[0]
+        if g.get("momentum", 0) or g.get("dampening", 0) or g.get("nesterov", False) or g.get("maximize", False):
+            return False
+        params = list(model.parameters())
+        return (len(params) > 0 and all(p.is_cuda and p.requires_grad and p.dtype == torch.float32 for p in params)
+                and len(g["params"]) == len(params))
 
     def close(self):
         """Release what refers to the process group before it is destroyed (a captured step holds RCCL work)."""
@@ -163,16 +187,24 @@ class BaseTrainer(object):
         t0 = end = time.time()
 
         engine_sums = phase == "train" and self.engine is not None and hasattr(self.engine, "take_loss_sum")
+        engine_stats = phase == "train" and self.engine is not None and hasattr(self.engine, "take_stat_sums")
         if engine_sums:
             self.engine.take_loss_sum()                     # (steps taken outside this epoch)
+        if engine_stats:
+            self.engine.take_stat_sums()
 
         def flush():
             nonlocal n_pending
             if n_pending:
                 if engine_sums:                             # the step engine accumulates its loss inside the step (one graph node)
+                    assert list(self.loss_stats) == ["loss"] or set(self.loss_stats) <= {"loss", "infoNCE"}, self.loss_stats
                     tot = self.engine.take_loss_sum()
                     for l in self.loss_stats:
                         avg_loss_stats[l].update(tot / n_pending, n_pending)
+                elif engine_stats:                          # ... and the SimSiam engine one sum per loss statistic
+                    tot = self.engine.take_stat_sums()
+                    for l in self.loss_stats:
+                        avg_loss_stats[l].update(tot[l] / n_pending, n_pending)
                 else:
                     for l in self.loss_stats:
                         avg_loss_stats[l].update(float(dev_sums[l].item()) / n_pending, n_pending)
@@ -189,7 +221,10 @@ class BaseTrainer(object):
                 if k != "meta" and isinstance(batch[k], torch.Tensor):
                     batch[k] = batch[k].to(device=self.device, non_blocking=True)
             if phase == "train" and self.engine is not None:
-                loss = self.engine.step(batch["input"], batch["input_aug"])
+                if hasattr(self.engine, "step_batch"):
+                    loss = self.engine.step_batch(batch)
+                else:
+                    loss = self.engine.step(batch["input"], batch["input_aug"])
                 loss_stats = {l: loss for l in self.loss_stats}
             else:
                 with torch.set_grad_enabled(phase == "train"):
@@ -200,7 +235,7 @@ class BaseTrainer(object):
                     if self.exchange is not None:
                         self.exchange.sync()
                     self.optimizer.step()
-            if not engine_sums:
+            if not engine_sums and not engine_stats:
                 for l in self.loss_stats:
                     v = loss_stats[l].detach().float().mean()
                     dev_sums[l] = v.clone() if dev_sums[l] is None else dev_sums[l] + v

@@ -608,6 +608,13 @@ int mi_ema_update(float* k, const float* q, float m, long n, mi_stream_t stream)
  * data-parallel ranks' gradients (DistributedDataParallel's averaging, moco_main.py:44-66), 1 otherwise. */
 int mi_sgd_step(float* p, const float* g, const float* lr_dev, float lr, float weight_decay, float grad_scale, long n,
                 mi_stream_t stream);
+/* Round 6: p <- p - lr (grad_scale (g + g2) + wd p): the step of a model whose two views wrote their parameter gradients into two
+ * arenas (trains/simsiam_engine.py; simsiam_main.py:65 SGD over both views' accumulated gradients). */
+int mi_sgd_step2(float* p, const float* g, const float* g2, const float* lr_dev, float lr, float weight_decay, float grad_scale, long n,
+                 mi_stream_t stream);
+/* sums[i] += *src_i for the non-NULL device scalars a, b, c, d (the per-step loss meters of trains/base_trainer.py:514-530, kept on
+ * the device and read once per print interval). */
+int mi_scalar_accumulate(float* sums, const float* a, const float* b, const float* c, const float* d, mi_stream_t stream);
 /* models/moco.py:41-52: queue[:, ptr:ptr+B] = keys.T; ptr = (ptr+B) % R, ptr read and advanced on
  * the device (no host sync).  R % B == 0 as the reference asserts. */
 int mi_queue_enqueue(float* queue, int64_t* queue_ptr, const float* keys, int B, int C, int R,

@@ -278,11 +278,11 @@ def _w_simsiam(rank, world, port, out):
     H.convert_sync_batchnorm(net)
     tr = train_factory["simsiam3d"](opt, net, torch.optim.SGD(net.parameters(), lr=opt.lr))
     tr.set_distributed_device(0)
-    assert tr.exchange is not None
+    assert tr.engine is not None and tr.engine.dist_on and tr.engine.world == 2      # (round 6: the SimSiam step engine does the exchange)
     sl = slice(4 * rank, 4 * rank + 4)
     ret, _ = tr.train(1, [{"input": x[sl], "input_aug": xa[sl]}])
     torch.cuda.synchronize()
-    torch.save({"w": tr.exchange.arena.flat.cpu(), "loss": ret["loss"]}, os.path.join(out, "m%d.pt" % rank))
+    torch.save({"w": tr.engine.arena.flat.cpu(), "loss": ret["loss"]}, os.path.join(out, "m%d.pt" % rank))
     dist.destroy_process_group()
 
 
@@ -344,7 +344,7 @@ def _w_det(rank, world, port, out, same):
     tr.set_distributed_device(0)
     ret, _ = tr.train(1, [dict(batch)])
     torch.cuda.synchronize()
-    torch.save({"w": tr.exchange.arena.flat.cpu(), "loss": ret["loss"], "calls": tr.exchange.calls},
+    torch.save({"w": tr.engine.arena.flat.cpu(), "loss": ret["loss"], "calls": tr.exchange.calls},
                os.path.join(out, "d%d_%d.pt" % (int(same), rank)))
     dist.destroy_process_group()
 

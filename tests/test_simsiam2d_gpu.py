@@ -259,3 +259,65 @@ def test_conv2d_direct_plane_kernel_matches_the_implicit_gemm_and_float64(case, 
     assert not H.p2d_usable(tuple(xc.shape), c, c, (1, 3, 3), 1, (0, 1, 1))
     y_ig = H.conv_fwd(xc, param, 3, 1, 1)
     assert float((y_ig.cpu().double() - 0.5 * y64).abs().max()) <= tol * float(y64.abs().max())
+
+
+def _simsiam_trainer(seed, hipgraph, engine=True, monkeypatch=None, lr=0.05):
+    from types import SimpleNamespace
+    from cet_pick_amd.models.model import create_model
+    from cet_pick_amd.synthetic import seeded_state_dict
+    from cet_pick_amd.trains.train_factory import train_factory
+    net = create_model("simsiam2d_18", {"proj": 128, "pred": 128}, 128)
+    net.load_state_dict(seeded_state_dict(net, seed=seed))
+    opt = SimpleNamespace(task="simsiam3d", num_iters=-1, print_iter=0, hide_data_time=True, exp_id="t", lr=lr, hipgraph=hipgraph)
+    if not engine:
+        monkeypatch.setenv("CETPICK_SIMSIAM_ENGINE", "0")
+    tr = train_factory["simsiam3d"](opt, net, torch.optim.SGD(net.parameters(), lr=lr))
+    tr.set_device([0], None, "cuda")
+    if not engine:
+        monkeypatch.delenv("CETPICK_SIMSIAM_ENGINE")
+    return net, tr
+
+
+def test_simsiam_engine_step_equals_plain_sequence(monkeypatch):
+    """SimSiamStepEngine (round 6: flat arenas, second gradient arena instead of a grad.add_ per parameter, fused SGD kernel, cached
+    weight images, device meters, hipGraph replay from the third call on) against the plain sequence `model(x1, x2); loss; zero_grad;
+    backward; sgd_step_` on the same seeded weights and batches: the parameters after every one of five steps, the losses and the
+    meters - BIT FOR BIT (same kernels on the same operands; g1 + g2 is one rounding either way)."""
+    from cet_pick_amd import hipops as H
+    net_e, tr_e = _simsiam_trainer(321, hipgraph=True)
+    net_p, tr_p = _simsiam_trainer(321, hipgraph=False, engine=False, monkeypatch=monkeypatch)
+    assert tr_e.engine is not None and tr_e.engine.use_graph and tr_p.engine is None
+    arena_p = H.ParamArena(net_p)
+    g = torch.Generator().manual_seed(4)
+    losses = []
+    for it in range(5):
+        x1 = torch.randn(16, 1, 36, 36, generator=g).cuda()
+        x2 = (x1.flip(-1) + 0.1 * torch.randn(16, 1, 36, 36, generator=g).cuda()).contiguous()
+        le = tr_e.train_step(x1, x2)
+        # plain sequence
+        arena_p.zero_grad()
+        tr_p.model_with_loss.train()
+        _, lp, stats = tr_p.model_with_loss({"input": x1, "input_aug": x2}, 0, "train")
+        lp.backward()
+        H.sgd_step_(arena_p.flat, arena_p.flat_grad, 0.05)
+        assert torch.equal(le, lp.detach()), (it, float(le), float(lp))
+        assert torch.equal(tr_e.engine.arena.flat, arena_p.flat), it
+        for (n1, b1), (n2, b2) in zip(net_e.named_buffers(), net_p.named_buffers()):
+            assert torch.equal(b1, b2), (it, n1)
+        losses.append(float(lp))
+    assert tr_e.engine._graph is not None                      # steps 3.. were graph replays
+    nodes = tr_e.engine.node_counts()
+    assert nodes["memcpy"] == 0 and nodes["kernel"] > 100
+    sums = tr_e.engine.take_stat_sums()
+    assert abs(sums["loss"] - sum(losses)) <= 1e-5 * abs(sum(losses)) and sums["cosine_loss"] == sums["loss"] and sums["output_std"] > 0
+    # a write through torch ops between two steps (a checkpoint load): the engine re-cuts its weight images by itself
+    with torch.no_grad():
+        tr_e.engine.arena.flat.mul_(0.999)
+        arena_p.flat.mul_(0.999)
+    le = tr_e.train_step(x1, x2)
+    arena_p.zero_grad()
+    _, lp, _ = tr_p.model_with_loss({"input": x1, "input_aug": x2}, 0, "train")
+    lp.backward()
+    H.sgd_step_(arena_p.flat, arena_p.flat_grad, 0.05)
+    assert torch.equal(le, lp.detach()) and torch.equal(tr_e.engine.arena.flat, arena_p.flat)
+    tr_e.close()
