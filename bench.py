@@ -637,6 +637,11 @@ def main():
             from tools.bench_detector import run as detector_secondary
             out["secondary"]["detector"] = detector_secondary()
             log("detector secondary done")
+            # the other half of the train path north_star names: the SimSiam-2D loop at the reference's documented exploration
+            # configuration (docs/explore.md:67: simsiam2d_18, --bbox 36, batch 256, SGD lr 1e-3), tools/bench_simsiam2d.py
+            from tools.bench_simsiam2d import run as simsiam2d_record
+            out["secondary"]["simsiam2d_train_step"] = simsiam2d_record(with_cpu=not args.no_cpu_baseline)
+            log("SimSiam-2D secondary done")
         if not args.no_cpu_baseline and world == 1:
             v, cores = cpu_baseline(B, 4, 317)
             out["cpu_baseline"] = {"value": v, "unit": "subtomograms/sec", "cores": cores, "kind": "port",
@@ -662,6 +667,8 @@ def main():
         head["entry_point_value"] = out["entry_point"]["value"] if "entry_point" in out else None
         head["unet4_forward_ms"] = (sec.get("detector") or {}).get("unet4_forward", {}).get("ms")
         head["semi_train_step_ms"] = (sec.get("detector") or {}).get("semi_train_step", {}).get("ms")
+        head["simsiam2d_train_step_ms"] = (sec.get("simsiam2d_train_step") or {}).get("ms")
+        head["simsiam2d_crop_pairs_per_sec"] = (sec.get("simsiam2d_train_step") or {}).get("crop_pairs_per_sec")
         head.update({k: v for k, v in out.items() if k not in head})
         out = head
         emit(out)                                    # the line is out before any tear-down
