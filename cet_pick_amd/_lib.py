@@ -115,10 +115,6 @@ SIGNATURES = {
     "mi_bn_stats": (_I, [_P, _L, _I, _P, _P, _Z, _P]),
     "mi_bn_apply_fwd": (_I, [_P, _P, _L, _I, _P, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P]),
     "mi_bn_relu_maxpool3d_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
-    "mi_bn_relu_maxpool3d_bwd_usable": (_I, [_I] * 8),
-    "mi_bn_relu_maxpool3d_bwd_workspace_bytes": (_Z, [_I] * 5),
-    "mi_bn_relu_maxpool3d_bwd_reduce": (_I, [_P, _P, _P] + [_I] * 8 + [_P, _P, _P, _P, _P, _Z, _P]),
-    "mi_bn_relu_maxpool3d_bwd_apply": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P, _P, _P, _P, _D, _P, _P, _P]),
     "mi_bn_relu_bwd_reduce_x": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "mi_bn_relu_bwd_apply_x": (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _P, _D, _P, _P, _P]),
     "mi_bn_small_fwd": (_I, [_P, _P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P]),

@@ -622,7 +622,7 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 // lane's eight k values are two image rows of four: the x-shifted fragments get a zero at BOTH row edges; a workgroup owns one
 // (dz, dy) pair and one 64 x 64 block of the 128 x 128 channels (36 groups instead of 9).
 // CT = channels of a voxel in memory (64 / 128 / 256): a workgroup owns one 64 x 64 block of the CT x CT channels, 9 (CT / 64)^2 groups.
-// <false, 64> layer1 and <true, 128> layer2 of 32^3 crops; <false, 128> layer2 and <true, 256> layer3 of 64^3 crops.
+// <false, 64> layer1 and <true, 128> layer2 of 32^3 crops; <false, 128> layer2 of 64^3 crops.
 // TILED (round 5, <false, 64, true>: layer1 of 64^3 crops, 16 x 16 planes): the unit is an 8 x 8 TILE of a plane.  The tile of X is
 // staged already shifted by the workgroup's dy (rows of the neighbouring tile, zeros outside the plane), so the fragment rows need no
 // select; the x-shifted fragments take their edge element from ONE halo column per side (X[.][x0 - 1], X[.][x0 + 8]: 8 rows x 64
@@ -1358,11 +1358,10 @@ int mi_direct3t_wgrad_launch(const float* x, const float* dy, float* slabs, int 
     return MI_OK;
 }
 
-// ---- 64^3 crops: layer2 (128 -> 128 on 8 x 8 planes, kind 3) and layer3 (256 -> 256 on 4 x 4 x 4, kind 4), single launches ----
-// kind 3: 36 groups x 7 chains of planes; kind 4: 144 groups x 2 chains of samples.  Slabs of [27][CT][CT] floats.
-int mi_direct3x_wgrad_splits(int kind) { return kind == 3 ? 7 : kind == 4 ? 2 : 0; }
+// ---- 64^3 crops: layer2 (128 -> 128 on 8 x 8 planes, kind 3), single launches: 36 groups x 7 chains of planes; slabs of [27][CT][CT] floats ----
+int mi_direct3x_wgrad_splits(int kind) { return kind == 3 ? 7 : 0; }
 size_t mi_direct3x_wgrad_slab_bytes(int kind) {
-    const size_t ct = kind == 3 ? 128 : kind == 4 ? 256 : 0;
+    const size_t ct = kind == 3 ? 128 : 0;
     return sizeof(float) * (size_t)mi_direct3x_wgrad_splits(kind) * NTAP * ct * ct;
 }
 int mi_direct3x_wgrad_launch(int kind, const float* x, const float* dy, float* slabs, int N, int D, hipStream_t s) {
@@ -1371,9 +1370,6 @@ int mi_direct3x_wgrad_launch(int kind, const float* x, const float* dy, float* s
     if (kind == 3) {
         p.N = N; p.D = D; p.bytes = (unsigned)(4l * N * D * PLANE * 128);
         hipLaunchKernelGGL((direct3_wgrad_kernel<false, 128>), dim3(36 * p.splits), dim3(512), 0, s, p);
-    } else if (kind == 4) {
-        p.N = N; p.D = 1; p.bytes = (unsigned)(4l * N * PLANE * 256);
-        hipLaunchKernelGGL((direct3_wgrad_kernel<true, 256>), dim3(144 * p.splits), dim3(512), 0, s, p);
     } else return MI_E_UNSUPPORTED;
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;

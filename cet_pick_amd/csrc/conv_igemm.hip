@@ -91,9 +91,6 @@ int mi_cube2_launch(int dgrad, const float* a, const float* w, float* slabs, int
 // ... and the small dense products of the Linear layers (register-staged, final in one launch)
 bool mi_pair_wgrad_usable(int N, int Di, int Hi, int Wi, int Ci, int Co, int kd, int kh, int kw, int stride, int pd, int ph, int pw,
                           int dd, int dh, int dw);
-int mi_pairw_splits(int N, int Di, int Ci, int Co, int k, int stride);
-size_t mi_pairw_workspace_bytes(int N, int Di, int Ci, int Co, int k, int stride);
-int mi_pairw_launch(const float* x, const float* dy, float* dwt, void* ws, int N, int Di, int Ci, int Co, int k, int stride, hipStream_t s);
 int mi_pair_wgrad_splits(int N, int Di, int Ci, int Co, int k, int stride);
 size_t mi_pair_wgrad_slab_bytes(int N, int Di, int Ci, int Co, int k, int stride);
 int mi_pair_wgrad_launch(const float* x, const float* dy, float* dwt, float* slabs, int N, int Di, int Ci, int Co, int k, int stride,
@@ -1284,16 +1281,8 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
     if (mode == MODE_WGRAD && conv_arith_bf16x3() &&
         mi_pair_wgrad_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw))
     {
-        // MI_PAIRW=1: pre-cut operand images + LDS-DMA (conv_pairw.hip; measured, not faster: r04_experiments.txt item 26)
-        const char* pw = getenv("MI_PAIRW");
-        if (pw && atoi(pw) != 0 && ws && ws_bytes >= mi_pairw_workspace_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride)) {
-            const int splits = mi_pairw_splits(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride);
-            g_last_conv_kernel = splits > 1 ? "pairw + reduce" : "pairw";
-            int rc = mi_pairw_launch(a_src, b_src, out, ws, g.N, g.Di, g.Ci, g.Co, g.kd, g.stride, s);
-            if (rc || splits == 1) return rc;
-            if (defer_splits) { *defer_splits = splits; return MI_OK; }
-            return mi_direct3_finish_slabs((const float*)ws, splits, (long)g.kd * g.kh * g.kw * g.Ci * g.Co, out, nullptr, nullptr, 0, s);
-        }
+        // (round 4 also built this from pre-cut operand images + LDS-DMA - conv_pairw.hip, measured not faster: r04_experiments.txt
+        // item 26 - it left the library in round 6)
         const int splits = mi_pair_wgrad_splits(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride);
         if (splits == 1 || (ws && ws_bytes >= mi_pair_wgrad_slab_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride))) {
             g_last_conv_kernel = splits > 1 ? "pair_wgrad + reduce" : "pair_wgrad";
@@ -1340,10 +1329,10 @@ int run_conv(int mode, const Geom& g, const float* a_src, const float* b_src, fl
         return mi_direct3_finish_slabs((const float*)ws, splits, 27l * g.Ci * g.Co, out, nullptr, nullptr, 0, s);
     }
     // 64^3 crops: layer2 (kind 3: 71.3 against 100.5 us at batch 32, 41.8 against 57.7 at batch 16; MI_NO_D3X_WGRAD=1: the implicit GEMM)
-    // and - opt-in, MI_D3X_WGRAD_256=1: 59.3 against 60.4 / 38.0 against 35.6 us, no gain - layer3 (kind 4) on the same kernel
-    if (mode == MODE_WGRAD && ((dkind == 3 && !env_int("MI_NO_D3X_WGRAD")) || (dkind == 4 && env_int("MI_D3X_WGRAD_256"))) && ws &&
+    // (layer3, kind 4, on the same kernel: 59.3 against 60.4 / 38.0 against 35.6 us, no gain - r05_experiments.txt; removed in round 6)
+    if (mode == MODE_WGRAD && dkind == 3 && !env_int("MI_NO_D3X_WGRAD") && ws &&
         ws_bytes >= mi_direct3x_wgrad_slab_bytes(dkind)) {
-        g_last_conv_kernel = dkind == 3 ? "direct3_wgrad (128 channels) + reduce" : "direct3s_wgrad (256 channels) + reduce";
+        g_last_conv_kernel = "direct3_wgrad (128 channels) + reduce";
         int rc = mi_direct3x_wgrad_launch(dkind, a_src, b_src, (float*)ws, g.N, g.Di, s);
         if (rc) return rc;
         const int splits = mi_direct3x_wgrad_splits(dkind);
@@ -1401,8 +1390,7 @@ extern "C" size_t mi_conv3d_workspace_bytes(int N, int Di, int Hi, int Wi, int C
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
     best = std::max(best, direct3_ws_bytes(g));
     if (mi_pair_wgrad_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw))
-        best = std::max(std::max(best, mi_pair_wgrad_slab_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride)),
-                        mi_pairw_workspace_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride));
+        best = std::max(best, mi_pair_wgrad_slab_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride));
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;
@@ -1506,8 +1494,7 @@ extern "C" size_t mi_convnd_workspace_bytes(int N, int Di, int Hi, int Wi, int C
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
     best = std::max(best, direct3_ws_bytes(g));
     if (mi_pair_wgrad_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw))
-        best = std::max(std::max(best, mi_pair_wgrad_slab_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride)),
-                        mi_pairw_workspace_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride));
+        best = std::max(best, mi_pair_wgrad_slab_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride));
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;
@@ -1581,7 +1568,6 @@ extern "C" int mi_convnd_wgrad_slabs_batch_f32(const float* const* xs, const flo
     if (is_stem7(g)) return MI_E_UNSUPPORTED;
     // same order of preference as run_conv(MODE_WGRAD, ...)
     if (mi_pair_wgrad_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw)) {
-        if (getenv("MI_PAIRW") && atoi(getenv("MI_PAIRW")) != 0) return MI_E_UNSUPPORTED;
         if (nb > mi_pair_wgrad_batch_max()) return MI_E_UNSUPPORTED;
         const int splits = mi_pair_wgrad_splits(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride);
         if (splits > 1) {
@@ -1666,8 +1652,7 @@ extern "C" size_t mi_convnd_dil_workspace_bytes(int N, int Di, int Hi, int Wi, i
     size_t best = is_stem7(g) ? std::max(mi_stem7_wgrad_workspace_bytes(g.N, g.Di, g.Hi, g.Wi, g.Co), mi_stem7_fwd_workspace_bytes()) : 0;
     best = std::max(best, direct3_ws_bytes(g));
     if (mi_pair_wgrad_usable(g.N, g.Di, g.Hi, g.Wi, g.Ci, g.Co, g.kd, g.kh, g.kw, g.stride, g.pd, g.ph, g.pw, g.dd, g.dh, g.dw))
-        best = std::max(std::max(best, mi_pair_wgrad_slab_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride)),
-                        mi_pairw_workspace_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride));
+        best = std::max(best, mi_pair_wgrad_slab_bytes(g.N, g.Di, g.Ci, g.Co, g.kd, g.stride));
     for (int mode = 0; mode < 3; ++mode) {
         Setup st;
         if (setup_conv(mode, g, &st)) continue;

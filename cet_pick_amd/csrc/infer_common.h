@@ -108,12 +108,6 @@ bool mi_dogf_usable(const float* rec, const float* g1, const float* g2, const fl
 int mi_launch_dogf(DogfParams p, const DogfGrid& g, float s1, float s2, hipStream_t st);
 int mi_dogf_own();         // columns a strip of the y march owns
 
-// the same stage on the matrix cores (infer_dogm.hip): x + z passes | y pass + DoG + 3x3 xy-NMS + statistics + candidates
-DogfGrid mi_dogm_grid(int D, int H, int W, int bz, int bxy);
-bool mi_dogm_usable(const float* rec, const float* g1, const float* g2, const float* nms_out, int D, int H, int W,
-                    float s1, float s2, int k, int bz, int bxy);
-int mi_launch_dogm(DogfParams p, const DogfGrid& g, float s1, float s2, hipStream_t st);
-int mi_dogm_own();         // columns a strip of its y march owns
 
 dim3 mi_march_grid(int D, int H, int W, int* zchunk_out);
 int mi_launch_march(MarchParams p, int kz, int kxy, hipStream_t s);

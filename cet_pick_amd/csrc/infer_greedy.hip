@@ -1290,9 +1290,8 @@ size_t dog_ws_layout(int D, int H, int W, DogWs* w, char* base) {
     size_t f_seg = 0, f_ent = 0;
     if (2 * bxy_l < H && 2 * bxy_l < W) {
         const DogfGrid fg0 = mi_dogf_grid(D, H, W, 0, bxy_l);
-        const DogfGrid mg0 = mi_dogm_grid(D, H, W, 0, bxy_l);                   // (infer_dogm.hip: narrower strips, one chunk)
-        f_seg = std::max(std::max<size_t>(4 * 12288, (size_t)D * fg0.n_strips), (size_t)mg0.n_seg) + 64;      // (mi_dogf_grid: chunks double while waves < 6144; x4 for the MI_DOGF_NYC knob)
-        f_ent = std::max((size_t)D * fg0.n_strips * (size_t)(H - 2 * bxy_l) * 16 + 96 * f_seg, (size_t)mg0.n_seg * mg0.seg_cap);
+        f_seg = std::max<size_t>(4 * 12288, (size_t)D * fg0.n_strips) + 64;      // (mi_dogf_grid: chunks double while waves < 6144; x4 for the MI_DOGF_NYC knob)
+        f_ent = (size_t)D * fg0.n_strips * (size_t)(H - 2 * bxy_l) * 16 + 96 * f_seg;
     }
     const size_t cand_room = std::max(std::max(cand_cap, (size_t)xg.n_seg * xg.seg_cap), f_ent);
     p = take(sizeof(uint2) * cand_room);
@@ -1306,8 +1305,7 @@ size_t dog_ws_layout(int D, int H, int W, DogWs* w, char* base) {
     p = take(sizeof(uint2) * seg_room); if (w) w->seg_range = (uint2*)p;
     // sub-index of the fused picker's segments: (rows of a chunk / 8 + 1) slots per segment
     const size_t sub_room = 3 * seg_room + (2 * bxy_l < H && 2 * bxy_l < W
-                                            ? (size_t)D * std::max(mi_dogf_grid(D, H, W, 0, bxy_l).n_strips, mi_dogm_grid(D, H, W, 0, bxy_l).n_strips) *
-                                                  (size_t)((H - 2 * bxy_l) / 8 + 2) : 0);
+                                            ? (size_t)D * mi_dogf_grid(D, H, W, 0, bxy_l).n_strips * (size_t)((H - 2 * bxy_l) / 8 + 2) : 0);
     p = take(sizeof(unsigned) * sub_room); if (w) { w->sub = (unsigned*)p; w->sub_room = sub_room; }
     // the dense candidate map reuses a Gaussian buffer (free once the last DoG level is consumed)
     off += greedy_ws_layout(n_vox, greedy_default_cap(n_vox, false), w ? &w->gw : nullptr, base ? base + off : nullptr, false);
@@ -1339,14 +1337,10 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
     // also zeroes the header and the candidate bitmap, the candidate filter computes the cutoff in its prologue.
     {
         const int bxy_f = (H > 512 && W > 512) ? 60 : 30;
-        // round 5: the same two launches on the matrix cores where the volume allows (infer_dogm.hip), else the vector chain
-        // (the neighbour search visits at most two strips per row of cells: its window, 2 ceil(d / 2) + 1 columns, must not span
-        // three of the matrix-core chain's 30-column strips)
-        const bool use_m = n_sigmas == 2 && 2 * (int)ceil(0.5 * nms_d) < mi_dogm_own() &&
-                           mi_dogm_usable(rec, w.g[0], w.g[1], heat_out, D, H, W, sigmas_host[0], sigmas_host[1], k, border_z, bxy_f);
-        if (use_m || (n_sigmas == 2 && mi_dogf_usable(rec, w.g[0], w.g[1], heat_out, D, H, W, sigmas_host[0], sigmas_host[1], k,
-                                                      border_z, bxy_f))) {
-            const DogfGrid fg = use_m ? mi_dogm_grid(D, H, W, border_z, bxy_f) : mi_dogf_grid(D, H, W, border_z, bxy_f);
+        // (round 5 built the same two launches on the matrix cores - banded-Toeplitz bf16x3 products, picks identical - and measured
+        // them slower, 290 + 248 us against 203 + 152: profiles/r05_experiments.txt; the kernels left the library in round 6)
+        if (n_sigmas == 2 && mi_dogf_usable(rec, w.g[0], w.g[1], heat_out, D, H, W, sigmas_host[0], sigmas_host[1], k, border_z, bxy_f)) {
+            const DogfGrid fg = mi_dogf_grid(D, H, W, border_z, bxy_f);
             if (fg.n_seg > 0 && (size_t)fg.n_seg * fg.seg_cap <= w.cand_room && fg.n_seg <= w.seg_room) {
                 DogfParams q = {};
                 q.rec = rec; q.g1 = w.g[0]; q.g2 = w.g[1]; q.nms_out = heat_out;
@@ -1359,7 +1353,7 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
                                        (size_t)fg.n_seg * (nb + 1) <= w.sub_room;
                 if (!use_index) { q.clr[1] = gw.bits; q.clr_n[1] = bits_words; }     // (the bitmap search: A/B and fallback)
                 if (heat_out) MI_HIP(hipMemsetAsync(heat_out, 0, sizeof(float) * n_vox, s));      // the zeroed border
-                int rcf = use_m ? mi_launch_dogm(q, fg, sigmas_host[0], sigmas_host[1], s) : mi_launch_dogf(q, fg, sigmas_host[0], sigmas_host[1], s);
+                int rcf = mi_launch_dogf(q, fg, sigmas_host[0], sigmas_host[1], s);
                 if (rcf) return rcf;
                 gw.map = reinterpret_cast<int*>(w.tmp);               // (g[0] / g[1] are read by the y march only: free as
                 gw.vmap = reinterpret_cast<unsigned*>(w.heat); gw.vol = nullptr;    // well, but these two are never touched)
@@ -1377,7 +1371,7 @@ extern "C" int mi_dog_pick(const float* rec, int D, int H, int W, const float* s
                     SegIndex sx = {};
                     sx.seg_range = w.seg_range; sx.coord = coord; sx.coordz = coordz; sx.sub = w.sub; sx.nb = nb;
                     sx.D = D; sx.H = H; sx.W = W; sx.bz = border_z; sx.by = bxy_f; sx.bx = bxy_f;
-                    sx.ychunk = fg.ychunk; sx.n_ychunks = fg.n_ychunks; sx.n_strips = fg.n_strips; sx.own = use_m ? mi_dogm_own() : mi_dogf_own();
+                    sx.ychunk = fg.ychunk; sx.n_ychunks = fg.n_ychunks; sx.n_strips = fg.n_strips; sx.own = mi_dogf_own();
                     gw.sx = sx;
                 } else {
                     const unsigned fb = std::min<unsigned>((fg.n_seg + 7) / 8, 1024u);

@@ -1322,200 +1322,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k3s2_kernel(const float* dy, 
     }
 }
 
-// Round 5 (opt-in, MI_POOL_BWD_GATHER=1): the stem's backward chain WITHOUT the dense pool gradient.  maxpool_bwd_k3s2_kernel's gather
-// costs ~12 us of its 27 (the rest is the 67 MB store), so gathering twice moves fewer bytes than storing the gradient behind the ReLU
-// once and reading it twice:
-//   <false>: gather + ReLU mask (recomputed from x) + the two BatchNorm backward sums, per-workgroup partials in fp64 (the caller's
-//            pool_bwd_finalize_kernel adds them in a fixed order);             reads x (67 MB), the pooled gradient and argmax bytes
-//   <true> : gather + mask + dx = gamma * invstd * (dy' - sum_dy / count - xhat * sum_dyxhat / count);      reads x, writes dx
-// against pool backward (w 67 MB) + column reduce (r 134 MB) + apply (r 134, w 67): 201 of 402 MB, three launches instead of four.
-// Same thread layout and candidate order as maxpool_bwd_k3s2_kernel (the gathered gradient is bit-identical to its output); a
-// thread's sums run over the rows of its band in f32 (4 terms), everything above that in fp64.
-template <bool APPLY>
-__global__ __launch_bounds__(256) void bn_relu_pool_bwd_k3s2_kernel(const float* dy, const uint8_t* arg, const float* x, float* dx,
-                                                                   int Di, int Hi, int Wi, int C, int Do, int Ho, int Wo, int band,
-                                                                   const float* save, const float* gamma, const float* beta,
-                                                                   const double* sums, double count, float* dgamma, float* dbeta,
-                                                                   double* partials) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char pool_lds[];
-    const int yb = blockIdx.y * band, ye = min(Hi, yb + band);
-    const int yo_lo = yb >> 1, yo_hi = min(Ho - 1, ye >> 1);
-    const int Hb = band / 2 + 1;
-    const int plane_o = Ho * Wo * C;
-    const int plane_b = Hb * Wo * C;
-    float* s_dy = reinterpret_cast<float*>(pool_lds);
-    uint8_t* s_arg = pool_lds + 2 * (size_t)plane_b * sizeof(float);
-    const int zi = blockIdx.x % Di, n = blockIdx.x / Di;
-    const int z0 = zi >> 1;
-    const int nz = (zi & 1) ? ((z0 + 1 < Do) ? 2 : 1) : 1;
-    const int CV = C >> 2;
-    const int cv = threadIdx.x % CV, xi = threadIdx.x / CV;
-    // this thread's rows of x first: their latency runs under the staging of the pooled band
-    const long ystride = 4l * Wi * CV;
-    const long obase = 4 * ((((long)n * Di + zi) * Hi * Wi + xi) * CV + cv);
-    float4 xr[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xr[r] = (yb + r < ye) ? ld4(x + obase + (yb + r) * ystride) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int rows_b = (yo_hi - yo_lo + 1) * Wo * C / 4;
-    for (int q = threadIdx.x; q < nz * rows_b; q += 256) {
-        const int zq = q / rows_b, r = q % rows_b;
-        const long src = ((long)n * Do + z0 + zq) * plane_o + (long)yo_lo * Wo * C + 4 * r;
-        *reinterpret_cast<float4*>(s_dy + zq * plane_b + 4 * r) = ld4(dy + src);
-        *reinterpret_cast<unsigned*>(s_arg + zq * plane_b + 4 * r) = *reinterpret_cast<const unsigned*>(arg + src);
-    }
-    const int c = 4 * cv;
-    float mean[4], inv[4], gg[4], bb[4], gi[4], sdy[4], sdx[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        mean[k] = save[c + k]; inv[k] = save[C + c + k];
-        gg[k] = gamma ? gamma[c + k] : 1.f; bb[k] = beta ? beta[c + k] : 0.f;
-        gi[k] = gg[k] * inv[k];
-        if (APPLY) {
-            const float rc = (float)(1.0 / count);
-            sdy[k] = (float)sums[c + k] * rc; sdx[k] = (float)sums[C + c + k] * rc;
-        }
-    }
-    if (APPLY && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < CV) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (dbeta) dbeta[c + k] = (float)sums[c + k];
-            if (dgamma) dgamma[c + k] = (float)sums[C + c + k];
-        }
-    }
-    __syncthreads();
-    const int x0 = xi >> 1;
-    const int nx = (xi & 1) ? ((x0 + 1 < Wo) ? 2 : 1) : 1;
-    const int xoff0 = x0 * C + 4 * cv, xoff1 = xoff0 + C;
-    const int tx0 = (xi & 1) ? 2 : 1;
-    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int yi = yb + r;
-        if (yi >= ye) break;
-        const int y0 = yi >> 1;
-        const int ny = (yi & 1) ? ((y0 + 1 < Ho) ? 2 : 1) : 1;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int a = 0; a < nz; ++a) {
-            const int tz = (zi & 1) ? (a ? 0 : 2) : 1;
-            for (int b = 0; b < ny; ++b) {
-                const int ty = (yi & 1) ? (b ? 0 : 2) : 1;
-                const int rowb = (a * Hb + y0 + b - yo_lo) * Wo * C;
-                const int tzy = (tz * 3 + ty) * 3;
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    if (cc >= nx) break;
-                    const int o = rowb + (cc ? xoff1 : xoff0);
-                    const unsigned tp = (unsigned)(tzy + (cc ? 0 : tx0));
-                    const unsigned xw = *reinterpret_cast<const unsigned*>(s_arg + o) ^ (tp * 0x01010101u);     // zero byte = hit
-                    if (((xw - 0x01010101u) & ~xw & 0x80808080u) != 0u) {
-                        const float4 d = *reinterpret_cast<const float4*>(s_dy + o);
-                        if ((xw & 0x000000ffu) == 0u) acc[0] += d.x;
-                        if ((xw & 0x0000ff00u) == 0u) acc[1] += d.y;
-                        if ((xw & 0x00ff0000u) == 0u) acc[2] += d.z;
-                        if ((xw & 0xff000000u) == 0u) acc[3] += d.w;
-                    }
-                }
-            }
-        }
-        const float xv[4] = {xr[r].x, xr[r].y, xr[r].z, xr[r].w};
-        float o4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float xh = (xv[k] - mean[k]) * inv[k];
-            const float dm = fmaf(xh, gg[k], bb[k]) > 0.f ? acc[k] : 0.f;       // ReLU mask from the recomputed y
-            if (APPLY) o4[k] = gi[k] * (dm - sdy[k] - xh * sdx[k]);
-            else { s0[k] += dm; s1[k] = fmaf(dm, xh, s1[k]); }
-        }
-        if (APPLY) st4(dx + obase + yi * ystride, make_float4(o4[0], o4[1], o4[2], o4[3]));
-    }
-    if (!APPLY) {
-        // the 256 / CV threads of a channel vector added in fp64, in thread order: the workgroup's partial row
-        __shared__ double red[2][256][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { red[0][threadIdx.x][k] = (double)s0[k]; red[1][threadIdx.x][k] = (double)s1[k]; }
-        __syncthreads();
-        if (xi == 0) {
-            double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
-            const int RS = 256 / CV;
-            for (int rr = 0; rr < RS; ++rr)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { a0[k] += red[0][rr * CV + cv][k]; a1[k] += red[1][rr * CV + cv][k]; }
-            // partials[column][workgroup]: the finalize reads a column's row contiguously
-            const long n_part = (long)gridDim.x * gridDim.y, part = (long)blockIdx.y * gridDim.x + blockIdx.x;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { partials[(c + k) * n_part + part] = a0[k]; partials[(C + c + k) * n_part + part] = a1[k]; }
-        }
-    }
-}
-
-// one workgroup per column: thread t adds entries t, t + 256, ... in that order, then a fixed-shape tree over the 256 threads
-__global__ __launch_bounds__(256) void pool_bwd_finalize_kernel(const double* partials, long n_part, double* sums) {
-    const double* row = partials + (long)blockIdx.x * n_part;
-    double s = 0;
-    for (long b = threadIdx.x; b < n_part; b += 256) s += row[b];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    __shared__ double w[4];
-    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) sums[blockIdx.x] = (w[0] + w[1]) + (w[2] + w[3]);
-}
-
-static bool pool_bwd_fused_geom(int N, int Di, int Hi, int Wi, int C, int k, int stride, int pad) {
-    // measured (profiles/r05_experiments.txt item 6): alone 100 against 108 us per backward, but the captured step is 30 us SLOWER with
-    // it (1.588 against 1.556 ms) - the gather's instructions compete with the weight-gradient kernels next to it, the bytes it saves
-    // were not the limit there.  Opt-in: MI_POOL_BWD_GATHER=1.
-    { const char* v = getenv("MI_POOL_BWD_GATHER"); if (!v || atoi(v) == 0) return false; }
-    if (!(k == 3 && stride == 2 && pad == 1) || N <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || C % 4 || Wi * (C / 4) != 256) return false;
-    if (!colreduce_ok(C) || (long)N * Di >= (1l << 31) || (long)N * Di * Hi * Wi * C >= (1l << 40)) return false;
-    const int Wo = (Wi + 2 - 3) / 2 + 1;
-    return 2 * (size_t)(4 / 2 + 1) * Wo * C * 5 <= 64 * 1024;
-}
-static constexpr int POOL_BWD_BAND = 4;
-
-/* Backward of maxpool3d(relu(bn(x)), 3, 2, 1) in two launches that gather the pooled gradient themselves (no dense gradient
- * behind the ReLU in memory).  usable: the stem's geometry class (k 3 / stride 2 / pad 1, Wi * C / 4 == 256); otherwise the caller
- * runs mi_maxpool3d_bwd + mi_bn_relu_bwd_reduce_x + mi_bn_relu_bwd_apply_x. */
-extern "C" int mi_bn_relu_maxpool3d_bwd_usable(int N, int Di, int Hi, int Wi, int C, int k, int stride, int pad) {
-    return pool_bwd_fused_geom(N, Di, Hi, Wi, C, k, stride, pad) ? 1 : 0;
-}
-extern "C" size_t mi_bn_relu_maxpool3d_bwd_workspace_bytes(int N, int Di, int Hi, int Wi, int C) {
-    const long parts = (long)N * Di * ((Hi + POOL_BWD_BAND - 1) / POOL_BWD_BAND);
-    return sizeof(double) * 2 * (size_t)C * (size_t)parts + 256;
-}
-extern "C" int mi_bn_relu_maxpool3d_bwd_reduce(const float* dp, const uint8_t* argmax, const float* x, int N, int Di, int Hi, int Wi,
-                                               int C, int k, int stride, int pad, const float* save_mean_invstd, const float* gamma,
-                                               const float* beta, double* sums, void* ws, size_t ws_bytes, mi_stream_t stream) {
-    if (!dp || !argmax || !x || !save_mean_invstd || !sums) return MI_E_ARG;
-    if (!pool_bwd_fused_geom(N, Di, Hi, Wi, C, k, stride, pad)) return MI_E_UNSUPPORTED;
-    if (!ws || ws_bytes < mi_bn_relu_maxpool3d_bwd_workspace_bytes(N, Di, Hi, Wi, C)) return MI_E_WORKSPACE;
-    const int Do = (Di - 1) / 2 + 1, Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1, band = POOL_BWD_BAND;
-    const dim3 grid((unsigned)(N * Di), (unsigned)((Hi + band - 1) / band));
-    const size_t lds = 2 * (size_t)(band / 2 + 1) * Wo * C * 5;
-    hipLaunchKernelGGL((bn_relu_pool_bwd_k3s2_kernel<false>), grid, dim3(256), lds, (hipStream_t)stream, dp, argmax, x, (float*)nullptr,
-                       Di, Hi, Wi, C, Do, Ho, Wo, band, save_mean_invstd, gamma, beta, (const double*)nullptr, 1.0, (float*)nullptr,
-                       (float*)nullptr, (double*)ws);
-    MI_RETURN_IF_LAUNCH_FAILED();
-    hipLaunchKernelGGL(pool_bwd_finalize_kernel, dim3(2 * C), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
-                       (long)grid.x * grid.y, sums);
-    MI_RETURN_IF_LAUNCH_FAILED();
-    return MI_OK;
-}
-extern "C" int mi_bn_relu_maxpool3d_bwd_apply(const float* dp, const uint8_t* argmax, const float* x, float* dx, int N, int Di, int Hi,
-                                              int Wi, int C, int k, int stride, int pad, const float* save_mean_invstd,
-                                              const float* gamma, const float* beta, const double* sums, double count, float* dgamma,
-                                              float* dbeta, mi_stream_t stream) {
-    if (!dp || !argmax || !x || !dx || !save_mean_invstd || !sums || !(count > 0)) return MI_E_ARG;
-    if (!pool_bwd_fused_geom(N, Di, Hi, Wi, C, k, stride, pad)) return MI_E_UNSUPPORTED;
-    const int Do = (Di - 1) / 2 + 1, Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1, band = POOL_BWD_BAND;
-    const dim3 grid((unsigned)(N * Di), (unsigned)((Hi + band - 1) / band));
-    const size_t lds = 2 * (size_t)(band / 2 + 1) * Wo * C * 5;
-    hipLaunchKernelGGL((bn_relu_pool_bwd_k3s2_kernel<true>), grid, dim3(256), lds, (hipStream_t)stream, dp, argmax, x, dx, Di, Hi, Wi,
-                       C, Do, Ho, Wo, band, save_mean_invstd, gamma, beta, sums, count, dgamma, dbeta, (double*)nullptr);
-    MI_RETURN_IF_LAUNCH_FAILED();
-    return MI_OK;
-}
-
+// (Round 5 built the stem's backward chain WITHOUT the dense pool gradient - both BatchNorm halves gathering the pooled gradient
+// themselves: 8 us faster alone, 30 us slower inside the captured step, profiles/r05_experiments.txt item 6; removed in round 6.)
 extern "C" int mi_maxpool3d_bwd(const float* dy, const uint8_t* argmax, float* dx, int N, int Di,
                                 int Hi, int Wi, int C, int k, int stride, int pad, mi_stream_t stream) {
     if (!dy || !argmax || !dx || C % 4 || k <= 0 || k > 6 || stride <= 0 || pad < 0) return MI_E_ARG;

@@ -1145,7 +1145,7 @@ def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None, pool=False):
 CONCAT_DIRECT = os.environ.get("CETPICK_CONCAT_DIRECT", "1") != "0"
 
 
-def skip_into_concat_ok(conv, bn, x, co_up):
+def skip_into_concat_ok(conv, bn, x, co_up, up=None, up_bn=None):
     """True when a down-convolution block's last layer (conv -> bn -> ReLU -> pool on x) can write its un-pooled output - the skip
     connection - straight into the concatenation buffer of the up-convolution block that consumes it, AND that block's transposed
     convolution will write the other channels there with its fused epilogue (upconv_bn_relu_concat): inference, both on conv_d32.hip."""
@@ -1155,6 +1155,15 @@ def skip_into_concat_ok(conv, bn, x, co_up):
     n, h, w, ci = x.shape
     co = conv.co
     if co != co_up or co not in (32, 64) or h % 16 or w % 32:          # the up block: 2 co -> co on (h / 2, w / 2), rows % 8, columns % 16
+        return False
+    # the concatenation buffer is co_up + co channels wide: both kernels that write into it address it with 32-bit byte offsets and
+    # answer MI_E_UNSUPPORTED from 0x7fff0000 bytes on (a 32-slice chunk of a 1024 x 1024 tomogram: 2^31) - the dense form takes over
+    if 4 * n * h * w * (co_up + co) >= 0x7fff0000:
+        return False
+    # ... and the up block's side of the bargain: evaluation-mode BatchNorm that can be folded, weights in kernel layout
+    if up_bn is not None and (up_bn.training or not up_bn.track_running_stats):
+        return False
+    if up is not None and not _phys_ok(up.gemm_view()):
         return False
     k3, p3 = _k3(conv.k, False), _p3(conv.pad, False)
     return _d32_kind((n, 1, h, w, ci), ci, co, k3, conv.stride, p3, None, True) in (1, 3)
@@ -1690,23 +1699,13 @@ class _BNReluPoolFn(torch.autograd.Function):
         m = n * d * h * w
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         gamma, beta = mod.weight, mod.bias
-        # the pool's backward materialised once, then BatchNorm's two halves with the ReLU mask recomputed from x.  Opt-in
-        # (MI_POOL_BWD_GATHER=1, the stem's geometry): both halves gather the pooled gradient themselves - half the bytes, 8 us
-        # faster alone, 30 us slower inside the captured step (r05_experiments.txt item 6)
-        gather = bool(lib.mi_bn_relu_maxpool3d_bwd_usable(n, d, h, w, c, k, stride, pad))
-        if gather:
-            ws = _ws(lib.mi_bn_relu_maxpool3d_bwd_workspace_bytes(n, d, h, w, c), dev, "pool_bwd")
-            L.check(lib.mi_bn_relu_maxpool3d_bwd_reduce(L.ptr(dp), L.ptr(arg), L.ptr(x), n, d, h, w, c, k, stride, pad, L.ptr(save),
-                                                        L.ptr(gamma), L.ptr(beta), L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()),
-                    "mi_bn_relu_maxpool3d_bwd_reduce")
-            dy = None
-        else:
-            dy = torch.empty_like(x)
-            L.check(lib.mi_maxpool3d_bwd(L.ptr(dp), L.ptr(arg), L.ptr(dy), n, d, h, w, c, k, stride, pad, L.stream()),
-                    "mi_maxpool3d_bwd")
-            ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
-            L.check(lib.mi_bn_relu_bwd_reduce_x(L.ptr(dy), L.ptr(x), m, c, L.ptr(save), L.ptr(gamma), L.ptr(beta), L.ptr(sums),
-                                                L.ptr(ws), ws.numel(), L.stream()), "mi_bn_relu_bwd_reduce_x")
+        # the pool's backward materialised once, then BatchNorm's two halves with the ReLU mask recomputed from x
+        dy = torch.empty_like(x)
+        L.check(lib.mi_maxpool3d_bwd(L.ptr(dp), L.ptr(arg), L.ptr(dy), n, d, h, w, c, k, stride, pad, L.stream()),
+                "mi_maxpool3d_bwd")
+        ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
+        L.check(lib.mi_bn_relu_bwd_reduce_x(L.ptr(dy), L.ptr(x), m, c, L.ptr(save), L.ptr(gamma), L.ptr(beta), L.ptr(sums),
+                                            L.ptr(ws), ws.numel(), L.stream()), "mi_bn_relu_bwd_reduce_x")
         dg = db = None
         acc_g = acc_b = False
         if gamma is not None and gamma.requires_grad:
@@ -1720,17 +1719,10 @@ class _BNReluPoolFn(torch.autograd.Function):
                 L.check(lib.mi_bn_param_grads(L.ptr(sums), c, L.ptr(dg), L.ptr(db), L.stream()), "mi_bn_param_grads")
             import torch.distributed as dist
             dist_all_reduce(sums)
-        if gather:
-            dx = torch.empty_like(x)
-            L.check(lib.mi_bn_relu_maxpool3d_bwd_apply(L.ptr(dp), L.ptr(arg), L.ptr(x), L.ptr(dx), n, d, h, w, c, k, stride, pad,
-                                                       L.ptr(save), L.ptr(gamma), L.ptr(beta), L.ptr(sums), ctx.count,
-                                                       L.ptr(None if distributed else dg), L.ptr(None if distributed else db),
-                                                       L.stream()), "mi_bn_relu_maxpool3d_bwd_apply")
-        else:
-            dx = dy                                        # in place: each element is read, then written, by one thread
-            L.check(lib.mi_bn_relu_bwd_apply_x(L.ptr(dy), L.ptr(x), L.ptr(dx), m, c, L.ptr(save), L.ptr(gamma), L.ptr(beta),
-                                               L.ptr(sums), ctx.count, L.ptr(None if distributed else dg),
-                                               L.ptr(None if distributed else db), L.stream()), "mi_bn_relu_bwd_apply_x")
+        dx = dy                                            # in place: each element is read, then written, by one thread
+        L.check(lib.mi_bn_relu_bwd_apply_x(L.ptr(dy), L.ptr(x), L.ptr(dx), m, c, L.ptr(save), L.ptr(gamma), L.ptr(beta),
+                                           L.ptr(sums), ctx.count, L.ptr(None if distributed else dg),
+                                           L.ptr(None if distributed else db), L.stream()), "mi_bn_relu_bwd_apply_x")
         if acc_g:
             gamma.grad.add_(dg)
         if acc_b:

@@ -35,13 +35,14 @@ class DownConv(nn.Module):
         self.norm0 = H.HipBatchNorm(co)
         self.norm1 = H.HipBatchNorm(co)
 
-    def forward(self, x, co_up=None):
+    def forward(self, x, co_up=None, up=None):
         """-> (input of the next level, skip connection, concatenation buffer or None).  co_up: the channels the up-convolution block
         that consumes the skip connection puts in front of it - at inference, where both layers run on the patch-resident kernel, the skip
         connection is written straight into that block's concatenation buffer (no concatenation pass)."""
         y = H.conv_bn(self.conv1, self.norm0, x, relu=True)
         if self.pooling:
-            if co_up is not None and H.skip_into_concat_ok(self.conv2, self.norm1, y, co_up):
+            if co_up is not None and H.skip_into_concat_ok(self.conv2, self.norm1, y, co_up, up=up.upconv if up is not None else None,
+                                                           up_bn=up.norm0 if up is not None else None):
                 n, h, w, _ = y.shape
                 cat = torch.empty((n, h, w, co_up + self.conv2.co), dtype=torch.float32, device=y.device)
                 skip, pooled = H.conv_bn(self.conv2, self.norm1, y, relu=True, pool=True, out=cat[..., co_up:])
@@ -105,7 +106,7 @@ class UNet(nn.Module):
         for j, blk in enumerate(self.down_convs):
             # the skip connection of down block j is consumed by up block nd - 2 - j
             up = self.up_convs[nd - 2 - j] if j < nd - 1 else None
-            x, before_pool, cat = blk(x, co_up=up.upconv.co if up is not None else None)
+            x, before_pool, cat = blk(x, co_up=up.upconv.co if up is not None else None, up=up)
             skips.append((before_pool, cat))
         for i, blk in enumerate(self.up_convs):
             enc, cat = skips[-(i + 2)]

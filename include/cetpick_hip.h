@@ -450,26 +450,11 @@ int mi_bn_apply_fwd(const float* x, float* y, long M, int C, const double* sums,
                     float* save_mean_invstd, const float* res, int relu, mi_stream_t stream);
 /* The stem's BatchNorm3d + ReLU + MaxPool3d(3, 2, 1) (moco_encoder_3d.py:170-172) fused: relu(bn(x)) is never
  * written.  fwd: after mi_bn_stats (+ SyncBN all-reduce); sums == NULL = eval mode.  x (N,Di,Hi,Wi,C), pooled
- * (N,Do,Ho,Wo,C), argmax uint8.  bwd: mi_maxpool3d_bwd, then mi_bn_relu_bwd_{reduce,apply}_x; or, where _usable says so (opt-in,
- * MI_POOL_BWD_GATHER=1), mi_bn_relu_maxpool3d_bwd_{reduce,apply}, which gather the pooled gradient themselves (half the bytes;
- * measured slower inside the training step, faster alone). */
+ * (N,Do,Ho,Wo,C), argmax uint8.  bwd: mi_maxpool3d_bwd, then mi_bn_relu_bwd_{reduce,apply}_x. */
 int mi_bn_relu_maxpool3d_fwd(const float* x, float* y, uint8_t* argmax, int N, int Di, int Hi, int Wi, int C, int k,
                              int stride, int pad, const double* sums, double count, const float* gamma,
                              const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                              long long* num_batches_tracked, float* save_mean_invstd, mi_stream_t stream);
-/* Backward of maxpool3d(relu(bn(x)), 3, 2, 1) from the POOLED gradient dp (N,Do,Ho,Wo,C) and the argmax bytes of the forward
- * (trains/base_trainer.py:497 loss.backward() through moco_encoder_3d.py:170-172): _reduce leaves sums = [sum dy', sum dy' * xhat]
- * (2C doubles, dy' = gradient behind the ReLU; SyncBN all-reduces them), _apply writes dx (N,Di,Hi,Wi,C) and, when not NULL,
- * dgamma / dbeta.  ws: mi_bn_relu_maxpool3d_bwd_workspace_bytes.  MI_E_UNSUPPORTED outside _usable's geometry class. */
-int mi_bn_relu_maxpool3d_bwd_usable(int N, int Di, int Hi, int Wi, int C, int k, int stride, int pad);
-size_t mi_bn_relu_maxpool3d_bwd_workspace_bytes(int N, int Di, int Hi, int Wi, int C);
-int mi_bn_relu_maxpool3d_bwd_reduce(const float* dp, const uint8_t* argmax, const float* x, int N, int Di, int Hi, int Wi, int C,
-                                    int k, int stride, int pad, const float* save_mean_invstd, const float* gamma,
-                                    const float* beta, double* sums, void* ws, size_t ws_bytes, mi_stream_t stream);
-int mi_bn_relu_maxpool3d_bwd_apply(const float* dp, const uint8_t* argmax, const float* x, float* dx, int N, int Di, int Hi, int Wi,
-                                   int C, int k, int stride, int pad, const float* save_mean_invstd, const float* gamma,
-                                   const float* beta, const double* sums, double count, float* dgamma, float* dbeta,
-                                   mi_stream_t stream);
 /* Backward of relu(bn(x)) without the stored activation (mask recomputed from x); dy = mi_maxpool3d_bwd's output. */
 int mi_bn_relu_bwd_reduce_x(const float* dy, const float* x, long M, int C, const float* save_mean_invstd,
                             const float* gamma, const float* beta, double* sums, void* ws, size_t ws_bytes,

@@ -274,32 +274,6 @@ def test_dog_pick_chains_agree(shape, sigmas, nms_d, monkeypatch):
     np.testing.assert_array_equal(s0, so)
 
 
-@pytest.mark.parametrize("shape", [(64, 256, 256), (48, 200, 264)])
-def test_dog_pick_matrix_core_chain_agrees(shape, monkeypatch):
-    """The picker's filter stage on the matrix cores (infer_dogm.hip, opt-in MI_DOGM=1: banded-Toeplitz bf16x3 products for
-    the x, z and y passes) against the vector chain on the same tomogram: same cutoff to 1e-6, NMS'd heat-maps to 2e-7,
-    identical picks."""
-    from cet_pick_amd.utils import image as Im
-    vol, _ = make_tomo(shape, seed=321)
-    v = dev(vol)
-
-    def run():
-        s, c, n, cut, heat = Im.dog_pick(v, [3, 5], return_heat=True)
-        k = int(n.item())
-        return s[:k].cpu().numpy(), c[:k].cpu().numpy(), float(cut.item()), heat.cpu().numpy()
-
-    s0, c0, cut0, h0 = run()
-    monkeypatch.setenv("MI_DOGM", "1")
-    s1, c1, cut1, h1 = run()
-    monkeypatch.delenv("MI_DOGM")
-    assert len(s0) > 20
-    assert abs(cut1 - cut0) <= 1e-6 * abs(cut0)
-    np.testing.assert_allclose(h1, h0, rtol=0, atol=2e-7)
-    np.testing.assert_array_equal((h1 != 0), (h0 != 0))
-    np.testing.assert_array_equal(c1, c0)
-    np.testing.assert_allclose(s1, s0, rtol=1e-5)
-
-
 def test_get_potential_coords(golden):
     from cet_pick_amd.utils import image as Im
     g = golden("dog_small.npz")

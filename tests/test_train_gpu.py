@@ -150,7 +150,6 @@ def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
     ref64 = chain(x.double(), w.double(), res.double(), mask.double(), dy.double())
     cpu32 = chain(x, w, res, mask, dy)                   # the arbiter: the same chain in fp32 on the CPU
     out = {}
-    monkeypatch.setenv("MI_D3X_WGRAD_256", "1")          # (layer3 of 64^3 crops on direct3_wgrad_kernel<true, 256>: opt-in, tested here)
     for tag, off in (("direct", "0"), ("igemm", "1")):
         monkeypatch.setenv("MI_CONV_NO_DIRECT", off)
         yf = H.conv_fwd(cl(x), param, 3, 1, 1, cl(res), True)
@@ -870,16 +869,12 @@ def test_maxpool_backward_parity_form_equals_generic(shape, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(4, 16, 16, 16, 64), (2, 5, 7, 16, 64), (3, 10, 12, 32, 32), (2, 2, 2, 64, 16), (1, 9, 3, 8, 128)])
-def test_stem_backward_gather_form_equals_dense_form_and_torch(shape, monkeypatch):
-    """Round 5: the backward of maxpool3d(relu(bn(x)), 3, 2, 1) with the pooled gradient gathered inside both BatchNorm halves
-    (bn_relu_pool_bwd_k3s2_kernel<false / true>, opt-in MI_POOL_BWD_GATHER=1: no dense gradient behind the ReLU) against the default
-    form (pool backward, column reduce, apply) and against torch (BatchNorm3d + ReLU + MaxPool3d), on the stem's
-    geometry class incl. odd depths / heights and a last band of fewer than four rows (moco_encoder_3d.py:170-172)."""
-    from cet_pick_amd import hipops as H, _lib as L
+def test_stem_backward_matches_torch(shape):
+    """The backward of maxpool3d(relu(bn(x)), 3, 2, 1) - pool backward, column reduce with the ReLU mask recomputed from x, apply -
+    against torch (BatchNorm3d + ReLU + MaxPool3d), on the stem's geometry class incl. odd depths / heights and a last band of fewer
+    than four rows (moco_encoder_3d.py:170-172)."""
+    from cet_pick_amd import hipops as H
     n, d, h, w, c = shape
-    assert L.lib().mi_bn_relu_maxpool3d_bwd_usable(n, d, h, w, c, 3, 2, 1) == 0          # opt-in
-    monkeypatch.setenv("MI_POOL_BWD_GATHER", "1")
-    assert L.lib().mi_bn_relu_maxpool3d_bwd_usable(n, d, h, w, c, 3, 2, 1) == 1
     g = torch.Generator().manual_seed(sum(shape) + 5)
     x = torch.randn(n, c, d, h, w, generator=g) * 2 + 0.5
     bn_ref = torch.nn.BatchNorm3d(c)
@@ -890,42 +885,27 @@ def test_stem_backward_gather_form_equals_dense_form_and_torch(shape, monkeypatc
     yr = F.max_pool3d(torch.relu(bn_ref(xr)), 3, 2, 1)
     dy = torch.randn(yr.shape, generator=g)
     yr.backward(dy)
-    got = {}
-    for form in ("gather", "dense"):
-        if form == "dense":
-            monkeypatch.delenv("MI_POOL_BWD_GATHER")
-            assert L.lib().mi_bn_relu_maxpool3d_bwd_usable(n, d, h, w, c, 3, 2, 1) == 0
-        bn = H.HipBatchNorm(c)
-        bn.load_state_dict(bn_ref.state_dict())
-        bn = bn.cuda().train()
-        xc = cl(x).requires_grad_(True)
-        y = H.bn_relu_maxpool3d(xc, bn, 3, 2, 1)
-        y.backward(cl(dy))
-        got[form] = (xc.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
-    for a, b in zip(got["gather"], got["dense"]):
-        # same gathered gradient, same mask; the two sums are added in another order (f32 over 4 rows, then fp64)
-        scale = float(b.abs().max()) + 1e-30
-        assert float((a - b).abs().max()) <= 2e-6 * scale
-    np.testing.assert_allclose(ncdhw(got["gather"][0]).numpy(), xr.grad.numpy(), rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(got["gather"][1].cpu().numpy(), bn_ref.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(got["gather"][2].cpu().numpy(), bn_ref.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+    bn = H.HipBatchNorm(c)
+    bn.load_state_dict(bn_ref.state_dict())
+    bn = bn.cuda().train()
+    xc = cl(x).requires_grad_(True)
+    y = H.bn_relu_maxpool3d(xc, bn, 3, 2, 1)
+    y.backward(cl(dy))
+    np.testing.assert_allclose(ncdhw(xc.grad).numpy(), xr.grad.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), bn_ref.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), bn_ref.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["pair_wgrad", "pairw", "pairw64"])
 @pytest.mark.parametrize("case", [(64, 4, 128, 128, 3, 1), (70, 4, 128, 128, 3, 1), (9, 8, 64, 128, 3, 2), (9, 8, 64, 128, 1, 2),
                                   (5, 6, 64, 64, 3, 2), (33, 2, 256, 128, 3, 1), (3, 8, 64, 64, 3, 1)])
-def test_pair_weight_gradient_forms_match_float64(case, form, monkeypatch):
-    """The opt-in weight-gradient kernels of round 4 (r04_experiments.txt item 26) on layer2 / layer2.0 / layer3 / layer1 shapes:
-    pair_wgrad_kernel with a tap's chain in segments (MI_PAIR_WGRAD_MAXOUT) and pairw_kernel from pre-cut operand images
-    (MI_PAIRW=1; 128 x 128 and 64 x 64 tiles) against float64, with the error bound of the default path (bf16x3 = f32-equivalent)."""
+def test_pair_weight_gradient_forms_match_float64(case, monkeypatch):
+    """pair_wgrad_kernel with a tap's chain in segments (MI_PAIR_WGRAD_MAXOUT) on layer2 / layer2.0 / layer3 / layer1 shapes against
+    float64, with the error bound of the default path (bf16x3 = f32-equivalent)."""
     from cet_pick_amd import hipops as H, _lib as L
     n, d, ci, co, k, s = case
     pad = 1 if k == 3 else 0
     monkeypatch.setenv("MI_PAIR_WGRAD_MAXOUT", "8")
-    monkeypatch.setenv("MI_PAIRW", "0" if form == "pair_wgrad" else "1")
-    if form == "pairw64":
-        monkeypatch.setenv("MI_PAIRW_B2", "1")
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(n, ci, d, d, d, generator=g)
     param, w = make_w(co, ci, k, g)
@@ -936,7 +916,7 @@ def test_pair_weight_gradient_forms_match_float64(case, form, monkeypatch):
     (gw,) = torch.autograd.grad(y64, w64, dy.double().cuda())
     param.grad = None
     H.conv_wgrad_into(cl(x), cl(dy), param, k, s, pad)
-    assert L.lib().mi_debug_last_conv_kernel().decode().startswith("pair_wgrad" if form == "pair_wgrad" else "pairw")
+    assert L.lib().mi_debug_last_conv_kernel().decode().startswith("pair_wgrad")
     scale = float(gw.abs().max())
     assert float((param.grad.double() - gw).abs().max()) <= 2e-6 * scale * max(1.0, (n * d ** 3 / 512) ** 0.5)
 

@@ -154,6 +154,35 @@ def test_skip_connections_written_into_the_concatenation_equal_the_copied_form()
     assert float((outs["direct"] - outs["separate"]).abs().max()) <= 2e-6 * float(outs["separate"].abs().max())
 
 
+def test_skip_into_concatenation_declines_a_buffer_of_2_gib():
+    """the concatenation buffer is co_up + co channels wide; from 0x7fff0000 bytes on the kernels that write into it
+    decline (32-bit byte offsets), so the predicate must send such a level through the dense skip + copy form instead of raising - a
+    32-slice chunk of a 1024 x 1024 tomogram (32 x 512 x 512 x 64 floats = 2^31 bytes) is the first case.  The U-Net forward on that
+    chunk runs and equals the copied form bit for bit."""
+    from cet_pick_amd import hipops as H
+    from cet_pick_amd.models.networks.unet_small import UNet
+    torch.manual_seed(5)
+    net = UNet(16, out_channels=32, n_blocks=4).cuda().eval()
+    blk, up = net.down_convs[0], net.up_convs[-1]
+    with torch.no_grad():
+        y31 = torch.empty(31, 512, 512, 32, device="cuda")
+        y32 = torch.empty(32, 512, 512, 32, device="cuda")
+        assert H.skip_into_concat_ok(blk.conv2, blk.norm1, y31, up.upconv.co, up=up.upconv, up_bn=up.norm0)
+        assert not H.skip_into_concat_ok(blk.conv2, blk.norm1, y32, up.upconv.co, up=up.upconv, up_bn=up.norm0)
+        up.norm0.train()                                   # an up block whose BatchNorm cannot be folded declines as well
+        assert not H.skip_into_concat_ok(blk.conv2, blk.norm1, y31, up.upconv.co, up=up.upconv, up_bn=up.norm0)
+        up.norm0.eval()
+        del y31, y32
+        x = torch.randn(32, 512, 512, 16, device="cuda")
+        direct = net(x)
+        saved, H.CONCAT_DIRECT = H.CONCAT_DIRECT, False
+        try:
+            copied = net(x)
+        finally:
+            H.CONCAT_DIRECT = saved
+        assert torch.equal(direct, copied)
+
+
 @pytest.mark.parametrize("ci,co,h,w", [(16, 32, 32, 48), (32, 32, 16, 16), (32, 64, 32, 32), (64, 64, 16, 48), (64, 128, 16, 32), (128, 128, 16, 16)])
 def test_down_convolution_pool_in_the_epilogue_equals_the_pooling_pass(ci, co, h, w):
     """mi_conv_d32_fwd_pool_f32 (round 5; unet.py:198-249): conv -> folded BatchNorm -> ReLU with the 2 x 2 max-pool as a second output of
