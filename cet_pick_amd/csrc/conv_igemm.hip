@@ -1592,6 +1592,13 @@ extern "C" int mi_convnd_wgrad_slabs_batch_f32(const float* const* xs, const flo
         *splits_out = mi_direct3s_wgrad_splits(nb);
         return mi_direct3s_wgrad_launch_batch(xs, dys, slabs, nb, g.N, s);
     }
+    //  64^3 crops: layer2 (kind 3) and layer1 on 8 x 8 tiles (kind 5) have dedicated single-launch kernels in run_conv and no
+    // batched form: the caller issues single launches, which reach them - the batched implicit GEMM below would bypass them
+    {
+        const int dk = direct3_kind(g);
+        if (dk == 3 && !env_int("MI_NO_D3X_WGRAD")) return MI_E_UNSUPPORTED;
+        if (dk == 5 && g.Hi % 8 == 0 && g.Wi % 8 == 0 && !env_int("MI_NO_D3T_WGRAD")) return MI_E_UNSUPPORTED;
+    }
     Setup st;
     int rc = setup_conv(MODE_WGRAD, g, &st);
     if (rc) return rc;

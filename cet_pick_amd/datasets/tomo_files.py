@@ -140,7 +140,7 @@ class TomoFileMocoLoader(SyntheticMocoLoader):
     def _cut(self, idx, shifted):
         """one view of the samples `idx` with the per-batch bookkeeping on the HOST (rounds 3-4: index arithmetic in numpy, an
         index upload and a scatter per tomogram); kept as the reference form of what `__iter__` serves
-        (tests/test_loader_gpu.py) - the batches themselves come from the device-side table"""
+        (tests/test_entry_points_gpu.py::test_device_side_loader_serves_the_crops_of_the_host_side_one) - the batches themselves come from the device-side table"""
         c = (self.crop,) * 3
         out = torch.empty((len(idx), 1) + c, dtype=torch.float32, device=self.vols[0].device)
         for v in np.unique(self.owner[idx]):

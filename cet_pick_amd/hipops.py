@@ -851,18 +851,27 @@ WGRAD_BATCH_MAX = 4
 # (tests/test_trainer_gpu.py::test_engine_step_equals_plain_sequence_bitwise) although a batched layer1 gradient is cut into other
 # chains than a single one.
 _BACKWARD_END = None
+_BACKWARD_END_TASK = -1          # autograd graph-task id of the pass the queued jobs belong to
 
 
 def _defer_to_backward_end(job):
-    global _BACKWARD_END
+    global _BACKWARD_END, _BACKWARD_END_TASK
     try:
-        # (one callback per job: the first one to run flushes everything, the others find the list empty - and a list left
-        # behind by a backward pass that raised cannot stay unflushed for ever)
+        # (one callback per job: the first one to run flushes everything, the others find the list empty)
         torch.autograd.Variable._execution_engine.queue_callback(_flush_backward_end)
     except RuntimeError:                                   # not inside a backward pass (a direct call): launch now
         return False
+    task = torch._C._current_graph_task_id()
+    if _BACKWARD_END is not None and task != _BACKWARD_END_TASK:
+        #  jobs of a backward pass that RAISED (its final callbacks never ran): their operands belong to a dead pass -
+        # dropped, never launched into the gradients of this one
+        for stale in _BACKWARD_END:
+            if stale.param is not None:
+                stale.param._mi_wgrad_pending = False
+        _BACKWARD_END = None
     if _BACKWARD_END is None:
         _BACKWARD_END = []
+        _BACKWARD_END_TASK = task
     _BACKWARD_END.append(job)
     if job.param is not None:
         job.param._mi_wgrad_pending = True                 # (a second contribution to this parameter flushes first: conv_wgrad_into)

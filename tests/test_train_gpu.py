@@ -925,7 +925,9 @@ def test_pair_weight_gradient_forms_match_float64(case, monkeypatch):
 @pytest.mark.parametrize("case,nb,family", [((16, 8, 64, 64, 3, 1), 4, "direct3_wgrad x nb"), ((16, 8, 64, 64, 3, 1), 3, "direct3_wgrad x nb"),
                                             ((24, 4, 128, 128, 3, 1), 3, "direct3s_wgrad x nb"), ((64, 4, 128, 128, 3, 1), 2, "direct3s_wgrad x nb"), ((7, 4, 128, 128, 3, 1), 4, "direct3s_wgrad x nb"),
                                             ((24, 4, 128, 64, 3, 1), 3, "implicit GEMM x nb"), ((24, 4, 128, 128, 3, 1), 3, "implicit GEMM x nb"), ((20, 2, 256, 256, 3, 1), 4, "pair_wgrad x nb"),
-                                            ((6, 8, 32, 48, 3, 1), 2, "implicit GEMM x nb"), ((16, 8, 64, 64, 3, 1), 5, "direct3_wgrad x nb")])
+                                            ((6, 8, 32, 48, 3, 1), 2, "implicit GEMM x nb"), ((16, 8, 64, 64, 3, 1), 5, "direct3_wgrad x nb"),
+                                            #  the 64^3-crop shapes: no batched kernel - the group goes out as single launches of the dedicated ones
+                                            ((3, 16, 64, 64, 3, 1), 2, "single:direct3_wgrad (8 x 8 tiles)"), ((3, 8, 128, 128, 3, 1), 3, "single:direct3_wgrad (128 channels)")])
 def test_batched_weight_gradients_against_single_launches(case, nb, family, monkeypatch):
     """Round 5: the weight gradients of a stage's equal convolutions in ONE launch (hipops.run_wgrad_jobs ->
     mi_convnd_wgrad_slabs_batch_f32; layer1's four on direct3_wgrad_kernel, layer2's three on the implicit GEMM, layer3's on
@@ -964,7 +966,7 @@ def test_batched_weight_gradients_against_single_launches(case, nb, family, monk
             H.conv_wgrad_into(x, dy, prm, k, s_, pad)
         H.flush_wgrad_reduces()
         name = batched(batch, list(range(nb)))
-        assert name.startswith(family if nb != 5 else "direct3_wgrad + reduce"), name
+        assert name.startswith(family[7:] if family.startswith("single:") else family if nb != 5 else "direct3_wgrad + reduce"), name
         batched(pair, [0, nb - 1])                     # the first and the last problem again, in a launch of two
     finally:
         H.DEFERRED_WGRADS = None
@@ -977,7 +979,7 @@ def test_batched_weight_gradients_against_single_launches(case, nb, family, monk
         bound = 2e-6 * float(gw.abs().max()) * max(1.0, (n * do ** 3 / 512) ** 0.5)
         assert float((b.grad.double() - gw).abs().max()) <= bound
         assert float((a.grad.double() - gw).abs().max()) <= bound
-        if not family.startswith("direct3") or (nb == 5 and i == 4):
+        if not family.startswith("direct3") or (nb == 5 and i == 4):         # (single launches either way: bit for bit)
             assert torch.equal(a.grad, b.grad), i
         if i in (0, nb - 1) and nb != 5:
             assert torch.equal(pair[i].grad, b.grad), i
@@ -1052,3 +1054,37 @@ def test_linear_stats_epilogue_matches_statistics_pass(m, ci, co, bias):
     want = torch.cat([y.double().sum(0), (y.double() ** 2).sum(0)])
     scale = torch.cat([y.double().abs().sum(0), (y.double() ** 2).sum(0)])
     assert float(((sums - want).abs() / scale).max()) < 1e-12
+
+
+@pytest.mark.gpu
+def test_weight_gradients_of_a_backward_pass_that_raised_are_dropped():
+    """layer1-shaped weight gradients wait for the END of a plain backward pass (one batched launch); a pass that raises never
+    runs its final callbacks, and the queued jobs used to be launched into the NEXT pass's gradients.  They are now tagged with the
+    autograd graph task and dropped by the first deferral of another pass."""
+    from cet_pick_amd import hipops as H
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    g = torch.Generator().manual_seed(3)
+    conv = H.HipConv3d(64, 64, 3, 1, 1).cuda()
+    x = cl(torch.randn(4, 64, 8, 8, 8, generator=g))
+    xin = x.clone().requires_grad_(True)
+    y = conv(Boom.apply(xin))
+    with pytest.raises(RuntimeError, match="boom"):
+        (y * 3.0).sum().backward()                             # conv's weight gradient is queued, then the pass dies
+    assert H._BACKWARD_END is not None and len(H._BACKWARD_END) == 1
+    conv.weight.grad = None
+    x2 = cl(torch.randn(4, 64, 8, 8, 8, generator=g)).requires_grad_(True)
+    conv(x2).sum().backward()
+    got = conv.weight.grad.clone()
+    assert H._BACKWARD_END is None and not getattr(conv.weight, "_mi_wgrad_pending", False)
+    conv.weight.grad = None
+    conv(x2.detach().requires_grad_(True)).sum().backward()    # the same pass on a clean slate
+    assert torch.equal(got, conv.weight.grad)
