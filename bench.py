@@ -652,6 +652,10 @@ def main():
         out["entry_point"] = entry_point_record(B)
         out["entry_point"]["ratio_to_value"] = out["entry_point"]["value"] / out["value"]
         log("entry-point record done")
+        # ... and what the inference entry points deliver on the C3 volume read from an MRC file (tools/bench_infer_entry.py)
+        from tools.bench_infer_entry import run as infer_entry_record
+        out["entry_point_infer"] = infer_entry_record()
+        log("inference entry-point record done")
     if rank == 0:
         # the whole metric as top-level scalars, in front of the long nested blocks (the driver's parsed record keeps these)
         head = {}
@@ -667,6 +671,7 @@ def main():
         head["entry_point_value"] = out["entry_point"]["value"] if "entry_point" in out else None
         head["unet4_forward_ms"] = (sec.get("detector") or {}).get("unet4_forward", {}).get("ms")
         head["semi_train_step_ms"] = (sec.get("detector") or {}).get("semi_train_step", {}).get("ms")
+        head["entry_point_infer_tot_ms"] = (out.get("entry_point_infer") or {}).get("test_py_detector", {}).get("tot_ms")
         head["simsiam2d_train_step_ms"] = (sec.get("simsiam2d_train_step") or {}).get("ms")
         head["simsiam2d_crop_pairs_per_sec"] = (sec.get("simsiam2d_train_step") or {}).get("crop_pairs_per_sec")
         head.update({k: v for k, v in out.items() if k not in head})

@@ -35,16 +35,45 @@ class TomodetDetector(BaseDetector):
         preds = tomo_post_process(dets, z_dim_tot=z_dim_tot)[0]
         return preds, meta["name"][0]
 
+    def begin_hm_download(self, hm):
+        """The heat-map's way to the host, started right behind the decode (BaseDetector.run) so that it overlaps the detections'
+        post-processing: the (D, H', W') -> (H', D, W') swap of tomo_det.py:60 and the NaN test of :64 run on the device, the payload
+        goes into a pinned buffer with one non-blocking copy, and `_hm.mrc` is written from that buffer (round 6; before: a pageable
+        67 MB copy, a host transpose, a host NaN scan, an astype copy and a tobytes copy - 84 of the 137 ms a 256 x 512 x 512 tomogram
+        took)."""
+        vol = hm.detach()[0][0]
+        swapped = vol.permute(1, 0, 2).contiguous()                       # (H', D, W'), as np.swapaxes(hm, 1, 0) leaves it
+        nan_flag = torch.isnan(swapped).any().reshape(1).to(torch.uint8)
+        n = swapped.numel()
+        pin = getattr(self, "_hm_pin", None)
+        if pin is None or pin.numel() < n:
+            pin = self._hm_pin = torch.empty(n, dtype=torch.float32, pin_memory=True)
+            self._flag_pin = torch.empty(1, dtype=torch.uint8, pin_memory=True)
+        pin[:n].copy_(swapped.reshape(-1), non_blocking=True)
+        self._flag_pin.copy_(nan_flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hm_pending = (hm.data_ptr(), tuple(swapped.shape), ev, swapped)      # (`swapped` stays alive until the copy has run)
+
+    def _hm_on_host(self, hm):
+        pend = getattr(self, "_hm_pending", None)
+        if pend is None or pend[0] != hm.data_ptr():
+            self.begin_hm_download(hm)
+            pend = self._hm_pending
+        self._hm_pending = None
+        _, shape, ev, _keep = pend
+        ev.synchronize()
+        if int(self._flag_pin[0]):
+            raise ValueError("Output contains NaN values")
+        n = int(np.prod(shape))
+        return self._hm_pin[:n].numpy().reshape(shape)                    # a view of the pinned buffer: no copy
+
     def save_detection(self, hm, dets, path, meta, prefix="", name=""):
         if not os.path.exists(path):
             os.mkdir(path)
-        hm = hm.detach().cpu().numpy()[0][0]
-        max_z, max_y, max_x = hm.shape
+        max_z, max_y, max_x = hm.shape[2], hm.shape[3], hm.shape[4]
         max_x, max_y = max_x * 2, max_y * 2
-        hm = np.swapaxes(hm, 1, 0)
-        if np.isnan(hm).any():
-            raise ValueError("Output contains NaN values")
-        mrcio.write(os.path.join(path, "{}_hm.mrc".format(name)), np.float32(hm), is_vol=True)
+        mrcio.write(os.path.join(path, "{}_hm.mrc".format(name)), self._hm_on_host(hm), is_vol=True)
         opt = self.opt
         pre_coords = []
         with open(os.path.join(path, "{}.txt".format(name)), "w+") as out_detect:

@@ -169,6 +169,31 @@ class TomoConvUNet(nn.Module):
             y = self.unet(H.conv_bn(self.conv1, self.bn1, x, relu=True))
         _, hh, ww, ch = y.shape
         v = y.view(b, d, hh, ww, ch)                                              # slices are the z axis again
+        slab = int(getattr(self, "head_slab", 0)) or (64 if 4 * v.numel() >= 0x7fff0000 else 0)
+        if slab and b == 1 and d > slab and not self.training and not torch.is_grad_enabled():
+            return [self._heads_in_z_slabs(v, slab)]
+        return [self._heads(v)]
+
+    def _heads_in_z_slabs(self, v, slab):
+        """Inference on a volume whose 32-channel feature map reaches 2 GiB (256 x 512 x 512 in: 256 x 256 x 256 x 32 floats - the
+        kernels address an operand with 32-bit byte offsets): the 3-D head runs on z-slabs with a halo of three planes - one per
+        3 x 3 x 3 layer (z dilation 1) and one for the (3, 1, 1) heads -, whose interior planes are exactly the whole-volume result
+        (at the volume's own ends the zero padding IS the reference's)."""
+        b, d, hh, ww, _ = v.shape
+        outs = {}
+        for z0 in range(0, d, slab):
+            lo, hi = max(0, z0 - 3), min(d, z0 + slab + 3)
+            part = self._heads(v[:, lo:hi])
+            n = min(slab, d - z0)
+            for k, t in part.items():                                             # logical (B, C, D, H, W)
+                if k not in outs:
+                    outs[k] = torch.empty((b, d, hh, ww, t.shape[1]), dtype=t.dtype, device=t.device)
+                outs[k][:, z0:z0 + n] = t.permute(0, 2, 3, 4, 1)[:, z0 - lo:z0 - lo + n]
+            del part
+        return {k: t.permute(0, 4, 1, 2, 3) for k, t in outs.items()}
+
+    def _heads(self, v):
+        b, d, hh, ww, ch = v.shape
         v = self.feature_head[0](v, relu=True)
         v = self.feature_head[2](v, relu=True)
         ret = {}
@@ -178,14 +203,14 @@ class TomoConvUNet(nn.Module):
             if pair is not None:
                 ret["proj"] = pair[0].permute(0, 4, 1, 2, 3)
                 ret["hm"] = pair[1].permute(0, 4, 1, 2, 3)
-                return [{k: ret[k] for k in self.heads}]
+                return {k: ret[k] for k in self.heads}
         for head in self.heads:
             out = self.__getattr__(head)(v)
             if "proj" in head:
                 k = out.shape[-1]
                 out = H.l2_normalize(out.view(-1, k)).view(b, d, hh, ww, k)
             ret[head] = out.permute(0, 4, 1, 2, 3)                                # logical (B, C, D, H, W)
-        return [ret]
+        return ret
 
 
 def get_tomo_unet_small(num_layers, heads, head_conv, last_k=3, local_path=None):

@@ -15,7 +15,12 @@ from .opts import opts
 from .utils.utils import TextLog
 
 
+LAST_STAGES = {}         # seconds of the last call's stages (tools/bench_infer_entry.py)
+
+
 def test(opt):
+    import time
+    t_start = time.time()
     Dataset = SyntheticSimSiamDataset
     opt = opts().update_dataset_info_and_set_heads(opt, Dataset)
     TextLog(opt).close()
@@ -30,19 +35,23 @@ def test(opt):
     from .datasets.tomo_files import use_files
     if use_files(opt, "test"):
         from .datasets.tomo_files import TomoFileSimSiamDataset as Dataset
+    t_model = time.time()
     dataset = Dataset(opt, "test", (3, opt.bbox, opt.bbox), sigma1=opt.dog, device=opt.device)
+    torch.cuda.synchronize()
+    t_data = time.time()
     normed = S.to_uint8_normalize(dataset.sub_vols_3d, dataset.mean_subvols3d, dataset.std_subvols3d)
-    all_proj, all_pred, all_sub = [], [], []
+    all_proj, all_pred = [], []
     with torch.no_grad():
         for i in range(0, normed.shape[0], 256):                        # batch_size=256 (:150)
-            x = normed[i:i + 256].contiguous()
-            ret = model.forward_test(x)
-            all_proj.append(ret["proj"].detach().cpu().numpy())
-            all_pred.append(ret["pred"].detach().cpu().numpy())
-            all_sub.append(x.cpu().numpy())
+            ret = model.forward_test(normed[i:i + 256].contiguous())
+            all_proj.append(ret["proj"].detach())                       # (stay on the device: one copy to the host at the end, not three
+            all_pred.append(ret["pred"].detach())                       #  synchronising copies per batch as :163-176 makes)
+    proj, pred = torch.cat(all_proj, 0).cpu().numpy(), torch.cat(all_pred, 0).cpu().numpy()
+    subvol = normed.cpu().numpy()
+    t_net = time.time()
     out_file = os.path.join(opt.save_dir, "all_output_info.npz")
-    np.savez(out_file, proj=np.concatenate(all_proj, 0), pred=np.concatenate(all_pred, 0),
-             name=np.asarray(dataset.names_all), coords=np.asarray(dataset.coords), subvol=np.concatenate(all_sub, 0))
+    np.savez(out_file, proj=proj, pred=pred, name=np.asarray(dataset.names_all), coords=np.asarray(dataset.coords), subvol=subvol)
+    LAST_STAGES.update({"model": t_model - t_start, "load_pick_crop": t_data - t_model, "net": t_net - t_data, "save": time.time() - t_net})
     print("opt.save_dir", opt.save_dir)
     return out_file
 

@@ -13,11 +13,18 @@ from .opts import opts
 from .utils.utils import AverageMeter, TextLog
 
 
+LAST_STAGES = {}         # seconds of the last tomogram's stages outside BaseDetector.run's dict (tools/bench_infer_entry.py)
+
+
 def _mrc_list(path, opt):
+    import time
     from .utils import loader
     rows = [ln.split("\t") for ln in open(path).read().splitlines()[1:] if ln.strip()]
     for name, p in rows:
+        t0 = time.time()
         rec = loader.preprocess(loader.load_rec(p, order=opt.order, compress=opt.compress), opt.gauss)
+        torch.cuda.synchronize()
+        LAST_STAGES["file_to_device"] = time.time() - t0
         yield {"input": rec[None].float(), "meta": {"name": [name], "zdim": int(rec.shape[0])}}
 
 
@@ -33,6 +40,7 @@ def test(opt):
     n = 0
     for batch in loader:
         ret = detector.run(batch["input"], batch["meta"])
+        LAST_STAGES.update(getattr(detector, "last_stages", {}))
         for t in avg_time_stats:
             avg_time_stats[t].update(ret[t])
         n += 1

@@ -187,4 +187,4 @@ def write(fname, array, header=None, Apix=1., xorg=0., yorg=0., zorg=0., is_vol=
         header = MRCHeader.make_default_header(array, is_vol, Apix, xorg, yorg, zorg)
     with open(fname, "wb") as f:
         header.write(f)
-        f.write(array.tobytes())
+        f.write(memoryview(array).cast("B"))     # the payload straight from the (contiguous) array: no tobytes() copy

@@ -444,6 +444,24 @@ def test_unet_forward_vs_oracle_larger():
         np.testing.assert_allclose(out[h].cpu().numpy(), r, rtol=0, atol=3e-4 * max(1.0, np.abs(r).max()))
 
 
+def test_unet_head_in_z_slabs_equals_the_whole_volume():
+    """Round 6 (found by the entry-point record on the 256 x 512 x 512 volume: the 32-channel feature map of such a volume is 2 GiB and the
+    kernels address an operand with 32-bit byte offsets): the dilated 3-D head + both heads on z-slabs with a three-plane halo give the
+    whole-volume outputs - same kernels on the same neighbourhoods, only a launch's tile origin moves: hm / proj to rounding order."""
+    net = _net()
+    x = torch.randn(1, 29, 64, 64, generator=torch.Generator().manual_seed(15)).cuda()
+    with torch.no_grad():
+        whole = {k: v.clone() for k, v in net(x)[0].items()}
+        net.head_slab = 8                                 # 29 planes: slabs of 8, 8, 8 and 5 with halos
+        try:
+            slabbed = net(x)[0]
+        finally:
+            net.head_slab = 0
+    for h in HEADS:
+        assert slabbed[h].shape == whole[h].shape
+        np.testing.assert_allclose(slabbed[h].cpu().numpy(), whole[h].cpu().numpy(), rtol=0, atol=2e-6 * max(1.0, float(whole[h].abs().max())))
+
+
 def test_unet_inference_in_slice_chunks_matches_whole_volume_and_oracle():
     """Round 4: the evaluation-mode forward runs the per-slice 2-D U-Net `slice_chunk` slices at a time (ragged last chunk
     included) - same outputs as the whole volume at once (the only difference a split-K choice can make is rounding order),
