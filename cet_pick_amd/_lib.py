@@ -73,6 +73,9 @@ SIGNATURES = {
     "mi_conv2d_p2d_wimg_bytes": (_Z, [_I]),
     "mi_conv2d_p2d_prep": (_I, [_P, _P, _P, _P, _I, _P]),
     "mi_conv2d_p2d_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mi_conv2d_stem3_workspace_bytes": (_Z, [_I]),
+    "mi_conv2d_stem3_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "mi_conv2d_stem3_wgrad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
     "mi_conv3d_cube2_workspace_bytes": (_Z, [_I, _I]),
     "mi_conv3d_cube2_usable": (_I, [_I] * 9),
     "mi_conv3d_cube2_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),

@@ -290,6 +290,85 @@ __global__ __launch_bounds__(256) void p2d_prep_kernel(P2DPrepBatch b) {
     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * PW_BLK) = o[pl];
 }
 
+// ---- the encoder's first layer: Conv2d(1, Co, 3, padding=1) (simsiam_model_2d.py:634) - nine taps of ONE input channel ----
+// Not matrix work: 9 multiply-adds per output element against 4 bytes written (forward) or read (weight gradient) - HBM-bound at
+// 85 MB per view and direction; on the implicit GEMM (K = 9 padded to a 32-deep slice) it took 56 / 147 us.  f32 FMA chains.
+// forward: a thread owns (voxel, 4 output channels); weights in registers.
+__global__ __launch_bounds__(256) void stem3_fwd_kernel(const float* x, const float* w, float* y, int H, int W, int Co, long total) {
+    const int cg = Co >> 2;                              // channel groups of 4 per voxel
+    const int g = threadIdx.x % cg;
+    float wv[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 q = *reinterpret_cast<const float4*>(w + t * Co + 4 * g);
+        wv[t][0] = q.x; wv[t][1] = q.y; wv[t][2] = q.z; wv[t][3] = q.w;
+    }
+    const int vpb = 256 / cg;                            // voxels per block pass
+    for (long v = (long)blockIdx.x * vpb + threadIdx.x / cg; v < total; v += (long)gridDim.x * vpb) {
+        const int xx = (int)(v % W), yy = (int)((v / W) % H);
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const int y2 = yy + ty - 1, x2 = xx + tx - 1;
+                const float xv = ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W) ? x[v + (ty - 1) * W + (tx - 1)] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = fmaf(xv, wv[ty * 3 + tx][k], a[k]);
+            }
+        *reinterpret_cast<float4*>(y + v * Co + 4 * g) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+}
+// weight gradient: dW[t][co] = sum_v x[v + t] dy[v][co].  A thread owns 4 channels and every (256 / cg)-th voxel of its block's
+// share; the block's partial [9][Co] goes to the workspace and stem3_wgrad_final_kernel adds the blocks in block order (fp64).
+constexpr int ST3_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void stem3_wgrad_kernel(const float* x, const float* dy, float* part, int H, int W, int Co, long total) {
+    __shared__ float red[256][37];                       // (+1: bank spread)
+    const int cg = Co >> 2, g = threadIdx.x % cg, vl = threadIdx.x / cg, vpb = 256 / cg;
+    float a[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[t][k] = 0.f;
+    const int per = (int)((total + gridDim.x - 1) / gridDim.x);
+    const int v0 = blockIdx.x * per, v1 = (long)v0 + per < total ? v0 + per : (int)total;
+    int xx = (v0 + vl) % W, yy = ((v0 + vl) / W) % H;   // (walked, not divided, from here on)
+    for (int v = v0 + vl; v < v1; v += vpb, xx += vpb) {
+        while (xx >= W) { xx -= W; yy = yy + 1 == H ? 0 : yy + 1; }
+        const float4 d = *reinterpret_cast<const float4*>(dy + (long)v * Co + 4 * g);
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const int y2 = yy + ty - 1, x2 = xx + tx - 1;
+                const float xv = ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W) ? x[v + (ty - 1) * W + (tx - 1)] : 0.f;
+                a[ty * 3 + tx][0] = fmaf(xv, d.x, a[ty * 3 + tx][0]); a[ty * 3 + tx][1] = fmaf(xv, d.y, a[ty * 3 + tx][1]);
+                a[ty * 3 + tx][2] = fmaf(xv, d.z, a[ty * 3 + tx][2]); a[ty * 3 + tx][3] = fmaf(xv, d.w, a[ty * 3 + tx][3]);
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[threadIdx.x][t * 4 + k] = a[t][k];
+    __syncthreads();
+    // thread j < 9 Co: element (t, co) = sum over the block's voxel lanes, in lane order
+    for (int j = threadIdx.x; j < 9 * Co; j += 256) {
+        const int t = j / Co, co = j % Co;
+        float sacc = 0.f;
+        for (int l = 0; l < vpb; ++l) sacc += red[l * cg + (co >> 2)][t * 4 + (co & 3)];
+        part[(long)blockIdx.x * 9 * Co + j] = sacc;
+    }
+}
+// one WAVE per gradient element: lane l adds the partials of blocks l, l + 64, ... (in that order), then the lanes in a fixed tree
+__global__ __launch_bounds__(256) void stem3_wgrad_final_kernel(const float* part, float* dw, int n, int nblocks) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= n) return;
+    double sacc = 0.0;
+    for (int b = lane; b < nblocks; b += 64) sacc += (double)part[(long)b * n + j];
+    sacc = wave_sum(sacc);
+    if (lane == 0) dw[j] = (float)sacc;
+}
+
 template <int W_, int HMIN, int CT>
 int p2d_launch(const P2DParams& p, hipStream_t s) {
     const long tiles = (p.total + P_TM - 1) / P_TM;
@@ -344,4 +423,32 @@ extern "C" int mi_conv2d_p2d_f32(const float* a, const void* wimg, float* out, c
     if (W == 36) return p2d_launch<36, 36, 64>(p, s);
     if (W == 18) return p2d_launch<18, 18, 128>(p, s);
     return p2d_launch<9, 9, 256>(p, s);
+}
+
+// The 2-D encoder's first layer, Conv2d(1, Co, 3, padding=1) (models/networks/simsiam_model_2d.py:634; Co a multiple of 4, <= 64):
+// x (N, H, W) one channel, w (3, 3, 1, Co) kernel layout, y / dy (N, H, W, Co).  ws: mi_conv2d_stem3_workspace_bytes(Co) bytes.
+extern "C" size_t mi_conv2d_stem3_workspace_bytes(int Co) { return sizeof(float) * (size_t)ST3_BLOCKS * 9 * (size_t)(Co > 0 ? Co : 0); }
+extern "C" int mi_conv2d_stem3_fwd_f32(const float* x, const float* w, float* y, int N, int H, int W, int Co, mi_stream_t stream) {
+    if (!x || !w || !y || N < 1 || H < 1 || W < 1) return MI_E_ARG;
+    if (Co < 4 || Co > 64 || (Co & 3) || 256 % (Co >> 2)) return MI_E_UNSUPPORTED;
+    const long total = (long)N * H * W;
+    const long blocks = (total + 256 / (Co >> 2) - 1) / (256 / (Co >> 2));
+    hipLaunchKernelGGL(stem3_fwd_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, x, w, y, H, W, Co,
+                       total);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+extern "C" int mi_conv2d_stem3_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int Co, void* ws, size_t ws_bytes,
+                                         mi_stream_t stream) {
+    if (!x || !dy || !dw || !ws || N < 1 || H < 1 || W < 1) return MI_E_ARG;
+    if (Co < 4 || Co > 64 || (Co & 3) || 256 % (Co >> 2)) return MI_E_UNSUPPORTED;
+    if (ws_bytes < mi_conv2d_stem3_workspace_bytes(Co)) return MI_E_ARG;
+    const long total = (long)N * H * W;
+    if (total >= 0x7fffffffl) return MI_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(stem3_wgrad_kernel, dim3(ST3_BLOCKS), dim3(256), 0, s, x, dy, (float*)ws, H, W, Co, total);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(stem3_wgrad_final_kernel, dim3((9 * Co + 3) / 4), dim3(256), 0, s, (const float*)ws, dw, 9 * Co, ST3_BLOCKS);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
 }

@@ -544,6 +544,11 @@ def p2d_usable(x_shape, ci, co, k3, stride, p3, dil=None):
     return bool(L.lib().mi_conv2d_p2d_usable(int(n), int(h), int(w), int(ci)))
 
 
+def _stem3_ok(co):
+    """Conv2d(1, co, 3, padding=1) on its own kernels (conv_p2d.hip stem3_*): co a multiple of 4 that divides the block evenly."""
+    return 4 <= co <= 64 and co % 4 == 0 and 256 % (co // 4) == 0 and not os.environ.get("MI_NO_P2D")
+
+
 def p2d_prep(items):
     """items: [(weight, dgrad flag, image tensor)] - all cut in one launch per 16 (mi_conv2d_p2d_prep) on the current stream."""
     import ctypes
@@ -615,6 +620,16 @@ def conv_fwd(x, w, k, stride, pad, res=None, relu=False, dil=None, owner=None, i
             return _smallk_call(x, w, None, relu, taps, owner=owner)
         if kind:                                      # inference, 3 x 3: patch-resident direct kernel (conv_d32.hip)
             return _d32_call(x, w, None, relu, kind, owner=owner)
+    if (not nd5 and x.is_cuda and x.shape[-1] == 1 and tuple(k3) == (1, 3, 3) and stride == 1 and tuple(p3) == (0, 1, 1) and dil is None
+            and res is None and not relu and _stem3_ok(int(w.shape[0]))):
+        n, h, wd, _ = x.shape
+        y = torch.empty((n, h, wd, int(w.shape[0])), dtype=torch.float32, device=x.device)
+        lib = L.lib()
+        def call():
+            return L.check(lib.mi_conv2d_stem3_fwd_f32(L.ptr(x), L.ptr(w), L.ptr(y), n, h, wd, int(w.shape[0]), L.stream()),
+                           "mi_conv2d_stem3_fwd_f32")
+        _prof_run("fwd", 2.0 * y.numel() * 9, call)
+        return y
     if not nd5 and x.is_cuda and p2d_usable(x.shape, x.shape[-1], w.shape[0], k3, stride, p3, dil):
         if res is not None:
             _f32c(res, "res")
@@ -998,6 +1013,17 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
     g, acc = _grad_target(param)
     tgt = torch.empty_like(g) if acc else g
     flops = 2.0 * dy.numel() * ci * k3[0] * k3[1] * k3[2]
+    if (not nd5 and x.is_cuda and ci == 1 and tuple(k3) == (1, 3, 3) and stride == 1 and tuple(p3) == (0, 1, 1) and dil is None
+            and _stem3_ok(int(co)) and _phys_ok(param)):
+        _f32c(x, "x"), _f32c(dy, "dy")
+        ws = _ws(lib.mi_conv2d_stem3_workspace_bytes(int(co)), x.device, "stem3")
+        def call():
+            return L.check(lib.mi_conv2d_stem3_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, h, wd, int(co), L.ptr(ws), ws.numel(),
+                                                         L.stream()), "mi_conv2d_stem3_wgrad_f32")
+        _prof_run("wgrad", flops, call)
+        if acc:
+            g.add_(tgt)
+        return
     # (under bench.py's roofline pass only the jobs the engine will queue take the job form - run_wgrad_jobs times them group by group -,
     # everything else is timed right here, call by call)
     slab_form = (not acc and (dil is None or tuple(_k3(dil, nd5)) == (1, 1, 1)) and x.is_cuda and

@@ -321,6 +321,14 @@ int mi_conv2d_p2d_prep(const void* const* w, void* const* img, const int* dgrad,
 int mi_conv2d_p2d_f32(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N, int H, int W,
                       int C, mi_stream_t stream);
 
+/* The 2-D encoder's first layer, Conv2d(1, Co, 3, padding=1) (models/networks/simsiam_model_2d.py:634): nine taps of one input channel -
+ * HBM-bound f32 FMA chains, not matrix work.  x (N, H, W), w (3, 3, 1, Co) kernel layout, y / dy (N, H, W, Co); Co a multiple of 4, <= 64
+ * (else MI_E_UNSUPPORTED).  The weight gradient sums per-block partials in block order (deterministic); ws: _workspace_bytes(Co). */
+size_t mi_conv2d_stem3_workspace_bytes(int Co);
+int mi_conv2d_stem3_fwd_f32(const float* x, const float* w, float* y, int N, int H, int W, int Co, mi_stream_t stream);
+int mi_conv2d_stem3_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int Co, void* ws, size_t ws_bytes,
+                              mi_stream_t stream);
+
 /* 3^3 / stride 1 / padding 1 convolutions on 2 x 2 x 2 volumes, C -> C channels, C = 128 / 256 / 512 (layer3 and feature_3d
  * of the MoCo-3D encoder, models/networks/moco_encoder_3d.py:55-84,172,178), bf16x3 arithmetic, FINAL IN ONE LAUNCH (round 4:
  * the last of the four reduction quarters of an output tile to arrive sums them - in a fixed order - and applies the epilogue):
