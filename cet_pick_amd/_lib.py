@@ -73,6 +73,8 @@ SIGNATURES = {
     "mi_conv2d_p2d_wimg_bytes": (_Z, [_I]),
     "mi_conv2d_p2d_prep": (_I, [_P, _P, _P, _P, _I, _P]),
     "mi_conv2d_p2d_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mi_conv2d_p2d_wgrad_workspace_bytes": (_Z, [_I] * 4),
+    "mi_conv2d_p2d_wgrad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
     "mi_conv2d_stem3_workspace_bytes": (_Z, [_I]),
     "mi_conv2d_stem3_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "mi_conv2d_stem3_wgrad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),

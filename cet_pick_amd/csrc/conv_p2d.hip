@@ -369,6 +369,223 @@ __global__ __launch_bounds__(256) void stem3_wgrad_final_kernel(const float* par
     if (lane == 0) dw[j] = (float)sacc;
 }
 
+// ---- weight gradient of the same layers: dW[tap][ci][co] = sum over output voxels o of X[o + tap][ci] dY[o][co] ----------------------
+// The reduction runs over voxels, so both operands are staged voxel-major ([voxel][32 channels] bf16 rows of 64 bytes per channel half
+// and bf16 plane) and the MFMA fragments come out of LDS through the transposing read (ds_read_b64_tr_b16: a lane names its own row), as
+// in conv_direct3.hip's direct3_wgrad_kernel.  What is new is the geometry: a K-block is 64 consecutive output voxels of the FLAT
+// (n, y, x) order; X is staged in the PADDED flat order f = (n (H + 1) + 1 + y) (W + 1) + x + 1 - one zero column per row, one zero row
+// between planes - so that a tap is ONE row offset ((ty - 1) (W + 1) + tx - 1) for every lane and every out-of-plane neighbour is a
+// staged zero: no select, no mask, any H = W.  A workgroup owns (32 input channels, 64 output channels, one chain of K-blocks): its four
+// waves are (output-channel half) x (half of a K-block's four k-steps), nine accumulators each - all taps from one staged window
+// (per k-step and wave: 6 + 54 transposing reads, 54 MFMAs); the two k-halves are added through LDS at the end and the chain's
+// [9][32][64] tile goes into its split-K slab; p2d_wgrad_reduce_kernel adds the slabs in slab order.
+constexpr int PW_KB = 64;                   // output voxels per K-block (4 k-steps)
+constexpr int PW_ROW = 64;                  // bytes of a (voxel, 32 channels) bf16 row
+typedef __bf16 bf16x4p __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4p lds_bf16x4p;
+
+template <int W_>
+struct P2WCfg {
+    static constexpr int H_ = W_;                                       // square planes
+    static constexpr int PW = W_ + 1;                                   // padded-flat pitch
+    static constexpr int R = (PW_KB - 1 + W_ - 1) / W_ + 1;             // image rows a K-block can touch
+    static constexpr int NB = (R - 1 + H_ - 1) / H_;                    // plane boundaries among them
+    static constexpr int SPAN = PW_KB + (R - 1) + NB * PW;              // padded-flat positions from its first to its last voxel
+    static constexpr int XR = SPAN + 2 * (PW + 1);                      // + the taps' reach on both sides
+    static constexpr int XPL = XR * PW_ROW;                             // one bf16 plane of the X window (32 channels)
+    static constexpr int YH = PW_KB * PW_ROW, YPL = 2 * YH;             // dY: channel half, plane
+    static constexpr int YB = 3 * XPL;                                  // byte offset of dY
+    static constexpr int LDS = 3 * XPL + 3 * YPL;
+    static constexpr int UX = (4 * XR + 255) / 256;                     // X staging units (row, 8 channels) per thread
+    static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+    static_assert(LDS >= 2 * 12288, "the k-half exchange (two channel halves x three taps) reuses the staging memory");
+};
+
+struct P2WParams {
+    const float* x;           // (N, H, W, CT)
+    const float* dy;          // (N, H, W, CT)
+    float* slabs;             // [splits][9][CT][CT]
+    int N;
+    long total;               // N H W
+    int nkb;                  // K-blocks in all
+    int splits;
+    unsigned bytes;
+};
+
+template <int W_, int CT>
+__global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
+    typedef P2WCfg<W_> G;
+    constexpr int H_ = G::H_, PW = G::PW, HW = H_ * W_;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l32 = lane & 31, i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int wn = wave & 1, kh = wave >> 1;             // output-channel half; k-steps 2 kh, 2 kh + 1 of every K-block
+    constexpr int NCI = CT / 32, NCO = CT / 64;
+    const int tile = blockIdx.x % (NCI * NCO), split = blockIdx.x / (NCI * NCO);
+    const int ci0 = (tile / NCO) * 32, co0 = (tile % NCO) * 64;
+    // this chain's K-blocks: [kb0, kb1)
+    const int per = (p.nkb + p.splits - 1) / p.splits;
+    const int kb0 = split * per, kb1 = kb0 + per < p.nkb ? kb0 + per : p.nkb;
+
+    const __amdgpu_buffer_rsrc_t xrs = p_rsrc(p.x, p.bytes), yrs = p_rsrc(p.dy, p.bytes);
+    // fragment addressing (transposing read): this lane names row q4 of its 16-lane group's 4-row block, columns 16 g16 + 4 (i16 & 3)
+    const int q4 = i16 >> 2;
+    const int coloff = (16 * g16 + 4 * (i16 & 3)) * 2;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const long o0 = (long)kb * PW_KB;
+        const int n0 = (int)(o0 / HW), r0 = (int)(o0 - (long)n0 * HW), y0 = r0 / W_, x0 = r0 - y0 * W_;
+        const int fstart = (n0 * (H_ + 1) + 1 + y0) * PW + x0 + 1 - (PW + 1);       // padded-flat position of window row 0 (may be < 0)
+        __syncthreads();                                 // every wave is done with the previous window
+        // ---- stage dY: unit (voxel v, 8-channel group cg) ----
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = tid + 256 * u, v = q >> 3, cg = q & 7;
+            const long o = o0 + v;
+            const unsigned off = o < p.total ? 4u * (unsigned)(o * CT + co0 + 8 * cg) : 0x80000000u;
+            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)off, 16, 0);
+            float vv[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vv[e] = __uint_as_float(a[e]); vv[4 + e] = __uint_as_float(b[e]); }
+            u32x4 o3[3];
+            p_cut8(vv, o3);
+            unsigned char* dst = lds + G::YB + (cg >> 2) * G::YH + v * PW_ROW + (cg & 3) * 16;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * G::YPL) = o3[pl];
+        }
+        // ---- stage the X window: unit (window row r, 8-channel group cg); pads, separators and rows outside the batch are zeros ----
+#pragma unroll
+        for (int u = 0; u < G::UX; ++u) {
+            const int q = tid + 256 * u, r = q >> 2, cg = q & 3;
+            if (r < G::XR) {
+                const int f = fstart + r;
+                const int P = f / PW, xc = f - P * PW;   // (f < 0: P <= 0 below)
+                const int n = P / (H_ + 1), yy = P - n * (H_ + 1) - 1;
+                const bool ok = f >= 0 && xc >= 1 && yy >= 0 && n < p.N;
+                const unsigned off = ok ? 4u * (unsigned)((((long)n * H_ + yy) * W_ + (xc - 1)) * CT + ci0 + 8 * cg) : 0x80000000u;
+                const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 16, 0);
+                float vv[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vv[e] = __uint_as_float(a[e]); vv[4 + e] = __uint_as_float(b[e]); }
+                u32x4 o3[3];
+                p_cut8(vv, o3);
+                unsigned char* dst = lds + r * PW_ROW + cg * 16;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * G::XPL) = o3[pl];
+            }
+        }
+        // ---- this lane's rows of the window for its two k-steps: voxel o0 + 16 (2 kh + lk) + 8 h + q4 (+ 4) ----
+        int xrow[2][2];
+#pragma unroll
+        for (int lk = 0; lk < 2; ++lk)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                long o = o0 + 16 * (2 * kh + lk) + 8 * h + q4 + 4 * hi;
+                if (o >= p.total) o = p.total - 1;       // (its dY row is zero: any staged row will do)
+                const int n = (int)(o / HW), rr = (int)(o - (long)n * HW), y = rr / W_, x = rr - y * W_;
+                xrow[lk][hi] = ((n * (H_ + 1) + 1 + y) * PW + x + 1 - fstart) * PW_ROW + coloff;
+            }
+        __syncthreads();
+        // ---- 2 k-steps x (dY fragment + 9 taps x X fragment) ----
+#pragma unroll
+        for (int lk = 0; lk < 2; ++lk) {
+            bf16x8 bfg[3];
+            const unsigned char* yb = lds + G::YB + wn * G::YH + (16 * (2 * kh + lk) + 8 * h + q4) * PW_ROW + coloff;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const bf16x4p lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4p*)(yb + pl * G::YPL));
+                const bf16x4p hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4p*)(yb + pl * G::YPL + 4 * PW_ROW));
+                bfg[pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            bf16x8 af[2][3];
+            auto read_a = [&](int t, int set) {
+                const int sh = ((t / 3 - 1) * PW + (t % 3 - 1)) * PW_ROW;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const bf16x4p lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4p*)(lds + pl * G::XPL + xrow[lk][0] + sh));
+                    const bf16x4p hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4p*)(lds + pl * G::XPL + xrow[lk][1] + sh));
+                    af[set][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            };
+            read_a(0, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t + 1 < 9) read_a(t + 1, (t + 1) & 1);
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][PA[pr]], bfg[PB[pr]], acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- the two k-halves added through LDS (three taps at a time), then the slab: C/D layout col = lane & 31 (co), row = ci ----
+    float* red = reinterpret_cast<float*>(lds);          // [co half 2][tap 3][register 16][lane 64]
+    float* out = p.slabs + (long)split * (9l * CT * CT);
+#pragma unroll
+    for (int g3 = 0; g3 < 3; ++g3) {
+        __syncthreads();
+        if (kh == 1) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wn * 3 + t) * 16 + r) * 64 + lane] = acc[3 * g3 + t][r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    out[((long)(3 * g3 + t) * CT + ci) * CT + co0 + 32 * wn + l32] = acc[3 * g3 + t][r] + red[((wn * 3 + t) * 16 + r) * 64 + lane];
+                }
+        }
+    }
+}
+
+// dW = sum of the slabs, in slab order: a block owns 16 float4 of the gradient x 16 slab lanes (lane l adds slabs l, l + 16, ...), the
+// sixteen partial sums of an element are then added in lane order
+__global__ __launch_bounds__(256) void p2d_wgrad_reduce_kernel(const float* slabs, int n_slabs, long n4, float* out) {
+    __shared__ float4 part[16][17];
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long i4 = (long)blockIdx.x * 16 + e;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < n4)
+        for (int sidx = sl; sidx < n_slabs; sidx += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(slabs + ((long)sidx * n4 + i4) * 4);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    part[sl][e] = a;
+    __syncthreads();
+    if (sl == 0 && i4 < n4) {
+        float4 t = part[0][e];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 v = part[k][e]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(out + i4 * 4) = t;
+    }
+}
+
+template <int W_, int CT>
+int p2d_wgrad_launch(const float* x, const float* dy, float* dw, float* slabs, int N, int splits, hipStream_t s) {
+    P2WParams p = {};
+    p.x = x; p.dy = dy; p.slabs = slabs; p.N = N; p.total = (long)N * W_ * W_;
+    p.nkb = (int)((p.total + PW_KB - 1) / PW_KB); p.splits = splits; p.bytes = (unsigned)(4l * p.total * CT);
+    hipLaunchKernelGGL((p2d_wgrad_kernel<W_, CT>), dim3((unsigned)((CT / 32) * (CT / 64) * splits)), dim3(256), 0, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    const long n4 = 9l * CT * CT / 4;
+    hipLaunchKernelGGL(p2d_wgrad_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, (const float*)slabs, splits, n4, dw);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
 template <int W_, int HMIN, int CT>
 int p2d_launch(const P2DParams& p, hipStream_t s) {
     const long tiles = (p.total + P_TM - 1) / P_TM;
@@ -451,4 +668,23 @@ extern "C" int mi_conv2d_stem3_wgrad_f32(const float* x, const float* dy, float*
     hipLaunchKernelGGL(stem3_wgrad_final_kernel, dim3((9 * Co + 3) / 4), dim3(256), 0, s, (const float*)ws, dw, 9 * Co, ST3_BLOCKS);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
+}
+
+// Weight gradient of the same layers (mi_conv2d_p2d_usable shapes with H == W): dw (3, 3, C, C) kernel layout, written (not accumulated).
+// ws: mi_conv2d_p2d_wgrad_workspace_bytes(N, H, W, C) bytes of split-K slabs (512 chains of K-blocks over the chip).
+static int p2d_wgrad_splits(int C) { return 512 / ((C / 32) * (C / 64)); }
+extern "C" size_t mi_conv2d_p2d_wgrad_workspace_bytes(int N, int H, int W, int C) {
+    if (!mi_conv2d_p2d_usable(N, H, W, C) || H != W) return 0;
+    return sizeof(float) * (size_t)p2d_wgrad_splits(C) * 9 * (size_t)C * C;
+}
+extern "C" int mi_conv2d_p2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int C, void* ws, size_t ws_bytes,
+                                       mi_stream_t stream) {
+    if (!x || !dy || !dw || !ws) return MI_E_ARG;
+    if (!mi_conv2d_p2d_usable(N, H, W, C) || H != W || getenv("MI_NO_P2D_WGRAD")) return MI_E_UNSUPPORTED;
+    if (ws_bytes < mi_conv2d_p2d_wgrad_workspace_bytes(N, H, W, C)) return MI_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int splits = p2d_wgrad_splits(C);
+    if (W == 36) return p2d_wgrad_launch<36, 64>(x, dy, dw, (float*)ws, N, splits, s);
+    if (W == 18) return p2d_wgrad_launch<18, 128>(x, dy, dw, (float*)ws, N, splits, s);
+    return p2d_wgrad_launch<9, 256>(x, dy, dw, (float*)ws, N, splits, s);
 }

@@ -1026,6 +1026,18 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
         return
     # (under bench.py's roofline pass only the jobs the engine will queue take the job form - run_wgrad_jobs times them group by group -,
     # everything else is timed right here, call by call)
+    if (not nd5 and x.is_cuda and h == wd and p2d_usable(tuple(x.shape), ci, int(co), k3, stride, p3, dil) and _phys_ok(param)
+            and not os.environ.get("MI_NO_P2D_WGRAD")):
+        # the 2-D encoder's 3 x 3 / stride-1 layers: voxel-major operands through the transposing LDS read (conv_p2d.hip p2d_wgrad_kernel)
+        _f32c(x, "x"), _f32c(dy, "dy")
+        ws = _ws(lib.mi_conv2d_p2d_wgrad_workspace_bytes(n, h, wd, ci), x.device, "p2d_wgrad")
+        def call():
+            return L.check(lib.mi_conv2d_p2d_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, h, wd, ci, L.ptr(ws), ws.numel(), L.stream()),
+                           "mi_conv2d_p2d_wgrad_f32")
+        _prof_run("wgrad", flops, call)
+        if acc:
+            g.add_(tgt)
+        return
     slab_form = (not acc and (dil is None or tuple(_k3(dil, nd5)) == (1, 1, 1)) and x.is_cuda and
                  (PROFILE is None or (DEFERRED_WGRADS is not None and SIDE_WGRADS is not None and dy.numel() // co <= SIDE_ROWS_MAX)))
     if slab_form and (DEFERRED_WGRADS is not None or (WGRAD_BATCH and lib.mi_conv3d_direct_usable(n, d, h, wd, ci, co, k3[0], stride, p3[0]) in (1, 2)

@@ -320,6 +320,12 @@ size_t mi_conv2d_p2d_wimg_bytes(int C);
 int mi_conv2d_p2d_prep(const void* const* w, void* const* img, const int* dgrad, const int* channels, int n, mi_stream_t stream);
 int mi_conv2d_p2d_f32(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N, int H, int W,
                       int C, mi_stream_t stream);
+/* ... and their weight gradient (H == W): dw (3, 3, C, C) kernel layout = sum over the batch's voxels of x[o + tap] (x) dy[o], written (not
+ * accumulated); both operands staged voxel-major and read through the transposing LDS read, X in a padded flat order in which a tap is one
+ * row offset; split-K slabs in ws (mi_conv2d_p2d_wgrad_workspace_bytes), added in slab order.  MI_NO_P2D_WGRAD=1: MI_E_UNSUPPORTED. */
+size_t mi_conv2d_p2d_wgrad_workspace_bytes(int N, int H, int W, int C);
+int mi_conv2d_p2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int C, void* ws, size_t ws_bytes,
+                            mi_stream_t stream);
 
 /* The 2-D encoder's first layer, Conv2d(1, Co, 3, padding=1) (models/networks/simsiam_model_2d.py:634): nine taps of one input channel -
  * HBM-bound f32 FMA chains, not matrix work.  x (N, H, W), w (3, 3, 1, Co) kernel layout, y / dy (N, H, W, Co); Co a multiple of 4, <= 64

@@ -250,6 +250,15 @@ def test_conv2d_direct_plane_kernel_matches_the_implicit_gemm_and_float64(case, 
     assert float((dx.cpu().double() - dx64).abs().max()) <= tol * sc
     want = (dx64 + res.cpu().double()) * (mask.cpu() > 0)
     assert float((dx_m.cpu().double() - want).abs().max()) <= tol * sc
+    # weight gradient (p2d_wgrad_kernel) against float64, and against the implicit GEMM below
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    (gw64,) = torch.autograd.grad(F.conv2d(xr, wr, padding=1), wr, dy.cpu().double().permute(0, 3, 1, 2))
+    param.grad = None
+    H.conv_wgrad_into(xc, dy, param, 3, 1, 1)
+    gw = param.grad.detach().clone()
+    wtol = 2e-6 * max(1.0, (n * h * w / 512) ** 0.5)       # f32 accumulation over n h w voxels
+    assert float((gw.cpu().double() - gw64).abs().max()) <= wtol * float(gw64.abs().max())
+    param.grad = None
     # the weights change (a torch op bumps the version): the cached images follow
     with torch.no_grad():
         param.mul_(0.5)
@@ -259,6 +268,10 @@ def test_conv2d_direct_plane_kernel_matches_the_implicit_gemm_and_float64(case, 
     assert not H.p2d_usable(tuple(xc.shape), c, c, (1, 3, 3), 1, (0, 1, 1))
     y_ig = H.conv_fwd(xc, param, 3, 1, 1)
     assert float((y_ig.cpu().double() - 0.5 * y64).abs().max()) <= tol * float(y64.abs().max())
+    monkeypatch.setenv("MI_NO_P2D_WGRAD", "1")
+    param.grad = None
+    H.conv_wgrad_into(xc, dy, param, 3, 1, 1)
+    assert float((param.grad.cpu().double() - gw64).abs().max()) <= wtol * float(gw64.abs().max())
 
 
 def _simsiam_trainer(seed, hipgraph, engine=True, monkeypatch=None, lr=0.05):
