@@ -440,41 +440,56 @@ __global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 
-    for (int kb = kb0; kb < kb1; ++kb) {
+    // staging registers: the NEXT K-block's operands are fetched while this one's products run
+    u32x4 ldy[2][2], ldx[G::UX][2];
+    auto window_start = [&](int kb) {                    // padded-flat position of window row 0 of K-block kb (may be < 0)
         const long o0 = (long)kb * PW_KB;
         const int n0 = (int)(o0 / HW), r0 = (int)(o0 - (long)n0 * HW), y0 = r0 / W_, x0 = r0 - y0 * W_;
-        const int fstart = (n0 * (H_ + 1) + 1 + y0) * PW + x0 + 1 - (PW + 1);       // padded-flat position of window row 0 (may be < 0)
-        __syncthreads();                                 // every wave is done with the previous window
-        // ---- stage dY: unit (voxel v, 8-channel group cg) ----
+        return (n0 * (H_ + 1) + 1 + y0) * PW + x0 + 1 - (PW + 1);
+    };
+    auto fetch = [&](int kb) {
+        const long o0 = (long)kb * PW_KB;
+        const int fstart = window_start(kb);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int q = tid + 256 * u, v = q >> 3, cg = q & 7;
             const long o = o0 + v;
-            const unsigned off = o < p.total ? 4u * (unsigned)(o * CT + co0 + 8 * cg) : 0x80000000u;
-            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)off, 16, 0);
+            const unsigned off = (kb < kb1 && o < p.total) ? 4u * (unsigned)(o * CT + co0 + 8 * cg) : 0x80000000u;
+            ldy[u][0] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)off, 0, 0);
+            ldy[u][1] = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)off, 16, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < G::UX; ++u) {
+            const int q = tid + 256 * u, r = q >> 2, cg = q & 3;
+            const int f = fstart + r;
+            const int P = f / PW, xc = f - P * PW;
+            const int n = P / (H_ + 1), yy = P - n * (H_ + 1) - 1;
+            const bool ok = kb < kb1 && r < G::XR && f >= 0 && xc >= 1 && yy >= 0 && n < p.N;
+            const unsigned off = ok ? 4u * (unsigned)((((long)n * H_ + yy) * W_ + (xc - 1)) * CT + ci0 + 8 * cg) : 0x80000000u;
+            ldx[u][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0);
+            ldx[u][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 16, 0);
+        }
+    };
+    auto store = [&]() {                                 // cut + store what `fetch` brought: dY units, then the X window's units
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = tid + 256 * u, v = q >> 3, cg = q & 7;
             float vv[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { vv[e] = __uint_as_float(a[e]); vv[4 + e] = __uint_as_float(b[e]); }
+            for (int e = 0; e < 4; ++e) { vv[e] = __uint_as_float(ldy[u][0][e]); vv[4 + e] = __uint_as_float(ldy[u][1][e]); }
             u32x4 o3[3];
             p_cut8(vv, o3);
             unsigned char* dst = lds + G::YB + (cg >> 2) * G::YH + v * PW_ROW + (cg & 3) * 16;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * G::YPL) = o3[pl];
         }
-        // ---- stage the X window: unit (window row r, 8-channel group cg); pads, separators and rows outside the batch are zeros ----
 #pragma unroll
         for (int u = 0; u < G::UX; ++u) {
             const int q = tid + 256 * u, r = q >> 2, cg = q & 3;
             if (r < G::XR) {
-                const int f = fstart + r;
-                const int P = f / PW, xc = f - P * PW;   // (f < 0: P <= 0 below)
-                const int n = P / (H_ + 1), yy = P - n * (H_ + 1) - 1;
-                const bool ok = f >= 0 && xc >= 1 && yy >= 0 && n < p.N;
-                const unsigned off = ok ? 4u * (unsigned)((((long)n * H_ + yy) * W_ + (xc - 1)) * CT + ci0 + 8 * cg) : 0x80000000u;
-                const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 16, 0);
                 float vv[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { vv[e] = __uint_as_float(a[e]); vv[4 + e] = __uint_as_float(b[e]); }
+                for (int e = 0; e < 4; ++e) { vv[e] = __uint_as_float(ldx[u][0][e]); vv[4 + e] = __uint_as_float(ldx[u][1][e]); }
                 u32x4 o3[3];
                 p_cut8(vv, o3);
                 unsigned char* dst = lds + r * PW_ROW + cg * 16;
@@ -482,6 +497,13 @@ __global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
                 for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * G::XPL) = o3[pl];
             }
         }
+    };
+    fetch(kb0);
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const long o0 = (long)kb * PW_KB;
+        const int fstart = window_start(kb);
+        __syncthreads();                                 // every wave is done with the previous window
+        store();
         // ---- this lane's rows of the window for its two k-steps: voxel o0 + 16 (2 kh + lk) + 8 h + q4 (+ 4) ----
         int xrow[2][2];
 #pragma unroll
@@ -491,8 +513,10 @@ __global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
                 long o = o0 + 16 * (2 * kh + lk) + 8 * h + q4 + 4 * hi;
                 if (o >= p.total) o = p.total - 1;       // (its dY row is zero: any staged row will do)
                 const int n = (int)(o / HW), rr = (int)(o - (long)n * HW), y = rr / W_, x = rr - y * W_;
-                xrow[lk][hi] = ((n * (H_ + 1) + 1 + y) * PW + x + 1 - fstart) * PW_ROW + coloff;
+                // (biased by the taps' reach: the offset of tap (ty, tx) is then (ty PW + tx) rows >= 0 - a ds_read immediate)
+                xrow[lk][hi] = ((n * (H_ + 1) + 1 + y) * PW + x + 1 - fstart - (PW + 1)) * PW_ROW + coloff;
             }
+        fetch(kb + 1);                                   // (behind the last K-block: nothing - offsets out of range)
         __syncthreads();
         // ---- 2 k-steps x (dY fragment + 9 taps x X fragment) ----
 #pragma unroll
@@ -507,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
             }
             bf16x8 af[2][3];
             auto read_a = [&](int t, int set) {
-                const int sh = ((t / 3 - 1) * PW + (t % 3 - 1)) * PW_ROW;
+                const int sh = ((t / 3) * PW + t % 3) * PW_ROW;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
                     const bf16x4p lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4p*)(lds + pl * G::XPL + xrow[lk][0] + sh));
@@ -522,7 +546,16 @@ __global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
 #pragma unroll
                 for (int pr = 0; pr < 6; ++pr)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][PA[pr]], bfg[PB[pr]], acc[t], 0, 0, 0);
+                // issue order inside a tap: its first MFMA, then the next tap's six fragment reads (five MFMAs = 160 cycles to land)
+                // (the 36-wide window has three staging units per thread in flight: pinned, its allocation spills 16 registers and the
+                // kernel is no faster - left to the scheduler there)
+                if constexpr (G::UX <= 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+                }
             }
+            if constexpr (G::UX <= 2) __builtin_amdgcn_sched_barrier(0);
         }
     }
 
