@@ -116,6 +116,7 @@ SIGNATURES = {
     "mi_mse_loss_bwd": (_I, [_P, _P, _L, _P, _P, _P, _P, _P]),
     "mi_ucl_rowsums_fwd": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "mi_ucl_rowsums_bwd": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "mi_ucl_rowsums_bwd_ranged": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mi_colreduce_workspace_bytes": (_Z, [_L, _I]),
     "mi_bn_stats": (_I, [_P, _L, _I, _P, _P, _Z, _P]),
     "mi_bn_apply_fwd": (_I, [_P, _P, _L, _I, _P, _D, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P]),

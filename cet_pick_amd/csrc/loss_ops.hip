@@ -235,8 +235,11 @@ __global__ __launch_bounds__(256, 3) void ucl_fwd_kernel(const float* feat, cons
                                                      float inv_T, float* rowmax, float* s_all, float* s_pos,
                                                      float* s_other, float* e_pair) {
     typedef UclS<DIM> SP;
-    __shared__ __attribute__((aligned(16))) unsigned char colb[SP::BYTES];
-    __shared__ uint8_t colc[UB];
+    // (round 6: two column tiles resident - tile t + 1 is fetched, cut and stored while tile t's product and exponentials run: ONE
+    // barrier per tile instead of two)
+    constexpr bool DB = DIM == 32;                        // (64-wide features: the second buffer would cost the third resident workgroup)
+    __shared__ __attribute__((aligned(16))) unsigned char colb_[DB ? 2 : 1][SP::BYTES];
+    __shared__ uint8_t colc_[DB ? 2 : 1][UB];
     __shared__ float mrg[2][UB][4];                       // merge of the two column halves (wn)
     __shared__ float s_pair[UB];                          // S[row][pair(row)]: one writer per row in the whole walk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -256,19 +259,33 @@ __global__ __launch_bounds__(256, 3) void ucl_fwd_kernel(const float* feat, cons
     for (int r = 0; r < 16; ++r) st[r] = {-INFINITY, -INFINITY, 0.f, 0.f, 0.f};
     if (tid < UB) s_pair[tid] = -INFINITY;
 
-    for (int col0 = 0; col0 < n2; col0 += UB) {
-        __syncthreads();
+    auto stage_tile = [&](int b, int c0) {
         for (int q = tid; q < UB * (DIM / 8); q += 256) {
             const int c = q / (DIM / 8), k8 = (q % (DIM / 8)) * 8;
             float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (col0 + c < n2) {
-                const float4 a = ld4(feat + (long)(col0 + c) * DIM + k8), b = ld4(feat + (long)(col0 + c) * DIM + k8 + 4);
-                v[0] = a.x * fs; v[1] = a.y * fs; v[2] = a.z * fs; v[3] = a.w * fs; v[4] = b.x * fs; v[5] = b.y * fs; v[6] = b.z * fs; v[7] = b.w * fs;
+            if (c0 + c < n2) {
+                const float4 a = ld4(feat + (long)(c0 + c) * DIM + k8), b4 = ld4(feat + (long)(c0 + c) * DIM + k8 + 4);
+                v[0] = a.x * fs; v[1] = a.y * fs; v[2] = a.z * fs; v[3] = a.w * fs; v[4] = b4.x * fs; v[5] = b4.y * fs; v[6] = b4.z * fs; v[7] = b4.w * fs;
             }
-            SP::stage(colb, c, k8, v);
+            SP::stage(colb_[b], c, k8, v);
         }
-        if (tid < UB) colc[tid] = col0 + tid < n2 ? cls[col0 + tid] : 0;
+        if (tid < UB) colc_[b][tid] = c0 + tid < n2 ? cls[c0 + tid] : 0;
+    };
+    if (DB) {
+        stage_tile(0, 0);
         __syncthreads();
+    }
+    for (int col0 = 0; col0 < n2; col0 += UB) {
+        const int cur = DB ? (col0 / UB) & 1 : 0;
+        if (DB) {
+            if (col0 + UB < n2) stage_tile(cur ^ 1, col0 + UB);
+        } else {
+            __syncthreads();
+            stage_tile(0, col0);
+            __syncthreads();
+        }
+        const unsigned char* colb = colb_[cur];
+        const uint8_t* colc = colc_[cur];
         const f32x16 acc = SP::product(colb, af, wn * 32, l32, h);
         const int col = col0 + wn * 32 + l32;
         const bool colok = col < n2;
@@ -316,6 +333,7 @@ __global__ __launch_bounds__(256, 3) void ucl_fwd_kernel(const float* feat, cons
                 }
             }
         }
+        if (DB) __syncthreads();                           // the next tile is in place; this one's buffer is free
     }
     // merge the 32 lanes that share a row (same h), then the two column halves
 #pragma unroll
@@ -351,13 +369,23 @@ __global__ __launch_bounds__(256, 3) void ucl_fwd_kernel(const float* feat, cons
 // dF[row] = inv_T * sum_col W[row][col] F[col],
 //   TRANS == 0:  W = E[row][col] * c(row; col),   E = exp(S - rowmax[row])          (d/d row-side features)
 //   TRANS == 1:  W = E[col][row] * c(col; row),   E = exp(S - rowmax[col])          (d/d column-side features)
+//   TRANS == 2:  both at once (round 6): S is symmetric, so the tile (rows R, columns C) a row block forms for its row-side term IS the
+//                transpose of the tile (C, R) its column-side term needs - W = E_R c(row; col) + E_C c(col; row) from ONE similarity
+//                product, ONE staged column tile and ONE contraction with F[col] (before: two kernels, each with both products)
 // with c(i; j) = g_all[i] + g_pos[i] [pos j] + g_other[i] [other j] + g_pair[i] [j == pair(i)], zero on the diagonal.
 // The W tile goes through LDS to become the A operand of the second product.
 template <int DIM, int TRANS>
-__global__ __launch_bounds__(256, DIM == 64 ? 2 : 3) void ucl_bwd_kernel(const float* feat, const uint8_t* cls, int n2, int n_half,
+__global__ __launch_bounds__(256, (DIM == 64 || TRANS >= 2) ? 2 : 3) void ucl_bwd_kernel(const float* feat, const uint8_t* cls, int n2, int n_half,
                                                      float inv_T, const float* rowmax, const float* g_all,
                                                      const float* g_pos, const float* g_other, const float* g_pair,
-                                                     float* dfeat, int accumulate) {
+                                                     float* dfeat, int accumulate, const float* range = nullptr) {
+    // TRANS == 3 (round 6): TRANS == 2 with ONE exponential per similarity.  exp(S - max_row) = exp(S - M) exp(M - max_row) for any
+    // reference M; with M = the largest row maximum (range[0], base-2 units) the second factor is a per-row constant folded into the
+    // row's g_* once, and a tile element costs one exp2 for both of its terms.  Safe when the row maxima lie within 2^16 of each other
+    // (range[1] != 0: the factors stay far from overflow and what underflows in exp(S - M) is < 2^-100 of its row's largest term) - always
+    // so for L2-normalised features (the diagonal 1 / T is every row's maximum), which is what the detector's projection head emits;
+    // otherwise this kernel returns at once and the TRANS == 2 launch behind it does the work (and vice versa).
+    if (TRANS >= 2 && range != nullptr && (range[1] != 0.f) != (TRANS == 3)) return;
     constexpr int LD = DIM + 1;
     constexpr int WL = UB + 1;
     constexpr int NT = DIM / 32;                          // 32-wide output column tiles of the second product
@@ -370,9 +398,12 @@ __global__ __launch_bounds__(256, DIM == 64 ? 2 : 3) void ucl_bwd_kernel(const f
     __shared__ __attribute__((aligned(16))) float arena[COLF + 4 * 32 * WP];
     static_assert(2 * UB * LD <= COLF + 4 * 32 * WP, "epilogue does not fit the arena");
     float (*const wt)[32 * WP] = reinterpret_cast<float (*)[32 * WP]>(arena + COLF);
-    __shared__ __attribute__((aligned(16))) unsigned char colb[SP::BYTES];      // the tile's bf16x3 planes (first product)
-    __shared__ float cmeta[UB][5];                        // TRANS: rowmax, g_* of the tile's columns
-    __shared__ uint8_t colc[UB];
+    // (round 6, the merged forms: two column tiles resident - tile t + 1 is cut and stored while tile t's products
+    // run, ONE barrier per tile instead of two)
+    constexpr bool DB = TRANS >= 2;
+    __shared__ __attribute__((aligned(16))) unsigned char colb_[DB ? 2 : 1][SP::BYTES];      // the tiles' bf16x3 planes (first product)
+    __shared__ float cmeta_[DB ? 2 : 1][UB][5];           // TRANS: rowmax, g_* of the tile's columns
+    __shared__ uint8_t colc_[DB ? 2 : 1][UB];
     (void)WL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l32 = lane & 31;
@@ -389,11 +420,13 @@ __global__ __launch_bounds__(256, DIM == 64 ? 2 : 3) void ucl_bwd_kernel(const f
     // workgroup's 64 rows sit in LDS and come as ONE 16-byte broadcast read per row (all five in registers: 198 VGPRs, two
     // waves per SIMD - the kernel's vector work hides behind a third wave's MFMAs)
     __shared__ __attribute__((aligned(16))) float rmeta[UB][4];
-    if (!TRANS && tid < UB) {
+    const float gmax = TRANS == 3 ? range[0] : 0.f;         // M, base-2 units
+    if (TRANS != 1 && tid < UB) {
         const int row = row0 + tid;
         const bool ok = row < n2;
-        rmeta[tid][0] = ok ? g_pos[row] : 0.f; rmeta[tid][1] = ok ? g_other[row] : 0.f;
-        rmeta[tid][2] = ok ? g_pair[row] : 0.f; rmeta[tid][3] = 0.f;
+        const float sg = (TRANS == 3 && ok) ? __builtin_amdgcn_exp2f(gmax - rowmax[row] * LOG2E) : 1.f;
+        rmeta[tid][0] = ok ? g_pos[row] * sg : 0.f; rmeta[tid][1] = ok ? g_other[row] * sg : 0.f;
+        rmeta[tid][2] = ok ? g_pair[row] * sg : 0.f; rmeta[tid][3] = 0.f;
     }
     float rm[16], ra[16];
     uint8_t rcl[16];
@@ -401,8 +434,9 @@ __global__ __launch_bounds__(256, DIM == 64 ? 2 : 3) void ucl_bwd_kernel(const f
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool ok = row < n2;
-        rm[r] = (!TRANS && ok) ? rowmax[row] * LOG2E : 0.f;
-        ra[r] = (!TRANS && ok) ? g_all[row] : 0.f;
+        rm[r] = (TRANS != 1 && ok) ? rowmax[row] * LOG2E : 0.f;
+        ra[r] = (TRANS != 1 && ok) ? g_all[row] : 0.f;
+        if (TRANS == 3) { ra[r] *= ok ? __builtin_amdgcn_exp2f(gmax - rm[r]) : 0.f; rm[r] = gmax; }
         rcl[r] = ok ? cls[row] : 0;
     }
     // Two levels of accumulation: `out` collects UCL_FLUSH column tiles on the matrix pipe and is then added into `tot` by the
@@ -419,6 +453,50 @@ __global__ __launch_bounds__(256, DIM == 64 ? 2 : 3) void ucl_bwd_kernel(const f
 #pragma unroll
         for (int r = 0; r < 16; ++r) { out[j][r] = 0.f; if (TWO_LEVEL) tot[j][r] = 0.f; }
 
+    constexpr int NPRE = UB * (DIM / 8) / 256;            // staging units (column, 8 features) per thread and tile
+    static_assert(UB * (DIM / 8) % 256 == 0, "staging units");
+    float4 pre[NPRE][2];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int q = tid + 256 * u;
+            const int c = q / (DIM / 8), k8 = (q % (DIM / 8)) * 8;
+            const bool ok = c0 + c < n2;
+            pre[u][0] = ok ? ld4(feat + (long)(c0 + c) * DIM + k8) : make_float4(0, 0, 0, 0);
+            pre[u][1] = ok ? ld4(feat + (long)(c0 + c) * DIM + k8 + 4) : make_float4(0, 0, 0, 0);
+        }
+    };
+    constexpr bool PRE = DB || DIM == 64;                 // (the two-launch 32-wide forms run three waves per SIMD: no registers to spare)
+    // cut + store the tile held in `pre` (columns c0 ..) into buffer b, with its columns' metadata
+    auto stage_tile = [&](int b, int c0) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int q = tid + 256 * u;
+            const int c = q / (DIM / 8), k8 = (q % (DIM / 8)) * 8;
+            float v[8];
+            v[0] = pre[u][0].x * fs; v[1] = pre[u][0].y * fs; v[2] = pre[u][0].z * fs; v[3] = pre[u][0].w * fs;
+            v[4] = pre[u][1].x * fs; v[5] = pre[u][1].y * fs; v[6] = pre[u][1].z * fs; v[7] = pre[u][1].w * fs;
+            SP::stage(colb_[b], c, k8, v);                 // (both products read the planes)
+        }
+        if (tid < UB) {
+            const int c = c0 + tid;
+            const bool ok = c < n2;
+            colc_[b][tid] = ok ? cls[c] : 0;
+            if (TRANS != 0) {
+                const float cmxv = ok ? rowmax[c] * LOG2E : 0.f;
+                const float sg = (TRANS == 3 && ok) ? __builtin_amdgcn_exp2f(gmax - cmxv) : 1.f;
+                cmeta_[b][tid][0] = TRANS == 3 ? gmax : cmxv; cmeta_[b][tid][1] = ok ? g_all[c] * sg : 0.f;
+                cmeta_[b][tid][2] = ok ? g_pos[c] * sg : 0.f; cmeta_[b][tid][3] = ok ? g_other[c] * sg : 0.f;
+                cmeta_[b][tid][4] = ok ? g_pair[c] * sg : 0.f;
+            }
+        }
+    };
+    if (DB) {
+        prefetch(0);
+        stage_tile(0, 0);
+        prefetch(UB);
+        __syncthreads();
+    } else if (PRE) prefetch(0);
     for (int col0 = 0; col0 < n2; col0 += UB) {
         if (TWO_LEVEL && (col0 / UB) % UCL_FLUSH == UCL_FLUSH - 1) {     // (uniform)
 #pragma unroll
@@ -426,27 +504,21 @@ __global__ __launch_bounds__(256, DIM == 64 ? 2 : 3) void ucl_bwd_kernel(const f
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { tot[j][r] += out[j][r]; out[j][r] = 0.f; }
         }
-        __syncthreads();
-        for (int q = tid; q < UB * (DIM / 8); q += 256) {
-            const int c = q / (DIM / 8), k8 = (q % (DIM / 8)) * 8;
-            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (col0 + c < n2) {
-                const float4 a = ld4(feat + (long)(col0 + c) * DIM + k8), b = ld4(feat + (long)(col0 + c) * DIM + k8 + 4);
-                v[0] = a.x * fs; v[1] = a.y * fs; v[2] = a.z * fs; v[3] = a.w * fs; v[4] = b.x * fs; v[5] = b.y * fs; v[6] = b.z * fs; v[7] = b.w * fs;
-            }
-            SP::stage(colb, c, k8, v);                     // (both products read the planes)
+        const int cur = DB ? (col0 / UB) & 1 : 0;
+        if (!DB) {
+            __syncthreads();
+            if (!PRE) prefetch(col0);                      // (PRE: fetched during the previous tile's products)
+            stage_tile(0, col0);
+            if (PRE) prefetch(col0 + UB);
+            __syncthreads();
+        } else {
+            // the next tile goes into the other buffer (its features arrived during the previous tile), the one after it is fetched
+            if (col0 + UB < n2) stage_tile(cur ^ 1, col0 + UB);
+            prefetch(col0 + 2 * UB);
         }
-        if (tid < UB) {
-            const int c = col0 + tid;
-            const bool ok = c < n2;
-            colc[tid] = ok ? cls[c] : 0;
-            if (TRANS) {
-                cmeta[tid][0] = ok ? rowmax[c] * LOG2E : 0.f; cmeta[tid][1] = ok ? g_all[c] : 0.f;
-                cmeta[tid][2] = ok ? g_pos[c] : 0.f; cmeta[tid][3] = ok ? g_other[c] : 0.f;
-                cmeta[tid][4] = ok ? g_pair[c] : 0.f;
-            }
-        }
-        __syncthreads();
+        const unsigned char* colb = colb_[cur];
+        const float (*cmeta)[5] = cmeta_[cur];
+        const uint8_t* colc = colc_[cur];
         const f32x16 acc = SP::product(colb, af, wn * 32, l32, h);
         const int lc = wn * 32 + l32, col = col0 + lc;
         const bool colok = col < n2;
@@ -458,18 +530,29 @@ __global__ __launch_bounds__(256, DIM == 64 ? 2 : 3) void ucl_bwd_kernel(const f
                            (clo + 32 <= rlo - n_half || clo >= rlo + 32 - n_half);
         if (plain) {                                       // (wave-uniform) no diagonal, no pair element, nothing ragged
             float c0, c1, c2, cmx;
-            if (TRANS) {
+            if (TRANS == 1) {
                 const float* cm = cmeta[lc];
                 cmx = cm[0]; c0 = cm[1]; c1 = cm[2]; c2 = cm[3];
             } else {
                 c0 = (cc & 1) ? 1.f : 0.f; c1 = (cc & 2) ? 1.f : 0.f; c2 = 0.f; cmx = 0.f;
             }
+            float k0 = 0.f, k1 = 0.f, k2 = 0.f, kmx = 0.f;             // TRANS == 2: the column's g_all, g_pos, g_other and maximum
+            if (TRANS >= 2) { const float* cm = cmeta[lc]; kmx = cm[0]; k0 = cm[1]; k1 = cm[2]; k2 = cm[3]; }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int tr = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float s = acc[r];
                 float w;
-                if (!TRANS) {
+                if (TRANS == 3) {
+                    const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
+                    const float cf = fmaf((float)((rcl[r] >> 1) & 1), k2, fmaf((float)(rcl[r] & 1), k1, fmaf(c1, mq.y, fmaf(c0, mq.x, ra[r] + k0))));
+                    w = __builtin_amdgcn_exp2f(s - gmax) * cf;
+                } else if (TRANS == 2) {
+                    const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
+                    const float wr = __builtin_amdgcn_exp2f(s - rm[r]) * fmaf(c1, mq.y, fmaf(c0, mq.x, ra[r]));
+                    const float wc = __builtin_amdgcn_exp2f(s - kmx) * fmaf((float)((rcl[r] >> 1) & 1), k2, fmaf((float)(rcl[r] & 1), k1, k0));
+                    w = wr + wc;
+                } else if (!TRANS) {
                     const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
                     w = __builtin_amdgcn_exp2f(s - rm[r]) * fmaf(c1, mq.y, fmaf(c0, mq.x, ra[r]));
                 }
@@ -486,7 +569,14 @@ __global__ __launch_bounds__(256, DIM == 64 ? 2 : 3) void ucl_bwd_kernel(const f
             if (colok && row < n2 && col != row) {
                 const float s = acc[r];
                 const int pr = row < n_half ? row + n_half : row - n_half;
-                if (!TRANS) {
+                if (TRANS >= 2) {                             // (TRANS == 3: rm[r] = cm[0] = M and the coefficients arrive scaled)
+                    const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
+                    const float* cm = cmeta[lc];
+                    w = __builtin_amdgcn_exp2f(s - rm[r]) * (ra[r] + ((cc & 1) ? mq.x : 0.f) + ((cc & 2) ? mq.y : 0.f) +
+                                             (col == pr ? mq.z : 0.f)) +
+                        __builtin_amdgcn_exp2f(s - cm[0]) * (cm[1] + ((rcl[r] & 1) ? cm[2] : 0.f) + ((rcl[r] & 2) ? cm[3] : 0.f) +
+                                             (col == pr ? cm[4] : 0.f));
+                } else if (!TRANS) {
                     const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
                     w = __builtin_amdgcn_exp2f(s - rm[r]) * (ra[r] + ((cc & 1) ? mq.x : 0.f) + ((cc & 2) ? mq.y : 0.f) +
                                              (col == pr ? mq.z : 0.f));
@@ -532,6 +622,7 @@ __global__ __launch_bounds__(256, DIM == 64 ? 2 : 3) void ucl_bwd_kernel(const f
                 }
             }
         }
+        if (DB) __syncthreads();                           // the next tile is in place; this one's buffer is free
     }
     if (TWO_LEVEL) {
 #pragma unroll
@@ -628,21 +719,62 @@ extern "C" int mi_ucl_rowsums_fwd(const float* feat, const uint8_t* cls, int n2,
     return MI_OK;
 }
 
+// range[0] = the largest row maximum (base-2 units), range[1] = 1 when all row maxima lie within 2^16 of it (ucl_bwd_kernel TRANS == 3)
+__global__ __launch_bounds__(1024) void ucl_rowmax_range_kernel(const float* rowmax, int n2, float* range) {
+    __shared__ float smx[16], smn[16];
+    float mx = -INFINITY, mn = INFINITY;
+    for (int i = threadIdx.x; i < n2; i += 1024) { const float v = rowmax[i]; mx = fmaxf(mx, v); mn = fminf(mn, v); }
+    mx = wave_max(mx); mn = -wave_max(-mn);
+    if ((threadIdx.x & 63) == 0) { smx[threadIdx.x >> 6] = mx; smn[threadIdx.x >> 6] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) { mx = fmaxf(mx, smx[k]); mn = fminf(mn, smn[k]); }
+        const float L2E = 1.4426950408889634f;
+        range[0] = mx * L2E;
+        range[1] = ((mx - mn) * L2E <= 16.f && mx == mx && mn == mn) ? 1.f : 0.f;      // (NaN anywhere: the general kernel)
+    }
+}
+
 extern "C" int mi_ucl_rowsums_bwd(const float* feat, const uint8_t* cls, int n2, int dim, float inv_T,
                                   const float* rowmax, const float* g_all, const float* g_pos, const float* g_other,
                                   const float* g_pair, float* dfeat, mi_stream_t stream) {
     if (!feat || !cls || !rowmax || !g_all || !g_pos || !g_other || !g_pair || !dfeat || n2 <= 0 || (n2 & 1)) return MI_E_ARG;
     const dim3 grid((n2 + UB - 1) / UB), block(256);
     hipStream_t s = (hipStream_t)stream;
+    // round 6: one launch forms both terms from one similarity tile (TRANS == 2); MI_UCL_BWD_SPLIT=1: the two launches of rounds 2-5
+    // (the 64-wide form stays split: its merged kernel would hold both sides' metadata at one resident wave less per SIMD)
+    const bool split = getenv("MI_UCL_BWD_SPLIT") != nullptr;
 #define MI_UCL_BWD(D_)                                                                                              \
     hipLaunchKernelGGL((ucl_bwd_kernel<D_, 0>), grid, block, 0, s, feat, cls, n2, n2 / 2, inv_T, rowmax, g_all, g_pos, \
                        g_other, g_pair, dfeat, 0);                                                                  \
     hipLaunchKernelGGL((ucl_bwd_kernel<D_, 1>), grid, block, 0, s, feat, cls, n2, n2 / 2, inv_T, rowmax, g_all, g_pos, \
                        g_other, g_pair, dfeat, 1)
-    if (dim == 32) { MI_UCL_BWD(32); }
+    if (dim == 32 && !split) {
+        hipLaunchKernelGGL((ucl_bwd_kernel<32, 2>), grid, block, 0, s, feat, cls, n2, n2 / 2, inv_T, rowmax, g_all, g_pos, g_other, g_pair,
+                           dfeat, 0, (const float*)nullptr);
+    } else if (dim == 32) { MI_UCL_BWD(32); }
     else if (dim == 64) { MI_UCL_BWD(64); }
     else return MI_E_UNSUPPORTED;
 #undef MI_UCL_BWD
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+// ... with a two-float scratch `range`: the one-exponential form where the row maxima allow it (ucl_bwd_kernel TRANS == 3), decided on the
+// device - a range kernel, then both forms' launches, of which one returns at once
+extern "C" int mi_ucl_rowsums_bwd_ranged(const float* feat, const uint8_t* cls, int n2, int dim, float inv_T, const float* rowmax,
+                                         const float* g_all, const float* g_pos, const float* g_other, const float* g_pair, float* dfeat,
+                                         float* range, mi_stream_t stream) {
+    if (!range || dim != 32 || getenv("MI_UCL_BWD_SPLIT") || getenv("MI_UCL_BWD_TWO_EXP"))
+        return mi_ucl_rowsums_bwd(feat, cls, n2, dim, inv_T, rowmax, g_all, g_pos, g_other, g_pair, dfeat, stream);
+    if (!feat || !cls || !rowmax || !g_all || !g_pos || !g_other || !g_pair || !dfeat || n2 <= 0 || (n2 & 1)) return MI_E_ARG;
+    const dim3 grid((n2 + UB - 1) / UB), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ucl_rowmax_range_kernel, dim3(1), dim3(1024), 0, s, rowmax, n2, range);
+    hipLaunchKernelGGL((ucl_bwd_kernel<32, 3>), grid, block, 0, s, feat, cls, n2, n2 / 2, inv_T, rowmax, g_all, g_pos, g_other, g_pair, dfeat,
+                       0, (const float*)range);
+    hipLaunchKernelGGL((ucl_bwd_kernel<32, 2>), grid, block, 0, s, feat, cls, n2, n2 / 2, inv_T, rowmax, g_all, g_pos, g_other, g_pair, dfeat,
+                       0, (const float*)range);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

@@ -121,9 +121,10 @@ class _UclRowSumsFn(torch.autograd.Function):
         z = lambda g: torch.zeros(n2, dtype=torch.float32, device=feat.device) if g is None else g.contiguous().float()
         g_all, g_pos, g_other, g_pair = z(g_all), z(g_pos), z(g_other), z(g_pair)
         dfeat = torch.empty_like(feat)
-        L.check(L.lib().mi_ucl_rowsums_bwd(L.ptr(feat), L.ptr(cls), n2, dim, ctx.inv_T, L.ptr(rowmax), L.ptr(g_all),
-                                           L.ptr(g_pos), L.ptr(g_other), L.ptr(g_pair), L.ptr(dfeat), L.stream()),
-                "mi_ucl_rowsums_bwd")
+        rng = torch.empty(2, dtype=torch.float32, device=feat.device)      # (largest row maximum, fast-path flag): decided on the device
+        L.check(L.lib().mi_ucl_rowsums_bwd_ranged(L.ptr(feat), L.ptr(cls), n2, dim, ctx.inv_T, L.ptr(rowmax), L.ptr(g_all),
+                                                  L.ptr(g_pos), L.ptr(g_other), L.ptr(g_pair), L.ptr(dfeat), L.ptr(rng), L.stream()),
+                "mi_ucl_rowsums_bwd_ranged")
         return dfeat, None, None
 
 

@@ -653,6 +653,12 @@ int mi_ucl_rowsums_fwd(const float* feat, const uint8_t* cls, int n2, int dim, f
 int mi_ucl_rowsums_bwd(const float* feat, const uint8_t* cls, int n2, int dim, float inv_T, const float* rowmax,
                        const float* g_all, const float* g_pos, const float* g_other, const float* g_pair,
                        float* dfeat, mi_stream_t stream);
+/* Round 6: the same gradient with both terms of a similarity tile formed at once (S is symmetric: one product, one contraction - what
+ * mi_ucl_rowsums_bwd does too, MI_UCL_BWD_SPLIT=1 for the two launches of rounds 2-5) and, where the row maxima lie within 2^16 of each
+ * other - always for L2-normalised features - ONE exponential per similarity; decided on the device from `range` (2 floats of scratch). */
+int mi_ucl_rowsums_bwd_ranged(const float* feat, const uint8_t* cls, int n2, int dim, float inv_T, const float* rowmax,
+                              const float* g_all, const float* g_pos, const float* g_other, const float* g_pair, float* dfeat,
+                              float* range, mi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -133,3 +133,51 @@ def test_tomo_cr_semi_loss_vs_oracle(flip_prob):
         np.testing.assert_allclose(got, want, rtol=0, atol=5e-4 * np.abs(want).max() + 1e-9, err_msg=name)
     val_loss, _ = TomoCRSemiLoss(opt)([{"hm": hm.cuda().clone(), "proj": None}], {"hm": gt.cuda()}, 1, "val")
     np.testing.assert_allclose(val_loss.item(), O.neg_loss(torch.clamp(torch.sigmoid(hm), 1e-4, 1 - 1e-4).squeeze(), gt.squeeze()).item(), rtol=1e-4)
+
+
+@pytest.mark.parametrize("normalised", [True, False])
+def test_ucl_backward_forms_agree(normalised, monkeypatch):
+    """Round 6: the contrastive backward forms both terms of a similarity tile at once (S is symmetric: one product, one contraction) and,
+    where the row maxima lie within 2^16 of each other, with ONE exponential per similarity - chosen on the device.  L2-normalised
+    features take the one-exponential kernel, features whose norms spread the row maxima over 2^70 the general one; both must give the
+    gradient of the two-launch form of rounds 2-5 (MI_UCL_BWD_SPLIT=1) and of a dense float64 evaluation."""
+    from cet_pick_amd.models.loss import _UclRowSumsFn
+    n2, dim, inv_T = 2048, 32, 1.0 / 0.07
+    g = torch.Generator().manual_seed(11 + int(normalised))
+    f = torch.nn.functional.normalize(torch.randn(n2, dim, generator=g), dim=1)
+    if not normalised:
+        f = f * torch.linspace(0.5, 2.0, n2)[torch.randperm(n2, generator=g)][:, None]
+    cls = torch.randint(0, 4, (n2,), generator=g).to(torch.uint8).cuda()
+    gouts = [torch.randn(n2, generator=g).cuda() * s for s in (0.0, 1.0, 0.7, 0.5, 0.3)]       # (no gradient through the maximum itself)
+
+    def grad():
+        fa = f.clone().cuda().requires_grad_()
+        outs = _UclRowSumsFn.apply(fa, cls, inv_T)
+        torch.autograd.backward(list(outs[1:]), [go.clone() for go in gouts[1:]])
+        return fa.grad.clone(), [o.detach() for o in outs]
+
+    g_default, outs = grad()
+    spread = float((outs[0].max() - outs[0].min()) * 1.4426950408889634)
+    assert (spread <= 16.0) == normalised, spread
+    monkeypatch.setenv("MI_UCL_BWD_TWO_EXP", "1")
+    g_two, _ = grad()
+    monkeypatch.delenv("MI_UCL_BWD_TWO_EXP")
+    monkeypatch.setenv("MI_UCL_BWD_SPLIT", "1")
+    g_split, _ = grad()
+    scale = float(g_split.abs().max())
+    if not normalised:
+        assert torch.equal(g_default, g_two)               # the device picked the general kernel: same launch
+    assert float((g_default - g_split).abs().max()) <= 2e-5 * scale
+    assert float((g_two - g_split).abs().max()) <= 2e-5 * scale
+    # dense float64: E = exp(S - rowmax) off the diagonal, row sums weighted by the class masks, the pair element
+    F64 = f.double().cuda().requires_grad_()
+    S = (F64 @ F64.t()) * inv_T
+    m = S.max(1, keepdim=True)[0].detach()
+    E = torch.exp(S - m) * (1 - torch.eye(n2, dtype=torch.float64, device="cuda"))
+    pos, oth = (cls & 1).double(), ((cls >> 1) & 1).double()
+    pair = (torch.arange(n2, device="cuda") + n2 // 2) % n2
+    sa, sp, so = E.sum(1) + 1, (E * pos).sum(1) + pos, (E * oth).sum(1) + oth
+    ep = torch.exp(S - m)[torch.arange(n2), pair]
+    (sa * gouts[1].double() + sp * gouts[2].double() + so * gouts[3].double() + ep * gouts[4].double()).sum().backward()
+    ref = F64.grad
+    assert float((g_default.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
