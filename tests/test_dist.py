@@ -344,7 +344,7 @@ def _w_det(rank, world, port, out, same):
     tr.set_distributed_device(0)
     ret, _ = tr.train(1, [dict(batch)])
     torch.cuda.synchronize()
-    torch.save({"w": tr.engine.arena.flat.cpu(), "loss": ret["loss"], "calls": tr.exchange.calls},
+    torch.save({"w": tr.exchange.arena.flat.cpu(), "loss": ret["loss"], "calls": tr.exchange.calls},
                os.path.join(out, "d%d_%d.pt" % (int(same), rank)))
     dist.destroy_process_group()
 

@@ -927,7 +927,7 @@ def test_pair_weight_gradient_forms_match_float64(case, monkeypatch):
                                             ((24, 4, 128, 64, 3, 1), 3, "implicit GEMM x nb"), ((24, 4, 128, 128, 3, 1), 3, "implicit GEMM x nb"), ((20, 2, 256, 256, 3, 1), 4, "pair_wgrad x nb"),
                                             ((6, 8, 32, 48, 3, 1), 2, "implicit GEMM x nb"), ((16, 8, 64, 64, 3, 1), 5, "direct3_wgrad x nb"),
                                             #  the 64^3-crop shapes: no batched kernel - the group goes out as single launches of the dedicated ones
-                                            ((3, 16, 64, 64, 3, 1), 2, "single:direct3_wgrad (8 x 8 tiles)"), ((3, 8, 128, 128, 3, 1), 3, "single:direct3_wgrad (128 channels)")])
+                                            ((6, 16, 64, 64, 3, 1), 2, "single:direct3_wgrad (8 x 8 tiles)"), ((16, 8, 128, 128, 3, 1), 3, "single:direct3_wgrad (128 channels)")])
 def test_batched_weight_gradients_against_single_launches(case, nb, family, monkeypatch):
     """Round 5: the weight gradients of a stage's equal convolutions in ONE launch (hipops.run_wgrad_jobs ->
     mi_convnd_wgrad_slabs_batch_f32; layer1's four on direct3_wgrad_kernel, layer2's three on the implicit GEMM, layer3's on
