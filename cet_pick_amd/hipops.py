@@ -1538,6 +1538,33 @@ def dist_all_reduce(tensor):
     dist.all_reduce(tensor)
 
 
+def dist_all_reduce_pair(a, b):
+    """all_reduce(a); all_reduce(b) as ONE collective where the backend can group them (RCCL: ncclGroupStart / End - one launch, one
+    latency): the SyncBN statistics of encoder_q's and encoder_k's layer i, whose forward passes MoCo runs layer-locked (round 6).
+    Synchronous, like every collective here (see above)."""
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl" and a.is_cuda:
+        with dist.distributed_c10d._coalescing_manager():
+            dist.all_reduce(a)
+            dist.all_reduce(b)
+    else:
+        dist.all_reduce(a)
+        dist.all_reduce(b)
+
+
+def bn_local_sums(x):
+    """This rank's column sums (sum x, sum x^2: 2C doubles) of a channels-last activation - the statistics pass of a SyncBN whose
+    all-reduce the caller issues itself (paired with another branch's: MoCo's layer-locked forward)."""
+    _f32c(x, "x")
+    c = x.shape[-1]
+    m = x.numel() // c
+    lib = L.lib()
+    ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), x.device, "colreduce")
+    sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+    L.check(lib.mi_bn_stats(L.ptr(x), m, c, L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()), "mi_bn_stats")
+    return sums
+
+
 def dist_all_gather(tensor_list, tensor):
     import torch.distributed as dist
     dist.all_gather(tensor_list, tensor)
@@ -1573,8 +1600,10 @@ class _BNFn(torch.autograd.Function):
         distributed = mod.sync and _distributed()
         ctx.small = (mod.training or not mod.track_running_stats) and m <= BN_SMALL_MAX_ROWS and not distributed
         given_sums = None
+        reduced = False
         if pre is not None and isinstance(pre[0], str):
             given_sums = pre[1]                           # this rank's column sums from the producing Linear's epilogue (SyncBN)
+            reduced = pre[0] == "reduced"                 # ... or the GLOBAL sums: the caller has all-reduced them (paired with another branch's)
             pre = None
         if pre is not None:
             # (y, save) came out of the producing Linear's launch (linear_bn): nothing to run here
@@ -1608,7 +1637,8 @@ class _BNFn(torch.autograd.Function):
             count = float(m)
             if mod.sync and _distributed():
                 import torch.distributed as dist
-                dist_all_reduce(sums)                     # RCCL: 2*C doubles
+                if not reduced:
+                    dist_all_reduce(sums)                 # RCCL: 2*C doubles
                 count = float(m) * _dist_world()
             track = mod.track_running_stats and mod.training
             L.check(lib.mi_bn_apply_fwd(L.ptr(x), L.ptr(y), m, c, L.ptr(sums), count, L.ptr(gamma), L.ptr(beta),
@@ -1699,7 +1729,7 @@ class _BNReluPoolFn(torch.autograd.Function):
     """MaxPool3d(k, s, p)(relu(bn(x))) without materialising relu(bn(x)): the stem of the 3-D encoder."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mod, k, stride, pad, given_sums=None):
+    def forward(ctx, x, gamma, beta, mod, k, stride, pad, given_sums=None, reduced=False):
         n, d, h, w, c = x.shape
         lib = L.lib()
         dev = x.device
@@ -1720,7 +1750,8 @@ class _BNReluPoolFn(torch.autograd.Function):
                 L.check(lib.mi_bn_stats(L.ptr(x), m, c, L.ptr(sums), L.ptr(ws), ws.numel(), L.stream()), "mi_bn_stats")
             if mod.sync and _distributed():
                 import torch.distributed as dist
-                dist_all_reduce(sums)
+                if not reduced:                           # (reduced: the caller has all-reduced `given_sums`, paired with another branch's)
+                    dist_all_reduce(sums)
                 count = float(m) * _dist_world()
         track = mod.track_running_stats and mod.training
         use_running = not train
@@ -1774,13 +1805,13 @@ class _BNReluPoolFn(torch.autograd.Function):
             gamma.grad.add_(dg)
         if acc_b:
             beta.grad.add_(db)
-        return dx, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
-def bn_relu_maxpool3d(x, bn, k, stride, pad, sums=None):
+def bn_relu_maxpool3d(x, bn, k, stride, pad, sums=None, reduced=False):
     """maxpool3d(bn(x, relu=True), k, stride, pad) as one fused layer (bn: HipBatchNorm).  sums: the column sums of x and
     x^2 (2C doubles) where the producer of x already has them (the stem's epilogue) - the statistics pass is skipped."""
-    return _BNReluPoolFn.apply(_f32c(x, "x"), bn.weight, bn.bias, bn, k, stride, pad, sums)
+    return _BNReluPoolFn.apply(_f32c(x, "x"), bn.weight, bn.bias, bn, k, stride, pad, sums, reduced)
 
 
 def linear_bn(x, lin, bn, relu=False):
@@ -1801,6 +1832,25 @@ def linear_bn(x, lin, bn, relu=False):
         lin._fuse_bn = None
         lin._bn_pre = None
     return bn(xl, relu=relu, pre=pre)                 # (through the module: forward hooks keep firing)
+
+
+def linear_with_local_sums(x, lin, bn):
+    """(lin(x), this rank's column sums of it) for a SyncBN whose all-reduce the CALLER issues (MoCo's layer-locked forward pairs it
+    with the other encoder's): the sums come out of the product's epilogue where linear_bn's would, else from a statistics pass."""
+    train = bn.training or not bn.track_running_stats
+    if x.is_cuda and x.dim() == 2 and x.shape[0] <= 64 and train and PROFILE is None:
+        lin._fuse_bn = (bn, False, True)
+        try:
+            xl = lin(x)
+            pre = getattr(lin, "_bn_pre", None)
+        finally:
+            lin._fuse_bn = None
+            lin._bn_pre = None
+        if pre is not None and pre[0] == "sums":
+            return xl, pre[1]
+        return xl, bn_local_sums(xl)
+    xl = lin(x)
+    return xl, bn_local_sums(xl)
 
 
 class HipBatchNorm(nn.Module):

@@ -93,8 +93,79 @@ class MoCo(nn.Module):
             self._dequeue_and_enqueue(self._pending_keys)
             self._pending_keys = None
 
+    # Data parallel with SyncBN (moco_main.py:64-66): the two forward passes run LAYER-LOCKED - both encoders' forward generators
+    # (forward_sync_gen) stop in front of each of their five statistics exchanges, and the sums of encoder_q's and encoder_k's layer i
+    # go out as ONE collective (hipops.dist_all_reduce_pair: RCCL groups the two all-reduces into one launch, one xGMI latency) - 10
+    # SyncBN collectives per step (5 forward pairs + 5 backward) instead of 15 (round 6).  Replicas stay identical: every
+    # rank issues the same collectives in the same order.  pair_sync_bn = False keeps one collective per layer and branch.
+    pair_sync_bn = True
+    sync_collectives = 0           # collectives the last forward issued for SyncBN statistics (tests / diagnostics)
+
+    def _paired_ok(self):
+        def sync_all(enc):
+            bns = [m for m in enc.modules() if isinstance(m, H.HipBatchNorm)]
+            return bool(bns) and all(m.sync and (m.training or not m.track_running_stats) for m in bns)
+        return (self.pair_sync_bn and H._distributed() and H.PROFILE is None and H.RELU_TAP is None
+                and hasattr(self.encoder_q, "forward_sync_gen") and hasattr(self.encoder_k, "forward_sync_gen")
+                and sync_all(self.encoder_q) and sync_all(self.encoder_k))
+
+    def _forward_paired(self, im_q, im_k):
+        """(q_raw, k_raw) with the branches' SyncBN exchanges paired.  On the GPU the key branch keeps its side stream: at a pair the
+        main stream waits for the key branch's sums, all-reduces both, and the side stream waits for the result."""
+        two = self.overlap_key_branch and im_q.is_cuda
+        cur = side = None
+        if two:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=im_q.device)
+            cur, side = torch.cuda.current_stream(), self._side
+            side.wait_stream(cur)
+
+        class _Null:
+            def __enter__(self): return None
+            def __exit__(self, *a): return False
+        on_side = (lambda: torch.cuda.stream(side)) if two else _Null
+        with on_side(), torch.no_grad():
+            self._momentum_update_key_encoder()
+        gq, gk = self.encoder_q.forward_sync_gen(im_q), self.encoder_k.forward_sync_gen(im_k)
+        q_out = k_out = None
+        n_coll = 0
+        while True:
+            sq = sk = None
+            try:
+                sq = next(gq)
+            except StopIteration as e:
+                q_out = e.value
+            with on_side(), torch.no_grad():
+                try:
+                    sk = next(gk)
+                except StopIteration as e:
+                    k_out = e.value
+            if (sq is None) != (sk is None):
+                raise RuntimeError("the two encoders stopped at different SyncBN layers: they are not the same architecture")
+            if sq is None:
+                break
+            if two:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                cur.wait_event(ev)
+                sk.record_stream(cur)
+            H.dist_all_reduce_pair(sq, sk)
+            n_coll += 1
+            if two:
+                ev2 = torch.cuda.Event()
+                ev2.record(cur)
+                side.wait_event(ev2)
+        self.sync_collectives = n_coll
+        q_raw, k_raw = q_out[0]["proj"], k_out[0]["proj"].detach()
+        if two:
+            cur.wait_stream(side)
+            k_raw.record_stream(cur)
+        return q_raw, k_raw
+
     def forward(self, im_q, im_k):
-        if self.overlap_key_branch and im_q.is_cuda:
+        if self._paired_ok():
+            q_raw, k_raw = self._forward_paired(im_q, im_k)
+        elif self.overlap_key_branch and im_q.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=im_q.device)
             cur = torch.cuda.current_stream()

@@ -144,6 +144,49 @@ class TomoResClassifier3D(nn.Module):
             H.RELU_TAP[head + ".4"] = x.detach().clone()
         return H.linear_bn(x, seq[6], seq[7])
 
+    # ---- the same forward as a GENERATOR that stops in front of every SyncBN exchange (round 6) ---------------------
+    def forward_sync_gen(self, x1):
+        """`forward` under SyncBN (moco_main.py:64-66) with the five statistics all-reduces handed to the caller: yields this rank's
+        column sums (2C doubles) of bn1, feature_3d.1, proj.1, proj.4, proj.7 in turn, expects them all-reduced IN PLACE when resumed,
+        returns `forward`'s result.  MoCo drives encoder_q's and encoder_k's generators in lock step and all-reduces the two branches'
+        sums of a layer as ONE collective (5 for the two forward passes of a step instead of 10).  Grad mode and stream are the caller's at
+        every resume - none is entered in here (a context manager held across a yield would leak into the caller)."""
+        b, c, d, h, w = x1.shape
+        if c != 1:
+            raise ValueError("the moco3d encoder takes single-channel sub-tomograms (B,1,D,H,W)")
+        x = x1.contiguous().float().view(b, d, h, w, 1)
+        self.conv1.stats_for_bn = True
+        x = self.conv1(x)
+        sums = getattr(self.conv1, "bn_sums", None)
+        self.conv1.bn_sums = None
+        if sums is None:
+            sums = H.bn_local_sums(x)
+        yield sums
+        x = self._mark(H.bn_relu_maxpool3d(x, self.bn1, 3, 2, 1, sums=sums, reduced=True), "layer1")
+        first = True
+        for tag, layer in (("layer2", self.layer1), ("layer3", self.layer2), (None, self.layer3)):
+            for blk in layer:
+                x = blk(x, mask_dx=not first, dout_masked=True)
+                first = False
+            if tag is not None:
+                x = self._mark(x, tag)
+        x = self.feature_3d[0](x, mask_dx=True)
+        sums = H.bn_local_sums(x)
+        yield sums
+        x = H.global_avgpool(self.feature_3d[1](x, relu=True, pre=("reduced", sums)))
+        x = self.fc(x)
+        ret1 = {}
+        for head in self.heads:
+            if "proj" in head:
+                seq = self.__getattr__(head)
+                y = x
+                for li, bi, relu in ((0, 1, True), (3, 4, True), (6, 7, False)):
+                    yl, sums = H.linear_with_local_sums(y, seq[li], seq[bi])
+                    yield sums
+                    y = seq[bi](yl, relu=relu, pre=("reduced", sums))
+                ret1[head] = y
+        return [ret1]
+
     def forward_test(self, x1):
         """moco_encoder_3d.py:326-351: {'proj': z.detach()}."""
         x = self._trunk(x1)

@@ -138,6 +138,19 @@ def _w_step(rank, world, port, out):
     torch.cuda.synchronize()
     # the gradient exchange went out in four buckets, deepest layers first (overlapped with the backward pass)
     assert eng.buckets_sent == ["layer3", "layer2", "layer1", "stem"], eng.buckets_sent
+    # round 6: the two forward passes ran layer-locked - one SyncBN collective per layer for encoder_q and encoder_k together
+    assert moco.sync_collectives == 5, moco.sync_collectives
+    # ... and the un-paired form (one collective per layer and branch) gives the same step: a second engine on a fresh copy
+    moco_u = _make_moco()
+    H.convert_sync_batchnorm(moco_u)
+    moco_u.train()
+    moco_u.pair_sync_bn = False
+    eng_u = MocoStepEngine(moco_u, lr=0.05)
+    loss_u = eng_u.step(xq[sl].cuda(), xk[sl].cuda())
+    torch.cuda.synchronize()
+    assert moco_u.sync_collectives == 0
+    assert torch.equal(loss_u, loss) and torch.equal(eng_u.arena_q.flat, eng.arena_q.flat) and torch.equal(eng_u.arena_k.flat, eng.arena_k.flat)
+    assert torch.equal(moco_u.queue, moco.queue)
     assert sorted(eng._bucket.values())[0][0] == 0 and sorted(eng._bucket.values())[-1][1] == eng.arena_q.numel
     torch.save({"loss": float(loss), "queue": moco.queue.cpu(), "ptr": int(moco.queue_ptr),
                 "q_flat": eng.arena_q.flat.cpu(), "k_flat": eng.arena_k.flat.cpu(),

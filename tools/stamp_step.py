@@ -64,6 +64,8 @@ def timed(eng, x, y, n):
 eng, x, y, _ = build(False)
 timed(eng, x, y, 20)
 print("plain    %.4f ms/step" % timed(eng, x, y, R), flush=True)
+print("graph nodes of the captured step: %s; SyncBN collectives of the forward passes: %s (paired: one per layer for encoder_q + encoder_k)"
+      % (eng.node_counts(), getattr(eng.moco, "sync_collectives", None)), flush=True)
 eng.close()
 del eng
 H.STAMPS = None
