@@ -286,6 +286,14 @@ def inference_secondary(dev, with_cpu=True, rank=0, world=1):
         "dog_pick": entry("tomogram 256x512x512, sigma=(3,5), nms_xy k=3, greedy d=14", v.numel(), t_dog,
                           DOG_KERNELS, INFER_TRAFFIC),
     }
+    # the picker's second roofline: its filter stage is vector arithmetic - 198 multiply-adds per voxel over the
+    # three passes of both Gaussians ((R1 + R2 + 2) per pass, R = 12 and 20) - against the f32 vector peak of MI355X_MICROARCH.md
+    dflop = 198.0 * 2 * v.numel()
+    dms = out["dog_pick"]["ms"]
+    out["dog_pick"]["roofline_valu"] = {"bound": "valu", "achieved": dflop / dms / 1e9, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": dflop / dms / 1e9 / PEAK_F32_MATRIX_TFLOPS, "algorithmic_gflop": dflop / 1e9,
+                                        "note": "whole chain time against the filter stage's 198 FMA per voxel (26.6 GFLOP at 256x512x512); the "
+                                                "f32 vector peak equals the f32 matrix peak figure of the guide (157.3 TFLOP/s)"}
     if with_cpu:
         # CPU baselines on a bounded sample: the oracle (numpy / C port), and for the picker also the reference's own
         # arithmetic for the Gaussians - scipy.ndimage.gaussian_filter, single-threaded - in front of the oracle's tail.
@@ -616,8 +624,14 @@ def main():
             from cet_pick_amd.build import source_sha16
             tj = json.load(open(tpath))
             if tj.get("source_sha16") == source_sha16(tj.get("source_prefixes")):
-                out["roofline"]["traffic"] = tj["hbm_bytes_per_step"] / (n_launch // 3)
-                out["roofline"]["traffic_note"] = ("bytes per conv call (%d per step), profiles/%s"
+                # bytes PER STEP (a per-call average over 61 heterogeneous launches is a unit nobody can use);
+                # SURVEY.md 8(d) estimates ~1.6 GB per step (EMA + SGD + weights + activations)
+                out["roofline"]["traffic"] = tj["hbm_bytes_per_step"]
+                out["roofline"]["traffic_per_conv_call"] = tj["hbm_bytes_per_step"] / (n_launch // 3)
+                out["roofline"]["traffic_ratio_to_estimate"] = tj["hbm_bytes_per_step"] / 1.6e9
+                out["roofline"]["traffic_note"] = ("HBM bytes per training step of the conv family (%d calls), PMC FETCH_SIZE (x2, gfx950) + "
+                                                   "WRITE_SIZE, profiles/%s; ratio to SURVEY 8(d)'s 1.6 GB estimate beside it: the step moves "
+                                                   "~1.4 TB/s, far from the HBM roof - MFMA stays the binding bound"
                                                    % (n_launch // 3, os.path.basename(tpath)))
             else:
                 out["roofline"]["traffic_note"] = "stale: profiles/%s was measured on other kernel sources" % os.path.basename(tpath)

@@ -22,7 +22,22 @@ def timeit(fn, n=5, warm=2):
     return (time.perf_counter() - t0) / n
 
 
-def run(small=False, only_semi=False):
+def latest_traffic(suffix, per_call_key="hbm_bytes_per_step"):
+    """(HBM bytes per step / call, note) from the newest profiles/rNN_<suffix> whose kernel-source hash still matches the tree
+    (tools/pmc_run.sh + tools/pmc_summary.py: separate --pmc passes, FETCH_SIZE doubled on gfx950), else (None, why)."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_" + suffix)))
+    if not c:
+        return None, "no profiles/rNN_%s" % suffix
+    from cet_pick_amd.build import source_sha16
+    d = json.load(open(c[-1]))
+    if d.get("source_sha16") != source_sha16(d.get("source_prefixes")):
+        return None, "stale: profiles/%s was measured on other kernel sources" % os.path.basename(c[-1])
+    return d.get(per_call_key), "PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE over every launch of one call, profiles/%s" % os.path.basename(c[-1])
+
+
+def run(small=False, only_semi=False, only_unet=False):
     from cet_pick_amd.utils import loader
     from cet_pick_amd.models.model import create_model
     from cet_pick_amd.models.loss import UnbiasedConLoss
@@ -33,6 +48,14 @@ def run(small=False, only_semi=False):
     g = torch.Generator().manual_seed(0)
     if only_semi:                     # (rocprofv3 of the C5 step alone: profiles/rNN_c5_kernel_stats.csv)
         return _semi_step(out, small, heads, g, create_model, seeded_state_dict)
+    if only_unet:                     # (PMC traffic pass, profiles/rNN_unet_traffic.json: exactly five forwards, nothing else)
+        net = create_model("unet_4", heads, 32)
+        net.load_state_dict(seeded_state_dict(net, seed=321))
+        net = net.cuda().eval()
+        vol = torch.randn((1, 16, 128, 128) if small else (1, 128, 512, 512), device="cuda")
+        with torch.no_grad():
+            t = timeit(lambda: net(vol), n=4, warm=1)
+        return {"unet4_forward": {"input": list(vol.shape), "ms": t * 1e3, "forwards": 5}}
     # a12: load_rec (xzy order, compress) + preprocess of a 256 x 512 x 512 tomogram already on the host
     shape = (64, 128, 128) if small else (512, 256, 512)          # file order (x, z, y): 256 slices of 512 x 512
     rec = np.random.default_rng(0).standard_normal(shape).astype(np.float32)
@@ -67,6 +90,10 @@ def run(small=False, only_semi=False):
                                          "achieved": cflops / cms / 1e9, "peak": 2500.0 / 6, "unit": "TFLOP/s",
                                          "frac": cflops / cms / 1e9 / (2500.0 / 6), "traffic": None,
                                          "whole_forward_tflops": cflops / t / 1e12}}
+    if not small:
+        tr, note = latest_traffic("unet_traffic.json")
+        out["unet4_forward"]["roofline"]["traffic"] = tr
+        out["unet4_forward"]["roofline"]["traffic_note"] = note + " (bytes per forward of the 128 x 512 x 512 tomogram)"
     # a23: debiased contrastive loss, N = 12,288 per view, dim 32, forward + backward
     n, dim = (2048, 32) if small else (12288, 32)
     g = torch.Generator().manual_seed(0)
@@ -122,8 +149,9 @@ def _semi_step(out, small, heads, g, create_model, seeded_state_dict):
                               "roofline": {"bound": "mfma", "kernel": "ucl_fwd_kernel + ucl_bwd_kernel<32, 3> (round 6: the backward forms both terms of a "
                                                                       "similarity tile from ONE product with one exponential, tiles double-buffered)",
                                            "achieved": ucl_flop / t / 1e12, "peak": 2500.0 / 6, "unit": "TFLOP/s",
-                                           "frac": ucl_flop / t / 1e12 / (2500.0 / 6), "traffic": None,
+                                           "frac": ucl_flop / t / 1e12 / (2500.0 / 6), "traffic": (None if small else latest_traffic("c5_traffic.json")[0]),
                                            "frac_f32_mfma_peak": ucl_flop / t / 1e12 / 157.3,
+                                           "traffic_note": latest_traffic("c5_traffic.json")[1] + " (bytes per training step)",
                                            "note": "whole step time against the loss kernels' FLOPs (they are ~95 % of it); with the "
                                                    "products on the bf16 pipe the kernels are bound by their vector work (one exp and "
                                                    "~10 instructions per similarity), not by the matrix cores; not launch-bound: a "
@@ -132,4 +160,4 @@ def _semi_step(out, small, heads, g, create_model, seeded_state_dict):
 
 
 if __name__ == "__main__":
-    print(json.dumps(run(small="--small" in sys.argv, only_semi="--only-semi" in sys.argv)))
+    print(json.dumps(run(small="--small" in sys.argv, only_semi="--only-semi" in sys.argv, only_unet="--only-unet" in sys.argv)))

@@ -85,6 +85,8 @@ def run(small=False, with_cpu=True, only_step=False, steps=20):
         os.chdir(tmp)
         opt, model, optimizer, trainer, dataset = _build(batch, shape, tmp)
         dev = opt.device
+        if "--no-graph" in sys.argv and getattr(trainer, "engine", None) is not None:      # (PMC passes: every launch a plain dispatch)
+            trainer.engine.use_graph = False
         # ---- the step alone, on ONE resident batch (inputs in HBM before the timed region) ----
         dataset.set_epoch(0)
         first = next(iter(dataset))
@@ -137,6 +139,11 @@ def run(small=False, with_cpu=True, only_step=False, steps=20):
                                        for t, v in sorted(by.items())},
                            "measured": "per conv call of one eager step: 8 back-to-back launches between two HIP events on the "
                                        "launch stream; compare profiles/r06_simsiam2d_kernel_stats.csv"}
+        if not small:
+            from tools.bench_detector import latest_traffic
+            tr, note = latest_traffic("simsiam2d_traffic.json")
+            rec["roofline"]["traffic"] = tr
+            rec["roofline"]["traffic_note"] = note + " (bytes per training step, conv family)"
         if "--calls" in sys.argv:                        # every conv call of the step in issue order: (mode, GFLOP, us, TFLOP/s)
             rec["calls"] = [(t, round(f / 1e9, 3), round(a.elapsed_time(b) / r * 1e3, 1), round(f / (a.elapsed_time(b) / r) / 1e9, 1))
                             for t, f, a, b, r in prof]

@@ -4,7 +4,7 @@
 # leaves raw rocprofv3 output under gpurun_out/<tag>_final/; tools/refresh_profiles_local.sh turns it into profiles/<tag>_*.
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
-T=${1:-r05}
+T=${1:-r06}
 O=$T"_final"
 mkdir -p $R/gpurun_out/$O
 cd $R
@@ -18,4 +18,9 @@ echo "traces done"
 # 2. PMC passes (counters only, one pass per group)
 tools/pmc_run.sh $O/pmc_infer FETCH_SIZE:WRITE_SIZE $R/tools/prof_infer.py both 3
 tools/pmc_run.sh $O/pmc_train FETCH_SIZE:WRITE_SIZE:SQ_VALU_MFMA_BUSY_CYCLES,GRBM_GUI_ACTIVE $R/bench.py --no-graph --no-conv-profile --no-secondary --no-cpu-baseline --no-entry-point --steps 6 --warmup 3
+# round 6: traffic of the SimSiam-2D step, the unet_4 forward and the C5 step from their own PMC passes
+tools/gprof.sh $O/simsiam2d $R/tools/bench_simsiam2d.py --only-step > gpurun_out/$O/simsiam2d.txt 2>&1
+tools/pmc_run.sh $O/pmc_simsiam2d FETCH_SIZE:WRITE_SIZE $R/tools/bench_simsiam2d.py --only-step --no-graph
+tools/pmc_run.sh $O/pmc_unet FETCH_SIZE:WRITE_SIZE $R/tools/bench_detector.py --only-unet
+PMC_TIMEOUT=400 tools/pmc_run.sh $O/pmc_c5 FETCH_SIZE:WRITE_SIZE $R/tools/bench_detector.py --only-semi
 echo "pmc done"

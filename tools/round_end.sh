@@ -3,7 +3,7 @@
 #   tools/round_end.sh <tag>     -> raw output under gpurun_out/<tag>_final/, summaries by tools/refresh_profiles_local.sh <tag>
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
-T=${1:-r05}
+T=${1:-r06}
 O=$R/gpurun_out/${T}_final
 cd $R
 tools/refresh_profiles.sh $T
