@@ -97,8 +97,9 @@ class MoCo(nn.Module):
     # (forward_sync_gen) stop in front of each of their five statistics exchanges, and the sums of encoder_q's and encoder_k's layer i
     # go out as ONE collective (hipops.dist_all_reduce_pair: RCCL groups the two all-reduces into one launch, one xGMI latency) - 10
     # SyncBN collectives per step (5 forward pairs + 5 backward) instead of 15 (round 6).  Replicas stay identical: every
-    # rank issues the same collectives in the same order.  pair_sync_bn = False keeps one collective per layer and branch.
-    pair_sync_bn = True
+    # rank issues the same collectives in the same order.  pair_sync_bn = False (CETPICK_PAIR_SYNCBN=0) keeps one collective per layer and branch.
+    import os as _os
+    pair_sync_bn = _os.environ.get("CETPICK_PAIR_SYNCBN", "1") != "0"
     sync_collectives = 0           # collectives the last forward issued for SyncBN statistics (tests / diagnostics)
 
     def _paired_ok(self):
