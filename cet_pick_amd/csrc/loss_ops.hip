@@ -446,6 +446,21 @@ __global__ __launch_bounds__(256, (DIM == 64 || TRANS >= 2) ? 2 : 3) void ucl_bw
     // 24,576 rows against dense float64 rows; a row of dF is ~1/400 of its terms' magnitudes, so that was 4e-4 of the row).
     // (64-wide features - two accumulators per wave - keep the single level: the second pair of totals would cost the kernel a
     // resident wave per SIMD; the detector's projection head is 32 wide)
+    // TRANS == 3 (round 6): the coefficient of a tile element is BILINEAR in a row vector and a column vector,
+    //   cf(row, col) = g_all'[row] 1 + g_pos'[row] [pos col] + g_other'[row] [other col] + 1 g_all'[col] + [pos row] g_pos'[col] + [other row] g_other'[col]
+    // (' = scaled by the row's / column's exp(M - max)), i.e. a rank-6 product U V^T: three v_mfma_f32_32x32x2_f32 per tile on the
+    // idle matrix pipe instead of ~12 vector operations per element (the kernel was bound by vector issue: ~350 VALU instructions per
+    // tile and wave against 24 MFMAs).  A operand: this wave's row l32, k = h of each of the three k-steps - constant over the walk.
+    float ua[3] = {0.f, 0.f, 0.f};
+    if (TRANS == 3) {
+        const int row = row0 + wm * 32 + l32;
+        const bool ok = row < n2;
+        const float sg = ok ? __builtin_amdgcn_exp2f(gmax - rowmax[row] * LOG2E) : 0.f;
+        const uint8_t rc = ok ? cls[row] : 0;
+        ua[0] = ok ? (h ? g_pos[row] : g_all[row]) * sg : 0.f;
+        ua[1] = h ? (ok ? 1.f : 0.f) : (ok ? g_other[row] * sg : 0.f);
+        ua[2] = h ? (float)((rc >> 1) & 1) : (float)(rc & 1);
+    }
     constexpr bool TWO_LEVEL = NT == 1;
     f32x16 out[NT], tot[TWO_LEVEL ? NT : 1];
 #pragma unroll
@@ -538,15 +553,21 @@ __global__ __launch_bounds__(256, (DIM == 64 || TRANS >= 2) ? 2 : 3) void ucl_bw
             }
             float k0 = 0.f, k1 = 0.f, k2 = 0.f, kmx = 0.f;             // TRANS == 2: the column's g_all, g_pos, g_other and maximum
             if (TRANS >= 2) { const float* cm = cmeta[lc]; kmx = cm[0]; k0 = cm[1]; k1 = cm[2]; k2 = cm[3]; }
+            f32x16 cf3;
+            if (TRANS == 3) {                             // the tile's coefficients: U V^T, B operand = this lane's column, k = h
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cf3[r] = 0.f;
+                cf3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[0], h ? c0 : 1.f, cf3, 0, 0, 0);
+                cf3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[1], h ? k0 : c1, cf3, 0, 0, 0);
+                cf3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[2], h ? k2 : k1, cf3, 0, 0, 0);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int tr = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float s = acc[r];
                 float w;
                 if (TRANS == 3) {
-                    const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
-                    const float cf = fmaf((float)((rcl[r] >> 1) & 1), k2, fmaf((float)(rcl[r] & 1), k1, fmaf(c1, mq.y, fmaf(c0, mq.x, ra[r] + k0))));
-                    w = __builtin_amdgcn_exp2f(s - gmax) * cf;
+                    w = __builtin_amdgcn_exp2f(s - gmax) * cf3[r];
                 } else if (TRANS == 2) {
                     const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
                     const float wr = __builtin_amdgcn_exp2f(s - rm[r]) * fmaf(c1, mq.y, fmaf(c0, mq.x, ra[r]));
