@@ -61,38 +61,49 @@ struct P2DParams {
     int N, H;
     long total;               // N H W output voxels
     unsigned a_bytes;
+    int W, nv;                // generic instance (W_ = 0): plane width and patch voxels (PR (W + 2)), from the host
 };
 
 // W_: plane width (the patch pitch W_ + 2 is a compile-time constant: tap offsets are ds_read immediates); HMIN: smallest plane
 // height this instance is launched on (bounds the zero rows a tile can contain); CT: channels, in = out.
+// W_ = 0 (round 6, the generic instance): width, height and patch extent are run-time values - a tap offset costs an address add instead
+// of being an immediate, LDS is sized at launch - so that ANY --bbox takes the kernel (the default is 32: 32 / 16 / 8 planes), not only 36.
 template <int W_, int HMIN, int CT>
 struct P2DCfg {
+    static constexpr bool GEN = W_ == 0;
+    static constexpr int WD = GEN ? 1 : W_, HD = GEN ? 1 : HMIN;       // (divisors of the compile-time geometry)
     static constexpr int PX = W_ + 2;
-    static constexpr int R = (P_TM - 1 + W_ - 1) / W_ + 1;              // image rows 128 consecutive voxels can touch
-    static constexpr int NB = (R - 1 + HMIN - 1) / HMIN;               // plane boundaries among them
+    static constexpr int R = (P_TM - 1 + WD - 1) / WD + 1;              // image rows 128 consecutive voxels can touch
+    static constexpr int NB = (R - 1 + HD - 1) / HD;                   // plane boundaries among them
     static constexpr int PR = R + NB + 2;                               // patch rows: + separators + halo
-    static constexpr int NV = PR * PX;
+    static constexpr int NV = GEN ? 16 : PR * PX;
     static constexpr int ARR = NV * 16;                                 // one (chunk, plane, k-half) array
     static constexpr int PL = 2 * ARR, KSB = 3 * PL;                    // plane, chunk
     static constexpr int LDS = 2 * KSB;                                 // two resident chunks
-    static constexpr int UNITS = (2 * NV + 255) / 256;                  // staging units (voxel, k-half) per thread and chunk
+    static constexpr int UNITS = GEN ? 4 : (2 * NV + 255) / 256;        // staging units (voxel, k-half) per thread and chunk (generic: <= 512 patch voxels)
     static constexpr int KS = CT / 16, NSTEP = KS * 9;
     static_assert(KS % 2 == 0 && 18 % P_RB == 0, "chunk pairs keep ring and LDS slots static");
     static_assert(LDS <= 80 * 1024, "two workgroups per CU");
 };
+extern __shared__ __attribute__((aligned(16))) unsigned char p2d_dyn_lds[];
 
 template <int W_, int HMIN, int CT>
 __global__ __launch_bounds__(256, 2) void p2d_kernel(P2DParams p) {
     typedef P2DCfg<W_, HMIN, CT> G;
-    __shared__ __attribute__((aligned(16))) unsigned char patch[G::LDS];
+    constexpr bool GEN = G::GEN;
+    __shared__ __attribute__((aligned(16))) unsigned char patch_static[GEN ? 16 : G::LDS];
+    unsigned char* const patch = GEN ? p2d_dyn_lds : patch_static;
+    // geometry: compile-time constants, or (generic instance) the launch's values
+    const int Wd = GEN ? p.W : W_, PXd = Wd + 2, NVd = GEN ? p.nv : G::NV;
+    const int ARRd = NVd * 16, PLd = 2 * ARRd, KSBd = 3 * PLd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l32 = lane & 31;
     const int mh = wave >> 1, cw = wave & 1;             // wave tile: voxel half mh of the 128 x column half cw
     const int cb = blockIdx.y;                           // 64-channel block of the output channels
     const long o0 = (long)blockIdx.x * P_TM;             // first output voxel (flat)
-    const int HW = p.H * W_;
+    const int HW = p.H * Wd;
     // padded row of the first voxel; the patch starts one row above it
-    const int n0 = (int)(o0 / HW), y0 = (int)(o0 - (long)n0 * HW) / W_;
+    const int n0 = (int)(o0 / HW), y0 = (int)(o0 - (long)n0 * HW) / Wd;
     const int pstart = n0 * (p.H + 1) + y0;              // = P(o0) - 1
 
     const __amdgpu_buffer_rsrc_t wrs = p_rsrc(p.wimg, (unsigned)((CT / 64) * G::NSTEP * PW_STEP));
@@ -128,12 +139,12 @@ __global__ __launch_bounds__(256, 2) void p2d_kernel(P2DParams p) {
 #pragma unroll
     for (int u = 0; u < G::UNITS; ++u) {
         const int q = tid + 256 * u, vox = q >> 1, hh = q & 1;
-        const int pr = vox / G::PX, pc = vox - pr * G::PX;
+        const int pr = vox / PXd, pc = vox - pr * PXd;
         const int P = pstart + pr;                       // padded row: n (H + 1) + 1 + y; 0 (mod H + 1) = separator
         const int n = P / (p.H + 1), y = P - n * (p.H + 1) - 1, x = pc - 1;
-        const bool ok = vox < G::NV && y >= 0 && n < p.N && (unsigned)x < (unsigned)W_;
-        st_off[u] = ok ? 4u * (unsigned)((((long)n * p.H + y) * W_ + x) * CT + hh * 8) : 0x80000000u;
-        st_lds[u] = vox < G::NV ? hh * G::ARR + vox * 16 : -1;
+        const bool ok = vox < NVd && y >= 0 && n < p.N && (unsigned)x < (unsigned)Wd;
+        st_off[u] = ok ? 4u * (unsigned)((((long)n * p.H + y) * Wd + x) * CT + hh * 8) : 0x80000000u;
+        st_lds[u] = vox < NVd ? hh * ARRd + vox * 16 : -1;
     }
     u32x4 ld[G::UNITS][2];
     auto stage_load = [&](int c) {
@@ -152,9 +163,9 @@ __global__ __launch_bounds__(256, 2) void p2d_kernel(P2DParams p) {
             for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(ld[u][0][e]); v[4 + e] = __uint_as_float(ld[u][1][e]); }
             u32x4 o[3];
             p_cut8(v, o);
-            unsigned char* dst = patch + slot * G::KSB + st_lds[u];
+            unsigned char* dst = patch + slot * KSBd + st_lds[u];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * G::PL) = o[pl];
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * PLd) = o[pl];
         }
     };
     stage_load(0);
@@ -165,9 +176,9 @@ __global__ __launch_bounds__(256, 2) void p2d_kernel(P2DParams p) {
     for (int i = 0; i < 2; ++i) {
         long o = o0 + 64 * mh + 32 * i + l32;
         if (o >= p.total) o = p.total - 1;               // (rows behind the batch: computed on a valid voxel, never stored)
-        const int n = (int)(o / HW), rem = (int)(o - (long)n * HW), y = rem / W_, x = rem - y * W_;
+        const int n = (int)(o / HW), rem = (int)(o - (long)n * HW), y = rem / Wd, x = rem - y * Wd;
         const int prow = n * (p.H + 1) + 1 + y - pstart; // >= 1
-        vbase[i] = ((prow - 1) * G::PX + x) * 16 + h * G::ARR;
+        vbase[i] = ((prow - 1) * PXd + x) * 16 + h * ARRd;
     }
 
     f32x16 acc[2];
@@ -182,12 +193,12 @@ __global__ __launch_bounds__(256, 2) void p2d_kernel(P2DParams p) {
     bf16x8 af[2][2][3];
     auto frags = [&](int slot, int tap, auto SETc) {
         constexpr int SET = decltype(SETc)::value;
-        const int imm = ((tap / 3) * G::PX + tap % 3) * 16 + slot * G::KSB;
+        const int imm = ((tap / 3) * PXd + tap % 3) * 16 + slot * KSBd;        // (an immediate in the compile-time instances)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                af[SET][i][pl] = *reinterpret_cast<const bf16x8*>(patch + vbase[i] + imm + pl * G::PL);
+                af[SET][i][pl] = *reinterpret_cast<const bf16x8*>(patch + vbase[i] + imm + pl * PLd);
     };
     auto frags_at = [&](int s, int slot, int tap) {      // s: static position inside the chunk pair (its parity picks the set)
         if (s & 1) frags(slot, tap, std::integral_constant<int, 1>{});
@@ -384,22 +395,33 @@ constexpr int PW_ROW = 64;                  // bytes of a (voxel, 32 channels) b
 typedef __bf16 bf16x4p __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4p lds_bf16x4p;
 
+// W_ = 0: the generic instance (any H, W whose window has <= 192 rows: run-time geometry, divisions through a float reciprocal)
 template <int W_>
 struct P2WCfg {
-    static constexpr int H_ = W_;                                       // square planes
+    static constexpr bool GEN = W_ == 0;
+    static constexpr int WD = GEN ? 1 : W_;
+    static constexpr int H_ = W_;                                       // square planes (compile-time instances)
     static constexpr int PW = W_ + 1;                                   // padded-flat pitch
-    static constexpr int R = (PW_KB - 1 + W_ - 1) / W_ + 1;             // image rows a K-block can touch
-    static constexpr int NB = (R - 1 + H_ - 1) / H_;                    // plane boundaries among them
+    static constexpr int R = (PW_KB - 1 + WD - 1) / WD + 1;             // image rows a K-block can touch
+    static constexpr int NB = (R - 1 + WD - 1) / WD;                    // plane boundaries among them
     static constexpr int SPAN = PW_KB + (R - 1) + NB * PW;              // padded-flat positions from its first to its last voxel
-    static constexpr int XR = SPAN + 2 * (PW + 1);                      // + the taps' reach on both sides
+    static constexpr int XR = GEN ? 8 : SPAN + 2 * (PW + 1);            // + the taps' reach on both sides
     static constexpr int XPL = XR * PW_ROW;                             // one bf16 plane of the X window (32 channels)
     static constexpr int YH = PW_KB * PW_ROW, YPL = 2 * YH;             // dY: channel half, plane
     static constexpr int YB = 3 * XPL;                                  // byte offset of dY
     static constexpr int LDS = 3 * XPL + 3 * YPL;
-    static constexpr int UX = (4 * XR + 255) / 256;                     // X staging units (row, 8 channels) per thread
+    static constexpr int UX = GEN ? 3 : (4 * XR + 255) / 256;           // X staging units (row, 8 channels) per thread
     static_assert(LDS <= 80 * 1024, "two workgroups per CU");
     static_assert(LDS >= 2 * 12288, "the k-half exchange (two channel halves x three taps) reuses the staging memory");
 };
+// n / d and n % d for 0 <= n < 2^24 through the reciprocal (the generic instances' plane decode: a handful per K-block, where an
+// emulated 32-bit division is ~40 instructions)
+__device__ __forceinline__ void p_divmod(int n, int d, float inv, int& q, int& r) {
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { q -= 1; r += d; }
+    else if (r >= d) { q += 1; r -= d; }
+}
 
 struct P2WParams {
     const float* x;           // (N, H, W, CT)
@@ -410,13 +432,23 @@ struct P2WParams {
     int nkb;                  // K-blocks in all
     int splits;
     unsigned bytes;
+    int H, W, xr;             // generic instance: plane extents and window rows
 };
 
 template <int W_, int CT>
 __global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
     typedef P2WCfg<W_> G;
-    constexpr int H_ = G::H_, PW = G::PW, HW = H_ * W_;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[G::LDS];
+    constexpr bool GEN = G::GEN;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_static[GEN ? 16 : G::LDS];
+    unsigned char* const lds = GEN ? p2d_dyn_lds : lds_static;
+    const int Wd = GEN ? p.W : W_, H_ = GEN ? p.H : G::H_, PW = Wd + 1, HW = H_ * Wd, XRd = GEN ? p.xr : G::XR;
+    const int XPLd = XRd * PW_ROW, YBd = 3 * XPLd;
+    const float inv_hw = 1.0f / (float)HW, inv_w = 1.0f / (float)Wd, inv_pw = 1.0f / (float)PW, inv_h1 = 1.0f / (float)(H_ + 1);
+    // (o / HW, o % HW / W ...: the compile-time instances divide by constants, the generic one through reciprocals)
+    auto voxel_of = [&](long o, int& n, int& y, int& x) {
+        if (GEN) { int rr; p_divmod((int)o, HW, inv_hw, n, rr); p_divmod(rr, Wd, inv_w, y, x); }
+        else { n = (int)(o / HW); const int rr = (int)(o - (long)n * HW); y = rr / Wd; x = rr - y * Wd; }
+    };
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l32 = lane & 31, i16 = lane & 15, g16 = (lane >> 4) & 1;
@@ -444,7 +476,8 @@ __global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
     u32x4 ldy[2][2], ldx[G::UX][2];
     auto window_start = [&](int kb) {                    // padded-flat position of window row 0 of K-block kb (may be < 0)
         const long o0 = (long)kb * PW_KB;
-        const int n0 = (int)(o0 / HW), r0 = (int)(o0 - (long)n0 * HW), y0 = r0 / W_, x0 = r0 - y0 * W_;
+        int n0, y0, x0;
+        voxel_of(o0, n0, y0, x0);
         return (n0 * (H_ + 1) + 1 + y0) * PW + x0 + 1 - (PW + 1);
     };
     auto fetch = [&](int kb) {
@@ -462,10 +495,11 @@ __global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
         for (int u = 0; u < G::UX; ++u) {
             const int q = tid + 256 * u, r = q >> 2, cg = q & 3;
             const int f = fstart + r;
-            const int P = f / PW, xc = f - P * PW;
-            const int n = P / (H_ + 1), yy = P - n * (H_ + 1) - 1;
-            const bool ok = kb < kb1 && r < G::XR && f >= 0 && xc >= 1 && yy >= 0 && n < p.N;
-            const unsigned off = ok ? 4u * (unsigned)((((long)n * H_ + yy) * W_ + (xc - 1)) * CT + ci0 + 8 * cg) : 0x80000000u;
+            int P, xc, n, yy;
+            if (GEN) { p_divmod(f < 0 ? 0 : f, PW, inv_pw, P, xc); p_divmod(P, H_ + 1, inv_h1, n, yy); yy -= 1; }
+            else { P = f / PW; xc = f - P * PW; n = P / (H_ + 1); yy = P - n * (H_ + 1) - 1; }
+            const bool ok = kb < kb1 && r < XRd && f >= 0 && xc >= 1 && yy >= 0 && n < p.N;
+            const unsigned off = ok ? 4u * (unsigned)((((long)n * H_ + yy) * Wd + (xc - 1)) * CT + ci0 + 8 * cg) : 0x80000000u;
             ldx[u][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0);
             ldx[u][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 16, 0);
         }
@@ -479,14 +513,14 @@ __global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
             for (int e = 0; e < 4; ++e) { vv[e] = __uint_as_float(ldy[u][0][e]); vv[4 + e] = __uint_as_float(ldy[u][1][e]); }
             u32x4 o3[3];
             p_cut8(vv, o3);
-            unsigned char* dst = lds + G::YB + (cg >> 2) * G::YH + v * PW_ROW + (cg & 3) * 16;
+            unsigned char* dst = lds + YBd + (cg >> 2) * G::YH + v * PW_ROW + (cg & 3) * 16;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * G::YPL) = o3[pl];
         }
 #pragma unroll
         for (int u = 0; u < G::UX; ++u) {
             const int q = tid + 256 * u, r = q >> 2, cg = q & 3;
-            if (r < G::XR) {
+            if (r < XRd) {
                 float vv[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { vv[e] = __uint_as_float(ldx[u][0][e]); vv[4 + e] = __uint_as_float(ldx[u][1][e]); }
@@ -494,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
                 p_cut8(vv, o3);
                 unsigned char* dst = lds + r * PW_ROW + cg * 16;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * G::XPL) = o3[pl];
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * XPLd) = o3[pl];
             }
         }
     };
@@ -512,7 +546,8 @@ __global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
             for (int hi = 0; hi < 2; ++hi) {
                 long o = o0 + 16 * (2 * kh + lk) + 8 * h + q4 + 4 * hi;
                 if (o >= p.total) o = p.total - 1;       // (its dY row is zero: any staged row will do)
-                const int n = (int)(o / HW), rr = (int)(o - (long)n * HW), y = rr / W_, x = rr - y * W_;
+                int n, y, x;
+                voxel_of(o, n, y, x);
                 // (biased by the taps' reach: the offset of tap (ty, tx) is then (ty PW + tx) rows >= 0 - a ds_read immediate)
                 xrow[lk][hi] = ((n * (H_ + 1) + 1 + y) * PW + x + 1 - fstart - (PW + 1)) * PW_ROW + coloff;
             }
@@ -522,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
 #pragma unroll
         for (int lk = 0; lk < 2; ++lk) {
             bf16x8 bfg[3];
-            const unsigned char* yb = lds + G::YB + wn * G::YH + (16 * (2 * kh + lk) + 8 * h + q4) * PW_ROW + coloff;
+            const unsigned char* yb = lds + YBd + wn * G::YH + (16 * (2 * kh + lk) + 8 * h + q4) * PW_ROW + coloff;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
                 const bf16x4p lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4p*)(yb + pl * G::YPL));
@@ -534,8 +569,8 @@ __global__ __launch_bounds__(256, 2) void p2d_wgrad_kernel(P2WParams p) {
                 const int sh = ((t / 3) * PW + t % 3) * PW_ROW;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    const bf16x4p lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4p*)(lds + pl * G::XPL + xrow[lk][0] + sh));
-                    const bf16x4p hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4p*)(lds + pl * G::XPL + xrow[lk][1] + sh));
+                    const bf16x4p lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4p*)(lds + pl * XPLd + xrow[lk][0] + sh));
+                    const bf16x4p hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4p*)(lds + pl * XPLd + xrow[lk][1] + sh));
                     af[set][pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
             };
@@ -606,12 +641,22 @@ __global__ __launch_bounds__(256) void p2d_wgrad_reduce_kernel(const float* slab
     }
 }
 
+// window rows of the generic instance for (H, W) planes: 0 = does not fit (three staging units per thread, reciprocal divisions < 2^24)
+int p2dg_wgrad_rows(int N, int H, int W) {
+    if (N < 1 || H < 1 || W < 1) return 0;
+    const int PW = W + 1, R = (PW_KB - 1 + W - 1) / W + 1, NB = (R - 1 + H - 1) / H;
+    const int xr = PW_KB + (R - 1) + NB * PW + 2 * (PW + 1);
+    if (xr > 192 || (long)(N + 1) * (H + 1) * PW >= (1l << 24) || (long)N * H * W >= (1l << 24)) return 0;
+    return xr;
+}
 template <int W_, int CT>
-int p2d_wgrad_launch(const float* x, const float* dy, float* dw, float* slabs, int N, int splits, hipStream_t s) {
+int p2d_wgrad_launch(const float* x, const float* dy, float* dw, float* slabs, int N, int splits, hipStream_t s, int H = W_, int W = W_) {
     P2WParams p = {};
-    p.x = x; p.dy = dy; p.slabs = slabs; p.N = N; p.total = (long)N * W_ * W_;
+    p.x = x; p.dy = dy; p.slabs = slabs; p.N = N; p.total = (long)N * H * W;
     p.nkb = (int)((p.total + PW_KB - 1) / PW_KB); p.splits = splits; p.bytes = (unsigned)(4l * p.total * CT);
-    hipLaunchKernelGGL((p2d_wgrad_kernel<W_, CT>), dim3((unsigned)((CT / 32) * (CT / 64) * splits)), dim3(256), 0, s, p);
+    p.H = H; p.W = W; p.xr = W_ ? 0 : p2dg_wgrad_rows(N, H, W);
+    const size_t dyn = W_ ? 0 : (size_t)3 * p.xr * PW_ROW + 3 * 2 * PW_KB * PW_ROW;
+    hipLaunchKernelGGL((p2d_wgrad_kernel<W_, CT>), dim3((unsigned)((CT / 32) * (CT / 64) * splits)), dim3(256), dyn, s, p);
     MI_RETURN_IF_LAUNCH_FAILED();
     const long n4 = 9l * CT * CT / 4;
     hipLaunchKernelGGL(p2d_wgrad_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, (const float*)slabs, splits, n4, dw);
@@ -627,16 +672,34 @@ int p2d_launch(const P2DParams& p, hipStream_t s) {
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }
+// the generic instance's patch: rows 128 consecutive voxels can touch + separators + halo, W + 2 wide; 0 = does not fit
+int p2dg_patch_voxels(int H, int W) {
+    if (H < 1 || W < 1) return 0;
+    const int R = (P_TM - 1 + W - 1) / W + 1, NB = (R - 1 + H - 1) / H, nv = (R + NB + 2) * (W + 2);
+    return (nv <= 426 && 2 * nv <= 1024) ? nv : 0;       // 2 chunks x 6 arrays x 16 bytes per voxel <= 80 KB; <= 4 staging units per thread
+}
+template <int CT>
+int p2dg_launch(P2DParams p, int W, hipStream_t s) {
+    const long tiles = (p.total + P_TM - 1) / P_TM;
+    if (tiles > 0x7fffffffl) return MI_E_UNSUPPORTED;
+    p.W = W; p.nv = p2dg_patch_voxels(p.H, W);
+    if (!p.nv) return MI_E_UNSUPPORTED;
+    hipLaunchKernelGGL((p2d_kernel<0, 0, CT>), dim3((unsigned)tiles, CT / 64), dim3(256), (size_t)(2 * 6 * 16) * p.nv, s, p);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
 
 }  // namespace
 
 // 1: a shape of p2d_kernel - 3 x 3, stride 1, padding 1, C -> C channels on (N, H, W) planes with (W, C) one of (36, 64), (18, 128),
 // (9, 256) (the SimSiam 2-D encoder at --bbox 36) and H >= W; MI_NO_P2D=1: off (the implicit GEMM takes the layer)
 extern "C" int mi_conv2d_p2d_usable(int N, int H, int W, int C) {
-    if (getenv("MI_NO_P2D") || N < 1 || H < W) return 0;
-    if (!((W == 36 && C == 64) || (W == 18 && C == 128) || (W == 9 && C == 256))) return 0;
+    if (getenv("MI_NO_P2D") || N < 1 || H < 1 || W < 1) return 0;
+    if (C != 64 && C != 128 && C != 256) return 0;
     if (4l * N * H * W * C >= 0x7fff0000l) return 0;
-    return 1;
+    if (H >= W && ((W == 36 && C == 64) || (W == 18 && C == 128) || (W == 9 && C == 256))) return 1;      // compile-time instances
+    // 2: the generic instance (any plane whose patch fits; MI_NO_P2D_GENERIC=1: off)
+    return (!getenv("MI_NO_P2D_GENERIC") && p2dg_patch_voxels(H, W) > 0) ? 2 : 0;
 }
 extern "C" size_t mi_conv2d_p2d_wimg_bytes(int C) { return (size_t)(C / 64) * (C / 16) * 9 * PW_STEP; }
 
@@ -665,11 +728,13 @@ extern "C" int mi_conv2d_p2d_prep(const void* const* w, void* const* img, const 
 extern "C" int mi_conv2d_p2d_f32(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N,
                                  int H, int W, int C, mi_stream_t stream) {
     if (!a || !wimg || !out) return MI_E_ARG;
-    if (!mi_conv2d_p2d_usable(N, H, W, C)) return MI_E_UNSUPPORTED;
+    const int kind = mi_conv2d_p2d_usable(N, H, W, C);
+    if (!kind) return MI_E_UNSUPPORTED;
     P2DParams p = {};
     p.a = a; p.wimg = (const unsigned char*)wimg; p.out = out; p.res = res; p.mask = mask; p.relu = relu;
     p.N = N; p.H = H; p.total = (long)N * H * W; p.a_bytes = (unsigned)(4l * N * H * W * C);
     hipStream_t s = (hipStream_t)stream;
+    if (kind == 2) return C == 64 ? p2dg_launch<64>(p, W, s) : C == 128 ? p2dg_launch<128>(p, W, s) : p2dg_launch<256>(p, W, s);
     if (W == 36) return p2d_launch<36, 36, 64>(p, s);
     if (W == 18) return p2d_launch<18, 18, 128>(p, s);
     return p2d_launch<9, 9, 256>(p, s);
@@ -707,17 +772,26 @@ extern "C" int mi_conv2d_stem3_wgrad_f32(const float* x, const float* dy, float*
 // ws: mi_conv2d_p2d_wgrad_workspace_bytes(N, H, W, C) bytes of split-K slabs (512 chains of K-blocks over the chip).
 static int p2d_wgrad_splits(int C) { return 512 / ((C / 32) * (C / 64)); }
 extern "C" size_t mi_conv2d_p2d_wgrad_workspace_bytes(int N, int H, int W, int C) {
-    if (!mi_conv2d_p2d_usable(N, H, W, C) || H != W) return 0;
+    const int kind = mi_conv2d_p2d_usable(N, H, W, C);
+    if (!kind) return 0;
+    const bool fixed = kind == 1 && H == W;              // (a taller plane of a compile-time width takes the generic instance)
+    if (!fixed && (getenv("MI_NO_P2D_GENERIC") || !p2dg_wgrad_rows(N, H, W))) return 0;
     return sizeof(float) * (size_t)p2d_wgrad_splits(C) * 9 * (size_t)C * C;
 }
 extern "C" int mi_conv2d_p2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int C, void* ws, size_t ws_bytes,
                                        mi_stream_t stream) {
     if (!x || !dy || !dw || !ws) return MI_E_ARG;
-    if (!mi_conv2d_p2d_usable(N, H, W, C) || H != W || getenv("MI_NO_P2D_WGRAD")) return MI_E_UNSUPPORTED;
-    if (ws_bytes < mi_conv2d_p2d_wgrad_workspace_bytes(N, H, W, C)) return MI_E_ARG;
+    const size_t need = getenv("MI_NO_P2D_WGRAD") ? 0 : mi_conv2d_p2d_wgrad_workspace_bytes(N, H, W, C);
+    if (!need) return MI_E_UNSUPPORTED;
+    if (ws_bytes < need) return MI_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int splits = p2d_wgrad_splits(C);
-    if (W == 36) return p2d_wgrad_launch<36, 64>(x, dy, dw, (float*)ws, N, splits, s);
-    if (W == 18) return p2d_wgrad_launch<18, 128>(x, dy, dw, (float*)ws, N, splits, s);
-    return p2d_wgrad_launch<9, 256>(x, dy, dw, (float*)ws, N, splits, s);
+    if (mi_conv2d_p2d_usable(N, H, W, C) == 1 && H == W) {
+        if (W == 36) return p2d_wgrad_launch<36, 64>(x, dy, dw, (float*)ws, N, splits, s);
+        if (W == 18) return p2d_wgrad_launch<18, 128>(x, dy, dw, (float*)ws, N, splits, s);
+        return p2d_wgrad_launch<9, 256>(x, dy, dw, (float*)ws, N, splits, s);
+    }
+    if (C == 64) return p2d_wgrad_launch<0, 64>(x, dy, dw, (float*)ws, N, splits, s, H, W);
+    if (C == 128) return p2d_wgrad_launch<0, 128>(x, dy, dw, (float*)ws, N, splits, s, H, W);
+    return p2d_wgrad_launch<0, 256>(x, dy, dw, (float*)ws, N, splits, s, H, W);
 }

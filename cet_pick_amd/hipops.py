@@ -1026,11 +1026,13 @@ def conv_wgrad_into(x, dy, param, k, stride, pad, dil=None):
         return
     # (under bench.py's roofline pass only the jobs the engine will queue take the job form - run_wgrad_jobs times them group by group -,
     # everything else is timed right here, call by call)
-    if (not nd5 and x.is_cuda and h == wd and p2d_usable(tuple(x.shape), ci, int(co), k3, stride, p3, dil) and _phys_ok(param)
-            and not os.environ.get("MI_NO_P2D_WGRAD")):
+    p2d_ws = (int(lib.mi_conv2d_p2d_wgrad_workspace_bytes(n, h, wd, ci))
+              if (not nd5 and x.is_cuda and p2d_usable(tuple(x.shape), ci, int(co), k3, stride, p3, dil) and _phys_ok(param)
+                  and not os.environ.get("MI_NO_P2D_WGRAD")) else 0)
+    if p2d_ws:
         # the 2-D encoder's 3 x 3 / stride-1 layers: voxel-major operands through the transposing LDS read (conv_p2d.hip p2d_wgrad_kernel)
         _f32c(x, "x"), _f32c(dy, "dy")
-        ws = _ws(lib.mi_conv2d_p2d_wgrad_workspace_bytes(n, h, wd, ci), x.device, "p2d_wgrad")
+        ws = _ws(p2d_ws, x.device, "p2d_wgrad")
         def call():
             return L.check(lib.mi_conv2d_p2d_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(tgt), n, h, wd, ci, L.ptr(ws), ws.numel(), L.stream()),
                            "mi_conv2d_p2d_wgrad_f32")

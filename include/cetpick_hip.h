@@ -309,9 +309,11 @@ int mi_conv3d_direct_f32(const float* a, const void* wimg, float* out, const flo
 
 /* Round 6: patch-resident direct kernel for the 3 x 3 / stride 1 / padding 1 convolutions of the SimSiam 2-D encoder's BasicBlocks
  * (models/networks/simsiam_model_2d.py:473-502; TomoResClassifier2D.forward :776-819) at --bbox 36 (docs/explore.md:67), forward and
- * data gradient, bf16x3 arithmetic: C -> C channels on (N, H, W, C) channels-last planes with (W, C) = (36, 64), (18, 128), (9, 256),
- * H >= W (csrc/conv_p2d.hip: the batch tiled as ONE flat run of voxels, 128 per workgroup, a zero row between planes).
- *   mi_conv2d_p2d_usable: 1 for such a shape (MI_NO_P2D=1: 0);  mi_conv2d_p2d_wimg_bytes(C): bytes of one weight image;
+ * data gradient, bf16x3 arithmetic: C -> C channels (64 / 128 / 256) on (N, H, W, C) channels-last planes (csrc/conv_p2d.hip: the batch
+ * tiled as ONE flat run of voxels, 128 per workgroup, a zero row between planes).
+ *   mi_conv2d_p2d_usable: 1 = a compile-time instance ((W, C) = (36, 64), (18, 128), (9, 256), H >= W: tap offsets are immediates), 2 = the
+ *     generic instance (any H, W up to ~64 whose patch fits: run-time geometry - the default --bbox 32 and every other), 0 = neither
+ *     (MI_NO_P2D=1: always 0; MI_NO_P2D_GENERIC=1: never 2);  mi_conv2d_p2d_wimg_bytes(C): bytes of one weight image;
  *   mi_conv2d_p2d_prep: n images in one launch from (3, 3, C_i, C_i) kernel-layout weights (dgrad[i] != 0: the transposed,
  *     tap-flipped image of the data gradient; the four arrays are HOST arrays);
  *   mi_conv2d_p2d_f32: out = act(conv(a; image) + res) * (mask > 0); res / mask may be NULL (forward: a = x; dgrad: a = dy, relu 0). */
@@ -320,7 +322,7 @@ size_t mi_conv2d_p2d_wimg_bytes(int C);
 int mi_conv2d_p2d_prep(const void* const* w, void* const* img, const int* dgrad, const int* channels, int n, mi_stream_t stream);
 int mi_conv2d_p2d_f32(const float* a, const void* wimg, float* out, const float* res, const float* mask, int relu, int N, int H, int W,
                       int C, mi_stream_t stream);
-/* ... and their weight gradient (H == W): dw (3, 3, C, C) kernel layout = sum over the batch's voxels of x[o + tap] (x) dy[o], written (not
+/* ... and their weight gradient (_workspace_bytes = 0: this shape has none - windows of more than 192 rows, W > ~40): dw (3, 3, C, C) kernel layout = sum over the batch's voxels of x[o + tap] (x) dy[o], written (not
  * accumulated); both operands staged voxel-major and read through the transposing LDS read, X in a padded flat order in which a tap is one
  * row offset; split-K slabs in ws (mi_conv2d_p2d_wgrad_workspace_bytes), added in slab order.  MI_NO_P2D_WGRAD=1: MI_E_UNSUPPORTED. */
 size_t mi_conv2d_p2d_wgrad_workspace_bytes(int N, int H, int W, int C);

@@ -217,7 +217,10 @@ def test_simsiam2d3d_encoder_matches_reference_golden(golden):
     np.testing.assert_allclose(ft["pred"].cpu().numpy(), g["test_pred"], rtol=2e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("case", [(5, 36, 36, 64), (3, 40, 36, 64), (7, 18, 18, 128), (9, 9, 9, 256), (37, 9, 9, 256)])
+@pytest.mark.parametrize("case", [(5, 36, 36, 64), (3, 40, 36, 64), (7, 18, 18, 128), (9, 9, 9, 256), (37, 9, 9, 256),
+                                  # the generic instance (run-time geometry): the default --bbox 32 and others, H != W, a one-row plane
+                                  (4, 32, 32, 64), (6, 16, 16, 128), (10, 8, 8, 256), (3, 24, 20, 64), (2, 48, 48, 64), (2, 64, 64, 128),
+                                  (5, 12, 12, 128), (9, 6, 6, 256), (3, 20, 36, 64), (7, 1, 9, 64)])
 def test_conv2d_direct_plane_kernel_matches_the_implicit_gemm_and_float64(case, monkeypatch):
     """conv_p2d.hip (round 6): the 3 x 3 / stride-1 layers of the 2-D encoder, forward and data gradient (with the residual /
     mask / ReLU epilogues), against float64 and against the implicit GEMM - batch sizes whose flat voxel run ends inside a
@@ -234,6 +237,11 @@ def test_conv2d_direct_plane_kernel_matches_the_implicit_gemm_and_float64(case, 
     param.data = param.data.cuda()
     xc = x.permute(0, 2, 3, 1).contiguous().cuda()
     assert H.p2d_usable(tuple(xc.shape), c, c, (1, 3, 3), 1, (0, 1, 1))
+    from cet_pick_amd import _lib as L
+    kind = int(L.lib().mi_conv2d_p2d_usable(n, h, w, c))
+    assert kind == (1 if (w, c) in ((36, 64), (18, 128), (9, 256)) and h >= w else 2)
+    # the weight gradient has its kernel wherever the X window of a 64-voxel K-block has <= 192 rows (W <= ~40)
+    assert (int(L.lib().mi_conv2d_p2d_wgrad_workspace_bytes(n, h, w, c)) > 0) == (w <= 40), (n, h, w, c)
     res = torch.randn(n, h, w, c, generator=g).cuda()
     y = H.conv_fwd(xc, param, 3, 1, 1)
     y_res = H.conv_fwd(xc, param, 3, 1, 1, res=res, relu=True)

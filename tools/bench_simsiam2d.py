@@ -25,6 +25,10 @@ GFLOP_FWD_PER_VIEW = 1.063          # 36 x 36 view through the
 PEAK_BF16X3 = 2500.0 / 6.0
 
 
+def _bbox():
+    return int(sys.argv[sys.argv.index("--bbox") + 1]) if "--bbox" in sys.argv else 36
+
+
 def _build(batch, shape, tmp):
     from cet_pick_amd import simsiam_main
     from cet_pick_amd.opts import opts
@@ -35,7 +39,7 @@ def _build(batch, shape, tmp):
     mrc.write(os.path.join(tmp, "data", "c2.rec"), vol)
     with open(os.path.join(tmp, "data", "train_images.txt"), "w") as f:
         f.write("image_name\trec_path\nc2\tc2.rec\n")
-    opt = opts().parse(["simsiam3d", "--arch", "simsiam2d_18", "--dataset", "simsiam3d", "--order", "zxy", "--bbox", "36",
+    opt = opts().parse(["simsiam3d", "--arch", "simsiam2d_18", "--dataset", "simsiam3d", "--order", "zxy", "--bbox", str(_bbox()),
                         "--batch_size", str(batch), "--lr", "0.001", "--exp_id", "bench_simsiam2d", "--debug", "0", "--dog", "3,5",
                         "--num_epochs", "1"])
     return simsiam_main.build(opt)
@@ -106,9 +110,9 @@ def run(small=False, with_cpu=True, only_step=False, steps=20):
         torch.cuda.synchronize()
         wall_ms = (time.perf_counter() - t0) / steps * 1e3
         ev_ms = e0.elapsed_time(e1) / steps
-        flop_step = 2 * 3 * GFLOP_FWD_PER_VIEW * 1e9 * batch
-        rec = {"workload": "simsiam_main.py simsiam3d --arch simsiam2d_18 --bbox 36 --batch_size %d --lr 1e-3 (docs/explore.md:67): "
-                           "%d pairs of 36 x 36 views per step, crops of the %s tomogram" % (batch, batch, "x".join(map(str, shape))),
+        flop_step = 2 * 3 * GFLOP_FWD_PER_VIEW * 1e9 * batch * (_bbox() / 36.0) ** 2
+        rec = {"workload": "simsiam_main.py simsiam3d --arch simsiam2d_18 --bbox %d --batch_size %d --lr 1e-3 (docs/explore.md:67): "
+                           "%d pairs of %d x %d views per step, crops of the %s tomogram" % (_bbox(), batch, batch, _bbox(), _bbox(), "x".join(map(str, shape))),
                "ms": wall_ms, "ms_hip_events": ev_ms, "crop_pairs_per_sec": batch / wall_ms * 1e3, "batch": batch,
                "crops_in_dataset": int(dataset.num_samples), "final_loss": float(loss),
                "engine": type(getattr(trainer, "engine", None)).__name__ if getattr(trainer, "engine", None) is not None else None,
