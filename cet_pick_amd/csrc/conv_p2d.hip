@@ -27,7 +27,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PW_BLK = 1024;                // one B fragment plane: 64 lanes x 16 bytes
 constexpr int PW_STEP = 2 * 3 * PW_BLK;     // bytes per k-step: [column half][plane]
-constexpr int P_RB = 6;                     // weight k-steps in flight
+#ifndef P2D_RB
+#define P2D_RB 6
+#endif
+#ifndef P2D_STAGE_TAP
+#define P2D_STAGE_TAP 2
+#endif
+constexpr int P_RB = P2D_RB;                // weight k-steps in flight (tuning builds: -DP2D_RB=3|6|9)
 constexpr int P_TM = 128;                   // output voxels per workgroup (wave tile: 64 voxels x 32 columns)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t p_rsrc(const void* base, unsigned bytes) {
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void p2d_kernel(P2DParams p) {
             wload_at(g + P_RB - 1, s + P_RB - 1);
             // the next chunk of the patch: cut + stored a few taps into this chunk (its loads have been in flight since the
             // previous chunk), the loads of the chunk after it right behind
-            if (tap == 2 && c + 1 < G::KS) {
+            if (tap == P2D_STAGE_TAP && c + 1 < G::KS) {
                 stage_store((cc + 1) & 1);
                 if (c + 2 < G::KS) stage_load(c + 2);
             }
