@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, 3) void ucl_fwd_kernel(const float* feat, cons
 // with c(i; j) = g_all[i] + g_pos[i] [pos j] + g_other[i] [other j] + g_pair[i] [j == pair(i)], zero on the diagonal.
 // The W tile goes through LDS to become the A operand of the second product.
 template <int DIM, int TRANS>
-__global__ __launch_bounds__(256, (DIM == 64 || TRANS >= 2) ? 2 : 3) void ucl_bwd_kernel(const float* feat, const uint8_t* cls, int n2, int n_half,
+__global__ __launch_bounds__(256, (DIM == 64 || TRANS == 2) ? 2 : 3) void ucl_bwd_kernel(const float* feat, const uint8_t* cls, int n2, int n_half,
                                                      float inv_T, const float* rowmax, const float* g_all,
                                                      const float* g_pos, const float* g_other, const float* g_pair,
                                                      float* dfeat, int accumulate, const float* range = nullptr) {
@@ -394,9 +394,11 @@ __global__ __launch_bounds__(256, (DIM == 64 || TRANS >= 2) ? 2 : 3) void ucl_bw
     // memory holds the two column halves' partial dF (2 x UB x LD)
     typedef UclS<DIM> SP;
     constexpr int WP = 36;                                // W tile row pitch (floats): 16-byte rows, bank-disjoint b128 reads
-    constexpr int COLF = (UB * LD + 3) & ~3;              // (the W tiles start 16-byte aligned)
+    // (TRANS >= 2: the epilogue's 2 x UB x LD floats alias the two column-tile buffers instead - 8.4 KB less, which with the register
+    // diet below lets THREE workgroups share a CU: the per-tile chain of a wave is serial and two waves per SIMD did not cover it)
+    constexpr int COLF = TRANS >= 2 ? 0 : ((UB * LD + 3) & ~3);   // (the W tiles start 16-byte aligned)
     __shared__ __attribute__((aligned(16))) float arena[COLF + 4 * 32 * WP];
-    static_assert(2 * UB * LD <= COLF + 4 * 32 * WP, "epilogue does not fit the arena");
+    static_assert(TRANS >= 2 || 2 * UB * LD <= COLF + 4 * 32 * WP, "epilogue does not fit the arena");
     float (*const wt)[32 * WP] = reinterpret_cast<float (*)[32 * WP]>(arena + COLF);
     // (round 6, the merged forms: two column tiles resident - tile t + 1 is cut and stored while tile t's products
     // run, ONE barrier per tile instead of two)
@@ -426,19 +428,24 @@ __global__ __launch_bounds__(256, (DIM == 64 || TRANS >= 2) ? 2 : 3) void ucl_bw
         const bool ok = row < n2;
         const float sg = (TRANS == 3 && ok) ? __builtin_amdgcn_exp2f(gmax - rowmax[row] * LOG2E) : 1.f;
         rmeta[tid][0] = ok ? g_pos[row] * sg : 0.f; rmeta[tid][1] = ok ? g_other[row] * sg : 0.f;
-        rmeta[tid][2] = ok ? g_pair[row] * sg : 0.f; rmeta[tid][3] = 0.f;
+        rmeta[tid][2] = ok ? g_pair[row] * sg : 0.f; rmeta[tid][3] = (TRANS == 3 && ok) ? g_all[row] * sg : 0.f;
     }
-    float rm[16], ra[16];
-    uint8_t rcl[16];
+    __shared__ uint8_t rcls[UB];                          // TRANS == 3: the rows' class bytes (the rare diagonal / pair / ragged tiles read them)
+    if (TRANS == 3 && tid < UB) rcls[tid] = row0 + tid < n2 ? cls[row0 + tid] : 0;
+    // (TRANS == 3 keeps none of these: its row maximum is the constant M, g_all' and the class bytes sit in LDS for the rare tiles that
+    // need them - 40 registers less, the third resident workgroup)
+    float rm[TRANS == 3 ? 1 : 16], ra[TRANS == 3 ? 1 : 16];
+    uint8_t rcl[TRANS == 3 ? 1 : 16];
+    if constexpr (TRANS != 3) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const bool ok = row < n2;
-        rm[r] = (TRANS != 1 && ok) ? rowmax[row] * LOG2E : 0.f;
-        ra[r] = (TRANS != 1 && ok) ? g_all[row] : 0.f;
-        if (TRANS == 3) { ra[r] *= ok ? __builtin_amdgcn_exp2f(gmax - rm[r]) : 0.f; rm[r] = gmax; }
-        rcl[r] = ok ? cls[row] : 0;
-    }
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool ok = row < n2;
+            rm[r] = (TRANS != 1 && ok) ? rowmax[row] * LOG2E : 0.f;
+            ra[r] = (TRANS != 1 && ok) ? g_all[row] : 0.f;
+            rcl[r] = ok ? cls[row] : 0;
+        }
+    } else { rm[0] = gmax; ra[0] = 0.f; rcl[0] = 0; }
     // Two levels of accumulation: `out` collects UCL_FLUSH column tiles on the matrix pipe and is then added into `tot` by the
     // vector unit.  One accumulator for the whole walk (2N / 32 tiles x 12 MFMAs = 73,728 dependent accumulations at 2N =
     // 196,608) showed a bias of -2e-5 of the sum, growing linearly with N - the MFMA aligns its products to the (large)
@@ -566,14 +573,14 @@ __global__ __launch_bounds__(256, (DIM == 64 || TRANS >= 2) ? 2 : 3) void ucl_bw
                 const int tr = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float s = acc[r];
                 float w;
-                if (TRANS == 3) {
+                if constexpr (TRANS == 3) {
                     w = __builtin_amdgcn_exp2f(s - gmax) * cf3[r];
-                } else if (TRANS == 2) {
+                } else if constexpr (TRANS == 2) {
                     const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
                     const float wr = __builtin_amdgcn_exp2f(s - rm[r]) * fmaf(c1, mq.y, fmaf(c0, mq.x, ra[r]));
                     const float wc = __builtin_amdgcn_exp2f(s - kmx) * fmaf((float)((rcl[r] >> 1) & 1), k2, fmaf((float)(rcl[r] & 1), k1, k0));
                     w = wr + wc;
-                } else if (!TRANS) {
+                } else if constexpr (TRANS == 0) {
                     const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
                     w = __builtin_amdgcn_exp2f(s - rm[r]) * fmaf(c1, mq.y, fmaf(c0, mq.x, ra[r]));
                 }
@@ -590,14 +597,20 @@ __global__ __launch_bounds__(256, (DIM == 64 || TRANS >= 2) ? 2 : 3) void ucl_bw
             if (colok && row < n2 && col != row) {
                 const float s = acc[r];
                 const int pr = row < n_half ? row + n_half : row - n_half;
-                if (TRANS >= 2) {                             // (TRANS == 3: rm[r] = cm[0] = M and the coefficients arrive scaled)
+                if constexpr (TRANS == 3) {                   // (row maximum = cm[0] = M, the coefficients arrive scaled; g_all' and the class from LDS)
+                    const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
+                    const float* cm = cmeta[lc];
+                    const uint8_t rc = rcls[wm * 32 + tr];
+                    w = __builtin_amdgcn_exp2f(s - gmax) * (mq.w + ((cc & 1) ? mq.x : 0.f) + ((cc & 2) ? mq.y : 0.f) + (col == pr ? mq.z : 0.f) +
+                                                            cm[1] + ((rc & 1) ? cm[2] : 0.f) + ((rc & 2) ? cm[3] : 0.f) + (col == pr ? cm[4] : 0.f));
+                } else if constexpr (TRANS == 2) {
                     const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
                     const float* cm = cmeta[lc];
                     w = __builtin_amdgcn_exp2f(s - rm[r]) * (ra[r] + ((cc & 1) ? mq.x : 0.f) + ((cc & 2) ? mq.y : 0.f) +
                                              (col == pr ? mq.z : 0.f)) +
                         __builtin_amdgcn_exp2f(s - cm[0]) * (cm[1] + ((rcl[r] & 1) ? cm[2] : 0.f) + ((rcl[r] & 2) ? cm[3] : 0.f) +
                                              (col == pr ? cm[4] : 0.f));
-                } else if (!TRANS) {
+                } else if constexpr (TRANS == 0) {
                     const float4 mq = *reinterpret_cast<const float4*>(rmeta[wm * 32 + tr]);
                     w = __builtin_amdgcn_exp2f(s - rm[r]) * (ra[r] + ((cc & 1) ? mq.x : 0.f) + ((cc & 2) ? mq.y : 0.f) +
                                              (col == pr ? mq.z : 0.f));
@@ -652,8 +665,9 @@ __global__ __launch_bounds__(256, (DIM == 64 || TRANS >= 2) ? 2 : 3) void ucl_bw
             for (int r = 0; r < 16; ++r) out[j][r] += tot[j][r];
     }
     // sum the two column halves and write
-    __syncthreads();                                      // the arena is free
-    float* const outm = arena;                            // [2][UB][LD]
+    __syncthreads();                                      // the arena / the column buffers are free
+    static_assert(TRANS < 2 || 2 * UB * LD * 4 <= 2 * SP::BYTES, "epilogue does not fit the column buffers");
+    float* const outm = TRANS >= 2 ? reinterpret_cast<float*>(&colb_[0][0]) : arena;      // [2][UB][LD]
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
