@@ -97,9 +97,12 @@ class MoCo(nn.Module):
     # (forward_sync_gen) stop in front of each of their five statistics exchanges, and the sums of encoder_q's and encoder_k's layer i
     # go out as ONE collective (hipops.dist_all_reduce_pair: RCCL groups the two all-reduces into one launch, one xGMI latency) - 10
     # SyncBN collectives per step (5 forward pairs + 5 backward) instead of 15 (round 6).  Replicas stay identical: every
-    # rank issues the same collectives in the same order.  pair_sync_bn = False (CETPICK_PAIR_SYNCBN=0) keeps one collective per layer and branch.
+    # rank issues the same collectives in the same order.  OPT-IN (pair_sync_bn = True / CETPICK_PAIR_SYNCBN=1): on the one place it can be measured - the
+    # 1-rank RCCL rehearsal, every collective issued and captured - the lock step costs more than it saves (1.627 against 1.580 ms per step, same box,
+    # alternating runs): un-paired, a branch's exchange only holds ITS stream while the other branch computes; paired, both branches meet at every layer.
+    # Whether five saved xGMI latencies outweigh that on real ranks is unmeasured (profiles/r06_experiments.txt item 9).
     import os as _os
-    pair_sync_bn = _os.environ.get("CETPICK_PAIR_SYNCBN", "1") != "0"
+    pair_sync_bn = _os.environ.get("CETPICK_PAIR_SYNCBN", "0") != "0"
     sync_collectives = 0           # collectives the last forward issued for SyncBN statistics (tests / diagnostics)
 
     def _paired_ok(self):

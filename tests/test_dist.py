@@ -122,6 +122,7 @@ def _w_step(rank, world, port, out):
     moco = _make_moco()
     H.convert_sync_batchnorm(moco)
     moco.train()
+    moco.pair_sync_bn = True                         # (round 6, opt-in: one SyncBN collective per layer for both encoders)
     eng = MocoStepEngine(moco, lr=0.05)
     xq, xk = _batches()
     sl = slice(4 * rank, 4 * rank + 4)
