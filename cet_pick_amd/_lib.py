@@ -130,6 +130,7 @@ SIGNATURES = {
     "mi_bn_eval_fwd": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "mi_bn_bwd_reduce": (_I, [_P, _P, _P, _L, _I, _P, _I, _P, _P, _Z, _P]),
     "mi_bn_bwd_apply": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _D, _I, _P, _P, _P]),
+    "mi_bn_bwd_apply_res": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _D, _P, _P, _P]),
     "mi_bn_param_grads": (_I, [_P, _I, _P, _P, _P]),
     "mi_colsum": (_I, [_P, _L, _I, _P, _P, _P, _Z, _P]),
     "mi_maxpool3d_fwd": (_I, [_P, _P, _P] + [_I] * 8 + [_P]),

@@ -541,7 +541,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, cons
                                                           const float* y, float* dx, long n4, int C,
                                                           const float* save, const float* gamma,
                                                           const double* sums, double count,
-                                                          int relu, float* dgamma, float* dbeta) {
+                                                          int relu, float* dgamma, float* dbeta, float* dres) {
+    // dres (may be null): the gradient behind the ReLU, dy * (y > 0), for a residual branch added in front of the activation -
+    // written on the way instead of by a masking launch of its own in front of this one
     const int CV = C >> 2;
     const int c = (int)(threadIdx.x % CV) * 4;
     const float rc = (float)(1.0 / count);
@@ -568,6 +570,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, cons
 #pragma unroll
             for (int k = 0; k < 4; ++k) d[k] = yv[k] > 0.f ? d[k] : 0.f;
         }
+        if (dres) st4(dres + 4 * i, make_float4(d[0], d[1], d[2], d[3]));
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1218,7 +1221,18 @@ extern "C" int mi_bn_bwd_apply(const float* dy, const float* x, const float* y, 
     hipStream_t s = (hipStream_t)stream;
     long n4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dy, x, y, dx, n4, C,
-                       save_mean_invstd, gamma, sums, count, relu, dgamma, dbeta);
+                       save_mean_invstd, gamma, sums, count, relu, dgamma, dbeta, (float*)nullptr);
+    MI_RETURN_IF_LAUNCH_FAILED();
+    return MI_OK;
+}
+
+extern "C" int mi_bn_bwd_apply_res(const float* dy, const float* x, const float* y, float* dx, float* dres, long M,
+                                   int C, const float* save_mean_invstd, const float* gamma,
+                                   const double* sums, double count, float* dgamma, float* dbeta, mi_stream_t stream) {
+    if (!dy || !x || !y || !dx || !dres || !save_mean_invstd || !sums || !colreduce_ok(C) || !(count > 0)) return MI_E_ARG;
+    long n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, dy, x, y, dx, n4, C,
+                       save_mean_invstd, gamma, sums, count, 1, dgamma, dbeta, dres);
     MI_RETURN_IF_LAUNCH_FAILED();
     return MI_OK;
 }

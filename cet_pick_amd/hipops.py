@@ -1110,12 +1110,32 @@ def _stem_fwd_with_stats(x, w, mod):
     return y
 
 
+class GradSlot:
+    """A gradient contribution handed from one autograd node to another of the same block instead of through autograd's sum: the
+    node behind a residual connection (BatchNorm + residual + ReLU) leaves the residual branch's gradient here, the block's first
+    convolution - whose input IS that residual - adds it in its data gradient's epilogue (`res`).  One element-wise launch less
+    per identity block and pass; the sum is the same single rounding."""
+    __slots__ = ("tensor",)
+
+    def __init__(self):
+        self.tensor = None
+
+
+FUSE_RES_GRAD = os.environ.get("CETPICK_FUSE_RES_GRAD", "1") != "0"
+
+
+def grad_slot_for(x):
+    """A GradSlot when the gradient of `x` will be computed (and the fusion is on), else None."""
+    return GradSlot() if (FUSE_RES_GRAD and torch.is_grad_enabled() and x.requires_grad and x.is_cuda and PROFILE is None) else None
+
+
 class _ConvFn(torch.autograd.Function):
     """y = act(conv(x, W)); W's gradient goes to mod.weight.grad directly."""
 
     @staticmethod
-    def forward(ctx, x, w, mod, relu, mask_dx=False, inference=False):
+    def forward(ctx, x, w, mod, relu, mask_dx=False, inference=False, grad_slot=None):
         ctx.mod, ctx.relu, ctx.mask_dx = mod, relu, mask_dx
+        ctx.grad_slot = grad_slot
         y = _stem_fwd_with_stats(x, w, mod) if (getattr(mod, "stats_for_bn", False) and not relu) else None
         if y is None:
             y = conv_fwd(x, w, mod.k, mod.stride, mod.pad, None, relu, dil=getattr(mod, "dil", None), owner=mod.weight,
@@ -1135,10 +1155,16 @@ class _ConvFn(torch.autograd.Function):
         if mod.weight.requires_grad:
             conv_wgrad_into(x, dy, mod.weight, mod.k, mod.stride, mod.pad, dil=dil)
         dx = None
+        extra = None
+        if ctx.grad_slot is not None:
+            extra, ctx.grad_slot.tensor = ctx.grad_slot.tensor, None
         if ctx.x_needs_grad:
             # mask_dx: x is the output of a ReLU whose derivative the producer left to this layer (see basic_block)
-            dx = conv_dgrad(dy, mod.weight, x.shape, mod.k, mod.stride, mod.pad, None, x if ctx.mask_dx else None, dil=dil)
-        return dx, None, None, None, None, None
+            # extra: the gradient x receives through the block's residual connection (GradSlot), added in the epilogue
+            if extra is not None and ctx.mask_dx:
+                raise L.HipExtensionError("a residual gradient slot and a masked data gradient do not combine")
+            dx = conv_dgrad(dy, mod.weight, x.shape, mod.k, mod.stride, mod.pad, extra, x if ctx.mask_dx else None, dil=dil)
+        return dx, None, None, None, None, None, None
 
 
 def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None, pool=False):
@@ -1386,8 +1412,8 @@ class HipConv2d(nn.Module):
             bound = 1.0 / (ci * k * k) ** 0.5
             self.weight.uniform_(-bound, bound)
 
-    def forward(self, x, relu=False):
-        return _ConvFn.apply(x, self.weight, self, relu, False, inference_mode())
+    def forward(self, x, relu=False, grad_slot=None):
+        return _ConvFn.apply(x, self.weight, self, relu, False, inference_mode(), grad_slot)
 
 
 class _LinearFn(torch.autograd.Function):
@@ -1593,7 +1619,8 @@ class _BNFn(torch.autograd.Function):
     """y = act(bn(x) + res); res (optional) is a residual branch added before the activation."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mod, relu, res=None, pre=None):
+    def forward(ctx, x, gamma, beta, mod, relu, res=None, pre=None, res_slot=None):
+        ctx.res_slot = res_slot if res is not None else None
         shape = x.shape
         c = shape[-1]
         m = x.numel() // c
@@ -1671,12 +1698,22 @@ class _BNFn(torch.autograd.Function):
         if not ctx.train_stats:
             raise L.HipExtensionError("BatchNorm backward in eval mode is not on the hot path")
         dres = None
+        want_dres = False
         if ctx.has_res:
             # the residual branch receives the gradient behind the activation; BN continues from it
-            if relu:
-                dy = relu_mask(dy, y)
-                relu = False
-            dres = dy
+            if relu and not ctx.small:
+                want_dres = True                          # (written by the apply launch below: no masking launch in front of the two)
+            else:
+                if relu:
+                    dy = relu_mask(dy, y)
+                    relu = False
+                dres = dy
+        def hand_over(dres):
+            # through the block's GradSlot when its first convolution adds the residual gradient in its own epilogue
+            if ctx.res_slot is not None and dres is not None:
+                ctx.res_slot.tensor = dres
+                return None
+            return dres
         if ctx.small:
             gamma = mod.weight
             dg = db = None
@@ -1693,7 +1730,7 @@ class _BNFn(torch.autograd.Function):
                 gamma.grad.add_(dg)
             if acc_b:
                 mod.bias.grad.add_(db)
-            return dx, None, None, None, None, dres, None
+            return dx, None, None, None, None, hand_over(dres), None, None
         ws = _ws(lib.mi_colreduce_workspace_bytes(m, c), dev, "colreduce")
         sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
         L.check(lib.mi_bn_bwd_reduce(L.ptr(dy), L.ptr(x), L.ptr(y), m, c, L.ptr(save), int(relu), L.ptr(sums),
@@ -1716,15 +1753,21 @@ class _BNFn(torch.autograd.Function):
             dist_all_reduce(sums)                      # dx needs the global sums
         dx = torch.empty_like(x)
         # single process: the same launch writes dgamma / dbeta from the sums
-        L.check(lib.mi_bn_bwd_apply(L.ptr(dy), L.ptr(x), L.ptr(y), L.ptr(dx), m, c, L.ptr(save), L.ptr(gamma),
-                                    L.ptr(sums), ctx.count, int(relu), L.ptr(None if distributed else dg),
-                                    L.ptr(None if distributed else db), L.stream()),
-                "mi_bn_bwd_apply")
+        if want_dres:
+            dres = torch.empty_like(dy)
+            L.check(lib.mi_bn_bwd_apply_res(L.ptr(dy), L.ptr(x), L.ptr(y), L.ptr(dx), L.ptr(dres), m, c, L.ptr(save), L.ptr(gamma),
+                                            L.ptr(sums), ctx.count, L.ptr(None if distributed else dg),
+                                            L.ptr(None if distributed else db), L.stream()), "mi_bn_bwd_apply_res")
+        else:
+            L.check(lib.mi_bn_bwd_apply(L.ptr(dy), L.ptr(x), L.ptr(y), L.ptr(dx), m, c, L.ptr(save), L.ptr(gamma),
+                                        L.ptr(sums), ctx.count, int(relu), L.ptr(None if distributed else dg),
+                                        L.ptr(None if distributed else db), L.stream()),
+                    "mi_bn_bwd_apply")
         if acc_g:
             gamma.grad.add_(dg)
         if acc_b:
             mod.bias.grad.add_(db)
-        return dx, None, None, None, None, dres, None
+        return dx, None, None, None, None, hand_over(dres), None, None
 
 
 class _BNReluPoolFn(torch.autograd.Function):
@@ -1873,8 +1916,8 @@ class HipBatchNorm(nn.Module):
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, relu=False, res=None, pre=None):
-        return _BNFn.apply(_f32c(x, "x"), self.weight, self.bias, self, relu, res, pre)
+    def forward(self, x, relu=False, res=None, pre=None, res_slot=None):
+        return _BNFn.apply(_f32c(x, "x"), self.weight, self.bias, self, relu, res, pre, res_slot)
 
 
 def convert_sync_batchnorm(module):

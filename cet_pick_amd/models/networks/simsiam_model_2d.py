@@ -39,14 +39,17 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
+        # identity shortcut: the gradient x receives through it is added in conv1's data-gradient epilogue (hipops.GradSlot) instead of
+        # by an element-wise launch of autograd's
+        slot = H.grad_slot_for(x) if self.downsample is None else None
+        out = self.bn1(self.conv1(x, grad_slot=slot), relu=True)
         out = self.conv2(out)
         residual = x
         if self.downsample is not None:
             residual = self.downsample[0](x)
             if len(self.downsample) > 1:                    # the 2d3d variant normalises the shortcut (:601-607 there)
                 residual = self.downsample[1](residual)
-        return self.bn2(out, relu=True, res=residual)       # relu(bn2(out) + residual)
+        return self.bn2(out, relu=True, res=residual, res_slot=slot)       # relu(bn2(out) + residual)
 
 
 class TomoResClassifier2D(nn.Module):

@@ -509,6 +509,13 @@ int mi_bn_bwd_reduce(const float* dy, const float* x, const float* y, long M, in
 int mi_bn_bwd_apply(const float* dy, const float* x, const float* y, float* dx, long M, int C,
                     const float* save_mean_invstd, const float* gamma, const double* sums,
                     double count, int relu, float* dgamma, float* dbeta, mi_stream_t stream);
+
+/* mi_bn_bwd_apply for y = relu(bn(x) + residual) (cet_pick/models/networks/simsiam_model_2d.py:473-502, the end of a BasicBlock): the
+ * gradient behind the ReLU, dres = dy * (y > 0), is what the residual branch receives - written by the same pass (no masking launch in
+ * front of it); the statistics in `sums` are mi_bn_bwd_reduce's with relu = 1. */
+int mi_bn_bwd_apply_res(const float* dy, const float* x, const float* y, float* dx, float* dres, long M, int C,
+                        const float* save_mean_invstd, const float* gamma, const double* sums, double count,
+                        float* dgamma, float* dbeta, mi_stream_t stream);
 /* dgamma = sums[C..2C), dbeta = sums[0..C) from the LOCAL (pre all-reduce) backward sums: under
  * SyncBN the affine gradients stay per-rank and are averaged with the other gradients, exactly as
  * torch.nn.SyncBatchNorm does. */
