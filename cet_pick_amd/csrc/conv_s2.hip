@@ -115,12 +115,14 @@ __global__ __launch_bounds__(512, OCC) void s2_dgrad_kernel(S2DgradParams p) {
     const int w_voff = cbk * (3 * S2_WBLK) + lane * 16;
     bf16x8 bfr[RING][3];
 
-    // ---- patch staging: unit q = (voxel record, 8 channels): NV * CR / 8 = 1024 units, 2 per thread ----
+    // ---- patch staging: unit q = (voxel record, 8 channels): NV * CR / 8 units, UPT per thread (2; 4 for the 64^3 crops' layer3.0) ----
+    constexpr int UPT = NV * CR / 8 / 512;
+    static_assert(UPT * 512 * 8 == NV * CR, "staging divides");
     auto stage = [&](const float* src) {
         const __amdgpu_buffer_rsrc_t ars = rsrc_s2(src, p.a_bytes);
-        u32x4 ld[2][2];
+        u32x4 ld[UPT][2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UPT; ++u) {
             const int q = tid + 512 * u, vox = q / (CR / 8), cg = q % (CR / 8);
             const bool ok = n0 + vox / VO < p.N;
             const unsigned off = ok ? 4u * (unsigned)(((long)n0 * VO + vox) * CR + cg * 8) : 0x80000000u;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(512, OCC) void s2_dgrad_kernel(S2DgradParams p) {
             ld[u][1] = __builtin_amdgcn_raw_buffer_load_b128(ars, (int)(off + 16u), 0, 0);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UPT; ++u) {
             const int q = tid + 512 * u, vox = q / (CR / 8), cg = q % (CR / 8);
             float v[8];
 #pragma unroll
@@ -253,6 +255,7 @@ bool s2_shape(int Gi, int Ci, int Co, int* G) {
     // input grid Gi (= 2 G), Ci input channels of the convolution (the gradient's output channels), Co its output channels
     if (Gi == 8 && Ci == 64 && Co == 128) { *G = 4; return true; }
     if (Gi == 4 && Ci == 128 && Co == 256) { *G = 2; return true; }
+    if (Gi == 8 && Ci == 128 && Co == 256) { *G = 4; return true; }        // layer3.0 of the 64^3 crops (round 6)
     return false;
 }
 size_t s2_img_bytes(int Ci, int Co) { return (size_t)27 * (Co / 16) * (Ci / 32) * 3 * S2_WBLK; }
@@ -556,7 +559,12 @@ static int s2_dgrad_launch(const float* dh, const float* dout, const unsigned ch
     p.wimg_bytes = (unsigned)s2_img_bytes(Ci, Co); p.dsimg_bytes = (unsigned)s2_dsimg_bytes(Ci, Co);
     unsigned char slot_tap[27];
     s2_dgrad_tables(p.order, p.tap_off, slot_tap);
-    if (G == 4) {
+    if (G == 4 && Ci == 128) {
+        // 64^3 crops, layer3.0: 8^3 -> 4^3 at 128 -> 256 channels - one sample per workgroup (64 rows), its 256 reduction channels cut four
+        // ways over the wave groups, one column block of the 128 per workgroup (126 KB of LDS: one workgroup per CU)
+        p.n_groups = N;
+        hipLaunchKernelGGL((s2_dgrad_kernel<4, 256, 128, 1, 4, 8, 1>), dim3((unsigned)(N * 8), 4), dim3(512), 0, s, p);
+    } else if (G == 4) {
         p.n_groups = N;
         const char* rg = getenv("MI_S2_RING");
         if (rg && atoi(rg) == 8) hipLaunchKernelGGL((s2_dgrad_kernel<4, 128, 64, 2, 2, 8, 2>), dim3((unsigned)(N * 8), 1), dim3(512), 0, s, p);
@@ -633,7 +641,7 @@ extern "C" int mi_conv3d_s2_prep(const float* const* w, const float* const* w_ds
 
 /* Forward of a stride-2 block front of the MoCo-3D encoder (models/networks/moco_encoder_3d.py:55-84, 257-272): hmid = relu(conv3d(x;
  * w [27][Ci][Co], k 3, stride 2, pad 1)) and the shortcut r = conv3d(x; w_ds [Ci][Co], k 1, stride 2) in one launch.  Shapes: the
- * encoder's two (Gi 8, 64 -> 128 and Gi 4, 128 -> 256), bf16x3 arithmetic; otherwise MI_E_UNSUPPORTED (run mi_conv3d_fwd_f32
+ * encoder's two at 32^3 crops (Gi 8, 64 -> 128 and Gi 4, 128 -> 256) and layer3.0 of the 64^3 crops (Gi 8, 128 -> 256), bf16x3 arithmetic; otherwise MI_E_UNSUPPORTED (run mi_conv3d_fwd_f32
  * twice).  The weight image is cut into `ws` (mi_conv3d_s2_fwd_workspace_bytes) by this call. */
 extern "C" int mi_conv3d_s2_fwd_usable(int N, int Gi, int Ci, int Co) {
     const char* no = getenv("MI_CONV_NO_S2FWD");       // A/B switch: the generic launches
@@ -649,7 +657,10 @@ static int s2_fwd_launch(const float* x, const unsigned char* img, float* hmid, 
     S2FwdParams p = {x, img, hmid, r, N, (unsigned)(4l * N * Gi * Gi * Gi * Ci), (unsigned)s2_fwd_img_bytes(Ci, Co)};
     const char* nar = getenv("MI_S2FWD_NARROW");        // tuning: two column blocks per workgroup (half the workgroups)
     const bool narrow = nar && atoi(nar);
-    if (G == 4) {
+    if (G == 4 && Ci == 128) {
+        // 64^3 crops, layer3.0 (8^3 -> 4^3, 128 -> 256): a sample's 64 rows x one block of 32 output channels per workgroup
+        hipLaunchKernelGGL((s2_fwd_kernel<4, 128, 256, 2, 1, 4, 1>), dim3((unsigned)N, 8), dim3(512), 0, s, p);
+    } else if (G == 4) {
         if (narrow) hipLaunchKernelGGL((s2_fwd_kernel<4, 64, 128, 2, 2, 2, 2>), dim3((unsigned)N, 2), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((s2_fwd_kernel<4, 64, 128, 2, 1, 4, 2>), dim3((unsigned)N, 4), dim3(512), 0, s, p);
     } else {

@@ -576,12 +576,12 @@ int mi_ce_label0_bwd(const float* logits, const float* row_lse, const float* gra
                      mi_stream_t stream);
 
 /* Data gradient of the encoder's stride-2 3x3x3 convolutions (moco_encoder_3d.py:55-84,257-272: layer2.0.conv1 64 -> 128 on 8^3,
- * layer3.0.conv1 128 -> 256 on 4^3; padding 1) with the block's 1x1 stride-2 shortcut folded in - one launch per block instead of
+ * layer3.0.conv1 128 -> 256 on 4^3 - and on 8^3, the 64^3 crops' layer3.0; padding 1) with the block's 1x1 stride-2 shortcut folded in - one launch per block instead of
  * two data-gradient launches and their split-K reduces (csrc/conv_s2.hip):
  *   dx (N, Gi, Gi, Gi, Ci) = (conv_dgrad(dh; w) [+ conv1x1_dgrad(dout; w_ds)] + res) * (mask > 0)
  * dh / dout: (N, Gi/2, Gi/2, Gi/2, Co); w: [27][Ci][Co], w_ds: [Ci][Co] (kernel layouts); dout and w_ds are given together or
  * both NULL; res / mask (shape of dx) may be NULL.  `ws`: mi_conv3d_s2_dgrad_workspace_bytes(Ci, Co) bytes - the call cuts the
- * weight images into it.  mi_conv3d_s2_dgrad_usable: 1 for the two shapes above (bf16x3 arithmetic), else 0 (the caller keeps
+ * weight images into it.  mi_conv3d_s2_dgrad_usable: 1 for the three shapes above (bf16x3 arithmetic), else 0 (the caller keeps
  * mi_convnd_dgrad_f32). */
 int mi_conv3d_s2_dgrad_usable(int N, int Gi, int Ci, int Co);
 size_t mi_conv3d_s2_dgrad_workspace_bytes(int Ci, int Co);

@@ -165,11 +165,12 @@ def test_conv_direct3_matches_igemm_and_float64(n, d, hw, c, monkeypatch):
 
 
 @pytest.mark.parametrize("n,gi,ci,co,with_ds", [(3, 8, 64, 128, True), (64, 8, 64, 128, True), (2, 8, 64, 128, False),
-                                                  (5, 4, 128, 256, True), (70, 4, 128, 256, True), (4, 4, 128, 256, False)])
+                                                  (5, 4, 128, 256, True), (70, 4, 128, 256, True), (4, 4, 128, 256, False),
+                                                  (3, 8, 128, 256, True), (33, 8, 128, 256, True), (2, 8, 128, 256, False)])
 def test_s2_block_dgrad_matches_generic_and_float64(n, gi, ci, co, with_ds):
     """csrc/conv_s2.hip: the data gradient of a BasicBlock's stride-2 front (3^3 stride-2 convolution + 1x1 stride-2 shortcut,
     ReLU mask of the input) in one launch, against the two generic launches and against torch in float64; ragged batches
-    (layer3's workgroups hold four samples) and the variant without a shortcut."""
+    (layer3's workgroups hold four samples), the variant without a shortcut, and layer3.0 of the 64^3 crops (8^3 -> 4^3 at 128 -> 256)."""
     from cet_pick_amd import hipops as H
     from conftest import f32_equivalent
     g = torch.Generator().manual_seed(n + gi + co)
@@ -198,7 +199,8 @@ def test_s2_block_dgrad_matches_generic_and_float64(n, gi, ci, co, with_ds):
     assert float((got - gen).abs().max()) / float(r64.abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("n,gi,ci,co", [(3, 8, 64, 128), (64, 8, 64, 128), (5, 4, 128, 256), (70, 4, 128, 256), (1, 4, 128, 256)])
+@pytest.mark.parametrize("n,gi,ci,co", [(3, 8, 64, 128), (64, 8, 64, 128), (5, 4, 128, 256), (70, 4, 128, 256), (1, 4, 128, 256),
+                                        (3, 8, 128, 256), (33, 8, 128, 256)])
 def test_s2_block_fwd_matches_generic_and_float64(n, gi, ci, co, monkeypatch):
     """csrc/conv_s2.hip s2_fwd_kernel: relu(3^3 stride-2 convolution) and the 1x1 stride-2 shortcut of a BasicBlock's front in one
     launch, against the generic launches and against torch in float64; ragged batches (layer3's workgroups hold four samples);
@@ -1009,6 +1011,12 @@ def test_conv_dispatch_by_shape(monkeypatch):
     assert fwd(8, 16, 64, 64) == "direct3h (8 x 8 tiles)"          # layer1 of a 64^3 crop (round 4), from 128 workgroups on
     assert fwd(16, 12, 64, 64).startswith("implicit GEMM")         # layer1 of a 48^3 crop: a 12 x 12 plane fills 56 % of four tiles (measured slower)
     assert fwd(8, 14, 64, 64) == "direct3h (8 x 8 tiles)"          # ragged planes from 75 % fill on (round 5)
+    # stride-2 block fronts (conv + shortcut in one launch): the 32^3 crops' two and layer3.0 of the 64^3 crops (round 6); layer2.0 of the
+    # 64^3 crops (16^3 -> 8^3: a sample no longer fits a workgroup's LDS) stays on the generic launches
+    assert lib.mi_conv3d_s2_fwd_usable(32, 8, 64, 128) == 1 and lib.mi_conv3d_s2_dgrad_usable(32, 8, 64, 128) == 1
+    assert lib.mi_conv3d_s2_fwd_usable(32, 4, 128, 256) == 1 and lib.mi_conv3d_s2_dgrad_usable(32, 4, 128, 256) == 1
+    assert lib.mi_conv3d_s2_fwd_usable(32, 8, 128, 256) == 1 and lib.mi_conv3d_s2_dgrad_usable(32, 8, 128, 256) == 1
+    assert lib.mi_conv3d_s2_fwd_usable(32, 16, 64, 128) == 0 and lib.mi_conv3d_s2_dgrad_usable(32, 16, 64, 128) == 0
     # weight gradients (round 5: layer2's shape has direct3_wgrad_kernel<true> too, opt-in)
     def wgrad(n, d, ci, co, k=3, s=1, p=1):
         x = torch.randn(n, d, d, d, ci, device="cuda")
