@@ -1133,9 +1133,11 @@ class _ConvFn(torch.autograd.Function):
     """y = act(conv(x, W)); W's gradient goes to mod.weight.grad directly."""
 
     @staticmethod
-    def forward(ctx, x, w, mod, relu, mask_dx=False, inference=False, grad_slot=None):
+    def forward(ctx, x, w, mod, relu, mask_dx=False, inference=False, grad_slot=None, dx_slot=None):
         ctx.mod, ctx.relu, ctx.mask_dx = mod, relu, mask_dx
-        ctx.grad_slot = grad_slot
+        ctx.grad_slot = grad_slot                        # a gradient of x that arrives here instead of through autograd's sum: added in the epilogue
+        ctx.dx_slot = dx_slot                            # ... and this node's own gradient of x LEAVES through a slot (a shortcut convolution:
+                                                         # the block's first convolution, which runs later in the backward pass, adds it)
         y = _stem_fwd_with_stats(x, w, mod) if (getattr(mod, "stats_for_bn", False) and not relu) else None
         if y is None:
             y = conv_fwd(x, w, mod.k, mod.stride, mod.pad, None, relu, dil=getattr(mod, "dil", None), owner=mod.weight,
@@ -1164,7 +1166,11 @@ class _ConvFn(torch.autograd.Function):
             if extra is not None and ctx.mask_dx:
                 raise L.HipExtensionError("a residual gradient slot and a masked data gradient do not combine")
             dx = conv_dgrad(dy, mod.weight, x.shape, mod.k, mod.stride, mod.pad, extra, x if ctx.mask_dx else None, dil=dil)
-        return dx, None, None, None, None, None, None
+            if ctx.dx_slot is not None:
+                if ctx.dx_slot.tensor is not None:
+                    raise L.HipExtensionError("gradient slot already holds a tensor")
+                ctx.dx_slot.tensor, dx = dx, None
+        return dx, None, None, None, None, None, None, None
 
 
 def conv_bias_fwd(x, w, bias, k, stride, pad, relu=False, out=None, pool=False):
@@ -1412,8 +1418,8 @@ class HipConv2d(nn.Module):
             bound = 1.0 / (ci * k * k) ** 0.5
             self.weight.uniform_(-bound, bound)
 
-    def forward(self, x, relu=False, grad_slot=None):
-        return _ConvFn.apply(x, self.weight, self, relu, False, inference_mode(), grad_slot)
+    def forward(self, x, relu=False, grad_slot=None, dx_slot=None):
+        return _ConvFn.apply(x, self.weight, self, relu, False, inference_mode(), grad_slot, dx_slot)
 
 
 class _LinearFn(torch.autograd.Function):

@@ -39,17 +39,18 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        # identity shortcut: the gradient x receives through it is added in conv1's data-gradient epilogue (hipops.GradSlot) instead of
-        # by an element-wise launch of autograd's
-        slot = H.grad_slot_for(x) if self.downsample is None else None
+        # The gradient x receives through the shortcut is added in conv1's data-gradient epilogue (hipops.GradSlot) instead of by an
+        # element-wise launch of autograd's: an identity shortcut's comes from bn2's backward, a convolution shortcut's from that
+        # convolution's own data gradient (created after conv1, so autograd runs it before conv1's backward).
+        slot = H.grad_slot_for(x)
         out = self.bn1(self.conv1(x, grad_slot=slot), relu=True)
         out = self.conv2(out)
-        residual = x
-        if self.downsample is not None:
-            residual = self.downsample[0](x)
-            if len(self.downsample) > 1:                    # the 2d3d variant normalises the shortcut (:601-607 there)
-                residual = self.downsample[1](residual)
-        return self.bn2(out, relu=True, res=residual, res_slot=slot)       # relu(bn2(out) + residual)
+        if self.downsample is None:
+            return self.bn2(out, relu=True, res=x, res_slot=slot)          # relu(bn2(out) + x)
+        residual = self.downsample[0](x, dx_slot=slot)
+        if len(self.downsample) > 1:                        # the 2d3d variant normalises the shortcut (:601-607 there)
+            residual = self.downsample[1](residual)
+        return self.bn2(out, relu=True, res=residual)       # relu(bn2(out) + residual)
 
 
 class TomoResClassifier2D(nn.Module):
