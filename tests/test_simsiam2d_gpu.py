@@ -342,3 +342,62 @@ def test_simsiam_engine_step_equals_plain_sequence(monkeypatch):
     H.sgd_step_(arena_p.flat, arena_p.flat_grad, 0.05)
     assert torch.equal(le, lp.detach()) and torch.equal(tr_e.engine.arena.flat, arena_p.flat)
     tr_e.close()
+
+
+@pytest.mark.parametrize("n,hw,cin,planes,stride", [(24, 18, 128, 128, 1), (6, 36, 64, 64, 1), (8, 36, 64, 128, 2), (40, 8, 64, 64, 1)])
+def test_block_residual_gradient_slots_equal_autograd_sum(n, hw, cin, planes, stride, monkeypatch):
+    """hipops.GradSlot (round 6): the gradient a BasicBlock's input receives through the shortcut - from bn2's backward (identity shortcut;
+    mi_bn_bwd_apply_res writes the masked gradient on the way) or from the shortcut convolution's data gradient - is added in conv1's
+    data-gradient epilogue instead of by autograd's sum.  Same single rounding: the input gradient and every parameter gradient are
+    BIT-EQUAL to the plain form (CETPICK_FUSE_RES_GRAD=0); both match torch in float64.  The last case takes the small-BatchNorm path
+    (one-launch backward, no slot for the mask), the others the statistics + apply passes."""
+    import copy
+    import torch.nn as nn
+    from cet_pick_amd import hipops as H
+    from cet_pick_amd.models.networks.simsiam_model_2d import BasicBlock
+    g = torch.Generator().manual_seed(n * 1000 + hw)
+    ds = None
+    if stride != 1 or cin != planes:
+        ds = nn.Sequential(H.HipConv2d(cin, planes, 1, stride=stride, pad=0))
+    blk0 = BasicBlock(cin, planes, stride, ds).cuda()
+    with torch.no_grad():
+        for p in blk0.parameters():
+            if p.dim() == 1:
+                p.copy_((torch.rand(p.shape, generator=g) + 0.5).cuda())
+    x0 = torch.randn(n, hw, hw, cin, generator=g)
+    ho = hw // stride
+    dy = torch.randn(n, ho, ho, planes, generator=g)
+
+    def run(fused):
+        monkeypatch.setattr(H, "FUSE_RES_GRAD", fused)
+        blk = copy.deepcopy(blk0)
+        blk.train()
+        x = x0.cuda().requires_grad_(True)
+        xin = x * 1.0                                        # (a non-leaf input, as inside the network)
+        y = blk(xin)
+        y.backward(dy.cuda())
+        return [y.detach(), x.grad] + [p.grad for p in blk.parameters()]
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    # float64 reference (NCHW torch modules with the same parameters)
+    import torch.nn.functional as F
+    sd = {k: v.detach().cpu().double() for k, v in blk0.state_dict().items()}
+    xr = x0.double().permute(0, 3, 1, 2).requires_grad_(True)
+    def bn(t, pre):
+        return F.batch_norm(t, None, None, sd[pre + ".weight"], sd[pre + ".bias"], True, 0.1, 1e-5)
+    h = torch.relu(bn(F.conv2d(xr, sd["conv1.weight"], stride=stride, padding=1), "bn1"))
+    h = bn(F.conv2d(h, sd["conv2.weight"], padding=1), "bn2")
+    res = xr if ds is None else F.conv2d(xr, sd["downsample.0.weight"], stride=stride)
+    yr = torch.relu(h + res)
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    got_y, got_dx = a[0].cpu().double(), a[1].cpu().double()
+    assert float((got_y - yr.detach().permute(0, 2, 3, 1)).abs().max()) <= 2e-5 * float(yr.detach().abs().max())
+    # (a unit within fp32 rounding of zero may take the other branch of a ReLU than float64 does - its gradient then differs by O(1) in
+    # a few elements: the bulk is held tightly, the whole in norm)
+    err = (got_dx - xr.grad.detach().permute(0, 2, 3, 1)).abs()
+    scale = float(xr.grad.abs().max())
+    assert float((err <= 5e-5 * scale).double().mean()) >= 0.99          # (a flipped unit reaches a 5 x 5 neighbourhood of dx through two convolutions)
+    assert float(err.norm()) <= 1e-2 * float(xr.grad.norm())
