@@ -229,10 +229,33 @@ def workspace(nbytes, device, tag="default", init=None):
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
         if init is not None:
             init(buf)
+            _ws_inits[key] = init
         _workspaces[key] = buf
     return buf
+
+
+_ws_inits = {}
+
+
+def prime_workspaces_for_stream(src_stream, dst_stream):
+    """Give `dst_stream` its own copy of every kept-clean (init) workspace `src_stream` has, initialised NOW: a step engine calls this
+    in front of a hipGraph capture on `dst_stream` - workspaces are keyed by stream, and one that is first allocated inside the capture
+    has its initialising fill recorded as a node that replays with every step (2.6 MB of zeros for cube2_kernel's arrival counters)."""
+    src, dst = src_stream.cuda_stream, dst_stream.cuda_stream
+    if src == dst:
+        return
+    with torch.cuda.stream(dst_stream):
+        for key in [k for k in _workspaces if k[2] == src and k in _ws_inits]:
+            nk = (key[0], key[1], dst)
+            if nk in _workspaces and _workspaces[nk].numel() >= _workspaces[key].numel():
+                continue
+            buf = torch.empty(_workspaces[key].numel(), dtype=torch.uint8, device=_workspaces[key].device)
+            _ws_inits[key](buf)
+            _workspaces[nk], _ws_inits[nk] = buf, _ws_inits[key]
+    dst_stream.synchronize()
 
 
 def drop_workspace(device, tag):
     """Forget a cached workspace (after a failed call its kept-clean header can no longer be trusted)."""
     _workspaces.pop(_ws_key(device, tag), None)
+    _ws_inits.pop(_ws_key(device, tag), None)

@@ -300,7 +300,11 @@ class MocoStepEngine:
             # thread; (2) a query of an event whose own stream has joined the capture fails in either mode
             # (hipErrorCapturedEvent) - _drain_watchdog() above emptied the watchdog's list, and nothing captured adds to it.
             mode = "thread_local" if self.dist_on else "global"
-            with torch.cuda.graph(graph, capture_error_mode=mode):       # records, does not execute
+            # (the capture runs on a stream of its own: the kept-clean workspaces the eager steps made for THEIR stream get a twin for it
+            # now, or their zero-fill would be recorded and replay with every step)
+            cap = torch.cuda.Stream(device=self.lr_dev.device)
+            H.L.prime_workspaces_for_stream(torch.cuda.current_stream(), cap)
+            with torch.cuda.graph(graph, stream=cap, capture_error_mode=mode):       # records, does not execute
                 self._step_eager(self._static_q, self._static_k)
         except Exception as e:                        # e.g. a collective that cannot be captured
             if not self.dist_on:
