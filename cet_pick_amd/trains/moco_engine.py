@@ -303,7 +303,8 @@ class MocoStepEngine:
             # (the capture runs on a stream of its own: the kept-clean workspaces the eager steps made for THEIR stream get a twin for it
             # now, or their zero-fill would be recorded and replay with every step)
             cap = torch.cuda.Stream(device=self.lr_dev.device)
-            H.L.prime_workspaces_for_stream(torch.cuda.current_stream(), cap)
+            if os.environ.get("CETPICK_PRIME_WS", "1") != "0":            # (A/B: 0 leaves the fill in the graph)
+                H.L.prime_workspaces_for_stream(torch.cuda.current_stream(), cap)
             with torch.cuda.graph(graph, stream=cap, capture_error_mode=mode):       # records, does not execute
                 self._step_eager(self._static_q, self._static_k)
         except Exception as e:                        # e.g. a collective that cannot be captured
